@@ -1,0 +1,183 @@
+/*
+ * vo_mi355x.h -- C ABI of libvo_mi355x.so: the MI355X (gfx950) visual-odometry inner loop.
+ *
+ * The reference (JonasFrey96/Visual-Odom-Pipeline) is pure Python and has no FFI; its hot path
+ * sits behind two Python classes and bottoms out in OpenCV / SciPy calls.  This header declares
+ * the flat entry points a ctypes binding uses to replace exactly those calls.  Every export cites
+ * the reference call site it replaces (paths relative to /root/reference).  INTEGRATION.md shows
+ * the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns int32_t: VO_OK (0) or a negative VO_E_* code; vo_last_error(ctx)
+ *     gives the message.  No C++ exception crosses the boundary.
+ *   - the caller owns all host buffers (C-contiguous numpy arrays); the library owns only the
+ *     device memory inside the opaque vo_ctx.  One vo_ctx = one GPU + one HIP stream; calls on
+ *     one ctx must be serialised by the caller; different ctxs are independent.
+ *   - synchronous entry points return with the outputs written.  The *_async / *_resident forms
+ *     only enqueue work on the ctx's stream; vo_sync() waits for it.
+ *   - there is NO CPU fallback: without a HIP device vo_ctx_create fails with VO_E_HIP.
+ */
+#ifndef VO_MI355X_H
+#define VO_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VO_ABI_VERSION 1
+
+enum {
+  VO_OK = 0,
+  VO_E_INVALID = -1,     /* bad argument */
+  VO_E_HIP = -2,         /* HIP runtime error / no device */
+  VO_E_NOMEM = -3,
+  VO_E_STATE = -4,       /* call sequence error (e.g. tracking before two frames were pushed) */
+  VO_E_CAPACITY = -5,    /* a fixed-capacity device buffer would overflow */
+  VO_E_NUMERIC = -6      /* solver breakdown (non-positive pivot, non-finite cost) */
+};
+
+typedef struct vo_ctx vo_ctx;
+
+/* ---- parameters (defaults = the reference's hard-coded values) ------------------------------ */
+
+/* cv2.calcOpticalFlowPyrLK parameters, src/extractor/extractor.py:16-19 */
+typedef struct {
+  int32_t win;               /* 31  (winSize 31x31; odd, <= 31)                     */
+  int32_t max_level;         /* 3   (=> 4 pyramid levels)                            */
+  int32_t max_count;         /* 30  TERM_CRITERIA_COUNT                              */
+  double  epsilon;           /* 0.03 TERM_CRITERIA_EPS (squared internally)          */
+  float   min_eig_threshold; /* 1e-4 (OpenCV default)                                */
+  int32_t _pad;
+} vo_klt_params;
+
+/* cv2.goodFeaturesToTrack parameters, src/extractor/extractor.py:21-24 */
+typedef struct {
+  int32_t max_corners;       /* 1000 */
+  int32_t block_size;        /* 31   */
+  double  quality_level;     /* 0.03 */
+  double  min_distance;      /* min_kp_dist (7 in src/pipeline/pipeline.py:21,27) */
+} vo_st_params;
+
+/* BundleAdjuster configuration, src/bundle_adjuster/bundle_adjuster.py:8-16 and
+ * src/pipeline/pipeline.py:28-29 (xtol = ftol = 1e-3, loss 'huber', f_scale 1) */
+typedef struct {
+  int32_t max_iters;         /* LM iterations (linearise + solve + evaluate) cap, e.g. 50 */
+  int32_t _pad;
+  double  ftol;              /* 1e-3 */
+  double  xtol;              /* 1e-3 */
+  double  gtol;              /* 1e-8 (scipy default) */
+  double  lambda0;           /* initial Marquardt damping, 1e-4 */
+  double  huber_delta;       /* 1.0 px */
+} vo_ba_params;
+
+typedef struct {
+  double  cost0;             /* 0.5 * sum rho(|e|^2) at the input */
+  double  cost;              /* at the output */
+  double  lambda;            /* final damping */
+  int32_t iters;             /* LM iterations executed */
+  int32_t accepted;          /* accepted steps */
+  int32_t status;            /* 1 gtol, 2 ftol, 3 xtol, 0 max_iters, 4 damping overflow, <0 VO_E_* */
+  int32_t n_obs;
+} vo_ba_stats;
+
+/* ---- context -------------------------------------------------------------------------------- */
+int32_t vo_abi_version(void);
+int32_t vo_device_count(int32_t* n);
+/* width/height: image size; max_pts: capacity of the tracked point set (and of DLT batches);
+ * max_level / win: pyramid depth and LK window the frame store is built for (3 / 31 in the
+ * reference, extractor.py:16-19).  Levels stop early when the next one would be <= win in either
+ * dimension, as cv2.buildOpticalFlowPyramid does. */
+int32_t vo_ctx_create(int32_t device, int32_t width, int32_t height, int32_t max_pts,
+                      int32_t max_level, int32_t win, vo_ctx** out);
+int32_t vo_ctx_destroy(vo_ctx* ctx);
+const char* vo_last_error(const vo_ctx* ctx);
+int32_t vo_sync(vo_ctx* ctx);
+
+/* ---- frames: pyramid + Scharr derivatives ---------------------------------------------------
+ * Replaces the pyramid / derivative construction inside cv2.calcOpticalFlowPyrLK
+ * (extractor.py:44-45,65-66 rebuild it on each of 4 calls per frame; here once per frame).
+ * Pushing a frame rotates cur -> prev.  `stride` in bytes (>= width). */
+int32_t vo_frame_push(vo_ctx* ctx, const uint8_t* img, int32_t stride);
+/* frames preloaded into HBM (bench: inputs resident before the timed region) */
+int32_t vo_seq_upload(vo_ctx* ctx, const uint8_t* frames, int32_t n_frames);
+int32_t vo_frame_push_resident(vo_ctx* ctx, int32_t frame_index);           /* async */
+/* parity probes: which = 0 prev / 1 cur; img_out (h_l x w_l u8), deriv_out (h_l x w_l x 2 i16), either may be NULL */
+int32_t vo_pyramid_level_size(vo_ctx* ctx, int32_t level, int32_t* w, int32_t* h);
+int32_t vo_pyramid_read(vo_ctx* ctx, int32_t which, int32_t level, uint8_t* img_out, int16_t* deriv_out);
+
+/* ---- KLT ------------------------------------------------------------------------------------
+ * Replaces cv2.calcOpticalFlowPyrLK(prev, cur, p0, None, **lk_params) at extractor.py:44,65
+ * (and, being deterministic, the redundant second call at :45,:66).
+ * p0: n x 2 f32.  Outputs: p1 n x 2 f32, status n u8, err n f32, iters n x (max_level+1) i32
+ * (iterations run per pyramid level, -1 = level skipped; may be NULL). */
+int32_t vo_klt_default_params(vo_klt_params* p);
+int32_t vo_klt_track(vo_ctx* ctx, const float* p0, int32_t n, const vo_klt_params* prm,
+                     float* p1, uint8_t* status, float* err, int32_t* iters);
+/* resident form: the point set lives in HBM and is advanced in place (p <- tracked p) */
+int32_t vo_points_upload(vo_ctx* ctx, const float* p, int32_t n);
+int32_t vo_points_download(vo_ctx* ctx, float* p, uint8_t* status, float* err, int32_t n);
+int32_t vo_klt_track_resident(vo_ctx* ctx, int32_t n, const vo_klt_params* prm);  /* async */
+
+/* ---- Shi-Tomasi re-detection ----------------------------------------------------------------
+ * Replaces the exclusion-mask loop + cv2.goodFeaturesToTrack(img, mask=mask, **shitomasi_params)
+ * at extractor.py:103-112 on the CURRENT frame.  cur_pts (n_cur x 2 f32, may be NULL) are the
+ * tracked keypoints; discs of `mask_radius` at int32-truncated coordinates are excluded
+ * (cv2.circle fill semantics).  `mask` (h x w u8, may be NULL) is an optional explicit mask that
+ * is AND-ed with the discs.  out_pts: max_corners x 2 f32 (integer-valued x, y); *n_out set. */
+int32_t vo_st_default_params(vo_st_params* p);
+int32_t vo_shi_tomasi(vo_ctx* ctx, const float* cur_pts, int32_t n_cur, int32_t mask_radius,
+                      const uint8_t* mask, const vo_st_params* prm, float* out_pts, int32_t* n_out);
+int32_t vo_shi_tomasi_resident(vo_ctx* ctx, int32_t n_cur, int32_t mask_radius,
+                               const vo_st_params* prm);                      /* async; uses the resident points */
+int32_t vo_shi_tomasi_fetch(vo_ctx* ctx, float* out_pts, int32_t* n_out);     /* sync + copy out */
+/* parity probes: min-eigenvalue map (h x w f32) and the mask actually used (h x w u8) of the last call */
+int32_t vo_shi_tomasi_read(vo_ctx* ctx, float* eig_out, uint8_t* mask_out, int32_t* n_candidates);
+
+/* ---- DLT triangulation ----------------------------------------------------------------------
+ * Replaces cv2.triangulatePoints(P0, P1, uv0, uv1) at extractor.py:270 and the reprojection
+ * statistics TriangulatorNL.refine filters on (src/extractor/triangulate.py:87-111,139).
+ * P0, P1: 3x4 f32 row-major (already rounded to f32 as extractor.py:268-269 does);
+ * uv0, uv1: n x 2 f32.  X4: 4 x n f32 (OpenCV layout, homogeneous, unit norm).
+ * Optional filter statistics (computed in f64 on the f32-rounded, dehomogenised point exactly as
+ * the reference does): K 3x3 f64, H0/H1 4x4 f64 row-major -> depth1 n f64 ((H1 [X;1])_z) and
+ * reproj n f64 ((|e0| + |e1|) / 2).  Pass K = NULL to skip them. */
+int32_t vo_triangulate_dlt(vo_ctx* ctx, const float* P0, const float* P1, const float* uv0,
+                           const float* uv1, int32_t n, float* X4,
+                           const double* K, const double* H0, const double* H1,
+                           double* depth1, double* reproj);
+
+/* ---- sliding-window bundle adjustment -------------------------------------------------------
+ * Replaces the scipy.optimize.least_squares call in BundleAdjuster.adjust
+ * (src/bundle_adjuster/bundle_adjuster.py:189-194) and its objective (:18-65).
+ * Problem layout (float64, C-contiguous):
+ *   K       3x3
+ *   poses   W x 6   (rvec, tvec) world->camera; slot 0 = newest frame (as :169-176)
+ *   points  N x 3
+ *   obs     W x N x 2 pixel observations; NaN in obs[i][j][0] = landmark j not seen in slot i
+ * Same cost as the reference (Huber on the per-observation pixel-error norm, f_scale 1, no gauge
+ * fixing); solver = analytic Jacobian, IRLS-weighted J^T J, landmark Schur complement (f64 MFMA
+ * SYRK), dense Cholesky, Levenberg-Marquardt -- see DESIGN.md. */
+int32_t vo_ba_default_params(vo_ba_params* p);
+int32_t vo_ba_adjust(vo_ctx* ctx, const double* K, const double* poses, const double* points,
+                     const double* obs, int32_t n_slots, int32_t n_pts, const vo_ba_params* prm,
+                     double* poses_out, double* points_out, vo_ba_stats* stats);
+/* resident form for the bench: upload once, solve repeatedly from the same x0 */
+int32_t vo_ba_upload(vo_ctx* ctx, const double* K, const double* poses, const double* points,
+                     const double* obs, int32_t n_slots, int32_t n_pts);
+int32_t vo_ba_solve_resident(vo_ctx* ctx, const vo_ba_params* prm);          /* async */
+int32_t vo_ba_fetch(vo_ctx* ctx, double* poses_out, double* points_out, vo_ba_stats* stats);
+/* parity probes at the uploaded x0 (no iteration):
+ *   residual: m f64 in the reference's order (slot-major, ascending landmark; :18-65)
+ *   normal equations with Huber IRLS weights: Hpp W x 6 x 6, gp W x 6, Hll N x 3 x 3, gl N x 3,
+ *   reduced camera system at damping lambda: S 6W x 6W, rhs 6W; one LM step dposes W x 6, dpoints N x 3.
+ *   Any output pointer may be NULL. */
+int32_t vo_ba_probe(vo_ctx* ctx, double lambda, double huber_delta, double* residual, int32_t* n_obs,
+                    double* cost, double* Hpp, double* gp, double* Hll, double* gl, double* S,
+                    double* rhs, double* dposes, double* dpoints);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VO_MI355X_H */

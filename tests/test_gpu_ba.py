@@ -1,0 +1,124 @@
+"""GPU parity: bundle adjustment through the C ABI vs the reference (golden G1) and the numpy oracle."""
+import glob
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(path):
+    import cv2  # stub: Rodrigues only
+    from helpers import golden_ba_problem
+    g = np.load(path)
+    K, poses, points, obs, tags = golden_ba_problem(g, lambda R: cv2.Rodrigues(R)[0])
+    return g, K, poses, points, obs
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from vo_mi355x import VoContext
+    c = VoContext(64, 64, max_pts=64)
+    yield c
+    c.close()
+
+
+def _goldens(golden_dir):
+    return sorted(glob.glob(golden_dir + "/ba_*.npz"))
+
+
+def test_ba_residual_matches_reference(ctx, golden_dir):
+    """BA-1: residual vector at x0 in the reference's order == the reference's own output (1e-9 px)"""
+    for path in _goldens(golden_dir):
+        g, K, poses, points, obs = _load(path)
+        ctx.ba_upload(K, poses, points, obs)
+        pr = ctx.ba_probe(lam=1e-4)
+        assert len(pr["residual"]) == len(g["r0"])
+        assert np.abs(pr["residual"] - g["r0"]).max() <= 1e-9
+        import ba_oracle as bo
+        assert abs(pr["cost"] - 0.5 * bo.huber_rho(g["r0"] ** 2).sum()) <= 1e-9 * max(1.0, pr["cost"])
+
+
+def test_ba_normal_equations_and_step_match_oracle(ctx, golden_dir):
+    """BA-3/4/5: Huber-weighted J^T J blocks, gradient, reduced camera system and one LM step vs float64 numpy"""
+    import ba_oracle as bo
+    for path in _goldens(golden_dir):
+        g, K, poses, points, obs = _load(path)
+        lam = 1e-3
+        ctx.ba_upload(K, poses, points, obs)
+        pr = ctx.ba_probe(lam=lam)
+        ne = bo.normal_equations(K, poses, points, obs)
+
+        def rel(a, b):
+            return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+        assert rel(pr["Hpp"], ne["Hpp"]) <= 1e-10
+        assert rel(pr["gp"], ne["gp"]) <= 1e-10
+        assert rel(pr["Hll"], ne["Hll"]) <= 1e-10
+        assert rel(pr["gl"], ne["gl"]) <= 1e-10
+        S, rhs, _, _, _ = bo.schur_system(ne, lam)
+        assert rel(pr["S"], S) <= 1e-8, rel(pr["S"], S)
+        assert rel(pr["rhs"], rhs) <= 1e-8
+        dp, dl, _ = bo.lm_step(ne, lam)
+        assert rel(pr["dposes"], dp) <= 1e-6, rel(pr["dposes"], dp)
+        assert rel(pr["dpoints"], dl) <= 1e-6, rel(pr["dpoints"], dl)
+
+
+def test_ba_jacobian_vs_reference_finite_differences(golden_dir):
+    """BA-3: analytic blocks (as used on the GPU, via the oracle twin) vs the reference's FD Jacobian"""
+    import ba_oracle as bo
+    path = _goldens(golden_dir)[0]
+    g, K, poses, points, obs = _load(path)
+    J = bo.dense_jacobian_norm_form(K, poses, points, obs)
+    Jfd = np.zeros_like(J)
+    Jfd[g["Jfd_row"], g["Jfd_col"]] = g["Jfd_val"]
+    big = np.abs(J) > 1.0
+    assert (np.abs(J - Jfd)[big] / np.abs(J)[big]).max() <= 5e-3
+
+
+def test_ba_solution_vs_oracle_and_reference(ctx, golden_dir):
+    """BA-6/7: same iterates as the numpy LM; final cost <= the reference's (default and near-converged runs)"""
+    import ba_oracle as bo
+    for path in _goldens(golden_dir):
+        g, K, poses, points, obs = _load(path)
+        prm = ctx.ba_params(max_iters=50, ftol=1e-3, xtol=1e-3)
+        po, pt, st = ctx.ba_adjust(K, poses, points, obs, prm)
+        ref = bo.solve(K, poses, points, obs, max_iters=50, ftol=1e-3, xtol=1e-3)
+        assert st["iters"] == ref["iters"] and st["accepted"] == ref["accepted"] and st["status"] == ref["status"]
+        assert abs(st["cost"] - ref["cost"]) <= 1e-7 * ref["cost"]
+        assert abs(st["cost0"] - ref["cost0"]) <= 1e-9 * ref["cost0"]
+        assert np.abs(po - ref["poses"]).max() <= 1e-6 and np.abs(pt - ref["points"]).max() <= 1e-5
+        assert abs(bo.cost(K, po, pt, obs) - st["cost"]) <= 1e-9 * st["cost"]
+        # BA-7: at the reference's tolerances the build must not be worse than the reference's scipy run
+        assert st["cost"] <= float(g["ref_cost"]) * (1 + 1e-3)
+        # tight run: at least as low as the reference's near-converged cost
+        prm = ctx.ba_params(max_iters=200, ftol=1e-12, xtol=1e-12)
+        po2, pt2, st2 = ctx.ba_adjust(K, poses, points, obs, prm)
+        assert st2["cost"] <= float(g["tight_cost"]) * (1 + 1e-4)
+
+
+def test_ba_resident_repeatable(ctx):
+    from vo_mi355x import synthetic as syn
+    s = syn.make_ba_scene(n_pts=500, n_slots=10, seed=3, visibility=0.8)
+    prm = ctx.ba_params(max_iters=8)
+    ctx.ba_upload(s["K"], s["poses0"], s["points0"], s["obs"])
+    outs = []
+    for _ in range(2):
+        ctx.ba_solve_resident(prm)
+        outs.append(ctx.ba_fetch())
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])   # bitwise reproducible
+    po, pt, st = ctx.ba_adjust(s["K"], s["poses0"], s["points0"], s["obs"], prm)
+    assert np.array_equal(po, outs[0][0]) and st["cost"] == outs[0][2]["cost"]
+    assert st["cost"] < 0.05 * st["cost0"]
+
+
+def test_ba_full_size_properties(ctx):
+    """BASELINE shape (N = 2000, W = 10): gauge-invariant checks (cost decrease, reprojection RMS, gauge invariance)"""
+    import ba_oracle as bo
+    from vo_mi355x import synthetic as syn
+    s = syn.make_ba_scene(n_pts=2000, n_slots=10, seed=0)
+    po, pt, st = ctx.ba_adjust(s["K"], s["poses0"], s["points0"], s["obs"], ctx.ba_params(max_iters=30))
+    assert st["n_obs"] == 20000 and st["cost"] < 0.02 * st["cost0"]
+    r = bo.residual_norm(s["K"], po, pt, s["obs"])
+    assert np.sqrt((r ** 2).mean()) < 0.5          # observation noise is 0.3 px per axis
+    ref = bo.solve(s["K"], s["poses0"], s["points0"], s["obs"], max_iters=30)
+    assert abs(st["cost"] - ref["cost"]) <= 1e-6 * ref["cost"]

@@ -1,0 +1,132 @@
+// Two-view DLT triangulation, one thread per point, float64 one-sided Jacobi SVD in registers.
+//
+// Replaces cv2.triangulatePoints(P0, P1, uv0, uv1) at /root/reference/src/extractor/extractor.py:270
+// (OpenCV 4.4 calib3d/triangulate.cpp: per point a 4x4 double matrix A with rows x*P[2]-P[0],
+// y*P[2]-P[1] for both views, SVD, last right-singular vector) and fuses the
+// statistics TriangulatorNL.refine filters on (/root/reference/src/extractor/triangulate.py:87-111):
+// camera-1 depth and the mean reprojection error (|e0| + |e1|) / 2, evaluated in float64 on the
+// float32-rounded, float32-dehomogenised point exactly like extractor.py:271 / triangulate.py:15-29.
+#include "vo_internal.h"
+
+struct dlt_args {
+  float P0[12], P1[12];
+  double M0[12], M1[12];   // K @ H[:3,:] (f64) of both views
+  double H1z[4];           // third row of H1
+  int n, want_stats;
+};
+
+__global__ void __launch_bounds__(64) k_dlt(dlt_args a, const float* __restrict__ uv0, const float* __restrict__ uv1,
+                                            float* __restrict__ X4, double* __restrict__ depth1,
+                                            double* __restrict__ reproj) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const float u0 = uv0[2 * i], v0 = uv0[2 * i + 1], u1 = uv1[2 * i], v1 = uv1[2 * i + 1];
+  double U[4][4], V[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    U[0][k] = (double)u0 * (double)a.P0[8 + k] - (double)a.P0[k];
+    U[1][k] = (double)v0 * (double)a.P0[8 + k] - (double)a.P0[4 + k];
+    U[2][k] = (double)u1 * (double)a.P1[8 + k] - (double)a.P1[k];
+    U[3][k] = (double)v1 * (double)a.P1[8 + k] - (double)a.P1[4 + k];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) V[r][k] = (r == k) ? 1.0 : 0.0;
+
+  for (int sweep = 0; sweep < 60; sweep++) {
+    bool changed = false;
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+      for (int q = p + 1; q < 4; q++) {
+        double al = 0, be = 0, ga = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { al += U[k][p] * U[k][p]; be += U[k][q] * U[k][q]; ga += U[k][p] * U[k][q]; }
+        if (fabs(ga) > 2.220446049250313e-16 * sqrt(al * be)) {
+          changed = true;
+          const double zeta = (be - al) / (2.0 * ga);
+          const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const double up = U[k][p], uq = U[k][q];
+            U[k][p] = c * up - s * uq; U[k][q] = s * up + c * uq;
+            const double vp = V[k][p], vq = V[k][q];
+            V[k][p] = c * vp - s * vq; V[k][q] = s * vp + c * vq;
+          }
+        }
+      }
+    if (!changed) break;
+  }
+  // smallest singular value <-> column of U with the smallest norm
+  double bn = 0; double x[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    double nn = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) nn += U[k][j] * U[k][j];
+    if (j == 0 || nn < bn) {
+      bn = nn;
+#pragma unroll
+      for (int k = 0; k < 4; k++) x[k] = V[k][j];
+    }
+  }
+  float xf[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { xf[k] = (float)x[k]; X4[(size_t)k * a.n + i] = xf[k]; }
+
+  if (a.want_stats) {
+    // float32 dehomogenisation (numpy float32 divide), then float64 statistics
+    const double X = (double)(xf[0] / xf[3]), Y = (double)(xf[1] / xf[3]), Z = (double)(xf[2] / xf[3]);
+    depth1[i] = a.H1z[0] * X + a.H1z[1] * Y + a.H1z[2] * Z + a.H1z[3];
+    double e[2];
+#pragma unroll
+    for (int view = 0; view < 2; view++) {
+      const double* M = view ? a.M1 : a.M0;
+      const double px = M[0] * X + M[1] * Y + M[2] * Z + M[3];
+      const double py = M[4] * X + M[5] * Y + M[6] * Z + M[7];
+      const double pz = M[8] * X + M[9] * Y + M[10] * Z + M[11];
+      const double du = (double)(view ? u1 : u0) - px / pz, dv = (double)(view ? v1 : v0) - py / pz;
+      e[view] = sqrt(du * du + dv * dv);
+    }
+    reproj[i] = (e[0] + e[1]) / 2;
+  }
+}
+
+extern "C" int32_t vo_triangulate_dlt(vo_ctx* c, const float* P0, const float* P1, const float* uv0,
+                                      const float* uv1, int32_t n, float* X4, const double* K,
+                                      const double* H0, const double* H1, double* depth1, double* reproj) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, n >= 0 && n <= c->max_pts, VO_E_CAPACITY, "n exceeds max_pts");
+  if (n == 0) return VO_OK;
+  VO_CHECK(c, P0 && P1 && uv0 && uv1 && X4, VO_E_INVALID, "null buffer");
+  const bool stats = K != nullptr;
+  if (stats) VO_CHECK(c, H0 && H1 && depth1 && reproj, VO_E_INVALID, "statistics need K, H0, H1, depth1, reproj");
+  VO_HIP(c, hipSetDevice(c->device));
+  dlt_args a;
+  for (int k = 0; k < 12; k++) { a.P0[k] = P0[k]; a.P1[k] = P1[k]; a.M0[k] = 0; a.M1[k] = 0; }
+  for (int k = 0; k < 4; k++) a.H1z[k] = 0;
+  if (stats) {
+    for (int r = 0; r < 3; r++)
+      for (int col = 0; col < 4; col++) {
+        double s0 = 0, s1 = 0;
+        for (int k = 0; k < 3; k++) { s0 += K[r * 3 + k] * H0[k * 4 + col]; s1 += K[r * 3 + k] * H1[k * 4 + col]; }
+        a.M0[r * 4 + col] = s0; a.M1[r * 4 + col] = s1;
+      }
+    for (int k = 0; k < 4; k++) a.H1z[k] = H1[8 + k];
+  }
+  a.n = n; a.want_stats = stats ? 1 : 0;
+  VO_HIP(c, hipMemcpyAsync(c->d_uv0, uv0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipMemcpyAsync(c->d_uv1, uv1, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_dlt, dim3(vo_div_up(n, 64)), dim3(64), 0, c->stream, a, c->d_uv0, c->d_uv1, c->d_X4,
+                     c->d_depth, c->d_reproj);
+  VO_HIP(c, hipGetLastError());
+  VO_HIP(c, hipMemcpyAsync(X4, c->d_X4, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, c->stream));
+  if (stats) {
+    VO_HIP(c, hipMemcpyAsync(depth1, c->d_depth, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipMemcpyAsync(reproj, c->d_reproj, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  }
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  return VO_OK;
+}

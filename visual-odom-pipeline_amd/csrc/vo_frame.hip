@@ -1,0 +1,272 @@
+// Context lifetime + frame store: padded image pyramid and Scharr derivatives in HBM.
+//
+// Replaces the pyramid / derivative construction cv2.calcOpticalFlowPyrLK performs on every call
+// (/root/reference/src/extractor/extractor.py:44-45,65-66 -> 8 pyramid builds per frame in the
+// reference; here ONE per frame, kept resident and rotated prev <-> cur).
+//
+// HBM layout per frame, per level l (w_l x h_l interior):
+//   img[l] : uint8, (h_l + 64) rows x pitch_l, interior origin at (32, 32), border = the
+//            BORDER_REFLECT_101 extension of the interior (what buildOpticalFlowPyramid pads with),
+//            so the tracker reads windows with plain unaligned dword loads and no index math.
+//   der[l] : int16 x 2 interleaved (Ix, Iy) Scharr, same pixel pitch, border = 0 (BORDER_CONSTANT).
+// pitch_l is a multiple of 64 pixels so rows start on 64 B (img) / 256 B (der) boundaries.
+// All arithmetic here is integer and bit-exact against oracle/vo_oracle.c.
+#include "vo_internal.h"
+
+#include <new>
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int d_reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * (len - 1) - p;
+  return p;
+}
+
+// Level 0: raw (w x h, tight) -> padded image with reflect-101 border.
+__global__ void __launch_bounds__(256) k_pad_level0(const uint8_t* __restrict__ raw, int w, int h,
+                                                    uint8_t* __restrict__ dst, int pitch, int ph) {
+  const int X = blockIdx.x * blockDim.x + threadIdx.x;   // padded column
+  const int Y = blockIdx.y;
+  if (X >= w + 2 * VO_PAD || Y >= ph) return;
+  const int x = d_reflect101(X - VO_PAD, w), y = d_reflect101(Y - VO_PAD, h);
+  dst[(size_t)Y * pitch + X] = raw[(size_t)y * w + x];
+}
+
+// One launch per level l, two block roles:
+//   blocks [0, nb_scharr)            : Scharr derivative of level l (interior only)
+//   blocks [nb_scharr, gridDim.x)    : pyrDown level l -> l+1 including its reflect-101 border
+// Both only READ level l, so they are independent inside the launch.
+__global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restrict__ src, int w, int h, int pitch,
+                                                        int16_t* __restrict__ der, int nb_scharr,
+                                                        uint8_t* __restrict__ dst, int dw, int dh, int dpitch) {
+  if ((int)blockIdx.x < nb_scharr) {
+    // ---- Scharr: Ix = [3 10 3]^T (x) [-1 0 1], Iy = [-1 0 1]^T (x) [3 10 3], un-normalised ----
+    const int per_row = (w + 255) / 256;
+    const int y = blockIdx.x / per_row;
+    const int x = (blockIdx.x - y * per_row) * 256 + threadIdx.x;
+    if (x >= w) return;
+    const uint8_t* p = src + (size_t)(y + VO_PAD) * pitch + (x + VO_PAD);
+    const int a00 = p[-pitch - 1], a01 = p[-pitch], a02 = p[-pitch + 1];
+    const int a10 = p[-1], a12 = p[1];
+    const int a20 = p[pitch - 1], a21 = p[pitch], a22 = p[pitch + 1];
+    const int ix = (a02 + a22 - a00 - a20) * 3 + (a12 - a10) * 10;
+    const int iy = (a20 + a22 - a00 - a02) * 3 + (a21 - a01) * 10;
+    const uint32_t packed = ((uint32_t)(uint16_t)(int16_t)ix) | ((uint32_t)(uint16_t)(int16_t)iy << 16);
+    reinterpret_cast<uint32_t*>(der)[(size_t)(y + VO_PAD) * pitch + (x + VO_PAD)] = packed;
+  } else {
+    // ---- pyrDown: 5x5 [1 4 6 4 1]^2, (sum + 128) >> 8, output padded domain ----
+    const int b = blockIdx.x - nb_scharr;
+    const int pw = dw + 2 * VO_PAD;
+    const int per_row = (pw + 255) / 256;
+    const int Y = b / per_row;
+    const int X = (b - Y * per_row) * 256 + threadIdx.x;
+    if (X >= pw || Y >= dh + 2 * VO_PAD) return;
+    const int x = d_reflect101(X - VO_PAD, dw), y = d_reflect101(Y - VO_PAD, dh);
+    // source is padded by 32 with reflect-101, so 2x-2 .. 2x+2 never needs index reflection
+    const uint8_t* p = src + (size_t)(2 * y + VO_PAD) * pitch + (2 * x + VO_PAD);
+    int sum = 0;
+#pragma unroll
+    for (int j = -2; j <= 2; j++) {
+      const uint8_t* r = p + j * pitch;
+      const int row = r[-2] + 4 * r[-1] + 6 * r[0] + 4 * r[1] + r[2];
+      const int wj = (j == 0) ? 6 : ((j == -1 || j == 1) ? 4 : 1);
+      sum += wj * row;
+    }
+    dst[(size_t)Y * dpitch + X] = (uint8_t)((sum + 128) >> 8);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t vo_abi_version(void) { return VO_ABI_VERSION; }
+
+extern "C" int32_t vo_device_count(int32_t* n) {
+  if (!n) return VO_E_INVALID;
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) { *n = 0; return VO_E_HIP; }
+  *n = c;
+  return VO_OK;
+}
+
+static thread_local std::string g_create_err;
+
+extern "C" const char* vo_last_error(const vo_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
+  if (!c) return VO_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  vo_st_destroy(c);
+  vo_ba_destroy(c);
+  for (int f = 0; f < 2; f++)
+    for (int l = 0; l < VO_MAX_LEVELS; l++) {
+      if (c->fr[f].img[l]) (void)hipFree(c->fr[f].img[l]);
+      if (c->fr[f].der[l]) (void)hipFree(c->fr[f].der[l]);
+    }
+  void* bufs[] = {c->d_raw, c->d_seq, c->d_p0, c->d_p1, c->d_err, c->d_status, c->d_iters,
+                  c->d_uv0, c->d_uv1, c->d_X4, c->d_depth, c->d_reproj};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return VO_OK;
+}
+
+extern "C" int32_t vo_ctx_create(int32_t device, int32_t width, int32_t height, int32_t max_pts,
+                                 int32_t max_level, int32_t win, vo_ctx** out) {
+  if (!out) return VO_E_INVALID;
+  *out = nullptr;
+  if (width < 8 || height < 8 || max_pts < 1 || max_level < 0 || max_level >= VO_MAX_LEVELS ||
+      win < 3 || win > VO_MAX_WIN || (win & 1) == 0) {
+    g_create_err = "vo_ctx_create: invalid argument";
+    return VO_E_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_create_err = "vo_ctx_create: no HIP device (this library has no CPU fallback)";
+    return VO_E_HIP;
+  }
+  if (device < 0 || device >= ndev) { g_create_err = "vo_ctx_create: bad device index"; return VO_E_INVALID; }
+  vo_ctx* c = new (std::nothrow) vo_ctx();
+  if (!c) return VO_E_NOMEM;
+  for (int f = 0; f < 2; f++)
+    for (int l = 0; l < VO_MAX_LEVELS; l++) { c->fr[f].img[l] = nullptr; c->fr[f].der[l] = nullptr; }
+  c->device = device; c->width = width; c->height = height; c->max_pts = max_pts;
+  c->max_level = max_level; c->win = win;
+  auto fail = [&](int32_t code) { g_create_err = c->err; vo_ctx_destroy(c); return code; };
+#define CR(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { c->err = std::string(#expr) + " -> " + hipGetErrorString(_e); return fail(VO_E_HIP); } } while (0)
+  CR(hipSetDevice(device));
+  CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  // pyramid geometry (buildOpticalFlowPyramid truncation rule)
+  int w = width, h = height, top = 0;
+  for (int l = 0; l <= max_level; l++) {
+    if (l > 0) {
+      const int nw = (w + 1) / 2, nh = (h + 1) / 2;
+      if (nw <= win || nh <= win) break;
+      w = nw; h = nh;
+    }
+    c->lv[l].w = w; c->lv[l].h = h;
+    c->lv[l].pitch = ((w + 2 * VO_PAD + 63) / 64) * 64;
+    c->lv[l].ph = h + 2 * VO_PAD;
+    top = l;
+  }
+  c->top = top;
+  for (int f = 0; f < 2; f++)
+    for (int l = 0; l <= top; l++) {
+      const size_t px = (size_t)c->lv[l].pitch * c->lv[l].ph;
+      CR(hipMalloc((void**)&c->fr[f].img[l], px));
+      CR(hipMalloc((void**)&c->fr[f].der[l], px * 4));
+      CR(hipMemsetAsync(c->fr[f].img[l], 0, px, c->stream));
+      CR(hipMemsetAsync(c->fr[f].der[l], 0, px * 4, c->stream));   // border stays 0 forever
+    }
+  CR(hipMalloc((void**)&c->d_raw, (size_t)width * height));
+  CR(hipMalloc((void**)&c->d_p0, sizeof(float) * 2 * max_pts));
+  CR(hipMalloc((void**)&c->d_p1, sizeof(float) * 2 * max_pts));
+  CR(hipMalloc((void**)&c->d_err, sizeof(float) * max_pts));
+  CR(hipMalloc((void**)&c->d_status, max_pts));
+  CR(hipMalloc((void**)&c->d_iters, sizeof(int32_t) * max_pts * VO_MAX_LEVELS));
+  CR(hipMalloc((void**)&c->d_uv0, sizeof(float) * 2 * max_pts));
+  CR(hipMalloc((void**)&c->d_uv1, sizeof(float) * 2 * max_pts));
+  CR(hipMalloc((void**)&c->d_X4, sizeof(float) * 4 * max_pts));
+  CR(hipMalloc((void**)&c->d_depth, sizeof(double) * max_pts));
+  CR(hipMalloc((void**)&c->d_reproj, sizeof(double) * max_pts));
+  CR(hipStreamSynchronize(c->stream));
+#undef CR
+  *out = c;
+  return VO_OK;
+}
+
+extern "C" int32_t vo_sync(vo_ctx* c) {
+  if (!c) return VO_E_INVALID;
+  VO_HIP(c, hipSetDevice(c->device));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// frames
+// ------------------------------------------------------------------------------------------------
+static int32_t build_pyramid(vo_ctx* c, const uint8_t* d_raw_img) {
+  c->cur ^= 1;
+  vo_frame& F = c->fr[c->cur];
+  {
+    const vo_level& L = c->lv[0];
+    dim3 grid(vo_div_up(L.w + 2 * VO_PAD, 256), L.ph);
+    hipLaunchKernelGGL(k_pad_level0, grid, dim3(256), 0, c->stream, d_raw_img, L.w, L.h, F.img[0], L.pitch, L.ph);
+  }
+  for (int l = 0; l <= c->top; l++) {
+    const vo_level& L = c->lv[l];
+    const int nb_scharr = vo_div_up(L.w, 256) * L.h;
+    int nb_down = 0;
+    uint8_t* dst = nullptr; int dw = 0, dh = 0, dpitch = 0;
+    if (l < c->top) {
+      const vo_level& D = c->lv[l + 1];
+      dst = F.img[l + 1]; dw = D.w; dh = D.h; dpitch = D.pitch;
+      nb_down = vo_div_up(D.w + 2 * VO_PAD, 256) * D.ph;
+    }
+    hipLaunchKernelGGL(k_scharr_pyrdown, dim3(nb_scharr + nb_down), dim3(256), 0, c->stream,
+                       F.img[l], L.w, L.h, L.pitch, F.der[l], nb_scharr, dst, dw, dh, dpitch);
+  }
+  VO_HIP(c, hipGetLastError());
+  c->n_pushed++;
+  return VO_OK;
+}
+
+extern "C" int32_t vo_frame_push(vo_ctx* c, const uint8_t* img, int32_t stride) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, img != nullptr && stride >= c->width, VO_E_INVALID, "bad image / stride");
+  VO_HIP(c, hipSetDevice(c->device));
+  VO_HIP(c, hipMemcpy2DAsync(c->d_raw, c->width, img, stride, c->width, c->height, hipMemcpyHostToDevice, c->stream));
+  int32_t r = build_pyramid(c, c->d_raw);
+  if (r != VO_OK) return r;
+  VO_HIP(c, hipStreamSynchronize(c->stream));   // the host buffer may be reused by the caller
+  return VO_OK;
+}
+
+extern "C" int32_t vo_seq_upload(vo_ctx* c, const uint8_t* frames, int32_t n_frames) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, frames != nullptr && n_frames > 0, VO_E_INVALID, "bad sequence");
+  VO_HIP(c, hipSetDevice(c->device));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->d_seq) { VO_HIP(c, hipFree(c->d_seq)); c->d_seq = nullptr; c->seq_n = 0; }
+  const size_t bytes = (size_t)c->width * c->height * n_frames;
+  VO_HIP(c, hipMalloc((void**)&c->d_seq, bytes));
+  VO_HIP(c, hipMemcpy(c->d_seq, frames, bytes, hipMemcpyHostToDevice));
+  c->seq_n = n_frames;
+  return VO_OK;
+}
+
+extern "C" int32_t vo_frame_push_resident(vo_ctx* c, int32_t idx) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->d_seq != nullptr && idx >= 0 && idx < c->seq_n, VO_E_STATE, "no resident sequence / bad index");
+  VO_HIP(c, hipSetDevice(c->device));
+  return build_pyramid(c, c->d_seq + (size_t)idx * c->width * c->height);
+}
+
+extern "C" int32_t vo_pyramid_level_size(vo_ctx* c, int32_t level, int32_t* w, int32_t* h) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, level >= 0 && level <= c->top && w && h, VO_E_INVALID, "bad level");
+  *w = c->lv[level].w; *h = c->lv[level].h;
+  return VO_OK;
+}
+
+extern "C" int32_t vo_pyramid_read(vo_ctx* c, int32_t which, int32_t level, uint8_t* img_out, int16_t* deriv_out) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, level >= 0 && level <= c->top && (which == 0 || which == 1), VO_E_INVALID, "bad level / which");
+  VO_CHECK(c, c->n_pushed >= (which == 0 ? 2 : 1), VO_E_STATE, "frame not pushed yet");
+  VO_HIP(c, hipSetDevice(c->device));
+  const vo_frame& F = c->fr[which == 1 ? c->cur : (c->cur ^ 1)];
+  const vo_level& L = c->lv[level];
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  if (img_out)
+    VO_HIP(c, hipMemcpy2D(img_out, L.w, F.img[level] + (size_t)VO_PAD * L.pitch + VO_PAD, L.pitch, L.w, L.h,
+                          hipMemcpyDeviceToHost));
+  if (deriv_out)
+    VO_HIP(c, hipMemcpy2D(deriv_out, (size_t)L.w * 4, F.der[level] + ((size_t)VO_PAD * L.pitch + VO_PAD) * 2,
+                          (size_t)L.pitch * 4, (size_t)L.w * 4, L.h, hipMemcpyDeviceToHost));
+  return VO_OK;
+}

@@ -1,0 +1,355 @@
+// Pyramidal Lucas-Kanade tracker for gfx950: ONE WAVE (64 lanes) PER KEYPOINT, all pyramid levels
+// in one launch, template in registers, exact integer arithmetic.
+//
+// Replaces cv2.calcOpticalFlowPyrLK(prev, cur, p0, None, winSize=(31,31), maxLevel=3,
+// criteria=(EPS|COUNT, 30, 0.03)) at /root/reference/src/extractor/extractor.py:44-45,65-66.
+// Algorithm = OpenCV 4.4 video/lkpyramid.cpp LKTrackerInvoker, with the 2x2
+// normal matrix / mismatch vector summed EXACTLY in integers (oracle/vo_oracle.c acc_mode = 1), so
+// results are bit-identical to the CPU oracle independent of summation order.
+//
+// Lane <-> window mapping (window <= 31x31, read footprint 32 rows x 34 bytes):
+//   lane = cp*4 + r,  cp = 0..15 (column pair), r = 0..3;  step s = 0..7 covers window row 4s + r,
+//   columns 2cp and 2cp+1.  One unaligned dword load per lane per step fetches the 3 bytes the two
+//   bilinear footprints need from the top row; the bottom row is the quad neighbour's top row
+//   (DPP quad_perm rotate, no memory traffic).  => 8 dword loads per lane per LK iteration for a
+//   1 KB window, served by L1/L2 (a pyramid level is <= 0.6 MB; HBM sees it once).
+//   The template (I, Ix, Iy at 16 pixels per lane) lives in 48 VGPRs across all iterations.
+#include "vo_internal.h"
+
+#define W_BITS 14
+
+struct klt_level_args {
+  const uint8_t* imgI;
+  const uint32_t* derI;   // (Ix | Iy << 16) per pixel
+  const uint8_t* imgJ;
+  int w, h, pitch;
+};
+
+struct klt_args {
+  klt_level_args lv[VO_MAX_LEVELS];
+  int top, win, max_count, n, iters_stride;
+  float min_eig;
+  double eps2;
+};
+
+__device__ __forceinline__ uint32_t ld_u32_any(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+
+// lane q of every quad receives the value of lane (q+1)&3 of the same quad
+__device__ __forceinline__ uint32_t quad_rot1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x39 /* quad_perm:[1,2,3,0] */, 0xf, 0xf, true);
+}
+
+// exact wave-wide sum of an int32 per lane whose total fits in int32; result uniform
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// exact wave-wide sum of arbitrary int32 per lane as int64 (split into 16-bit halves)
+__device__ __forceinline__ long long wave_sum_i64(int v) {
+  const int lo = wave_sum_i32(v & 0xFFFF);
+  const int hi = wave_sum_i32(v >> 16);
+  return ((long long)hi << 16) + (long long)lo;
+}
+
+__device__ __forceinline__ void lk_weights(float a, float b, int& iw00, int& iw01, int& iw10, int& iw11) {
+  iw00 = (int)rintf((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
+  iw01 = (int)rintf(a * (1.f - b) * (float)(1 << W_BITS));
+  iw10 = (int)rintf((1.f - a) * b * (float)(1 << W_BITS));
+  iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+}
+
+__device__ __forceinline__ float uniform_f(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// bilinear samples (x512 fixed point -> 5 fractional bits) of the two pixels a lane owns in one step
+__device__ __forceinline__ void sample2(uint32_t T, uint32_t B, int iw00, int iw01, int iw10, int iw11, int& v0, int& v1) {
+  const int t0 = T & 0xff, t1 = (T >> 8) & 0xff, t2 = (T >> 16) & 0xff;
+  const int b0 = B & 0xff, b1 = (B >> 8) & 0xff, b2 = (B >> 16) & 0xff;
+  v0 = (t0 * iw00 + t1 * iw01 + b0 * iw10 + b1 * iw11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+  v1 = (t1 * iw00 + t2 * iw01 + b1 * iw10 + b2 * iw11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+}
+
+__device__ __forceinline__ int deriv_interp(uint32_t d00, uint32_t d01, uint32_t d10, uint32_t d11, int hi,
+                                            int iw00, int iw01, int iw10, int iw11) {
+  const int sh = hi ? 16 : 0;
+  const int a = (int)(short)(d00 >> sh), b = (int)(short)(d01 >> sh);
+  const int c = (int)(short)(d10 >> sh), d = (int)(short)(d11 >> sh);
+  return (a * iw00 + b * iw01 + c * iw10 + d * iw11 + (1 << (W_BITS - 1))) >> W_BITS;
+}
+
+__global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __restrict__ p0, float* __restrict__ p1,
+                                                  uint8_t* __restrict__ status, float* __restrict__ err,
+                                                  int32_t* __restrict__ iters) {
+  const int pt = blockIdx.x;
+  if (pt >= A.n) return;
+  const int lane = threadIdx.x;
+  const int cp = lane >> 2, r = lane & 3;
+  const int win = A.win;
+  const float half = (float)(win - 1) * 0.5f;
+  const float FLT_SCALE = 1.f / (float)(1 << 20);
+
+  const float p0x = uniform_f(p0[2 * pt]), p0y = uniform_f(p0[2 * pt + 1]);
+  float outx = 0.f, outy = 0.f;   // nextPts[pt]
+  int st = 1;
+  float errv = 0.f;
+
+  // per-lane validity of its 16 template pixels (bit 2s+k)
+  uint32_t vmask = 0;
+#pragma unroll
+  for (int s = 0; s < 8; s++) {
+    const int row = 4 * s + r;
+    if (row < win) {
+      if (2 * cp < win) vmask |= 1u << (2 * s);
+      if (2 * cp + 1 < win) vmask |= 1u << (2 * s + 1);
+    }
+  }
+
+  for (int level = A.top; level >= 0; level--) {
+    const klt_level_args L = A.lv[level];
+    const float scale = 1.f / (float)(1 << level);
+    float prevx = p0x * scale, prevy = p0y * scale;
+    float nextx, nexty;
+    if (level == A.top) { nextx = prevx; nexty = prevy; }
+    else { nextx = outx * 2.f; nexty = outy * 2.f; }
+    outx = nextx; outy = nexty;
+    int n_it = -1;
+
+    prevx -= half; prevy -= half;
+    const int ipx = (int)floorf(prevx), ipy = (int)floorf(prevy);
+    if (ipx < -win || ipx >= L.w || ipy < -win || ipy >= L.h) {
+      if (level == 0) { st = 0; errv = 0.f; }
+      if (iters && lane == 0) iters[pt * A.iters_stride + level] = n_it;
+      continue;
+    }
+    int iw00, iw01, iw10, iw11;
+    lk_weights(prevx - (float)ipx, prevy - (float)ipy, iw00, iw01, iw10, iw11);
+
+    // ---- template: I (5 frac bits), Ix, Iy at the lane's 16 pixels; exact A11, A12, A22 ----
+    int tI[16], tX[16], tY[16];
+    {
+      uint32_t T[8], D0[8], D1[8], D2[8];
+      const size_t base = (size_t)(ipy + VO_PAD + r) * L.pitch + (size_t)(ipx + VO_PAD + 2 * cp);
+#pragma unroll
+      for (int s = 0; s < 8; s++) {
+        const size_t off = base + (size_t)(4 * s) * L.pitch;
+        T[s] = ld_u32_any(L.imgI + off);
+        D0[s] = L.derI[off]; D1[s] = L.derI[off + 1]; D2[s] = L.derI[off + 2];
+      }
+      int a11 = 0, a12 = 0, a22 = 0;
+#pragma unroll
+      for (int s = 0; s < 8; s++) {
+        const int sn = (s < 7) ? s + 1 : 7;
+        const uint32_t B = quad_rot1(r == 0 ? T[sn] : T[s]);
+        const uint32_t E0 = quad_rot1(r == 0 ? D0[sn] : D0[s]);
+        const uint32_t E1 = quad_rot1(r == 0 ? D1[sn] : D1[s]);
+        const uint32_t E2 = quad_rot1(r == 0 ? D2[sn] : D2[s]);
+        int v0, v1;
+        sample2(T[s], B, iw00, iw01, iw10, iw11, v0, v1);
+        int x0 = deriv_interp(D0[s], D1[s], E0, E1, 0, iw00, iw01, iw10, iw11);
+        int y0 = deriv_interp(D0[s], D1[s], E0, E1, 1, iw00, iw01, iw10, iw11);
+        int x1 = deriv_interp(D1[s], D2[s], E1, E2, 0, iw00, iw01, iw10, iw11);
+        int y1 = deriv_interp(D1[s], D2[s], E1, E2, 1, iw00, iw01, iw10, iw11);
+        if (!((vmask >> (2 * s)) & 1)) { x0 = 0; y0 = 0; }
+        if (!((vmask >> (2 * s + 1)) & 1)) { x1 = 0; y1 = 0; }
+        tI[2 * s] = v0; tI[2 * s + 1] = v1;
+        tX[2 * s] = x0; tX[2 * s + 1] = x1;
+        tY[2 * s] = y0; tY[2 * s + 1] = y1;
+        a11 += x0 * x0 + x1 * x1;
+        a12 += x0 * y0 + x1 * y1;
+        a22 += y0 * y0 + y1 * y1;
+      }
+      const long long iA11 = wave_sum_i64(a11), iA12 = wave_sum_i64(a12), iA22 = wave_sum_i64(a22);
+      // (kept in registers below)
+      const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
+      float D = A11 * A22 - A12 * A12;
+      const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
+      if (minEig < A.min_eig || D < 1.1920929e-07f) {
+        if (level == 0) st = 0;
+        if (iters && lane == 0) iters[pt * A.iters_stride + level] = n_it;
+        continue;
+      }
+      D = 1.f / D;
+
+      nextx -= half; nexty -= half;
+      float pdx = 0.f, pdy = 0.f;
+      int j = 0;
+      for (; j < A.max_count; j++) {
+        const int inx = (int)floorf(nextx), iny = (int)floorf(nexty);
+        if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) {
+          if (level == 0) st = 0;
+          break;
+        }
+        int jw00, jw01, jw10, jw11;
+        lk_weights(nextx - (float)inx, nexty - (float)iny, jw00, jw01, jw10, jw11);
+        uint32_t Tj[8];
+        const uint8_t* pj = L.imgJ + (size_t)(iny + VO_PAD + r) * L.pitch + (size_t)(inx + VO_PAD + 2 * cp);
+#pragma unroll
+        for (int s = 0; s < 8; s++) Tj[s] = ld_u32_any(pj + (size_t)(4 * s) * L.pitch);
+        int b1 = 0, b2 = 0;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+          const int sn = (s < 7) ? s + 1 : 7;
+          const uint32_t B = quad_rot1(r == 0 ? Tj[sn] : Tj[s]);
+          int v0, v1;
+          sample2(Tj[s], B, jw00, jw01, jw10, jw11, v0, v1);
+          const int d0 = v0 - tI[2 * s], d1 = v1 - tI[2 * s + 1];
+          b1 += d0 * tX[2 * s] + d1 * tX[2 * s + 1];
+          b2 += d0 * tY[2 * s] + d1 * tY[2 * s + 1];
+        }
+        const float fb1 = (float)wave_sum_i64(b1) * FLT_SCALE;
+        const float fb2 = (float)wave_sum_i64(b2) * FLT_SCALE;
+        const float dx = (A12 * fb2 - A22 * fb1) * D;
+        const float dy = (A12 * fb1 - A11 * fb2) * D;
+        nextx += dx; nexty += dy;
+        outx = nextx + half; outy = nexty + half;
+        if ((double)dx * (double)dx + (double)dy * (double)dy <= A.eps2) { j++; break; }
+        if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+          outx -= dx * 0.5f; outy -= dy * 0.5f;
+          j++;
+          break;
+        }
+        pdx = dx; pdy = dy;
+      }
+      n_it = j;
+      if (iters && lane == 0) iters[pt * A.iters_stride + level] = n_it;
+
+      if (st && level == 0) {
+        const float nx = outx - half, ny = outy - half;
+        const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+        if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) {
+          st = 0;
+        } else {
+          int jw00, jw01, jw10, jw11;
+          lk_weights(nx - (float)inx, ny - (float)iny, jw00, jw01, jw10, jw11);
+          uint32_t Tj[8];
+          const uint8_t* pj = L.imgJ + (size_t)(iny + VO_PAD + r) * L.pitch + (size_t)(inx + VO_PAD + 2 * cp);
+#pragma unroll
+          for (int s = 0; s < 8; s++) Tj[s] = ld_u32_any(pj + (size_t)(4 * s) * L.pitch);
+          int e = 0;
+#pragma unroll
+          for (int s = 0; s < 8; s++) {
+            const int sn = (s < 7) ? s + 1 : 7;
+            const uint32_t B = quad_rot1(r == 0 ? Tj[sn] : Tj[s]);
+            int v0, v1;
+            sample2(Tj[s], B, jw00, jw01, jw10, jw11, v0, v1);
+            const int d0 = v0 - tI[2 * s], d1 = v1 - tI[2 * s + 1];
+            if ((vmask >> (2 * s)) & 1) e += d0 < 0 ? -d0 : d0;
+            if ((vmask >> (2 * s + 1)) & 1) e += d1 < 0 ? -d1 : d1;
+          }
+          const int ierr = wave_sum_i32(e);
+          errv = (float)ierr * 1.f / (float)(32 * win * win);
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    p1[2 * pt] = outx; p1[2 * pt + 1] = outy;
+    status[pt] = (uint8_t)st;
+    err[pt] = st ? errv : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t vo_klt_default_params(vo_klt_params* p) {
+  if (!p) return VO_E_INVALID;
+  p->win = 31; p->max_level = 3; p->max_count = 30; p->epsilon = 0.03; p->min_eig_threshold = 1e-4f; p->_pad = 0;
+  return VO_OK;
+}
+
+static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, const float* d_in, float* d_out) {
+  VO_CHECK(c, c->n_pushed >= 2, VO_E_STATE, "need two pushed frames");
+  VO_CHECK(c, n >= 0 && n <= c->max_pts, VO_E_CAPACITY, "n exceeds max_pts");
+  VO_CHECK(c, prm && prm->win >= 3 && prm->win <= VO_MAX_WIN && (prm->win & 1), VO_E_INVALID, "win must be odd, 3..31");
+  VO_CHECK(c, prm->max_level >= 0 && prm->max_level < VO_MAX_LEVELS, VO_E_INVALID, "bad max_level");
+  if (n == 0) return VO_OK;
+  klt_args A;
+  const vo_frame& P = c->fr[c->cur ^ 1];
+  const vo_frame& C = c->fr[c->cur];
+  // effective top level: levels available in the frame store, truncated by this call's window rule
+  int top = 0;
+  for (int l = 1; l <= c->top && l <= prm->max_level; l++) {
+    if (c->lv[l].w <= prm->win || c->lv[l].h <= prm->win) break;
+    top = l;
+  }
+  for (int l = 0; l <= top; l++) {
+    A.lv[l].imgI = P.img[l]; A.lv[l].derI = reinterpret_cast<const uint32_t*>(P.der[l]); A.lv[l].imgJ = C.img[l];
+    A.lv[l].w = c->lv[l].w; A.lv[l].h = c->lv[l].h; A.lv[l].pitch = c->lv[l].pitch;
+  }
+  A.top = top; A.win = prm->win;
+  int mc = prm->max_count; if (mc < 0) mc = 0; if (mc > 100) mc = 100;
+  double eps = prm->epsilon; if (eps < 0) eps = 0; if (eps > 10) eps = 10;
+  A.max_count = mc; A.eps2 = eps * eps; A.min_eig = prm->min_eig_threshold; A.n = n;
+  A.iters_stride = prm->max_level + 1;
+  // levels above `top` are reported as skipped (-1)
+  VO_HIP(c, hipMemsetAsync(c->d_iters, 0xff, sizeof(int32_t) * (size_t)n * A.iters_stride, c->stream));
+  hipLaunchKernelGGL(k_klt_track, dim3(n), dim3(64), 0, c->stream, A, d_in, d_out, c->d_status, c->d_err, c->d_iters);
+  VO_HIP(c, hipGetLastError());
+  return VO_OK;
+}
+
+extern "C" int32_t vo_klt_track(vo_ctx* c, const float* p0, int32_t n, const vo_klt_params* prm,
+                                float* p1, uint8_t* status, float* err, int32_t* iters) {
+  if (!c) return VO_E_INVALID;
+  vo_klt_params def;
+  if (!prm) { vo_klt_default_params(&def); prm = &def; }
+  VO_CHECK(c, n >= 0 && n <= c->max_pts, VO_E_CAPACITY, "n exceeds max_pts");
+  if (n == 0) return VO_OK;
+  VO_CHECK(c, p0 && p1 && status && err, VO_E_INVALID, "null buffer");
+  VO_HIP(c, hipSetDevice(c->device));
+  VO_HIP(c, hipMemcpyAsync(c->d_p0, p0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+  int32_t r = klt_launch(c, n, prm, c->d_p0, c->d_p1);
+  if (r != VO_OK) return r;
+  VO_HIP(c, hipMemcpyAsync(p1, c->d_p1, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipMemcpyAsync(err, c->d_err, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+  if (iters)
+    VO_HIP(c, hipMemcpyAsync(iters, c->d_iters, sizeof(int32_t) * (size_t)n * (prm->max_level + 1), hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
+extern "C" int32_t vo_points_upload(vo_ctx* c, const float* p, int32_t n) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, p && n >= 0 && n <= c->max_pts, VO_E_CAPACITY, "bad point set");
+  VO_HIP(c, hipSetDevice(c->device));
+  VO_HIP(c, hipMemcpyAsync(c->d_p0, p, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  c->n_resident = n;
+  return VO_OK;
+}
+
+extern "C" int32_t vo_points_download(vo_ctx* c, float* p, uint8_t* status, float* err, int32_t n) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, n >= 0 && n <= c->n_resident, VO_E_INVALID, "n exceeds the resident point set");
+  VO_HIP(c, hipSetDevice(c->device));
+  if (p) VO_HIP(c, hipMemcpyAsync(p, c->d_p0, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+  if (status) VO_HIP(c, hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, c->stream));
+  if (err) VO_HIP(c, hipMemcpyAsync(err, c->d_err, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
+extern "C" int32_t vo_klt_track_resident(vo_ctx* c, int32_t n, const vo_klt_params* prm) {
+  if (!c) return VO_E_INVALID;
+  vo_klt_params def;
+  if (!prm) { vo_klt_default_params(&def); prm = &def; }
+  VO_CHECK(c, n >= 0 && n <= c->n_resident, VO_E_INVALID, "n exceeds the resident point set");
+  VO_HIP(c, hipSetDevice(c->device));
+  int32_t r = klt_launch(c, n, prm, c->d_p0, c->d_p1);
+  if (r != VO_OK) return r;
+  float* t = c->d_p0; c->d_p0 = c->d_p1; c->d_p1 = t;   // tracked positions become the resident set
+  return VO_OK;
+}

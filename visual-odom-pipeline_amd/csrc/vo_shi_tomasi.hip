@@ -1,0 +1,420 @@
+// Shi-Tomasi re-detection on the current frame: exclusion mask + goodFeaturesToTrack, all on device.
+//
+// Replaces /root/reference/src/extractor/extractor.py:103-112:
+//     mask = 255; for kp: cv2.circle(mask, int32(kp.uv), mask_radius, 0, -1)
+//     cv2.goodFeaturesToTrack(img, mask=mask, maxCorners=1000, qualityLevel=0.03, minDistance=7, blockSize=31)
+// Algorithm = OpenCV 4.4 imgproc/featureselect.cpp + corner.cpp + drawing.cpp.
+// The 31x31 structure-tensor sums are exact int32 (Sobel outputs are integers before the scale), so
+// the eigenvalue map, the candidate ranking and the selected corners are bit-identical to
+// oracle/vo_oracle.c (exact_int = 1).
+//
+// Launches (one stream, no host round trip):
+//   k_st_sobel_hsum : Sobel 3x3 products -> LDS -> horizontal box sums (3 int32 planes) + mask init
+//   k_st_discs      : filled midpoint circles of the tracked keypoints into the mask
+//   k_st_vsum_eig   : sliding vertical box sums -> min-eigenvalue map + masked global max
+//   k_st_nms        : threshold + 3x3 non-max suppression + mask -> compacted (value, index) keys
+//   k_st_select     : ONE workgroup: bitonic sort of the keys in LDS (value desc, index desc) and the
+//                     greedy min-distance selection done as parallel fixed-point rounds (a candidate is
+//                     accepted iff every higher-ranked candidate within min_distance is rejected) --
+//                     equivalent to OpenCV's sequential grid scan, output in rank order, first maxCorners.
+#include "vo_internal.h"
+
+#define ST_CAND_CAP 16384        // keys sorted in LDS (128 KB of the CU's 160 KB)
+#define ST_OUT_CAP 4096
+#define ST_MAX_RADIUS 31
+
+struct vo_st_ws {
+  uint8_t* d_mask = nullptr;
+  uint8_t* d_user_mask = nullptr;
+  int32_t* d_h = nullptr;          // 3 planes W*H: hxx, hxy, hyy
+  float* d_eig = nullptr;
+  uint32_t* d_scalars = nullptr;   // [0] max eig bits, [1] n candidates, [2] n out (int), [3] rounds
+  unsigned long long* d_cand = nullptr;
+  int32_t* d_cellhead = nullptr;   // grid of linked lists (global, L2 resident)
+  int32_t* d_next = nullptr;       // ST_CAND_CAP
+  uint8_t* d_state = nullptr;      // ST_CAND_CAP
+  float* d_out = nullptr;          // ST_OUT_CAP x 2
+  float* d_pts = nullptr;          // uploaded cur_pts (non-resident call)
+  int cell_cap = 0;
+  int last_max_corners = 0;
+};
+
+struct disc_rows { int hw[ST_MAX_RADIUS + 1]; };
+
+__device__ __forceinline__ int st_reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * (len - 1) - p;
+  return p;
+}
+
+__global__ void __launch_bounds__(256) k_st_sobel_hsum(const uint8_t* __restrict__ img, int pitch, int W, int H, int r,
+                                                       int32_t* __restrict__ hxx, int32_t* __restrict__ hxy,
+                                                       int32_t* __restrict__ hyy, uint8_t* __restrict__ mask,
+                                                       const uint8_t* __restrict__ user_mask,
+                                                       uint32_t* __restrict__ scalars) {
+  __shared__ int32_t sxx[256 + 2 * 15 + 2], sxy[256 + 2 * 15 + 2], syy[256 + 2 * 15 + 2];
+  const int y = blockIdx.y, x0 = blockIdx.x * 256, t = threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && t < 4) scalars[t] = 0;
+  const int span = 256 + 2 * r;
+  for (int i = t; i < span; i += 256) {
+    const int xs = st_reflect101(x0 - r + i, W);   // box filter reflects the PRODUCT image
+    const uint8_t* p = img + (size_t)(y + VO_PAD) * pitch + (xs + VO_PAD);
+    const int a00 = p[-pitch - 1], a01 = p[-pitch], a02 = p[-pitch + 1];
+    const int a10 = p[-1], a12 = p[1];
+    const int a20 = p[pitch - 1], a21 = p[pitch], a22 = p[pitch + 1];
+    const int dx = (a02 - a00) + 2 * (a12 - a10) + (a22 - a20);
+    const int dy = (a20 - a00) + 2 * (a21 - a01) + (a22 - a02);
+    sxx[i] = dx * dx; sxy[i] = dx * dy; syy[i] = dy * dy;
+  }
+  __syncthreads();
+  const int x = x0 + t;
+  if (x < W) {
+    int32_t a = 0, b = 0, c = 0;
+    for (int i = 0; i <= 2 * r; i++) { a += sxx[t + i]; b += sxy[t + i]; c += syy[t + i]; }
+    const size_t o = (size_t)y * W + x;
+    hxx[o] = a; hxy[o] = b; hyy[o] = c;
+    mask[o] = user_mask ? user_mask[o] : (uint8_t)255;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_st_discs(const float* __restrict__ pts, int n, int radius, disc_rows rows,
+                                                  uint8_t* __restrict__ mask, int W, int H) {
+  const int nrows = 2 * radius + 1;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * nrows) return;
+  const int k = gid / nrows, dy = gid - k * nrows - radius;
+  const int cx = (int)pts[2 * k], cy = (int)pts[2 * k + 1];   // np.int32(): truncation toward zero
+  const int y = cy + dy;
+  if (y < 0 || y >= H) return;
+  const int hw = rows.hw[dy < 0 ? -dy : dy];
+  if (hw < 0) return;
+  int xa = cx - hw, xb = cx + hw;
+  if (xa < 0) xa = 0;
+  if (xb > W - 1) xb = W - 1;
+  for (int x = xa; x <= xb; x++) mask[(size_t)y * W + x] = 0;
+}
+
+#define ST_RG 8   // output rows per thread in the vertical pass
+__global__ void __launch_bounds__(256) k_st_vsum_eig(const int32_t* __restrict__ hxx, const int32_t* __restrict__ hxy,
+                                                     const int32_t* __restrict__ hyy, const uint8_t* __restrict__ mask,
+                                                     int W, int H, int r, float s2, float* __restrict__ eig,
+                                                     uint32_t* __restrict__ scalars) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const int y0 = blockIdx.y * ST_RG;
+  float lmax = 0.f;
+  if (x < W) {
+    int32_t sa = 0, sb = 0, sc = 0;
+    for (int j = -r; j <= r; j++) {
+      const size_t o = (size_t)st_reflect101(y0 + j, H) * W + x;
+      sa += hxx[o]; sb += hxy[o]; sc += hyy[o];
+    }
+    for (int k = 0; k < ST_RG; k++) {
+      const int y = y0 + k;
+      if (y >= H) break;
+      if (k > 0) {
+        const size_t on = (size_t)st_reflect101(y + r, H) * W + x, oo = (size_t)st_reflect101(y - r - 1, H) * W + x;
+        sa += hxx[on] - hxx[oo]; sb += hxy[on] - hxy[oo]; sc += hyy[on] - hyy[oo];
+      }
+      const float a = ((float)sa * s2) * 0.5f, b = (float)sb * s2, c = ((float)sc * s2) * 0.5f;
+      const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+      eig[(size_t)y * W + x] = e;
+      if (mask[(size_t)y * W + x] && e > lmax) lmax = e;
+    }
+  }
+  // wave max, one atomic per wave; positive floats order like their bit patterns
+  for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+  if ((threadIdx.x & 63) == 0 && lmax > 0.f) atomicMax(&scalars[0], __float_as_uint(lmax));
+}
+
+__global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, const uint8_t* __restrict__ mask, int W,
+                                                int H, double quality, unsigned long long* __restrict__ cand,
+                                                uint32_t* __restrict__ scalars) {
+  const int x = blockIdx.x * 256 + threadIdx.x + 1;
+  const int y = blockIdx.y + 1;
+  if (x >= W - 1 || y >= H - 1) return;
+  const float maxv = __uint_as_float(scalars[0]);
+  const float thr = (float)((double)maxv * quality);
+  const size_t o = (size_t)y * W + x;
+  const float v = eig[o];
+  if (!(v > thr) || v == 0.f || !mask[o]) return;
+  const float* e = eig + o;
+  const bool ismax = e[-W - 1] <= v && e[-W] <= v && e[-W + 1] <= v && e[-1] <= v && e[1] <= v &&
+                     e[W - 1] <= v && e[W] <= v && e[W + 1] <= v;
+  if (!ismax) return;
+  const uint32_t pos = atomicAdd(&scalars[1], 1u);
+  if (pos < ST_CAND_CAP) cand[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(uint32_t)o;
+}
+
+__global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __restrict__ cand,
+                                                    uint32_t* __restrict__ scalars, int W, int H, int cell, int gw, int gh,
+                                                    double md2, int use_dist, int max_corners,
+                                                    int32_t* __restrict__ cellhead, int32_t* __restrict__ nxt,
+                                                    volatile uint8_t* __restrict__ state, float* __restrict__ out) {
+  extern __shared__ unsigned long long keys[];   // n2 keys, then scan scratch
+  __shared__ int s_flag;
+  __shared__ int s_scan[1024];
+  const int tid = threadIdx.x;
+  const uint32_t ncand = scalars[1];
+  if (ncand > ST_CAND_CAP) { if (tid == 0) scalars[2] = 0xFFFFFFFFu; return; }   // host reports VO_E_CAPACITY
+  const int n = (int)ncand;
+  int n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  for (int i = tid; i < n2; i += 1024) keys[i] = (i < n) ? cand[i] : 0ull;
+  for (int i = tid; i < gw * gh; i += 1024) cellhead[i] = -1;
+  __syncthreads();
+  // ---- bitonic sort, descending ----
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n2; i += 1024) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long a = keys[i], b = keys[l];
+          const bool desc = ((i & k) == 0);
+          if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  // ---- grid lists (rank = index into keys) ----
+  for (int i = tid; i < n; i += 1024) {
+    const int idx = (int)(uint32_t)keys[i];
+    const int y = idx / W, x = idx - y * W;
+    const int cidx = (y / cell) * gw + (x / cell);
+    state[i] = use_dist ? 0 : 1;
+    if (use_dist) nxt[i] = atomicExch(&cellhead[cidx], i);
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- greedy min-distance selection as monotone parallel rounds ----
+  if (use_dist) {
+    for (int round = 0; round < n + 1; round++) {
+      if (tid == 0) s_flag = 0;
+      __syncthreads();
+      bool undecided = false;
+      for (int i = tid; i < n; i += 1024) {
+        if (state[i] != 0) continue;
+        const int idx = (int)(uint32_t)keys[i];
+        const int y = idx / W, x = idx - y * W;
+        const int xc = x / cell, yc = y / cell;
+        const int x1 = max(xc - 1, 0), y1 = max(yc - 1, 0), x2 = min(xc + 1, gw - 1), y2 = min(yc + 1, gh - 1);
+        bool any_acc = false, any_und = false;
+        for (int yy = y1; yy <= y2; yy++)
+          for (int xx = x1; xx <= x2; xx++)
+            for (int q = cellhead[yy * gw + xx]; q >= 0; q = nxt[q]) {
+              if (q >= i) continue;   // only higher-ranked candidates matter
+              const int qi = (int)(uint32_t)keys[q];
+              const int qy = qi / W, qx = qi - qy * W;
+              const int ddx = x - qx, ddy = y - qy;
+              if ((double)(ddx * ddx + ddy * ddy) < md2) {
+                const uint8_t s = state[q];
+                if (s == 1) any_acc = true;
+                else if (s == 0) any_und = true;
+              }
+            }
+        if (any_acc) state[i] = 2;
+        else if (!any_und) state[i] = 1;
+        else undecided = true;
+      }
+      if (undecided) s_flag = 1;
+      __threadfence_block();
+      __syncthreads();
+      const int f = s_flag;
+      __syncthreads();
+      if (!f) break;
+    }
+  }
+  // ---- ordered compaction of the accepted candidates (rank order), first max_corners ----
+  const int per = (n + 1023) / 1024;
+  const int b0 = tid * per, b1 = min(b0 + per, n);
+  int cnt = 0;
+  for (int i = b0; i < b1; i++) cnt += (state[i] == 1);
+  s_scan[tid] = cnt;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = (tid >= o) ? s_scan[tid - o] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  int pos = s_scan[tid] - cnt;
+  const int total = s_scan[1023];
+  int limit = (max_corners > 0) ? min(max_corners, ST_OUT_CAP) : ST_OUT_CAP;
+  for (int i = b0; i < b1; i++)
+    if (state[i] == 1) {
+      if (pos < limit) {
+        const int idx = (int)(uint32_t)keys[i];
+        const int y = idx / W, x = idx - y * W;
+        out[2 * pos] = (float)x; out[2 * pos + 1] = (float)y;
+      }
+      pos++;
+    }
+  if (tid == 0) scalars[2] = (uint32_t)min(total, limit);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+void vo_st_destroy(vo_ctx* c) {
+  if (!c->st) return;
+  vo_st_ws* s = c->st;
+  void* bufs[] = {s->d_mask, s->d_user_mask, s->d_h, s->d_eig, s->d_scalars, s->d_cand, s->d_cellhead,
+                  s->d_next, s->d_state, s->d_out, s->d_pts};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  delete s;
+  c->st = nullptr;
+}
+
+static int32_t st_init(vo_ctx* c) {
+  if (c->st) return VO_OK;
+  vo_st_ws* s = new vo_st_ws();
+  c->st = s;
+  const size_t np = (size_t)c->width * c->height;
+  VO_HIP(c, hipMalloc((void**)&s->d_mask, np));
+  VO_HIP(c, hipMalloc((void**)&s->d_user_mask, np));
+  VO_HIP(c, hipMalloc((void**)&s->d_h, np * 3 * sizeof(int32_t)));
+  VO_HIP(c, hipMalloc((void**)&s->d_eig, np * sizeof(float)));
+  VO_HIP(c, hipMalloc((void**)&s->d_scalars, 16 * sizeof(uint32_t)));
+  VO_HIP(c, hipMalloc((void**)&s->d_cand, sizeof(unsigned long long) * ST_CAND_CAP));
+  s->cell_cap = (int)np;   // cell >= 1 px
+  VO_HIP(c, hipMalloc((void**)&s->d_cellhead, sizeof(int32_t) * (size_t)s->cell_cap));
+  VO_HIP(c, hipMalloc((void**)&s->d_next, sizeof(int32_t) * ST_CAND_CAP));
+  VO_HIP(c, hipMalloc((void**)&s->d_state, ST_CAND_CAP));
+  VO_HIP(c, hipMalloc((void**)&s->d_out, sizeof(float) * 2 * ST_OUT_CAP));
+  VO_HIP(c, hipMalloc((void**)&s->d_pts, sizeof(float) * 2 * (size_t)c->max_pts));
+  VO_HIP(c, hipMemsetAsync(s->d_scalars, 0, 16 * sizeof(uint32_t), c->stream));
+  VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_st_select), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(unsigned long long) * ST_CAND_CAP)));
+  return VO_OK;
+}
+
+// filled-circle row table: the integer midpoint loop of imgproc/drawing.cpp Circle()
+static void circle_rows(int radius, disc_rows* rows) {
+  for (int i = 0; i <= ST_MAX_RADIUS; i++) rows->hw[i] = -1;
+  int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+  while (dx >= dy) {
+    if (dx > rows->hw[dy]) rows->hw[dy] = dx;
+    if (dy > rows->hw[dx]) rows->hw[dx] = dy;
+    dy++;
+    err += plus;
+    plus += 2;
+    const int mask = (err <= 0) - 1;
+    err -= minus & mask;
+    dx += mask;
+    minus -= mask & 2;
+  }
+}
+
+extern "C" int32_t vo_st_default_params(vo_st_params* p) {
+  if (!p) return VO_E_INVALID;
+  p->max_corners = 1000; p->block_size = 31; p->quality_level = 0.03; p->min_distance = 7.0;
+  return VO_OK;
+}
+
+static int32_t st_launch(vo_ctx* c, const float* d_pts, int n_cur, int mask_radius, const uint8_t* d_user_mask,
+                         const vo_st_params* prm) {
+  VO_CHECK(c, c->n_pushed >= 1, VO_E_STATE, "no frame pushed");
+  VO_CHECK(c, prm->block_size >= 1 && prm->block_size <= 31 && (prm->block_size & 1), VO_E_INVALID,
+           "block_size must be odd, <= 31");
+  VO_CHECK(c, mask_radius >= 0 && mask_radius <= ST_MAX_RADIUS, VO_E_INVALID, "mask_radius must be 0..31");
+  VO_CHECK(c, prm->max_corners <= ST_OUT_CAP, VO_E_CAPACITY, "max_corners exceeds 4096");
+  vo_st_ws* s = c->st;
+  const int W = c->width, H = c->height, r = prm->block_size / 2;
+  const size_t np = (size_t)W * H;
+  const vo_frame& F = c->fr[c->cur];
+  int32_t* hxx = s->d_h; int32_t* hxy = s->d_h + np; int32_t* hyy = s->d_h + 2 * np;
+  hipLaunchKernelGGL(k_st_sobel_hsum, dim3(vo_div_up(W, 256), H), dim3(256), 0, c->stream, F.img[0], c->lv[0].pitch, W, H,
+                     r, hxx, hxy, hyy, s->d_mask, d_user_mask, s->d_scalars);
+  if (n_cur > 0) {
+    disc_rows rows;
+    circle_rows(mask_radius, &rows);
+    const int total = n_cur * (2 * mask_radius + 1);
+    hipLaunchKernelGGL(k_st_discs, dim3(vo_div_up(total, 256)), dim3(256), 0, c->stream, d_pts, n_cur, mask_radius, rows,
+                       s->d_mask, W, H);
+  }
+  const double scale_d = 1.0 / ((double)(1 << 2) * prm->block_size * 255.0);
+  const float sf = (float)scale_d;
+  const float s2 = sf * sf;
+  hipLaunchKernelGGL(k_st_vsum_eig, dim3(vo_div_up(W, 256), vo_div_up(H, ST_RG)), dim3(256), 0, c->stream, hxx, hxy, hyy,
+                     s->d_mask, W, H, r, s2, s->d_eig, s->d_scalars);
+  hipLaunchKernelGGL(k_st_nms, dim3(vo_div_up(W - 2, 256), H - 2), dim3(256), 0, c->stream, s->d_eig, s->d_mask, W, H,
+                     prm->quality_level, s->d_cand, s->d_scalars);
+  const int use_dist = prm->min_distance >= 1.0 ? 1 : 0;
+  int cell = use_dist ? (int)lrint(prm->min_distance) : 1;
+  if (cell < 1) cell = 1;
+  const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
+  const double md2 = prm->min_distance * prm->min_distance;
+  hipLaunchKernelGGL(k_st_select, dim3(1), dim3(1024), sizeof(unsigned long long) * ST_CAND_CAP, c->stream, s->d_cand,
+                     s->d_scalars, W, H, cell, gw, gh, md2, use_dist, prm->max_corners, s->d_cellhead, s->d_next,
+                     s->d_state, s->d_out);
+  VO_HIP(c, hipGetLastError());
+  s->last_max_corners = prm->max_corners;
+  return VO_OK;
+}
+
+static int32_t st_fetch(vo_ctx* c, float* out_pts, int32_t* n_out) {
+  vo_st_ws* s = c->st;
+  uint32_t sc[4];
+  VO_HIP(c, hipMemcpyAsync(sc, s->d_scalars, sizeof(sc), hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  if (sc[2] == 0xFFFFFFFFu) {
+    *n_out = 0;
+    return vo_fail(c, VO_E_CAPACITY, "shi_tomasi: more than 16384 NMS candidates");
+  }
+  *n_out = (int32_t)sc[2];
+  if (*n_out > 0) {
+    VO_HIP(c, hipMemcpy(out_pts, s->d_out, sizeof(float) * 2 * (size_t)(*n_out), hipMemcpyDeviceToHost));
+  }
+  return VO_OK;
+}
+
+extern "C" int32_t vo_shi_tomasi(vo_ctx* c, const float* cur_pts, int32_t n_cur, int32_t mask_radius, const uint8_t* mask,
+                                 const vo_st_params* prm, float* out_pts, int32_t* n_out) {
+  if (!c) return VO_E_INVALID;
+  vo_st_params def;
+  if (!prm) { vo_st_default_params(&def); prm = &def; }
+  VO_CHECK(c, out_pts && n_out, VO_E_INVALID, "null output");
+  VO_CHECK(c, n_cur >= 0 && n_cur <= c->max_pts && (n_cur == 0 || cur_pts), VO_E_CAPACITY, "bad cur_pts");
+  VO_HIP(c, hipSetDevice(c->device));
+  int32_t r = st_init(c);
+  if (r != VO_OK) return r;
+  vo_st_ws* s = c->st;
+  if (n_cur > 0) VO_HIP(c, hipMemcpyAsync(s->d_pts, cur_pts, sizeof(float) * 2 * n_cur, hipMemcpyHostToDevice, c->stream));
+  if (mask) VO_HIP(c, hipMemcpyAsync(s->d_user_mask, mask, (size_t)c->width * c->height, hipMemcpyHostToDevice, c->stream));
+  r = st_launch(c, s->d_pts, n_cur, mask_radius, mask ? s->d_user_mask : nullptr, prm);
+  if (r != VO_OK) return r;
+  return st_fetch(c, out_pts, n_out);
+}
+
+extern "C" int32_t vo_shi_tomasi_resident(vo_ctx* c, int32_t n_cur, int32_t mask_radius, const vo_st_params* prm) {
+  if (!c) return VO_E_INVALID;
+  vo_st_params def;
+  if (!prm) { vo_st_default_params(&def); prm = &def; }
+  VO_CHECK(c, n_cur >= 0 && n_cur <= c->n_resident, VO_E_INVALID, "n_cur exceeds the resident point set");
+  VO_HIP(c, hipSetDevice(c->device));
+  int32_t r = st_init(c);
+  if (r != VO_OK) return r;
+  return st_launch(c, c->d_p0, n_cur, mask_radius, nullptr, prm);
+}
+
+extern "C" int32_t vo_shi_tomasi_fetch(vo_ctx* c, float* out_pts, int32_t* n_out) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->st && out_pts && n_out, VO_E_STATE, "no shi_tomasi call to fetch");
+  VO_HIP(c, hipSetDevice(c->device));
+  return st_fetch(c, out_pts, n_out);
+}
+
+extern "C" int32_t vo_shi_tomasi_read(vo_ctx* c, float* eig_out, uint8_t* mask_out, int32_t* n_candidates) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->st, VO_E_STATE, "no shi_tomasi call yet");
+  VO_HIP(c, hipSetDevice(c->device));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  const size_t np = (size_t)c->width * c->height;
+  if (eig_out) VO_HIP(c, hipMemcpy(eig_out, c->st->d_eig, np * sizeof(float), hipMemcpyDeviceToHost));
+  if (mask_out) VO_HIP(c, hipMemcpy(mask_out, c->st->d_mask, np, hipMemcpyDeviceToHost));
+  if (n_candidates) {
+    uint32_t sc[4];
+    VO_HIP(c, hipMemcpy(sc, c->st->d_scalars, sizeof(sc), hipMemcpyDeviceToHost));
+    *n_candidates = (int32_t)sc[1];
+  }
+  return VO_OK;
+}

@@ -1,0 +1,115 @@
+"""ctypes binding of libvo_mi355x.so (C ABI declared in include/vo_mi355x.h).
+
+The library is the product: hand-written HIP kernels for gfx950.  There is no
+CPU fallback -- if the shared object is missing or no HIP device is present the
+calls raise.  Nothing in this package imports anything from `oracle/`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libvo_mi355x.so")
+CSRC_DIR = os.path.join(PKG_ROOT, "csrc")
+
+VO_OK = 0
+ERRORS = {-1: "VO_E_INVALID", -2: "VO_E_HIP", -3: "VO_E_NOMEM", -4: "VO_E_STATE", -5: "VO_E_CAPACITY",
+          -6: "VO_E_NUMERIC"}
+
+
+class VoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "VO_E_?"), code, msg))
+        self.code = code
+
+
+class KltParams(C.Structure):
+    _fields_ = [("win", C.c_int32), ("max_level", C.c_int32), ("max_count", C.c_int32),
+                ("epsilon", C.c_double), ("min_eig_threshold", C.c_float), ("_pad", C.c_int32)]
+
+
+class StParams(C.Structure):
+    _fields_ = [("max_corners", C.c_int32), ("block_size", C.c_int32), ("quality_level", C.c_double),
+                ("min_distance", C.c_double)]
+
+
+class BaParams(C.Structure):
+    _fields_ = [("max_iters", C.c_int32), ("_pad", C.c_int32), ("ftol", C.c_double), ("xtol", C.c_double),
+                ("gtol", C.c_double), ("lambda0", C.c_double), ("huber_delta", C.c_double)]
+
+
+class BaStats(C.Structure):
+    _fields_ = [("cost0", C.c_double), ("cost", C.c_double), ("lam", C.c_double), ("iters", C.c_int32),
+                ("accepted", C.c_int32), ("status", C.c_int32), ("n_obs", C.c_int32)]
+
+
+_u8p, _i16p, _i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.POINTER(C.c_int32)
+_f32p, _f64p = C.POINTER(C.c_float), C.POINTER(C.c_double)
+_ctx = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/vo_mi355x.h declares
+SIGNATURES = {
+    "vo_abi_version": (C.c_int32, []),
+    "vo_device_count": (C.c_int32, [_i32p]),
+    "vo_ctx_create": (C.c_int32, [C.c_int32] * 6 + [C.POINTER(_ctx)]),
+    "vo_ctx_destroy": (C.c_int32, [_ctx]),
+    "vo_last_error": (C.c_char_p, [_ctx]),
+    "vo_sync": (C.c_int32, [_ctx]),
+    "vo_frame_push": (C.c_int32, [_ctx, _u8p, C.c_int32]),
+    "vo_seq_upload": (C.c_int32, [_ctx, _u8p, C.c_int32]),
+    "vo_frame_push_resident": (C.c_int32, [_ctx, C.c_int32]),
+    "vo_pyramid_level_size": (C.c_int32, [_ctx, C.c_int32, _i32p, _i32p]),
+    "vo_pyramid_read": (C.c_int32, [_ctx, C.c_int32, C.c_int32, _u8p, _i16p]),
+    "vo_klt_default_params": (C.c_int32, [C.POINTER(KltParams)]),
+    "vo_klt_track": (C.c_int32, [_ctx, _f32p, C.c_int32, C.POINTER(KltParams), _f32p, _u8p, _f32p, _i32p]),
+    "vo_points_upload": (C.c_int32, [_ctx, _f32p, C.c_int32]),
+    "vo_points_download": (C.c_int32, [_ctx, _f32p, _u8p, _f32p, C.c_int32]),
+    "vo_klt_track_resident": (C.c_int32, [_ctx, C.c_int32, C.POINTER(KltParams)]),
+    "vo_st_default_params": (C.c_int32, [C.POINTER(StParams)]),
+    "vo_shi_tomasi": (C.c_int32, [_ctx, _f32p, C.c_int32, C.c_int32, _u8p, C.POINTER(StParams), _f32p, _i32p]),
+    "vo_shi_tomasi_resident": (C.c_int32, [_ctx, C.c_int32, C.c_int32, C.POINTER(StParams)]),
+    "vo_shi_tomasi_fetch": (C.c_int32, [_ctx, _f32p, _i32p]),
+    "vo_shi_tomasi_read": (C.c_int32, [_ctx, _f32p, _u8p, _i32p]),
+    "vo_triangulate_dlt": (C.c_int32, [_ctx, _f32p, _f32p, _f32p, _f32p, C.c_int32, _f32p, _f64p, _f64p, _f64p,
+                                       _f64p, _f64p]),
+    "vo_ba_default_params": (C.c_int32, [C.POINTER(BaParams)]),
+    "vo_ba_adjust": (C.c_int32, [_ctx, _f64p, _f64p, _f64p, _f64p, C.c_int32, C.c_int32, C.POINTER(BaParams),
+                                 _f64p, _f64p, C.POINTER(BaStats)]),
+    "vo_ba_upload": (C.c_int32, [_ctx, _f64p, _f64p, _f64p, _f64p, C.c_int32, C.c_int32]),
+    "vo_ba_solve_resident": (C.c_int32, [_ctx, C.POINTER(BaParams)]),
+    "vo_ba_fetch": (C.c_int32, [_ctx, _f64p, _f64p, C.POINTER(BaStats)]),
+    "vo_ba_probe": (C.c_int32, [_ctx, C.c_double, C.c_double, _f64p, _i32p, _f64p, _f64p, _f64p, _f64p, _f64p,
+                                _f64p, _f64p, _f64p, _f64p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built -- run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VoError(-2, "libvo_mi355x.so not built (%s); run `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` -- there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        missing = [n for n in SIGNATURES if not hasattr(L, n)]
+        if missing:
+            raise VoError(-2, "libvo_mi355x.so lacks symbols %s -- stale build?" % missing)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def ptr(a, t):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def as_c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)

@@ -1,0 +1,163 @@
+"""Synthetic inputs for tests and bench.py.
+
+There are no datasets in the image and no network, so every measurement runs on
+seeded synthetic data of the BASELINE shapes:
+
+* images: band-limited noise texture warped by a known similarity motion per
+  frame (gives KLT an analytic ground truth),
+* BA scene: KITTI-like camera, forward motion, noisy observations.
+"""
+import numpy as np
+
+KITTI_K = np.array([[718.856, 0.0, 607.1928], [0.0, 718.856, 185.2157], [0.0, 0.0, 1.0]])
+
+
+def _gauss_kernel(sigma):
+    r = int(np.ceil(3 * sigma))
+    x = np.arange(-r, r + 1, dtype=np.float64)
+    k = np.exp(-0.5 * (x / sigma) ** 2)
+    return (k / k.sum()).astype(np.float32)
+
+
+def _blur(img, sigma):
+    k = _gauss_kernel(sigma)
+    r = len(k) // 2
+    p = np.pad(img, ((0, 0), (r, r)), mode="reflect")
+    out = np.zeros_like(img)
+    for i, kv in enumerate(k):
+        out += kv * p[:, i:i + img.shape[1]]
+    p = np.pad(out, ((r, r), (0, 0)), mode="reflect")
+    out2 = np.zeros_like(img)
+    for i, kv in enumerate(k):
+        out2 += kv * p[i:i + img.shape[0], :]
+    return out2
+
+
+def make_texture(h, w, seed=1234):
+    """float32 texture, mean 128 / std 40, two octaves (sigma 2 px + 0.5 * sigma 6 px)."""
+    rng = np.random.default_rng(seed)
+    n = rng.standard_normal((h, w)).astype(np.float32)
+    a = _blur(n, 2.0)
+    b = _blur(n, 6.0)
+    t = a / a.std() + 0.5 * b / b.std()
+    t = (t - t.mean()) / t.std()
+    return (128.0 + 40.0 * t).astype(np.float32)
+
+
+def frame_motion(t, w, h):
+    """2x3 affine A_t mapping frame-0 pixel coordinates to frame-t coordinates:
+    translation (2.0 t, 0.7 t) px, rotation 0.002 t rad about the image centre,
+    scale 1 + 0.003 t."""
+    c = np.array([(w - 1) * 0.5, (h - 1) * 0.5])
+    ang, s = 0.002 * t, 1.0 + 0.003 * t
+    R = s * np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+    tr = np.array([2.0 * t, 0.7 * t])
+    A = np.zeros((2, 3))
+    A[:, :2] = R
+    A[:, 2] = c - R @ c + tr
+    return A
+
+
+def warp_points(A, pts):
+    pts = np.asarray(pts, np.float64).reshape(-1, 2)
+    return pts @ A[:, :2].T + A[:, 2]
+
+
+def render_frame(tex, A, w, h, margin):
+    """Sample the (larger) texture at the inverse-warped pixel grid, bilinear.
+    tex covers frame-0 coordinates [-margin, w+margin) x [-margin, h+margin)."""
+    Ainv = np.linalg.inv(np.vstack([A, [0, 0, 1]]))[:2]
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    sx = Ainv[0, 0] * xs + Ainv[0, 1] * ys + Ainv[0, 2] + margin
+    sy = Ainv[1, 0] * xs + Ainv[1, 1] * ys + Ainv[1, 2] + margin
+    x0 = np.floor(sx).astype(np.int64)
+    y0 = np.floor(sy).astype(np.int64)
+    fx = (sx - x0).astype(np.float32)
+    fy = (sy - y0).astype(np.float32)
+    x0 = np.clip(x0, 0, tex.shape[1] - 2)
+    y0 = np.clip(y0, 0, tex.shape[0] - 2)
+    v = (tex[y0, x0] * (1 - fx) * (1 - fy) + tex[y0, x0 + 1] * fx * (1 - fy) +
+         tex[y0 + 1, x0] * (1 - fx) * fy + tex[y0 + 1, x0 + 1] * fx * fy)
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+
+def make_sequence(n_frames, w=1241, h=376, seed=1234, margin=96):
+    """-> (frames uint8 [n, h, w], motions [n, 2, 3])"""
+    tex = make_texture(h + 2 * margin, w + 2 * margin, seed)
+    frames = np.empty((n_frames, h, w), np.uint8)
+    motions = np.empty((n_frames, 2, 3))
+    for t in range(n_frames):
+        A = frame_motion(t, w, h)
+        motions[t] = A
+        frames[t] = render_frame(tex, A, w, h, margin)
+    return frames, motions
+
+
+def grid_points(n, w, h, margin=24, seed=7):
+    """n jittered-grid keypoints, float32 (n, 2), >= margin px from the border."""
+    rng = np.random.default_rng(seed)
+    aspect = (w - 2 * margin) / (h - 2 * margin)
+    ny = max(1, int(np.sqrt(n / aspect)))
+    nx = int(np.ceil(n / ny))
+    xs = np.linspace(margin, w - 1 - margin, nx)
+    ys = np.linspace(margin, h - 1 - margin, ny)
+    g = np.stack(np.meshgrid(xs, ys), -1).reshape(-1, 2)[:n]
+    g = g + rng.uniform(-2.0, 2.0, g.shape)
+    return g.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------
+# BA scene
+# ----------------------------------------------------------------------------
+def rodrigues(r):
+    r = np.asarray(r, np.float64).reshape(3)
+    th = np.linalg.norm(r)
+    if th < np.finfo(np.float64).eps:
+        return np.eye(3)
+    k = r / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * Kx
+
+
+def make_ba_scene(n_pts=2000, n_slots=10, K=KITTI_K, seed=0, obs_noise=0.3, pt_noise=0.3,
+                  pose_noise=0.02, visibility=1.0, width=1241, height=376):
+    """Sliding-window BA problem in the layout the C-ABI takes.
+
+    Slot 0 is the NEWEST frame (the reference packs poses newest-first,
+    /root/reference/src/bundle_adjuster/bundle_adjuster.py:169-176).
+    Returns dict(K, poses0 [W,6] (rvec,tvec), points0 [N,3], obs [W,N,2] (NaN =
+    not observed), poses_gt, points_gt)."""
+    rng = np.random.default_rng(seed)
+    W, N = n_slots, n_pts
+    pts = np.stack([rng.uniform(-15, 15, N), rng.uniform(-3, 3, N), rng.uniform(12, 60, N)], 1)
+    poses_gt = np.zeros((W, 6))
+    for i in range(W):
+        f = W - 1 - i  # frame index in time; slot 0 = newest
+        yaw = 0.01 * f
+        Rwc = rodrigues([0, yaw, 0])  # camera orientation in world
+        cam_c = np.array([0.0, 0.0, 0.8 * f])
+        R = Rwc.T  # world -> camera
+        t = -R @ cam_c
+        # rvec of R
+        th = np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))
+        if th < 1e-12:
+            rv = np.zeros(3)
+        else:
+            rv = th / (2 * np.sin(th)) * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+        poses_gt[i, :3], poses_gt[i, 3:] = rv, t
+    obs = np.full((W, N, 2), np.nan)
+    for i in range(W):
+        R = rodrigues(poses_gt[i, :3])
+        Xc = pts @ R.T + poses_gt[i, 3:]
+        p = Xc @ K.T
+        uv = p[:, :2] / p[:, 2:3]
+        uv += rng.normal(0, obs_noise, uv.shape)
+        vis = Xc[:, 2] > 0.5
+        if visibility < 1.0:
+            vis &= rng.uniform(size=N) < visibility
+        obs[i, vis] = uv[vis]
+    points0 = pts + rng.normal(0, pt_noise, pts.shape)
+    poses0 = poses_gt.copy()
+    poses0[:-2, 3:] += rng.normal(0, pose_noise, (W - 2, 3)) if W > 2 else 0.0
+    return dict(K=np.array(K, np.float64), poses0=poses0, points0=points0, obs=obs,
+                poses_gt=poses_gt, points_gt=pts)
