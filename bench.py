@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the VO inner loop on MI355X (BASELINE.json metric).
+
+Workload (config.workload = "kitti_shaped_1241x376_2000pts_ba10", BASELINE.json configs[2], the configuration the
+metric string names): per frame and per sequence
+    pyramid + Scharr of the new frame -> KLT of 2000 keypoints (31x31, 4 levels, <= 30 its, eps 0.03)
+    -> DLT of 1000 new tracks (+ filter statistics) -> sliding-window BA (N = 2000 landmarks, W = 10 poses,
+    Huber, LM with ftol = xtol = 1e-3, at most --ba-iters iterations) -> Shi-Tomasi re-detection (<= 1000 corners,
+    2000 exclusion discs).
+One "step" = one such frame for each of the --seqs independent sequences a GPU carries (sequences are the unit
+that shards: frames of ONE sequence are sequential).  All inputs (frames, keypoints, BA problem) are resident in HBM
+before the timed region; per step only the results come back (points, corners, landmarks, poses).
+Multi-GPU: one process per GPU (torch.distributed launch contract), independent sequences per rank, no data-path
+collective -> "scaling": "weak".  torch.distributed (gloo) is used ONLY for the barrier / max-over-ranks timing.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "visual-odom-pipeline_amd"))
+
+import numpy as np  # noqa: E402
+
+W_IMG, H_IMG, N_PTS, N_NEW, BA_N, BA_W = 1241, 376, 2000, 1000, 2000, 10
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--seqs", type=int, default=4, help="independent sequences per GPU (one ctx + stream each)")
+    ap.add_argument("--ba-iters", type=int, default=10, help="LM iteration budget per adjust")
+    ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames per sequence (played ping-pong)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    return ap.parse_args()
+
+
+class Dist:
+    """barrier + max over ranks; torch.distributed(gloo) only when launched with WORLD_SIZE > 1"""
+
+    def __init__(self):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.td = None
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            import torch
+            import torch.distributed as td
+            td.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+            self.td, self.torch = td, torch
+
+    def barrier(self):
+        if self.td:
+            self.td.barrier()
+
+    def max(self, v):
+        if not self.td:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64)
+        self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
+        return float(t[0])
+
+    def sum(self, v):
+        if not self.td:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64)
+        self.td.all_reduce(t, op=self.td.ReduceOp.SUM)
+        return float(t[0])
+
+    def close(self):
+        if self.td:
+            self.td.destroy_process_group()
+
+
+def pingpong(t, n):
+    """frame index of step t for a sequence of n frames played 0..n-1..0.."""
+    period = 2 * (n - 1)
+    k = t % period
+    return k if k < n else period - k
+
+
+class Sequence:
+    """One VO sequence = one ctx (one HIP stream) with everything resident."""
+
+    def __init__(self, device, frames, seed, ba_iters):
+        from vo_mi355x import VoContext, synthetic as syn
+        self.c = VoContext(W_IMG, H_IMG, max_pts=max(N_PTS, N_NEW), device=device)
+        c = self.c
+        c.upload_sequence(frames)
+        self.nf = frames.shape[0]
+        c.points_upload(syn.grid_points(N_PTS, W_IMG, H_IMG, seed=seed))
+        # DLT: 1000 new tracks between two window poses of the BA scene
+        s = syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=seed)
+        K = s["K"]
+        H0, H1 = np.eye(4), np.eye(4)
+        H0[:3, :3], H0[:3, 3] = syn.rodrigues(s["poses_gt"][3, :3]), s["poses_gt"][3, 3:]
+        H1[:3, :3], H1[:3, 3] = syn.rodrigues(s["poses_gt"][0, :3]), s["poses_gt"][0, 3:]
+        self.dlt_in = ((K @ H0[:3]).astype(np.float32), (K @ H1[:3]).astype(np.float32),
+                       s["obs"][3, :N_NEW].astype(np.float32), s["obs"][0, :N_NEW].astype(np.float32), K, H0, H1)
+        c.dlt_upload(*self.dlt_in)
+        self.scene = s
+        c.ba_upload(K, s["poses0"], s["points0"], s["obs"])
+        self.ba_prm = c.ba_params(max_iters=ba_iters, ftol=1e-3, xtol=1e-3)
+        self.klt_prm = c.klt_params()
+        self.st_prm = c.st_params()
+        self.t = 0
+        c.push_frame_resident(0)
+        self.t = 1
+
+    def enqueue(self):
+        c = self.c
+        c.push_frame_resident(pingpong(self.t, self.nf))
+        c.klt_track_resident(N_PTS, self.klt_prm)
+        c.dlt_resident()
+        c.ba_solve_resident(self.ba_prm)
+        c.shi_tomasi_resident(N_PTS, 7, self.st_prm)
+        self.t += 1
+
+    def fetch(self):
+        c = self.c
+        self.last = (c.points_download(N_PTS), c.dlt_fetch(), c.ba_fetch(), c.shi_tomasi_fetch())
+        return self.last
+
+
+def cpu_baseline(frames, n_frames, ba_iters):
+    """The CPU oracle (the build's restatement of the reference's OpenCV / SciPy-side arithmetic) on the same
+    workload, one host thread, a bounded sample of frames.  Reported, not the target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ba_oracle as bo
+    import vo_oracle as o
+    from vo_mi355x import synthetic as syn
+    p = syn.grid_points(N_PTS, W_IMG, H_IMG, seed=7)
+    s = syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=0)
+    K = s["K"]
+    P0 = (K @ np.hstack([syn.rodrigues(s["poses_gt"][3, :3]), s["poses_gt"][3, 3:, None]])).astype(np.float32)
+    P1 = (K @ np.hstack([syn.rodrigues(s["poses_gt"][0, :3]), s["poses_gt"][0, 3:, None]])).astype(np.float32)
+    t0 = time.perf_counter()
+    for t in range(n_frames):
+        a, b = frames[pingpong(t, len(frames))], frames[pingpong(t + 1, len(frames))]
+        p1, st, err = o.klt(a, b, p)                                   # builds both pyramids, like one cv2 call
+        o.triangulate(P0, P1, s["obs"][3, :N_NEW], s["obs"][0, :N_NEW])
+        bo.solve(K, s["poses0"], s["points0"], s["obs"], max_iters=ba_iters, ftol=1e-3, xtol=1e-3)
+        mask = np.full((H_IMG, W_IMG), 255, np.uint8)
+        for x, y in np.int32(p1):
+            o.circle_mask(mask, (x, y), 7, 0)
+        o.good_features(b, mask)
+        p = p1
+    dt = time.perf_counter() - t0
+    return n_frames / dt, dt
+
+
+def main():
+    a = parse()
+    dist = Dist()
+    from vo_mi355x import synthetic as syn
+    t_gen = time.perf_counter()
+    frames, _ = syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + dist.rank)
+    seqs = [Sequence(dist.local_rank, frames, seed=100 * dist.rank + i, ba_iters=a.ba_iters) for i in range(a.seqs)]
+    t_setup = time.perf_counter() - t_gen
+
+    def step():
+        for s in seqs:
+            s.enqueue()
+        for s in seqs:
+            s.fetch()
+
+    for _ in range(a.warmup):
+        step()
+    # ---- timed region: exactly K steps; KLT kernel bracketed by hipEvents on its own stream ----
+    for s in seqs:
+        s.c.profile_enable((s.c.PROF_KLT,))
+        s.c.sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    for s in seqs:
+        s.c.sync()
+    dist.barrier()
+    dt = dist.max(time.perf_counter() - t0)
+    klt_ms, klt_n = 0.0, 0
+    for s in seqs:
+        ms, n = s.c.profile_read(s.c.PROF_KLT)
+        klt_ms += ms
+        klt_n += n
+        s.c.profile_enable(())
+    frames_total = dist.sum(float(a.steps * a.seqs))
+    fps = frames_total / dt
+
+    out = None
+    if dist.rank == 0:
+        # ---- untimed extras on rank 0: stage breakdown, iteration counts, parity spot check inputs ----
+        s0 = seqs[0]
+        s0.c.profile_enable((0, 1, 2, 3, 4))
+        reps = 20
+        for _ in range(reps):
+            s0.enqueue()
+            s0.fetch()
+        stage = {}
+        for name, r in (("pyramid_scharr", 0), ("klt", 1), ("shi_tomasi", 2), ("dlt", 3), ("ba", 4)):
+            ms, n = s0.c.profile_read(r)
+            stage[name] = round(ms / max(n, 1), 4)
+        s0.c.profile_enable(())
+        pts, st_, err_, it = s0.c.points_download(N_PTS, return_iters=True)
+        it_mean = [float(np.maximum(it[:, l], 0).mean()) for l in range(it.shape[1])]
+        ba_stats = s0.last[2][2]
+        # ALGORITHMIC bytes of one KLT launch: N * sum_l (5120 + 1024 * it_l)
+        klt_bytes = N_PTS * sum(5120.0 + 1024.0 * x for x in it_mean)
+        klt_avg_s = (klt_ms / max(klt_n, 1)) * 1e-3
+        achieved = klt_bytes / klt_avg_s / 1e9 if klt_avg_s > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": "k_klt_track", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "avg_launch_us": round(klt_avg_s * 1e6, 3), "algorithmic_bytes_per_launch": int(klt_bytes),
+                "klt_mean_iters_per_level": [round(x, 3) for x in it_mean]}
+        cpu = None
+        if not a.no_cpu_baseline:
+            v, secs = cpu_baseline(frames, a.cpu_frames, a.ba_iters)
+            cpu = {"value": round(v, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": "%d frames of the same workload on the CPU oracle (C: pyramid+KLT+Shi-Tomasi+DLT, numpy: BA), "
+                             "%.1f s, host has %d cores" % (a.cpu_frames, secs, os.cpu_count() or 0)}
+        out = {"metric": "frames/sec @1241x376, 2000 KLT pts, 10-frame BA window", "value": round(fps, 2),
+               "unit": "frames/s", "n_gpus": dist.world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "u8/i32 (KLT, Shi-Tomasi) + f64 (DLT, BA)", "data": "synthetic",
+               "config": {"workload": "kitti_shaped_1241x376_2000pts_ba10", "width": W_IMG, "height": H_IMG,
+                          "klt_points": N_PTS, "klt_win": 31, "klt_levels": 4, "dlt_points": N_NEW,
+                          "ba_landmarks": BA_N, "ba_window": BA_W, "ba_observations": BA_N * BA_W,
+                          "ba_lm_iteration_budget": a.ba_iters, "ba_lm_iterations_run": ba_stats["iters"],
+                          "ba_final_cost": round(ba_stats["cost"], 4), "ba_initial_cost": round(ba_stats["cost0"], 2),
+                          "sequences_per_gpu": a.seqs, "frames_per_step": a.seqs * dist.world,
+                          "parallelism": "independent sequences, %d per GPU x %d GPU(s), no collective" % (a.seqs, dist.world)},
+               "stage_ms_single_sequence": stage, "roofline": roof, "cpu_baseline": cpu,
+               "setup_s": round(t_setup, 2)}
+    dist.barrier()
+    for s in seqs:
+        s.c.close()
+    dist.close()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -117,7 +117,8 @@ int32_t vo_klt_track(vo_ctx* ctx, const float* p0, int32_t n, const vo_klt_param
                      float* p1, uint8_t* status, float* err, int32_t* iters);
 /* resident form: the point set lives in HBM and is advanced in place (p <- tracked p) */
 int32_t vo_points_upload(vo_ctx* ctx, const float* p, int32_t n);
-int32_t vo_points_download(vo_ctx* ctx, float* p, uint8_t* status, float* err, int32_t n);
+/* iters (may be NULL): n x (max_level+1) of the last resident track, as in vo_klt_track */
+int32_t vo_points_download(vo_ctx* ctx, float* p, uint8_t* status, float* err, int32_t* iters, int32_t n);
 int32_t vo_klt_track_resident(vo_ctx* ctx, int32_t n, const vo_klt_params* prm);  /* async */
 
 /* ---- Shi-Tomasi re-detection ----------------------------------------------------------------
@@ -148,6 +149,12 @@ int32_t vo_triangulate_dlt(vo_ctx* ctx, const float* P0, const float* P1, const 
                            const double* K, const double* H0, const double* H1,
                            double* depth1, double* reproj);
 
+/* resident form for the bench (inputs uploaded once, kernel enqueued per frame, results fetched at the frame's end) */
+int32_t vo_dlt_upload(vo_ctx* ctx, const float* P0, const float* P1, const float* uv0, const float* uv1,
+                      int32_t n, const double* K, const double* H0, const double* H1);
+int32_t vo_dlt_resident(vo_ctx* ctx);                                          /* async */
+int32_t vo_dlt_fetch(vo_ctx* ctx, float* X4, double* depth1, double* reproj);
+
 /* ---- sliding-window bundle adjustment -------------------------------------------------------
  * Replaces the scipy.optimize.least_squares call in BundleAdjuster.adjust
  * (src/bundle_adjuster/bundle_adjuster.py:189-194) and its objective (:18-65).
@@ -176,6 +183,14 @@ int32_t vo_ba_fetch(vo_ctx* ctx, double* poses_out, double* points_out, vo_ba_st
 int32_t vo_ba_probe(vo_ctx* ctx, double lambda, double huber_delta, double* residual, int32_t* n_obs,
                     double* cost, double* Hpp, double* gp, double* Hll, double* gl, double* S,
                     double* rhs, double* dposes, double* dpoints);
+
+/* ---- in-stream timing (hipEvent pairs recorded on the ctx stream around a region's launches) -----
+ * Used by bench.py for the roofline figure: region VO_PROF_KLT brackets exactly the k_klt_track launch.
+ * vo_profile_read synchronises the stream and returns the summed elapsed time and the number of
+ * recorded regions since vo_profile_enable(ctx, mask); mask = OR of (1 << region), 0 = off. */
+enum { VO_PROF_FRAME = 0, VO_PROF_KLT = 1, VO_PROF_ST = 2, VO_PROF_DLT = 3, VO_PROF_BA = 4, VO_PROF_COUNT = 5 };
+int32_t vo_profile_enable(vo_ctx* ctx, int32_t region_mask);
+int32_t vo_profile_read(vo_ctx* ctx, int32_t region, double* total_ms, int32_t* count);
 
 #ifdef __cplusplus
 }

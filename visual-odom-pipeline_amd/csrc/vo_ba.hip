@@ -728,6 +728,7 @@ extern "C" int32_t vo_ba_upload(vo_ctx* c, const double* K, const double* poses,
 // enqueue `n_it` LM iterations starting at iteration index `it0` (state must be in place)
 static int32_t ba_enqueue_iters(vo_ctx* c, const ba_params_dev& prm, int it0, int n_it) {
   vo_ba_ws* b = c->ba;
+  vo_prof_scope prof(c, VO_PROF_BA);
   const ba_ptrs P = ba_make_ptrs(b);
   const size_t lds = ba_solve_lds(b->W);
   for (int it = it0; it < it0 + n_it; it++) {

@@ -94,17 +94,9 @@ __global__ void __launch_bounds__(64) k_dlt(dlt_args a, const float* __restrict_
   }
 }
 
-extern "C" int32_t vo_triangulate_dlt(vo_ctx* c, const float* P0, const float* P1, const float* uv0,
-                                      const float* uv1, int32_t n, float* X4, const double* K,
-                                      const double* H0, const double* H1, double* depth1, double* reproj) {
-  if (!c) return VO_E_INVALID;
-  VO_CHECK(c, n >= 0 && n <= c->max_pts, VO_E_CAPACITY, "n exceeds max_pts");
-  if (n == 0) return VO_OK;
-  VO_CHECK(c, P0 && P1 && uv0 && uv1 && X4, VO_E_INVALID, "null buffer");
+static void dlt_fill_args(dlt_args& a, const float* P0, const float* P1, const double* K, const double* H0,
+                          const double* H1, int n) {
   const bool stats = K != nullptr;
-  if (stats) VO_CHECK(c, H0 && H1 && depth1 && reproj, VO_E_INVALID, "statistics need K, H0, H1, depth1, reproj");
-  VO_HIP(c, hipSetDevice(c->device));
-  dlt_args a;
   for (int k = 0; k < 12; k++) { a.P0[k] = P0[k]; a.P1[k] = P1[k]; a.M0[k] = 0; a.M1[k] = 0; }
   for (int k = 0; k < 4; k++) a.H1z[k] = 0;
   if (stats) {
@@ -117,16 +109,78 @@ extern "C" int32_t vo_triangulate_dlt(vo_ctx* c, const float* P0, const float* P
     for (int k = 0; k < 4; k++) a.H1z[k] = H1[8 + k];
   }
   a.n = n; a.want_stats = stats ? 1 : 0;
-  VO_HIP(c, hipMemcpyAsync(c->d_uv0, uv0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
-  VO_HIP(c, hipMemcpyAsync(c->d_uv1, uv1, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_dlt, dim3(vo_div_up(n, 64)), dim3(64), 0, c->stream, a, c->d_uv0, c->d_uv1, c->d_X4,
+}
+
+static int32_t dlt_launch(vo_ctx* c, const dlt_args& a) {
+  vo_prof_scope prof(c, VO_PROF_DLT);
+  hipLaunchKernelGGL(k_dlt, dim3(vo_div_up(a.n, 64)), dim3(64), 0, c->stream, a, c->d_uv0, c->d_uv1, c->d_X4,
                      c->d_depth, c->d_reproj);
   VO_HIP(c, hipGetLastError());
+  return VO_OK;
+}
+
+extern "C" int32_t vo_triangulate_dlt(vo_ctx* c, const float* P0, const float* P1, const float* uv0,
+                                      const float* uv1, int32_t n, float* X4, const double* K,
+                                      const double* H0, const double* H1, double* depth1, double* reproj) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, n >= 0 && n <= c->max_pts, VO_E_CAPACITY, "n exceeds max_pts");
+  if (n == 0) return VO_OK;
+  VO_CHECK(c, P0 && P1 && uv0 && uv1 && X4, VO_E_INVALID, "null buffer");
+  const bool stats = K != nullptr;
+  if (stats) VO_CHECK(c, H0 && H1 && depth1 && reproj, VO_E_INVALID, "statistics need K, H0, H1, depth1, reproj");
+  VO_HIP(c, hipSetDevice(c->device));
+  dlt_args a;
+  dlt_fill_args(a, P0, P1, K, H0, H1, n);
+  VO_HIP(c, hipMemcpyAsync(c->d_uv0, uv0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipMemcpyAsync(c->d_uv1, uv1, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+  int32_t r = dlt_launch(c, a);
+  if (r != VO_OK) return r;
   VO_HIP(c, hipMemcpyAsync(X4, c->d_X4, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, c->stream));
   if (stats) {
     VO_HIP(c, hipMemcpyAsync(depth1, c->d_depth, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipMemcpyAsync(reproj, c->d_reproj, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   }
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
+extern "C" int32_t vo_dlt_upload(vo_ctx* c, const float* P0, const float* P1, const float* uv0, const float* uv1,
+                                 int32_t n, const double* K, const double* H0, const double* H1) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, n >= 1 && n <= c->max_pts, VO_E_CAPACITY, "n exceeds max_pts");
+  VO_CHECK(c, P0 && P1 && uv0 && uv1, VO_E_INVALID, "null buffer");
+  if (K) VO_CHECK(c, H0 && H1, VO_E_INVALID, "statistics need K, H0, H1");
+  VO_HIP(c, hipSetDevice(c->device));
+  for (int k = 0; k < 12; k++) { c->dlt_P0[k] = P0[k]; c->dlt_P1[k] = P1[k]; }
+  c->dlt_stats = K ? 1 : 0;
+  if (K) {
+    for (int k = 0; k < 9; k++) c->dlt_K[k] = K[k];
+    for (int k = 0; k < 16; k++) { c->dlt_H0[k] = H0[k]; c->dlt_H1[k] = H1[k]; }
+  }
+  VO_HIP(c, hipMemcpyAsync(c->d_uv0, uv0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipMemcpyAsync(c->d_uv1, uv1, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  c->dlt_n = n;
+  return VO_OK;
+}
+
+extern "C" int32_t vo_dlt_resident(vo_ctx* c) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->dlt_n > 0, VO_E_STATE, "vo_dlt_upload first");
+  VO_HIP(c, hipSetDevice(c->device));
+  dlt_args a;
+  dlt_fill_args(a, c->dlt_P0, c->dlt_P1, c->dlt_stats ? c->dlt_K : nullptr, c->dlt_H0, c->dlt_H1, c->dlt_n);
+  return dlt_launch(c, a);
+}
+
+extern "C" int32_t vo_dlt_fetch(vo_ctx* c, float* X4, double* depth1, double* reproj) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->dlt_n > 0, VO_E_STATE, "nothing to fetch");
+  VO_HIP(c, hipSetDevice(c->device));
+  const int n = c->dlt_n;
+  if (X4) VO_HIP(c, hipMemcpyAsync(X4, c->d_X4, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, c->stream));
+  if (depth1 && c->dlt_stats) VO_HIP(c, hipMemcpyAsync(depth1, c->d_depth, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  if (reproj && c->dlt_stats) VO_HIP(c, hipMemcpyAsync(reproj, c->d_reproj, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   return VO_OK;
 }

@@ -79,6 +79,56 @@ __global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// in-stream timing
+// ------------------------------------------------------------------------------------------------
+static hipEvent_t prof_event(vo_ctx* c) {
+  vo_prof& p = c->prof;
+  if (p.used == p.pool.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    p.pool.push_back(e);
+  }
+  return p.pool[p.used++];
+}
+
+vo_prof_scope::vo_prof_scope(vo_ctx* c_, int region_) : c(c_), region(region_) {
+  if (!((c->prof.mask >> region) & 1)) return;
+  e0 = prof_event(c); e1 = prof_event(c);
+  if (e0) (void)hipEventRecord(e0, c->stream);
+}
+
+vo_prof_scope::~vo_prof_scope() {
+  if (!e0 || !e1) return;
+  (void)hipEventRecord(e1, c->stream);
+  c->prof.pairs[region].push_back(std::make_pair(e0, e1));
+}
+
+extern "C" int32_t vo_profile_enable(vo_ctx* c, int32_t region_mask) {
+  if (!c) return VO_E_INVALID;
+  VO_HIP(c, hipSetDevice(c->device));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  c->prof.mask = region_mask;
+  c->prof.used = 0;
+  for (int r = 0; r < VO_PROF_COUNT; r++) c->prof.pairs[r].clear();
+  return VO_OK;
+}
+
+extern "C" int32_t vo_profile_read(vo_ctx* c, int32_t region, double* total_ms, int32_t* count) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, region >= 0 && region < VO_PROF_COUNT && total_ms && count, VO_E_INVALID, "bad region");
+  VO_HIP(c, hipSetDevice(c->device));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  double t = 0;
+  for (auto& pr : c->prof.pairs[region]) {
+    float ms = 0;
+    VO_HIP(c, hipEventElapsedTime(&ms, pr.first, pr.second));
+    t += ms;
+  }
+  *total_ms = t; *count = (int32_t)c->prof.pairs[region].size();
+  return VO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
 extern "C" int32_t vo_abi_version(void) { return VO_ABI_VERSION; }
@@ -111,6 +161,7 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
   void* bufs[] = {c->d_raw, c->d_seq, c->d_p0, c->d_p1, c->d_err, c->d_status, c->d_iters,
                   c->d_uv0, c->d_uv1, c->d_X4, c->d_depth, c->d_reproj};
   for (void* b : bufs) if (b) (void)hipFree(b);
+  for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return VO_OK;
@@ -191,6 +242,7 @@ extern "C" int32_t vo_sync(vo_ctx* c) {
 // frames
 // ------------------------------------------------------------------------------------------------
 static int32_t build_pyramid(vo_ctx* c, const uint8_t* d_raw_img) {
+  vo_prof_scope prof(c, VO_PROF_FRAME);
   c->cur ^= 1;
   vo_frame& F = c->fr[c->cur];
   {

@@ -22,6 +22,14 @@ struct vo_frame {
   int16_t* der[VO_MAX_LEVELS];   // padded, interleaved (Ix, Iy), same pixel pitch; border = 0
 };
 
+#include <vector>
+struct vo_prof {
+  int mask = 0;                                                  // bit r = region r is timed
+  std::vector<hipEvent_t> pool;                                  // all events ever created (reused)
+  size_t used = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs[VO_PROF_COUNT];
+};
+
 struct vo_st_ws;   // Shi-Tomasi workspace (vo_shi_tomasi.hip)
 struct vo_ba_ws;   // bundle-adjustment workspace (vo_ba.hip)
 
@@ -44,11 +52,16 @@ struct vo_ctx {
   uint8_t* d_status = nullptr;
   int32_t* d_iters = nullptr;        // n x (max_level + 1)
   int n_resident = 0;
+  int iters_stride = 0;              // of the last KLT launch
   // DLT scratch
   float* d_uv0 = nullptr; float* d_uv1 = nullptr; float* d_X4 = nullptr;
   double* d_depth = nullptr; double* d_reproj = nullptr;
+  int dlt_n = 0, dlt_stats = 0;
+  float dlt_P0[12], dlt_P1[12];
+  double dlt_K[9], dlt_H0[16], dlt_H1[16];
   vo_st_ws* st = nullptr;
   vo_ba_ws* ba = nullptr;
+  vo_prof prof;
   std::string err;
 };
 
@@ -72,6 +85,13 @@ inline int32_t vo_fail(vo_ctx* c, int32_t code, const std::string& msg) {
   do {                                                                                    \
     if (!(cond)) return vo_fail((c), (code), std::string(__func__) + ": " + (msg));       \
   } while (0)
+
+// RAII bracket: records an event pair on the ctx stream around a region when profiling is on
+struct vo_prof_scope {
+  vo_ctx* c; int region; hipEvent_t e0 = nullptr, e1 = nullptr;
+  vo_prof_scope(vo_ctx* c_, int region_);
+  ~vo_prof_scope();
+};
 
 static inline int vo_div_up(int a, int b) { return (a + b - 1) / b; }
 

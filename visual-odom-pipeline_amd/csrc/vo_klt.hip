@@ -293,9 +293,13 @@ static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, const floa
   double eps = prm->epsilon; if (eps < 0) eps = 0; if (eps > 10) eps = 10;
   A.max_count = mc; A.eps2 = eps * eps; A.min_eig = prm->min_eig_threshold; A.n = n;
   A.iters_stride = prm->max_level + 1;
+  c->iters_stride = A.iters_stride;
   // levels above `top` are reported as skipped (-1)
   VO_HIP(c, hipMemsetAsync(c->d_iters, 0xff, sizeof(int32_t) * (size_t)n * A.iters_stride, c->stream));
-  hipLaunchKernelGGL(k_klt_track, dim3(n), dim3(64), 0, c->stream, A, d_in, d_out, c->d_status, c->d_err, c->d_iters);
+  {
+    vo_prof_scope prof(c, VO_PROF_KLT);   // brackets exactly this launch (bench.py roofline figure)
+    hipLaunchKernelGGL(k_klt_track, dim3(n), dim3(64), 0, c->stream, A, d_in, d_out, c->d_status, c->d_err, c->d_iters);
+  }
   VO_HIP(c, hipGetLastError());
   return VO_OK;
 }
@@ -331,13 +335,15 @@ extern "C" int32_t vo_points_upload(vo_ctx* c, const float* p, int32_t n) {
   return VO_OK;
 }
 
-extern "C" int32_t vo_points_download(vo_ctx* c, float* p, uint8_t* status, float* err, int32_t n) {
+extern "C" int32_t vo_points_download(vo_ctx* c, float* p, uint8_t* status, float* err, int32_t* iters, int32_t n) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, n >= 0 && n <= c->n_resident, VO_E_INVALID, "n exceeds the resident point set");
   VO_HIP(c, hipSetDevice(c->device));
   if (p) VO_HIP(c, hipMemcpyAsync(p, c->d_p0, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->stream));
   if (status) VO_HIP(c, hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, c->stream));
   if (err) VO_HIP(c, hipMemcpyAsync(err, c->d_err, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+  if (iters && c->iters_stride > 0)
+    VO_HIP(c, hipMemcpyAsync(iters, c->d_iters, sizeof(int32_t) * (size_t)n * c->iters_stride, hipMemcpyDeviceToHost, c->stream));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   return VO_OK;
 }

@@ -318,6 +318,7 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, int n_cur, int mask_radi
   VO_CHECK(c, mask_radius >= 0 && mask_radius <= ST_MAX_RADIUS, VO_E_INVALID, "mask_radius must be 0..31");
   VO_CHECK(c, prm->max_corners <= ST_OUT_CAP, VO_E_CAPACITY, "max_corners exceeds 4096");
   vo_st_ws* s = c->st;
+  vo_prof_scope prof(c, VO_PROF_ST);
   const int W = c->width, H = c->height, r = prm->block_size / 2;
   const size_t np = (size_t)W * H;
   const vo_frame& F = c->fr[c->cur];

@@ -65,7 +65,7 @@ SIGNATURES = {
     "vo_klt_default_params": (C.c_int32, [C.POINTER(KltParams)]),
     "vo_klt_track": (C.c_int32, [_ctx, _f32p, C.c_int32, C.POINTER(KltParams), _f32p, _u8p, _f32p, _i32p]),
     "vo_points_upload": (C.c_int32, [_ctx, _f32p, C.c_int32]),
-    "vo_points_download": (C.c_int32, [_ctx, _f32p, _u8p, _f32p, C.c_int32]),
+    "vo_points_download": (C.c_int32, [_ctx, _f32p, _u8p, _f32p, _i32p, C.c_int32]),
     "vo_klt_track_resident": (C.c_int32, [_ctx, C.c_int32, C.POINTER(KltParams)]),
     "vo_st_default_params": (C.c_int32, [C.POINTER(StParams)]),
     "vo_shi_tomasi": (C.c_int32, [_ctx, _f32p, C.c_int32, C.c_int32, _u8p, C.POINTER(StParams), _f32p, _i32p]),
@@ -74,6 +74,11 @@ SIGNATURES = {
     "vo_shi_tomasi_read": (C.c_int32, [_ctx, _f32p, _u8p, _i32p]),
     "vo_triangulate_dlt": (C.c_int32, [_ctx, _f32p, _f32p, _f32p, _f32p, C.c_int32, _f32p, _f64p, _f64p, _f64p,
                                        _f64p, _f64p]),
+    "vo_dlt_upload": (C.c_int32, [_ctx, _f32p, _f32p, _f32p, _f32p, C.c_int32, _f64p, _f64p, _f64p]),
+    "vo_dlt_resident": (C.c_int32, [_ctx]),
+    "vo_dlt_fetch": (C.c_int32, [_ctx, _f32p, _f64p, _f64p]),
+    "vo_profile_enable": (C.c_int32, [_ctx, C.c_int32]),
+    "vo_profile_read": (C.c_int32, [_ctx, C.c_int32, _f64p, _i32p]),
     "vo_ba_default_params": (C.c_int32, [C.POINTER(BaParams)]),
     "vo_ba_adjust": (C.c_int32, [_ctx, _f64p, _f64p, _f64p, _f64p, C.c_int32, C.c_int32, C.POINTER(BaParams),
                                  _f64p, _f64p, C.POINTER(BaStats)]),

@@ -22,6 +22,7 @@ class VoContext:
         self.width, self.height, self.max_pts = width, height, max_pts
         self.max_level, self.win, self.device = max_level, win, device
         self._st_max_corners = 1000
+        self._klt_levels = max_level + 1
 
     # -- lifetime -------------------------------------------------------------------------------
     def close(self):
@@ -107,15 +108,18 @@ class VoContext:
         p = as_c(np.asarray(p, np.float32).reshape(-1, 2), np.float32)
         self._ck(self._L.vo_points_upload(self._h, ptr(p, C.c_float), p.shape[0]))
 
-    def points_download(self, n):
+    def points_download(self, n, return_iters=False):
         p = np.zeros((n, 2), np.float32)
         st = np.zeros(n, np.uint8)
         err = np.zeros(n, np.float32)
-        self._ck(self._L.vo_points_download(self._h, ptr(p, C.c_float), ptr(st, C.c_uint8), ptr(err, C.c_float), n))
-        return p, st, err
+        it = np.full((n, self._klt_levels), -1, np.int32) if return_iters else None
+        self._ck(self._L.vo_points_download(self._h, ptr(p, C.c_float), ptr(st, C.c_uint8), ptr(err, C.c_float),
+                                            ptr(it, C.c_int32), n))
+        return (p, st, err, it) if return_iters else (p, st, err)
 
     def klt_track_resident(self, n, params=None):
         prm = params if params is not None else self.klt_params()
+        self._klt_levels = prm.max_level + 1
         self._ck(self._L.vo_klt_track_resident(self._h, n, C.byref(prm)))
 
     # -- Shi-Tomasi -----------------------------------------------------------------------------
@@ -183,6 +187,41 @@ class VoContext:
                                             ptr(H0, C.c_double), ptr(H1, C.c_double), ptr(depth, C.c_double),
                                             ptr(reproj, C.c_double)))
         return X4, depth, reproj
+
+    def dlt_upload(self, P0, P1, uv0, uv1, K=None, H0=None, H1=None):
+        P0, P1 = as_c(P0, np.float32), as_c(P1, np.float32)
+        uv0 = as_c(np.asarray(uv0, np.float32).reshape(-1, 2), np.float32)
+        uv1 = as_c(np.asarray(uv1, np.float32).reshape(-1, 2), np.float32)
+        self._dlt_n, self._dlt_stats = uv0.shape[0], K is not None
+        if K is not None:
+            K, H0, H1 = as_c(K, np.float64), as_c(H0, np.float64), as_c(H1, np.float64)
+        d = C.c_double
+        self._ck(self._L.vo_dlt_upload(self._h, ptr(P0, C.c_float), ptr(P1, C.c_float), ptr(uv0, C.c_float),
+                                       ptr(uv1, C.c_float), self._dlt_n, ptr(K, d), ptr(H0, d), ptr(H1, d)))
+
+    def dlt_resident(self):
+        self._ck(self._L.vo_dlt_resident(self._h))
+
+    def dlt_fetch(self):
+        n = self._dlt_n
+        X4, depth, reproj = np.zeros((4, n), np.float32), np.zeros(n), np.zeros(n)
+        self._ck(self._L.vo_dlt_fetch(self._h, ptr(X4, C.c_float), ptr(depth, C.c_double), ptr(reproj, C.c_double)))
+        return (X4, depth, reproj) if self._dlt_stats else X4
+
+    # -- in-stream timing -----------------------------------------------------------------------
+    PROF_FRAME, PROF_KLT, PROF_ST, PROF_DLT, PROF_BA = range(5)
+
+    def profile_enable(self, regions=(0, 1, 2, 3, 4)):
+        """regions: iterable of PROF_* ids to time with hipEvent pairs on the ctx stream; () switches timing off"""
+        mask = 0
+        for r in regions:
+            mask |= 1 << r
+        self._ck(self._L.vo_profile_enable(self._h, mask))
+
+    def profile_read(self, region):
+        t, n = C.c_double(0), C.c_int32(0)
+        self._ck(self._L.vo_profile_read(self._h, region, C.byref(t), C.byref(n)))
+        return t.value, n.value
 
     # -- BA -------------------------------------------------------------------------------------
     def ba_params(self, max_iters=50, ftol=1e-3, xtol=1e-3, gtol=1e-8, lambda0=1e-4, huber_delta=1.0):
