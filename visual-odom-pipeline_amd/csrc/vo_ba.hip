@@ -1,39 +1,48 @@
 // Sliding-window bundle adjustment on gfx950: analytic Jacobians, IRLS-weighted J^T J, landmark Schur
-// complement as an f64-MFMA SYRK, in-LDS Cholesky, Levenberg-Marquardt with the accept/reject logic
-// on the device (no host round trip inside the solve).
+// complement as an f64-MFMA SYRK, 6x6-blocked Cholesky in LDS, Levenberg-Marquardt with the accept/reject
+// logic on the device (no host round trip inside the solve).
 //
 // Replaces the scipy.optimize.least_squares(...) call of BundleAdjuster.adjust,
 // /root/reference/src/bundle_adjuster/bundle_adjuster.py:189-194, and its objective :18-65 / :68-83.
 // Same cost as the reference (Huber, f_scale 1, on the per-observation pixel-error norm; no gauge fixing);
-// the solver is the one `north_star` asks for and oracle/ba_oracle.py defines (and the tests compare
-// against step by step): residual e (2), blocks J_p (2x6), J_l (2x3), w = rho'(|e|^2),
+// the solver is the one `north_star` asks for and oracle/ba_oracle.py defines (the tests compare against it
+// step by step): residual e (2), blocks J_p (2x6), J_l (2x3), w = rho'(|e|^2),
 //   H = sum w J^T J, g = sum w J^T e, (H + lambda diag H) d = -g via Schur on the 3x3 landmark blocks.
 //
 // Data in HBM (float64):
-//   obs   [W][N][2]   slot-major (slot 0 = newest frame), NaN = not observed  -> coalesced over landmarks
+//   obs   [W][N][2]   slot-major (slot 0 = newest frame), NaN = not observed
 //   x[2]  {poses [W][6], points [N][3]}  current / trial, selected by state.cur
-//   Yt    [3N (+pad)][RP]   RP = roundup(6W+1, 16): row 3j+c holds column c of Y_j = H_pl,j L_j for every
-//         pose parameter, and y_j[c] = (L_j^T g_l,j)[c] in column 6W, so that ONE SYRK  Yt^T Yt  yields both
-//         E = sum_j H_pl M_j H_pl^T and r = sum_j H_pl M_j g_l  (M_j = (H_ll,j + lambda D_j)^-1 = L_j L_j^T).
 //
-// One LM iteration = 4 launches on the ctx stream (state is double buffered by iteration parity):
-//   k_ba_linearize : [decide previous step] ; landmark role: thread per landmark (H_ll, g_l, L_j, Yt rows);
-//                    camera role: block per (slot, landmark chunk) -> partial H_pp / g_p / cost
-//   k_ba_syrk      : v_mfma_f64_16x16x4_f64 over K-slices of Yt, upper 16x16 tiles -> partial tiles
-//   k_ba_solve     : one workgroup: reduce partials, assemble the damped reduced camera system, left-looking
-//                    Cholesky of [S rhs] in LDS, back substitution -> d_poses
-//   k_ba_update    : thread per landmark: back-substitute d_point, trial x, trial cost, step statistics
-// k_ba_finalize applies the last decision and publishes x / stats.
+// Work mapping: ONE LANE PER OBSERVATION.  A landmark owns a group of LPP = 16 (W <= 16) or 32 lanes, lane s of
+// the group handles the observation in window slot s; landmark sums are DPP row-rotate all-reduces inside the
+// group, camera sums are cross-group shuffles + one LDS pass, so every observation is linearised exactly once
+// per kernel and nothing is re-read from HBM.
+//
+// One LM iteration = 3 launches on the ctx stream (state double-buffered by iteration parity):
+//   k_ba_build  : [decide previous step]; per workgroup (1024 lanes = 64 or 32 landmarks): linearise, H_ll/g_l,
+//                 damped 3x3 inverse factor L_j, camera partial sums (H_pp, g_p, cost); the workgroup's slice of
+//                 Y^ = [H_pl L | L^T g_l] is staged in LDS ((3 PPB) x RP panel, 120 KB) and its Gram matrix
+//                 Y^ Y^T -- i.e. E = sum_j H_pl M_j H_pl^T and r = sum_j H_pl M_j g_l at once -- is accumulated
+//                 with v_mfma_f64_16x16x4_f64 (upper 16x16 tiles) -> one partial tile set per workgroup
+//   k_ba_solve  : one workgroup: fixed-order reduction of the partials, damped reduced camera system
+//                 S = H_pp + lambda D - E, 6x6-blocked Cholesky of [S rhs] in LDS (diagonal blocks factorised
+//                 redundantly in registers -> 2 barriers per block column), wave-level back substitution
+//   k_ba_update : lane per observation again: d_point = -M_j (g_l + sum_i B_ij^T d_pose_i), trial x, trial cost,
+//                 step statistics
+// k_ba_finalize applies the last decision and publishes x / stats.  All reductions have a fixed order, so a
+// solve is bitwise reproducible from run to run.
 #include "vo_internal.h"
 
 #include <math.h>
 
-#define BA_LIN_THREADS 128
+#define BA_THREADS 1024
+#define BA_WAVES (BA_THREADS / 64)
 #define BA_AUX 18            // per landmark: Hll(6) gl(3) Cinv(6) z(3)
 #define BA_POSE_VALS 28      // Hpp upper (21) + gp (6) + cost (1)
 #define BA_MAX_SLOTS 20
-#define BA_SOLVE_THREADS 512
 #define BA_EVAL_VALS 4
+#define BA_PITCH_PAD 16      // panel row pitch = RP + 16 doubles: 16-lane row groups land on disjoint LDS banks
+#define BA_CAM 21            // per-slot camera data staged in LDS: R(9) t(3) Jr(9)
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -52,23 +61,32 @@ struct ba_params_dev {
   int max_iters;
 };
 
+struct ba_ptrs {
+  const double* K; const double* obs; const double* x0;
+  double* x[2];
+  double* aux; double* posepart; double* gmax; double* tiles; double* dp; double* evalpart;
+  ba_state* state; ba_info* info;
+  int W, N, LPP, PPB, nblk, RP, RT, n_tiles, pitch;
+};
+
 struct vo_ba_ws {
-  int W = 0, N = 0, RP = 0, RT = 0, n_tiles = 0, KS = 0, KL = 0, K4 = 0, n_chunk = 0, n_pblk = 0, n_eblk = 0;
+  int W = 0, N = 0, LPP = 0, PPB = 0, nblk = 0, RP = 0, RT = 0, n_tiles = 0, pitch = 0;
   int cap_W = 0, cap_N = 0;
+  size_t build_lds = 0, solve_lds = 0;
   double* d_K = nullptr;        // 9
   double* d_obs = nullptr;      // W*N*2
   double* d_x0 = nullptr;       // W*6 + N*3
   double* d_x[2] = {nullptr, nullptr};
-  double* d_Yt = nullptr;       // K4 * RP
   double* d_aux = nullptr;      // N * BA_AUX
-  double* d_posepart = nullptr; // W * n_chunk * 28
-  double* d_gmax = nullptr;     // n_pblk
-  double* d_tiles = nullptr;    // KS * n_tiles * 256
+  double* d_posepart = nullptr; // nblk * W * 28
+  double* d_gmax = nullptr;     // nblk
+  double* d_tiles = nullptr;    // nblk * n_tiles * 256
   double* d_dp = nullptr;       // 6W
-  double* d_evalpart = nullptr; // n_eblk * 4
+  double* d_evalpart = nullptr; // nblk * 4
   double* d_S = nullptr;        // probe: (6W)^2 + 6W
-  double* d_Hpp = nullptr;      // W*36 + W*6 (probe / reduced values)
+  double* d_Hpp = nullptr;      // W*28 reduced pose values (probe)
   double* d_res = nullptr;      // probe residual W*N
+  double* d_dl = nullptr;       // probe d_points 3N
   double* d_xout = nullptr;     // published solution 6W + 3N
   ba_state* d_state = nullptr;  // [2]
   ba_info* d_info = nullptr;
@@ -105,8 +123,6 @@ __device__ __forceinline__ void d_right_jacobian(const double* r, double* J) {
   J[6] = a * y + b * z * x;       J[7] = -a * x + b * z * y;      J[8] = 1.0 + b * (z * z - th2);
 }
 
-// per-slot camera data staged in LDS: R(9) t(3) Jr(9)
-#define BA_CAM 21
 __device__ __forceinline__ void stage_cameras(const double* poses, int W, double* cam, int tid, int nthreads) {
   for (int i = tid; i < W; i += nthreads) {
     const double* p = poses + 6 * i;
@@ -135,7 +151,8 @@ __device__ __forceinline__ bool ba_linearize_obs(const double* __restrict__ K, c
   const double p0 = K[0] * xc + K[1] * yc + K[2] * zc;
   const double p1 = K[3] * xc + K[4] * yc + K[5] * zc;
   const double p2 = K[6] * xc + K[7] * yc + K[8] * zc;
-  const double u = p0 / p2, v = p1 / p2;
+  const double ip2 = 1.0 / p2;
+  const double u = p0 * ip2, v = p1 * ip2;
   o.e0 = u - uo; o.e1 = v - vo;
   const double s = o.e0 * o.e0 + o.e1 * o.e1;
   const double d2 = delta * delta;
@@ -143,7 +160,7 @@ __device__ __forceinline__ bool ba_linearize_obs(const double* __restrict__ K, c
   else { const double rs = sqrt(s); o.w = delta / rs; o.rho = 2.0 * delta * rs - d2; }
   double A[2][3];
 #pragma unroll
-  for (int c = 0; c < 3; c++) { A[0][c] = (K[c] - u * K[6 + c]) / p2; A[1][c] = (K[3 + c] - v * K[6 + c]) / p2; }
+  for (int c = 0; c < 3; c++) { A[0][c] = (K[c] - u * K[6 + c]) * ip2; A[1][c] = (K[3 + c] - v * K[6 + c]) * ip2; }
 #pragma unroll
   for (int k = 0; k < 2; k++)
 #pragma unroll
@@ -170,8 +187,43 @@ __device__ __forceinline__ bool ba_linearize_obs(const double* __restrict__ K, c
   return true;
 }
 
+// ---- cross-lane helpers on doubles ----
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+// sum over the LPP (16 or 32) lanes of a landmark group; every lane of the group gets the total
+__device__ __forceinline__ double group_allreduce(double v, int lpp) {
+  v += dpp_f64<0x128>(v);   // row_ror:8
+  v += dpp_f64<0x124>(v);   // row_ror:4
+  v += dpp_f64<0x122>(v);   // row_ror:2
+  v += dpp_f64<0x121>(v);   // row_ror:1
+  if (lpp == 32) v += __shfl_xor(v, 16);
+  return v;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(x) to double precision: v_rsq_f64 seed + two Newton steps
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * y, y, 1.0);
+  y = fma(0.5 * y, e, y);
+  e = fma(-x * y, y, 1.0);
+  y = fma(0.5 * y, e, y);
+  return y;
+}
+
 // ------------------------------------------------------------------------------------------------
-// LM decision (runs redundantly in every thread that needs the new state; inputs are identical)
+// LM decision (inputs are identical in every workgroup, so every workgroup derives the same state)
 // ------------------------------------------------------------------------------------------------
 __device__ inline void ba_decide(const ba_state& in, const ba_info& info, const double* __restrict__ evalpart, int n_eblk,
                                  const ba_params_dev& prm, ba_state& out) {
@@ -213,277 +265,343 @@ __device__ inline void ba_decide(const ba_state& in, const ba_info& info, const 
   if (!out.done && out.iter >= prm.max_iters) { out.done = 1; out.status = 0; }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_ba_linearize
-// ------------------------------------------------------------------------------------------------
-struct ba_ptrs {
-  const double* K; const double* obs;
-  double* x[2];
-  double* Yt; double* aux; double* posepart; double* gmax; double* tiles; double* dp; double* evalpart;
-  ba_state* state; ba_info* info;
-  int W, N, RP, n_chunk, n_pblk, n_eblk, KS, KL, K4, n_tiles, RT;
-};
+__device__ inline ba_state ba_init_state(const ba_params_dev& prm) {
+  ba_state s;
+  s.lambda = prm.lambda0; s.nu = 2.0; s.cost = 0; s.cost0 = 0;
+  s.cur = 0; s.iter = 0; s.accepted = 0; s.status = 0; s.done = 0; s.n_obs = 0;
+  return s;
+}
 
-__global__ void __launch_bounds__(BA_LIN_THREADS) k_ba_linearize(ba_ptrs P, ba_params_dev prm, int it, double probe_lambda) {
+// ------------------------------------------------------------------------------------------------
+// k_ba_build
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BA_THREADS) k_ba_build(ba_ptrs P, ba_params_dev prm, int it, double probe_lambda) {
+  extern __shared__ double dyn[];   // phase A: camera-sum scratch [wave][LPP][28]; phase B: Y^ panel [3 PPB][pitch]
   __shared__ double s_cam[BA_CAM * BA_MAX_SLOTS];
   __shared__ double s_K[9];
-  __shared__ double s_red[BA_POSE_VALS * BA_LIN_THREADS];
+  __shared__ double s_gmax[BA_WAVES];
   __shared__ ba_state s_st;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // ---- state for this iteration ----
   if (tid == 0) {
     ba_state st;
-    if (it == 0) st = P.state[0];                       // initialised by the host-enqueued memcpy
-    else ba_decide(P.state[(it - 1) & 1], *P.info, P.evalpart, P.n_eblk, prm, st);
+    if (it == 0) st = ba_init_state(prm);
+    else ba_decide(P.state[(it - 1) & 1], *P.info, P.evalpart, P.nblk, prm, st);
     if (probe_lambda >= 0) st.lambda = probe_lambda;
     s_st = st;
-    if (blockIdx.x == 0 && it > 0) P.state[it & 1] = st;
+    if (blockIdx.x == 0) P.state[it & 1] = st;
   }
   __syncthreads();
   const ba_state st = s_st;
   if (st.done) return;
-  const int W = P.W, N = P.N;
-  const double* poses = P.x[st.cur];
-  const double* pts = P.x[st.cur] + 6 * W;
-  stage_cameras(poses, W, s_cam, tid, BA_LIN_THREADS);
+  const int W = P.W, N = P.N, LPP = P.LPP;
+  // iteration 0 reads the uploaded x0 and seeds x[0] with it (each workgroup its own landmarks)
+  const double* poses = (it == 0) ? P.x0 : P.x[st.cur];
+  const double* pts = poses + 6 * W;
+  stage_cameras(poses, W, s_cam, tid, BA_THREADS);
   if (tid < 9) s_K[tid] = P.K[tid];
+  if (it == 0 && blockIdx.x == 0 && tid < 6 * W) P.x[0][tid] = poses[tid];
   __syncthreads();
 
-  if ((int)blockIdx.x < P.n_pblk) {
-    // ================= landmark role: one thread per landmark =================
-    const int j = blockIdx.x * BA_LIN_THREADS + tid;
+  const int pl = tid / LPP, slot = tid - pl * LPP;       // landmark (local), window slot
+  const int j = blockIdx.x * P.PPB + pl;
+  ba_obs_lin o;
+  bool have = false;
+  if (it == 0 && slot == 0 && j < N) {
+    double* dst = P.x[0] + 6 * W + 3 * j;
+    dst[0] = pts[3 * j]; dst[1] = pts[3 * j + 1]; dst[2] = pts[3 * j + 2];
+  }
+  if (slot < W && j < N) {
+    const double X[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
+    const double* ob = P.obs + ((size_t)slot * N + j) * 2;
+    have = ba_linearize_obs<true>(s_K, s_cam + BA_CAM * slot, X, ob[0], ob[1], prm.delta, o);
+  }
+  if (!have) {
+    o.e0 = o.e1 = o.w = o.rho = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) o.Jl[k][c] = 0;
+#pragma unroll
+      for (int c = 0; c < 6; c++) o.Jp[k][c] = 0;
+    }
+  }
+  // ---- landmark sums over the group ----
+  const double h00 = group_allreduce(o.w * (o.Jl[0][0] * o.Jl[0][0] + o.Jl[1][0] * o.Jl[1][0]), LPP);
+  const double h10 = group_allreduce(o.w * (o.Jl[0][1] * o.Jl[0][0] + o.Jl[1][1] * o.Jl[1][0]), LPP);
+  const double h11 = group_allreduce(o.w * (o.Jl[0][1] * o.Jl[0][1] + o.Jl[1][1] * o.Jl[1][1]), LPP);
+  const double h20 = group_allreduce(o.w * (o.Jl[0][2] * o.Jl[0][0] + o.Jl[1][2] * o.Jl[1][0]), LPP);
+  const double h21 = group_allreduce(o.w * (o.Jl[0][2] * o.Jl[0][1] + o.Jl[1][2] * o.Jl[1][1]), LPP);
+  const double h22 = group_allreduce(o.w * (o.Jl[0][2] * o.Jl[0][2] + o.Jl[1][2] * o.Jl[1][2]), LPP);
+  const double g0 = group_allreduce(o.w * (o.Jl[0][0] * o.e0 + o.Jl[1][0] * o.e1), LPP);
+  const double g1 = group_allreduce(o.w * (o.Jl[0][1] * o.e0 + o.Jl[1][1] * o.e1), LPP);
+  const double g2 = group_allreduce(o.w * (o.Jl[0][2] * o.e0 + o.Jl[1][2] * o.e1), LPP);
+  // ---- damped 3x3 block: Cholesky C C^T, Cinv = C^-1 (lower), y = Cinv g, z = Cinv^T y = M g ----
+  const double lam = st.lambda;
+  const double a00 = h00 + lam * fmax(h00, 1e-12), a11 = h11 + lam * fmax(h11, 1e-12), a22 = h22 + lam * fmax(h22, 1e-12);
+  const double i00 = rsqrt_nr(a00);
+  const double c10 = h10 * i00, c20 = h20 * i00;
+  const double i11 = rsqrt_nr(a11 - c10 * c10);
+  const double c21 = (h21 - c20 * c10) * i11;
+  const double i22 = rsqrt_nr(a22 - c20 * c20 - c21 * c21);
+  const double i10 = -c10 * i00 * i11;
+  const double i21 = -c21 * i11 * i22;
+  const double i20 = -(c20 * i00 + c21 * i10) * i22;
+  const double y0 = i00 * g0, y1 = i10 * g0 + i11 * g1, y2 = i20 * g0 + i21 * g1 + i22 * g2;
+  if (slot == 0 && j < N) {
+    double* ax = P.aux + (size_t)j * BA_AUX;
+    ax[0] = h00; ax[1] = h10; ax[2] = h11; ax[3] = h20; ax[4] = h21; ax[5] = h22;
+    ax[6] = g0; ax[7] = g1; ax[8] = g2;
+    ax[9] = i00; ax[10] = i10; ax[11] = i11; ax[12] = i20; ax[13] = i21; ax[14] = i22;
+    ax[15] = i00 * y0 + i10 * y1 + i20 * y2; ax[16] = i11 * y1 + i21 * y2; ax[17] = i22 * y2;
+  }
+  // ---- max |g_l| of the workgroup ----
+  {
+    double gm = (j < N) ? fmax(fabs(g0), fmax(fabs(g1), fabs(g2))) : 0.0;
+    for (int ofs = 32; ofs > 0; ofs >>= 1) gm = fmax(gm, __shfl_xor(gm, ofs));
+    if (lane == 0) s_gmax[wave] = gm;
+  }
+  // ---- camera sums: across the landmarks of the wave by shuffles, across waves through LDS ----
+  // (each value is formed, reduced and stored before the next one to keep the register footprint small)
+  {
+    double* dst = dyn + (size_t)(wave * LPP + (lane & (LPP - 1))) * BA_POSE_VALS;
+    const bool writer = lane < LPP;
+    int q = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int c = a; c < 6; c++) {
+        double s = o.w * (o.Jp[0][a] * o.Jp[0][c] + o.Jp[1][a] * o.Jp[1][c]);
+        if (LPP == 16) s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (writer) dst[q] = s;
+        q++;
+      }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      double s = o.w * (o.Jp[0][a] * o.e0 + o.Jp[1][a] * o.e1);
+      if (LPP == 16) s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (writer) dst[21 + a] = s;
+    }
+    {
+      double s = 0.5 * o.rho;
+      if (LPP == 16) s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (writer) dst[27] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < W * BA_POSE_VALS) {
+    const int sl = tid / BA_POSE_VALS, k = tid - sl * BA_POSE_VALS;
+    double s = 0;
+#pragma unroll
+    for (int wv = 0; wv < BA_WAVES; wv++) s += dyn[(size_t)(wv * LPP + sl) * BA_POSE_VALS + k];
+    P.posepart[((size_t)blockIdx.x * W + sl) * BA_POSE_VALS + k] = s;
+  }
+  if (tid == 0) {
     double gm = 0;
-    if (j < N) {
-      const double X[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
-      double h00 = 0, h10 = 0, h11 = 0, h20 = 0, h21 = 0, h22 = 0, g0 = 0, g1 = 0, g2 = 0;
-      for (int i = 0; i < W; i++) {
-        const double* ob = P.obs + ((size_t)i * N + j) * 2;
-        ba_obs_lin o;
-        if (!ba_linearize_obs<false>(s_K, s_cam + BA_CAM * i, X, ob[0], ob[1], prm.delta, o)) continue;
-        h00 += o.w * (o.Jl[0][0] * o.Jl[0][0] + o.Jl[1][0] * o.Jl[1][0]);
-        h10 += o.w * (o.Jl[0][1] * o.Jl[0][0] + o.Jl[1][1] * o.Jl[1][0]);
-        h11 += o.w * (o.Jl[0][1] * o.Jl[0][1] + o.Jl[1][1] * o.Jl[1][1]);
-        h20 += o.w * (o.Jl[0][2] * o.Jl[0][0] + o.Jl[1][2] * o.Jl[1][0]);
-        h21 += o.w * (o.Jl[0][2] * o.Jl[0][1] + o.Jl[1][2] * o.Jl[1][1]);
-        h22 += o.w * (o.Jl[0][2] * o.Jl[0][2] + o.Jl[1][2] * o.Jl[1][2]);
-        g0 += o.w * (o.Jl[0][0] * o.e0 + o.Jl[1][0] * o.e1);
-        g1 += o.w * (o.Jl[0][1] * o.e0 + o.Jl[1][1] * o.e1);
-        g2 += o.w * (o.Jl[0][2] * o.e0 + o.Jl[1][2] * o.e1);
-      }
-      gm = fmax(fabs(g0), fmax(fabs(g1), fabs(g2)));
-      const double lam = st.lambda;
-      const double a00 = h00 + lam * fmax(h00, 1e-12), a11 = h11 + lam * fmax(h11, 1e-12), a22 = h22 + lam * fmax(h22, 1e-12);
-      // Cholesky of the damped 3x3 block and its inverse (lower triangular)
-      const double c00 = sqrt(a00), c10 = h10 / c00, c20 = h20 / c00;
-      const double c11 = sqrt(a11 - c10 * c10), c21 = (h21 - c20 * c10) / c11;
-      const double c22 = sqrt(a22 - c20 * c20 - c21 * c21);
-      const double i00 = 1.0 / c00, i11 = 1.0 / c11, i22 = 1.0 / c22;
-      const double i10 = -c10 * i00 * i11;
-      const double i21 = -c21 * i11 * i22;
-      const double i20 = -(c20 * i00 + c21 * i10) * i22;
-      const double y0 = i00 * g0, y1 = i10 * g0 + i11 * g1, y2 = i20 * g0 + i21 * g1 + i22 * g2;
-      const double z0 = i00 * y0 + i10 * y1 + i20 * y2, z1 = i11 * y1 + i21 * y2, z2 = i22 * y2;
-      double* ax = P.aux + (size_t)j * BA_AUX;
-      ax[0] = h00; ax[1] = h10; ax[2] = h11; ax[3] = h20; ax[4] = h21; ax[5] = h22;
-      ax[6] = g0; ax[7] = g1; ax[8] = g2;
-      ax[9] = i00; ax[10] = i10; ax[11] = i11; ax[12] = i20; ax[13] = i21; ax[14] = i22;
-      ax[15] = z0; ax[16] = z1; ax[17] = z2;
-      double* y_rows = P.Yt + (size_t)(3 * j) * P.RP;
-      y_rows[6 * W] = y0; y_rows[P.RP + 6 * W] = y1; y_rows[2 * P.RP + 6 * W] = y2;
-      for (int i = 0; i < W; i++) {
-        const double* ob = P.obs + ((size_t)i * N + j) * 2;
-        ba_obs_lin o;
-        double* d0 = y_rows + 6 * i;
-        if (!ba_linearize_obs<true>(s_K, s_cam + BA_CAM * i, X, ob[0], ob[1], prm.delta, o)) {
+    for (int wv = 0; wv < BA_WAVES; wv++) gm = fmax(gm, s_gmax[wv]);
+    P.gmax[blockIdx.x] = gm;
+  }
+  __syncthreads();
+  // ---- Y^ panel of this workgroup in LDS: row 3 pl + c, columns 6 slot .. 6 slot + 5, column 6W = y ----
+  const int pitch = P.pitch;
+  if (slot < W) {
+    double* r0 = dyn + (size_t)(3 * pl) * pitch + 6 * slot;
 #pragma unroll
-          for (int a = 0; a < 6; a++) { d0[a] = 0; d0[P.RP + a] = 0; d0[2 * P.RP + a] = 0; }
-          continue;
-        }
-#pragma unroll
-        for (int a = 0; a < 6; a++) {
-          const double b0 = o.w * (o.Jp[0][a] * o.Jl[0][0] + o.Jp[1][a] * o.Jl[1][0]);
-          const double b1 = o.w * (o.Jp[0][a] * o.Jl[0][1] + o.Jp[1][a] * o.Jl[1][1]);
-          const double b2 = o.w * (o.Jp[0][a] * o.Jl[0][2] + o.Jp[1][a] * o.Jl[1][2]);
-          d0[a] = b0 * i00;                                   // Y[a][0] = B[a][0] Cinv[0][0]
-          d0[P.RP + a] = b0 * i10 + b1 * i11;                 // Y[a][1]
-          d0[2 * P.RP + a] = b0 * i20 + b1 * i21 + b2 * i22;  // Y[a][2]
-        }
-      }
-    }
-    // block max of |g_l| (deterministic tree)
-    s_red[tid] = gm;
-    __syncthreads();
-    for (int o = BA_LIN_THREADS / 2; o > 0; o >>= 1) {
-      if (tid < o) s_red[tid] = fmax(s_red[tid], s_red[tid + o]);
-      __syncthreads();
-    }
-    if (tid == 0) P.gmax[blockIdx.x] = s_red[0];
-  } else {
-    // ================= camera role: block = (slot, landmark chunk) =================
-    const int b = blockIdx.x - P.n_pblk;
-    const int slot = b / P.n_chunk, chunk = b - slot * P.n_chunk;
-    const int j = chunk * BA_LIN_THREADS + tid;
-    double v[BA_POSE_VALS];
-#pragma unroll
-    for (int q = 0; q < BA_POSE_VALS; q++) v[q] = 0;
-    if (j < N) {
-      const double X[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
-      const double* ob = P.obs + ((size_t)slot * N + j) * 2;
-      ba_obs_lin o;
-      if (ba_linearize_obs<true>(s_K, s_cam + BA_CAM * slot, X, ob[0], ob[1], prm.delta, o)) {
-        int q = 0;
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-          for (int c = a; c < 6; c++) v[q++] = o.w * (o.Jp[0][a] * o.Jp[0][c] + o.Jp[1][a] * o.Jp[1][c]);
-#pragma unroll
-        for (int a = 0; a < 6; a++) v[21 + a] = o.w * (o.Jp[0][a] * o.e0 + o.Jp[1][a] * o.e1);
-        v[27] = 0.5 * o.rho;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < BA_POSE_VALS; q++) s_red[q * BA_LIN_THREADS + tid] = v[q];
-    __syncthreads();
-    // fixed-order reduction: 4 lanes per value sum 32 entries each, then combine
-    if (tid < BA_POSE_VALS * 4) {
-      const int q = tid >> 2, part = tid & 3;
-      double s = 0;
-      const double* src = s_red + q * BA_LIN_THREADS + part * (BA_LIN_THREADS / 4);
-      for (int k = 0; k < BA_LIN_THREADS / 4; k++) s += src[k];
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      if (part == 0) P.posepart[((size_t)slot * P.n_chunk + chunk) * BA_POSE_VALS + q] = s;
+    for (int a = 0; a < 6; a++) {
+      const double b0 = o.w * (o.Jp[0][a] * o.Jl[0][0] + o.Jp[1][a] * o.Jl[1][0]);
+      const double b1 = o.w * (o.Jp[0][a] * o.Jl[0][1] + o.Jp[1][a] * o.Jl[1][1]);
+      const double b2 = o.w * (o.Jp[0][a] * o.Jl[0][2] + o.Jp[1][a] * o.Jl[1][2]);
+      r0[a] = b0 * i00;                                   // Y[a][0] = B[a][0] Cinv[0][0]
+      r0[pitch + a] = b0 * i10 + b1 * i11;                // Y[a][1]
+      r0[2 * pitch + a] = b0 * i20 + b1 * i21 + b2 * i22; // Y[a][2]
     }
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_ba_syrk : partial tiles of Yt^T Yt with v_mfma_f64_16x16x4_f64
-//   grid (KS, ceil(n_tiles/4)), block 256 = 4 waves, one upper tile per wave
-//   A[i][k] = Yt[k0+k][16 ta + i]  (lane: i = l&15, k = l>>4),  B[k][j] = Yt[k0+k][16 tb + j]
-//   D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ba_syrk(ba_ptrs P, int it) {
-  const ba_state st = P.state[it & 1];
-  if (st.done) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile = blockIdx.y * 4 + wave;
-  if (tile >= P.n_tiles) return;
-  // tile index -> (ta <= tb)
-  int ta = 0, rem = tile;
-  while (rem >= P.RT - ta) { rem -= P.RT - ta; ta++; }
-  const int tb = ta + rem;
-  const int k_begin = blockIdx.x * P.KL;
-  int k_end = k_begin + P.KL;
-  if (k_end > P.K4) k_end = P.K4;
-  d4 acc = {0.0, 0.0, 0.0, 0.0};
-  const double* base = P.Yt + (size_t)(lane >> 4) * P.RP + (lane & 15);
-  for (int k0 = k_begin; k0 < k_end; k0 += 4) {
-    const double a = base[(size_t)k0 * P.RP + 16 * ta];
-    const double b = base[(size_t)k0 * P.RP + 16 * tb];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  if (slot == 0) {
+    double* r0 = dyn + (size_t)(3 * pl) * pitch;
+    const bool in = j < N;
+    r0[6 * W] = in ? y0 : 0.0; r0[pitch + 6 * W] = in ? y1 : 0.0; r0[2 * pitch + 6 * W] = in ? y2 : 0.0;
+    for (int cidx = 6 * W + 1; cidx < P.RP; cidx++) { r0[cidx] = 0; r0[pitch + cidx] = 0; r0[2 * pitch + cidx] = 0; }
   }
-  double* out = P.tiles + ((size_t)blockIdx.x * P.n_tiles + tile) * 256 + lane * 4;
-  out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2]; out[3] = acc[3];
+  __syncthreads();
+  // ---- Gram matrix of the panel: upper 16x16 tiles, one wave per tile, v_mfma_f64_16x16x4_f64 ----
+  //   A[i][k] = panel[k0 + k][16 ta + i]  (lane: i = l & 15, k = l >> 4),  B[k][j] = panel[k0 + k][16 tb + j]
+  //   D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+  const int krows = 3 * P.PPB;
+  for (int tile = wave; tile < P.n_tiles; tile += BA_WAVES) {
+    int ta = 0, rem = tile;
+    while (rem >= P.RT - ta) { rem -= P.RT - ta; ta++; }
+    const int tb = ta + rem;
+    const double* base = dyn + (size_t)(lane >> 4) * pitch + (lane & 15);
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k0 = 0; k0 < krows; k0 += 4) {
+      const double a = base[(size_t)k0 * pitch + 16 * ta];
+      const double b = base[(size_t)k0 * pitch + 16 * tb];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    double* out = P.tiles + ((size_t)blockIdx.x * P.n_tiles + tile) * 256 + lane * 4;
+    out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2]; out[3] = acc[3];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_ba_solve : one workgroup
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double ba_tile_elem(const double* __restrict__ tiles, int KS, int n_tiles, int RT, int a, int b) {
-  // element (a, b) of Yt^T Yt, any order of a, b (symmetric); sums the K-slice partials in fixed order
-  if (a > b) { const int t = a; a = b; b = t; }
-  const int ta = a >> 4, tb = b >> 4, ii = a & 15, jj = b & 15;
-  const int tile = ta * RT - (ta * (ta - 1)) / 2 + (tb - ta);
-  const int lane = (ii & 3) * 16 + jj, reg = ii >> 2;
-  const double* p = tiles + (size_t)tile * 256 + lane * 4 + reg;
-  double s = 0;
-  for (int ks = 0; ks < KS; ks++) s += p[(size_t)ks * n_tiles * 256];
-  return s;
-}
-
-__global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs P, ba_params_dev prm, int it, double* __restrict__ probe_S,
-                                                               double* __restrict__ hpp_out) {
+__global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_dev prm, int it, double* __restrict__ probe_S,
+                                                         double* __restrict__ hpp_out) {
   extern __shared__ double sm[];
+  __shared__ int s_fail;
   const ba_state st = P.state[it & 1];
   if (st.done) return;
   const int tid = threadIdx.x;
-  const int W = P.W, n = 6 * W, n1 = n + 1, pitch = n1 + 1;
-  double* A = sm;                       // n1 x pitch (lower triangle used), row n = rhs^T
-  double* s_tmp = A + (size_t)n1 * pitch;      // n1
-  double* s_hpp = s_tmp + n1;           // W * 28 reduced pose values
-  double* s_dp = s_hpp + W * BA_POSE_VALS;     // n
-  double* s_misc = s_dp + n;            // 8
-  __shared__ int s_fail;
+  const int W = P.W, n = 6 * W, n1 = n + 1;
+  const int PT = n1 | 1;                       // odd column pitch
+  double* A = sm;                              // column-major lower triangle of [S rhs; rhs^T .], A[col * PT + row]
+  double* s_hpp = A + (size_t)n1 * PT;         // W * 28 reduced camera sums
+  double* s_invd = s_hpp + W * BA_POSE_VALS;   // n inverse diagonal of L
+  double* s_dp = s_invd + n1;                  // n
   if (tid == 0) s_fail = 0;
-  // ---- reduce pose partials ----
-  for (int q = tid; q < W * BA_POSE_VALS; q += BA_SOLVE_THREADS) {
-    const int slot = q / BA_POSE_VALS, k = q - slot * BA_POSE_VALS;
+  // ---- reduce camera partials (fixed order) ----
+  for (int q = tid; q < W * BA_POSE_VALS; q += BA_THREADS) {
     double s = 0;
-    for (int c = 0; c < P.n_chunk; c++) s += P.posepart[((size_t)slot * P.n_chunk + c) * BA_POSE_VALS + k];
+    for (int b = 0; b < P.nblk; b++) s += P.posepart[(size_t)b * W * BA_POSE_VALS + q];
     s_hpp[q] = s;
   }
-  // ---- -E (lower triangle) and r (row n) ----
-  for (int e = tid; e < n1 * n1; e += BA_SOLVE_THREADS) {
-    const int a = e / n1, b = e - a * n1;
-    if (b > a) continue;
-    if (a == n && b == n) { A[(size_t)a * pitch + b] = 1.0; continue; }
-    const double v = ba_tile_elem(P.tiles, P.KS, P.n_tiles, P.RT, a, b);
-    A[(size_t)a * pitch + b] = (a == n) ? v : -v;   // row n: +r ; block: -E
+  // ---- -E (lower triangle) and +r (row n) from the Gram partial tiles ----
+  for (int e = tid; e < n1 * n1; e += BA_THREADS) {
+    const int col = e / n1, row = e - col * n1;       // consecutive threads -> consecutive rows
+    if (row < col) continue;
+    if (row == n && col == n) { A[(size_t)col * PT + row] = 1.0; continue; }
+    // element (a = col, b = row), a <= b, lives in upper tile (ta, tb)
+    const int ta = col >> 4, tb = row >> 4, ii = col & 15, jj = row & 15;
+    const int tile = ta * P.RT - (ta * (ta - 1)) / 2 + (tb - ta);
+    const double* p = P.tiles + (size_t)tile * 256 + ((ii & 3) * 16 + jj) * 4 + (ii >> 2);
+    const size_t stride = (size_t)P.n_tiles * 256;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int b = 0;
+    for (; b + 4 <= P.nblk; b += 4) {
+      const double v0 = p[(size_t)b * stride], v1 = p[(size_t)(b + 1) * stride];
+      const double v2 = p[(size_t)(b + 2) * stride], v3 = p[(size_t)(b + 3) * stride];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; b < P.nblk; b++) s0 += p[(size_t)b * stride];
+    const double v = (s0 + s1) + (s2 + s3);
+    A[(size_t)col * PT + row] = (row == n) ? v : -v;
   }
   __syncthreads();
   // ---- + damped Hpp blocks, rhs = -gp + r ----
   const double lam = st.lambda;
-  for (int q = tid; q < W * 36; q += BA_SOLVE_THREADS) {
-    const int slot = q / 36, rr = (q % 36) / 6, cc = q % 6;
+  for (int q = tid; q < W * 36; q += BA_THREADS) {
+    const int sl = q / 36, rr = (q % 36) / 6, cc = q % 6;
     if (cc > rr) continue;
-    // upper-packed index of (cc, rr), cc <= rr
-    const int idx = cc * 6 - (cc * (cc - 1)) / 2 + (rr - cc);
-    double v = s_hpp[slot * BA_POSE_VALS + idx];
+    const int idx = cc * 6 - (cc * (cc - 1)) / 2 + (rr - cc);   // upper-packed (cc, rr)
+    double v = s_hpp[sl * BA_POSE_VALS + idx];
     if (rr == cc) v += lam * fmax(v, 1e-12);
-    A[(size_t)(6 * slot + rr) * pitch + 6 * slot + cc] += v;
+    A[(size_t)(6 * sl + cc) * PT + 6 * sl + rr] += v;
   }
-  for (int a = tid; a < n; a += BA_SOLVE_THREADS) A[(size_t)n * pitch + a] -= s_hpp[(a / 6) * BA_POSE_VALS + 21 + a % 6];
+  for (int a = tid; a < n; a += BA_THREADS) A[(size_t)a * PT + n] -= s_hpp[(a / 6) * BA_POSE_VALS + 21 + a % 6];
   __syncthreads();
   if (probe_S) {   // reduced camera system before factorisation (parity probe)
-    for (int e = tid; e < n * n; e += BA_SOLVE_THREADS) {
+    for (int e = tid; e < n * n; e += BA_THREADS) {
       const int a = e / n, b = e - a * n;
-      probe_S[e] = (b <= a) ? A[(size_t)a * pitch + b] : A[(size_t)b * pitch + a];
+      probe_S[e] = (b <= a) ? A[(size_t)b * PT + a] : A[(size_t)a * PT + b];
     }
-    for (int a = tid; a < n; a += BA_SOLVE_THREADS) probe_S[(size_t)n * n + a] = A[(size_t)n * pitch + a];
+    for (int a = tid; a < n; a += BA_THREADS) probe_S[(size_t)n * n + a] = A[(size_t)a * PT + n];
   }
-  if (hpp_out) for (int q = tid; q < W * BA_POSE_VALS; q += BA_SOLVE_THREADS) hpp_out[q] = s_hpp[q];
-  // ---- left-looking Cholesky of the augmented matrix; 4 threads per row ----
-  const int row = tid >> 2, part = tid & 3;
-  for (int k = 0; k < n; k++) {
-    double c = 0;
-    if (row >= k && row < n1) {
-      const double* ri = A + (size_t)row * pitch;
-      const double* rk = A + (size_t)k * pitch;
-      for (int j = part; j < k; j += 4) c += ri[j] * rk[j];
+  if (hpp_out) for (int q = tid; q < W * BA_POSE_VALS; q += BA_THREADS) hpp_out[q] = s_hpp[q];
+  // ---- 6x6-blocked right-looking Cholesky of the augmented matrix (row n carries rhs -> y) ----
+  for (int kb = 0; kb < W; kb++) {
+    const int c0 = 6 * kb;
+    const int r = c0 + tid;
+    if (r < n1) {
+      double D[6][6], inv[6], x[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++)
+#pragma unroll
+        for (int d = 0; d < 6; d++) D[c][d] = (d <= c) ? A[(size_t)(c0 + d) * PT + c0 + c] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; c++) x[c] = (r >= c0 + c) ? A[(size_t)(c0 + c) * PT + r] : 0.0;
+      bool bad = false;
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double s = D[c][c];
+#pragma unroll
+        for (int d = 0; d < c; d++) s -= D[c][d] * D[c][d];
+        if (!(s > 0)) { bad = true; s = 1.0; }
+        const double rs = rsqrt_nr(s);
+        D[c][c] = s * rs; inv[c] = rs;
+#pragma unroll
+        for (int e = c + 1; e < 6; e++) {
+          double t = D[e][c];
+#pragma unroll
+          for (int d = 0; d < c; d++) t -= D[e][d] * D[c][d];
+          D[e][c] = t * rs;
+        }
+      }
+      if (bad && tid == 0) s_fail = 1;
+      if (tid < 6) {
+        // rows of the diagonal block itself
+#pragma unroll
+        for (int c = 0; c < 6; c++) if (c <= tid) {
+          double v = 0;
+#pragma unroll
+          for (int t6 = 0; t6 < 6; t6++) if (t6 == tid) v = D[t6][c];
+          A[(size_t)(c0 + c) * PT + r] = v;
+        }
+        if (tid == 0) {
+#pragma unroll
+          for (int c = 0; c < 6; c++) s_invd[c0 + c] = inv[c];
+        }
+      } else {
+        // x L_kk^T = a  (forward substitution along the row)
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          double t = x[c];
+#pragma unroll
+          for (int d = 0; d < c; d++) t -= x[d] * D[c][d];
+          x[c] = t * inv[c];
+          A[(size_t)(c0 + c) * PT + r] = x[c];
+        }
+      }
     }
-    c += __shfl_xor(c, 1);
-    c += __shfl_xor(c, 2);
-    if (part == 0 && row >= k && row < n1) s_tmp[row] = A[(size_t)row * pitch + k] - c;
     __syncthreads();
-    const double ck = s_tmp[k];
-    if (!(ck > 0)) { if (tid == 0) s_fail = 1; }
-    const double dinv = 1.0 / sqrt(ck > 0 ? ck : 1.0);
-    if (part == 0 && row >= k && row < n1) A[(size_t)row * pitch + k] = (row == k) ? sqrt(ck > 0 ? ck : 1.0) : s_tmp[row] * dinv;
+    const int s0 = c0 + 6, m = n1 - s0;
+    for (int idx = tid; idx < m * m; idx += BA_THREADS) {
+      const int jj = idx / m, ii = idx - jj * m;
+      if (jj > ii) continue;
+      const int i = s0 + ii, jcol = s0 + jj;
+      if (i == n && jcol == n) continue;
+      double acc = A[(size_t)jcol * PT + i];
+#pragma unroll
+      for (int c = 0; c < 6; c++) acc -= A[(size_t)(c0 + c) * PT + i] * A[(size_t)(c0 + c) * PT + jcol];
+      A[(size_t)jcol * PT + i] = acc;
+    }
     __syncthreads();
   }
-  // ---- back substitution  L^T dp = y  (y = row n of A) ----
-  for (int a = tid; a < n; a += BA_SOLVE_THREADS) s_dp[a] = A[(size_t)n * pitch + a];
+  // ---- back substitution  L^T dp = y  by wave 0 (lane i holds rows i and i + 64) ----
+  if (tid < 64) {
+    const int lane = tid;
+    double y0 = (lane < n) ? A[(size_t)lane * PT + n] : 0.0;
+    double y1 = (lane + 64 < n) ? A[(size_t)(lane + 64) * PT + n] : 0.0;
+    for (int k = n - 1; k >= 0; k--) {
+      const int src = k & 63;
+      const double yk = (k < 64) ? readlane_f64(y0, src) : readlane_f64(y1, src);
+      const double dk = yk * s_invd[k];
+      // L[k][i] = A[i * PT + k], i < k
+      if (lane < k) y0 -= A[(size_t)lane * PT + k] * dk;
+      if (lane + 64 < k) y1 -= A[(size_t)(lane + 64) * PT + k] * dk;
+      if (lane == src) { if (k < 64) y0 = dk; else y1 = dk; }
+    }
+    if (lane < n) s_dp[lane] = y0;
+    if (lane + 64 < n) s_dp[lane + 64] = y1;
+  }
   __syncthreads();
-  for (int k = n - 1; k >= 0; k--) {
-    const double dk = s_dp[k] / A[(size_t)k * pitch + k];
-    __syncthreads();
-    if (tid == 0) s_dp[k] = dk;
-    for (int i = tid; i < k; i += BA_SOLVE_THREADS) s_dp[i] -= A[(size_t)k * pitch + i] * dk;
-    __syncthreads();
-  }
   // ---- publish ----
-  for (int a = tid; a < n; a += BA_SOLVE_THREADS) P.dp[a] = s_fail ? 0.0 : s_dp[a];
+  const int fail = s_fail;
+  for (int a = tid; a < n; a += BA_THREADS) P.dp[a] = fail ? 0.0 : s_dp[a];
   if (tid == 0) {
     const double* poses = P.x[st.cur];
     double cost = 0, pred = 0, step2 = 0, x2 = 0, ginf = 0;
@@ -492,117 +610,133 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs P, ba_par
       for (int a = 0; a < 6; a++) {
         const double g = s_hpp[i * BA_POSE_VALS + 21 + a];
         const int idx = a * 6 - (a * (a - 1)) / 2;
-        const double D = fmax(s_hpp[i * BA_POSE_VALS + idx], 1e-12);
-        const double d = s_fail ? 0.0 : s_dp[6 * i + a];
-        pred += lam * D * d * d - g * d;
+        const double Dg = fmax(s_hpp[i * BA_POSE_VALS + idx], 1e-12);
+        const double d = fail ? 0.0 : s_dp[6 * i + a];
+        pred += lam * Dg * d * d - g * d;
         step2 += d * d;
         x2 += poses[6 * i + a] * poses[6 * i + a];
         ginf = fmax(ginf, fabs(g));
       }
     }
-    for (int b = 0; b < P.n_pblk; b++) ginf = fmax(ginf, P.gmax[b]);
+    for (int b = 0; b < P.nblk; b++) ginf = fmax(ginf, P.gmax[b]);
     ba_info inf;
     inf.cost_cur = cost; inf.pred_pose = pred; inf.step2_pose = step2; inf.x2_pose = x2; inf.ginf = ginf;
-    inf.chol_fail = s_fail; inf.pad = 0;
+    inf.chol_fail = fail; inf.pad = 0;
     *P.info = inf;
   }
-  (void)s_misc;
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_ba_update : back-substitute landmarks, form the trial x, evaluate the trial cost
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BA_LIN_THREADS) k_ba_update(ba_ptrs P, ba_params_dev prm, int it, double* __restrict__ probe_dl) {
-  __shared__ double s_cam[BA_CAM * BA_MAX_SLOTS];
+__global__ void __launch_bounds__(BA_THREADS) k_ba_update(ba_ptrs P, ba_params_dev prm, int it, double* __restrict__ probe_dl) {
+  __shared__ double s_cam[BA_CAM * BA_MAX_SLOTS];    // current poses
+  __shared__ double s_camt[BA_CAM * BA_MAX_SLOTS];   // trial poses
   __shared__ double s_K[9];
   __shared__ double s_dp[6 * BA_MAX_SLOTS];
   __shared__ double s_pose[6 * BA_MAX_SLOTS];
-  __shared__ double s_red[BA_EVAL_VALS * BA_LIN_THREADS];
+  __shared__ double s_red[BA_WAVES * BA_EVAL_VALS];
   const ba_state st = P.state[it & 1];
   if (st.done) return;
-  const int tid = threadIdx.x, W = P.W, N = P.N;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, W = P.W, N = P.N, LPP = P.LPP;
   const double* poses = P.x[st.cur];
   const double* pts = P.x[st.cur] + 6 * W;
   double* tposes = P.x[st.cur ^ 1];
   double* tpts = P.x[st.cur ^ 1] + 6 * W;
-  for (int a = tid; a < 6 * W; a += BA_LIN_THREADS) {
+  for (int a = tid; a < 6 * W; a += BA_THREADS) {
     const double d = P.dp[a];
     s_dp[a] = d;
     s_pose[a] = poses[a] + d;
     if (blockIdx.x == 0) tposes[a] = poses[a] + d;
   }
   if (tid < 9) s_K[tid] = P.K[tid];
+  stage_cameras(poses, W, s_cam, tid, BA_THREADS);
   __syncthreads();
-  stage_cameras(s_pose, W, s_cam, tid, BA_LIN_THREADS);
+  stage_cameras(s_pose, W, s_camt, tid, BA_THREADS);
   __syncthreads();
-  const int j = blockIdx.x * BA_LIN_THREADS + tid;
-  double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+  const int pl = tid / LPP, slot = tid - pl * LPP;
+  const int j = blockIdx.x * P.PPB + pl;
+  double X[3] = {0, 0, 0};
+  double uo = __builtin_nan(""), vo = 0;
+  double v0 = 0, v1 = 0, v2 = 0;
+  if (j < N) {
+    X[0] = pts[3 * j]; X[1] = pts[3 * j + 1]; X[2] = pts[3 * j + 2];
+    if (slot < W) {
+      const double* ob = P.obs + ((size_t)slot * N + j) * 2;
+      uo = ob[0]; vo = ob[1];
+      ba_obs_lin o;
+      if (ba_linearize_obs<true>(s_K, s_cam + BA_CAM * slot, X, uo, vo, prm.delta, o)) {
+        const double* d = s_dp + 6 * slot;
+        double q0 = 0, q1 = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) { q0 += o.Jp[0][a] * d[a]; q1 += o.Jp[1][a] * d[a]; }
+        v0 = o.w * (o.Jl[0][0] * q0 + o.Jl[1][0] * q1);     // B^T d_pose = w Jl^T (Jp d_pose)
+        v1 = o.w * (o.Jl[0][1] * q0 + o.Jl[1][1] * q1);
+        v2 = o.w * (o.Jl[0][2] * q0 + o.Jl[1][2] * q1);
+      }
+    }
+  }
+  v0 = group_allreduce(v0, LPP); v1 = group_allreduce(v1, LPP); v2 = group_allreduce(v2, LPP);
+  double e0 = 0, e1 = 0, e2 = 0, e3 = 0;
   if (j < N) {
     const double* ax = P.aux + (size_t)j * BA_AUX;
-    const double* yr = P.Yt + (size_t)(3 * j) * P.RP;
-    double t0 = 0, t1 = 0, t2 = 0;
-    for (int a = 0; a < 6 * W; a++) {
-      const double d = s_dp[a];
-      t0 += yr[a] * d; t1 += yr[P.RP + a] * d; t2 += yr[2 * P.RP + a] * d;
-    }
+    const double u0 = ax[6] + v0, u1 = ax[7] + v1, u2 = ax[8] + v2;
     const double i00 = ax[9], i10 = ax[10], i11 = ax[11], i20 = ax[12], i21 = ax[13], i22 = ax[14];
-    const double dl0 = -(ax[15] + i00 * t0 + i10 * t1 + i20 * t2);
-    const double dl1 = -(ax[16] + i11 * t1 + i21 * t2);
-    const double dl2 = -(ax[17] + i22 * t2);
-    const double X0[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
-    const double X[3] = {X0[0] + dl0, X0[1] + dl1, X0[2] + dl2};
-    tpts[3 * j] = X[0]; tpts[3 * j + 1] = X[1]; tpts[3 * j + 2] = X[2];
-    if (probe_dl) { probe_dl[3 * j] = dl0; probe_dl[3 * j + 1] = dl1; probe_dl[3 * j + 2] = dl2; }
-    double cost = 0;
-    for (int i = 0; i < W; i++) {
-      const double* ob = P.obs + ((size_t)i * N + j) * 2;
+    const double t0 = i00 * u0, t1 = i10 * u0 + i11 * u1, t2 = i20 * u0 + i21 * u1 + i22 * u2;   // Cinv u
+    const double dl0 = -(i00 * t0 + i10 * t1 + i20 * t2), dl1 = -(i11 * t1 + i21 * t2), dl2 = -(i22 * t2);
+    const double Xt[3] = {X[0] + dl0, X[1] + dl1, X[2] + dl2};
+    if (slot < W) {
       ba_obs_lin o;
-      if (ba_linearize_obs<false>(s_K, s_cam + BA_CAM * i, X, ob[0], ob[1], prm.delta, o)) cost += 0.5 * o.rho;
+      if (ba_linearize_obs<false>(s_K, s_camt + BA_CAM * slot, Xt, uo, vo, prm.delta, o)) e0 = 0.5 * o.rho;
     }
-    const double lam = st.lambda;
-    v0 = cost;
-    v1 = lam * (fmax(ax[0], 1e-12) * dl0 * dl0 + fmax(ax[2], 1e-12) * dl1 * dl1 + fmax(ax[5], 1e-12) * dl2 * dl2)
-         - (ax[6] * dl0 + ax[7] * dl1 + ax[8] * dl2);
-    v2 = dl0 * dl0 + dl1 * dl1 + dl2 * dl2;
-    v3 = X0[0] * X0[0] + X0[1] * X0[1] + X0[2] * X0[2];
+    if (slot == 0) {
+      tpts[3 * j] = Xt[0]; tpts[3 * j + 1] = Xt[1]; tpts[3 * j + 2] = Xt[2];
+      if (probe_dl) { probe_dl[3 * j] = dl0; probe_dl[3 * j + 1] = dl1; probe_dl[3 * j + 2] = dl2; }
+      const double lam = st.lambda;
+      e1 = lam * (fmax(ax[0], 1e-12) * dl0 * dl0 + fmax(ax[2], 1e-12) * dl1 * dl1 + fmax(ax[5], 1e-12) * dl2 * dl2)
+           - (ax[6] * dl0 + ax[7] * dl1 + ax[8] * dl2);
+      e2 = dl0 * dl0 + dl1 * dl1 + dl2 * dl2;
+      e3 = X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+    }
   }
-  s_red[tid] = v0; s_red[BA_LIN_THREADS + tid] = v1; s_red[2 * BA_LIN_THREADS + tid] = v2; s_red[3 * BA_LIN_THREADS + tid] = v3;
+  for (int ofs = 32; ofs > 0; ofs >>= 1) {
+    e0 += __shfl_xor(e0, ofs); e1 += __shfl_xor(e1, ofs); e2 += __shfl_xor(e2, ofs); e3 += __shfl_xor(e3, ofs);
+  }
+  if (lane == 0) { s_red[wave * 4] = e0; s_red[wave * 4 + 1] = e1; s_red[wave * 4 + 2] = e2; s_red[wave * 4 + 3] = e3; }
   __syncthreads();
-  for (int o = BA_LIN_THREADS / 2; o > 0; o >>= 1) {
-    if (tid < o)
-#pragma unroll
-      for (int q = 0; q < BA_EVAL_VALS; q++) s_red[q * BA_LIN_THREADS + tid] += s_red[q * BA_LIN_THREADS + tid + o];
-    __syncthreads();
+  if (tid < BA_EVAL_VALS) {
+    double s = 0;
+    for (int wv = 0; wv < BA_WAVES; wv++) s += s_red[wv * 4 + tid];
+    P.evalpart[blockIdx.x * BA_EVAL_VALS + tid] = s;
   }
-  if (tid < BA_EVAL_VALS) P.evalpart[blockIdx.x * BA_EVAL_VALS + tid] = s_red[tid * BA_LIN_THREADS];
 }
 
 __global__ void k_ba_finalize(ba_ptrs P, ba_params_dev prm, int n_it, double* __restrict__ x_out, ba_state* __restrict__ st_out) {
   __shared__ ba_state s_st;
   if (threadIdx.x == 0) {
     ba_state st;
-    if (n_it == 0) st = P.state[0];
-    else ba_decide(P.state[(n_it - 1) & 1], *P.info, P.evalpart, P.n_eblk, prm, st);
+    if (n_it == 0) st = ba_init_state(prm);
+    else ba_decide(P.state[(n_it - 1) & 1], *P.info, P.evalpart, P.nblk, prm, st);
     s_st = st;
     *st_out = st;
     P.state[n_it & 1] = st;
   }
   __syncthreads();
-  const double* x = P.x[s_st.cur];
+  const double* x = (n_it == 0) ? P.x0 : P.x[s_st.cur];
   const int total = 6 * P.W + 3 * P.N;
   for (int i = threadIdx.x; i < total; i += blockDim.x) x_out[i] = x[i];
 }
 
 // per-observation residual norms at x (dense [W][N], NaN where unobserved) -- parity probe
-__global__ void __launch_bounds__(BA_LIN_THREADS) k_ba_residual(ba_ptrs P, const double* __restrict__ x, double delta,
-                                                                double* __restrict__ res) {
+__global__ void __launch_bounds__(128) k_ba_residual(ba_ptrs P, const double* __restrict__ x, double delta,
+                                                     double* __restrict__ res) {
   __shared__ double s_cam[BA_CAM * BA_MAX_SLOTS];
   __shared__ double s_K[9];
   const int tid = threadIdx.x;
-  stage_cameras(x, P.W, s_cam, tid, BA_LIN_THREADS);
+  stage_cameras(x, P.W, s_cam, tid, 128);
   if (tid < 9) s_K[tid] = P.K[tid];
   __syncthreads();
-  const int j = blockIdx.x * BA_LIN_THREADS + tid;
+  const int j = blockIdx.x * 128 + tid;
   if (j >= P.N) return;
   const double* pts = x + 6 * P.W;
   const double X[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
@@ -621,8 +755,8 @@ __global__ void __launch_bounds__(BA_LIN_THREADS) k_ba_residual(ba_ptrs P, const
 void vo_ba_destroy(vo_ctx* c) {
   if (!c->ba) return;
   vo_ba_ws* b = c->ba;
-  void* bufs[] = {b->d_K, b->d_obs, b->d_x0, b->d_x[0], b->d_x[1], b->d_Yt, b->d_aux, b->d_posepart, b->d_gmax,
-                  b->d_tiles, b->d_dp, b->d_evalpart, b->d_S, b->d_Hpp, b->d_res, b->d_xout, b->d_state, b->d_info};
+  void* bufs[] = {b->d_K, b->d_obs, b->d_x0, b->d_x[0], b->d_x[1], b->d_aux, b->d_posepart, b->d_gmax,
+                  b->d_tiles, b->d_dp, b->d_evalpart, b->d_S, b->d_Hpp, b->d_res, b->d_dl, b->d_xout, b->d_state, b->d_info};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (b->h_state) (void)hipHostFree(b->h_state);
   delete b;
@@ -635,9 +769,18 @@ extern "C" int32_t vo_ba_default_params(vo_ba_params* p) {
   return VO_OK;
 }
 
-static size_t ba_solve_lds(int W) {
-  const int n = 6 * W, n1 = n + 1, pitch = n1 + 1;
-  return sizeof(double) * ((size_t)n1 * pitch + n1 + (size_t)W * BA_POSE_VALS + n + 8);
+static void ba_geometry(vo_ba_ws* b, int W, int N) {
+  b->W = W; b->N = N;
+  b->LPP = (W <= 16) ? 16 : 32;
+  b->PPB = BA_THREADS / b->LPP;
+  b->nblk = vo_div_up(N, b->PPB);
+  b->RP = ((6 * W + 1 + 15) / 16) * 16; b->RT = b->RP / 16; b->n_tiles = b->RT * (b->RT + 1) / 2;
+  b->pitch = b->RP + BA_PITCH_PAD;
+  const size_t panel = sizeof(double) * (size_t)3 * b->PPB * b->pitch;
+  const size_t scratch = sizeof(double) * (size_t)BA_WAVES * b->LPP * BA_POSE_VALS;
+  b->build_lds = panel > scratch ? panel : scratch;
+  const int n1 = 6 * W + 1, PT = n1 | 1;
+  b->solve_lds = sizeof(double) * ((size_t)n1 * PT + (size_t)W * BA_POSE_VALS + n1 + n1 + 8);
 }
 
 static int32_t ba_alloc(vo_ctx* c, int W, int N) {
@@ -648,54 +791,42 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     vo_ba_ws* b = new vo_ba_ws();
     c->ba = b;
     b->cap_W = W; b->cap_N = N;
-    const int RP = ((6 * W + 1 + 15) / 16) * 16, RT = RP / 16;
-    const int K4 = ((3 * N + 3) / 4) * 4;
+    ba_geometry(b, W, N);
     const size_t nx = (size_t)6 * W + 3 * N;
     VO_HIP(c, hipMalloc((void**)&b->d_K, 9 * sizeof(double)));
     VO_HIP(c, hipMalloc((void**)&b->d_obs, sizeof(double) * 2 * W * N));
     VO_HIP(c, hipMalloc((void**)&b->d_x0, sizeof(double) * nx));
     VO_HIP(c, hipMalloc((void**)&b->d_x[0], sizeof(double) * nx));
     VO_HIP(c, hipMalloc((void**)&b->d_x[1], sizeof(double) * nx));
-    VO_HIP(c, hipMalloc((void**)&b->d_Yt, sizeof(double) * (size_t)K4 * RP));
     VO_HIP(c, hipMalloc((void**)&b->d_aux, sizeof(double) * (size_t)N * BA_AUX));
-    const int n_chunk = vo_div_up(N, BA_LIN_THREADS);
-    VO_HIP(c, hipMalloc((void**)&b->d_posepart, sizeof(double) * (size_t)W * n_chunk * BA_POSE_VALS));
-    VO_HIP(c, hipMalloc((void**)&b->d_gmax, sizeof(double) * n_chunk));
-    const int n_tiles = RT * (RT + 1) / 2;
-    VO_HIP(c, hipMalloc((void**)&b->d_tiles, sizeof(double) * (size_t)64 * n_tiles * 256));   // KS <= 64
+    VO_HIP(c, hipMalloc((void**)&b->d_posepart, sizeof(double) * (size_t)b->nblk * W * BA_POSE_VALS));
+    VO_HIP(c, hipMalloc((void**)&b->d_gmax, sizeof(double) * b->nblk));
+    VO_HIP(c, hipMalloc((void**)&b->d_tiles, sizeof(double) * (size_t)b->nblk * b->n_tiles * 256));
     VO_HIP(c, hipMalloc((void**)&b->d_dp, sizeof(double) * 6 * W));
-    VO_HIP(c, hipMalloc((void**)&b->d_evalpart, sizeof(double) * n_chunk * BA_EVAL_VALS));
+    VO_HIP(c, hipMalloc((void**)&b->d_evalpart, sizeof(double) * b->nblk * BA_EVAL_VALS));
     VO_HIP(c, hipMalloc((void**)&b->d_S, sizeof(double) * ((size_t)36 * W * W + 6 * W)));
     VO_HIP(c, hipMalloc((void**)&b->d_Hpp, sizeof(double) * (size_t)W * BA_POSE_VALS));
     VO_HIP(c, hipMalloc((void**)&b->d_res, sizeof(double) * (size_t)W * N));
+    VO_HIP(c, hipMalloc((void**)&b->d_dl, sizeof(double) * (size_t)3 * N));
     VO_HIP(c, hipMalloc((void**)&b->d_xout, sizeof(double) * nx));
     VO_HIP(c, hipMalloc((void**)&b->d_state, sizeof(ba_state) * 2));
     VO_HIP(c, hipMalloc((void**)&b->d_info, sizeof(ba_info)));
     VO_HIP(c, hipHostMalloc((void**)&b->h_state, sizeof(ba_state) * 2, hipHostMallocDefault));
-    VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)ba_solve_lds(BA_MAX_SLOTS)));
+    VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
+    VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
   }
-  vo_ba_ws* b = c->ba;
-  b->W = W; b->N = N;
-  b->RP = ((6 * W + 1 + 15) / 16) * 16; b->RT = b->RP / 16; b->n_tiles = b->RT * (b->RT + 1) / 2;
-  b->K4 = ((3 * N + 3) / 4) * 4;
-  b->n_chunk = vo_div_up(N, BA_LIN_THREADS); b->n_pblk = b->n_chunk; b->n_eblk = b->n_chunk;
-  // K-slices: ~256 rows (64 MFMA steps) per slice, at most 64 slices
-  int KS = vo_div_up(b->K4, 256);
-  if (KS > 64) KS = 64;
-  if (KS < 1) KS = 1;
-  b->KS = KS;
-  b->KL = ((vo_div_up(b->K4, KS) + 3) / 4) * 4;
+  ba_geometry(c->ba, W, N);
+  VO_CHECK(c, c->ba->build_lds <= 130 * 1024 && c->ba->solve_lds <= 130 * 1024, VO_E_CAPACITY, "window too large for LDS");
   return VO_OK;
 }
 
 static ba_ptrs ba_make_ptrs(vo_ba_ws* b) {
   ba_ptrs P;
-  P.K = b->d_K; P.obs = b->d_obs; P.x[0] = b->d_x[0]; P.x[1] = b->d_x[1]; P.Yt = b->d_Yt; P.aux = b->d_aux;
+  P.K = b->d_K; P.obs = b->d_obs; P.x0 = b->d_x0; P.x[0] = b->d_x[0]; P.x[1] = b->d_x[1]; P.aux = b->d_aux;
   P.posepart = b->d_posepart; P.gmax = b->d_gmax; P.tiles = b->d_tiles; P.dp = b->d_dp; P.evalpart = b->d_evalpart;
   P.state = b->d_state; P.info = b->d_info;
-  P.W = b->W; P.N = b->N; P.RP = b->RP; P.n_chunk = b->n_chunk; P.n_pblk = b->n_pblk; P.n_eblk = b->n_eblk;
-  P.KS = b->KS; P.KL = b->KL; P.K4 = b->K4; P.n_tiles = b->n_tiles; P.RT = b->RT;
+  P.W = b->W; P.N = b->N; P.LPP = b->LPP; P.PPB = b->PPB; P.nblk = b->nblk; P.RP = b->RP; P.RT = b->RT;
+  P.n_tiles = b->n_tiles; P.pitch = b->pitch;
   return P;
 }
 
@@ -719,36 +850,31 @@ extern "C" int32_t vo_ba_upload(vo_ctx* c, const double* K, const double* poses,
   VO_HIP(c, hipMemcpyAsync(b->d_obs, obs, sizeof(double) * 2 * W * N, hipMemcpyHostToDevice, c->stream));
   VO_HIP(c, hipMemcpyAsync(b->d_x0, poses, sizeof(double) * 6 * W, hipMemcpyHostToDevice, c->stream));
   VO_HIP(c, hipMemcpyAsync(b->d_x0 + 6 * W, points, sizeof(double) * 3 * N, hipMemcpyHostToDevice, c->stream));
-  VO_HIP(c, hipMemsetAsync(b->d_Yt, 0, sizeof(double) * (size_t)b->K4 * b->RP, c->stream));   // zero padding rows / columns
   VO_HIP(c, hipStreamSynchronize(c->stream));
   b->uploaded = true;
   return VO_OK;
 }
 
+static void ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& prm, int it, double probe_lambda,
+                           double* probe_S, double* hpp_out, double* probe_dl) {
+  vo_ba_ws* b = c->ba;
+  hipLaunchKernelGGL(k_ba_build, dim3(b->nblk), dim3(BA_THREADS), b->build_lds, c->stream, P, prm, it, probe_lambda);
+  hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(BA_THREADS), b->solve_lds, c->stream, P, prm, it, probe_S, hpp_out);
+  hipLaunchKernelGGL(k_ba_update, dim3(b->nblk), dim3(BA_THREADS), 0, c->stream, P, prm, it, probe_dl);
+}
+
 // enqueue `n_it` LM iterations starting at iteration index `it0` (state must be in place)
 static int32_t ba_enqueue_iters(vo_ctx* c, const ba_params_dev& prm, int it0, int n_it) {
-  vo_ba_ws* b = c->ba;
   vo_prof_scope prof(c, VO_PROF_BA);
-  const ba_ptrs P = ba_make_ptrs(b);
-  const size_t lds = ba_solve_lds(b->W);
-  for (int it = it0; it < it0 + n_it; it++) {
-    hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_pblk + b->W * b->n_chunk), dim3(BA_LIN_THREADS), 0, c->stream, P, prm, it, -1.0);
-    hipLaunchKernelGGL(k_ba_syrk, dim3(b->KS, vo_div_up(b->n_tiles, 4)), dim3(256), 0, c->stream, P, it);
-    hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(BA_SOLVE_THREADS), lds, c->stream, P, prm, it, (double*)nullptr, (double*)nullptr);
-    hipLaunchKernelGGL(k_ba_update, dim3(b->n_eblk), dim3(BA_LIN_THREADS), 0, c->stream, P, prm, it, (double*)nullptr);
-  }
+  const ba_ptrs P = ba_make_ptrs(c->ba);
+  for (int it = it0; it < it0 + n_it; it++) ba_launch_iter(c, P, prm, it, -1.0, nullptr, nullptr, nullptr);
   VO_HIP(c, hipGetLastError());
   return VO_OK;
 }
 
+// nothing to enqueue: iteration 0 of k_ba_build initialises the state and seeds x[0] from the uploaded x0
 static int32_t ba_begin(vo_ctx* c, const vo_ba_params* prm) {
-  vo_ba_ws* b = c->ba;
-  const size_t nx = (size_t)6 * b->W + 3 * b->N;
-  VO_HIP(c, hipMemcpyAsync(b->d_x[0], b->d_x0, sizeof(double) * nx, hipMemcpyDeviceToDevice, c->stream));
-  ba_state* s = b->h_state;
-  s->lambda = prm->lambda0; s->nu = 2.0; s->cost = 0; s->cost0 = 0;
-  s->cur = 0; s->iter = 0; s->accepted = 0; s->status = 0; s->done = 0; s->n_obs = 0;
-  VO_HIP(c, hipMemcpyAsync(b->d_state, s, sizeof(ba_state), hipMemcpyHostToDevice, c->stream));
+  (void)c; (void)prm;
   return VO_OK;
 }
 
@@ -764,7 +890,6 @@ extern "C" int32_t vo_ba_solve_resident(vo_ctx* c, const vo_ba_params* prm) {
   const ba_params_dev d = ba_dev_params(prm);
   r = ba_enqueue_iters(c, d, 0, prm->max_iters);
   if (r != VO_OK) return r;
-  // publish: final decision + x_cur -> d_xout; results are read by vo_ba_fetch
   vo_ba_ws* b = c->ba;
   const ba_ptrs P = ba_make_ptrs(b);
   hipLaunchKernelGGL(k_ba_finalize, dim3(1), dim3(256), 0, c->stream, P, d, prm->max_iters, b->d_xout, b->d_state + 0);
@@ -808,21 +933,17 @@ extern "C" int32_t vo_ba_adjust(vo_ctx* c, const double* K, const double* poses,
   // iterations are enqueued in chunks; between chunks the host peeks at the state to stop early
   const int CH = 4;
   int it = 0;
-  while (it < prm->max_iters) {
+  do {
     const int n = (prm->max_iters - it < CH) ? prm->max_iters - it : CH;
-    r = ba_enqueue_iters(c, d, it, n);
-    if (r != VO_OK) return r;
-    it += n;
+    if (n > 0) {
+      r = ba_enqueue_iters(c, d, it, n);
+      if (r != VO_OK) return r;
+      it += n;
+    }
     hipLaunchKernelGGL(k_ba_finalize, dim3(1), dim3(256), 0, c->stream, P, d, it, b->d_xout, b->d_state + (it & 1));
     VO_HIP(c, hipMemcpyAsync(b->h_state, b->d_state + (it & 1), sizeof(ba_state), hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipStreamSynchronize(c->stream));
-    if (b->h_state[0].done) break;
-  }
-  if (prm->max_iters == 0) {
-    hipLaunchKernelGGL(k_ba_finalize, dim3(1), dim3(256), 0, c->stream, P, d, 0, b->d_xout, b->d_state + 0);
-    VO_HIP(c, hipMemcpyAsync(b->h_state, b->d_state, sizeof(ba_state), hipMemcpyDeviceToHost, c->stream));
-    VO_HIP(c, hipStreamSynchronize(c->stream));
-  }
+  } while (!b->h_state[0].done && it < prm->max_iters);
   VO_HIP(c, hipMemcpy(poses_out, b->d_xout, sizeof(double) * 6 * b->W, hipMemcpyDeviceToHost));
   VO_HIP(c, hipMemcpy(points_out, b->d_xout + 6 * b->W, sizeof(double) * 3 * b->N, hipMemcpyDeviceToHost));
   if (stats) {
@@ -849,20 +970,14 @@ extern "C" int32_t vo_ba_probe(vo_ctx* c, double lambda, double huber_delta, dou
   if (r != VO_OK) return r;
   const ba_params_dev d = ba_dev_params(&prm);
   const ba_ptrs P = ba_make_ptrs(b);
-  const size_t lds = ba_solve_lds(W);
-  hipLaunchKernelGGL(k_ba_residual, dim3(b->n_chunk), dim3(BA_LIN_THREADS), 0, c->stream, P, b->d_x0, huber_delta, b->d_res);
-  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_pblk + W * b->n_chunk), dim3(BA_LIN_THREADS), 0, c->stream, P, d, 0, lambda);
-  hipLaunchKernelGGL(k_ba_syrk, dim3(b->KS, vo_div_up(b->n_tiles, 4)), dim3(256), 0, c->stream, P, 0);
-  hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(BA_SOLVE_THREADS), lds, c->stream, P, d, 0, b->d_S, b->d_Hpp);
-  // d_points land in the front of the eval scratch-free buffer: reuse d_x[1] after the update via probe_dl
-  double* d_dl = nullptr;
-  VO_HIP(c, hipMalloc((void**)&d_dl, sizeof(double) * 3 * N));
-  hipLaunchKernelGGL(k_ba_update, dim3(b->n_eblk), dim3(BA_LIN_THREADS), 0, c->stream, P, d, 0, d_dl);
+  hipLaunchKernelGGL(k_ba_residual, dim3(vo_div_up(N, 128)), dim3(128), 0, c->stream, P, b->d_x0, huber_delta, b->d_res);
+  ba_launch_iter(c, P, d, 0, lambda, b->d_S, b->d_Hpp, b->d_dl);
   VO_HIP(c, hipGetLastError());
   VO_HIP(c, hipStreamSynchronize(c->stream));
   // ---- copy out ----
-  double* h = (double*)malloc(sizeof(double) * ((size_t)W * N + (size_t)N * BA_AUX + (size_t)W * BA_POSE_VALS + (size_t)n * n + n + n + 3 * (size_t)N));
-  if (!h) { (void)hipFree(d_dl); return vo_fail(c, VO_E_NOMEM, "probe host buffer"); }
+  const size_t total = (size_t)W * N + (size_t)N * BA_AUX + (size_t)W * BA_POSE_VALS + (size_t)n * n + n + n + 3 * (size_t)N;
+  double* h = (double*)malloc(sizeof(double) * total);
+  if (!h) return vo_fail(c, VO_E_NOMEM, "probe host buffer");
   double* h_res = h; double* h_aux = h_res + (size_t)W * N; double* h_hpp = h_aux + (size_t)N * BA_AUX;
   double* h_S = h_hpp + (size_t)W * BA_POSE_VALS; double* h_dp = h_S + (size_t)n * n + n; double* h_dl = h_dp + n;
   hipError_t e = hipMemcpy(h_res, b->d_res, sizeof(double) * (size_t)W * N, hipMemcpyDeviceToHost);
@@ -870,8 +985,7 @@ extern "C" int32_t vo_ba_probe(vo_ctx* c, double lambda, double huber_delta, dou
   if (e == hipSuccess) e = hipMemcpy(h_hpp, b->d_Hpp, sizeof(double) * (size_t)W * BA_POSE_VALS, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(h_S, b->d_S, sizeof(double) * ((size_t)n * n + n), hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(h_dp, b->d_dp, sizeof(double) * n, hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(h_dl, d_dl, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToHost);
-  (void)hipFree(d_dl);
+  if (e == hipSuccess) e = hipMemcpy(h_dl, b->d_dl, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToHost);
   if (e != hipSuccess) { free(h); return vo_fail(c, VO_E_HIP, std::string("probe copy: ") + hipGetErrorString(e)); }
   int m = 0;
   double cs = 0;

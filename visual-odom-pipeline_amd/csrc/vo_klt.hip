@@ -72,20 +72,37 @@ __device__ __forceinline__ float uniform_f(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
-// bilinear samples (x512 fixed point -> 5 fractional bits) of the two pixels a lane owns in one step
-__device__ __forceinline__ void sample2(uint32_t T, uint32_t B, int iw00, int iw01, int iw10, int iw11, int& v0, int& v1) {
-  const int t0 = T & 0xff, t1 = (T >> 8) & 0xff, t2 = (T >> 16) & 0xff;
-  const int b0 = B & 0xff, b1 = (B >> 8) & 0xff, b2 = (B >> 16) & 0xff;
-  v0 = (t0 * iw00 + t1 * iw01 + b0 * iw10 + b1 * iw11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-  v1 = (t1 * iw00 + t2 * iw01 + b1 * iw10 + b2 * iw11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// D = a.lo * b.lo + a.hi * b.hi + c  (signed 16-bit halves) -> v_dot2c_i32_i16
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+}
+// (lo16(a) | lo16(b) << 16) -> one v_perm_b32
+__device__ __forceinline__ uint32_t pack_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+// bytes (k, k+1) of a dword widened to two 16-bit halves
+__device__ __forceinline__ uint32_t bytes01(uint32_t t) { return __builtin_amdgcn_perm(0u, t, 0x0c010c00u); }
+__device__ __forceinline__ uint32_t bytes12(uint32_t t) { return __builtin_amdgcn_perm(0u, t, 0x0c020c01u); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_abs(uint32_t a) {
+  const s16x2 v = __builtin_bit_cast(s16x2, a);
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v, -v));
 }
 
-__device__ __forceinline__ int deriv_interp(uint32_t d00, uint32_t d01, uint32_t d10, uint32_t d11, int hi,
-                                            int iw00, int iw01, int iw10, int iw11) {
-  const int sh = hi ? 16 : 0;
-  const int a = (int)(short)(d00 >> sh), b = (int)(short)(d01 >> sh);
-  const int c = (int)(short)(d10 >> sh), d = (int)(short)(d11 >> sh);
-  return (a * iw00 + b * iw01 + c * iw10 + d * iw11 + (1 << (W_BITS - 1))) >> W_BITS;
+// bilinear samples (5 fractional bits) of the two pixels a lane owns in one step, packed (v0 | v1 << 16).
+// T/B: top / bottom row dwords (3 useful bytes each); wt = iw00 | iw01 << 16, wb = iw10 | iw11 << 16.
+__device__ __forceinline__ uint32_t sample2(uint32_t T, uint32_t B, uint32_t wt, uint32_t wb) {
+  const int v0 = dot2(bytes01(B), wb, dot2(bytes01(T), wt, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+  const int v1 = dot2(bytes12(B), wb, dot2(bytes12(T), wt, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+  return pack_lo((uint32_t)v0, (uint32_t)v1);
+}
+
+// interpolated derivative of one pixel: top pair / bottom pair already gathered as (left | right << 16)
+__device__ __forceinline__ int deriv1(uint32_t top, uint32_t bot, uint32_t wt, uint32_t wb) {
+  return dot2(bot, wb, dot2(top, wt, 1 << (W_BITS - 1))) >> W_BITS;
 }
 
 __global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __restrict__ p0, float* __restrict__ p1,
@@ -104,16 +121,9 @@ __global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __res
   int st = 1;
   float errv = 0.f;
 
-  // per-lane validity of its 16 template pixels (bit 2s+k)
-  uint32_t vmask = 0;
-#pragma unroll
-  for (int s = 0; s < 8; s++) {
-    const int row = 4 * s + r;
-    if (row < win) {
-      if (2 * cp < win) vmask |= 1u << (2 * s);
-      if (2 * cp + 1 < win) vmask |= 1u << (2 * s + 1);
-    }
-  }
+  // validity of the lane's two columns as 16-bit masks (lo = column 2cp, hi = column 2cp + 1)
+  const uint32_t colmask = ((2 * cp < win) ? 0x0000FFFFu : 0u) | ((2 * cp + 1 < win) ? 0xFFFF0000u : 0u);
+  const uint32_t colones = colmask & 0x00010001u;
 
   for (int level = A.top; level >= 0; level--) {
     const klt_level_args L = A.lv[level];
@@ -134,9 +144,10 @@ __global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __res
     }
     int iw00, iw01, iw10, iw11;
     lk_weights(prevx - (float)ipx, prevy - (float)ipy, iw00, iw01, iw10, iw11);
+    const uint32_t wt = pack_lo((uint32_t)iw00, (uint32_t)iw01), wb = pack_lo((uint32_t)iw10, (uint32_t)iw11);
 
-    // ---- template: I (5 frac bits), Ix, Iy at the lane's 16 pixels; exact A11, A12, A22 ----
-    int tI[16], tX[16], tY[16];
+    // ---- template: packed pairs of I (5 frac bits), Ix, Iy for the lane's 16 pixels; exact A11, A12, A22 ----
+    uint32_t tI[8], tX[8], tY[8];
     {
       uint32_t T[8], D0[8], D1[8], D2[8];
       const size_t base = (size_t)(ipy + VO_PAD + r) * L.pitch + (size_t)(ipx + VO_PAD + 2 * cp);
@@ -154,23 +165,19 @@ __global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __res
         const uint32_t E0 = quad_rot1(r == 0 ? D0[sn] : D0[s]);
         const uint32_t E1 = quad_rot1(r == 0 ? D1[sn] : D1[s]);
         const uint32_t E2 = quad_rot1(r == 0 ? D2[sn] : D2[s]);
-        int v0, v1;
-        sample2(T[s], B, iw00, iw01, iw10, iw11, v0, v1);
-        int x0 = deriv_interp(D0[s], D1[s], E0, E1, 0, iw00, iw01, iw10, iw11);
-        int y0 = deriv_interp(D0[s], D1[s], E0, E1, 1, iw00, iw01, iw10, iw11);
-        int x1 = deriv_interp(D1[s], D2[s], E1, E2, 0, iw00, iw01, iw10, iw11);
-        int y1 = deriv_interp(D1[s], D2[s], E1, E2, 1, iw00, iw01, iw10, iw11);
-        if (!((vmask >> (2 * s)) & 1)) { x0 = 0; y0 = 0; }
-        if (!((vmask >> (2 * s + 1)) & 1)) { x1 = 0; y1 = 0; }
-        tI[2 * s] = v0; tI[2 * s + 1] = v1;
-        tX[2 * s] = x0; tX[2 * s + 1] = x1;
-        tY[2 * s] = y0; tY[2 * s + 1] = y1;
-        a11 += x0 * x0 + x1 * x1;
-        a12 += x0 * y0 + x1 * y1;
-        a22 += y0 * y0 + y1 * y1;
+        tI[s] = sample2(T[s], B, wt, wb);
+        const int x0 = deriv1(pack_lo(D0[s], D1[s]), pack_lo(E0, E1), wt, wb);
+        const int y0 = deriv1(pack_hi(D0[s], D1[s]), pack_hi(E0, E1), wt, wb);
+        const int x1 = deriv1(pack_lo(D1[s], D2[s]), pack_lo(E1, E2), wt, wb);
+        const int y1 = deriv1(pack_hi(D1[s], D2[s]), pack_hi(E1, E2), wt, wb);
+        const uint32_t m = (4 * s + r < win) ? colmask : 0u;    // rows / columns outside the window contribute nothing
+        const uint32_t xp = pack_lo((uint32_t)x0, (uint32_t)x1) & m, yp = pack_lo((uint32_t)y0, (uint32_t)y1) & m;
+        tX[s] = xp; tY[s] = yp;
+        a11 = dot2(xp, xp, a11);
+        a12 = dot2(xp, yp, a12);
+        a22 = dot2(yp, yp, a22);
       }
       const long long iA11 = wave_sum_i64(a11), iA12 = wave_sum_i64(a12), iA22 = wave_sum_i64(a22);
-      // (kept in registers below)
       const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
       float D = A11 * A22 - A12 * A12;
       const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
@@ -192,6 +199,7 @@ __global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __res
         }
         int jw00, jw01, jw10, jw11;
         lk_weights(nextx - (float)inx, nexty - (float)iny, jw00, jw01, jw10, jw11);
+        const uint32_t jt = pack_lo((uint32_t)jw00, (uint32_t)jw01), jb = pack_lo((uint32_t)jw10, (uint32_t)jw11);
         uint32_t Tj[8];
         const uint8_t* pj = L.imgJ + (size_t)(iny + VO_PAD + r) * L.pitch + (size_t)(inx + VO_PAD + 2 * cp);
 #pragma unroll
@@ -201,11 +209,9 @@ __global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __res
         for (int s = 0; s < 8; s++) {
           const int sn = (s < 7) ? s + 1 : 7;
           const uint32_t B = quad_rot1(r == 0 ? Tj[sn] : Tj[s]);
-          int v0, v1;
-          sample2(Tj[s], B, jw00, jw01, jw10, jw11, v0, v1);
-          const int d0 = v0 - tI[2 * s], d1 = v1 - tI[2 * s + 1];
-          b1 += d0 * tX[2 * s] + d1 * tX[2 * s + 1];
-          b2 += d0 * tY[2 * s] + d1 * tY[2 * s + 1];
+          const uint32_t d = pk_sub(sample2(Tj[s], B, jt, jb), tI[s]);   // (diff0 | diff1 << 16), |diff| <= 8160
+          b1 = dot2(d, tX[s], b1);
+          b2 = dot2(d, tY[s], b2);
         }
         const float fb1 = (float)wave_sum_i64(b1) * FLT_SCALE;
         const float fb2 = (float)wave_sum_i64(b2) * FLT_SCALE;
@@ -232,6 +238,7 @@ __global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __res
         } else {
           int jw00, jw01, jw10, jw11;
           lk_weights(nx - (float)inx, ny - (float)iny, jw00, jw01, jw10, jw11);
+          const uint32_t jt = pack_lo((uint32_t)jw00, (uint32_t)jw01), jb = pack_lo((uint32_t)jw10, (uint32_t)jw11);
           uint32_t Tj[8];
           const uint8_t* pj = L.imgJ + (size_t)(iny + VO_PAD + r) * L.pitch + (size_t)(inx + VO_PAD + 2 * cp);
 #pragma unroll
@@ -241,11 +248,8 @@ __global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __res
           for (int s = 0; s < 8; s++) {
             const int sn = (s < 7) ? s + 1 : 7;
             const uint32_t B = quad_rot1(r == 0 ? Tj[sn] : Tj[s]);
-            int v0, v1;
-            sample2(Tj[s], B, jw00, jw01, jw10, jw11, v0, v1);
-            const int d0 = v0 - tI[2 * s], d1 = v1 - tI[2 * s + 1];
-            if ((vmask >> (2 * s)) & 1) e += d0 < 0 ? -d0 : d0;
-            if ((vmask >> (2 * s + 1)) & 1) e += d1 < 0 ? -d1 : d1;
+            const uint32_t d = pk_abs(pk_sub(sample2(Tj[s], B, jt, jb), tI[s]));
+            e = dot2(d, (4 * s + r < win) ? colones : 0u, e);
           }
           const int ierr = wave_sum_i32(e);
           errv = (float)ierr * 1.f / (float)(32 * win * win);

@@ -30,12 +30,10 @@ struct vo_st_ws {
   float* d_eig = nullptr;
   uint32_t* d_scalars = nullptr;   // [0] max eig bits, [1] n candidates, [2] n out (int), [3] rounds
   unsigned long long* d_cand = nullptr;
-  int32_t* d_cellhead = nullptr;   // grid of linked lists (global, L2 resident)
-  int32_t* d_next = nullptr;       // ST_CAND_CAP
-  uint8_t* d_state = nullptr;      // ST_CAND_CAP
+  float* d_blockmax = nullptr;     // per-workgroup masked maxima of the eigenvalue pass
   float* d_out = nullptr;          // ST_OUT_CAP x 2
   float* d_pts = nullptr;          // uploaded cur_pts (non-resident call)
-  int cell_cap = 0;
+  int n_blockmax = 0;
   int last_max_corners = 0;
 };
 
@@ -98,61 +96,116 @@ __global__ void __launch_bounds__(256) k_st_discs(const float* __restrict__ pts,
 __global__ void __launch_bounds__(256) k_st_vsum_eig(const int32_t* __restrict__ hxx, const int32_t* __restrict__ hxy,
                                                      const int32_t* __restrict__ hyy, const uint8_t* __restrict__ mask,
                                                      int W, int H, int r, float s2, float* __restrict__ eig,
-                                                     uint32_t* __restrict__ scalars) {
+                                                     float* __restrict__ blockmax) {
+  __shared__ float s_m[4];
   const int x = blockIdx.x * 256 + threadIdx.x;
   const int y0 = blockIdx.y * ST_RG;
   float lmax = 0.f;
   if (x < W) {
     int32_t sa = 0, sb = 0, sc = 0;
-    for (int j = -r; j <= r; j++) {
+    int j = -r;
+    for (; j + 3 <= r; j += 4) {   // 12 independent loads in flight per step
+      const size_t o0 = (size_t)st_reflect101(y0 + j, H) * W + x, o1 = (size_t)st_reflect101(y0 + j + 1, H) * W + x;
+      const size_t o2 = (size_t)st_reflect101(y0 + j + 2, H) * W + x, o3 = (size_t)st_reflect101(y0 + j + 3, H) * W + x;
+      const int32_t a0 = hxx[o0], a1 = hxx[o1], a2 = hxx[o2], a3 = hxx[o3];
+      const int32_t b0 = hxy[o0], b1 = hxy[o1], b2 = hxy[o2], b3 = hxy[o3];
+      const int32_t c0 = hyy[o0], c1 = hyy[o1], c2 = hyy[o2], c3 = hyy[o3];
+      sa += (a0 + a1) + (a2 + a3); sb += (b0 + b1) + (b2 + b3); sc += (c0 + c1) + (c2 + c3);
+    }
+    for (; j <= r; j++) {
       const size_t o = (size_t)st_reflect101(y0 + j, H) * W + x;
       sa += hxx[o]; sb += hxy[o]; sc += hyy[o];
     }
+    // sliding window: all 6 * (ST_RG - 1) loads are independent of the running sums -> issue them up front
+    int32_t da[ST_RG], db[ST_RG], dc[ST_RG];
+    uint8_t mk[ST_RG];
+#pragma unroll
+    for (int k = 0; k < ST_RG; k++) {
+      const int y = min(y0 + k, H - 1);
+      mk[k] = mask[(size_t)y * W + x];
+      if (k == 0) { da[0] = db[0] = dc[0] = 0; continue; }
+      const size_t on = (size_t)st_reflect101(y + r, H) * W + x, oo = (size_t)st_reflect101(y - r - 1, H) * W + x;
+      da[k] = hxx[on] - hxx[oo]; db[k] = hxy[on] - hxy[oo]; dc[k] = hyy[on] - hyy[oo];
+    }
+#pragma unroll
     for (int k = 0; k < ST_RG; k++) {
       const int y = y0 + k;
-      if (y >= H) break;
-      if (k > 0) {
-        const size_t on = (size_t)st_reflect101(y + r, H) * W + x, oo = (size_t)st_reflect101(y - r - 1, H) * W + x;
-        sa += hxx[on] - hxx[oo]; sb += hxy[on] - hxy[oo]; sc += hyy[on] - hyy[oo];
+      sa += da[k]; sb += db[k]; sc += dc[k];
+      if (y < H) {
+        const float a = ((float)sa * s2) * 0.5f, b = (float)sb * s2, c = ((float)sc * s2) * 0.5f;
+        const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+        eig[(size_t)y * W + x] = e;
+        if (mk[k] && e > lmax) lmax = e;
       }
-      const float a = ((float)sa * s2) * 0.5f, b = (float)sb * s2, c = ((float)sc * s2) * 0.5f;
-      const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-      eig[(size_t)y * W + x] = e;
-      if (mask[(size_t)y * W + x] && e > lmax) lmax = e;
     }
   }
-  // wave max, one atomic per wave; positive floats order like their bit patterns
+  // block max -> one float per block (the next kernel reduces them; max is order independent)
   for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-  if ((threadIdx.x & 63) == 0 && lmax > 0.f) atomicMax(&scalars[0], __float_as_uint(lmax));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = lmax;
+  __syncthreads();
+  if (threadIdx.x == 0) blockmax[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
 }
 
+#define ST_NMS_ROWS 8
 __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, const uint8_t* __restrict__ mask, int W,
-                                                int H, double quality, unsigned long long* __restrict__ cand,
-                                                uint32_t* __restrict__ scalars) {
-  const int x = blockIdx.x * 256 + threadIdx.x + 1;
-  const int y = blockIdx.y + 1;
-  if (x >= W - 1 || y >= H - 1) return;
-  const float maxv = __uint_as_float(scalars[0]);
+                                                int H, double quality, const float* __restrict__ blockmax, int n_blockmax,
+                                                unsigned long long* __restrict__ cand, uint32_t* __restrict__ scalars) {
+  __shared__ float s_m[4];
+  __shared__ unsigned int s_cnt, s_base;
+  __shared__ unsigned long long s_list[256 * ST_NMS_ROWS / 2];
+  const int tid = threadIdx.x;
+  // ---- global masked maximum (minMaxLoc) from the per-block maxima ----
+  float m = 0.f;
+  for (int i = tid; i < n_blockmax; i += 256) m = fmaxf(m, blockmax[i]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) s_m[tid >> 6] = m;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  const float maxv = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) scalars[0] = __float_as_uint(maxv);
   const float thr = (float)((double)maxv * quality);
-  const size_t o = (size_t)y * W + x;
-  const float v = eig[o];
-  if (!(v > thr) || v == 0.f || !mask[o]) return;
-  const float* e = eig + o;
-  const bool ismax = e[-W - 1] <= v && e[-W] <= v && e[-W + 1] <= v && e[-1] <= v && e[1] <= v &&
-                     e[W - 1] <= v && e[W] <= v && e[W + 1] <= v;
-  if (!ismax) return;
-  const uint32_t pos = atomicAdd(&scalars[1], 1u);
-  if (pos < ST_CAND_CAP) cand[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(uint32_t)o;
+  const int x = blockIdx.x * 256 + tid + 1;
+  if (x < W - 1) {
+#pragma unroll
+    for (int ry = 0; ry < ST_NMS_ROWS; ry++) {
+      const int y = blockIdx.y * ST_NMS_ROWS + ry + 1;
+      if (y >= H - 1) break;
+      const size_t o = (size_t)y * W + x;
+      const float v = eig[o];
+      if (!(v > thr) || v == 0.f || !mask[o]) continue;
+      const float* e = eig + o;
+      const bool ismax = e[-W - 1] <= v && e[-W] <= v && e[-W + 1] <= v && e[-1] <= v && e[1] <= v &&
+                         e[W - 1] <= v && e[W] <= v && e[W + 1] <= v;
+      if (!ismax) continue;
+      const unsigned int pos = atomicAdd(&s_cnt, 1u);        // LDS; 3x3 maxima cannot be adjacent -> <= 1/4 of the pixels
+      s_list[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(uint32_t)o;
+    }
+  }
+  __syncthreads();
+  const unsigned int cnt = s_cnt;
+  if (tid == 0 && cnt) s_base = atomicAdd(&scalars[1], cnt);   // one global atomic per workgroup
+  __syncthreads();
+  for (unsigned int i = tid; i < cnt; i += 256) {
+    const unsigned int pos = s_base + i;
+    if (pos < ST_CAND_CAP) cand[pos] = s_list[i];
+  }
 }
 
+// LDS map of k_st_select (144 KB): sort phase: keys u64 [n2 <= 16384] at 0.
+// selection phase (keys dead): xy u32 [n] at 0 | cell heads u32 [<= 8192] at 64 KB | next u16 [n] at 96 KB | state u8 [n] at 128 KB
+#define ST_SEL_LDS (144 * 1024)
+#define ST_MAX_CELLS 8192
 __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __restrict__ cand,
                                                     uint32_t* __restrict__ scalars, int W, int H, int cell, int gw, int gh,
-                                                    double md2, int use_dist, int max_corners,
-                                                    int32_t* __restrict__ cellhead, int32_t* __restrict__ nxt,
-                                                    volatile uint8_t* __restrict__ state, float* __restrict__ out) {
-  extern __shared__ unsigned long long keys[];   // n2 keys, then scan scratch
+                                                    double md2, int use_dist, int max_corners, float* __restrict__ out) {
+  extern __shared__ unsigned char smem[];
   __shared__ int s_flag;
   __shared__ int s_scan[1024];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+  uint32_t* xy = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* heads = reinterpret_cast<uint32_t*>(smem + 64 * 1024);
+  uint16_t* nxt = reinterpret_cast<uint16_t*>(smem + 96 * 1024);
+  volatile uint8_t* state = reinterpret_cast<volatile uint8_t*>(smem + 128 * 1024);
   const int tid = threadIdx.x;
   const uint32_t ncand = scalars[1];
   if (ncand > ST_CAND_CAP) { if (tid == 0) scalars[2] = 0xFFFFFFFFu; return; }   // host reports VO_E_CAPACITY
@@ -160,9 +213,8 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
   int n2 = 1;
   while (n2 < n) n2 <<= 1;
   for (int i = tid; i < n2; i += 1024) keys[i] = (i < n) ? cand[i] : 0ull;
-  for (int i = tid; i < gw * gh; i += 1024) cellhead[i] = -1;
   __syncthreads();
-  // ---- bitonic sort, descending ----
+  // ---- bitonic sort, descending: (value desc, index desc) = OpenCV's greaterThanPtr order ----
   for (int k = 2; k <= n2; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int i = tid; i < n2; i += 1024) {
@@ -175,36 +227,54 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
       }
       __syncthreads();
     }
-  // ---- grid lists (rank = index into keys) ----
-  for (int i = tid; i < n; i += 1024) {
-    const int idx = (int)(uint32_t)keys[i];
-    const int y = idx / W, x = idx - y * W;
-    const int cidx = (y / cell) * gw + (x / cell);
-    state[i] = use_dist ? 0 : 1;
-    if (use_dist) nxt[i] = atomicExch(&cellhead[cidx], i);
+  // ---- keys -> packed (x, y) in rank order (read everything before overwriting the aliased region) ----
+  uint32_t myxy[ST_CAND_CAP / 1024];
+#pragma unroll
+  for (int q = 0; q < ST_CAND_CAP / 1024; q++) {
+    const int i = tid + q * 1024;
+    uint32_t v = 0;
+    if (i < n) {
+      const int idx = (int)(uint32_t)keys[i];
+      const int y = idx / W, x = idx - y * W;
+      v = (uint32_t)x | ((uint32_t)y << 16);
+    }
+    myxy[q] = v;
   }
-  __threadfence_block();
   __syncthreads();
-  // ---- greedy min-distance selection as monotone parallel rounds ----
+#pragma unroll
+  for (int q = 0; q < ST_CAND_CAP / 1024; q++) {
+    const int i = tid + q * 1024;
+    if (i < n) { xy[i] = myxy[q]; state[i] = use_dist ? 0 : 1; }
+  }
+  for (int i = tid; i < gw * gh; i += 1024) heads[i] = 0xFFFFu;
+  __syncthreads();
   if (use_dist) {
-    for (int round = 0; round < n + 1; round++) {
+    // ---- grid of linked lists (acceleration structure only: any cell size >= min_distance gives the same result) ----
+    for (int i = tid; i < n; i += 1024) {
+      const uint32_t p = xy[i];
+      const int x = p & 0xFFFF, y = p >> 16;
+      nxt[i] = (uint16_t)atomicExch(&heads[(y / cell) * gw + (x / cell)], (uint32_t)i);
+    }
+    __syncthreads();
+    // ---- greedy min-distance selection as monotone parallel rounds: a candidate is accepted iff every
+    //      higher-ranked candidate closer than min_distance is rejected (== the sequential scan) ----
+    for (int round = 0; round <= n; round++) {
       if (tid == 0) s_flag = 0;
       __syncthreads();
       bool undecided = false;
       for (int i = tid; i < n; i += 1024) {
         if (state[i] != 0) continue;
-        const int idx = (int)(uint32_t)keys[i];
-        const int y = idx / W, x = idx - y * W;
+        const uint32_t p = xy[i];
+        const int x = p & 0xFFFF, y = p >> 16;
         const int xc = x / cell, yc = y / cell;
         const int x1 = max(xc - 1, 0), y1 = max(yc - 1, 0), x2 = min(xc + 1, gw - 1), y2 = min(yc + 1, gh - 1);
         bool any_acc = false, any_und = false;
         for (int yy = y1; yy <= y2; yy++)
           for (int xx = x1; xx <= x2; xx++)
-            for (int q = cellhead[yy * gw + xx]; q >= 0; q = nxt[q]) {
-              if (q >= i) continue;   // only higher-ranked candidates matter
-              const int qi = (int)(uint32_t)keys[q];
-              const int qy = qi / W, qx = qi - qy * W;
-              const int ddx = x - qx, ddy = y - qy;
+            for (uint32_t q = heads[yy * gw + xx]; q != 0xFFFFu; q = nxt[q]) {
+              if ((int)q >= i) continue;   // only higher-ranked candidates matter
+              const uint32_t pq = xy[q];
+              const int ddx = x - (int)(pq & 0xFFFF), ddy = y - (int)(pq >> 16);
               if ((double)(ddx * ddx + ddy * ddy) < md2) {
                 const uint8_t s = state[q];
                 if (s == 1) any_acc = true;
@@ -216,7 +286,6 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
         else undecided = true;
       }
       if (undecided) s_flag = 1;
-      __threadfence_block();
       __syncthreads();
       const int f = s_flag;
       __syncthreads();
@@ -225,7 +294,7 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
   }
   // ---- ordered compaction of the accepted candidates (rank order), first max_corners ----
   const int per = (n + 1023) / 1024;
-  const int b0 = tid * per, b1 = min(b0 + per, n);
+  const int b0 = min(tid * per, n), b1 = min(b0 + per, n);
   int cnt = 0;
   for (int i = b0; i < b1; i++) cnt += (state[i] == 1);
   s_scan[tid] = cnt;
@@ -238,13 +307,12 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
   }
   int pos = s_scan[tid] - cnt;
   const int total = s_scan[1023];
-  int limit = (max_corners > 0) ? min(max_corners, ST_OUT_CAP) : ST_OUT_CAP;
+  const int limit = (max_corners > 0) ? min(max_corners, ST_OUT_CAP) : ST_OUT_CAP;
   for (int i = b0; i < b1; i++)
     if (state[i] == 1) {
       if (pos < limit) {
-        const int idx = (int)(uint32_t)keys[i];
-        const int y = idx / W, x = idx - y * W;
-        out[2 * pos] = (float)x; out[2 * pos + 1] = (float)y;
+        const uint32_t p = xy[i];
+        out[2 * pos] = (float)(p & 0xFFFF); out[2 * pos + 1] = (float)(p >> 16);
       }
       pos++;
     }
@@ -257,8 +325,7 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
 void vo_st_destroy(vo_ctx* c) {
   if (!c->st) return;
   vo_st_ws* s = c->st;
-  void* bufs[] = {s->d_mask, s->d_user_mask, s->d_h, s->d_eig, s->d_scalars, s->d_cand, s->d_cellhead,
-                  s->d_next, s->d_state, s->d_out, s->d_pts};
+  void* bufs[] = {s->d_mask, s->d_user_mask, s->d_h, s->d_eig, s->d_scalars, s->d_cand, s->d_blockmax, s->d_out, s->d_pts};
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete s;
   c->st = nullptr;
@@ -275,15 +342,13 @@ static int32_t st_init(vo_ctx* c) {
   VO_HIP(c, hipMalloc((void**)&s->d_eig, np * sizeof(float)));
   VO_HIP(c, hipMalloc((void**)&s->d_scalars, 16 * sizeof(uint32_t)));
   VO_HIP(c, hipMalloc((void**)&s->d_cand, sizeof(unsigned long long) * ST_CAND_CAP));
-  s->cell_cap = (int)np;   // cell >= 1 px
-  VO_HIP(c, hipMalloc((void**)&s->d_cellhead, sizeof(int32_t) * (size_t)s->cell_cap));
-  VO_HIP(c, hipMalloc((void**)&s->d_next, sizeof(int32_t) * ST_CAND_CAP));
-  VO_HIP(c, hipMalloc((void**)&s->d_state, ST_CAND_CAP));
+  s->n_blockmax = vo_div_up(c->width, 256) * vo_div_up(c->height, ST_RG);
+  VO_HIP(c, hipMalloc((void**)&s->d_blockmax, sizeof(float) * (size_t)s->n_blockmax));
   VO_HIP(c, hipMalloc((void**)&s->d_out, sizeof(float) * 2 * ST_OUT_CAP));
   VO_HIP(c, hipMalloc((void**)&s->d_pts, sizeof(float) * 2 * (size_t)c->max_pts));
   VO_HIP(c, hipMemsetAsync(s->d_scalars, 0, 16 * sizeof(uint32_t), c->stream));
   VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_st_select), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(unsigned long long) * ST_CAND_CAP)));
+                                (int)ST_SEL_LDS));
   return VO_OK;
 }
 
@@ -336,17 +401,18 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, int n_cur, int mask_radi
   const float sf = (float)scale_d;
   const float s2 = sf * sf;
   hipLaunchKernelGGL(k_st_vsum_eig, dim3(vo_div_up(W, 256), vo_div_up(H, ST_RG)), dim3(256), 0, c->stream, hxx, hxy, hyy,
-                     s->d_mask, W, H, r, s2, s->d_eig, s->d_scalars);
-  hipLaunchKernelGGL(k_st_nms, dim3(vo_div_up(W - 2, 256), H - 2), dim3(256), 0, c->stream, s->d_eig, s->d_mask, W, H,
-                     prm->quality_level, s->d_cand, s->d_scalars);
+                     s->d_mask, W, H, r, s2, s->d_eig, s->d_blockmax);
+  hipLaunchKernelGGL(k_st_nms, dim3(vo_div_up(W - 2, 256), vo_div_up(H - 2, ST_NMS_ROWS)), dim3(256), 0, c->stream, s->d_eig,
+                     s->d_mask, W, H, prm->quality_level, s->d_blockmax, s->n_blockmax, s->d_cand, s->d_scalars);
   const int use_dist = prm->min_distance >= 1.0 ? 1 : 0;
-  int cell = use_dist ? (int)lrint(prm->min_distance) : 1;
+  // grid cell: >= min_distance (3x3 neighbourhood then covers the exclusion radius), coarse enough to fit LDS
+  int cell = use_dist ? (int)ceil(prm->min_distance) : 1;
   if (cell < 1) cell = 1;
+  while (((W + cell - 1) / cell) * ((H + cell - 1) / cell) > ST_MAX_CELLS) cell++;
   const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
   const double md2 = prm->min_distance * prm->min_distance;
-  hipLaunchKernelGGL(k_st_select, dim3(1), dim3(1024), sizeof(unsigned long long) * ST_CAND_CAP, c->stream, s->d_cand,
-                     s->d_scalars, W, H, cell, gw, gh, md2, use_dist, prm->max_corners, s->d_cellhead, s->d_next,
-                     s->d_state, s->d_out);
+  hipLaunchKernelGGL(k_st_select, dim3(1), dim3(1024), ST_SEL_LDS, c->stream, s->d_cand,
+                     s->d_scalars, W, H, cell, gw, gh, md2, use_dist, prm->max_corners, s->d_out);
   VO_HIP(c, hipGetLastError());
   s->last_max_corners = prm->max_corners;
   return VO_OK;
