@@ -66,6 +66,7 @@ struct ba_ptrs {
   double* x[2];
   double* aux; double* posepart; double* gmax; double* tiles; double* dp; double* evalpart;
   ba_state* state; ba_info* info;
+  unsigned long long* dbg;
   int W, N, LPP, PPB, nblk, RP, RT, n_tiles, pitch;
 };
 
@@ -294,6 +295,8 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_build(ba_ptrs P, ba_params_de
   __syncthreads();
   const ba_state st = s_st;
   if (st.done) return;
+  unsigned long long* dbgb = (blockIdx.x == 0 && P.dbg) ? P.dbg + 16 : nullptr;
+  VO_STAMP(dbgb, 0);
   const int W = P.W, N = P.N, LPP = P.LPP;
   // iteration 0 reads the uploaded x0 and seeds x[0] with it (each workgroup its own landmarks)
   const double* poses = (it == 0) ? P.x0 : P.x[st.cur];
@@ -326,6 +329,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_build(ba_ptrs P, ba_params_de
       for (int c = 0; c < 6; c++) o.Jp[k][c] = 0;
     }
   }
+  VO_STAMP(dbgb, 1);   // cameras staged + observation linearised
   // ---- landmark sums over the group ----
   const double h00 = group_allreduce(o.w * (o.Jl[0][0] * o.Jl[0][0] + o.Jl[1][0] * o.Jl[1][0]), LPP);
   const double h10 = group_allreduce(o.w * (o.Jl[0][1] * o.Jl[0][0] + o.Jl[1][1] * o.Jl[1][0]), LPP);
@@ -361,6 +365,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_build(ba_ptrs P, ba_params_de
     for (int ofs = 32; ofs > 0; ofs >>= 1) gm = fmax(gm, __shfl_xor(gm, ofs));
     if (lane == 0) s_gmax[wave] = gm;
   }
+  VO_STAMP(dbgb, 2);   // group sums + 3x3 factor
   // ---- camera sums: across the landmarks of the wave by shuffles, across waves through LDS ----
   // (each value is formed, reduced and stored before the next one to keep the register footprint small)
   {
@@ -405,6 +410,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_build(ba_ptrs P, ba_params_de
     P.gmax[blockIdx.x] = gm;
   }
   __syncthreads();
+  VO_STAMP(dbgb, 3);   // camera sums reduced and written
   // ---- Y^ panel of this workgroup in LDS: row 3 pl + c, columns 6 slot .. 6 slot + 5, column 6W = y ----
   const int pitch = P.pitch;
   if (slot < W) {
@@ -429,6 +435,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_build(ba_ptrs P, ba_params_de
   // ---- Gram matrix of the panel: upper 16x16 tiles, one wave per tile, v_mfma_f64_16x16x4_f64 ----
   //   A[i][k] = panel[k0 + k][16 ta + i]  (lane: i = l & 15, k = l >> 4),  B[k][j] = panel[k0 + k][16 tb + j]
   //   D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+  VO_STAMP(dbgb, 4);   // panel staged
   const int krows = 3 * P.PPB;
   for (int tile = wave; tile < P.n_tiles; tile += BA_WAVES) {
     int ta = 0, rem = tile;
@@ -445,6 +452,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_build(ba_ptrs P, ba_params_de
     double* out = P.tiles + ((size_t)blockIdx.x * P.n_tiles + tile) * 256 + lane * 4;
     out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2]; out[3] = acc[3];
   }
+  VO_STAMP(dbgb, 5);   // Gram tiles (wave 0)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -464,6 +472,8 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_de
   double* s_invd = s_hpp + W * BA_POSE_VALS;   // n inverse diagonal of L
   double* s_dp = s_invd + n1;                  // n
   if (tid == 0) s_fail = 0;
+  unsigned long long* dbgs = P.dbg ? P.dbg + 8 : nullptr;
+  VO_STAMP(dbgs, 0);
   // ---- reduce camera partials (fixed order) ----
   for (int q = tid; q < W * BA_POSE_VALS; q += BA_THREADS) {
     double s = 0;
@@ -492,6 +502,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_de
     A[(size_t)col * PT + row] = (row == n) ? v : -v;
   }
   __syncthreads();
+  VO_STAMP(dbgs, 1);   // partials reduced
   // ---- + damped Hpp blocks, rhs = -gp + r ----
   const double lam = st.lambda;
   for (int q = tid; q < W * 36; q += BA_THREADS) {
@@ -512,6 +523,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_de
     for (int a = tid; a < n; a += BA_THREADS) probe_S[(size_t)n * n + a] = A[(size_t)a * PT + n];
   }
   if (hpp_out) for (int q = tid; q < W * BA_POSE_VALS; q += BA_THREADS) hpp_out[q] = s_hpp[q];
+  VO_STAMP(dbgs, 2);   // system assembled
   // ---- 6x6-blocked right-looking Cholesky of the augmented matrix (row n carries rhs -> y) ----
   for (int kb = 0; kb < W; kb++) {
     const int c0 = 6 * kb;
@@ -581,6 +593,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_de
     }
     __syncthreads();
   }
+  VO_STAMP(dbgs, 3);   // factorised
   // ---- back substitution  L^T dp = y  by wave 0 (lane i holds rows i and i + 64) ----
   if (tid < 64) {
     const int lane = tid;
@@ -599,6 +612,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_de
     if (lane + 64 < n) s_dp[lane + 64] = y1;
   }
   __syncthreads();
+  VO_STAMP(dbgs, 4);   // back substitution
   // ---- publish ----
   const int fail = s_fail;
   for (int a = tid; a < n; a += BA_THREADS) P.dp[a] = fail ? 0.0 : s_dp[a];
@@ -624,6 +638,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_de
     inf.chol_fail = fail; inf.pad = 0;
     *P.info = inf;
   }
+  VO_STAMP(dbgs, 5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -820,11 +835,13 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
   return VO_OK;
 }
 
+static ba_ptrs ba_make_ptrs(vo_ba_ws* b);
+static ba_ptrs ba_make_ptrs_dbg(vo_ctx* c) { ba_ptrs P = ba_make_ptrs(c->ba); P.dbg = c->d_dbg; return P; }
 static ba_ptrs ba_make_ptrs(vo_ba_ws* b) {
   ba_ptrs P;
   P.K = b->d_K; P.obs = b->d_obs; P.x0 = b->d_x0; P.x[0] = b->d_x[0]; P.x[1] = b->d_x[1]; P.aux = b->d_aux;
   P.posepart = b->d_posepart; P.gmax = b->d_gmax; P.tiles = b->d_tiles; P.dp = b->d_dp; P.evalpart = b->d_evalpart;
-  P.state = b->d_state; P.info = b->d_info;
+  P.state = b->d_state; P.info = b->d_info; P.dbg = nullptr;
   P.W = b->W; P.N = b->N; P.LPP = b->LPP; P.PPB = b->PPB; P.nblk = b->nblk; P.RP = b->RP; P.RT = b->RT;
   P.n_tiles = b->n_tiles; P.pitch = b->pitch;
   return P;
@@ -969,7 +986,7 @@ extern "C" int32_t vo_ba_probe(vo_ctx* c, double lambda, double huber_delta, dou
   int32_t r = ba_begin(c, &prm);
   if (r != VO_OK) return r;
   const ba_params_dev d = ba_dev_params(&prm);
-  const ba_ptrs P = ba_make_ptrs(b);
+  const ba_ptrs P = ba_make_ptrs_dbg(c);
   hipLaunchKernelGGL(k_ba_residual, dim3(vo_div_up(N, 128)), dim3(128), 0, c->stream, P, b->d_x0, huber_delta, b->d_res);
   ba_launch_iter(c, P, d, 0, lambda, b->d_S, b->d_Hpp, b->d_dl);
   VO_HIP(c, hipGetLastError());

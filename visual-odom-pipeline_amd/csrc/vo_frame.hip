@@ -113,6 +113,19 @@ extern "C" int32_t vo_profile_enable(vo_ctx* c, int32_t region_mask) {
   return VO_OK;
 }
 
+extern "C" int32_t vo_debug_cycles(vo_ctx* c, int32_t which, int64_t* out8) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, which >= 0 && which < 3 && out8, VO_E_INVALID, "bad selector");
+  VO_HIP(c, hipSetDevice(c->device));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  unsigned long long h[8];
+  VO_HIP(c, hipMemcpy(h, c->d_dbg + 8 * which, sizeof(h), hipMemcpyDeviceToHost));
+  out8[0] = 0;
+  for (int i = 1; i < 8; i++) out8[i] = (h[i] && h[i - 1]) ? (int64_t)(h[i] - h[i - 1]) : 0;
+  for (int i = 1; i < 8; i++) out8[0] += out8[i];
+  return VO_OK;
+}
+
 extern "C" int32_t vo_profile_read(vo_ctx* c, int32_t region, double* total_ms, int32_t* count) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, region >= 0 && region < VO_PROF_COUNT && total_ms && count, VO_E_INVALID, "bad region");
@@ -158,7 +171,7 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
       if (c->fr[f].img[l]) (void)hipFree(c->fr[f].img[l]);
       if (c->fr[f].der[l]) (void)hipFree(c->fr[f].der[l]);
     }
-  void* bufs[] = {c->d_raw, c->d_seq, c->d_p0, c->d_p1, c->d_err, c->d_status, c->d_iters,
+  void* bufs[] = {c->d_dbg, c->d_raw, c->d_seq, c->d_p0, c->d_p1, c->d_err, c->d_status, c->d_iters,
                   c->d_uv0, c->d_uv1, c->d_X4, c->d_depth, c->d_reproj};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
@@ -215,6 +228,8 @@ extern "C" int32_t vo_ctx_create(int32_t device, int32_t width, int32_t height, 
       CR(hipMemsetAsync(c->fr[f].der[l], 0, px * 4, c->stream));   // border stays 0 forever
     }
   CR(hipMalloc((void**)&c->d_raw, (size_t)width * height));
+  CR(hipMalloc((void**)&c->d_dbg, sizeof(unsigned long long) * 24));
+  CR(hipMemsetAsync(c->d_dbg, 0, sizeof(unsigned long long) * 24, c->stream));
   CR(hipMalloc((void**)&c->d_p0, sizeof(float) * 2 * max_pts));
   CR(hipMalloc((void**)&c->d_p1, sizeof(float) * 2 * max_pts));
   CR(hipMalloc((void**)&c->d_err, sizeof(float) * max_pts));

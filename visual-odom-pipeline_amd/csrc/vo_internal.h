@@ -62,6 +62,7 @@ struct vo_ctx {
   vo_st_ws* st = nullptr;
   vo_ba_ws* ba = nullptr;
   vo_prof prof;
+  unsigned long long* d_dbg = nullptr;   // 3 x 8 phase stamps (vo_debug_cycles)
   std::string err;
 };
 
@@ -92,6 +93,9 @@ struct vo_prof_scope {
   vo_prof_scope(vo_ctx* c_, int region_);
   ~vo_prof_scope();
 };
+
+// phase stamp helper for the diagnostic cycle counters (thread 0 of a workgroup)
+#define VO_STAMP(buf, idx) do { if ((buf) && threadIdx.x == 0) (buf)[idx] = __builtin_amdgcn_s_memtime(); } while (0)
 
 static inline int vo_div_up(int a, int b) { return (a + b - 1) / b; }
 

@@ -197,7 +197,8 @@ __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, c
 #define ST_MAX_CELLS 8192
 __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __restrict__ cand,
                                                     uint32_t* __restrict__ scalars, int W, int H, int cell, int gw, int gh,
-                                                    double md2, int use_dist, int max_corners, float* __restrict__ out) {
+                                                    double md2, int use_dist, int max_corners, float* __restrict__ out,
+                                                    unsigned long long* __restrict__ dbg) {
   extern __shared__ unsigned char smem[];
   __shared__ int s_flag;
   __shared__ int s_scan[1024];
@@ -207,6 +208,7 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
   uint16_t* nxt = reinterpret_cast<uint16_t*>(smem + 96 * 1024);
   volatile uint8_t* state = reinterpret_cast<volatile uint8_t*>(smem + 128 * 1024);
   const int tid = threadIdx.x;
+  VO_STAMP(dbg, 0);
   const uint32_t ncand = scalars[1];
   if (ncand > ST_CAND_CAP) { if (tid == 0) scalars[2] = 0xFFFFFFFFu; return; }   // host reports VO_E_CAPACITY
   const int n = (int)ncand;
@@ -227,6 +229,7 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
       }
       __syncthreads();
     }
+  VO_STAMP(dbg, 1);   // sort done
   // ---- keys -> packed (x, y) in rank order (read everything before overwriting the aliased region) ----
   uint32_t myxy[ST_CAND_CAP / 1024];
 #pragma unroll
@@ -256,6 +259,7 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
       nxt[i] = (uint16_t)atomicExch(&heads[(y / cell) * gw + (x / cell)], (uint32_t)i);
     }
     __syncthreads();
+    VO_STAMP(dbg, 2);   // grid built
     // ---- greedy min-distance selection as monotone parallel rounds: a candidate is accepted iff every
     //      higher-ranked candidate closer than min_distance is rejected (== the sequential scan) ----
     for (int round = 0; round <= n; round++) {
@@ -289,9 +293,10 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
       __syncthreads();
       const int f = s_flag;
       __syncthreads();
-      if (!f) break;
+      if (!f) { if (tid == 0) scalars[3] = (uint32_t)round + 1; break; }
     }
   }
+  VO_STAMP(dbg, 3);   // rounds done
   // ---- ordered compaction of the accepted candidates (rank order), first max_corners ----
   const int per = (n + 1023) / 1024;
   const int b0 = min(tid * per, n), b1 = min(b0 + per, n);
@@ -317,6 +322,7 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
       pos++;
     }
   if (tid == 0) scalars[2] = (uint32_t)min(total, limit);
+  VO_STAMP(dbg, 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -412,7 +418,7 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, int n_cur, int mask_radi
   const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
   const double md2 = prm->min_distance * prm->min_distance;
   hipLaunchKernelGGL(k_st_select, dim3(1), dim3(1024), ST_SEL_LDS, c->stream, s->d_cand,
-                     s->d_scalars, W, H, cell, gw, gh, md2, use_dist, prm->max_corners, s->d_out);
+                     s->d_scalars, W, H, cell, gw, gh, md2, use_dist, prm->max_corners, s->d_out, c->d_dbg);
   VO_HIP(c, hipGetLastError());
   s->last_max_corners = prm->max_corners;
   return VO_OK;

@@ -79,6 +79,7 @@ SIGNATURES = {
     "vo_dlt_fetch": (C.c_int32, [_ctx, _f32p, _f64p, _f64p]),
     "vo_profile_enable": (C.c_int32, [_ctx, C.c_int32]),
     "vo_profile_read": (C.c_int32, [_ctx, C.c_int32, _f64p, _i32p]),
+    "vo_debug_cycles": (C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_int64)]),
     "vo_ba_default_params": (C.c_int32, [C.POINTER(BaParams)]),
     "vo_ba_adjust": (C.c_int32, [_ctx, _f64p, _f64p, _f64p, _f64p, C.c_int32, C.c_int32, C.POINTER(BaParams),
                                  _f64p, _f64p, C.POINTER(BaStats)]),

@@ -223,6 +223,11 @@ class VoContext:
         self._ck(self._L.vo_profile_read(self._h, region, C.byref(t), C.byref(n)))
         return t.value, n.value
 
+    def debug_cycles(self, which):
+        out = np.zeros(8, np.int64)
+        self._ck(self._L.vo_debug_cycles(self._h, which, ptr(out, C.c_int64)))
+        return out
+
     # -- BA -------------------------------------------------------------------------------------
     def ba_params(self, max_iters=50, ftol=1e-3, xtol=1e-3, gtol=1e-8, lambda0=1e-4, huber_delta=1.0):
         p = BaParams()
