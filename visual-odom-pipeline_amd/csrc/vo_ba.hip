@@ -65,6 +65,7 @@ struct ba_ptrs {
   const double* K; const double* obs; const double* x0;
   double* x[2];
   double* aux; double* posepart; double* gmax; double* tiles; double* dp; double* evalpart;
+  double* tilesum; double* posesum;   // k_ba_reduce outputs: n_tiles*256, W*28 + 1 (last = max |g_l|)
   ba_state* state; ba_info* info;
   unsigned long long* dbg;
   int W, N, LPP, PPB, nblk, RP, RT, n_tiles, pitch;
@@ -84,6 +85,8 @@ struct vo_ba_ws {
   double* d_tiles = nullptr;    // nblk * n_tiles * 256
   double* d_dp = nullptr;       // 6W
   double* d_evalpart = nullptr; // nblk * 4
+  double* d_tilesum = nullptr;  // n_tiles * 256
+  double* d_posesum = nullptr;  // W * 28 + 1
   double* d_S = nullptr;        // probe: (6W)^2 + 6W
   double* d_Hpp = nullptr;      // W*28 reduced pose values (probe)
   double* d_res = nullptr;      // probe residual W*N
@@ -197,14 +200,39 @@ __device__ __forceinline__ double dpp_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// v[l] + v[l ^ 16] in every lane: v_permlane16_swap (VALU, no LDS traffic).  swap(a, b) with a = b = v leaves
+// a' = {row0, row0, row2, row2}, b' = {row1, row1, row3, row3}, so a' + b' is the pair sum everywhere.
+__device__ __forceinline__ double xor16_sum(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
+}
+// v[l] + v[l ^ 32] in every lane: v_permlane32_swap
+__device__ __forceinline__ double xor32_sum(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto l2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto h2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
+}
+
 // sum over the LPP (16 or 32) lanes of a landmark group; every lane of the group gets the total
 __device__ __forceinline__ double group_allreduce(double v, int lpp) {
   v += dpp_f64<0x128>(v);   // row_ror:8
   v += dpp_f64<0x124>(v);   // row_ror:4
   v += dpp_f64<0x122>(v);   // row_ror:2
   v += dpp_f64<0x121>(v);   // row_ror:1
-  if (lpp == 32) v += __shfl_xor(v, 16);
+  if (lpp == 32) v = xor16_sum(v);
   return v;
+}
+
+// sum over the 64 lanes of a wave, result in every lane
+__device__ __forceinline__ double wave_allreduce(double v) {
+  v += dpp_f64<0x128>(v);
+  v += dpp_f64<0x124>(v);
+  v += dpp_f64<0x122>(v);
+  v += dpp_f64<0x121>(v);
+  return xor32_sum(xor16_sum(v));
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int src) {
@@ -377,22 +405,22 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_build(ba_ptrs P, ba_params_de
 #pragma unroll
       for (int c = a; c < 6; c++) {
         double s = o.w * (o.Jp[0][a] * o.Jp[0][c] + o.Jp[1][a] * o.Jp[1][c]);
-        if (LPP == 16) s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
+        if (LPP == 16) s = xor16_sum(s);
+        s = xor32_sum(s);
         if (writer) dst[q] = s;
         q++;
       }
 #pragma unroll
     for (int a = 0; a < 6; a++) {
       double s = o.w * (o.Jp[0][a] * o.e0 + o.Jp[1][a] * o.e1);
-      if (LPP == 16) s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
+      if (LPP == 16) s = xor16_sum(s);
+      s = xor32_sum(s);
       if (writer) dst[21 + a] = s;
     }
     {
       double s = 0.5 * o.rho;
-      if (LPP == 16) s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
+      if (LPP == 16) s = xor16_sum(s);
+      s = xor32_sum(s);
       if (writer) dst[27] = s;
     }
   }
@@ -456,6 +484,36 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_build(ba_ptrs P, ba_params_de
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_ba_reduce : fixed-order sum of the per-workgroup partials (Gram tiles, camera sums, max |g_l|), one output
+// element per thread so that the one-workgroup solve reads ~23 KB instead of nblk x 23 KB.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ba_reduce(ba_ptrs P, int it) {
+  const ba_state st = P.state[it & 1];
+  if (st.done) return;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int n_tile_el = P.n_tiles * 256, n_pose_el = P.W * BA_POSE_VALS;
+  const double* src; size_t stride; double* dst;
+  if (e < n_tile_el) { src = P.tiles + e; stride = (size_t)n_tile_el; dst = P.tilesum + e; }
+  else if (e < n_tile_el + n_pose_el) { src = P.posepart + (e - n_tile_el); stride = (size_t)n_pose_el; dst = P.posesum + (e - n_tile_el); }
+  else if (e == n_tile_el + n_pose_el) {
+    double gm = 0;
+    for (int b = 0; b < P.nblk; b++) gm = fmax(gm, P.gmax[b]);
+    P.posesum[n_pose_el] = gm;
+    return;
+  } else return;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int b = 0;
+  for (; b + 8 <= P.nblk; b += 8) {
+    const double v0 = src[(size_t)b * stride], v1 = src[(size_t)(b + 1) * stride], v2 = src[(size_t)(b + 2) * stride];
+    const double v3 = src[(size_t)(b + 3) * stride], v4 = src[(size_t)(b + 4) * stride], v5 = src[(size_t)(b + 5) * stride];
+    const double v6 = src[(size_t)(b + 6) * stride], v7 = src[(size_t)(b + 7) * stride];
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3; s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+  }
+  for (; b < P.nblk; b++) s0 += src[(size_t)b * stride];
+  *dst = (s0 + s1) + (s2 + s3);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_ba_solve : one workgroup
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_dev prm, int it, double* __restrict__ probe_S,
@@ -474,13 +532,8 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_de
   if (tid == 0) s_fail = 0;
   unsigned long long* dbgs = P.dbg ? P.dbg + 8 : nullptr;
   VO_STAMP(dbgs, 0);
-  // ---- reduce camera partials (fixed order) ----
-  for (int q = tid; q < W * BA_POSE_VALS; q += BA_THREADS) {
-    double s = 0;
-    for (int b = 0; b < P.nblk; b++) s += P.posepart[(size_t)b * W * BA_POSE_VALS + q];
-    s_hpp[q] = s;
-  }
-  // ---- -E (lower triangle) and +r (row n) from the Gram partial tiles ----
+  // ---- reduced camera sums; -E (lower triangle) and +r (row n) from the reduced Gram tiles ----
+  for (int q = tid; q < W * BA_POSE_VALS; q += BA_THREADS) s_hpp[q] = P.posesum[q];
   for (int e = tid; e < n1 * n1; e += BA_THREADS) {
     const int col = e / n1, row = e - col * n1;       // consecutive threads -> consecutive rows
     if (row < col) continue;
@@ -488,17 +541,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_de
     // element (a = col, b = row), a <= b, lives in upper tile (ta, tb)
     const int ta = col >> 4, tb = row >> 4, ii = col & 15, jj = row & 15;
     const int tile = ta * P.RT - (ta * (ta - 1)) / 2 + (tb - ta);
-    const double* p = P.tiles + (size_t)tile * 256 + ((ii & 3) * 16 + jj) * 4 + (ii >> 2);
-    const size_t stride = (size_t)P.n_tiles * 256;
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int b = 0;
-    for (; b + 4 <= P.nblk; b += 4) {
-      const double v0 = p[(size_t)b * stride], v1 = p[(size_t)(b + 1) * stride];
-      const double v2 = p[(size_t)(b + 2) * stride], v3 = p[(size_t)(b + 3) * stride];
-      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
-    }
-    for (; b < P.nblk; b++) s0 += p[(size_t)b * stride];
-    const double v = (s0 + s1) + (s2 + s3);
+    const double v = P.tilesum[(size_t)tile * 256 + ((ii & 3) * 16 + jj) * 4 + (ii >> 2)];
     A[(size_t)col * PT + row] = (row == n) ? v : -v;
   }
   __syncthreads();
@@ -595,46 +638,69 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_de
   }
   VO_STAMP(dbgs, 3);   // factorised
   // ---- back substitution  L^T dp = y  by wave 0 (lane i holds rows i and i + 64) ----
+  // The recurrence only carries (y, dk); the rows of L^T are prefetched 4 steps ahead so that no LDS latency
+  // sits on the dependent chain.
   if (tid < 64) {
     const int lane = tid;
     double y0 = (lane < n) ? A[(size_t)lane * PT + n] : 0.0;
     double y1 = (lane + 64 < n) ? A[(size_t)(lane + 64) * PT + n] : 0.0;
-    for (int k = n - 1; k >= 0; k--) {
-      const int src = k & 63;
-      const double yk = (k < 64) ? readlane_f64(y0, src) : readlane_f64(y1, src);
-      const double dk = yk * s_invd[k];
-      // L[k][i] = A[i * PT + k], i < k
-      if (lane < k) y0 -= A[(size_t)lane * PT + k] * dk;
-      if (lane + 64 < k) y1 -= A[(size_t)(lane + 64) * PT + k] * dk;
-      if (lane == src) { if (k < 64) y0 = dk; else y1 = dk; }
+    const double iv0 = (lane < n) ? s_invd[lane] : 0.0, iv1 = (lane + 64 < n) ? s_invd[lane + 64] : 0.0;
+    double res0 = 0.0, res1 = 0.0;
+    double r0[4], r1[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = n - 1 - q;
+      r0[q] = (k >= 0 && lane < k) ? A[(size_t)lane * PT + k] : 0.0;          // L[k][i] = A[i * PT + k]
+      r1[q] = (k >= 0 && lane + 64 < k) ? A[(size_t)(lane + 64) * PT + k] : 0.0;
     }
-    if (lane < n) s_dp[lane] = y0;
-    if (lane + 64 < n) s_dp[lane + 64] = y1;
+    for (int kk = n - 1; kk >= 0; kk -= 4) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int k = kk - q;
+        if (k < 0) break;
+        const int src = k & 63;
+        const double dk = (k < 64) ? readlane_f64(y0 * iv0, src) : readlane_f64(y1 * iv1, src);
+        y0 -= r0[q] * dk; y1 -= r1[q] * dk;
+        if (lane == src) { if (k < 64) res0 = dk; else res1 = dk; }
+        const int kn = k - 4;     // refill this slot with the row needed 4 steps later
+        r0[q] = (kn >= 0 && lane < kn) ? A[(size_t)lane * PT + kn] : 0.0;
+        r1[q] = (kn >= 0 && lane + 64 < kn) ? A[(size_t)(lane + 64) * PT + kn] : 0.0;
+      }
+    }
+    if (lane < n) s_dp[lane] = res0;
+    if (lane + 64 < n) s_dp[lane + 64] = res1;
   }
   __syncthreads();
   VO_STAMP(dbgs, 4);   // back substitution
   // ---- publish ----
   const int fail = s_fail;
   for (int a = tid; a < n; a += BA_THREADS) P.dp[a] = fail ? 0.0 : s_dp[a];
-  if (tid == 0) {
+  if (tid < 128) {
+    // wave-parallel step statistics of the camera block (lanes = parameters)
     const double* poses = P.x[st.cur];
-    double cost = 0, pred = 0, step2 = 0, x2 = 0, ginf = 0;
-    for (int i = 0; i < W; i++) {
-      cost += s_hpp[i * BA_POSE_VALS + 27];
-      for (int a = 0; a < 6; a++) {
-        const double g = s_hpp[i * BA_POSE_VALS + 21 + a];
-        const int idx = a * 6 - (a * (a - 1)) / 2;
-        const double Dg = fmax(s_hpp[i * BA_POSE_VALS + idx], 1e-12);
-        const double d = fail ? 0.0 : s_dp[6 * i + a];
-        pred += lam * Dg * d * d - g * d;
-        step2 += d * d;
-        x2 += poses[6 * i + a] * poses[6 * i + a];
-        ginf = fmax(ginf, fabs(g));
-      }
+    double pred = 0, step2 = 0, x2 = 0, gabs = 0, cost = 0;
+    if (tid < n) {
+      const int i = tid / 6, a = tid - 6 * i;
+      const double g = s_hpp[i * BA_POSE_VALS + 21 + a];
+      const double Dg = fmax(s_hpp[i * BA_POSE_VALS + a * 6 - (a * (a - 1)) / 2], 1e-12);
+      const double d = fail ? 0.0 : s_dp[tid];
+      const double xv = (it == 0) ? P.x0[tid] : poses[tid];
+      pred = lam * Dg * d * d - g * d; step2 = d * d; x2 = xv * xv; gabs = fabs(g);
+      if (a == 0) cost = s_hpp[i * BA_POSE_VALS + 27];
     }
-    for (int b = 0; b < P.nblk; b++) ginf = fmax(ginf, P.gmax[b]);
+    pred = wave_allreduce(pred); step2 = wave_allreduce(step2); x2 = wave_allreduce(x2); cost = wave_allreduce(cost);
+    for (int ofs = 32; ofs > 0; ofs >>= 1) gabs = fmax(gabs, __shfl_xor(gabs, ofs));
+    if ((tid & 63) == 0) {
+      double* w = s_dp + n + 8 * (tid >> 6);   // scratch behind dp (s_dp has n1 + 8.. entries reserved)
+      w[0] = pred; w[1] = step2; w[2] = x2; w[3] = cost; w[4] = gabs;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double* w0 = s_dp + n; const double* w1 = s_dp + n + 8;
     ba_info inf;
-    inf.cost_cur = cost; inf.pred_pose = pred; inf.step2_pose = step2; inf.x2_pose = x2; inf.ginf = ginf;
+    inf.cost_cur = w0[3] + w1[3]; inf.pred_pose = w0[0] + w1[0]; inf.step2_pose = w0[1] + w1[1]; inf.x2_pose = w0[2] + w1[2];
+    inf.ginf = fmax(fmax(w0[4], w1[4]), P.posesum[W * BA_POSE_VALS]);
     inf.chol_fail = fail; inf.pad = 0;
     *P.info = inf;
   }
@@ -714,9 +780,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_update(ba_ptrs P, ba_params_d
       e3 = X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
     }
   }
-  for (int ofs = 32; ofs > 0; ofs >>= 1) {
-    e0 += __shfl_xor(e0, ofs); e1 += __shfl_xor(e1, ofs); e2 += __shfl_xor(e2, ofs); e3 += __shfl_xor(e3, ofs);
-  }
+  e0 = wave_allreduce(e0); e1 = wave_allreduce(e1); e2 = wave_allreduce(e2); e3 = wave_allreduce(e3);
   if (lane == 0) { s_red[wave * 4] = e0; s_red[wave * 4 + 1] = e1; s_red[wave * 4 + 2] = e2; s_red[wave * 4 + 3] = e3; }
   __syncthreads();
   if (tid < BA_EVAL_VALS) {
@@ -771,7 +835,7 @@ void vo_ba_destroy(vo_ctx* c) {
   if (!c->ba) return;
   vo_ba_ws* b = c->ba;
   void* bufs[] = {b->d_K, b->d_obs, b->d_x0, b->d_x[0], b->d_x[1], b->d_aux, b->d_posepart, b->d_gmax,
-                  b->d_tiles, b->d_dp, b->d_evalpart, b->d_S, b->d_Hpp, b->d_res, b->d_dl, b->d_xout, b->d_state, b->d_info};
+                  b->d_tiles, b->d_dp, b->d_evalpart, b->d_tilesum, b->d_posesum, b->d_S, b->d_Hpp, b->d_res, b->d_dl, b->d_xout, b->d_state, b->d_info};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (b->h_state) (void)hipHostFree(b->h_state);
   delete b;
@@ -795,7 +859,7 @@ static void ba_geometry(vo_ba_ws* b, int W, int N) {
   const size_t scratch = sizeof(double) * (size_t)BA_WAVES * b->LPP * BA_POSE_VALS;
   b->build_lds = panel > scratch ? panel : scratch;
   const int n1 = 6 * W + 1, PT = n1 | 1;
-  b->solve_lds = sizeof(double) * ((size_t)n1 * PT + (size_t)W * BA_POSE_VALS + n1 + n1 + 8);
+  b->solve_lds = sizeof(double) * ((size_t)n1 * PT + (size_t)W * BA_POSE_VALS + n1 + n1 + 24);
 }
 
 static int32_t ba_alloc(vo_ctx* c, int W, int N) {
@@ -819,6 +883,8 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     VO_HIP(c, hipMalloc((void**)&b->d_tiles, sizeof(double) * (size_t)b->nblk * b->n_tiles * 256));
     VO_HIP(c, hipMalloc((void**)&b->d_dp, sizeof(double) * 6 * W));
     VO_HIP(c, hipMalloc((void**)&b->d_evalpart, sizeof(double) * b->nblk * BA_EVAL_VALS));
+    VO_HIP(c, hipMalloc((void**)&b->d_tilesum, sizeof(double) * (size_t)b->n_tiles * 256));
+    VO_HIP(c, hipMalloc((void**)&b->d_posesum, sizeof(double) * ((size_t)W * BA_POSE_VALS + 1)));
     VO_HIP(c, hipMalloc((void**)&b->d_S, sizeof(double) * ((size_t)36 * W * W + 6 * W)));
     VO_HIP(c, hipMalloc((void**)&b->d_Hpp, sizeof(double) * (size_t)W * BA_POSE_VALS));
     VO_HIP(c, hipMalloc((void**)&b->d_res, sizeof(double) * (size_t)W * N));
@@ -841,6 +907,7 @@ static ba_ptrs ba_make_ptrs(vo_ba_ws* b) {
   ba_ptrs P;
   P.K = b->d_K; P.obs = b->d_obs; P.x0 = b->d_x0; P.x[0] = b->d_x[0]; P.x[1] = b->d_x[1]; P.aux = b->d_aux;
   P.posepart = b->d_posepart; P.gmax = b->d_gmax; P.tiles = b->d_tiles; P.dp = b->d_dp; P.evalpart = b->d_evalpart;
+  P.tilesum = b->d_tilesum; P.posesum = b->d_posesum;
   P.state = b->d_state; P.info = b->d_info; P.dbg = nullptr;
   P.W = b->W; P.N = b->N; P.LPP = b->LPP; P.PPB = b->PPB; P.nblk = b->nblk; P.RP = b->RP; P.RT = b->RT;
   P.n_tiles = b->n_tiles; P.pitch = b->pitch;
@@ -876,6 +943,7 @@ static void ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& prm
                            double* probe_S, double* hpp_out, double* probe_dl) {
   vo_ba_ws* b = c->ba;
   hipLaunchKernelGGL(k_ba_build, dim3(b->nblk), dim3(BA_THREADS), b->build_lds, c->stream, P, prm, it, probe_lambda);
+  hipLaunchKernelGGL(k_ba_reduce, dim3(vo_div_up(b->n_tiles * 256 + b->W * BA_POSE_VALS + 1, 256)), dim3(256), 0, c->stream, P, it);
   hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(BA_THREADS), b->solve_lds, c->stream, P, prm, it, probe_S, hpp_out);
   hipLaunchKernelGGL(k_ba_update, dim3(b->nblk), dim3(BA_THREADS), 0, c->stream, P, prm, it, probe_dl);
 }

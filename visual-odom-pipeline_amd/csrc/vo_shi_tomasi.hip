@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
                                                     uint32_t* __restrict__ scalars, int W, int H, int cell, int gw, int gh,
                                                     double md2, int use_dist, int max_corners, float* __restrict__ out,
                                                     unsigned long long* __restrict__ dbg) {
-  extern __shared__ unsigned char smem[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_flag;
   __shared__ int s_scan[1024];
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
