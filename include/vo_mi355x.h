@@ -192,7 +192,7 @@ enum { VO_PROF_FRAME = 0, VO_PROF_KLT = 1, VO_PROF_ST = 2, VO_PROF_DLT = 3, VO_P
 int32_t vo_profile_enable(vo_ctx* ctx, int32_t region_mask);
 int32_t vo_profile_read(vo_ctx* ctx, int32_t region, double* total_ms, int32_t* count);
 /* diagnostic: shader-clock stamps (s_memtime deltas, cycles) of the phases of the last launch of a
- * single-workgroup / critical-path kernel.  which: 0 = k_st_select, 1 = k_ba_solve, 2 = k_ba_build (workgroup 0).
+ * single-workgroup / critical-path kernel.  which: 0 = k_st_select, 1 = k_ba_solve, 2 = k_ba_build (workgroup 0), 3 = k_klt_track (one wave).
  * out8 receives 8 values (unused entries 0).  Synchronises the stream. */
 int32_t vo_debug_cycles(vo_ctx* ctx, int32_t which, int64_t* out8);
 

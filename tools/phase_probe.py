@@ -9,6 +9,9 @@ with VoContext(1241, 376, max_pts=2048) as c:
     c.push_frame(frames[0]); c.push_frame(frames[1])
     pts = syn.grid_points(2000, 1241, 376)
     for _ in range(3):
+        p1, st, err, it = c.klt_track(pts, return_iters=True)
+    print("klt one wave: iters", it[1000], "cycles [total, template, iter0, top level, levels..1, level0+err]", c.debug_cycles(3)[:6])
+    for _ in range(3):
         cr = c.shi_tomasi(pts, 7)
     eig, mask, nc = c.shi_tomasi_read()
     print("st_select: corners", len(cr), "candidates", nc, "cycles [total, sort, grid, rounds, compact]", c.debug_cycles(0)[:5])

@@ -35,8 +35,7 @@
 
 #include <math.h>
 
-#define BA_THREADS 1024
-#define BA_WAVES (BA_THREADS / 64)
+#define BA_SOLVE_THREADS 1024
 #define BA_AUX 18            // per landmark: Hll(6) gl(3) Cinv(6) z(3)
 #define BA_POSE_VALS 28      // Hpp upper (21) + gp (6) + cost (1)
 #define BA_MAX_SLOTS 20
@@ -72,7 +71,7 @@ struct ba_ptrs {
 };
 
 struct vo_ba_ws {
-  int W = 0, N = 0, LPP = 0, PPB = 0, nblk = 0, RP = 0, RT = 0, n_tiles = 0, pitch = 0;
+  int W = 0, N = 0, LPP = 0, PPB = 0, nblk = 0, RP = 0, RT = 0, n_tiles = 0, pitch = 0, tpb = 0;
   int cap_W = 0, cap_N = 0;
   size_t build_lds = 0, solve_lds = 0;
   double* d_K = nullptr;        // 9
@@ -304,11 +303,12 @@ __device__ inline ba_state ba_init_state(const ba_params_dev& prm) {
 // ------------------------------------------------------------------------------------------------
 // k_ba_build
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BA_THREADS) k_ba_build(ba_ptrs P, ba_params_dev prm, int it, double probe_lambda) {
+template <int TPB>
+__global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs P, ba_params_dev prm, int it, double probe_lambda) {
   extern __shared__ double dyn[];   // phase A: camera-sum scratch [wave][LPP][28]; phase B: Y^ panel [3 PPB][pitch]
   __shared__ double s_cam[BA_CAM * BA_MAX_SLOTS];
   __shared__ double s_K[9];
-  __shared__ double s_gmax[BA_WAVES];
+  __shared__ double s_gmax[(TPB / 64)];
   __shared__ ba_state s_st;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // ---- state for this iteration ----
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_build(ba_ptrs P, ba_params_de
   // iteration 0 reads the uploaded x0 and seeds x[0] with it (each workgroup its own landmarks)
   const double* poses = (it == 0) ? P.x0 : P.x[st.cur];
   const double* pts = poses + 6 * W;
-  stage_cameras(poses, W, s_cam, tid, BA_THREADS);
+  stage_cameras(poses, W, s_cam, tid, TPB);
   if (tid < 9) s_K[tid] = P.K[tid];
   if (it == 0 && blockIdx.x == 0 && tid < 6 * W) P.x[0][tid] = poses[tid];
   __syncthreads();
@@ -429,12 +429,12 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_build(ba_ptrs P, ba_params_de
     const int sl = tid / BA_POSE_VALS, k = tid - sl * BA_POSE_VALS;
     double s = 0;
 #pragma unroll
-    for (int wv = 0; wv < BA_WAVES; wv++) s += dyn[(size_t)(wv * LPP + sl) * BA_POSE_VALS + k];
+    for (int wv = 0; wv < (TPB / 64); wv++) s += dyn[(size_t)(wv * LPP + sl) * BA_POSE_VALS + k];
     P.posepart[((size_t)blockIdx.x * W + sl) * BA_POSE_VALS + k] = s;
   }
   if (tid == 0) {
     double gm = 0;
-    for (int wv = 0; wv < BA_WAVES; wv++) gm = fmax(gm, s_gmax[wv]);
+    for (int wv = 0; wv < (TPB / 64); wv++) gm = fmax(gm, s_gmax[wv]);
     P.gmax[blockIdx.x] = gm;
   }
   __syncthreads();
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_build(ba_ptrs P, ba_params_de
   //   D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
   VO_STAMP(dbgb, 4);   // panel staged
   const int krows = 3 * P.PPB;
-  for (int tile = wave; tile < P.n_tiles; tile += BA_WAVES) {
+  for (int tile = wave; tile < P.n_tiles; tile += (TPB / 64)) {
     int ta = 0, rem = tile;
     while (rem >= P.RT - ta) { rem -= P.RT - ta; ta++; }
     const int tb = ta + rem;
@@ -488,35 +488,44 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_build(ba_ptrs P, ba_params_de
 // element per thread so that the one-workgroup solve reads ~23 KB instead of nblk x 23 KB.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_ba_reduce(ba_ptrs P, int it) {
+  __shared__ double s_part[4][64];
   const ba_state st = P.state[it & 1];
   if (st.done) return;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;       // output within the workgroup, partial group
+  const int e = blockIdx.x * 64 + o;
   const int n_tile_el = P.n_tiles * 256, n_pose_el = P.W * BA_POSE_VALS;
-  const double* src; size_t stride; double* dst;
+  const double* src = nullptr; size_t stride = 0; double* dst = nullptr;
+  bool is_max = false;
   if (e < n_tile_el) { src = P.tiles + e; stride = (size_t)n_tile_el; dst = P.tilesum + e; }
   else if (e < n_tile_el + n_pose_el) { src = P.posepart + (e - n_tile_el); stride = (size_t)n_pose_el; dst = P.posesum + (e - n_tile_el); }
-  else if (e == n_tile_el + n_pose_el) {
-    double gm = 0;
-    for (int b = 0; b < P.nblk; b++) gm = fmax(gm, P.gmax[b]);
-    P.posesum[n_pose_el] = gm;
-    return;
-  } else return;
-  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  int b = 0;
-  for (; b + 8 <= P.nblk; b += 8) {
-    const double v0 = src[(size_t)b * stride], v1 = src[(size_t)(b + 1) * stride], v2 = src[(size_t)(b + 2) * stride];
-    const double v3 = src[(size_t)(b + 3) * stride], v4 = src[(size_t)(b + 4) * stride], v5 = src[(size_t)(b + 5) * stride];
-    const double v6 = src[(size_t)(b + 6) * stride], v7 = src[(size_t)(b + 7) * stride];
-    s0 += v0; s1 += v1; s2 += v2; s3 += v3; s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+  else if (e == n_tile_el + n_pose_el) { src = P.gmax; stride = 1; dst = P.posesum + n_pose_el; is_max = true; }
+  double acc = 0;
+  if (src) {
+    // group g sums partials g, g + 4, g + 8, ... (8 loads in flight), groups are combined in fixed order below
+    double s0 = 0, s1 = 0;
+    int b = g;
+    for (; b + 28 < P.nblk; b += 32) {
+      const double v0 = src[(size_t)b * stride], v1 = src[(size_t)(b + 4) * stride], v2 = src[(size_t)(b + 8) * stride];
+      const double v3 = src[(size_t)(b + 12) * stride], v4 = src[(size_t)(b + 16) * stride], v5 = src[(size_t)(b + 20) * stride];
+      const double v6 = src[(size_t)(b + 24) * stride], v7 = src[(size_t)(b + 28) * stride];
+      if (is_max) { s0 = fmax(fmax(fmax(s0, v0), fmax(v1, v2)), fmax(fmax(v3, v4), fmax(fmax(v5, v6), v7))); }
+      else { s0 += v0; s1 += v1; s0 += v2; s1 += v3; s0 += v4; s1 += v5; s0 += v6; s1 += v7; }
+    }
+    for (; b < P.nblk; b += 4) { const double v = src[(size_t)b * stride]; if (is_max) s0 = fmax(s0, v); else s0 += v; }
+    acc = is_max ? s0 : (s0 + s1);
   }
-  for (; b < P.nblk; b++) s0 += src[(size_t)b * stride];
-  *dst = (s0 + s1) + (s2 + s3);
+  s_part[g][o] = acc;
+  __syncthreads();
+  if (g == 0 && dst) {
+    const double a0 = s_part[0][o], a1 = s_part[1][o], a2 = s_part[2][o], a3 = s_part[3][o];
+    *dst = is_max ? fmax(fmax(a0, a1), fmax(a2, a3)) : ((a0 + a1) + (a2 + a3));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_ba_solve : one workgroup
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_dev prm, int it, double* __restrict__ probe_S,
+__global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs P, ba_params_dev prm, int it, double* __restrict__ probe_S,
                                                          double* __restrict__ hpp_out) {
   extern __shared__ double sm[];
   __shared__ int s_fail;
@@ -533,8 +542,8 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_de
   unsigned long long* dbgs = P.dbg ? P.dbg + 8 : nullptr;
   VO_STAMP(dbgs, 0);
   // ---- reduced camera sums; -E (lower triangle) and +r (row n) from the reduced Gram tiles ----
-  for (int q = tid; q < W * BA_POSE_VALS; q += BA_THREADS) s_hpp[q] = P.posesum[q];
-  for (int e = tid; e < n1 * n1; e += BA_THREADS) {
+  for (int q = tid; q < W * BA_POSE_VALS; q += BA_SOLVE_THREADS) s_hpp[q] = P.posesum[q];
+  for (int e = tid; e < n1 * n1; e += BA_SOLVE_THREADS) {
     const int col = e / n1, row = e - col * n1;       // consecutive threads -> consecutive rows
     if (row < col) continue;
     if (row == n && col == n) { A[(size_t)col * PT + row] = 1.0; continue; }
@@ -548,7 +557,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_de
   VO_STAMP(dbgs, 1);   // partials reduced
   // ---- + damped Hpp blocks, rhs = -gp + r ----
   const double lam = st.lambda;
-  for (int q = tid; q < W * 36; q += BA_THREADS) {
+  for (int q = tid; q < W * 36; q += BA_SOLVE_THREADS) {
     const int sl = q / 36, rr = (q % 36) / 6, cc = q % 6;
     if (cc > rr) continue;
     const int idx = cc * 6 - (cc * (cc - 1)) / 2 + (rr - cc);   // upper-packed (cc, rr)
@@ -556,16 +565,16 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_de
     if (rr == cc) v += lam * fmax(v, 1e-12);
     A[(size_t)(6 * sl + cc) * PT + 6 * sl + rr] += v;
   }
-  for (int a = tid; a < n; a += BA_THREADS) A[(size_t)a * PT + n] -= s_hpp[(a / 6) * BA_POSE_VALS + 21 + a % 6];
+  for (int a = tid; a < n; a += BA_SOLVE_THREADS) A[(size_t)a * PT + n] -= s_hpp[(a / 6) * BA_POSE_VALS + 21 + a % 6];
   __syncthreads();
   if (probe_S) {   // reduced camera system before factorisation (parity probe)
-    for (int e = tid; e < n * n; e += BA_THREADS) {
+    for (int e = tid; e < n * n; e += BA_SOLVE_THREADS) {
       const int a = e / n, b = e - a * n;
       probe_S[e] = (b <= a) ? A[(size_t)b * PT + a] : A[(size_t)a * PT + b];
     }
-    for (int a = tid; a < n; a += BA_THREADS) probe_S[(size_t)n * n + a] = A[(size_t)a * PT + n];
+    for (int a = tid; a < n; a += BA_SOLVE_THREADS) probe_S[(size_t)n * n + a] = A[(size_t)a * PT + n];
   }
-  if (hpp_out) for (int q = tid; q < W * BA_POSE_VALS; q += BA_THREADS) hpp_out[q] = s_hpp[q];
+  if (hpp_out) for (int q = tid; q < W * BA_POSE_VALS; q += BA_SOLVE_THREADS) hpp_out[q] = s_hpp[q];
   VO_STAMP(dbgs, 2);   // system assembled
   // ---- 6x6-blocked right-looking Cholesky of the augmented matrix (row n carries rhs -> y) ----
   for (int kb = 0; kb < W; kb++) {
@@ -624,9 +633,13 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_de
     }
     __syncthreads();
     const int s0 = c0 + 6, m = n1 - s0;
-    for (int idx = tid; idx < m * m; idx += BA_THREADS) {
-      const int jj = idx / m, ii = idx - jj * m;
-      if (jj > ii) continue;
+    for (int idx = tid; idx < (m * (m + 1)) / 2; idx += BA_SOLVE_THREADS) {
+      // idx -> (column jj, row ii >= jj) of the lower triangle, column-major packed: rows of a column are
+      // consecutive threads (conflict-free LDS)
+      int jj = (int)((2.f * m + 1.f - sqrtf((2.f * m + 1.f) * (2.f * m + 1.f) - 8.f * (float)idx)) * 0.5f);
+      while (jj > 0 && jj * m - (jj * (jj - 1)) / 2 > idx) jj--;
+      while ((jj + 1) * m - ((jj + 1) * jj) / 2 <= idx) jj++;
+      const int ii = jj + (idx - (jj * m - (jj * (jj - 1)) / 2));
       const int i = s0 + ii, jcol = s0 + jj;
       if (i == n && jcol == n) continue;
       double acc = A[(size_t)jcol * PT + i];
@@ -637,44 +650,54 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_de
     __syncthreads();
   }
   VO_STAMP(dbgs, 3);   // factorised
-  // ---- back substitution  L^T dp = y  by wave 0 (lane i holds rows i and i + 64) ----
-  // The recurrence only carries (y, dk); the rows of L^T are prefetched 4 steps ahead so that no LDS latency
-  // sits on the dependent chain.
+  // ---- back substitution  L^T dp = y  by wave 0, 6x6 block at a time (lane i holds rows i and i + 64):
+  //      every lane solves the 6x6 triangular block redundantly in registers (operands are wave-uniform LDS
+  //      broadcasts), then the lanes above the block subtract their 6-term update -> W steps instead of 6W ----
   if (tid < 64) {
     const int lane = tid;
     double y0 = (lane < n) ? A[(size_t)lane * PT + n] : 0.0;
     double y1 = (lane + 64 < n) ? A[(size_t)(lane + 64) * PT + n] : 0.0;
-    const double iv0 = (lane < n) ? s_invd[lane] : 0.0, iv1 = (lane + 64 < n) ? s_invd[lane + 64] : 0.0;
-    double res0 = 0.0, res1 = 0.0;
-    double r0[4], r1[4];
+    for (int kb = W - 1; kb >= 0; kb--) {
+      const int c0 = 6 * kb;
+      double yb[6], d[6];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int k = n - 1 - q;
-      r0[q] = (k >= 0 && lane < k) ? A[(size_t)lane * PT + k] : 0.0;          // L[k][i] = A[i * PT + k]
-      r1[q] = (k >= 0 && lane + 64 < k) ? A[(size_t)(lane + 64) * PT + k] : 0.0;
-    }
-    for (int kk = n - 1; kk >= 0; kk -= 4) {
+      for (int c = 0; c < 6; c++) {
+        const int k = c0 + c;
+        yb[c] = (k < 64) ? readlane_f64(y0, k & 63) : readlane_f64(y1, k & 63);
+      }
+      // solve L_kk^T d = yb  (L_kk[e][c] = A[(c0 + c) * PT + c0 + e], e >= c)
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int k = kk - q;
-        if (k < 0) break;
-        const int src = k & 63;
-        const double dk = (k < 64) ? readlane_f64(y0 * iv0, src) : readlane_f64(y1 * iv1, src);
-        y0 -= r0[q] * dk; y1 -= r1[q] * dk;
-        if (lane == src) { if (k < 64) res0 = dk; else res1 = dk; }
-        const int kn = k - 4;     // refill this slot with the row needed 4 steps later
-        r0[q] = (kn >= 0 && lane < kn) ? A[(size_t)lane * PT + kn] : 0.0;
-        r1[q] = (kn >= 0 && lane + 64 < kn) ? A[(size_t)(lane + 64) * PT + kn] : 0.0;
+      for (int c = 5; c >= 0; c--) {
+        double t = yb[c];
+#pragma unroll
+        for (int e = 5; e > c; e--) t -= A[(size_t)(c0 + c) * PT + c0 + e] * d[e];
+        d[c] = t * s_invd[c0 + c];
+      }
+      // rows above the block: y_i -= sum_c L[c0 + c][i] d_c,  L[k][i] = A[i * PT + k]
+      if (lane < c0) {
+        const double* col = A + (size_t)lane * PT + c0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) y0 -= col[c] * d[c];
+      }
+      if (lane + 64 < c0) {
+        const double* col = A + (size_t)(lane + 64) * PT + c0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) y1 -= col[c] * d[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        const int k = c0 + c;
+        if (lane == (k & 63)) { if (k < 64) y0 = d[c]; else y1 = d[c]; }
       }
     }
-    if (lane < n) s_dp[lane] = res0;
-    if (lane + 64 < n) s_dp[lane + 64] = res1;
+    if (lane < n) s_dp[lane] = y0;
+    if (lane + 64 < n) s_dp[lane + 64] = y1;
   }
   __syncthreads();
   VO_STAMP(dbgs, 4);   // back substitution
   // ---- publish ----
   const int fail = s_fail;
-  for (int a = tid; a < n; a += BA_THREADS) P.dp[a] = fail ? 0.0 : s_dp[a];
+  for (int a = tid; a < n; a += BA_SOLVE_THREADS) P.dp[a] = fail ? 0.0 : s_dp[a];
   if (tid < 128) {
     // wave-parallel step statistics of the camera block (lanes = parameters)
     const double* poses = P.x[st.cur];
@@ -710,13 +733,14 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_solve(ba_ptrs P, ba_params_de
 // ------------------------------------------------------------------------------------------------
 // k_ba_update : back-substitute landmarks, form the trial x, evaluate the trial cost
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BA_THREADS) k_ba_update(ba_ptrs P, ba_params_dev prm, int it, double* __restrict__ probe_dl) {
+template <int TPB>
+__global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs P, ba_params_dev prm, int it, double* __restrict__ probe_dl) {
   __shared__ double s_cam[BA_CAM * BA_MAX_SLOTS];    // current poses
   __shared__ double s_camt[BA_CAM * BA_MAX_SLOTS];   // trial poses
   __shared__ double s_K[9];
   __shared__ double s_dp[6 * BA_MAX_SLOTS];
   __shared__ double s_pose[6 * BA_MAX_SLOTS];
-  __shared__ double s_red[BA_WAVES * BA_EVAL_VALS];
+  __shared__ double s_red[(TPB / 64) * BA_EVAL_VALS];
   const ba_state st = P.state[it & 1];
   if (st.done) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, W = P.W, N = P.N, LPP = P.LPP;
@@ -724,16 +748,16 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_update(ba_ptrs P, ba_params_d
   const double* pts = P.x[st.cur] + 6 * W;
   double* tposes = P.x[st.cur ^ 1];
   double* tpts = P.x[st.cur ^ 1] + 6 * W;
-  for (int a = tid; a < 6 * W; a += BA_THREADS) {
+  for (int a = tid; a < 6 * W; a += TPB) {
     const double d = P.dp[a];
     s_dp[a] = d;
     s_pose[a] = poses[a] + d;
     if (blockIdx.x == 0) tposes[a] = poses[a] + d;
   }
   if (tid < 9) s_K[tid] = P.K[tid];
-  stage_cameras(poses, W, s_cam, tid, BA_THREADS);
+  stage_cameras(poses, W, s_cam, tid, TPB);
   __syncthreads();
-  stage_cameras(s_pose, W, s_camt, tid, BA_THREADS);
+  stage_cameras(s_pose, W, s_camt, tid, TPB);
   __syncthreads();
   const int pl = tid / LPP, slot = tid - pl * LPP;
   const int j = blockIdx.x * P.PPB + pl;
@@ -785,7 +809,7 @@ __global__ void __launch_bounds__(BA_THREADS) k_ba_update(ba_ptrs P, ba_params_d
   __syncthreads();
   if (tid < BA_EVAL_VALS) {
     double s = 0;
-    for (int wv = 0; wv < BA_WAVES; wv++) s += s_red[wv * 4 + tid];
+    for (int wv = 0; wv < (TPB / 64); wv++) s += s_red[wv * 4 + tid];
     P.evalpart[blockIdx.x * BA_EVAL_VALS + tid] = s;
   }
 }
@@ -851,12 +875,15 @@ extern "C" int32_t vo_ba_default_params(vo_ba_params* p) {
 static void ba_geometry(vo_ba_ws* b, int W, int N) {
   b->W = W; b->N = N;
   b->LPP = (W <= 16) ? 16 : 32;
-  b->PPB = BA_THREADS / b->LPP;
+  // workgroup size: 256 lanes (more workgroups -> more CUs, less contention on the f64 pipes) unless that would
+  // produce more than 160 partial sets, then 1024
+  b->tpb = (vo_div_up(N, 256 / b->LPP) <= 160) ? 256 : 1024;
+  b->PPB = b->tpb / b->LPP;
   b->nblk = vo_div_up(N, b->PPB);
   b->RP = ((6 * W + 1 + 15) / 16) * 16; b->RT = b->RP / 16; b->n_tiles = b->RT * (b->RT + 1) / 2;
   b->pitch = b->RP + BA_PITCH_PAD;
   const size_t panel = sizeof(double) * (size_t)3 * b->PPB * b->pitch;
-  const size_t scratch = sizeof(double) * (size_t)BA_WAVES * b->LPP * BA_POSE_VALS;
+  const size_t scratch = sizeof(double) * (size_t)(b->tpb / 64) * b->LPP * BA_POSE_VALS;
   b->build_lds = panel > scratch ? panel : scratch;
   const int n1 = 6 * W + 1, PT = n1 | 1;
   b->solve_lds = sizeof(double) * ((size_t)n1 * PT + (size_t)W * BA_POSE_VALS + n1 + n1 + 24);
@@ -893,7 +920,8 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     VO_HIP(c, hipMalloc((void**)&b->d_state, sizeof(ba_state) * 2));
     VO_HIP(c, hipMalloc((void**)&b->d_info, sizeof(ba_info)));
     VO_HIP(c, hipHostMalloc((void**)&b->h_state, sizeof(ba_state) * 2, hipHostMallocDefault));
-    VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
+    VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
+    VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
   }
   ba_geometry(c->ba, W, N);
@@ -942,10 +970,12 @@ extern "C" int32_t vo_ba_upload(vo_ctx* c, const double* K, const double* poses,
 static void ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& prm, int it, double probe_lambda,
                            double* probe_S, double* hpp_out, double* probe_dl) {
   vo_ba_ws* b = c->ba;
-  hipLaunchKernelGGL(k_ba_build, dim3(b->nblk), dim3(BA_THREADS), b->build_lds, c->stream, P, prm, it, probe_lambda);
-  hipLaunchKernelGGL(k_ba_reduce, dim3(vo_div_up(b->n_tiles * 256 + b->W * BA_POSE_VALS + 1, 256)), dim3(256), 0, c->stream, P, it);
-  hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(BA_THREADS), b->solve_lds, c->stream, P, prm, it, probe_S, hpp_out);
-  hipLaunchKernelGGL(k_ba_update, dim3(b->nblk), dim3(BA_THREADS), 0, c->stream, P, prm, it, probe_dl);
+  if (b->tpb == 256) hipLaunchKernelGGL(k_ba_build<256>, dim3(b->nblk), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
+  else hipLaunchKernelGGL(k_ba_build<1024>, dim3(b->nblk), dim3(1024), b->build_lds, c->stream, P, prm, it, probe_lambda);
+  hipLaunchKernelGGL(k_ba_reduce, dim3(vo_div_up(b->n_tiles * 256 + b->W * BA_POSE_VALS + 1, 64)), dim3(256), 0, c->stream, P, it);
+  hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(BA_SOLVE_THREADS), b->solve_lds, c->stream, P, prm, it, probe_S, hpp_out);
+  if (b->tpb == 256) hipLaunchKernelGGL(k_ba_update<256>, dim3(b->nblk), dim3(256), 0, c->stream, P, prm, it, probe_dl);
+  else hipLaunchKernelGGL(k_ba_update<1024>, dim3(b->nblk), dim3(1024), 0, c->stream, P, prm, it, probe_dl);
 }
 
 // enqueue `n_it` LM iterations starting at iteration index `it0` (state must be in place)

@@ -115,7 +115,7 @@ extern "C" int32_t vo_profile_enable(vo_ctx* c, int32_t region_mask) {
 
 extern "C" int32_t vo_debug_cycles(vo_ctx* c, int32_t which, int64_t* out8) {
   if (!c) return VO_E_INVALID;
-  VO_CHECK(c, which >= 0 && which < 3 && out8, VO_E_INVALID, "bad selector");
+  VO_CHECK(c, which >= 0 && which < 4 && out8, VO_E_INVALID, "bad selector");
   VO_HIP(c, hipSetDevice(c->device));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   unsigned long long h[8];
@@ -228,8 +228,8 @@ extern "C" int32_t vo_ctx_create(int32_t device, int32_t width, int32_t height, 
       CR(hipMemsetAsync(c->fr[f].der[l], 0, px * 4, c->stream));   // border stays 0 forever
     }
   CR(hipMalloc((void**)&c->d_raw, (size_t)width * height));
-  CR(hipMalloc((void**)&c->d_dbg, sizeof(unsigned long long) * 24));
-  CR(hipMemsetAsync(c->d_dbg, 0, sizeof(unsigned long long) * 24, c->stream));
+  CR(hipMalloc((void**)&c->d_dbg, sizeof(unsigned long long) * 32));
+  CR(hipMemsetAsync(c->d_dbg, 0, sizeof(unsigned long long) * 32, c->stream));
   CR(hipMalloc((void**)&c->d_p0, sizeof(float) * 2 * max_pts));
   CR(hipMalloc((void**)&c->d_p1, sizeof(float) * 2 * max_pts));
   CR(hipMalloc((void**)&c->d_err, sizeof(float) * max_pts));

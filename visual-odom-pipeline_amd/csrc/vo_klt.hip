@@ -107,10 +107,12 @@ __device__ __forceinline__ int deriv1(uint32_t top, uint32_t bot, uint32_t wt, u
 
 __global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __restrict__ p0, float* __restrict__ p1,
                                                   uint8_t* __restrict__ status, float* __restrict__ err,
-                                                  int32_t* __restrict__ iters) {
+                                                  int32_t* __restrict__ iters, unsigned long long* __restrict__ dbg) {
   const int pt = blockIdx.x;
   if (pt >= A.n) return;
   const int lane = threadIdx.x;
+  unsigned long long* dbgk = (pt == A.n / 2 && dbg) ? dbg + 24 : nullptr;   // diagnostic stamps of one wave
+  VO_STAMP(dbgk, 0);
   const int cp = lane >> 2, r = lane & 3;
   const int win = A.win;
   const float half = (float)(win - 1) * 0.5f;
@@ -178,6 +180,7 @@ __global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __res
         a22 = dot2(yp, yp, a22);
       }
       const long long iA11 = wave_sum_i64(a11), iA12 = wave_sum_i64(a12), iA22 = wave_sum_i64(a22);
+      if (level == A.top) VO_STAMP(dbgk, 1);   // first template
       const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
       float D = A11 * A22 - A12 * A12;
       const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
@@ -226,8 +229,11 @@ __global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __res
           break;
         }
         pdx = dx; pdy = dy;
+        if (level == A.top && j == 0) VO_STAMP(dbgk, 2);   // first LK iteration
       }
       n_it = j;
+      if (level == A.top) VO_STAMP(dbgk, 3);   // top level done
+      if (level == 1) VO_STAMP(dbgk, 4);       // levels top-1 .. 1 done
       if (iters && lane == 0) iters[pt * A.iters_stride + level] = n_it;
 
       if (st && level == 0) {
@@ -257,6 +263,7 @@ __global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __res
       }
     }
   }
+  VO_STAMP(dbgk, 5);
   if (lane == 0) {
     p1[2 * pt] = outx; p1[2 * pt + 1] = outy;
     status[pt] = (uint8_t)st;
@@ -302,7 +309,7 @@ static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, const floa
   VO_HIP(c, hipMemsetAsync(c->d_iters, 0xff, sizeof(int32_t) * (size_t)n * A.iters_stride, c->stream));
   {
     vo_prof_scope prof(c, VO_PROF_KLT);   // brackets exactly this launch (bench.py roofline figure)
-    hipLaunchKernelGGL(k_klt_track, dim3(n), dim3(64), 0, c->stream, A, d_in, d_out, c->d_status, c->d_err, c->d_iters);
+    hipLaunchKernelGGL(k_klt_track, dim3(n), dim3(64), 0, c->stream, A, d_in, d_out, c->d_status, c->d_err, c->d_iters, c->d_dbg);
   }
   VO_HIP(c, hipGetLastError());
   return VO_OK;
