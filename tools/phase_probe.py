@@ -14,7 +14,7 @@ with VoContext(1241, 376, max_pts=2048) as c:
     for _ in range(3):
         cr = c.shi_tomasi(pts, 7)
     eig, mask, nc = c.shi_tomasi_read()
-    print("st_select: corners", len(cr), "candidates", nc, "cycles [total, sort, grid, rounds, compact]", c.debug_cycles(0)[:5])
+    print("st_select: corners", len(cr), "candidates", nc, "cycles [total, sort, grid, rounds, compact]", c.debug_cycles(0)[:5], "rounds", c.debug_cycles(0)[7], "round0 cycles", c.debug_cycles(0)[5])
     s = syn.make_ba_scene(2000, 10, seed=0)
     c.ba_upload(s["K"], s["poses0"], s["points0"], s["obs"])
     for _ in range(3):

@@ -425,8 +425,8 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs P, ba_params_dev prm, 
     }
   }
   __syncthreads();
-  if (tid < W * BA_POSE_VALS) {
-    const int sl = tid / BA_POSE_VALS, k = tid - sl * BA_POSE_VALS;
+  for (int t = tid; t < W * BA_POSE_VALS; t += TPB) {
+    const int sl = t / BA_POSE_VALS, k = t - sl * BA_POSE_VALS;
     double s = 0;
 #pragma unroll
     for (int wv = 0; wv < (TPB / 64); wv++) s += dyn[(size_t)(wv * LPP + sl) * BA_POSE_VALS + k];
@@ -465,20 +465,37 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs P, ba_params_dev prm, 
   //   D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
   VO_STAMP(dbgb, 4);   // panel staged
   const int krows = 3 * P.PPB;
-  for (int tile = wave; tile < P.n_tiles; tile += (TPB / 64)) {
-    int ta = 0, rem = tile;
-    while (rem >= P.RT - ta) { rem -= P.RT - ta; ta++; }
-    const int tb = ta + rem;
-    const double* base = dyn + (size_t)(lane >> 4) * pitch + (lane & 15);
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int k0 = 0; k0 < krows; k0 += 4) {
-      const double a = base[(size_t)k0 * pitch + 16 * ta];
-      const double b = base[(size_t)k0 * pitch + 16 * tb];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  // a wave walks its tiles three at a time: three independent accumulator chains hide the LDS and MFMA latency
+  for (int tile0 = wave; tile0 < P.n_tiles; tile0 += 3 * (TPB / 64)) {
+    int tas[3], tbs[3];
+    bool on[3];
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      const int tile = tile0 + u * (TPB / 64);
+      on[u] = tile < P.n_tiles;
+      int ta = 0, rem = on[u] ? tile : 0;
+      while (rem >= P.RT - ta) { rem -= P.RT - ta; ta++; }
+      tas[u] = ta; tbs[u] = ta + rem;
     }
-    double* out = P.tiles + ((size_t)blockIdx.x * P.n_tiles + tile) * 256 + lane * 4;
-    out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2]; out[3] = acc[3];
+    const double* base = dyn + (size_t)(lane >> 4) * pitch + (lane & 15);
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0;
+#pragma unroll 2
+    for (int k0 = 0; k0 < krows; k0 += 4) {
+      const double* rowp = base + (size_t)k0 * pitch;
+      const double a0 = rowp[16 * tas[0]], b0 = rowp[16 * tbs[0]];
+      const double a1 = rowp[16 * tas[1]], b1 = rowp[16 * tbs[1]];
+      const double a2 = rowp[16 * tas[2]], b2 = rowp[16 * tbs[2]];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+      if (on[1]) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+      if (on[2]) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      if (!on[u]) continue;
+      const d4 acc = (u == 0) ? acc0 : (u == 1) ? acc1 : acc2;
+      double* out = P.tiles + ((size_t)blockIdx.x * P.n_tiles + tile0 + u * (TPB / 64)) * 256 + lane * 4;
+      out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2]; out[3] = acc[3];
+    }
   }
   VO_STAMP(dbgb, 5);   // Gram tiles (wave 0)
 }

@@ -121,8 +121,9 @@ extern "C" int32_t vo_debug_cycles(vo_ctx* c, int32_t which, int64_t* out8) {
   unsigned long long h[8];
   VO_HIP(c, hipMemcpy(h, c->d_dbg + 8 * which, sizeof(h), hipMemcpyDeviceToHost));
   out8[0] = 0;
-  for (int i = 1; i < 8; i++) out8[i] = (h[i] && h[i - 1]) ? (int64_t)(h[i] - h[i - 1]) : 0;
+  for (int i = 1; i < 8; i++) out8[i] = (h[i] && h[i - 1] && !(which == 0 && i >= 5)) ? (int64_t)(h[i] - h[i - 1]) : 0;
   for (int i = 1; i < 8; i++) out8[0] += out8[i];
+  if (which == 0) { out8[7] = (int64_t)h[6]; out8[5] = (h[5] && h[2]) ? (int64_t)(h[5] - h[2]) : 0; }   // rounds; cycles of round 0
   return VO_OK;
 }
 

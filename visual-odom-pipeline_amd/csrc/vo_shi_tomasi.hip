@@ -191,66 +191,115 @@ __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, c
   }
 }
 
-// LDS map of k_st_select (144 KB): sort phase: keys u64 [n2 <= 16384] at 0.
+// LDS map of k_st_select (144 KB): exchange buffer of the sort: keys u64 [n2 <= 16384] at 0.
 // selection phase (keys dead): xy u32 [n] at 0 | cell heads u32 [<= 8192] at 64 KB | next u16 [n] at 96 KB | state u8 [n] at 128 KB
 #define ST_SEL_LDS (144 * 1024)
 #define ST_MAX_CELLS 8192
+#define ST_KP_MAX (ST_CAND_CAP / 1024)
+
+// Bitonic sort (descending) of n2 = 1024 * KP keys held in REGISTERS: lane (wave w, lane l) owns keys
+// i = w * 64 KP + q * 64 + l, q < KP.  Compare-exchange distances j < 64 are cross-lane shuffles, 64 <= j < 64 KP
+// are pure register swaps, only j >= 64 KP (between waves) goes through LDS -- LDS latency (~100 cycles per
+// dependent access) is what bounds an all-LDS bitonic sort of this size.
+template <int KP>
+__device__ __forceinline__ void st_sort_regs(unsigned long long (&kr)[KP], unsigned long long* keys, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+  constexpr int SEG = KP * 64;
+  constexpr int N2 = KP * 1024;
+  const int ibase = wave * SEG + lane;
+#pragma unroll 1
+  for (int k = 2; k <= N2; k <<= 1) {
+#pragma unroll 1
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= SEG) {
+        // partner lives in another wave: exchange through LDS
+#pragma unroll
+        for (int q = 0; q < KP; q++) keys[ibase + q * 64] = kr[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < KP; q++) {
+          const int i = ibase + q * 64;
+          const unsigned long long other = keys[i ^ j];
+          const bool take_max = (((i & k) == 0) == ((i & j) == 0));
+          const unsigned long long mine = kr[q];
+          kr[q] = take_max ? (mine > other ? mine : other) : (mine < other ? mine : other);
+        }
+        __syncthreads();
+      } else if (j >= 64) {
+        const int jq = j >> 6;
+#pragma unroll
+        for (int q = 0; q < KP; q++) {
+          if ((q & jq) == 0 && (q | jq) < KP) {
+            const int i = ibase + q * 64;
+            const bool desc = ((i & k) == 0);
+            const unsigned long long a = kr[q], b = kr[q | jq];
+            const bool sw = desc ? (a < b) : (a > b);
+            kr[q] = sw ? b : a; kr[q | jq] = sw ? a : b;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < KP; q++) {
+          const int i = ibase + q * 64;
+          const unsigned long long mine = kr[q];
+          const unsigned long long other = __shfl_xor(mine, j);
+          const bool take_max = (((i & k) == 0) == ((lane & j) == 0));
+          kr[q] = take_max ? (mine > other ? mine : other) : (mine < other ? mine : other);
+        }
+      }
+    }
+  }
+}
+
+template <int KP>
+__device__ __forceinline__ void st_sort_dispatch(const unsigned long long* __restrict__ cand, int n, unsigned long long* keys,
+                                                 uint32_t* xy, int W, int tid) {
+  unsigned long long kr[KP];
+  const int ibase = (tid >> 6) * (KP * 64) + (tid & 63);
+#pragma unroll
+  for (int q = 0; q < KP; q++) { const int i = ibase + q * 64; kr[q] = (i < n) ? cand[i] : 0ull; }
+  st_sort_regs<KP>(kr, keys, tid);
+  __syncthreads();   // the exchange buffer aliases xy
+  // keys -> packed (x, y) in rank order
+#pragma unroll
+  for (int q = 0; q < KP; q++) {
+    const int i = ibase + q * 64;
+    if (i < n) {
+      const int idx = (int)(uint32_t)kr[q];
+      const int y = idx / W, x = idx - y * W;
+      xy[i] = (uint32_t)x | ((uint32_t)y << 16);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __restrict__ cand,
                                                     uint32_t* __restrict__ scalars, int W, int H, int cell, int gw, int gh,
                                                     double md2, int use_dist, int max_corners, float* __restrict__ out,
                                                     unsigned long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int s_flag;
+  __shared__ int s_flags[3];
   __shared__ int s_scan[1024];
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
   uint32_t* xy = reinterpret_cast<uint32_t*>(smem);
   uint32_t* heads = reinterpret_cast<uint32_t*>(smem + 64 * 1024);
   uint16_t* nxt = reinterpret_cast<uint16_t*>(smem + 96 * 1024);
-  volatile uint8_t* state = reinterpret_cast<volatile uint8_t*>(smem + 128 * 1024);
+  uint8_t* state = smem + 128 * 1024;   // plain LDS bytes (a volatile pointer here degrades to FLAT sc0 sc1 accesses)
   const int tid = threadIdx.x;
   VO_STAMP(dbg, 0);
   const uint32_t ncand = scalars[1];
   if (ncand > ST_CAND_CAP) { if (tid == 0) scalars[2] = 0xFFFFFFFFu; return; }   // host reports VO_E_CAPACITY
   const int n = (int)ncand;
-  int n2 = 1;
-  while (n2 < n) n2 <<= 1;
-  for (int i = tid; i < n2; i += 1024) keys[i] = (i < n) ? cand[i] : 0ull;
-  __syncthreads();
-  // ---- bitonic sort, descending: (value desc, index desc) = OpenCV's greaterThanPtr order ----
-  for (int k = 2; k <= n2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < n2; i += 1024) {
-        const int l = i ^ j;
-        if (l > i) {
-          const unsigned long long a = keys[i], b = keys[l];
-          const bool desc = ((i & k) == 0);
-          if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[l] = a; }
-        }
-      }
-      __syncthreads();
-    }
-  VO_STAMP(dbg, 1);   // sort done
-  // ---- keys -> packed (x, y) in rank order (read everything before overwriting the aliased region) ----
-  uint32_t myxy[ST_CAND_CAP / 1024];
-#pragma unroll
-  for (int q = 0; q < ST_CAND_CAP / 1024; q++) {
-    const int i = tid + q * 1024;
-    uint32_t v = 0;
-    if (i < n) {
-      const int idx = (int)(uint32_t)keys[i];
-      const int y = idx / W, x = idx - y * W;
-      v = (uint32_t)x | ((uint32_t)y << 16);
-    }
-    myxy[q] = v;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < ST_CAND_CAP / 1024; q++) {
-    const int i = tid + q * 1024;
-    if (i < n) { xy[i] = myxy[q]; state[i] = use_dist ? 0 : 1; }
-  }
+  // ---- sort by (value desc, index desc) = OpenCV's greaterThanPtr order; result: xy[] in rank order ----
+  if (n <= 1024) st_sort_dispatch<1>(cand, n, keys, xy, W, tid);
+  else if (n <= 2048) st_sort_dispatch<2>(cand, n, keys, xy, W, tid);
+  else if (n <= 4096) st_sort_dispatch<4>(cand, n, keys, xy, W, tid);
+  else if (n <= 8192) st_sort_dispatch<8>(cand, n, keys, xy, W, tid);
+  else st_sort_dispatch<16>(cand, n, keys, xy, W, tid);
+  for (int i = tid; i < n; i += 1024) state[i] = use_dist ? 0 : 1;
   for (int i = tid; i < gw * gh; i += 1024) heads[i] = 0xFFFFu;
+  if (tid < 3) s_flags[tid] = 0;
   __syncthreads();
+  VO_STAMP(dbg, 1);   // sort done
   if (use_dist) {
     // ---- grid of linked lists (acceleration structure only: any cell size >= min_distance gives the same result) ----
     for (int i = tid; i < n; i += 1024) {
@@ -260,41 +309,89 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
     }
     __syncthreads();
     VO_STAMP(dbg, 2);   // grid built
-    // ---- greedy min-distance selection as monotone parallel rounds: a candidate is accepted iff every
-    //      higher-ranked candidate closer than min_distance is rejected (== the sequential scan) ----
-    for (int round = 0; round <= n; round++) {
-      if (tid == 0) s_flag = 0;
-      __syncthreads();
-      bool undecided = false;
-      for (int i = tid; i < n; i += 1024) {
-        if (state[i] != 0) continue;
+    // ---- conflict lists: for each own candidate the (<= 4) higher-ranked candidates closer than min_distance,
+    //      found by ONE walk over the 3x3 cells (9 independent head reads, then the short chains) and kept in
+    //      registers, so that the selection rounds below touch one LDS byte per conflict ----
+    unsigned long long nb[ST_KP_MAX];
+    uint32_t over = 0, mine = 0, undec = 0;   // bit q: list overflowed / candidate exists / still undecided
+#pragma unroll
+    for (int q = 0; q < ST_KP_MAX; q++) {
+      nb[q] = ~0ull;
+      const int i = tid + q * 1024;
+      if (i < n) {
+        mine |= 1u << q; undec |= 1u << q;
         const uint32_t p = xy[i];
         const int x = p & 0xFFFF, y = p >> 16;
         const int xc = x / cell, yc = y / cell;
-        const int x1 = max(xc - 1, 0), y1 = max(yc - 1, 0), x2 = min(xc + 1, gw - 1), y2 = min(yc + 1, gh - 1);
-        bool any_acc = false, any_und = false;
-        for (int yy = y1; yy <= y2; yy++)
-          for (int xx = x1; xx <= x2; xx++)
-            for (uint32_t q = heads[yy * gw + xx]; q != 0xFFFFu; q = nxt[q]) {
-              if ((int)q >= i) continue;   // only higher-ranked candidates matter
-              const uint32_t pq = xy[q];
-              const int ddx = x - (int)(pq & 0xFFFF), ddy = y - (int)(pq >> 16);
-              if ((double)(ddx * ddx + ddy * ddy) < md2) {
-                const uint8_t s = state[q];
-                if (s == 1) any_acc = true;
-                else if (s == 0) any_und = true;
-              }
+        uint32_t hd[9];
+#pragma unroll
+        for (int c9 = 0; c9 < 9; c9++) {
+          const int xx = xc + (c9 % 3) - 1, yy = yc + (c9 / 3) - 1;
+          hd[c9] = (xx >= 0 && xx < gw && yy >= 0 && yy < gh) ? heads[yy * gw + xx] : 0xFFFFu;
+        }
+        int cnt = 0;
+        unsigned long long list = ~0ull;
+#pragma unroll
+        for (int c9 = 0; c9 < 9; c9++)
+          for (uint32_t qn = hd[c9]; qn != 0xFFFFu; qn = nxt[qn]) {
+            if ((int)qn >= i) continue;   // only higher-ranked candidates matter
+            const uint32_t pq = xy[qn];
+            const int ddx = x - (int)(pq & 0xFFFF), ddy = y - (int)(pq >> 16);
+            if ((double)(ddx * ddx + ddy * ddy) < md2) {
+              if (cnt < 4) list = (list << 16) | (unsigned long long)qn;
+              cnt++;
             }
-        if (any_acc) state[i] = 2;
-        else if (!any_und) state[i] = 1;
-        else undecided = true;
+          }
+        nb[q] = list;
+        if (cnt > 4) over |= 1u << q;
       }
-      if (undecided) s_flag = 1;
-      __syncthreads();
-      const int f = s_flag;
-      __syncthreads();
-      if (!f) { if (tid == 0) scalars[3] = (uint32_t)round + 1; break; }
     }
+    // ---- greedy min-distance selection as monotone parallel rounds: a candidate is accepted iff every
+    //      higher-ranked candidate closer than min_distance is rejected (== OpenCV's sequential scan) ----
+    for (int round = 0; round <= n; round++) {
+      if (tid == 0) s_flags[(round + 1) % 3] = 0;   // re-arm the flag last read two rounds ago
+#pragma unroll
+      for (int q = 0; q < ST_KP_MAX; q++) {
+        if (!((undec >> q) & 1)) continue;
+        const int i = tid + q * 1024;
+        bool any_acc = false, any_und = false;
+        if (!((over >> q) & 1)) {
+          const unsigned long long list = nb[q];
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const uint32_t qn = (uint32_t)(list >> (16 * t)) & 0xFFFFu;
+            if (qn != 0xFFFFu) {
+              const uint8_t sq = state[qn];
+              any_acc |= (sq == 1); any_und |= (sq == 0);
+            }
+          }
+        } else {
+          // rare: more than 4 conflicts -> walk the grid again
+          const uint32_t p = xy[i];
+          const int x = p & 0xFFFF, y = p >> 16;
+          const int xc = x / cell, yc = y / cell;
+          const int x1 = max(xc - 1, 0), y1 = max(yc - 1, 0), x2 = min(xc + 1, gw - 1), y2 = min(yc + 1, gh - 1);
+          for (int yy = y1; yy <= y2; yy++)
+            for (int xx = x1; xx <= x2; xx++)
+              for (uint32_t qn = heads[yy * gw + xx]; qn != 0xFFFFu; qn = nxt[qn]) {
+                if ((int)qn >= i) continue;
+                const uint32_t pq = xy[qn];
+                const int ddx = x - (int)(pq & 0xFFFF), ddy = y - (int)(pq >> 16);
+                if ((double)(ddx * ddx + ddy * ddy) < md2) {
+                  const uint8_t sq = state[qn];
+                  any_acc |= (sq == 1); any_und |= (sq == 0);
+                }
+              }
+        }
+        if (any_acc) { state[i] = 2; undec &= ~(1u << q); }
+        else if (!any_und) { state[i] = 1; undec &= ~(1u << q); }
+      }
+      if (undec) s_flags[round % 3] = 1;
+      __syncthreads();
+      if (round == 0) VO_STAMP(dbg, 5);
+      if (!s_flags[round % 3]) { if (tid == 0) { scalars[3] = (uint32_t)round + 1; if (dbg) dbg[6] = (unsigned long long)(round + 1); } break; }
+    }
+    (void)mine;
   }
   VO_STAMP(dbg, 3);   // rounds done
   // ---- ordered compaction of the accepted candidates (rank order), first max_corners ----
