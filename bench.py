@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--seqs", type=int, default=4, help="independent sequences per GPU (one ctx + stream each)")
     ap.add_argument("--ba-iters", type=int, default=10, help="LM iteration budget per adjust")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames per sequence (played ping-pong)")
+    ap.add_argument("--no-graph", action="store_true", help="plain launches instead of hipGraph replay")
+    ap.add_argument("--host-threads", type=int, default=0, help="enqueue/fetch the sequences from this many host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     return ap.parse_args()
@@ -117,17 +119,13 @@ class Sequence:
         self.t = 1
 
     def enqueue(self):
-        c = self.c
-        c.push_frame_resident(pingpong(self.t, self.nf))
-        c.klt_track_resident(N_PTS, self.klt_prm)
-        c.dlt_resident()
-        c.ba_solve_resident(self.ba_prm)
-        c.shi_tomasi_resident(N_PTS, 7, self.st_prm)
+        # one C call: pyramid + KLT + DLT + BA + Shi-Tomasi + result copies (replayed from a hipGraph)
+        self.c.frame_step_resident(pingpong(self.t, self.nf), N_PTS, True, True, True, 7, self.klt_prm, self.st_prm,
+                                   self.ba_prm)
         self.t += 1
 
     def fetch(self):
-        c = self.c
-        self.last = (c.points_download(N_PTS), c.dlt_fetch(), c.ba_fetch(), c.shi_tomasi_fetch())
+        self.last = self.c.frame_fetch()
         return self.last
 
 
@@ -166,8 +164,26 @@ def main():
     frames, _ = syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + dist.rank)
     seqs = [Sequence(dist.local_rank, frames, seed=100 * dist.rank + i, ba_iters=a.ba_iters) for i in range(a.seqs)]
     t_setup = time.perf_counter() - t_gen
+    if a.no_graph:
+        for s in seqs:
+            s.c.set_graph_mode(False)
+
+    pool = None
+    if a.host_threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(a.host_threads)
+        chunks = [seqs[i::a.host_threads] for i in range(a.host_threads)]
+
+        def run_chunk(ch):
+            for s in ch:
+                s.enqueue()
+            for s in ch:
+                s.fetch()
 
     def step():
+        if pool is not None:
+            list(pool.map(run_chunk, chunks))     # ctypes releases the GIL inside the C calls
+            return
         for s in seqs:
             s.enqueue()
         for s in seqs:
@@ -211,8 +227,8 @@ def main():
             stage[name] = round(ms / max(n, 1), 4)
         s0.c.profile_enable(())
         pts, st_, err_, it = s0.c.points_download(N_PTS, return_iters=True)
+        ba_stats = s0.last["ba_stats"]
         it_mean = [float(np.maximum(it[:, l], 0).mean()) for l in range(it.shape[1])]
-        ba_stats = s0.last[2][2]
         # ALGORITHMIC bytes of one KLT launch: N * sum_l (5120 + 1024 * it_l)
         klt_bytes = N_PTS * sum(5120.0 + 1024.0 * x for x in it_mean)
         klt_avg_s = (klt_ms / max(klt_n, 1)) * 1e-3
@@ -236,6 +252,7 @@ def main():
                           "ba_landmarks": BA_N, "ba_window": BA_W, "ba_observations": BA_N * BA_W,
                           "ba_lm_iteration_budget": a.ba_iters, "ba_lm_iterations_run": ba_stats["iters"],
                           "ba_final_cost": round(ba_stats["cost"], 4), "ba_initial_cost": round(ba_stats["cost0"], 2),
+                          "launch": "plain" if a.no_graph else "hipGraph replay", "host_threads": max(a.host_threads, 1),
                           "sequences_per_gpu": a.seqs, "frames_per_step": a.seqs * dist.world,
                           "parallelism": "independent sequences, %d per GPU x %d GPU(s), no collective" % (a.seqs, dist.world)},
                "stage_ms_single_sequence": stage, "roofline": roof, "cpu_baseline": cpu,

@@ -184,6 +184,20 @@ int32_t vo_ba_probe(vo_ctx* ctx, double lambda, double huber_delta, double* resi
                     double* cost, double* Hpp, double* gp, double* Hll, double* gl, double* S,
                     double* rhs, double* dposes, double* dpoints);
 
+/* ---- fused per-frame step on resident data ---------------------------------------------------
+ * One call enqueues the hot path of one frame in the order of Pipeline.step (src/pipeline/pipeline.py:92-167):
+ * frame `frame_idx` of the uploaded sequence -> pyramid/Scharr -> KLT of the resident points -> [DLT of the
+ * uploaded pairs] -> [BA of the uploaded problem] -> [Shi-Tomasi re-detection around the tracked points] ->
+ * result copies.  After the first frame of each buffer parity the launch sequence is replayed from a captured
+ * hipGraph (vo_set_graph_mode(ctx, 0) forces plain launches).  vo_frame_fetch waits and unpacks the results. */
+int32_t vo_frame_step_resident(vo_ctx* ctx, int32_t frame_idx, int32_t n_pts, int32_t do_dlt, int32_t do_ba,
+                               int32_t do_st, int32_t mask_radius, const vo_klt_params* klt,
+                               const vo_st_params* st, const vo_ba_params* ba);               /* async */
+int32_t vo_frame_fetch(vo_ctx* ctx, int32_t n_pts, float* p, uint8_t* status, float* err, float* X4,
+                       double* depth1, double* reproj, double* poses, double* points, vo_ba_stats* stats,
+                       float* corners, int32_t* n_corners);
+int32_t vo_set_graph_mode(vo_ctx* ctx, int32_t on);
+
 /* ---- in-stream timing (hipEvent pairs recorded on the ctx stream around a region's launches) -----
  * Used by bench.py for the roofline figure: region VO_PROF_KLT brackets exactly the k_klt_track launch.
  * vo_profile_read synchronises the stream and returns the summed elapsed time and the number of

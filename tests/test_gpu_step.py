@@ -1,0 +1,53 @@
+"""GPU: the fused per-frame step (plain launches and hipGraph replay) equals the individual resident calls, frame by frame."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(c, frames, pts, scene, n_new):
+    from vo_mi355x import synthetic as syn
+    c.upload_sequence(frames)
+    c.points_upload(pts)
+    K = scene["K"]
+    H0, H1 = np.eye(4), np.eye(4)
+    H0[:3, :3], H0[:3, 3] = syn.rodrigues(scene["poses_gt"][3, :3]), scene["poses_gt"][3, 3:]
+    H1[:3, :3], H1[:3, 3] = syn.rodrigues(scene["poses_gt"][0, :3]), scene["poses_gt"][0, 3:]
+    c.dlt_upload((K @ H0[:3]).astype(np.float32), (K @ H1[:3]).astype(np.float32), scene["obs"][3, :n_new],
+                 scene["obs"][0, :n_new], K, H0, H1)
+    c.ba_upload(K, scene["poses0"], scene["points0"], scene["obs"])
+    c.push_frame_resident(0)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_frame_step_matches_individual_calls(graph):
+    from vo_mi355x import VoContext, synthetic as syn
+    w, h, n, n_new = 640, 240, 600, 200
+    frames, _ = syn.make_sequence(5, w=w, h=h, seed=21, margin=64)
+    pts = syn.grid_points(n, w, h, seed=4)
+    scene = syn.make_ba_scene(n_pts=300, n_slots=6, seed=2, visibility=0.9)
+    order = [1, 2, 3, 4, 3, 2, 1]
+    ref = []
+    with VoContext(w, h, max_pts=1024) as c:
+        _setup(c, frames, pts, scene, n_new)
+        bap = c.ba_params(max_iters=6)
+        for f in order:
+            c.push_frame_resident(f)
+            c.klt_track_resident(n)
+            c.dlt_resident()
+            c.ba_solve_resident(bap)
+            c.shi_tomasi_resident(n, 7)
+            ref.append((c.points_download(n), c.dlt_fetch(), c.ba_fetch(), c.shi_tomasi_fetch()))
+    with VoContext(w, h, max_pts=1024) as c:
+        c.set_graph_mode(graph)
+        _setup(c, frames, pts, scene, n_new)
+        bap = c.ba_params(max_iters=6)
+        for k, f in enumerate(order):
+            c.frame_step_resident(f, n, ba=bap)
+            got = c.frame_fetch()
+            (p, st, err), (X4, depth, reproj), (po, pt, bst), corners = ref[k]
+            assert np.array_equal(got["points2d"], p) and np.array_equal(got["status"], st) and np.array_equal(got["err"], err), k
+            assert np.array_equal(got["X4"], X4) and np.array_equal(got["depth1"], depth) and np.array_equal(got["reproj"], reproj)
+            assert np.array_equal(got["poses"], po) and np.array_equal(got["landmarks"], pt)
+            assert got["ba_stats"]["cost"] == bst["cost"] and got["ba_stats"]["iters"] == bst["iters"]
+            assert np.array_equal(got["corners"], corners), k

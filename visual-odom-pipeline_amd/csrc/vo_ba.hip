@@ -34,6 +34,7 @@
 #include "vo_internal.h"
 
 #include <math.h>
+#include <string.h>
 
 #define BA_SOLVE_THREADS 1024
 #define BA_AUX 18            // per landmark: Hll(6) gl(3) Cinv(6) z(3)
@@ -90,7 +91,10 @@ struct vo_ba_ws {
   double* d_Hpp = nullptr;      // W*28 reduced pose values (probe)
   double* d_res = nullptr;      // probe residual W*N
   double* d_dl = nullptr;       // probe d_points 3N
-  double* d_xout = nullptr;     // published solution 6W + 3N
+  double* d_xout = nullptr;     // published solution 6W + 3N (points into d_pub)
+  uint8_t* d_pub = nullptr;     // [ba_state (64 B) | x]: what a fetch copies back in one go
+  uint8_t* h_pub = nullptr;     // pinned mirror
+  size_t pub_bytes = 0;
   ba_state* d_state = nullptr;  // [2]
   ba_info* d_info = nullptr;
   ba_state* h_state = nullptr;  // pinned
@@ -840,6 +844,7 @@ __global__ void k_ba_finalize(ba_ptrs P, ba_params_dev prm, int n_it, double* __
     s_st = st;
     *st_out = st;
     P.state[n_it & 1] = st;
+    *reinterpret_cast<ba_state*>(reinterpret_cast<unsigned char*>(x_out) - 64) = st;   // pub header
   }
   __syncthreads();
   const double* x = (n_it == 0) ? P.x0 : P.x[s_st.cur];
@@ -876,12 +881,15 @@ void vo_ba_destroy(vo_ctx* c) {
   if (!c->ba) return;
   vo_ba_ws* b = c->ba;
   void* bufs[] = {b->d_K, b->d_obs, b->d_x0, b->d_x[0], b->d_x[1], b->d_aux, b->d_posepart, b->d_gmax,
-                  b->d_tiles, b->d_dp, b->d_evalpart, b->d_tilesum, b->d_posesum, b->d_S, b->d_Hpp, b->d_res, b->d_dl, b->d_xout, b->d_state, b->d_info};
+                  b->d_tiles, b->d_dp, b->d_evalpart, b->d_tilesum, b->d_posesum, b->d_S, b->d_Hpp, b->d_res, b->d_dl, b->d_pub, b->d_state, b->d_info};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (b->h_state) (void)hipHostFree(b->h_state);
+  if (b->h_pub) (void)hipHostFree(b->h_pub);
   delete b;
   c->ba = nullptr;
 }
+
+bool vo_ba_ready(const vo_ctx* c) { return c->ba && c->ba->uploaded; }
 
 extern "C" int32_t vo_ba_default_params(vo_ba_params* p) {
   if (!p) return VO_E_INVALID;
@@ -933,7 +941,10 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     VO_HIP(c, hipMalloc((void**)&b->d_Hpp, sizeof(double) * (size_t)W * BA_POSE_VALS));
     VO_HIP(c, hipMalloc((void**)&b->d_res, sizeof(double) * (size_t)W * N));
     VO_HIP(c, hipMalloc((void**)&b->d_dl, sizeof(double) * (size_t)3 * N));
-    VO_HIP(c, hipMalloc((void**)&b->d_xout, sizeof(double) * nx));
+    b->pub_bytes = 64 + sizeof(double) * nx;
+    VO_HIP(c, hipMalloc((void**)&b->d_pub, b->pub_bytes));
+    VO_HIP(c, hipHostMalloc((void**)&b->h_pub, b->pub_bytes, hipHostMallocDefault));
+    b->d_xout = reinterpret_cast<double*>(b->d_pub + 64);
     VO_HIP(c, hipMalloc((void**)&b->d_state, sizeof(ba_state) * 2));
     VO_HIP(c, hipMalloc((void**)&b->d_info, sizeof(ba_info)));
     VO_HIP(c, hipHostMalloc((void**)&b->h_state, sizeof(ba_state) * 2, hipHostMallocDefault));
@@ -1034,16 +1045,30 @@ static void ba_fill_stats(const ba_state& s, int n_obs, vo_ba_stats* st) {
   st->status = s.status; st->n_obs = n_obs;
 }
 
+// internal: enqueue the D2H copy of the published result into the pinned mirror (used by the frame step)
+int32_t vo_ba_enqueue_pub_copy(vo_ctx* c) {
+  vo_ba_ws* b = c->ba;
+  VO_HIP(c, hipMemcpyAsync(b->h_pub, b->d_pub, b->pub_bytes, hipMemcpyDeviceToHost, c->stream));
+  return VO_OK;
+}
+
+// internal: unpack the pinned mirror (after a stream sync)
+void vo_ba_unpack_pub(vo_ctx* c, double* poses_out, double* points_out, vo_ba_stats* stats) {
+  vo_ba_ws* b = c->ba;
+  const double* x = reinterpret_cast<const double*>(b->h_pub + 64);
+  if (poses_out) memcpy(poses_out, x, sizeof(double) * 6 * b->W);
+  if (points_out) memcpy(points_out, x + 6 * b->W, sizeof(double) * 3 * b->N);
+  if (stats) ba_fill_stats(*reinterpret_cast<const ba_state*>(b->h_pub), -1, stats);
+}
+
 extern "C" int32_t vo_ba_fetch(vo_ctx* c, double* poses_out, double* points_out, vo_ba_stats* stats) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->ba && c->ba->uploaded, VO_E_STATE, "nothing to fetch");
   VO_HIP(c, hipSetDevice(c->device));
-  vo_ba_ws* b = c->ba;
-  VO_HIP(c, hipMemcpyAsync(b->h_state, b->d_state, sizeof(ba_state), hipMemcpyDeviceToHost, c->stream));
-  if (poses_out) VO_HIP(c, hipMemcpyAsync(poses_out, b->d_xout, sizeof(double) * 6 * b->W, hipMemcpyDeviceToHost, c->stream));
-  if (points_out) VO_HIP(c, hipMemcpyAsync(points_out, b->d_xout + 6 * b->W, sizeof(double) * 3 * b->N, hipMemcpyDeviceToHost, c->stream));
+  int32_t r = vo_ba_enqueue_pub_copy(c);
+  if (r != VO_OK) return r;
   VO_HIP(c, hipStreamSynchronize(c->stream));
-  if (stats) ba_fill_stats(b->h_state[0], -1, stats);
+  vo_ba_unpack_pub(c, poses_out, points_out, stats);
   return VO_OK;
 }
 

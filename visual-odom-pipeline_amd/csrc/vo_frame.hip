@@ -25,11 +25,14 @@ __device__ __forceinline__ int d_reflect101(int p, int len) {
 }
 
 // Level 0: raw (w x h, tight) -> padded image with reflect-101 border.
-__global__ void __launch_bounds__(256) k_pad_level0(const uint8_t* __restrict__ raw, int w, int h,
-                                                    uint8_t* __restrict__ dst, int pitch, int ph) {
+// `raw` is either the frame itself (frame_idx == nullptr) or the base of the resident sequence, in which case the
+// frame index is read from device memory (lets a captured graph be replayed for any frame).
+__global__ void __launch_bounds__(256) k_pad_level0(const uint8_t* __restrict__ raw, const int32_t* __restrict__ frame_idx,
+                                                    int w, int h, uint8_t* __restrict__ dst, int pitch, int ph) {
   const int X = blockIdx.x * blockDim.x + threadIdx.x;   // padded column
   const int Y = blockIdx.y;
   if (X >= w + 2 * VO_PAD || Y >= ph) return;
+  if (frame_idx) raw += (size_t)(*frame_idx) * w * h;
   const int x = d_reflect101(X - VO_PAD, w), y = d_reflect101(Y - VO_PAD, h);
   dst[(size_t)Y * pitch + X] = raw[(size_t)y * w + x];
 }
@@ -172,9 +175,11 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
       if (c->fr[f].img[l]) (void)hipFree(c->fr[f].img[l]);
       if (c->fr[f].der[l]) (void)hipFree(c->fr[f].der[l]);
     }
-  void* bufs[] = {c->d_dbg, c->d_raw, c->d_seq, c->d_p0, c->d_p1, c->d_err, c->d_status, c->d_iters,
-                  c->d_uv0, c->d_uv1, c->d_X4, c->d_depth, c->d_reproj};
+  for (int g = 0; g < 2; g++) if (c->step_graph[g]) (void)hipGraphExecDestroy(c->step_graph[g]);
+  void* bufs[] = {c->d_dbg, c->d_raw, c->d_seq, c->d_iters, c->d_uv0, c->d_uv1, c->d_slab, c->d_frame_idx};
   for (void* b : bufs) if (b) (void)hipFree(b);
+  if (c->h_slab) (void)hipHostFree(c->h_slab);
+  if (c->h_frame_idx) (void)hipHostFree(c->h_frame_idx);
   for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -231,16 +236,31 @@ extern "C" int32_t vo_ctx_create(int32_t device, int32_t width, int32_t height, 
   CR(hipMalloc((void**)&c->d_raw, (size_t)width * height));
   CR(hipMalloc((void**)&c->d_dbg, sizeof(unsigned long long) * 32));
   CR(hipMemsetAsync(c->d_dbg, 0, sizeof(unsigned long long) * 32, c->stream));
-  CR(hipMalloc((void**)&c->d_p0, sizeof(float) * 2 * max_pts));
-  CR(hipMalloc((void**)&c->d_p1, sizeof(float) * 2 * max_pts));
-  CR(hipMalloc((void**)&c->d_err, sizeof(float) * max_pts));
-  CR(hipMalloc((void**)&c->d_status, max_pts));
+  {
+    // result slab layout (all offsets 256-byte aligned)
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t M = (size_t)max_pts;
+    c->off_pa = take(8 * M); c->off_pb = take(8 * M); c->off_status = take(M); c->off_err = take(4 * M);
+    c->off_X4 = take(16 * M); c->off_depth = take(8 * M); c->off_reproj = take(8 * M);
+    c->off_st_scalars = take(64); c->off_st_out = take(8 * 4096);
+    c->slab_bytes = off;
+    CR(hipMalloc((void**)&c->d_slab, c->slab_bytes));
+    CR(hipMemsetAsync(c->d_slab, 0, c->slab_bytes, c->stream));
+    CR(hipHostMalloc((void**)&c->h_slab, c->slab_bytes, hipHostMallocDefault));
+    c->d_p0 = reinterpret_cast<float*>(c->d_slab + c->off_pa);
+    c->d_p1 = reinterpret_cast<float*>(c->d_slab + c->off_pb);
+    c->d_status = c->d_slab + c->off_status;
+    c->d_err = reinterpret_cast<float*>(c->d_slab + c->off_err);
+    c->d_X4 = reinterpret_cast<float*>(c->d_slab + c->off_X4);
+    c->d_depth = reinterpret_cast<double*>(c->d_slab + c->off_depth);
+    c->d_reproj = reinterpret_cast<double*>(c->d_slab + c->off_reproj);
+  }
   CR(hipMalloc((void**)&c->d_iters, sizeof(int32_t) * max_pts * VO_MAX_LEVELS));
   CR(hipMalloc((void**)&c->d_uv0, sizeof(float) * 2 * max_pts));
   CR(hipMalloc((void**)&c->d_uv1, sizeof(float) * 2 * max_pts));
-  CR(hipMalloc((void**)&c->d_X4, sizeof(float) * 4 * max_pts));
-  CR(hipMalloc((void**)&c->d_depth, sizeof(double) * max_pts));
-  CR(hipMalloc((void**)&c->d_reproj, sizeof(double) * max_pts));
+  CR(hipMalloc((void**)&c->d_frame_idx, sizeof(int32_t)));
+  CR(hipHostMalloc((void**)&c->h_frame_idx, sizeof(int32_t) * 64, hipHostMallocDefault));
   CR(hipStreamSynchronize(c->stream));
 #undef CR
   *out = c;
@@ -257,14 +277,14 @@ extern "C" int32_t vo_sync(vo_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 // frames
 // ------------------------------------------------------------------------------------------------
-static int32_t build_pyramid(vo_ctx* c, const uint8_t* d_raw_img) {
+int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, const int32_t* d_frame_idx) {
   vo_prof_scope prof(c, VO_PROF_FRAME);
   c->cur ^= 1;
   vo_frame& F = c->fr[c->cur];
   {
     const vo_level& L = c->lv[0];
     dim3 grid(vo_div_up(L.w + 2 * VO_PAD, 256), L.ph);
-    hipLaunchKernelGGL(k_pad_level0, grid, dim3(256), 0, c->stream, d_raw_img, L.w, L.h, F.img[0], L.pitch, L.ph);
+    hipLaunchKernelGGL(k_pad_level0, grid, dim3(256), 0, c->stream, d_raw_img, d_frame_idx, L.w, L.h, F.img[0], L.pitch, L.ph);
   }
   for (int l = 0; l <= c->top; l++) {
     const vo_level& L = c->lv[l];
@@ -289,7 +309,7 @@ extern "C" int32_t vo_frame_push(vo_ctx* c, const uint8_t* img, int32_t stride) 
   VO_CHECK(c, img != nullptr && stride >= c->width, VO_E_INVALID, "bad image / stride");
   VO_HIP(c, hipSetDevice(c->device));
   VO_HIP(c, hipMemcpy2DAsync(c->d_raw, c->width, img, stride, c->width, c->height, hipMemcpyHostToDevice, c->stream));
-  int32_t r = build_pyramid(c, c->d_raw);
+  int32_t r = vo_build_pyramid(c, c->d_raw, nullptr);
   if (r != VO_OK) return r;
   VO_HIP(c, hipStreamSynchronize(c->stream));   // the host buffer may be reused by the caller
   return VO_OK;
@@ -312,7 +332,7 @@ extern "C" int32_t vo_frame_push_resident(vo_ctx* c, int32_t idx) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->d_seq != nullptr && idx >= 0 && idx < c->seq_n, VO_E_STATE, "no resident sequence / bad index");
   VO_HIP(c, hipSetDevice(c->device));
-  return build_pyramid(c, c->d_seq + (size_t)idx * c->width * c->height);
+  return vo_build_pyramid(c, c->d_seq + (size_t)idx * c->width * c->height, nullptr);
 }
 
 extern "C" int32_t vo_pyramid_level_size(vo_ctx* c, int32_t level, int32_t* w, int32_t* h) {

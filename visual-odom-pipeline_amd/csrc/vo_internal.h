@@ -62,7 +62,21 @@ struct vo_ctx {
   vo_st_ws* st = nullptr;
   vo_ba_ws* ba = nullptr;
   vo_prof prof;
-  unsigned long long* d_dbg = nullptr;   // 3 x 8 phase stamps (vo_debug_cycles)
+  unsigned long long* d_dbg = nullptr;   // 4 x 8 phase stamps (vo_debug_cycles)
+  // result slab: every per-frame output of the front end lives in ONE device allocation (mirrored in pinned host
+  // memory) so that a frame's results come back with a single D2H copy instead of ten.
+  uint8_t* d_slab = nullptr;
+  uint8_t* h_slab = nullptr;
+  size_t slab_bytes = 0;
+  size_t off_pa = 0, off_pb = 0, off_status = 0, off_err = 0, off_X4 = 0, off_depth = 0, off_reproj = 0,
+         off_st_scalars = 0, off_st_out = 0;
+  // per-frame step (vo_frame_step_resident) captured as hipGraphs, one per frame parity
+  hipGraphExec_t step_graph[2] = {nullptr, nullptr};
+  int step_sig[2][8];                    // launch signature the graph was captured for
+  int32_t* d_frame_idx = nullptr;        // frame index consumed by the captured k_pad_level0
+  int32_t* h_frame_idx = nullptr;        // pinned ring of frame indices (H2D source must outlive the copy)
+  int frame_ring = 0;
+  int use_graph = 1;
   std::string err;
 };
 
@@ -98,6 +112,15 @@ struct vo_prof_scope {
 #define VO_STAMP(buf, idx) do { if ((buf) && threadIdx.x == 0) (buf)[idx] = __builtin_amdgcn_s_memtime(); } while (0)
 
 static inline int vo_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// cross-unit internals used by the fused frame step (vo_step.hip)
+int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, const int32_t* d_frame_idx);
+int32_t vo_ba_enqueue_pub_copy(vo_ctx* c);
+void vo_ba_unpack_pub(vo_ctx* c, double* poses_out, double* points_out, vo_ba_stats* stats);
+bool vo_ba_ready(const vo_ctx* c);
+bool vo_st_ready(const vo_ctx* c);
+int vo_st_last_max_corners(const vo_ctx* c);
+int32_t vo_st_prepare(vo_ctx* c);
 
 // sub-workspace lifetime hooks
 void vo_st_destroy(vo_ctx* c);

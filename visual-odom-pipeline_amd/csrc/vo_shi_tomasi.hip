@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
 void vo_st_destroy(vo_ctx* c) {
   if (!c->st) return;
   vo_st_ws* s = c->st;
-  void* bufs[] = {s->d_mask, s->d_user_mask, s->d_h, s->d_eig, s->d_scalars, s->d_cand, s->d_blockmax, s->d_out, s->d_pts};
+  void* bufs[] = {s->d_mask, s->d_user_mask, s->d_h, s->d_eig, s->d_cand, s->d_blockmax, s->d_pts};   // scalars / out live in the ctx slab
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete s;
   c->st = nullptr;
@@ -443,11 +443,11 @@ static int32_t st_init(vo_ctx* c) {
   VO_HIP(c, hipMalloc((void**)&s->d_user_mask, np));
   VO_HIP(c, hipMalloc((void**)&s->d_h, np * 3 * sizeof(int32_t)));
   VO_HIP(c, hipMalloc((void**)&s->d_eig, np * sizeof(float)));
-  VO_HIP(c, hipMalloc((void**)&s->d_scalars, 16 * sizeof(uint32_t)));
+  s->d_scalars = reinterpret_cast<uint32_t*>(c->d_slab + c->off_st_scalars);
   VO_HIP(c, hipMalloc((void**)&s->d_cand, sizeof(unsigned long long) * ST_CAND_CAP));
   s->n_blockmax = vo_div_up(c->width, 256) * vo_div_up(c->height, ST_RG);
   VO_HIP(c, hipMalloc((void**)&s->d_blockmax, sizeof(float) * (size_t)s->n_blockmax));
-  VO_HIP(c, hipMalloc((void**)&s->d_out, sizeof(float) * 2 * ST_OUT_CAP));
+  s->d_out = reinterpret_cast<float*>(c->d_slab + c->off_st_out);
   VO_HIP(c, hipMalloc((void**)&s->d_pts, sizeof(float) * 2 * (size_t)c->max_pts));
   VO_HIP(c, hipMemsetAsync(s->d_scalars, 0, 16 * sizeof(uint32_t), c->stream));
   VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_st_select), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -471,6 +471,10 @@ static void circle_rows(int radius, disc_rows* rows) {
     minus -= mask & 2;
   }
 }
+
+bool vo_st_ready(const vo_ctx* c) { return c->st != nullptr; }
+int vo_st_last_max_corners(const vo_ctx* c) { return c->st ? c->st->last_max_corners : 0; }
+int32_t vo_st_prepare(vo_ctx* c) { return st_init(c); }
 
 extern "C" int32_t vo_st_default_params(vo_st_params* p) {
   if (!p) return VO_E_INVALID;

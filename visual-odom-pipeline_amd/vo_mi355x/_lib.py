@@ -77,6 +77,11 @@ SIGNATURES = {
     "vo_dlt_upload": (C.c_int32, [_ctx, _f32p, _f32p, _f32p, _f32p, C.c_int32, _f64p, _f64p, _f64p]),
     "vo_dlt_resident": (C.c_int32, [_ctx]),
     "vo_dlt_fetch": (C.c_int32, [_ctx, _f32p, _f64p, _f64p]),
+    "vo_frame_step_resident": (C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.POINTER(KltParams), C.POINTER(StParams), C.POINTER(BaParams)]),
+    "vo_frame_fetch": (C.c_int32, [_ctx, C.c_int32, _f32p, _u8p, _f32p, _f32p, _f64p, _f64p, _f64p, _f64p,
+                                   C.POINTER(BaStats), _f32p, _i32p]),
+    "vo_set_graph_mode": (C.c_int32, [_ctx, C.c_int32]),
     "vo_profile_enable": (C.c_int32, [_ctx, C.c_int32]),
     "vo_profile_read": (C.c_int32, [_ctx, C.c_int32, _f64p, _i32p]),
     "vo_debug_cycles": (C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_int64)]),

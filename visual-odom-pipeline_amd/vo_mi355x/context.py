@@ -208,6 +208,51 @@ class VoContext:
         self._ck(self._L.vo_dlt_fetch(self._h, ptr(X4, C.c_float), ptr(depth, C.c_double), ptr(reproj, C.c_double)))
         return (X4, depth, reproj) if self._dlt_stats else X4
 
+    # -- fused frame step ----------------------------------------------------------------------
+    def set_graph_mode(self, on=True):
+        self._ck(self._L.vo_set_graph_mode(self._h, 1 if on else 0))
+
+    def frame_step_resident(self, frame_idx, n_pts, do_dlt=True, do_ba=True, do_st=True, mask_radius=7,
+                            klt=None, st=None, ba=None):
+        """enqueue one whole frame (pyramid, KLT, DLT, BA, re-detection, result copies); async"""
+        klt = klt if klt is not None else self.klt_params()
+        st = st if st is not None else self.st_params()
+        ba = ba if ba is not None else self.ba_params()
+        self._klt_levels = klt.max_level + 1
+        self._st_max_corners = st.max_corners
+        self._step_cfg = (n_pts, do_dlt, do_ba, do_st)
+        self._ck(self._L.vo_frame_step_resident(self._h, int(frame_idx), int(n_pts), int(do_dlt), int(do_ba), int(do_st),
+                                                int(mask_radius), C.byref(klt), C.byref(st), C.byref(ba)))
+
+    def frame_fetch(self):
+        """wait for the enqueued frame and return its results as a dict of numpy arrays"""
+        n_pts, do_dlt, do_ba, do_st = self._step_cfg
+        out = {}
+        p, stt, err = np.zeros((n_pts, 2), np.float32), np.zeros(n_pts, np.uint8), np.zeros(n_pts, np.float32)
+        X4 = depth = reproj = poses = points = corners = None
+        bs = BaStats()
+        nc = C.c_int32(0)
+        if do_dlt:
+            n = self._dlt_n
+            X4, depth, reproj = np.zeros((4, n), np.float32), np.zeros(n), np.zeros(n)
+        if do_ba:
+            W, N = self._ba_shape
+            poses, points = np.zeros((W, 6)), np.zeros((N, 3))
+        if do_st:
+            corners = np.zeros((max(self._st_max_corners, 1), 2), np.float32)
+        d = C.c_double
+        self._ck(self._L.vo_frame_fetch(self._h, n_pts, ptr(p, C.c_float), ptr(stt, C.c_uint8), ptr(err, C.c_float),
+                                        ptr(X4, C.c_float), ptr(depth, d), ptr(reproj, d), ptr(poses, d), ptr(points, d),
+                                        C.byref(bs), ptr(corners, C.c_float), C.byref(nc) if do_st else None))
+        out.update(points2d=p, status=stt, err=err)
+        if do_dlt:
+            out.update(X4=X4, depth1=depth, reproj=reproj)
+        if do_ba:
+            out.update(poses=poses, landmarks=points, ba_stats=self._stats(bs))
+        if do_st:
+            out["corners"] = corners[:nc.value].copy()
+        return out
+
     # -- in-stream timing -----------------------------------------------------------------------
     PROF_FRAME, PROF_KLT, PROF_ST, PROF_DLT, PROF_BA = range(5)
 
