@@ -257,7 +257,22 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 // ------------------------------------------------------------------------------------------------
 // LM decision (inputs are identical in every workgroup, so every workgroup derives the same state)
 // ------------------------------------------------------------------------------------------------
-__device__ inline void ba_decide(const ba_state& in, const ba_info& info, const double* __restrict__ evalpart, int n_eblk,
+// fixed-order block reduction of the per-workgroup step statistics written by k_ba_update (4 values per
+// workgroup): every thread stages partials in LDS, 4 threads sum them serially.  Call from all threads.
+template <int TPB>
+__device__ __forceinline__ void ba_reduce_evalpart(const double* __restrict__ evalpart, int n_eblk, double* s_part /* 4 * n_eblk */,
+                                                   double* s_sum /* 4 */) {
+  for (int i = threadIdx.x; i < 4 * n_eblk; i += TPB) s_part[i] = evalpart[i];
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double s = 0;
+    for (int b = 0; b < n_eblk; b++) s += s_part[b * BA_EVAL_VALS + threadIdx.x];
+    s_sum[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+__device__ inline void ba_decide(const ba_state& in, const ba_info& info, const double* __restrict__ sums,
                                  const ba_params_dev& prm, ba_state& out) {
   out = in;
   if (in.done) return;
@@ -265,11 +280,7 @@ __device__ inline void ba_decide(const ba_state& in, const ba_info& info, const 
   if (in.iter == 0) out.cost0 = F;
   out.cost = F;
   if (info.ginf < prm.gtol) { out.done = 1; out.status = 1; return; }
-  double Ft = 0, predp = 0, step2 = 0, x2 = 0;
-  for (int b = 0; b < n_eblk; b++) {
-    Ft += evalpart[b * BA_EVAL_VALS + 0]; predp += evalpart[b * BA_EVAL_VALS + 1];
-    step2 += evalpart[b * BA_EVAL_VALS + 2]; x2 += evalpart[b * BA_EVAL_VALS + 3];
-  }
+  const double Ft = sums[0], predp = sums[1], step2 = sums[2], x2 = sums[3];
   const double pred = 0.5 * (predp + info.pred_pose);
   const double step = sqrt(step2 + info.step2_pose), xn = sqrt(x2 + info.x2_pose);
   const bool ok = !info.chol_fail;
@@ -314,12 +325,14 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs P, ba_params_dev prm, 
   __shared__ double s_K[9];
   __shared__ double s_gmax[(TPB / 64)];
   __shared__ ba_state s_st;
+  __shared__ double s_esum[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  // ---- state for this iteration ----
+  // ---- state for this iteration (every workgroup derives it from the same inputs) ----
+  if (it > 0) ba_reduce_evalpart<TPB>(P.evalpart, P.nblk, dyn, s_esum);
   if (tid == 0) {
     ba_state st;
     if (it == 0) st = ba_init_state(prm);
-    else ba_decide(P.state[(it - 1) & 1], *P.info, P.evalpart, P.nblk, prm, st);
+    else ba_decide(P.state[(it - 1) & 1], *P.info, s_esum, prm, st);
     if (probe_lambda >= 0) st.lambda = probe_lambda;
     s_st = st;
     if (blockIdx.x == 0) P.state[it & 1] = st;
@@ -525,6 +538,16 @@ __global__ void __launch_bounds__(256) k_ba_reduce(ba_ptrs P, int it) {
     // group g sums partials g, g + 4, g + 8, ... (8 loads in flight), groups are combined in fixed order below
     double s0 = 0, s1 = 0;
     int b = g;
+    for (; b + 60 < P.nblk; b += 64) {   // 16 loads in flight
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) v[u] = src[(size_t)(b + 4 * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 16; u += 2) {
+        if (is_max) { s0 = fmax(s0, fmax(v[u], v[u + 1])); }
+        else { s0 += v[u]; s1 += v[u + 1]; }
+      }
+    }
     for (; b + 28 < P.nblk; b += 32) {
       const double v0 = src[(size_t)b * stride], v1 = src[(size_t)(b + 4) * stride], v2 = src[(size_t)(b + 8) * stride];
       const double v3 = src[(size_t)(b + 12) * stride], v4 = src[(size_t)(b + 16) * stride], v5 = src[(size_t)(b + 20) * stride];
@@ -835,12 +858,16 @@ __global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs P, ba_params_dev prm,
   }
 }
 
-__global__ void k_ba_finalize(ba_ptrs P, ba_params_dev prm, int n_it, double* __restrict__ x_out, ba_state* __restrict__ st_out) {
+__global__ void __launch_bounds__(256) k_ba_finalize(ba_ptrs P, ba_params_dev prm, int n_it, double* __restrict__ x_out,
+                                                     ba_state* __restrict__ st_out) {
   __shared__ ba_state s_st;
+  __shared__ double s_esum[4];
+  __shared__ double s_part[4 * 640];
+  if (n_it > 0) ba_reduce_evalpart<256>(P.evalpart, P.nblk, s_part, s_esum);
   if (threadIdx.x == 0) {
     ba_state st;
     if (n_it == 0) st = ba_init_state(prm);
-    else ba_decide(P.state[(n_it - 1) & 1], *P.info, P.evalpart, P.nblk, prm, st);
+    else ba_decide(P.state[(n_it - 1) & 1], *P.info, s_esum, prm, st);
     s_st = st;
     *st_out = st;
     P.state[n_it & 1] = st;
@@ -954,6 +981,7 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
   }
   ba_geometry(c->ba, W, N);
   VO_CHECK(c, c->ba->build_lds <= 130 * 1024 && c->ba->solve_lds <= 130 * 1024, VO_E_CAPACITY, "window too large for LDS");
+  VO_CHECK(c, c->ba->nblk <= 640, VO_E_CAPACITY, "too many landmarks for one adjust (raise the partial capacity)");
   return VO_OK;
 }
 
