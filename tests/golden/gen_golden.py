@@ -12,6 +12,8 @@ small .npz files next to this script:
         (/root/reference/src/bundle_adjuster/bundle_adjuster.py:18-65,85-124,127-215)
   tri_s{seed}.npz            G2: TriangulatorNL.refine filter masks / objective
         (/root/reference/src/extractor/triangulate.py:15-29,82-146)
+  glue_s{seed}.npz           G3: Extractor glue (extend_tracks / extend_landmarks / extract / triangulate_tracks,
+        /root/reference/src/extractor/extractor.py:38-132,193-253) run unmodified over the CPU oracle
   rodrigues.npz              G4: Rodrigues round trips of the stub (self-consistency)
 
 Usage:  python tests/golden/gen_golden.py
@@ -232,7 +234,95 @@ def run_rodrigues():
     print("wrote rodrigues.npz")
 
 
+def dump_kps(kps):
+    n = len(kps)
+    lens = np.array([len(k.uv_history) for k in kps], np.int64)
+    return dict(uv=np.array([np.asarray(k.uv, np.float64).reshape(2) for k in kps]).reshape(n, 2),
+                uv_first=np.array([np.asarray(k.uv_first, np.float64).reshape(2) for k in kps]).reshape(n, 2),
+                t_first=np.array([k.t_first for k in kps], np.int64), t_total=np.array([k.t_total for k in kps], np.int64),
+                tag=np.array([float(np.asarray(k.des).reshape(-1)[0]) for k in kps]), hist_len=lens,
+                hist=(np.concatenate([np.array(k.uv_history, np.float64).reshape(-1, 2) for k in kps]) if n else np.zeros((0, 2))))
+
+
+def dump_lms(lms):
+    n = len(lms)
+    return dict(p=np.array([np.asarray(l.p, np.float64).reshape(3) for l in lms]).reshape(n, 3),
+                t_latest=np.array([l.t_latest for l in lms], np.int64),
+                tag=np.array([float(np.asarray(l.des).reshape(-1)[0]) for l in lms]))
+
+
+def put(out, prefix, d):
+    for k, v in d.items():
+        out[prefix + "_" + k] = v
+
+
+def run_glue_case(seed=0):
+    """G3: the reference's Extractor glue (list bookkeeping, in-image test, bidirectional flag, track grouping and
+    bearing gate) run UNMODIFIED on top of the CPU oracle through the cv2 stub."""
+    import copy
+    from extractor import Extractor
+    cv2.set_backend(vo_oracle)
+    w, h = 240, 180
+    frames, _ = syn.make_sequence(3, w=w, h=h, seed=40 + seed, margin=48)
+    out = {"frames": frames}
+    ext = Extractor(min_kp_dist=7)
+    ext._im_prev = frames[0]
+    cands = ext.extract(frames[0], 1, current_kp=[], detector='shi-tomasi', mask_radius=7, describe=False)
+    for i, k in enumerate(cands):
+        k.des = np.array([[float(i)]])          # tag
+    put(out, "ex0", dump_kps(cands))
+    # a few tracks that must die: start them next to the border
+    rng = np.random.default_rng(seed)
+    for j in range(6):
+        uv = np.array([[w - 1.5 + 0.2 * j], [rng.uniform(5, h - 5)]], np.float32)
+        cands.append(Keypoint(1, 1, uv.copy(), uv.copy(), np.array([[1000.0 + j]]), [uv.copy()]))
+    put(out, "in0", dump_kps(cands))
+    c1 = ext.extend_tracks(frames[1], copy.deepcopy(cands), np.inf)
+    put(out, "tr1", dump_kps(c1))
+    c1b = ext.extend_tracks(frames[1], copy.deepcopy(cands), 4.1)       # finite "bidirectional" threshold (forward-forward quirk)
+    put(out, "tr1b", dump_kps(c1b))
+    ext._im_prev = frames[1]
+    c2 = ext.extend_tracks(frames[2], copy.deepcopy(c1), np.inf)
+    put(out, "tr2", dump_kps(c2))
+    # landmarks tracked 1 -> 2
+    lms = [Landmark(2, rng.normal(0, 1, (3, 1)), k.des.copy()) for k in c1]
+    ln, kn, ld, kd = ext.extend_landmarks(frames[2], copy.deepcopy(lms), copy.deepcopy(c1), np.inf)
+    put(out, "el_l", dump_lms(ln)); put(out, "el_k", dump_kps(kn)); put(out, "el_ld", dump_lms(ld)); put(out, "el_kd", dump_kps(kd))
+    # re-detection around the survivors
+    new = ext.extract(frames[2], 3, current_kp=c2, detector='shi-tomasi', mask_radius=7, describe=False)
+    put(out, "ex2", dump_kps(new))
+    # triangulate_tracks on a synthetic two-group scene (independent of the images)
+    K = syn.KITTI_K
+    T = 6
+    scene = syn.make_ba_scene(n_pts=60, n_slots=T, seed=seed, obs_noise=0.2)
+    poses_t = scene["poses_gt"][::-1]
+    traj = Trajectory({})
+    for t in range(T):
+        traj.append(t, pose_to_H(poses_t[t]))
+    cand = []
+    for j in range(60):
+        t_first = 1 if j % 2 else 2
+        t_total = (T - t_first) if j % 5 else 2          # every 5th track is too short
+        hist = [scene["obs"][T - 1 - t, j].astype(np.float32).reshape(2, 1) for t in range(t_first, t_first + t_total)]
+        if j % 7 == 0:
+            hist[-1] = hist[-1] + np.float32(9.0)        # gross outlier -> reprojection filter
+        cand.append(Keypoint(t_first, t_total, hist[0].copy(), hist[-1].copy(), np.array([[float(j)]]), hist))
+    out["tt_K"] = K; out["tt_traj"] = np.array([traj[t] for t in range(T)])
+    put(out, "tt_in", dump_kps(cand))
+    ln, lk, rest = ext.triangulate_tracks(K, copy.deepcopy(cand), traj, T - 1, min_track_length=3, min_bearing_angle=0.5,
+                                          max_err_reproj=2.0)
+    put(out, "tt_l", dump_lms(ln)); put(out, "tt_k", dump_kps(lk)); put(out, "tt_rest", dump_kps(rest))
+    path = os.path.join(HERE, "glue_s%d.npz" % seed)
+    np.savez_compressed(path, **out)
+    print("wrote", path, "extract", len(out["ex0_tag"]), "tracked", len(c1), len(c1b), len(c2), "landmarks alive/dead", len(ln), len(ld),
+          "new", len(new), "triangulated", len(out["tt_l_tag"]), "rest", len(rest))
+
+
 if __name__ == "__main__":
+    if "--glue-only" in sys.argv:
+        run_glue_case(0)
+        sys.exit(0)
+    run_glue_case(0)
     run_rodrigues()
     for seed, N, W in ((0, 64, 4), (1, 64, 4), (2, 256, 10), (0, 256, 10)):
         run_ba_case(seed, N, W)
