@@ -35,11 +35,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--seqs", type=int, default=4, help="independent sequences per GPU (one ctx + stream each)")
+    ap.add_argument("--seqs", type=int, default=32, help="independent sequences per GPU (one ctx + stream each)")
     ap.add_argument("--ba-iters", type=int, default=10, help="LM iteration budget per adjust")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames per sequence (played ping-pong)")
-    ap.add_argument("--no-graph", action="store_true", help="plain launches instead of hipGraph replay")
-    ap.add_argument("--host-threads", type=int, default=0, help="enqueue/fetch the sequences from this many host threads")
+    ap.add_argument("--graph", action="store_true", help="replay each frame from a captured hipGraph instead of plain launches")
+    ap.add_argument("--host-threads", type=int, default=16, help="enqueue/fetch the sequences from this many host threads")
+    ap.add_argument("--fixed-ba-budget", action="store_true",
+                    help="always enqueue --ba-iters LM iterations (default: last frame's iteration count + 2, capped)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     return ap.parse_args()
@@ -112,6 +114,7 @@ class Sequence:
         self.scene = s
         c.ba_upload(K, s["poses0"], s["points0"], s["obs"])
         self.ba_prm = c.ba_params(max_iters=ba_iters, ftol=1e-3, xtol=1e-3)
+        self.ba_iters_cap, self.adaptive = ba_iters, True
         self.klt_prm = c.klt_params()
         self.st_prm = c.st_params()
         self.t = 0
@@ -126,6 +129,10 @@ class Sequence:
 
     def fetch(self):
         self.last = self.c.frame_fetch()
+        if self.adaptive:
+            # the LM stops by its own ftol/xtol tests; the budget only bounds how many (early-exiting) launches are
+            # enqueued blindly.  Next frame: what this frame needed + 2, never more than --ba-iters.
+            self.ba_prm.max_iters = max(3, min(self.ba_iters_cap, self.last["ba_stats"]["iters"] + 2))
         return self.last
 
 
@@ -164,11 +171,12 @@ def main():
     frames, _ = syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + dist.rank)
     seqs = [Sequence(dist.local_rank, frames, seed=100 * dist.rank + i, ba_iters=a.ba_iters) for i in range(a.seqs)]
     t_setup = time.perf_counter() - t_gen
-    if a.no_graph:
-        for s in seqs:
-            s.c.set_graph_mode(False)
+    for s in seqs:
+        s.c.set_graph_mode(bool(a.graph))
+        s.adaptive = not a.fixed_ba_budget
 
     pool = None
+    a.host_threads = min(a.host_threads, a.seqs)
     if a.host_threads > 1:
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(a.host_threads)
@@ -233,8 +241,15 @@ def main():
         klt_bytes = N_PTS * sum(5120.0 + 1024.0 * x for x in it_mean)
         klt_avg_s = (klt_ms / max(klt_n, 1)) * 1e-3
         achieved = klt_bytes / klt_avg_s / 1e9 if klt_avg_s > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "klt_traffic.json")     # HBM bytes per k_klt_track launch from rocprofv3 --pmc
+        if os.path.exists(tf):                                      # passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), see DESIGN.md
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         roof = {"bound": "hbm", "kernel": "k_klt_track", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_launch_us": round(klt_avg_s * 1e6, 3), "algorithmic_bytes_per_launch": int(klt_bytes),
                 "klt_mean_iters_per_level": [round(x, 3) for x in it_mean]}
         cpu = None
@@ -252,7 +267,7 @@ def main():
                           "ba_landmarks": BA_N, "ba_window": BA_W, "ba_observations": BA_N * BA_W,
                           "ba_lm_iteration_budget": a.ba_iters, "ba_lm_iterations_run": ba_stats["iters"],
                           "ba_final_cost": round(ba_stats["cost"], 4), "ba_initial_cost": round(ba_stats["cost0"], 2),
-                          "launch": "plain" if a.no_graph else "hipGraph replay", "host_threads": max(a.host_threads, 1),
+                          "launch": "hipGraph replay" if a.graph else "plain", "ba_budget": "fixed" if a.fixed_ba_budget else "adaptive (last + 2)", "host_threads": max(a.host_threads, 1),
                           "sequences_per_gpu": a.seqs, "frames_per_step": a.seqs * dist.world,
                           "parallelism": "independent sequences, %d per GPU x %d GPU(s), no collective" % (a.seqs, dist.world)},
                "stage_ms_single_sequence": stage, "roofline": roof, "cpu_baseline": cpu,

@@ -188,8 +188,9 @@ int32_t vo_ba_probe(vo_ctx* ctx, double lambda, double huber_delta, double* resi
  * One call enqueues the hot path of one frame in the order of Pipeline.step (src/pipeline/pipeline.py:92-167):
  * frame `frame_idx` of the uploaded sequence -> pyramid/Scharr -> KLT of the resident points -> [DLT of the
  * uploaded pairs] -> [BA of the uploaded problem] -> [Shi-Tomasi re-detection around the tracked points] ->
- * result copies.  After the first frame of each buffer parity the launch sequence is replayed from a captured
- * hipGraph (vo_set_graph_mode(ctx, 0) forces plain launches).  vo_frame_fetch waits and unpacks the results. */
+ * result copies.  With vo_set_graph_mode(ctx, 1) the launch sequence is captured once per buffer parity and replayed
+ * as a hipGraph (bit-identical results; off by default: on ROCm 7.2 the replay costs more than ~45 plain launches).
+ * vo_frame_fetch waits and unpacks the results. */
 int32_t vo_frame_step_resident(vo_ctx* ctx, int32_t frame_idx, int32_t n_pts, int32_t do_dlt, int32_t do_ba,
                                int32_t do_st, int32_t mask_radius, const vo_klt_params* klt,
                                const vo_st_params* st, const vo_ba_params* ba);               /* async */

@@ -76,7 +76,7 @@ struct vo_ctx {
   int32_t* d_frame_idx = nullptr;        // frame index consumed by the captured k_pad_level0
   int32_t* h_frame_idx = nullptr;        // pinned ring of frame indices (H2D source must outlive the copy)
   int frame_ring = 0;
-  int use_graph = 1;
+  int use_graph = 0;                     // hipGraph replay is opt-in (vo_set_graph_mode): on ROCm 7.2 it is slower than plain launches
   std::string err;
 };
 
