@@ -91,6 +91,14 @@ int32_t vo_device_count(int32_t* n);
  * dimension, as cv2.buildOpticalFlowPyramid does. */
 int32_t vo_ctx_create(int32_t device, int32_t width, int32_t height, int32_t max_pts,
                       int32_t max_level, int32_t win, vo_ctx** out);
+/* BATCHED CONTEXT: `batch` independent sequences of identical shape advance in lockstep; every launch serves all of
+ * them (the path is launch / latency bound per sequence, batching is what fills the 256 CUs).  With batch > 1 EVERY
+ * array argument of every entry point below gains a leading dimension of length `batch` (images [batch][h][w],
+ * points [batch][n][2], status [batch][n], X4 [batch][4][n], P0 [batch][12], K [batch][9], obs [batch][W][N][2],
+ * out_pts [batch][max_corners][2], n_out [batch], stats [batch], ...); scalars (n, parameters) are shared.
+ * vo_ctx_create(...) == vo_ctx_create_batched(..., 1, ...). */
+int32_t vo_ctx_create_batched(int32_t device, int32_t width, int32_t height, int32_t max_pts,
+                              int32_t max_level, int32_t win, int32_t batch, vo_ctx** out);
 int32_t vo_ctx_destroy(vo_ctx* ctx);
 const char* vo_last_error(const vo_ctx* ctx);
 int32_t vo_sync(vo_ctx* ctx);
@@ -100,12 +108,13 @@ int32_t vo_sync(vo_ctx* ctx);
  * (extractor.py:44-45,65-66 rebuild it on each of 4 calls per frame; here once per frame).
  * Pushing a frame rotates cur -> prev.  `stride` in bytes (>= width). */
 int32_t vo_frame_push(vo_ctx* ctx, const uint8_t* img, int32_t stride);
-/* frames preloaded into HBM (bench: inputs resident before the timed region) */
+/* frames preloaded into HBM (bench: inputs resident before the timed region); frames: [batch][n_frames][h][w] */
 int32_t vo_seq_upload(vo_ctx* ctx, const uint8_t* frames, int32_t n_frames);
 int32_t vo_frame_push_resident(vo_ctx* ctx, int32_t frame_index);           /* async */
 /* parity probes: which = 0 prev / 1 cur; img_out (h_l x w_l u8), deriv_out (h_l x w_l x 2 i16), either may be NULL */
 int32_t vo_pyramid_level_size(vo_ctx* ctx, int32_t level, int32_t* w, int32_t* h);
-int32_t vo_pyramid_read(vo_ctx* ctx, int32_t which, int32_t level, uint8_t* img_out, int16_t* deriv_out);
+int32_t vo_pyramid_read(vo_ctx* ctx, int32_t which, int32_t level, uint8_t* img_out, int16_t* deriv_out);   /* sequence 0 */
+int32_t vo_pyramid_read_seq(vo_ctx* ctx, int32_t seq, int32_t which, int32_t level, uint8_t* img_out, int16_t* deriv_out);
 
 /* ---- KLT ------------------------------------------------------------------------------------
  * Replaces cv2.calcOpticalFlowPyrLK(prev, cur, p0, None, **lk_params) at extractor.py:44,65

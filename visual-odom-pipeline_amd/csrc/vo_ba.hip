@@ -68,8 +68,21 @@ struct ba_ptrs {
   double* tilesum; double* posesum;   // k_ba_reduce outputs: n_tiles*256, W*28 + 1 (last = max |g_l|)
   ba_state* state; ba_info* info;
   unsigned long long* dbg;
+  // per-problem strides (elements) of the batched buffers
+  size_t s_obs, s_x, s_aux, s_posepart, s_gmax, s_tiles, s_dp, s_evalpart, s_tilesum, s_posesum;
   int W, N, LPP, PPB, nblk, RP, RT, n_tiles, pitch;
 };
+
+// pointers of problem b of the batch
+__device__ __forceinline__ ba_ptrs ba_select(ba_ptrs P, int b) {
+  const size_t sb = (size_t)b;
+  P.K += sb * 9; P.obs += sb * P.s_obs; P.x0 += sb * P.s_x; P.x[0] += sb * P.s_x; P.x[1] += sb * P.s_x;
+  P.aux += sb * P.s_aux; P.posepart += sb * P.s_posepart; P.gmax += sb * P.s_gmax; P.tiles += sb * P.s_tiles;
+  P.dp += sb * P.s_dp; P.evalpart += sb * P.s_evalpart; P.tilesum += sb * P.s_tilesum; P.posesum += sb * P.s_posesum;
+  P.state += 2 * sb; P.info += sb;
+  if (b != 0) P.dbg = nullptr;
+  return P;
+}
 
 struct vo_ba_ws {
   int W = 0, N = 0, LPP = 0, PPB = 0, nblk = 0, RP = 0, RT = 0, n_tiles = 0, pitch = 0, tpb = 0;
@@ -319,7 +332,8 @@ __device__ inline ba_state ba_init_state(const ba_params_dev& prm) {
 // k_ba_build
 // ------------------------------------------------------------------------------------------------
 template <int TPB>
-__global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs P, ba_params_dev prm, int it, double probe_lambda) {
+__global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev prm, int it, double probe_lambda) {
+  const ba_ptrs P = ba_select(Pall, blockIdx.y);
   extern __shared__ double dyn[];   // phase A: camera-sum scratch [wave][LPP][28]; phase B: Y^ panel [3 PPB][pitch]
   __shared__ double s_cam[BA_CAM * BA_MAX_SLOTS];
   __shared__ double s_K[9];
@@ -521,7 +535,8 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs P, ba_params_dev prm, 
 // k_ba_reduce : fixed-order sum of the per-workgroup partials (Gram tiles, camera sums, max |g_l|), one output
 // element per thread so that the one-workgroup solve reads ~23 KB instead of nblk x 23 KB.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ba_reduce(ba_ptrs P, int it) {
+__global__ void __launch_bounds__(256) k_ba_reduce(ba_ptrs Pall, int it) {
+  const ba_ptrs P = ba_select(Pall, blockIdx.y);
   __shared__ double s_part[4][64];
   const ba_state st = P.state[it & 1];
   if (st.done) return;
@@ -569,8 +584,10 @@ __global__ void __launch_bounds__(256) k_ba_reduce(ba_ptrs P, int it) {
 // ------------------------------------------------------------------------------------------------
 // k_ba_solve : one workgroup
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs P, ba_params_dev prm, int it, double* __restrict__ probe_S,
+__global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_params_dev prm, int it, double* __restrict__ probe_S,
                                                          double* __restrict__ hpp_out) {
+  const ba_ptrs P = ba_select(Pall, blockIdx.x);      // one workgroup per problem of the batch
+  if (blockIdx.x != 0) { probe_S = nullptr; hpp_out = nullptr; }
   extern __shared__ double sm[];
   __shared__ int s_fail;
   const ba_state st = P.state[it & 1];
@@ -778,7 +795,9 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs P, ba_par
 // k_ba_update : back-substitute landmarks, form the trial x, evaluate the trial cost
 // ------------------------------------------------------------------------------------------------
 template <int TPB>
-__global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs P, ba_params_dev prm, int it, double* __restrict__ probe_dl) {
+__global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs Pall, ba_params_dev prm, int it, double* __restrict__ probe_dl) {
+  const ba_ptrs P = ba_select(Pall, blockIdx.y);
+  if (blockIdx.y != 0) probe_dl = nullptr;
   __shared__ double s_cam[BA_CAM * BA_MAX_SLOTS];    // current poses
   __shared__ double s_camt[BA_CAM * BA_MAX_SLOTS];   // trial poses
   __shared__ double s_K[9];
@@ -858,8 +877,12 @@ __global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs P, ba_params_dev prm,
   }
 }
 
-__global__ void __launch_bounds__(256) k_ba_finalize(ba_ptrs P, ba_params_dev prm, int n_it, double* __restrict__ x_out,
-                                                     ba_state* __restrict__ st_out) {
+// grid = batch; x_out / st_out of problem b: pub buffer b ([state 64 B | x]) resp. st_out + b * st_stride
+__global__ void __launch_bounds__(256) k_ba_finalize(ba_ptrs Pall, ba_params_dev prm, int n_it, unsigned char* __restrict__ pub,
+                                                     size_t pub_stride, ba_state* __restrict__ st_out, int st_stride) {
+  const ba_ptrs P = ba_select(Pall, blockIdx.x);
+  double* x_out = reinterpret_cast<double*>(pub + (size_t)blockIdx.x * pub_stride + 64);
+  st_out += (size_t)blockIdx.x * st_stride;
   __shared__ ba_state s_st;
   __shared__ double s_esum[4];
   __shared__ double s_part[4 * 640];
@@ -871,7 +894,7 @@ __global__ void __launch_bounds__(256) k_ba_finalize(ba_ptrs P, ba_params_dev pr
     s_st = st;
     *st_out = st;
     P.state[n_it & 1] = st;
-    *reinterpret_cast<ba_state*>(reinterpret_cast<unsigned char*>(x_out) - 64) = st;   // pub header
+    *reinterpret_cast<ba_state*>(reinterpret_cast<unsigned char*>(x_out) - 64) = st;   // pub header of this problem
   }
   __syncthreads();
   const double* x = (n_it == 0) ? P.x0 : P.x[s_st.cur];
@@ -880,8 +903,10 @@ __global__ void __launch_bounds__(256) k_ba_finalize(ba_ptrs P, ba_params_dev pr
 }
 
 // per-observation residual norms at x (dense [W][N], NaN where unobserved) -- parity probe
-__global__ void __launch_bounds__(128) k_ba_residual(ba_ptrs P, const double* __restrict__ x, double delta,
+__global__ void __launch_bounds__(128) k_ba_residual(ba_ptrs Pall, const double* __restrict__ x, double delta,
                                                      double* __restrict__ res) {
+  const ba_ptrs P = ba_select(Pall, blockIdx.y);
+  x += (size_t)blockIdx.y * Pall.s_x; res += (size_t)blockIdx.y * ((size_t)Pall.W * Pall.N);
   __shared__ double s_cam[BA_CAM * BA_MAX_SLOTS];
   __shared__ double s_K[9];
   const int tid = threadIdx.x;
@@ -941,40 +966,42 @@ static void ba_geometry(vo_ba_ws* b, int W, int N) {
   b->solve_lds = sizeof(double) * ((size_t)n1 * PT + (size_t)W * BA_POSE_VALS + n1 + n1 + 24);
 }
 
+// every buffer: [batch] x per-problem size
 static int32_t ba_alloc(vo_ctx* c, int W, int N) {
   VO_CHECK(c, W >= 1 && W <= BA_MAX_SLOTS, VO_E_CAPACITY, "window size must be 1..20");
   VO_CHECK(c, N >= 1, VO_E_INVALID, "no landmarks");
   if (c->ba && (c->ba->cap_W != W || c->ba->cap_N < N)) vo_ba_destroy(c);
+  const size_t B = (size_t)c->batch;
   if (!c->ba) {
     vo_ba_ws* b = new vo_ba_ws();
     c->ba = b;
     b->cap_W = W; b->cap_N = N;
     ba_geometry(b, W, N);
     const size_t nx = (size_t)6 * W + 3 * N;
-    VO_HIP(c, hipMalloc((void**)&b->d_K, 9 * sizeof(double)));
-    VO_HIP(c, hipMalloc((void**)&b->d_obs, sizeof(double) * 2 * W * N));
-    VO_HIP(c, hipMalloc((void**)&b->d_x0, sizeof(double) * nx));
-    VO_HIP(c, hipMalloc((void**)&b->d_x[0], sizeof(double) * nx));
-    VO_HIP(c, hipMalloc((void**)&b->d_x[1], sizeof(double) * nx));
-    VO_HIP(c, hipMalloc((void**)&b->d_aux, sizeof(double) * (size_t)N * BA_AUX));
-    VO_HIP(c, hipMalloc((void**)&b->d_posepart, sizeof(double) * (size_t)b->nblk * W * BA_POSE_VALS));
-    VO_HIP(c, hipMalloc((void**)&b->d_gmax, sizeof(double) * b->nblk));
-    VO_HIP(c, hipMalloc((void**)&b->d_tiles, sizeof(double) * (size_t)b->nblk * b->n_tiles * 256));
-    VO_HIP(c, hipMalloc((void**)&b->d_dp, sizeof(double) * 6 * W));
-    VO_HIP(c, hipMalloc((void**)&b->d_evalpart, sizeof(double) * b->nblk * BA_EVAL_VALS));
-    VO_HIP(c, hipMalloc((void**)&b->d_tilesum, sizeof(double) * (size_t)b->n_tiles * 256));
-    VO_HIP(c, hipMalloc((void**)&b->d_posesum, sizeof(double) * ((size_t)W * BA_POSE_VALS + 1)));
-    VO_HIP(c, hipMalloc((void**)&b->d_S, sizeof(double) * ((size_t)36 * W * W + 6 * W)));
+    VO_HIP(c, hipMalloc((void**)&b->d_K, 9 * sizeof(double) * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_obs, sizeof(double) * 2 * W * N * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_x0, sizeof(double) * nx * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_x[0], sizeof(double) * nx * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_x[1], sizeof(double) * nx * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_aux, sizeof(double) * (size_t)N * BA_AUX * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_posepart, sizeof(double) * (size_t)b->nblk * W * BA_POSE_VALS * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_gmax, sizeof(double) * b->nblk * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_tiles, sizeof(double) * (size_t)b->nblk * b->n_tiles * 256 * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_dp, sizeof(double) * 6 * W * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_evalpart, sizeof(double) * b->nblk * BA_EVAL_VALS * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_tilesum, sizeof(double) * (size_t)b->n_tiles * 256 * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_posesum, sizeof(double) * ((size_t)W * BA_POSE_VALS + 1) * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_S, sizeof(double) * ((size_t)36 * W * W + 6 * W)));          // probes: problem 0 only
     VO_HIP(c, hipMalloc((void**)&b->d_Hpp, sizeof(double) * (size_t)W * BA_POSE_VALS));
-    VO_HIP(c, hipMalloc((void**)&b->d_res, sizeof(double) * (size_t)W * N));
+    VO_HIP(c, hipMalloc((void**)&b->d_res, sizeof(double) * (size_t)W * N * B));
     VO_HIP(c, hipMalloc((void**)&b->d_dl, sizeof(double) * (size_t)3 * N));
-    b->pub_bytes = 64 + sizeof(double) * nx;
-    VO_HIP(c, hipMalloc((void**)&b->d_pub, b->pub_bytes));
-    VO_HIP(c, hipHostMalloc((void**)&b->h_pub, b->pub_bytes, hipHostMallocDefault));
+    b->pub_bytes = 64 + sizeof(double) * nx;                                                        // per problem
+    VO_HIP(c, hipMalloc((void**)&b->d_pub, b->pub_bytes * B));
+    VO_HIP(c, hipHostMalloc((void**)&b->h_pub, b->pub_bytes * B, hipHostMallocDefault));
     b->d_xout = reinterpret_cast<double*>(b->d_pub + 64);
-    VO_HIP(c, hipMalloc((void**)&b->d_state, sizeof(ba_state) * 2));
-    VO_HIP(c, hipMalloc((void**)&b->d_info, sizeof(ba_info)));
-    VO_HIP(c, hipHostMalloc((void**)&b->h_state, sizeof(ba_state) * 2, hipHostMallocDefault));
+    VO_HIP(c, hipMalloc((void**)&b->d_state, sizeof(ba_state) * 2 * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_info, sizeof(ba_info) * B));
+    VO_HIP(c, hipHostMalloc((void**)&b->h_state, sizeof(ba_state) * B, hipHostMallocDefault));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
@@ -985,8 +1012,6 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
   return VO_OK;
 }
 
-static ba_ptrs ba_make_ptrs(vo_ba_ws* b);
-static ba_ptrs ba_make_ptrs_dbg(vo_ctx* c) { ba_ptrs P = ba_make_ptrs(c->ba); P.dbg = c->d_dbg; return P; }
 static ba_ptrs ba_make_ptrs(vo_ba_ws* b) {
   ba_ptrs P;
   P.K = b->d_K; P.obs = b->d_obs; P.x0 = b->d_x0; P.x[0] = b->d_x[0]; P.x[1] = b->d_x[1]; P.aux = b->d_aux;
@@ -995,8 +1020,14 @@ static ba_ptrs ba_make_ptrs(vo_ba_ws* b) {
   P.state = b->d_state; P.info = b->d_info; P.dbg = nullptr;
   P.W = b->W; P.N = b->N; P.LPP = b->LPP; P.PPB = b->PPB; P.nblk = b->nblk; P.RP = b->RP; P.RT = b->RT;
   P.n_tiles = b->n_tiles; P.pitch = b->pitch;
+  // strides use the ALLOCATED capacity for N-dependent buffers? no: they are packed for the current problem size
+  const size_t W = (size_t)b->W, N = (size_t)b->N;
+  P.s_obs = 2 * W * N; P.s_x = 6 * W + 3 * N; P.s_aux = N * BA_AUX; P.s_posepart = (size_t)b->nblk * W * BA_POSE_VALS;
+  P.s_gmax = (size_t)b->nblk; P.s_tiles = (size_t)b->nblk * b->n_tiles * 256; P.s_dp = 6 * W;
+  P.s_evalpart = (size_t)b->nblk * BA_EVAL_VALS; P.s_tilesum = (size_t)b->n_tiles * 256; P.s_posesum = W * BA_POSE_VALS + 1;
   return P;
 }
+static ba_ptrs ba_make_ptrs_dbg(vo_ctx* c) { ba_ptrs P = ba_make_ptrs(c->ba); P.dbg = c->d_dbg; return P; }
 
 static ba_params_dev ba_dev_params(const vo_ba_params* p) {
   ba_params_dev d;
@@ -1005,6 +1036,7 @@ static ba_params_dev ba_dev_params(const vo_ba_params* p) {
   return d;
 }
 
+// K [batch][9], poses [batch][W][6], points [batch][N][3], obs [batch][W][N][2]
 extern "C" int32_t vo_ba_upload(vo_ctx* c, const double* K, const double* poses, const double* points, const double* obs,
                                 int32_t n_slots, int32_t n_pts) {
   if (!c) return VO_E_INVALID;
@@ -1013,11 +1045,11 @@ extern "C" int32_t vo_ba_upload(vo_ctx* c, const double* K, const double* poses,
   int32_t r = ba_alloc(c, n_slots, n_pts);
   if (r != VO_OK) return r;
   vo_ba_ws* b = c->ba;
-  const int W = b->W, N = b->N;
-  VO_HIP(c, hipMemcpyAsync(b->d_K, K, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  VO_HIP(c, hipMemcpyAsync(b->d_obs, obs, sizeof(double) * 2 * W * N, hipMemcpyHostToDevice, c->stream));
-  VO_HIP(c, hipMemcpyAsync(b->d_x0, poses, sizeof(double) * 6 * W, hipMemcpyHostToDevice, c->stream));
-  VO_HIP(c, hipMemcpyAsync(b->d_x0 + 6 * W, points, sizeof(double) * 3 * N, hipMemcpyHostToDevice, c->stream));
+  const size_t W = b->W, N = b->N, B = c->batch, nx = 6 * W + 3 * N;
+  VO_HIP(c, hipMemcpyAsync(b->d_K, K, 9 * sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipMemcpyAsync(b->d_obs, obs, sizeof(double) * 2 * W * N * B, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipMemcpy2DAsync(b->d_x0, sizeof(double) * nx, poses, sizeof(double) * 6 * W, sizeof(double) * 6 * W, B, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipMemcpy2DAsync(b->d_x0 + 6 * W, sizeof(double) * nx, points, sizeof(double) * 3 * N, sizeof(double) * 3 * N, B, hipMemcpyHostToDevice, c->stream));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   b->uploaded = true;
   return VO_OK;
@@ -1026,15 +1058,16 @@ extern "C" int32_t vo_ba_upload(vo_ctx* c, const double* K, const double* poses,
 static void ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& prm, int it, double probe_lambda,
                            double* probe_S, double* hpp_out, double* probe_dl) {
   vo_ba_ws* b = c->ba;
-  if (b->tpb == 256) hipLaunchKernelGGL(k_ba_build<256>, dim3(b->nblk), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
-  else hipLaunchKernelGGL(k_ba_build<1024>, dim3(b->nblk), dim3(1024), b->build_lds, c->stream, P, prm, it, probe_lambda);
-  hipLaunchKernelGGL(k_ba_reduce, dim3(vo_div_up(b->n_tiles * 256 + b->W * BA_POSE_VALS + 1, 64)), dim3(256), 0, c->stream, P, it);
-  hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(BA_SOLVE_THREADS), b->solve_lds, c->stream, P, prm, it, probe_S, hpp_out);
-  if (b->tpb == 256) hipLaunchKernelGGL(k_ba_update<256>, dim3(b->nblk), dim3(256), 0, c->stream, P, prm, it, probe_dl);
-  else hipLaunchKernelGGL(k_ba_update<1024>, dim3(b->nblk), dim3(1024), 0, c->stream, P, prm, it, probe_dl);
+  const int B = c->batch;
+  if (b->tpb == 256) hipLaunchKernelGGL(k_ba_build<256>, dim3(b->nblk, B), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
+  else hipLaunchKernelGGL(k_ba_build<1024>, dim3(b->nblk, B), dim3(1024), b->build_lds, c->stream, P, prm, it, probe_lambda);
+  hipLaunchKernelGGL(k_ba_reduce, dim3(vo_div_up(b->n_tiles * 256 + b->W * BA_POSE_VALS + 1, 64), B), dim3(256), 0, c->stream, P, it);
+  hipLaunchKernelGGL(k_ba_solve, dim3(B), dim3(BA_SOLVE_THREADS), b->solve_lds, c->stream, P, prm, it, probe_S, hpp_out);
+  if (b->tpb == 256) hipLaunchKernelGGL(k_ba_update<256>, dim3(b->nblk, B), dim3(256), 0, c->stream, P, prm, it, probe_dl);
+  else hipLaunchKernelGGL(k_ba_update<1024>, dim3(b->nblk, B), dim3(1024), 0, c->stream, P, prm, it, probe_dl);
 }
 
-// enqueue `n_it` LM iterations starting at iteration index `it0` (state must be in place)
+// enqueue `n_it` LM iterations starting at iteration index `it0`
 static int32_t ba_enqueue_iters(vo_ctx* c, const ba_params_dev& prm, int it0, int n_it) {
   vo_prof_scope prof(c, VO_PROF_BA);
   const ba_ptrs P = ba_make_ptrs(c->ba);
@@ -1043,10 +1076,9 @@ static int32_t ba_enqueue_iters(vo_ctx* c, const ba_params_dev& prm, int it0, in
   return VO_OK;
 }
 
-// nothing to enqueue: iteration 0 of k_ba_build initialises the state and seeds x[0] from the uploaded x0
-static int32_t ba_begin(vo_ctx* c, const vo_ba_params* prm) {
-  (void)c; (void)prm;
-  return VO_OK;
+static void ba_launch_finalize(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& d, int n_it, ba_state* st_out, int st_stride) {
+  vo_ba_ws* b = c->ba;
+  hipLaunchKernelGGL(k_ba_finalize, dim3(c->batch), dim3(256), 0, c->stream, P, d, n_it, b->d_pub, b->pub_bytes, st_out, st_stride);
 }
 
 extern "C" int32_t vo_ba_solve_resident(vo_ctx* c, const vo_ba_params* prm) {
@@ -1056,14 +1088,12 @@ extern "C" int32_t vo_ba_solve_resident(vo_ctx* c, const vo_ba_params* prm) {
   VO_CHECK(c, c->ba && c->ba->uploaded, VO_E_STATE, "vo_ba_upload first");
   VO_CHECK(c, prm->max_iters >= 0 && prm->max_iters <= 1000, VO_E_INVALID, "bad max_iters");
   VO_HIP(c, hipSetDevice(c->device));
-  int32_t r = ba_begin(c, prm);
-  if (r != VO_OK) return r;
   const ba_params_dev d = ba_dev_params(prm);
-  r = ba_enqueue_iters(c, d, 0, prm->max_iters);
+  int32_t r = ba_enqueue_iters(c, d, 0, prm->max_iters);
   if (r != VO_OK) return r;
   vo_ba_ws* b = c->ba;
   const ba_ptrs P = ba_make_ptrs(b);
-  hipLaunchKernelGGL(k_ba_finalize, dim3(1), dim3(256), 0, c->stream, P, d, prm->max_iters, b->d_xout, b->d_state + 0);
+  ba_launch_finalize(c, P, d, prm->max_iters, b->d_state + (prm->max_iters & 1), 2);
   VO_HIP(c, hipGetLastError());
   return VO_OK;
 }
@@ -1073,20 +1103,23 @@ static void ba_fill_stats(const ba_state& s, int n_obs, vo_ba_stats* st) {
   st->status = s.status; st->n_obs = n_obs;
 }
 
-// internal: enqueue the D2H copy of the published result into the pinned mirror (used by the frame step)
+// internal: enqueue the D2H copy of the published results into the pinned mirror (used by the frame step)
 int32_t vo_ba_enqueue_pub_copy(vo_ctx* c) {
   vo_ba_ws* b = c->ba;
-  VO_HIP(c, hipMemcpyAsync(b->h_pub, b->d_pub, b->pub_bytes, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipMemcpyAsync(b->h_pub, b->d_pub, b->pub_bytes * c->batch, hipMemcpyDeviceToHost, c->stream));
   return VO_OK;
 }
 
-// internal: unpack the pinned mirror (after a stream sync)
+// internal: unpack the pinned mirror (after a stream sync): poses_out [batch][W][6], points_out [batch][N][3], stats [batch]
 void vo_ba_unpack_pub(vo_ctx* c, double* poses_out, double* points_out, vo_ba_stats* stats) {
   vo_ba_ws* b = c->ba;
-  const double* x = reinterpret_cast<const double*>(b->h_pub + 64);
-  if (poses_out) memcpy(poses_out, x, sizeof(double) * 6 * b->W);
-  if (points_out) memcpy(points_out, x + 6 * b->W, sizeof(double) * 3 * b->N);
-  if (stats) ba_fill_stats(*reinterpret_cast<const ba_state*>(b->h_pub), -1, stats);
+  for (int q = 0; q < c->batch; q++) {
+    const uint8_t* pub = b->h_pub + (size_t)q * b->pub_bytes;
+    const double* x = reinterpret_cast<const double*>(pub + 64);
+    if (poses_out) memcpy(poses_out + (size_t)q * 6 * b->W, x, sizeof(double) * 6 * b->W);
+    if (points_out) memcpy(points_out + (size_t)q * 3 * b->N, x + 6 * b->W, sizeof(double) * 3 * b->N);
+    if (stats) ba_fill_stats(*reinterpret_cast<const ba_state*>(pub), -1, stats + q);
+  }
 }
 
 extern "C" int32_t vo_ba_fetch(vo_ctx* c, double* poses_out, double* points_out, vo_ba_stats* stats) {
@@ -1100,6 +1133,7 @@ extern "C" int32_t vo_ba_fetch(vo_ctx* c, double* poses_out, double* points_out,
   return VO_OK;
 }
 
+// arrays with a leading batch dimension; stats [batch]
 extern "C" int32_t vo_ba_adjust(vo_ctx* c, const double* K, const double* poses, const double* points, const double* obs,
                                 int32_t n_slots, int32_t n_pts, const vo_ba_params* prm, double* poses_out,
                                 double* points_out, vo_ba_stats* stats) {
@@ -1111,13 +1145,13 @@ extern "C" int32_t vo_ba_adjust(vo_ctx* c, const double* K, const double* poses,
   int32_t r = vo_ba_upload(c, K, poses, points, obs, n_slots, n_pts);
   if (r != VO_OK) return r;
   vo_ba_ws* b = c->ba;
-  r = ba_begin(c, prm);
-  if (r != VO_OK) return r;
   const ba_params_dev d = ba_dev_params(prm);
   const ba_ptrs P = ba_make_ptrs(b);
-  // iterations are enqueued in chunks; between chunks the host peeks at the state to stop early
+  const int B = c->batch;
+  // iterations are enqueued in chunks; between chunks the host peeks at the states to stop early
   const int CH = 4;
   int it = 0;
+  bool all_done = false;
   do {
     const int n = (prm->max_iters - it < CH) ? prm->max_iters - it : CH;
     if (n > 0) {
@@ -1125,21 +1159,32 @@ extern "C" int32_t vo_ba_adjust(vo_ctx* c, const double* K, const double* poses,
       if (r != VO_OK) return r;
       it += n;
     }
-    hipLaunchKernelGGL(k_ba_finalize, dim3(1), dim3(256), 0, c->stream, P, d, it, b->d_xout, b->d_state + (it & 1));
-    VO_HIP(c, hipMemcpyAsync(b->h_state, b->d_state + (it & 1), sizeof(ba_state), hipMemcpyDeviceToHost, c->stream));
+    ba_launch_finalize(c, P, d, it, b->d_state + (it & 1), 2);
+    VO_HIP(c, hipMemcpy2DAsync(b->h_state, sizeof(ba_state), b->d_state + (it & 1), 2 * sizeof(ba_state), sizeof(ba_state), B,
+                               hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipStreamSynchronize(c->stream));
-  } while (!b->h_state[0].done && it < prm->max_iters);
-  VO_HIP(c, hipMemcpy(poses_out, b->d_xout, sizeof(double) * 6 * b->W, hipMemcpyDeviceToHost));
-  VO_HIP(c, hipMemcpy(points_out, b->d_xout + 6 * b->W, sizeof(double) * 3 * b->N, hipMemcpyDeviceToHost));
-  if (stats) {
-    int n_obs = 0;
-    for (size_t k = 0; k < (size_t)b->W * b->N; k++) n_obs += (obs[2 * k] == obs[2 * k]);
-    ba_fill_stats(b->h_state[0], n_obs, stats);
+    all_done = true;
+    for (int q = 0; q < B; q++) all_done = all_done && b->h_state[q].done;
+  } while (!all_done && it < prm->max_iters);
+  r = vo_ba_enqueue_pub_copy(c);
+  if (r != VO_OK) return r;
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  vo_ba_unpack_pub(c, poses_out, points_out, stats);
+  bool bad = false;
+  for (int q = 0; q < B; q++) {
+    if (stats) {
+      int n_obs = 0;
+      const double* o = obs + (size_t)q * 2 * b->W * b->N;
+      for (size_t k = 0; k < (size_t)b->W * b->N; k++) n_obs += (o[2 * k] == o[2 * k]);
+      stats[q].n_obs = n_obs;
+    }
+    bad = bad || (b->h_state[q].cost != b->h_state[q].cost);
   }
-  if (b->h_state[0].cost != b->h_state[0].cost) return vo_fail(c, VO_E_NUMERIC, "bundle adjustment produced a non-finite cost");
+  if (bad) return vo_fail(c, VO_E_NUMERIC, "bundle adjustment produced a non-finite cost");
   return VO_OK;
 }
 
+// parity probe of problem 0 of the batch
 extern "C" int32_t vo_ba_probe(vo_ctx* c, double lambda, double huber_delta, double* residual, int32_t* n_obs, double* cost,
                                double* Hpp, double* gp, double* Hll, double* gl, double* S, double* rhs, double* dposes,
                                double* dpoints) {
@@ -1151,11 +1196,9 @@ extern "C" int32_t vo_ba_probe(vo_ctx* c, double lambda, double huber_delta, dou
   vo_ba_params prm;
   vo_ba_default_params(&prm);
   prm.huber_delta = huber_delta; prm.lambda0 = lambda; prm.max_iters = 1;
-  int32_t r = ba_begin(c, &prm);
-  if (r != VO_OK) return r;
   const ba_params_dev d = ba_dev_params(&prm);
   const ba_ptrs P = ba_make_ptrs_dbg(c);
-  hipLaunchKernelGGL(k_ba_residual, dim3(vo_div_up(N, 128)), dim3(128), 0, c->stream, P, b->d_x0, huber_delta, b->d_res);
+  hipLaunchKernelGGL(k_ba_residual, dim3(vo_div_up(N, 128), c->batch), dim3(128), 0, c->stream, P, b->d_x0, huber_delta, b->d_res);
   ba_launch_iter(c, P, d, 0, lambda, b->d_S, b->d_Hpp, b->d_dl);
   VO_HIP(c, hipGetLastError());
   VO_HIP(c, hipStreamSynchronize(c->stream));

@@ -8,18 +8,22 @@
 // float32-rounded, float32-dehomogenised point exactly like extractor.py:271 / triangulate.py:15-29.
 #include "vo_internal.h"
 
-struct dlt_args {
+struct vo_dlt_cam {          // per sequence
   float P0[12], P1[12];
   double M0[12], M1[12];   // K @ H[:3,:] (f64) of both views
   double H1z[4];           // third row of H1
-  int n, want_stats;
 };
 
-__global__ void __launch_bounds__(64) k_dlt(dlt_args a, const float* __restrict__ uv0, const float* __restrict__ uv1,
-                                            float* __restrict__ X4, double* __restrict__ depth1,
-                                            double* __restrict__ reproj) {
+// grid (ceil(n / 64), batch)
+__global__ void __launch_bounds__(64) k_dlt(const vo_dlt_cam* __restrict__ cams, int n, int want_stats, size_t uv_seq,
+                                            size_t slab_seq, const float* __restrict__ uv0, const float* __restrict__ uv1,
+                                            float* __restrict__ X4, double* __restrict__ depth1, double* __restrict__ reproj) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
+  if (i >= n) return;
+  const int bseq = blockIdx.y;
+  const vo_dlt_cam& a = cams[bseq];
+  uv0 += (size_t)bseq * uv_seq; uv1 += (size_t)bseq * uv_seq;
+  X4 = vo_seq(X4, slab_seq, bseq); depth1 = vo_seq(depth1, slab_seq, bseq); reproj = vo_seq(reproj, slab_seq, bseq);
   const float u0 = uv0[2 * i], v0 = uv0[2 * i + 1], u1 = uv1[2 * i], v1 = uv1[2 * i + 1];
   double U[4][4], V[4][4];
 #pragma unroll
@@ -74,9 +78,9 @@ __global__ void __launch_bounds__(64) k_dlt(dlt_args a, const float* __restrict_
   }
   float xf[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) { xf[k] = (float)x[k]; X4[(size_t)k * a.n + i] = xf[k]; }
+  for (int k = 0; k < 4; k++) { xf[k] = (float)x[k]; X4[(size_t)k * n + i] = xf[k]; }
 
-  if (a.want_stats) {
+  if (want_stats) {
     // float32 dehomogenisation (numpy float32 divide), then float64 statistics
     const double X = (double)(xf[0] / xf[3]), Y = (double)(xf[1] / xf[3]), Z = (double)(xf[2] / xf[3]);
     depth1[i] = a.H1z[0] * X + a.H1z[1] * Y + a.H1z[2] * Z + a.H1z[3];
@@ -94,31 +98,56 @@ __global__ void __launch_bounds__(64) k_dlt(dlt_args a, const float* __restrict_
   }
 }
 
-static void dlt_fill_args(dlt_args& a, const float* P0, const float* P1, const double* K, const double* H0,
-                          const double* H1, int n) {
-  const bool stats = K != nullptr;
-  for (int k = 0; k < 12; k++) { a.P0[k] = P0[k]; a.P1[k] = P1[k]; a.M0[k] = 0; a.M1[k] = 0; }
-  for (int k = 0; k < 4; k++) a.H1z[k] = 0;
-  if (stats) {
-    for (int r = 0; r < 3; r++)
-      for (int col = 0; col < 4; col++) {
-        double s0 = 0, s1 = 0;
-        for (int k = 0; k < 3; k++) { s0 += K[r * 3 + k] * H0[k * 4 + col]; s1 += K[r * 3 + k] * H1[k * 4 + col]; }
-        a.M0[r * 4 + col] = s0; a.M1[r * 4 + col] = s1;
-      }
-    for (int k = 0; k < 4; k++) a.H1z[k] = H1[8 + k];
+// host: per-sequence camera data from [batch] x (P0, P1[, K, H0, H1])
+static int32_t dlt_set_cams(vo_ctx* c, const float* P0, const float* P1, const double* K, const double* H0, const double* H1) {
+  const int B = c->batch;
+  std::vector<vo_dlt_cam> cams((size_t)B);
+  for (int b = 0; b < B; b++) {
+    vo_dlt_cam& a = cams[b];
+    for (int k = 0; k < 12; k++) { a.P0[k] = P0[12 * b + k]; a.P1[k] = P1[12 * b + k]; a.M0[k] = 0; a.M1[k] = 0; }
+    for (int k = 0; k < 4; k++) a.H1z[k] = 0;
+    if (K) {
+      const double* Kb = K + 9 * b; const double* H0b = H0 + 16 * b; const double* H1b = H1 + 16 * b;
+      for (int r = 0; r < 3; r++)
+        for (int col = 0; col < 4; col++) {
+          double s0 = 0, s1 = 0;
+          for (int k = 0; k < 3; k++) { s0 += Kb[r * 3 + k] * H0b[k * 4 + col]; s1 += Kb[r * 3 + k] * H1b[k * 4 + col]; }
+          a.M0[r * 4 + col] = s0; a.M1[r * 4 + col] = s1;
+        }
+      for (int k = 0; k < 4; k++) a.H1z[k] = H1b[8 + k];
+    }
   }
-  a.n = n; a.want_stats = stats ? 1 : 0;
+  if (!c->d_dlt_cam) VO_HIP(c, hipMalloc((void**)&c->d_dlt_cam, sizeof(vo_dlt_cam) * B));
+  VO_HIP(c, hipMemcpy(c->d_dlt_cam, cams.data(), sizeof(vo_dlt_cam) * B, hipMemcpyHostToDevice));   // synchronous: `cams` is a local
+  c->dlt_stats = K ? 1 : 0;
+  return VO_OK;
 }
 
-static int32_t dlt_launch(vo_ctx* c, const dlt_args& a) {
+static int32_t dlt_launch(vo_ctx* c, int n) {
   vo_prof_scope prof(c, VO_PROF_DLT);
-  hipLaunchKernelGGL(k_dlt, dim3(vo_div_up(a.n, 64)), dim3(64), 0, c->stream, a, c->d_uv0, c->d_uv1, c->d_X4,
-                     c->d_depth, c->d_reproj);
+  hipLaunchKernelGGL(k_dlt, dim3(vo_div_up(n, 64), c->batch), dim3(64), 0, c->stream, c->d_dlt_cam, n, c->dlt_stats,
+                     (size_t)c->max_pts * 2, c->slab_seq, c->d_uv0, c->d_uv1, vo_slab<float>(c, c->off_X4),
+                     vo_slab<double>(c, c->off_depth), vo_slab<double>(c, c->off_reproj));
   VO_HIP(c, hipGetLastError());
   return VO_OK;
 }
 
+static int32_t dlt_upload_uv(vo_ctx* c, const float* uv0, const float* uv1, int n) {
+  const size_t row = sizeof(float) * 2 * n, pitch = sizeof(float) * 2 * (size_t)c->max_pts;
+  VO_HIP(c, hipMemcpy2DAsync(c->d_uv0, pitch, uv0, row, row, c->batch, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipMemcpy2DAsync(c->d_uv1, pitch, uv1, row, row, c->batch, hipMemcpyHostToDevice, c->stream));
+  return VO_OK;
+}
+
+static int32_t dlt_download(vo_ctx* c, int n, float* X4, double* depth1, double* reproj) {
+  if (X4) VO_HIP(c, hipMemcpy2DAsync(X4, sizeof(float) * 4 * n, c->d_slab + c->off_X4, c->slab_seq, sizeof(float) * 4 * n, c->batch, hipMemcpyDeviceToHost, c->stream));
+  if (depth1 && c->dlt_stats) VO_HIP(c, hipMemcpy2DAsync(depth1, sizeof(double) * n, c->d_slab + c->off_depth, c->slab_seq, sizeof(double) * n, c->batch, hipMemcpyDeviceToHost, c->stream));
+  if (reproj && c->dlt_stats) VO_HIP(c, hipMemcpy2DAsync(reproj, sizeof(double) * n, c->d_slab + c->off_reproj, c->slab_seq, sizeof(double) * n, c->batch, hipMemcpyDeviceToHost, c->stream));
+  return VO_OK;
+}
+
+// All arrays carry a leading batch dimension: P0/P1 [batch][12], uv [batch][n][2], X4 [batch][4][n],
+// K [batch][9], H0/H1 [batch][16], depth1/reproj [batch][n].
 extern "C" int32_t vo_triangulate_dlt(vo_ctx* c, const float* P0, const float* P1, const float* uv0,
                                       const float* uv1, int32_t n, float* X4, const double* K,
                                       const double* H0, const double* H1, double* depth1, double* reproj) {
@@ -126,20 +155,16 @@ extern "C" int32_t vo_triangulate_dlt(vo_ctx* c, const float* P0, const float* P
   VO_CHECK(c, n >= 0 && n <= c->max_pts, VO_E_CAPACITY, "n exceeds max_pts");
   if (n == 0) return VO_OK;
   VO_CHECK(c, P0 && P1 && uv0 && uv1 && X4, VO_E_INVALID, "null buffer");
-  const bool stats = K != nullptr;
-  if (stats) VO_CHECK(c, H0 && H1 && depth1 && reproj, VO_E_INVALID, "statistics need K, H0, H1, depth1, reproj");
+  if (K) VO_CHECK(c, H0 && H1 && depth1 && reproj, VO_E_INVALID, "statistics need K, H0, H1, depth1, reproj");
   VO_HIP(c, hipSetDevice(c->device));
-  dlt_args a;
-  dlt_fill_args(a, P0, P1, K, H0, H1, n);
-  VO_HIP(c, hipMemcpyAsync(c->d_uv0, uv0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
-  VO_HIP(c, hipMemcpyAsync(c->d_uv1, uv1, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
-  int32_t r = dlt_launch(c, a);
+  int32_t r = dlt_set_cams(c, P0, P1, K, H0, H1);
   if (r != VO_OK) return r;
-  VO_HIP(c, hipMemcpyAsync(X4, c->d_X4, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, c->stream));
-  if (stats) {
-    VO_HIP(c, hipMemcpyAsync(depth1, c->d_depth, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    VO_HIP(c, hipMemcpyAsync(reproj, c->d_reproj, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-  }
+  r = dlt_upload_uv(c, uv0, uv1, n);
+  if (r != VO_OK) return r;
+  r = dlt_launch(c, n);
+  if (r != VO_OK) return r;
+  r = dlt_download(c, n, X4, depth1, reproj);
+  if (r != VO_OK) return r;
   VO_HIP(c, hipStreamSynchronize(c->stream));
   return VO_OK;
 }
@@ -151,14 +176,10 @@ extern "C" int32_t vo_dlt_upload(vo_ctx* c, const float* P0, const float* P1, co
   VO_CHECK(c, P0 && P1 && uv0 && uv1, VO_E_INVALID, "null buffer");
   if (K) VO_CHECK(c, H0 && H1, VO_E_INVALID, "statistics need K, H0, H1");
   VO_HIP(c, hipSetDevice(c->device));
-  for (int k = 0; k < 12; k++) { c->dlt_P0[k] = P0[k]; c->dlt_P1[k] = P1[k]; }
-  c->dlt_stats = K ? 1 : 0;
-  if (K) {
-    for (int k = 0; k < 9; k++) c->dlt_K[k] = K[k];
-    for (int k = 0; k < 16; k++) { c->dlt_H0[k] = H0[k]; c->dlt_H1[k] = H1[k]; }
-  }
-  VO_HIP(c, hipMemcpyAsync(c->d_uv0, uv0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
-  VO_HIP(c, hipMemcpyAsync(c->d_uv1, uv1, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+  int32_t r = dlt_set_cams(c, P0, P1, K, H0, H1);
+  if (r != VO_OK) return r;
+  r = dlt_upload_uv(c, uv0, uv1, n);
+  if (r != VO_OK) return r;
   VO_HIP(c, hipStreamSynchronize(c->stream));
   c->dlt_n = n;
   return VO_OK;
@@ -168,19 +189,15 @@ extern "C" int32_t vo_dlt_resident(vo_ctx* c) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->dlt_n > 0, VO_E_STATE, "vo_dlt_upload first");
   VO_HIP(c, hipSetDevice(c->device));
-  dlt_args a;
-  dlt_fill_args(a, c->dlt_P0, c->dlt_P1, c->dlt_stats ? c->dlt_K : nullptr, c->dlt_H0, c->dlt_H1, c->dlt_n);
-  return dlt_launch(c, a);
+  return dlt_launch(c, c->dlt_n);
 }
 
 extern "C" int32_t vo_dlt_fetch(vo_ctx* c, float* X4, double* depth1, double* reproj) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->dlt_n > 0, VO_E_STATE, "nothing to fetch");
   VO_HIP(c, hipSetDevice(c->device));
-  const int n = c->dlt_n;
-  if (X4) VO_HIP(c, hipMemcpyAsync(X4, c->d_X4, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, c->stream));
-  if (depth1 && c->dlt_stats) VO_HIP(c, hipMemcpyAsync(depth1, c->d_depth, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-  if (reproj && c->dlt_stats) VO_HIP(c, hipMemcpyAsync(reproj, c->d_reproj, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  int32_t r = dlt_download(c, c->dlt_n, X4, depth1, reproj);
+  if (r != VO_OK) return r;
   VO_HIP(c, hipStreamSynchronize(c->stream));
   return VO_OK;
 }

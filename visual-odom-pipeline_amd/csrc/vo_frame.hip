@@ -24,26 +24,30 @@ __device__ __forceinline__ int d_reflect101(int p, int len) {
   return p;
 }
 
-// Level 0: raw (w x h, tight) -> padded image with reflect-101 border.
-// `raw` is either the frame itself (frame_idx == nullptr) or the base of the resident sequence, in which case the
+// Level 0: raw (w x h, tight) -> padded image with reflect-101 border.  grid (x blocks, padded rows, batch).
+// `raw` is the frame of sequence 0 (frame_idx == nullptr) or the base of the resident sequences, in which case the
 // frame index is read from device memory (lets a captured graph be replayed for any frame).
-__global__ void __launch_bounds__(256) k_pad_level0(const uint8_t* __restrict__ raw, const int32_t* __restrict__ frame_idx,
-                                                    int w, int h, uint8_t* __restrict__ dst, int pitch, int ph) {
+__global__ void __launch_bounds__(256) k_pad_level0(const uint8_t* __restrict__ raw, size_t raw_seq_stride,
+                                                    const int32_t* __restrict__ frame_idx, int w, int h,
+                                                    uint8_t* __restrict__ dst, size_t dst_seq_stride, int pitch, int ph) {
   const int X = blockIdx.x * blockDim.x + threadIdx.x;   // padded column
   const int Y = blockIdx.y;
   if (X >= w + 2 * VO_PAD || Y >= ph) return;
+  raw += (size_t)blockIdx.z * raw_seq_stride;
+  dst += (size_t)blockIdx.z * dst_seq_stride;
   if (frame_idx) raw += (size_t)(*frame_idx) * w * h;
   const int x = d_reflect101(X - VO_PAD, w), y = d_reflect101(Y - VO_PAD, h);
   dst[(size_t)Y * pitch + X] = raw[(size_t)y * w + x];
 }
 
-// One launch per level l, two block roles:
+// One launch per level l, two block roles (grid.y = batch):
 //   blocks [0, nb_scharr)            : Scharr derivative of level l (interior only)
 //   blocks [nb_scharr, gridDim.x)    : pyrDown level l -> l+1 including its reflect-101 border
 // Both only READ level l, so they are independent inside the launch.
-__global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restrict__ src, int w, int h, int pitch,
+__global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restrict__ src, size_t src_seq_px, int w, int h, int pitch,
                                                         int16_t* __restrict__ der, int nb_scharr,
-                                                        uint8_t* __restrict__ dst, int dw, int dh, int dpitch) {
+                                                        uint8_t* __restrict__ dst, size_t dst_seq_px, int dw, int dh, int dpitch) {
+  src += (size_t)blockIdx.y * src_seq_px;
   if ((int)blockIdx.x < nb_scharr) {
     // ---- Scharr: Ix = [3 10 3]^T (x) [-1 0 1], Iy = [-1 0 1]^T (x) [3 10 3], un-normalised ----
     const int per_row = (w + 255) / 256;
@@ -57,7 +61,7 @@ __global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restric
     const int ix = (a02 + a22 - a00 - a20) * 3 + (a12 - a10) * 10;
     const int iy = (a20 + a22 - a00 - a02) * 3 + (a21 - a01) * 10;
     const uint32_t packed = ((uint32_t)(uint16_t)(int16_t)ix) | ((uint32_t)(uint16_t)(int16_t)iy << 16);
-    reinterpret_cast<uint32_t*>(der)[(size_t)(y + VO_PAD) * pitch + (x + VO_PAD)] = packed;
+    reinterpret_cast<uint32_t*>(der)[(size_t)blockIdx.y * src_seq_px + (size_t)(y + VO_PAD) * pitch + (x + VO_PAD)] = packed;
   } else {
     // ---- pyrDown: 5x5 [1 4 6 4 1]^2, (sum + 128) >> 8, output padded domain ----
     const int b = blockIdx.x - nb_scharr;
@@ -77,7 +81,7 @@ __global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restric
       const int wj = (j == 0) ? 6 : ((j == -1 || j == 1) ? 4 : 1);
       sum += wj * row;
     }
-    dst[(size_t)Y * dpitch + X] = (uint8_t)((sum + 128) >> 8);
+    dst[(size_t)blockIdx.y * dst_seq_px + (size_t)Y * dpitch + X] = (uint8_t)((sum + 128) >> 8);
   }
 }
 
@@ -176,7 +180,7 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
       if (c->fr[f].der[l]) (void)hipFree(c->fr[f].der[l]);
     }
   for (int g = 0; g < 2; g++) if (c->step_graph[g]) (void)hipGraphExecDestroy(c->step_graph[g]);
-  void* bufs[] = {c->d_dbg, c->d_raw, c->d_seq, c->d_iters, c->d_uv0, c->d_uv1, c->d_slab, c->d_frame_idx};
+  void* bufs[] = {c->d_dbg, c->d_raw, c->d_seq, c->d_iters, c->d_uv0, c->d_uv1, c->d_slab, c->d_frame_idx, c->d_dlt_cam};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_slab) (void)hipHostFree(c->h_slab);
   if (c->h_frame_idx) (void)hipHostFree(c->h_frame_idx);
@@ -188,10 +192,15 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
 
 extern "C" int32_t vo_ctx_create(int32_t device, int32_t width, int32_t height, int32_t max_pts,
                                  int32_t max_level, int32_t win, vo_ctx** out) {
+  return vo_ctx_create_batched(device, width, height, max_pts, max_level, win, 1, out);
+}
+
+extern "C" int32_t vo_ctx_create_batched(int32_t device, int32_t width, int32_t height, int32_t max_pts,
+                                         int32_t max_level, int32_t win, int32_t batch, vo_ctx** out) {
   if (!out) return VO_E_INVALID;
   *out = nullptr;
   if (width < 8 || height < 8 || max_pts < 1 || max_level < 0 || max_level >= VO_MAX_LEVELS ||
-      win < 3 || win > VO_MAX_WIN || (win & 1) == 0) {
+      win < 3 || win > VO_MAX_WIN || (win & 1) == 0 || batch < 1 || batch > 1024) {
     g_create_err = "vo_ctx_create: invalid argument";
     return VO_E_INVALID;
   }
@@ -205,7 +214,7 @@ extern "C" int32_t vo_ctx_create(int32_t device, int32_t width, int32_t height, 
   if (!c) return VO_E_NOMEM;
   for (int f = 0; f < 2; f++)
     for (int l = 0; l < VO_MAX_LEVELS; l++) { c->fr[f].img[l] = nullptr; c->fr[f].der[l] = nullptr; }
-  c->device = device; c->width = width; c->height = height; c->max_pts = max_pts;
+  c->device = device; c->width = width; c->height = height; c->max_pts = max_pts; c->batch = batch;
   c->max_level = max_level; c->win = win;
   auto fail = [&](int32_t code) { g_create_err = c->err; vo_ctx_destroy(c); return code; };
 #define CR(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { c->err = std::string(#expr) + " -> " + hipGetErrorString(_e); return fail(VO_E_HIP); } } while (0)
@@ -222,18 +231,19 @@ extern "C" int32_t vo_ctx_create(int32_t device, int32_t width, int32_t height, 
     c->lv[l].w = w; c->lv[l].h = h;
     c->lv[l].pitch = ((w + 2 * VO_PAD + 63) / 64) * 64;
     c->lv[l].ph = h + 2 * VO_PAD;
+    c->lvl_px[l] = (size_t)c->lv[l].pitch * c->lv[l].ph;
     top = l;
   }
   c->top = top;
   for (int f = 0; f < 2; f++)
     for (int l = 0; l <= top; l++) {
-      const size_t px = (size_t)c->lv[l].pitch * c->lv[l].ph;
+      const size_t px = c->lvl_px[l] * (size_t)batch;
       CR(hipMalloc((void**)&c->fr[f].img[l], px));
       CR(hipMalloc((void**)&c->fr[f].der[l], px * 4));
       CR(hipMemsetAsync(c->fr[f].img[l], 0, px, c->stream));
       CR(hipMemsetAsync(c->fr[f].der[l], 0, px * 4, c->stream));   // border stays 0 forever
     }
-  CR(hipMalloc((void**)&c->d_raw, (size_t)width * height));
+  CR(hipMalloc((void**)&c->d_raw, (size_t)width * height * batch));
   CR(hipMalloc((void**)&c->d_dbg, sizeof(unsigned long long) * 32));
   CR(hipMemsetAsync(c->d_dbg, 0, sizeof(unsigned long long) * 32, c->stream));
   {
@@ -244,21 +254,15 @@ extern "C" int32_t vo_ctx_create(int32_t device, int32_t width, int32_t height, 
     c->off_pa = take(8 * M); c->off_pb = take(8 * M); c->off_status = take(M); c->off_err = take(4 * M);
     c->off_X4 = take(16 * M); c->off_depth = take(8 * M); c->off_reproj = take(8 * M);
     c->off_st_scalars = take(64); c->off_st_out = take(8 * 4096);
-    c->slab_bytes = off;
+    c->slab_seq = off;
+    c->slab_bytes = off * (size_t)batch;
     CR(hipMalloc((void**)&c->d_slab, c->slab_bytes));
     CR(hipMemsetAsync(c->d_slab, 0, c->slab_bytes, c->stream));
     CR(hipHostMalloc((void**)&c->h_slab, c->slab_bytes, hipHostMallocDefault));
-    c->d_p0 = reinterpret_cast<float*>(c->d_slab + c->off_pa);
-    c->d_p1 = reinterpret_cast<float*>(c->d_slab + c->off_pb);
-    c->d_status = c->d_slab + c->off_status;
-    c->d_err = reinterpret_cast<float*>(c->d_slab + c->off_err);
-    c->d_X4 = reinterpret_cast<float*>(c->d_slab + c->off_X4);
-    c->d_depth = reinterpret_cast<double*>(c->d_slab + c->off_depth);
-    c->d_reproj = reinterpret_cast<double*>(c->d_slab + c->off_reproj);
   }
-  CR(hipMalloc((void**)&c->d_iters, sizeof(int32_t) * max_pts * VO_MAX_LEVELS));
-  CR(hipMalloc((void**)&c->d_uv0, sizeof(float) * 2 * max_pts));
-  CR(hipMalloc((void**)&c->d_uv1, sizeof(float) * 2 * max_pts));
+  CR(hipMalloc((void**)&c->d_iters, sizeof(int32_t) * (size_t)max_pts * VO_MAX_LEVELS * batch));
+  CR(hipMalloc((void**)&c->d_uv0, sizeof(float) * 2 * (size_t)max_pts * batch));
+  CR(hipMalloc((void**)&c->d_uv1, sizeof(float) * 2 * (size_t)max_pts * batch));
   CR(hipMalloc((void**)&c->d_frame_idx, sizeof(int32_t)));
   CR(hipHostMalloc((void**)&c->h_frame_idx, sizeof(int32_t) * 64, hipHostMallocDefault));
   CR(hipStreamSynchronize(c->stream));
@@ -277,51 +281,56 @@ extern "C" int32_t vo_sync(vo_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 // frames
 // ------------------------------------------------------------------------------------------------
-int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, const int32_t* d_frame_idx) {
+int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, size_t raw_seq_stride, const int32_t* d_frame_idx) {
   vo_prof_scope prof(c, VO_PROF_FRAME);
   c->cur ^= 1;
   vo_frame& F = c->fr[c->cur];
+  const int B = c->batch;
   {
     const vo_level& L = c->lv[0];
-    dim3 grid(vo_div_up(L.w + 2 * VO_PAD, 256), L.ph);
-    hipLaunchKernelGGL(k_pad_level0, grid, dim3(256), 0, c->stream, d_raw_img, d_frame_idx, L.w, L.h, F.img[0], L.pitch, L.ph);
+    dim3 grid(vo_div_up(L.w + 2 * VO_PAD, 256), L.ph, B);
+    hipLaunchKernelGGL(k_pad_level0, grid, dim3(256), 0, c->stream, d_raw_img, raw_seq_stride, d_frame_idx, L.w, L.h,
+                       F.img[0], c->lvl_px[0], L.pitch, L.ph);
   }
   for (int l = 0; l <= c->top; l++) {
     const vo_level& L = c->lv[l];
     const int nb_scharr = vo_div_up(L.w, 256) * L.h;
     int nb_down = 0;
-    uint8_t* dst = nullptr; int dw = 0, dh = 0, dpitch = 0;
+    uint8_t* dst = nullptr; int dw = 0, dh = 0, dpitch = 0; size_t dpx = 0;
     if (l < c->top) {
       const vo_level& D = c->lv[l + 1];
-      dst = F.img[l + 1]; dw = D.w; dh = D.h; dpitch = D.pitch;
+      dst = F.img[l + 1]; dw = D.w; dh = D.h; dpitch = D.pitch; dpx = c->lvl_px[l + 1];
       nb_down = vo_div_up(D.w + 2 * VO_PAD, 256) * D.ph;
     }
-    hipLaunchKernelGGL(k_scharr_pyrdown, dim3(nb_scharr + nb_down), dim3(256), 0, c->stream,
-                       F.img[l], L.w, L.h, L.pitch, F.der[l], nb_scharr, dst, dw, dh, dpitch);
+    hipLaunchKernelGGL(k_scharr_pyrdown, dim3(nb_scharr + nb_down, B), dim3(256), 0, c->stream,
+                       F.img[l], c->lvl_px[l], L.w, L.h, L.pitch, F.der[l], nb_scharr, dst, dpx, dw, dh, dpitch);
   }
   VO_HIP(c, hipGetLastError());
   c->n_pushed++;
   return VO_OK;
 }
 
+// img: `batch` images, sequence b at img + b * seq_stride bytes (seq_stride = stride * height when 0)
 extern "C" int32_t vo_frame_push(vo_ctx* c, const uint8_t* img, int32_t stride) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, img != nullptr && stride >= c->width, VO_E_INVALID, "bad image / stride");
   VO_HIP(c, hipSetDevice(c->device));
-  VO_HIP(c, hipMemcpy2DAsync(c->d_raw, c->width, img, stride, c->width, c->height, hipMemcpyHostToDevice, c->stream));
-  int32_t r = vo_build_pyramid(c, c->d_raw, nullptr);
+  // the batch's images are contiguous: [batch][height] rows of `stride` bytes
+  VO_HIP(c, hipMemcpy2DAsync(c->d_raw, c->width, img, stride, c->width, (size_t)c->height * c->batch, hipMemcpyHostToDevice, c->stream));
+  int32_t r = vo_build_pyramid(c, c->d_raw, (size_t)c->width * c->height, nullptr);
   if (r != VO_OK) return r;
   VO_HIP(c, hipStreamSynchronize(c->stream));   // the host buffer may be reused by the caller
   return VO_OK;
 }
 
+// frames: [batch][n_frames][height][width] uint8
 extern "C" int32_t vo_seq_upload(vo_ctx* c, const uint8_t* frames, int32_t n_frames) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, frames != nullptr && n_frames > 0, VO_E_INVALID, "bad sequence");
   VO_HIP(c, hipSetDevice(c->device));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   if (c->d_seq) { VO_HIP(c, hipFree(c->d_seq)); c->d_seq = nullptr; c->seq_n = 0; }
-  const size_t bytes = (size_t)c->width * c->height * n_frames;
+  const size_t bytes = (size_t)c->width * c->height * n_frames * c->batch;
   VO_HIP(c, hipMalloc((void**)&c->d_seq, bytes));
   VO_HIP(c, hipMemcpy(c->d_seq, frames, bytes, hipMemcpyHostToDevice));
   c->seq_n = n_frames;
@@ -332,7 +341,8 @@ extern "C" int32_t vo_frame_push_resident(vo_ctx* c, int32_t idx) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->d_seq != nullptr && idx >= 0 && idx < c->seq_n, VO_E_STATE, "no resident sequence / bad index");
   VO_HIP(c, hipSetDevice(c->device));
-  return vo_build_pyramid(c, c->d_seq + (size_t)idx * c->width * c->height, nullptr);
+  const size_t fr = (size_t)c->width * c->height;
+  return vo_build_pyramid(c, c->d_seq + (size_t)idx * fr, fr * c->seq_n, nullptr);
 }
 
 extern "C" int32_t vo_pyramid_level_size(vo_ctx* c, int32_t level, int32_t* w, int32_t* h) {
@@ -343,18 +353,22 @@ extern "C" int32_t vo_pyramid_level_size(vo_ctx* c, int32_t level, int32_t* w, i
 }
 
 extern "C" int32_t vo_pyramid_read(vo_ctx* c, int32_t which, int32_t level, uint8_t* img_out, int16_t* deriv_out) {
+  return vo_pyramid_read_seq(c, 0, which, level, img_out, deriv_out);
+}
+
+extern "C" int32_t vo_pyramid_read_seq(vo_ctx* c, int32_t seq, int32_t which, int32_t level, uint8_t* img_out, int16_t* deriv_out) {
   if (!c) return VO_E_INVALID;
-  VO_CHECK(c, level >= 0 && level <= c->top && (which == 0 || which == 1), VO_E_INVALID, "bad level / which");
+  VO_CHECK(c, level >= 0 && level <= c->top && (which == 0 || which == 1) && seq >= 0 && seq < c->batch, VO_E_INVALID, "bad level / which / seq");
   VO_CHECK(c, c->n_pushed >= (which == 0 ? 2 : 1), VO_E_STATE, "frame not pushed yet");
   VO_HIP(c, hipSetDevice(c->device));
   const vo_frame& F = c->fr[which == 1 ? c->cur : (c->cur ^ 1)];
   const vo_level& L = c->lv[level];
   VO_HIP(c, hipStreamSynchronize(c->stream));
   if (img_out)
-    VO_HIP(c, hipMemcpy2D(img_out, L.w, F.img[level] + (size_t)VO_PAD * L.pitch + VO_PAD, L.pitch, L.w, L.h,
+    VO_HIP(c, hipMemcpy2D(img_out, L.w, F.img[level] + (size_t)seq * c->lvl_px[level] + (size_t)VO_PAD * L.pitch + VO_PAD, L.pitch, L.w, L.h,
                           hipMemcpyDeviceToHost));
   if (deriv_out)
-    VO_HIP(c, hipMemcpy2D(deriv_out, (size_t)L.w * 4, F.der[level] + ((size_t)VO_PAD * L.pitch + VO_PAD) * 2,
+    VO_HIP(c, hipMemcpy2D(deriv_out, (size_t)L.w * 4, F.der[level] + ((size_t)seq * c->lvl_px[level] + (size_t)VO_PAD * L.pitch + VO_PAD) * 2,
                           (size_t)L.pitch * 4, (size_t)L.w * 4, L.h, hipMemcpyDeviceToHost));
   return VO_OK;
 }

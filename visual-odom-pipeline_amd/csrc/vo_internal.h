@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <type_traits>
 
 #include "vo_mi355x.h"
 
@@ -33,41 +34,44 @@ struct vo_prof {
 struct vo_st_ws;   // Shi-Tomasi workspace (vo_shi_tomasi.hip)
 struct vo_ba_ws;   // bundle-adjustment workspace (vo_ba.hip)
 
+struct vo_dlt_cam;  // per-sequence DLT camera data (vo_dlt.hip)
+
+// A context carries `batch` independent sequences in lockstep: every device buffer has a leading sequence
+// dimension with a uniform stride and every kernel a grid dimension over sequences, so that one launch serves
+// the whole batch (the path is launch / latency bound per sequence; batching is what fills the 256 CUs).
 struct vo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  int batch = 1;
   int width = 0, height = 0, max_pts = 0, max_level = 0, win = 0;
   int top = 0;                       // highest pyramid level index built
   vo_level lv[VO_MAX_LEVELS];
-  vo_frame fr[2];
+  size_t lvl_px[VO_MAX_LEVELS];      // pixels per sequence per level (= pitch * ph): the per-sequence stride
+  vo_frame fr[2];                    // sequence 0 of each buffer; sequence b at + b * lvl_px[l] pixels
   int cur = 0;                       // index of the current frame in fr[]
   int n_pushed = 0;
-  uint8_t* d_raw = nullptr;          // staging of one raw frame
-  uint8_t* d_seq = nullptr;          // preloaded sequence (vo_seq_upload)
+  uint8_t* d_raw = nullptr;          // staging of one raw frame per sequence
+  uint8_t* d_seq = nullptr;          // preloaded sequences [batch][seq_n][h][w] (vo_seq_upload)
   int seq_n = 0;
-  // tracked point set
-  float* d_p0 = nullptr;             // n x 2
-  float* d_p1 = nullptr;
-  float* d_err = nullptr;
-  uint8_t* d_status = nullptr;
-  int32_t* d_iters = nullptr;        // n x (max_level + 1)
+  // tracked point sets live in the result slab (off_pa / off_pb, ping-pong selected by p_parity)
+  int p_parity = 0;                  // 0: current points at off_pa
+  int32_t* d_iters = nullptr;        // [batch][n x (max_level + 1)]
   int n_resident = 0;
   int iters_stride = 0;              // of the last KLT launch
-  // DLT scratch
-  float* d_uv0 = nullptr; float* d_uv1 = nullptr; float* d_X4 = nullptr;
-  double* d_depth = nullptr; double* d_reproj = nullptr;
+  // DLT inputs
+  float* d_uv0 = nullptr; float* d_uv1 = nullptr;    // [batch][max_pts][2]
+  vo_dlt_cam* d_dlt_cam = nullptr;   // [batch]
   int dlt_n = 0, dlt_stats = 0;
-  float dlt_P0[12], dlt_P1[12];
-  double dlt_K[9], dlt_H0[16], dlt_H1[16];
   vo_st_ws* st = nullptr;
   vo_ba_ws* ba = nullptr;
   vo_prof prof;
   unsigned long long* d_dbg = nullptr;   // 4 x 8 phase stamps (vo_debug_cycles)
   // result slab: every per-frame output of the front end lives in ONE device allocation (mirrored in pinned host
   // memory) so that a frame's results come back with a single D2H copy instead of ten.
-  uint8_t* d_slab = nullptr;
+  uint8_t* d_slab = nullptr;             // [batch][slab_seq]
   uint8_t* h_slab = nullptr;
-  size_t slab_bytes = 0;
+  size_t slab_seq = 0;                   // bytes per sequence
+  size_t slab_bytes = 0;                 // batch * slab_seq
   size_t off_pa = 0, off_pb = 0, off_status = 0, off_err = 0, off_X4 = 0, off_depth = 0, off_reproj = 0,
          off_st_scalars = 0, off_st_out = 0;
   // per-frame step (vo_frame_step_resident) captured as hipGraphs, one per frame parity
@@ -101,6 +105,15 @@ inline int32_t vo_fail(vo_ctx* c, int32_t code, const std::string& msg) {
     if (!(cond)) return vo_fail((c), (code), std::string(__func__) + ": " + (msg));       \
   } while (0)
 
+// slab accessors (sequence 0; sequence b at + b * slab_seq bytes)
+template <class T> inline T* vo_slab(const vo_ctx* c, size_t off) { return reinterpret_cast<T*>(c->d_slab + off); }
+inline size_t vo_off_p(const vo_ctx* c) { return c->p_parity ? c->off_pb : c->off_pa; }       // current points
+inline size_t vo_off_p_next(const vo_ctx* c) { return c->p_parity ? c->off_pa : c->off_pb; }  // KLT output
+// device side: pointer of sequence b given the sequence-0 pointer and the byte stride
+template <class T> __device__ __forceinline__ T* vo_seq(T* base, size_t stride_bytes, int b) {
+  return reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(const_cast<typename std::remove_const<T>::type*>(base)) + (size_t)b * stride_bytes);
+}
+
 // RAII bracket: records an event pair on the ctx stream around a region when profiling is on
 struct vo_prof_scope {
   vo_ctx* c; int region; hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -114,9 +127,9 @@ struct vo_prof_scope {
 static inline int vo_div_up(int a, int b) { return (a + b - 1) / b; }
 
 // cross-unit internals used by the fused frame step (vo_step.hip)
-int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, const int32_t* d_frame_idx);
+int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, size_t raw_seq_stride, const int32_t* d_frame_idx);
 int32_t vo_ba_enqueue_pub_copy(vo_ctx* c);
-void vo_ba_unpack_pub(vo_ctx* c, double* poses_out, double* points_out, vo_ba_stats* stats);
+void vo_ba_unpack_pub(vo_ctx* c, double* poses_out, double* points_out, vo_ba_stats* stats);   // arrays over the batch
 bool vo_ba_ready(const vo_ctx* c);
 bool vo_st_ready(const vo_ctx* c);
 int vo_st_last_max_corners(const vo_ctx* c);

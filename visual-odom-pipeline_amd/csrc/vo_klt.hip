@@ -19,14 +19,17 @@
 #define W_BITS 14
 
 struct klt_level_args {
-  const uint8_t* imgI;
+  const uint8_t* imgI;    // sequence 0; sequence b at + b * seq_px pixels
   const uint32_t* derI;   // (Ix | Iy << 16) per pixel
   const uint8_t* imgJ;
+  size_t seq_px;
   int w, h, pitch;
 };
 
 struct klt_args {
   klt_level_args lv[VO_MAX_LEVELS];
+  size_t slab_seq;        // byte stride between the sequences' point / status / err arrays
+  size_t iters_seq;       // int32 stride between the sequences' iteration tables
   int top, win, max_count, n, iters_stride;
   float min_eig;
   double eps2;
@@ -111,7 +114,11 @@ __global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __res
   const int pt = blockIdx.x;
   if (pt >= A.n) return;
   const int lane = threadIdx.x;
-  unsigned long long* dbgk = (pt == A.n / 2 && dbg) ? dbg + 24 : nullptr;   // diagnostic stamps of one wave
+  const int bseq = blockIdx.y;            // sequence of the batch
+  p0 = vo_seq(p0, A.slab_seq, bseq); p1 = vo_seq(p1, A.slab_seq, bseq);
+  status = vo_seq(status, A.slab_seq, bseq); err = vo_seq(err, A.slab_seq, bseq);
+  if (iters) iters += (size_t)bseq * A.iters_seq;
+  unsigned long long* dbgk = (pt == A.n / 2 && bseq == 0 && dbg) ? dbg + 24 : nullptr;   // diagnostic stamps of one wave
   VO_STAMP(dbgk, 0);
   const int cp = lane >> 2, r = lane & 3;
   const int win = A.win;
@@ -128,7 +135,8 @@ __global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __res
   const uint32_t colones = colmask & 0x00010001u;
 
   for (int level = A.top; level >= 0; level--) {
-    const klt_level_args L = A.lv[level];
+    klt_level_args L = A.lv[level];
+    L.imgI += (size_t)bseq * L.seq_px; L.derI += (size_t)bseq * L.seq_px; L.imgJ += (size_t)bseq * L.seq_px;
     const float scale = 1.f / (float)(1 << level);
     float prevx = p0x * scale, prevy = p0y * scale;
     float nextx, nexty;
@@ -280,7 +288,7 @@ extern "C" int32_t vo_klt_default_params(vo_klt_params* p) {
   return VO_OK;
 }
 
-static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, const float* d_in, float* d_out) {
+static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, size_t off_in, size_t off_out) {
   VO_CHECK(c, c->n_pushed >= 2, VO_E_STATE, "need two pushed frames");
   VO_CHECK(c, n >= 0 && n <= c->max_pts, VO_E_CAPACITY, "n exceeds max_pts");
   VO_CHECK(c, prm && prm->win >= 3 && prm->win <= VO_MAX_WIN && (prm->win & 1), VO_E_INVALID, "win must be odd, 3..31");
@@ -297,6 +305,7 @@ static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, const floa
   }
   for (int l = 0; l <= top; l++) {
     A.lv[l].imgI = P.img[l]; A.lv[l].derI = reinterpret_cast<const uint32_t*>(P.der[l]); A.lv[l].imgJ = C.img[l];
+    A.lv[l].seq_px = c->lvl_px[l];
     A.lv[l].w = c->lv[l].w; A.lv[l].h = c->lv[l].h; A.lv[l].pitch = c->lv[l].pitch;
   }
   A.top = top; A.win = prm->win;
@@ -304,15 +313,26 @@ static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, const floa
   double eps = prm->epsilon; if (eps < 0) eps = 0; if (eps > 10) eps = 10;
   A.max_count = mc; A.eps2 = eps * eps; A.min_eig = prm->min_eig_threshold; A.n = n;
   A.iters_stride = prm->max_level + 1;
+  A.slab_seq = c->slab_seq; A.iters_seq = (size_t)c->max_pts * VO_MAX_LEVELS;
   c->iters_stride = A.iters_stride;
   // levels above `top` are reported as skipped (-1)
-  VO_HIP(c, hipMemsetAsync(c->d_iters, 0xff, sizeof(int32_t) * (size_t)n * A.iters_stride, c->stream));
+  VO_HIP(c, hipMemsetAsync(c->d_iters, 0xff, sizeof(int32_t) * A.iters_seq * c->batch, c->stream));
   {
     vo_prof_scope prof(c, VO_PROF_KLT);   // brackets exactly this launch (bench.py roofline figure)
-    hipLaunchKernelGGL(k_klt_track, dim3(n), dim3(64), 0, c->stream, A, d_in, d_out, c->d_status, c->d_err, c->d_iters, c->d_dbg);
+    hipLaunchKernelGGL(k_klt_track, dim3(n, c->batch), dim3(64), 0, c->stream, A, vo_slab<const float>(c, off_in),
+                       vo_slab<float>(c, off_out), vo_slab<uint8_t>(c, c->off_status), vo_slab<float>(c, c->off_err),
+                       c->d_iters, c->d_dbg);
   }
   VO_HIP(c, hipGetLastError());
   return VO_OK;
+}
+
+// strided copies between [batch][n * elem] host arrays and the per-sequence slab rows
+static hipError_t slab_h2d(vo_ctx* c, size_t off, const void* h, size_t row_bytes) {
+  return hipMemcpy2DAsync(c->d_slab + off, c->slab_seq, h, row_bytes, row_bytes, c->batch, hipMemcpyHostToDevice, c->stream);
+}
+static hipError_t slab_d2h(vo_ctx* c, void* h, size_t off, size_t row_bytes) {
+  return hipMemcpy2DAsync(h, row_bytes, c->d_slab + off, c->slab_seq, row_bytes, c->batch, hipMemcpyDeviceToHost, c->stream);
 }
 
 extern "C" int32_t vo_klt_track(vo_ctx* c, const float* p0, int32_t n, const vo_klt_params* prm,
@@ -324,14 +344,18 @@ extern "C" int32_t vo_klt_track(vo_ctx* c, const float* p0, int32_t n, const vo_
   if (n == 0) return VO_OK;
   VO_CHECK(c, p0 && p1 && status && err, VO_E_INVALID, "null buffer");
   VO_HIP(c, hipSetDevice(c->device));
-  VO_HIP(c, hipMemcpyAsync(c->d_p0, p0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
-  int32_t r = klt_launch(c, n, prm, c->d_p0, c->d_p1);
+  const size_t off_in = vo_off_p(c), off_out = vo_off_p_next(c);
+  VO_HIP(c, slab_h2d(c, off_in, p0, sizeof(float) * 2 * n));
+  int32_t r = klt_launch(c, n, prm, off_in, off_out);
   if (r != VO_OK) return r;
-  VO_HIP(c, hipMemcpyAsync(p1, c->d_p1, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->stream));
-  VO_HIP(c, hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, c->stream));
-  VO_HIP(c, hipMemcpyAsync(err, c->d_err, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
-  if (iters)
-    VO_HIP(c, hipMemcpyAsync(iters, c->d_iters, sizeof(int32_t) * (size_t)n * (prm->max_level + 1), hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, slab_d2h(c, p1, off_out, sizeof(float) * 2 * n));
+  VO_HIP(c, slab_d2h(c, status, c->off_status, n));
+  VO_HIP(c, slab_d2h(c, err, c->off_err, sizeof(float) * n));
+  if (iters) {
+    const size_t row = sizeof(int32_t) * (size_t)n * (prm->max_level + 1);
+    VO_HIP(c, hipMemcpy2DAsync(iters, row, c->d_iters, sizeof(int32_t) * (size_t)c->max_pts * VO_MAX_LEVELS, row, c->batch,
+                               hipMemcpyDeviceToHost, c->stream));
+  }
   VO_HIP(c, hipStreamSynchronize(c->stream));
   return VO_OK;
 }
@@ -340,7 +364,7 @@ extern "C" int32_t vo_points_upload(vo_ctx* c, const float* p, int32_t n) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, p && n >= 0 && n <= c->max_pts, VO_E_CAPACITY, "bad point set");
   VO_HIP(c, hipSetDevice(c->device));
-  VO_HIP(c, hipMemcpyAsync(c->d_p0, p, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+  if (n > 0) VO_HIP(c, slab_h2d(c, vo_off_p(c), p, sizeof(float) * 2 * n));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   c->n_resident = n;
   return VO_OK;
@@ -350,11 +374,16 @@ extern "C" int32_t vo_points_download(vo_ctx* c, float* p, uint8_t* status, floa
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, n >= 0 && n <= c->n_resident, VO_E_INVALID, "n exceeds the resident point set");
   VO_HIP(c, hipSetDevice(c->device));
-  if (p) VO_HIP(c, hipMemcpyAsync(p, c->d_p0, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->stream));
-  if (status) VO_HIP(c, hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, c->stream));
-  if (err) VO_HIP(c, hipMemcpyAsync(err, c->d_err, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
-  if (iters && c->iters_stride > 0)
-    VO_HIP(c, hipMemcpyAsync(iters, c->d_iters, sizeof(int32_t) * (size_t)n * c->iters_stride, hipMemcpyDeviceToHost, c->stream));
+  if (n > 0) {
+    if (p) VO_HIP(c, slab_d2h(c, p, vo_off_p(c), sizeof(float) * 2 * n));
+    if (status) VO_HIP(c, slab_d2h(c, status, c->off_status, n));
+    if (err) VO_HIP(c, slab_d2h(c, err, c->off_err, sizeof(float) * n));
+    if (iters && c->iters_stride > 0) {
+      const size_t row = sizeof(int32_t) * (size_t)n * c->iters_stride;
+      VO_HIP(c, hipMemcpy2DAsync(iters, row, c->d_iters, sizeof(int32_t) * (size_t)c->max_pts * VO_MAX_LEVELS, row, c->batch,
+                                 hipMemcpyDeviceToHost, c->stream));
+    }
+  }
   VO_HIP(c, hipStreamSynchronize(c->stream));
   return VO_OK;
 }
@@ -365,8 +394,8 @@ extern "C" int32_t vo_klt_track_resident(vo_ctx* c, int32_t n, const vo_klt_para
   if (!prm) { vo_klt_default_params(&def); prm = &def; }
   VO_CHECK(c, n >= 0 && n <= c->n_resident, VO_E_INVALID, "n exceeds the resident point set");
   VO_HIP(c, hipSetDevice(c->device));
-  int32_t r = klt_launch(c, n, prm, c->d_p0, c->d_p1);
+  int32_t r = klt_launch(c, n, prm, vo_off_p(c), vo_off_p_next(c));
   if (r != VO_OK) return r;
-  float* t = c->d_p0; c->d_p0 = c->d_p1; c->d_p1 = t;   // tracked positions become the resident set
+  c->p_parity ^= 1;   // tracked positions become the resident set
   return VO_OK;
 }

@@ -45,13 +45,20 @@ __device__ __forceinline__ int st_reflect101(int p, int len) {
   return p;
 }
 
-__global__ void __launch_bounds__(256) k_st_sobel_hsum(const uint8_t* __restrict__ img, int pitch, int W, int H, int r,
-                                                       int32_t* __restrict__ hxx, int32_t* __restrict__ hxy,
-                                                       int32_t* __restrict__ hyy, uint8_t* __restrict__ mask,
+// grid (x blocks, rows, batch); per-sequence strides: img_seq_px pixels, plane = W * H elements
+__global__ void __launch_bounds__(256) k_st_sobel_hsum(const uint8_t* __restrict__ img, size_t img_seq_px, int pitch, int W, int H, int r,
+                                                       int32_t* __restrict__ hbase, uint8_t* __restrict__ mask,
                                                        const uint8_t* __restrict__ user_mask,
-                                                       uint32_t* __restrict__ scalars) {
+                                                       uint32_t* __restrict__ scalars, size_t slab_seq) {
   __shared__ int32_t sxx[256 + 2 * 15 + 2], sxy[256 + 2 * 15 + 2], syy[256 + 2 * 15 + 2];
   const int y = blockIdx.y, x0 = blockIdx.x * 256, t = threadIdx.x;
+  const int bseq = blockIdx.z;
+  const size_t np = (size_t)W * H;
+  img += (size_t)bseq * img_seq_px;
+  int32_t* hxx = hbase + (size_t)bseq * 3 * np; int32_t* hxy = hxx + np; int32_t* hyy = hxy + np;
+  mask += (size_t)bseq * np;
+  if (user_mask) user_mask += (size_t)bseq * np;
+  scalars = vo_seq(scalars, slab_seq, bseq);
   if (blockIdx.x == 0 && blockIdx.y == 0 && t < 4) scalars[t] = 0;
   const int span = 256 + 2 * r;
   for (int i = t; i < span; i += 256) {
@@ -75,11 +82,14 @@ __global__ void __launch_bounds__(256) k_st_sobel_hsum(const uint8_t* __restrict
   }
 }
 
-__global__ void __launch_bounds__(256) k_st_discs(const float* __restrict__ pts, int n, int radius, disc_rows rows,
+// grid (blocks, batch); pts of sequence b at + b * pts_seq bytes
+__global__ void __launch_bounds__(256) k_st_discs(const float* __restrict__ pts, size_t pts_seq, int n, int radius, disc_rows rows,
                                                   uint8_t* __restrict__ mask, int W, int H) {
   const int nrows = 2 * radius + 1;
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= n * nrows) return;
+  pts = vo_seq(pts, pts_seq, blockIdx.y);
+  mask += (size_t)blockIdx.y * W * H;
   const int k = gid / nrows, dy = gid - k * nrows - radius;
   const int cx = (int)pts[2 * k], cy = (int)pts[2 * k + 1];   // np.int32(): truncation toward zero
   const int y = cy + dy;
@@ -93,13 +103,17 @@ __global__ void __launch_bounds__(256) k_st_discs(const float* __restrict__ pts,
 }
 
 #define ST_RG 8   // output rows per thread in the vertical pass
-__global__ void __launch_bounds__(256) k_st_vsum_eig(const int32_t* __restrict__ hxx, const int32_t* __restrict__ hxy,
-                                                     const int32_t* __restrict__ hyy, const uint8_t* __restrict__ mask,
+__global__ void __launch_bounds__(256) k_st_vsum_eig(const int32_t* __restrict__ hbase, const uint8_t* __restrict__ mask,
                                                      int W, int H, int r, float s2, float* __restrict__ eig,
                                                      float* __restrict__ blockmax) {
   __shared__ float s_m[4];
   const int x = blockIdx.x * 256 + threadIdx.x;
   const int y0 = blockIdx.y * ST_RG;
+  const int bseq = blockIdx.z;
+  const size_t np = (size_t)W * H;
+  const int32_t* hxx = hbase + (size_t)bseq * 3 * np; const int32_t* hxy = hxx + np; const int32_t* hyy = hxy + np;
+  mask += (size_t)bseq * np; eig += (size_t)bseq * np;
+  blockmax += (size_t)bseq * gridDim.x * gridDim.y;
   float lmax = 0.f;
   if (x < W) {
     int32_t sa = 0, sb = 0, sc = 0;
@@ -149,11 +163,17 @@ __global__ void __launch_bounds__(256) k_st_vsum_eig(const int32_t* __restrict__
 #define ST_NMS_ROWS 8
 __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, const uint8_t* __restrict__ mask, int W,
                                                 int H, double quality, const float* __restrict__ blockmax, int n_blockmax,
-                                                unsigned long long* __restrict__ cand, uint32_t* __restrict__ scalars) {
+                                                unsigned long long* __restrict__ cand, uint32_t* __restrict__ scalars, size_t slab_seq) {
   __shared__ float s_m[4];
   __shared__ unsigned int s_cnt, s_base;
   __shared__ unsigned long long s_list[256 * ST_NMS_ROWS / 2];
   const int tid = threadIdx.x;
+  {
+    const int bseq = blockIdx.z;
+    const size_t np = (size_t)W * H;
+    eig += (size_t)bseq * np; mask += (size_t)bseq * np; blockmax += (size_t)bseq * n_blockmax;
+    cand += (size_t)bseq * ST_CAND_CAP; scalars = vo_seq(scalars, slab_seq, bseq);
+  }
   // ---- global masked maximum (minMaxLoc) from the per-block maxima ----
   float m = 0.f;
   for (int i = tid; i < n_blockmax; i += 256) m = fmaxf(m, blockmax[i]);
@@ -275,8 +295,11 @@ __device__ __forceinline__ void st_sort_dispatch(const unsigned long long* __res
 __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __restrict__ cand,
                                                     uint32_t* __restrict__ scalars, int W, int H, int cell, int gw, int gh,
                                                     double md2, int use_dist, int max_corners, float* __restrict__ out,
-                                                    unsigned long long* __restrict__ dbg) {
+                                                    size_t slab_seq, unsigned long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cand += (size_t)blockIdx.x * ST_CAND_CAP;             // one workgroup per sequence
+  scalars = vo_seq(scalars, slab_seq, blockIdx.x); out = vo_seq(out, slab_seq, blockIdx.x);
+  if (blockIdx.x != 0) dbg = nullptr;
   __shared__ int s_flags[3];
   __shared__ int s_scan[1024];
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
@@ -438,18 +461,17 @@ static int32_t st_init(vo_ctx* c) {
   if (c->st) return VO_OK;
   vo_st_ws* s = new vo_st_ws();
   c->st = s;
-  const size_t np = (size_t)c->width * c->height;
-  VO_HIP(c, hipMalloc((void**)&s->d_mask, np));
-  VO_HIP(c, hipMalloc((void**)&s->d_user_mask, np));
-  VO_HIP(c, hipMalloc((void**)&s->d_h, np * 3 * sizeof(int32_t)));
-  VO_HIP(c, hipMalloc((void**)&s->d_eig, np * sizeof(float)));
-  s->d_scalars = reinterpret_cast<uint32_t*>(c->d_slab + c->off_st_scalars);
-  VO_HIP(c, hipMalloc((void**)&s->d_cand, sizeof(unsigned long long) * ST_CAND_CAP));
+  const size_t np = (size_t)c->width * c->height, B = (size_t)c->batch;
+  VO_HIP(c, hipMalloc((void**)&s->d_mask, np * B));
+  VO_HIP(c, hipMalloc((void**)&s->d_user_mask, np * B));
+  VO_HIP(c, hipMalloc((void**)&s->d_h, np * 3 * sizeof(int32_t) * B));
+  VO_HIP(c, hipMalloc((void**)&s->d_eig, np * sizeof(float) * B));
+  s->d_scalars = vo_slab<uint32_t>(c, c->off_st_scalars);
+  VO_HIP(c, hipMalloc((void**)&s->d_cand, sizeof(unsigned long long) * ST_CAND_CAP * B));
   s->n_blockmax = vo_div_up(c->width, 256) * vo_div_up(c->height, ST_RG);
-  VO_HIP(c, hipMalloc((void**)&s->d_blockmax, sizeof(float) * (size_t)s->n_blockmax));
-  s->d_out = reinterpret_cast<float*>(c->d_slab + c->off_st_out);
-  VO_HIP(c, hipMalloc((void**)&s->d_pts, sizeof(float) * 2 * (size_t)c->max_pts));
-  VO_HIP(c, hipMemsetAsync(s->d_scalars, 0, 16 * sizeof(uint32_t), c->stream));
+  VO_HIP(c, hipMalloc((void**)&s->d_blockmax, sizeof(float) * (size_t)s->n_blockmax * B));
+  s->d_out = vo_slab<float>(c, c->off_st_out);
+  VO_HIP(c, hipMalloc((void**)&s->d_pts, sizeof(float) * 2 * (size_t)c->max_pts * B));
   VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_st_select), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)ST_SEL_LDS));
   return VO_OK;
@@ -482,7 +504,8 @@ extern "C" int32_t vo_st_default_params(vo_st_params* p) {
   return VO_OK;
 }
 
-static int32_t st_launch(vo_ctx* c, const float* d_pts, int n_cur, int mask_radius, const uint8_t* d_user_mask,
+// pts: sequence-0 pointer of the exclusion-disc centres, pts_seq: byte stride between sequences
+static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cur, int mask_radius, const uint8_t* d_user_mask,
                          const vo_st_params* prm) {
   VO_CHECK(c, c->n_pushed >= 1, VO_E_STATE, "no frame pushed");
   VO_CHECK(c, prm->block_size >= 1 && prm->block_size <= 31 && (prm->block_size & 1), VO_E_INVALID,
@@ -491,26 +514,24 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, int n_cur, int mask_radi
   VO_CHECK(c, prm->max_corners <= ST_OUT_CAP, VO_E_CAPACITY, "max_corners exceeds 4096");
   vo_st_ws* s = c->st;
   vo_prof_scope prof(c, VO_PROF_ST);
-  const int W = c->width, H = c->height, r = prm->block_size / 2;
-  const size_t np = (size_t)W * H;
+  const int W = c->width, H = c->height, r = prm->block_size / 2, B = c->batch;
   const vo_frame& F = c->fr[c->cur];
-  int32_t* hxx = s->d_h; int32_t* hxy = s->d_h + np; int32_t* hyy = s->d_h + 2 * np;
-  hipLaunchKernelGGL(k_st_sobel_hsum, dim3(vo_div_up(W, 256), H), dim3(256), 0, c->stream, F.img[0], c->lv[0].pitch, W, H,
-                     r, hxx, hxy, hyy, s->d_mask, d_user_mask, s->d_scalars);
+  hipLaunchKernelGGL(k_st_sobel_hsum, dim3(vo_div_up(W, 256), H, B), dim3(256), 0, c->stream, F.img[0], c->lvl_px[0],
+                     c->lv[0].pitch, W, H, r, s->d_h, s->d_mask, d_user_mask, s->d_scalars, c->slab_seq);
   if (n_cur > 0) {
     disc_rows rows;
     circle_rows(mask_radius, &rows);
     const int total = n_cur * (2 * mask_radius + 1);
-    hipLaunchKernelGGL(k_st_discs, dim3(vo_div_up(total, 256)), dim3(256), 0, c->stream, d_pts, n_cur, mask_radius, rows,
-                       s->d_mask, W, H);
+    hipLaunchKernelGGL(k_st_discs, dim3(vo_div_up(total, 256), B), dim3(256), 0, c->stream, d_pts, pts_seq, n_cur, mask_radius,
+                       rows, s->d_mask, W, H);
   }
   const double scale_d = 1.0 / ((double)(1 << 2) * prm->block_size * 255.0);
   const float sf = (float)scale_d;
   const float s2 = sf * sf;
-  hipLaunchKernelGGL(k_st_vsum_eig, dim3(vo_div_up(W, 256), vo_div_up(H, ST_RG)), dim3(256), 0, c->stream, hxx, hxy, hyy,
+  hipLaunchKernelGGL(k_st_vsum_eig, dim3(vo_div_up(W, 256), vo_div_up(H, ST_RG), B), dim3(256), 0, c->stream, s->d_h,
                      s->d_mask, W, H, r, s2, s->d_eig, s->d_blockmax);
-  hipLaunchKernelGGL(k_st_nms, dim3(vo_div_up(W - 2, 256), vo_div_up(H - 2, ST_NMS_ROWS)), dim3(256), 0, c->stream, s->d_eig,
-                     s->d_mask, W, H, prm->quality_level, s->d_blockmax, s->n_blockmax, s->d_cand, s->d_scalars);
+  hipLaunchKernelGGL(k_st_nms, dim3(vo_div_up(W - 2, 256), vo_div_up(H - 2, ST_NMS_ROWS), B), dim3(256), 0, c->stream, s->d_eig,
+                     s->d_mask, W, H, prm->quality_level, s->d_blockmax, s->n_blockmax, s->d_cand, s->d_scalars, c->slab_seq);
   const int use_dist = prm->min_distance >= 1.0 ? 1 : 0;
   // grid cell: >= min_distance (3x3 neighbourhood then covers the exclusion radius), coarse enough to fit LDS
   int cell = use_dist ? (int)ceil(prm->min_distance) : 1;
@@ -518,29 +539,31 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, int n_cur, int mask_radi
   while (((W + cell - 1) / cell) * ((H + cell - 1) / cell) > ST_MAX_CELLS) cell++;
   const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
   const double md2 = prm->min_distance * prm->min_distance;
-  hipLaunchKernelGGL(k_st_select, dim3(1), dim3(1024), ST_SEL_LDS, c->stream, s->d_cand,
-                     s->d_scalars, W, H, cell, gw, gh, md2, use_dist, prm->max_corners, s->d_out, c->d_dbg);
+  hipLaunchKernelGGL(k_st_select, dim3(B), dim3(1024), ST_SEL_LDS, c->stream, s->d_cand,
+                     s->d_scalars, W, H, cell, gw, gh, md2, use_dist, prm->max_corners, s->d_out, c->slab_seq, c->d_dbg);
   VO_HIP(c, hipGetLastError());
   s->last_max_corners = prm->max_corners;
   return VO_OK;
 }
 
+// out_pts [batch][max_corners][2], n_out [batch]
 static int32_t st_fetch(vo_ctx* c, float* out_pts, int32_t* n_out) {
   vo_st_ws* s = c->st;
-  uint32_t sc[4];
-  VO_HIP(c, hipMemcpyAsync(sc, s->d_scalars, sizeof(sc), hipMemcpyDeviceToHost, c->stream));
+  const int B = c->batch;
+  const int mc = s->last_max_corners > 0 ? s->last_max_corners : ST_OUT_CAP;
+  std::vector<uint32_t> sc((size_t)4 * B);
+  VO_HIP(c, hipMemcpy2DAsync(sc.data(), 16, c->d_slab + c->off_st_scalars, c->slab_seq, 16, B, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipMemcpy2DAsync(out_pts, sizeof(float) * 2 * (size_t)mc, c->d_slab + c->off_st_out, c->slab_seq,
+                             sizeof(float) * 2 * (size_t)mc, B, hipMemcpyDeviceToHost, c->stream));
   VO_HIP(c, hipStreamSynchronize(c->stream));
-  if (sc[2] == 0xFFFFFFFFu) {
-    *n_out = 0;
-    return vo_fail(c, VO_E_CAPACITY, "shi_tomasi: more than 16384 NMS candidates");
-  }
-  *n_out = (int32_t)sc[2];
-  if (*n_out > 0) {
-    VO_HIP(c, hipMemcpy(out_pts, s->d_out, sizeof(float) * 2 * (size_t)(*n_out), hipMemcpyDeviceToHost));
+  for (int b = 0; b < B; b++) {
+    if (sc[4 * b + 2] == 0xFFFFFFFFu) { n_out[b] = 0; return vo_fail(c, VO_E_CAPACITY, "shi_tomasi: more than 16384 NMS candidates"); }
+    n_out[b] = (int32_t)sc[4 * b + 2];
   }
   return VO_OK;
 }
 
+// cur_pts [batch][n_cur][2], mask [batch][h][w] (optional), out_pts [batch][max_corners][2], n_out [batch]
 extern "C" int32_t vo_shi_tomasi(vo_ctx* c, const float* cur_pts, int32_t n_cur, int32_t mask_radius, const uint8_t* mask,
                                  const vo_st_params* prm, float* out_pts, int32_t* n_out) {
   if (!c) return VO_E_INVALID;
@@ -552,9 +575,12 @@ extern "C" int32_t vo_shi_tomasi(vo_ctx* c, const float* cur_pts, int32_t n_cur,
   int32_t r = st_init(c);
   if (r != VO_OK) return r;
   vo_st_ws* s = c->st;
-  if (n_cur > 0) VO_HIP(c, hipMemcpyAsync(s->d_pts, cur_pts, sizeof(float) * 2 * n_cur, hipMemcpyHostToDevice, c->stream));
-  if (mask) VO_HIP(c, hipMemcpyAsync(s->d_user_mask, mask, (size_t)c->width * c->height, hipMemcpyHostToDevice, c->stream));
-  r = st_launch(c, s->d_pts, n_cur, mask_radius, mask ? s->d_user_mask : nullptr, prm);
+  const size_t pts_seq = sizeof(float) * 2 * (size_t)c->max_pts;
+  if (n_cur > 0)
+    VO_HIP(c, hipMemcpy2DAsync(s->d_pts, pts_seq, cur_pts, sizeof(float) * 2 * n_cur, sizeof(float) * 2 * n_cur, c->batch,
+                               hipMemcpyHostToDevice, c->stream));
+  if (mask) VO_HIP(c, hipMemcpyAsync(s->d_user_mask, mask, (size_t)c->width * c->height * c->batch, hipMemcpyHostToDevice, c->stream));
+  r = st_launch(c, s->d_pts, pts_seq, n_cur, mask_radius, mask ? s->d_user_mask : nullptr, prm);
   if (r != VO_OK) return r;
   return st_fetch(c, out_pts, n_out);
 }
@@ -567,7 +593,7 @@ extern "C" int32_t vo_shi_tomasi_resident(vo_ctx* c, int32_t n_cur, int32_t mask
   VO_HIP(c, hipSetDevice(c->device));
   int32_t r = st_init(c);
   if (r != VO_OK) return r;
-  return st_launch(c, c->d_p0, n_cur, mask_radius, nullptr, prm);
+  return st_launch(c, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq, n_cur, mask_radius, nullptr, prm);
 }
 
 extern "C" int32_t vo_shi_tomasi_fetch(vo_ctx* c, float* out_pts, int32_t* n_out) {
@@ -577,18 +603,19 @@ extern "C" int32_t vo_shi_tomasi_fetch(vo_ctx* c, float* out_pts, int32_t* n_out
   return st_fetch(c, out_pts, n_out);
 }
 
+// eig_out [batch][h][w], mask_out [batch][h][w], n_candidates [batch]
 extern "C" int32_t vo_shi_tomasi_read(vo_ctx* c, float* eig_out, uint8_t* mask_out, int32_t* n_candidates) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->st, VO_E_STATE, "no shi_tomasi call yet");
   VO_HIP(c, hipSetDevice(c->device));
   VO_HIP(c, hipStreamSynchronize(c->stream));
-  const size_t np = (size_t)c->width * c->height;
+  const size_t np = (size_t)c->width * c->height * c->batch;
   if (eig_out) VO_HIP(c, hipMemcpy(eig_out, c->st->d_eig, np * sizeof(float), hipMemcpyDeviceToHost));
   if (mask_out) VO_HIP(c, hipMemcpy(mask_out, c->st->d_mask, np, hipMemcpyDeviceToHost));
   if (n_candidates) {
-    uint32_t sc[4];
-    VO_HIP(c, hipMemcpy(sc, c->st->d_scalars, sizeof(sc), hipMemcpyDeviceToHost));
-    *n_candidates = (int32_t)sc[1];
+    std::vector<uint32_t> sc((size_t)4 * c->batch);
+    VO_HIP(c, hipMemcpy2D(sc.data(), 16, c->d_slab + c->off_st_scalars, c->slab_seq, 16, c->batch, hipMemcpyDeviceToHost));
+    for (int b = 0; b < c->batch; b++) n_candidates[b] = (int32_t)sc[4 * b + 1];
   }
   return VO_OK;
 }

@@ -19,8 +19,9 @@ struct step_cfg {
 // enqueue everything of one frame on the ctx stream (also used under stream capture)
 static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame_idx, int frame_idx) {
   int32_t r;
-  if (d_frame_idx) r = vo_build_pyramid(c, c->d_seq, d_frame_idx);
-  else r = vo_build_pyramid(c, c->d_seq + (size_t)frame_idx * c->width * c->height, nullptr);
+  const size_t fr = (size_t)c->width * c->height;
+  if (d_frame_idx) r = vo_build_pyramid(c, c->d_seq, fr * c->seq_n, d_frame_idx);
+  else r = vo_build_pyramid(c, c->d_seq + (size_t)frame_idx * fr, fr * c->seq_n, nullptr);
   if (r != VO_OK) return r;
   r = vo_klt_track_resident(c, s.n_pts, &s.klt);
   if (r != VO_OK) return r;
@@ -36,7 +37,7 @@ static void step_signature(const vo_ctx* c, const step_cfg& s, int sig[8]) {
   sig[0] = s.n_pts; sig[1] = s.do_dlt | (s.do_ba << 1) | (s.do_st << 2); sig[2] = s.mask_radius;
   sig[3] = s.klt.win | (s.klt.max_level << 8) | (s.klt.max_count << 16);
   sig[4] = s.ba.max_iters; sig[5] = s.st.max_corners | (s.st.block_size << 16);
-  sig[6] = (c->d_p0 == reinterpret_cast<const float*>(c->d_slab + c->off_pa)) ? 0 : 1;   // point ping-pong parity
+  sig[6] = c->p_parity;   // point ping-pong parity
   sig[7] = c->dlt_n;
 }
 
@@ -77,7 +78,7 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
   } else {
     // replay: redo the host-side state changes the enqueue functions would have made
     c->cur ^= 1; c->n_pushed++;
-    float* t = c->d_p0; c->d_p0 = c->d_p1; c->d_p1 = t;
+    c->p_parity ^= 1;
   }
   c->frame_ring = (c->frame_ring + 1) & 63;
   c->h_frame_idx[c->frame_ring] = frame_idx;
@@ -86,9 +87,9 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
   return VO_OK;
 }
 
-// Waits for the step and unpacks the pinned result mirrors.  Any pointer may be NULL.
-// p/status/err: the tracked points (n_pts); X4 (4 x dlt_n), depth1, reproj; poses/points/stats of the BA;
-// corners (max_corners x 2) and *n_corners of the re-detection.
+// Waits for the step and unpacks the pinned result mirrors.  Any pointer may be NULL.  All arrays carry the leading
+// batch dimension: p [batch][n_pts][2], status/err [batch][n_pts]; X4 [batch][4][dlt_n], depth1/reproj [batch][dlt_n];
+// poses [batch][W][6], points [batch][N][3], stats [batch]; corners [batch][max_corners][2], n_corners [batch].
 extern "C" int32_t vo_frame_fetch(vo_ctx* c, int32_t n_pts, float* p, uint8_t* status, float* err, float* X4,
                                   double* depth1, double* reproj, double* poses, double* points, vo_ba_stats* stats,
                                   float* corners, int32_t* n_corners) {
@@ -96,24 +97,29 @@ extern "C" int32_t vo_frame_fetch(vo_ctx* c, int32_t n_pts, float* p, uint8_t* s
   VO_CHECK(c, n_pts >= 0 && n_pts <= c->max_pts, VO_E_INVALID, "bad n_pts");
   VO_HIP(c, hipSetDevice(c->device));
   VO_HIP(c, hipStreamSynchronize(c->stream));
-  const uint8_t* h = c->h_slab;
-  const size_t off_p = (c->d_p0 == reinterpret_cast<const float*>(c->d_slab + c->off_pa)) ? c->off_pa : c->off_pb;
-  if (p) memcpy(p, h + off_p, sizeof(float) * 2 * n_pts);
-  if (status) memcpy(status, h + c->off_status, n_pts);
-  if (err) memcpy(err, h + c->off_err, sizeof(float) * n_pts);
-  if (c->dlt_n > 0) {
-    if (X4) memcpy(X4, h + c->off_X4, sizeof(float) * 4 * c->dlt_n);
-    if (depth1) memcpy(depth1, h + c->off_depth, sizeof(double) * c->dlt_n);
-    if (reproj) memcpy(reproj, h + c->off_reproj, sizeof(double) * c->dlt_n);
+  const size_t off_p = vo_off_p(c);
+  const int mc = vo_st_last_max_corners(c) > 0 ? vo_st_last_max_corners(c) : 4096;
+  int32_t rc = VO_OK;
+  for (int b = 0; b < c->batch; b++) {
+    const uint8_t* h = c->h_slab + (size_t)b * c->slab_seq;
+    if (p) memcpy(p + (size_t)b * 2 * n_pts, h + off_p, sizeof(float) * 2 * n_pts);
+    if (status) memcpy(status + (size_t)b * n_pts, h + c->off_status, n_pts);
+    if (err) memcpy(err + (size_t)b * n_pts, h + c->off_err, sizeof(float) * n_pts);
+    if (c->dlt_n > 0) {
+      const size_t n = (size_t)c->dlt_n;
+      if (X4) memcpy(X4 + b * 4 * n, h + c->off_X4, sizeof(float) * 4 * n);
+      if (depth1) memcpy(depth1 + b * n, h + c->off_depth, sizeof(double) * n);
+      if (reproj) memcpy(reproj + b * n, h + c->off_reproj, sizeof(double) * n);
+    }
+    if (n_corners) {
+      const uint32_t* sc = reinterpret_cast<const uint32_t*>(h + c->off_st_scalars);
+      if (sc[2] == 0xFFFFFFFFu) { n_corners[b] = 0; rc = vo_fail(c, VO_E_CAPACITY, "shi_tomasi: more than 16384 NMS candidates"); continue; }
+      n_corners[b] = (int32_t)sc[2];
+      if (corners && n_corners[b] > 0) memcpy(corners + (size_t)b * 2 * mc, h + c->off_st_out, sizeof(float) * 2 * (size_t)n_corners[b]);
+    }
   }
   if ((poses || points || stats) && vo_ba_ready(c)) vo_ba_unpack_pub(c, poses, points, stats);
-  if (n_corners) {
-    const uint32_t* sc = reinterpret_cast<const uint32_t*>(h + c->off_st_scalars);
-    if (sc[2] == 0xFFFFFFFFu) { *n_corners = 0; return vo_fail(c, VO_E_CAPACITY, "shi_tomasi: more than 16384 NMS candidates"); }
-    *n_corners = (int32_t)sc[2];
-    if (corners && *n_corners > 0) memcpy(corners, h + c->off_st_out, sizeof(float) * 2 * (size_t)(*n_corners));
-  }
-  return VO_OK;
+  return rc;
 }
 
 extern "C" int32_t vo_set_graph_mode(vo_ctx* c, int32_t on) {

@@ -54,6 +54,8 @@ SIGNATURES = {
     "vo_abi_version": (C.c_int32, []),
     "vo_device_count": (C.c_int32, [_i32p]),
     "vo_ctx_create": (C.c_int32, [C.c_int32] * 6 + [C.POINTER(_ctx)]),
+    "vo_ctx_create_batched": (C.c_int32, [C.c_int32] * 7 + [C.POINTER(_ctx)]),
+    "vo_pyramid_read_seq": (C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_int32, _u8p, _i16p]),
     "vo_ctx_destroy": (C.c_int32, [_ctx]),
     "vo_last_error": (C.c_char_p, [_ctx]),
     "vo_sync": (C.c_int32, [_ctx]),

@@ -2,6 +2,10 @@
 
 Thin wrapper over the C ABI (include/vo_mi355x.h).  The drop-in classes in
 extractor.py / bundle_adjuster.py are built on top of this.
+
+Batched contexts: `VoContext(..., batch=B)` carries B independent sequences of identical shape in lockstep (one
+launch serves all of them).  With B > 1 every array argument / result gains a leading dimension of length B; with
+B == 1 (default) the arrays are exactly those of the single-sequence API.
 """
 import ctypes as C
 
@@ -12,15 +16,15 @@ from ._lib import BaParams, BaStats, KltParams, StParams, VoError, as_c, ptr
 
 
 class VoContext:
-    def __init__(self, width, height, max_pts=4096, device=0, max_level=3, win=31):
+    def __init__(self, width, height, max_pts=4096, device=0, max_level=3, win=31, batch=1):
         self._L = _lib.load()
         self._h = C.c_void_p()
-        rc = self._L.vo_ctx_create(device, width, height, max_pts, max_level, win, C.byref(self._h))
+        rc = self._L.vo_ctx_create_batched(device, width, height, max_pts, max_level, win, batch, C.byref(self._h))
         if rc != 0:
             msg = self._L.vo_last_error(None)
             raise VoError(rc, msg.decode() if msg else "vo_ctx_create failed")
         self.width, self.height, self.max_pts = width, height, max_pts
-        self.max_level, self.win, self.device = max_level, win, device
+        self.max_level, self.win, self.device, self.batch = max_level, win, device, batch
         self._st_max_corners = 1000
         self._klt_levels = max_level + 1
 
@@ -50,19 +54,37 @@ class VoContext:
     def sync(self):
         self._ck(self._L.vo_sync(self._h))
 
+    # -- batch helpers --------------------------------------------------------------------------
+    def _in(self, a, dtype, per_seq_shape):
+        """-> C-contiguous [batch, *per_seq_shape] view of the caller's array (batch dim optional when batch == 1)"""
+        a = np.asarray(a, dtype=dtype)
+        want = (self.batch,) + tuple(per_seq_shape)
+        if a.shape != want:
+            if self.batch == 1:
+                a = a.reshape(want)
+            else:
+                raise ValueError("expected array of shape %r, got %r" % (want, a.shape))
+        return np.ascontiguousarray(a)
+
+    def _out(self, a):
+        return a[0] if self.batch == 1 else a
+
     # -- frames ---------------------------------------------------------------------------------
     def push_frame(self, img):
         img = np.asarray(img)
-        if img.dtype != np.uint8 or img.ndim != 2 or img.shape != (self.height, self.width):
-            raise ValueError("push_frame: expected uint8 image of shape (%d, %d)" % (self.height, self.width))
-        if img.strides[1] != 1:
-            img = np.ascontiguousarray(img)
-        self._ck(self._L.vo_frame_push(self._h, ptr(img, C.c_uint8), img.strides[0]))
+        if img.dtype != np.uint8:
+            raise ValueError("push_frame: expected uint8")
+        img = self._in(img, np.uint8, (self.height, self.width))
+        self._ck(self._L.vo_frame_push(self._h, ptr(img, C.c_uint8), self.width))
 
     def upload_sequence(self, frames):
-        frames = as_c(frames, np.uint8)
-        assert frames.ndim == 3 and frames.shape[1:] == (self.height, self.width)
-        self._ck(self._L.vo_seq_upload(self._h, ptr(frames, C.c_uint8), frames.shape[0]))
+        """frames: [n_frames, h, w] (batch == 1) or [batch, n_frames, h, w]"""
+        frames = np.asarray(frames, np.uint8)
+        if frames.ndim == 3 and self.batch == 1:
+            frames = frames[None]
+        assert frames.ndim == 4 and frames.shape[0] == self.batch and frames.shape[2:] == (self.height, self.width)
+        frames = np.ascontiguousarray(frames)
+        self._ck(self._L.vo_seq_upload(self._h, ptr(frames, C.c_uint8), frames.shape[1]))
 
     def push_frame_resident(self, idx):
         self._ck(self._L.vo_frame_push_resident(self._h, int(idx)))
@@ -72,12 +94,12 @@ class VoContext:
         self._ck(self._L.vo_pyramid_level_size(self._h, level, C.byref(w), C.byref(h)))
         return w.value, h.value
 
-    def pyramid_read(self, which, level):
-        """-> (img uint8 [h,w], deriv int16 [h,w,2]) of the prev (which=0) / cur (which=1) frame."""
+    def pyramid_read(self, which, level, seq=0):
+        """-> (img uint8 [h,w], deriv int16 [h,w,2]) of the prev (which=0) / cur (which=1) frame of sequence `seq`."""
         w, h = self.level_size(level)
         img = np.empty((h, w), np.uint8)
         der = np.empty((h, w, 2), np.int16)
-        self._ck(self._L.vo_pyramid_read(self._h, which, level, ptr(img, C.c_uint8), ptr(der, C.c_int16)))
+        self._ck(self._L.vo_pyramid_read_seq(self._h, seq, which, level, ptr(img, C.c_uint8), ptr(der, C.c_int16)))
         return img, der
 
     # -- KLT ------------------------------------------------------------------------------------
@@ -89,33 +111,44 @@ class VoContext:
         p.max_count, p.epsilon, p.min_eig_threshold = max_count, epsilon, min_eig_threshold
         return p
 
+    def _npts(self, p):
+        p = np.asarray(p, np.float32)
+        if self.batch == 1:
+            p = p.reshape(1, -1, 2)
+        if p.ndim != 3 or p.shape[0] != self.batch or p.shape[2] != 2:
+            raise ValueError("points must have shape [batch, n, 2]")
+        return np.ascontiguousarray(p), p.shape[1]
+
     def klt_track(self, p0, params=None, return_iters=False):
-        """prev -> cur tracking.  p0 (n,2) float32 -> p1 (n,2) f32, status (n,) u8, err (n,) f32"""
-        p0 = as_c(np.asarray(p0, np.float32).reshape(-1, 2), np.float32)
-        n = p0.shape[0]
+        """prev -> cur tracking.  p0 (n,2) float32 -> p1 (n,2) f32, status (n,) u8, err (n,) f32  [leading batch dim if batch > 1]"""
+        p0, n = self._npts(p0)
+        B = self.batch
         prm = params if params is not None else self.klt_params()
-        p1 = np.zeros((n, 2), np.float32)
-        st = np.zeros(n, np.uint8)
-        err = np.zeros(n, np.float32)
-        it = np.full((n, prm.max_level + 1), -1, np.int32)
+        p1 = np.zeros((B, n, 2), np.float32)
+        st = np.zeros((B, n), np.uint8)
+        err = np.zeros((B, n), np.float32)
+        it = np.full((B, n, prm.max_level + 1), -1, np.int32)
         self._ck(self._L.vo_klt_track(self._h, ptr(p0, C.c_float), n, C.byref(prm), ptr(p1, C.c_float),
                                       ptr(st, C.c_uint8), ptr(err, C.c_float), ptr(it, C.c_int32)))
         if return_iters:
-            return p1, st, err, it
-        return p1, st, err
+            return self._out(p1), self._out(st), self._out(err), self._out(it)
+        return self._out(p1), self._out(st), self._out(err)
 
     def points_upload(self, p):
-        p = as_c(np.asarray(p, np.float32).reshape(-1, 2), np.float32)
-        self._ck(self._L.vo_points_upload(self._h, ptr(p, C.c_float), p.shape[0]))
+        p, n = self._npts(p)
+        self._ck(self._L.vo_points_upload(self._h, ptr(p, C.c_float), n))
 
     def points_download(self, n, return_iters=False):
-        p = np.zeros((n, 2), np.float32)
-        st = np.zeros(n, np.uint8)
-        err = np.zeros(n, np.float32)
-        it = np.full((n, self._klt_levels), -1, np.int32) if return_iters else None
+        B = self.batch
+        p = np.zeros((B, n, 2), np.float32)
+        st = np.zeros((B, n), np.uint8)
+        err = np.zeros((B, n), np.float32)
+        it = np.full((B, n, self._klt_levels), -1, np.int32) if return_iters else None
         self._ck(self._L.vo_points_download(self._h, ptr(p, C.c_float), ptr(st, C.c_uint8), ptr(err, C.c_float),
                                             ptr(it, C.c_int32), n))
-        return (p, st, err, it) if return_iters else (p, st, err)
+        if return_iters:
+            return self._out(p), self._out(st), self._out(err), self._out(it)
+        return self._out(p), self._out(st), self._out(err)
 
     def klt_track_resident(self, n, params=None):
         prm = params if params is not None else self.klt_params()
@@ -129,24 +162,27 @@ class VoContext:
         p.max_corners, p.quality_level, p.min_distance, p.block_size = max_corners, quality_level, min_distance, block_size
         return p
 
+    def _corners(self, out, n_out):
+        res = [out[b, :n_out[b]].copy() for b in range(self.batch)]
+        return res[0] if self.batch == 1 else res
+
     def shi_tomasi(self, cur_pts=None, mask_radius=7, mask=None, params=None):
-        """Re-detection on the CURRENT frame -> corners (m,2) float32 (integer-valued x,y)"""
+        """Re-detection on the CURRENT frame -> corners (m,2) float32 (integer-valued x,y) [list of B arrays if batch > 1]"""
         prm = params if params is not None else self.st_params()
-        n_cur = 0
-        pp = None
-        if cur_pts is not None and len(cur_pts):
-            cur_pts = as_c(np.asarray(cur_pts, np.float32).reshape(-1, 2), np.float32)
-            n_cur, pp = cur_pts.shape[0], ptr(cur_pts, C.c_float)
+        n_cur, pp = 0, None
+        if cur_pts is not None and np.size(cur_pts):
+            cur_pts, n_cur = self._npts(cur_pts)
+            pp = ptr(cur_pts, C.c_float)
         mp = None
         if mask is not None:
-            mask = as_c(mask, np.uint8)
-            assert mask.shape == (self.height, self.width)
+            mask = self._in(mask, np.uint8, (self.height, self.width))
             mp = ptr(mask, C.c_uint8)
-        out = np.zeros((max(prm.max_corners, 1), 2), np.float32)
-        n_out = C.c_int32(0)
+        mc = prm.max_corners if prm.max_corners > 0 else 4096
+        out = np.zeros((self.batch, mc, 2), np.float32)
+        n_out = np.zeros(self.batch, np.int32)
         self._ck(self._L.vo_shi_tomasi(self._h, pp, n_cur, int(mask_radius), mp, C.byref(prm), ptr(out, C.c_float),
-                                       C.byref(n_out)))
-        return out[:n_out.value].copy()
+                                       ptr(n_out, C.c_int32)))
+        return self._corners(out, n_out)
 
     def shi_tomasi_resident(self, n_cur, mask_radius=7, params=None):
         prm = params if params is not None else self.st_params()
@@ -154,59 +190,61 @@ class VoContext:
         self._ck(self._L.vo_shi_tomasi_resident(self._h, n_cur, int(mask_radius), C.byref(prm)))
 
     def shi_tomasi_fetch(self):
-        out = np.zeros((max(self._st_max_corners, 1), 2), np.float32)
-        n_out = C.c_int32(0)
-        self._ck(self._L.vo_shi_tomasi_fetch(self._h, ptr(out, C.c_float), C.byref(n_out)))
-        return out[:n_out.value].copy()
+        mc = self._st_max_corners if self._st_max_corners > 0 else 4096
+        out = np.zeros((self.batch, mc, 2), np.float32)
+        n_out = np.zeros(self.batch, np.int32)
+        self._ck(self._L.vo_shi_tomasi_fetch(self._h, ptr(out, C.c_float), ptr(n_out, C.c_int32)))
+        return self._corners(out, n_out)
 
     def shi_tomasi_read(self):
-        eig = np.empty((self.height, self.width), np.float32)
-        mask = np.empty((self.height, self.width), np.uint8)
-        nc = C.c_int32(0)
-        self._ck(self._L.vo_shi_tomasi_read(self._h, ptr(eig, C.c_float), ptr(mask, C.c_uint8), C.byref(nc)))
-        return eig, mask, nc.value
+        eig = np.empty((self.batch, self.height, self.width), np.float32)
+        mask = np.empty((self.batch, self.height, self.width), np.uint8)
+        nc = np.zeros(self.batch, np.int32)
+        self._ck(self._L.vo_shi_tomasi_read(self._h, ptr(eig, C.c_float), ptr(mask, C.c_uint8), ptr(nc, C.c_int32)))
+        if self.batch == 1:
+            return eig[0], mask[0], int(nc[0])
+        return eig, mask, nc
 
     # -- DLT ------------------------------------------------------------------------------------
+    def _dlt_inputs(self, P0, P1, uv0, uv1, K, H0, H1):
+        P0, P1 = self._in(P0, np.float32, (3, 4)), self._in(P1, np.float32, (3, 4))
+        uv0, n = self._npts(uv0)
+        uv1, n1 = self._npts(uv1)
+        assert n == n1
+        if K is not None:
+            K, H0, H1 = self._in(K, np.float64, (3, 3)), self._in(H0, np.float64, (4, 4)), self._in(H1, np.float64, (4, 4))
+        return P0, P1, uv0, uv1, n, K, H0, H1
+
     def triangulate(self, P0, P1, uv0, uv1, K=None, H0=None, H1=None):
         """cv2.triangulatePoints replacement.  -> X4 (4,n) f32 [, depth1 (n,) f64, reproj (n,) f64]"""
-        P0, P1 = as_c(P0, np.float32), as_c(P1, np.float32)
-        uv0 = as_c(np.asarray(uv0, np.float32).reshape(-1, 2), np.float32)
-        uv1 = as_c(np.asarray(uv1, np.float32).reshape(-1, 2), np.float32)
-        n = uv0.shape[0]
-        assert P0.shape == (3, 4) and P1.shape == (3, 4) and uv1.shape[0] == n
-        X4 = np.zeros((4, n), np.float32)
+        P0, P1, uv0, uv1, n, K, H0, H1 = self._dlt_inputs(P0, P1, uv0, uv1, K, H0, H1)
+        B, d = self.batch, C.c_double
+        X4 = np.zeros((B, 4, n), np.float32)
         if K is None:
             self._ck(self._L.vo_triangulate_dlt(self._h, ptr(P0, C.c_float), ptr(P1, C.c_float), ptr(uv0, C.c_float),
                                                 ptr(uv1, C.c_float), n, ptr(X4, C.c_float), None, None, None, None, None))
-            return X4
-        K, H0, H1 = as_c(K, np.float64), as_c(H0, np.float64), as_c(H1, np.float64)
-        depth = np.zeros(n, np.float64)
-        reproj = np.zeros(n, np.float64)
+            return self._out(X4)
+        depth, reproj = np.zeros((B, n)), np.zeros((B, n))
         self._ck(self._L.vo_triangulate_dlt(self._h, ptr(P0, C.c_float), ptr(P1, C.c_float), ptr(uv0, C.c_float),
-                                            ptr(uv1, C.c_float), n, ptr(X4, C.c_float), ptr(K, C.c_double),
-                                            ptr(H0, C.c_double), ptr(H1, C.c_double), ptr(depth, C.c_double),
-                                            ptr(reproj, C.c_double)))
-        return X4, depth, reproj
+                                            ptr(uv1, C.c_float), n, ptr(X4, C.c_float), ptr(K, d), ptr(H0, d), ptr(H1, d),
+                                            ptr(depth, d), ptr(reproj, d)))
+        return self._out(X4), self._out(depth), self._out(reproj)
 
     def dlt_upload(self, P0, P1, uv0, uv1, K=None, H0=None, H1=None):
-        P0, P1 = as_c(P0, np.float32), as_c(P1, np.float32)
-        uv0 = as_c(np.asarray(uv0, np.float32).reshape(-1, 2), np.float32)
-        uv1 = as_c(np.asarray(uv1, np.float32).reshape(-1, 2), np.float32)
-        self._dlt_n, self._dlt_stats = uv0.shape[0], K is not None
-        if K is not None:
-            K, H0, H1 = as_c(K, np.float64), as_c(H0, np.float64), as_c(H1, np.float64)
+        P0, P1, uv0, uv1, n, K, H0, H1 = self._dlt_inputs(P0, P1, uv0, uv1, K, H0, H1)
+        self._dlt_n, self._dlt_stats = n, K is not None
         d = C.c_double
         self._ck(self._L.vo_dlt_upload(self._h, ptr(P0, C.c_float), ptr(P1, C.c_float), ptr(uv0, C.c_float),
-                                       ptr(uv1, C.c_float), self._dlt_n, ptr(K, d), ptr(H0, d), ptr(H1, d)))
+                                       ptr(uv1, C.c_float), n, ptr(K, d), ptr(H0, d), ptr(H1, d)))
 
     def dlt_resident(self):
         self._ck(self._L.vo_dlt_resident(self._h))
 
     def dlt_fetch(self):
-        n = self._dlt_n
-        X4, depth, reproj = np.zeros((4, n), np.float32), np.zeros(n), np.zeros(n)
+        n, B = self._dlt_n, self.batch
+        X4, depth, reproj = np.zeros((B, 4, n), np.float32), np.zeros((B, n)), np.zeros((B, n))
         self._ck(self._L.vo_dlt_fetch(self._h, ptr(X4, C.c_float), ptr(depth, C.c_double), ptr(reproj, C.c_double)))
-        return (X4, depth, reproj) if self._dlt_stats else X4
+        return (self._out(X4), self._out(depth), self._out(reproj)) if self._dlt_stats else self._out(X4)
 
     # -- fused frame step ----------------------------------------------------------------------
     def set_graph_mode(self, on=True):
@@ -227,30 +265,32 @@ class VoContext:
     def frame_fetch(self):
         """wait for the enqueued frame and return its results as a dict of numpy arrays"""
         n_pts, do_dlt, do_ba, do_st = self._step_cfg
-        out = {}
-        p, stt, err = np.zeros((n_pts, 2), np.float32), np.zeros(n_pts, np.uint8), np.zeros(n_pts, np.float32)
+        B = self.batch
+        p, stt, err = np.zeros((B, n_pts, 2), np.float32), np.zeros((B, n_pts), np.uint8), np.zeros((B, n_pts), np.float32)
         X4 = depth = reproj = poses = points = corners = None
-        bs = BaStats()
-        nc = C.c_int32(0)
+        bs = (BaStats * B)()
+        nc = np.zeros(B, np.int32)
         if do_dlt:
             n = self._dlt_n
-            X4, depth, reproj = np.zeros((4, n), np.float32), np.zeros(n), np.zeros(n)
+            X4, depth, reproj = np.zeros((B, 4, n), np.float32), np.zeros((B, n)), np.zeros((B, n))
         if do_ba:
             W, N = self._ba_shape
-            poses, points = np.zeros((W, 6)), np.zeros((N, 3))
+            poses, points = np.zeros((B, W, 6)), np.zeros((B, N, 3))
+        mc = self._st_max_corners if self._st_max_corners > 0 else 4096
         if do_st:
-            corners = np.zeros((max(self._st_max_corners, 1), 2), np.float32)
+            corners = np.zeros((B, mc, 2), np.float32)
         d = C.c_double
         self._ck(self._L.vo_frame_fetch(self._h, n_pts, ptr(p, C.c_float), ptr(stt, C.c_uint8), ptr(err, C.c_float),
                                         ptr(X4, C.c_float), ptr(depth, d), ptr(reproj, d), ptr(poses, d), ptr(points, d),
-                                        C.byref(bs), ptr(corners, C.c_float), C.byref(nc) if do_st else None))
-        out.update(points2d=p, status=stt, err=err)
+                                        bs, ptr(corners, C.c_float), ptr(nc, C.c_int32) if do_st else None))
+        out = dict(points2d=self._out(p), status=self._out(stt), err=self._out(err))
         if do_dlt:
-            out.update(X4=X4, depth1=depth, reproj=reproj)
+            out.update(X4=self._out(X4), depth1=self._out(depth), reproj=self._out(reproj))
         if do_ba:
-            out.update(poses=poses, landmarks=points, ba_stats=self._stats(bs))
+            stats = [self._stats(bs[b]) for b in range(B)]
+            out.update(poses=self._out(poses), landmarks=self._out(points), ba_stats=stats[0] if B == 1 else stats)
         if do_st:
-            out["corners"] = corners[:nc.value].copy()
+            out["corners"] = self._corners(corners, nc)
         return out
 
     # -- in-stream timing -----------------------------------------------------------------------
@@ -285,26 +325,34 @@ class VoContext:
         return dict(cost0=s.cost0, cost=s.cost, lam=s.lam, iters=s.iters, accepted=s.accepted, status=s.status,
                     n_obs=s.n_obs)
 
+    def _ba_inputs(self, K, poses, points, obs):
+        obs = np.asarray(obs, np.float64)
+        if self.batch == 1 and obs.ndim == 3:
+            obs = obs[None]
+        assert obs.ndim == 4 and obs.shape[0] == self.batch and obs.shape[3] == 2
+        W, N = obs.shape[1:3]
+        return (self._in(K, np.float64, (3, 3)), self._in(poses, np.float64, (W, 6)), self._in(points, np.float64, (N, 3)),
+                np.ascontiguousarray(obs), W, N)
+
     def ba_adjust(self, K, poses, points, obs, params=None):
         """poses (W,6) [rvec,tvec; slot 0 newest], points (N,3), obs (W,N,2) NaN = unobserved.
-        -> poses (W,6), points (N,3), stats dict"""
-        K, poses, points, obs = as_c(K, np.float64), as_c(poses, np.float64), as_c(points, np.float64), as_c(obs, np.float64)
-        W, N = obs.shape[:2]
-        assert poses.shape == (W, 6) and points.shape == (N, 3) and obs.shape == (W, N, 2) and K.shape == (3, 3)
+        -> poses (W,6), points (N,3), stats dict   [leading batch dim / list of dicts if batch > 1]"""
+        K, poses, points, obs, W, N = self._ba_inputs(K, poses, points, obs)
+        B = self.batch
         prm = params if params is not None else self.ba_params()
-        po, pt, st = np.zeros_like(poses), np.zeros_like(points), BaStats()
-        self._ck(self._L.vo_ba_adjust(self._h, ptr(K, C.c_double), ptr(poses, C.c_double), ptr(points, C.c_double),
-                                      ptr(obs, C.c_double), W, N, C.byref(prm), ptr(po, C.c_double),
-                                      ptr(pt, C.c_double), C.byref(st)))
-        return po, pt, self._stats(st)
+        po, pt, st = np.zeros((B, W, 6)), np.zeros((B, N, 3)), (BaStats * B)()
+        d = C.c_double
+        self._ck(self._L.vo_ba_adjust(self._h, ptr(K, d), ptr(poses, d), ptr(points, d), ptr(obs, d), W, N, C.byref(prm),
+                                      ptr(po, d), ptr(pt, d), st))
+        self._ba_shape = (W, N)
+        stats = [self._stats(st[b]) for b in range(B)]
+        return self._out(po), self._out(pt), stats[0] if B == 1 else stats
 
     def ba_upload(self, K, poses, points, obs):
-        K, poses, points, obs = as_c(K, np.float64), as_c(poses, np.float64), as_c(points, np.float64), as_c(obs, np.float64)
-        W, N = obs.shape[:2]
-        assert poses.shape == (W, 6) and points.shape == (N, 3) and obs.shape == (W, N, 2) and K.shape == (3, 3)
+        K, poses, points, obs, W, N = self._ba_inputs(K, poses, points, obs)
         self._ba_shape = (W, N)
-        self._ck(self._L.vo_ba_upload(self._h, ptr(K, C.c_double), ptr(poses, C.c_double), ptr(points, C.c_double),
-                                      ptr(obs, C.c_double), W, N))
+        d = C.c_double
+        self._ck(self._L.vo_ba_upload(self._h, ptr(K, d), ptr(poses, d), ptr(points, d), ptr(obs, d), W, N))
 
     def ba_solve_resident(self, params=None):
         prm = params if params is not None else self.ba_params()
@@ -312,12 +360,14 @@ class VoContext:
 
     def ba_fetch(self):
         W, N = self._ba_shape
-        po, pt, st = np.zeros((W, 6)), np.zeros((N, 3)), BaStats()
-        self._ck(self._L.vo_ba_fetch(self._h, ptr(po, C.c_double), ptr(pt, C.c_double), C.byref(st)))
-        return po, pt, self._stats(st)
+        B = self.batch
+        po, pt, st = np.zeros((B, W, 6)), np.zeros((B, N, 3)), (BaStats * B)()
+        self._ck(self._L.vo_ba_fetch(self._h, ptr(po, C.c_double), ptr(pt, C.c_double), st))
+        stats = [self._stats(st[b]) for b in range(B)]
+        return self._out(po), self._out(pt), stats[0] if B == 1 else stats
 
     def ba_probe(self, lam=1e-4, huber_delta=1.0):
-        """Parity probe at the uploaded x0: residuals, normal equations, reduced system, one LM step."""
+        """Parity probe of problem 0 at the uploaded x0: residuals, normal equations, reduced system, one LM step."""
         W, N = self._ba_shape
         res = np.zeros(W * N)
         n_obs = C.c_int32(0)
