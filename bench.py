@@ -35,11 +35,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--seqs", type=int, default=32, help="independent sequences per GPU (one ctx + stream each)")
+    ap.add_argument("--seqs", type=int, default=32, help="independent sequences per GPU")
+    ap.add_argument("--ctxs", type=int, default=2, help="batched contexts (HIP streams) the sequences are split over")
     ap.add_argument("--ba-iters", type=int, default=10, help="LM iteration budget per adjust")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames per sequence (played ping-pong)")
     ap.add_argument("--graph", action="store_true", help="replay each frame from a captured hipGraph instead of plain launches")
-    ap.add_argument("--host-threads", type=int, default=16, help="enqueue/fetch the sequences from this many host threads")
+    ap.add_argument("--host-threads", type=int, default=2, help="enqueue/fetch the contexts from this many host threads")
     ap.add_argument("--fixed-ba-budget", action="store_true",
                     help="always enqueue --ba-iters LM iterations (default: last frame's iteration count + 2, capped)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -92,37 +93,41 @@ def pingpong(t, n):
     return k if k < n else period - k
 
 
-class Sequence:
-    """One VO sequence = one ctx (one HIP stream) with everything resident."""
+class Group:
+    """`batch` independent VO sequences carried in lockstep by ONE batched context (one HIP stream): every launch of
+    the hot path serves all of them.  Everything is resident in HBM."""
 
-    def __init__(self, device, frames, seed, ba_iters):
+    def __init__(self, device, frame_sets, seed0, batch, ba_iters):
         from vo_mi355x import VoContext, synthetic as syn
-        self.c = VoContext(W_IMG, H_IMG, max_pts=max(N_PTS, N_NEW), device=device)
+        self.B = batch
+        self.c = VoContext(W_IMG, H_IMG, max_pts=max(N_PTS, N_NEW), device=device, batch=batch)
         c = self.c
-        c.upload_sequence(frames)
-        self.nf = frames.shape[0]
-        c.points_upload(syn.grid_points(N_PTS, W_IMG, H_IMG, seed=seed))
-        # DLT: 1000 new tracks between two window poses of the BA scene
-        s = syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=seed)
-        K = s["K"]
-        H0, H1 = np.eye(4), np.eye(4)
-        H0[:3, :3], H0[:3, 3] = syn.rodrigues(s["poses_gt"][3, :3]), s["poses_gt"][3, 3:]
-        H1[:3, :3], H1[:3, 3] = syn.rodrigues(s["poses_gt"][0, :3]), s["poses_gt"][0, 3:]
-        self.dlt_in = ((K @ H0[:3]).astype(np.float32), (K @ H1[:3]).astype(np.float32),
-                       s["obs"][3, :N_NEW].astype(np.float32), s["obs"][0, :N_NEW].astype(np.float32), K, H0, H1)
-        c.dlt_upload(*self.dlt_in)
-        self.scene = s
-        c.ba_upload(K, s["poses0"], s["points0"], s["obs"])
+        c.upload_sequence(np.stack([frame_sets[b % len(frame_sets)] for b in range(batch)]))
+        self.nf = frame_sets[0].shape[0]
+        c.points_upload(np.stack([syn.grid_points(N_PTS, W_IMG, H_IMG, seed=seed0 + b) for b in range(batch)]))
+        # DLT: 1000 new tracks between two window poses of each BA scene; BA: N = 2000, W = 10 per sequence
+        scenes = [syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=seed0 + b) for b in range(batch)]
+        P0s, P1s, u0, u1, Ks, H0s, H1s = [], [], [], [], [], [], []
+        for s in scenes:
+            K = s["K"]
+            H0, H1 = np.eye(4), np.eye(4)
+            H0[:3, :3], H0[:3, 3] = syn.rodrigues(s["poses_gt"][3, :3]), s["poses_gt"][3, 3:]
+            H1[:3, :3], H1[:3, 3] = syn.rodrigues(s["poses_gt"][0, :3]), s["poses_gt"][0, 3:]
+            P0s.append((K @ H0[:3]).astype(np.float32)); P1s.append((K @ H1[:3]).astype(np.float32))
+            u0.append(s["obs"][3, :N_NEW].astype(np.float32)); u1.append(s["obs"][0, :N_NEW].astype(np.float32))
+            Ks.append(K); H0s.append(H0); H1s.append(H1)
+        c.dlt_upload(np.stack(P0s), np.stack(P1s), np.stack(u0), np.stack(u1), np.stack(Ks), np.stack(H0s), np.stack(H1s))
+        c.ba_upload(np.stack(Ks), np.stack([s["poses0"] for s in scenes]), np.stack([s["points0"] for s in scenes]),
+                    np.stack([s["obs"] for s in scenes]))
         self.ba_prm = c.ba_params(max_iters=ba_iters, ftol=1e-3, xtol=1e-3)
         self.ba_iters_cap, self.adaptive = ba_iters, True
         self.klt_prm = c.klt_params()
         self.st_prm = c.st_params()
-        self.t = 0
         c.push_frame_resident(0)
         self.t = 1
 
     def enqueue(self):
-        # one C call: pyramid + KLT + DLT + BA + Shi-Tomasi + result copies (replayed from a hipGraph)
+        # one C call: pyramid + KLT + DLT + BA + Shi-Tomasi + result copies for the whole batch
         self.c.frame_step_resident(pingpong(self.t, self.nf), N_PTS, True, True, True, 7, self.klt_prm, self.st_prm,
                                    self.ba_prm)
         self.t += 1
@@ -131,9 +136,15 @@ class Sequence:
         self.last = self.c.frame_fetch()
         if self.adaptive:
             # the LM stops by its own ftol/xtol tests; the budget only bounds how many (early-exiting) launches are
-            # enqueued blindly.  Next frame: what this frame needed + 2, never more than --ba-iters.
-            self.ba_prm.max_iters = max(3, min(self.ba_iters_cap, self.last["ba_stats"]["iters"] + 2))
+            # enqueued blindly.  Next frame: what this frame needed (max over the batch) + 2, never more than --ba-iters.
+            st = self.last["ba_stats"]
+            its = max(x["iters"] for x in st) if isinstance(st, list) else st["iters"]
+            self.ba_prm.max_iters = max(3, min(self.ba_iters_cap, its + 2))
         return self.last
+
+    def ba_stats0(self):
+        st = self.last["ba_stats"]
+        return st[0] if isinstance(st, list) else st
 
 
 def cpu_baseline(frames, n_frames, ba_iters):
@@ -168,15 +179,18 @@ def main():
     dist = Dist()
     from vo_mi355x import synthetic as syn
     t_gen = time.perf_counter()
-    frames, _ = syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + dist.rank)
-    seqs = [Sequence(dist.local_rank, frames, seed=100 * dist.rank + i, ba_iters=a.ba_iters) for i in range(a.seqs)]
+    a.ctxs = max(1, min(a.ctxs, a.seqs))
+    per = [a.seqs // a.ctxs + (1 if i < a.seqs % a.ctxs else 0) for i in range(a.ctxs)]
+    frame_sets = [syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + 16 * dist.rank + k)[0] for k in range(min(4, a.seqs))]
+    seqs = [Group(dist.local_rank, frame_sets, seed0=1000 * dist.rank + 100 * i, batch=per[i], ba_iters=a.ba_iters)
+            for i in range(a.ctxs)]
     t_setup = time.perf_counter() - t_gen
     for s in seqs:
         s.c.set_graph_mode(bool(a.graph))
         s.adaptive = not a.fixed_ba_budget
 
     pool = None
-    a.host_threads = min(a.host_threads, a.seqs)
+    a.host_threads = min(a.host_threads, a.ctxs)
     if a.host_threads > 1:
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(a.host_threads)
@@ -235,10 +249,11 @@ def main():
             stage[name] = round(ms / max(n, 1), 4)
         s0.c.profile_enable(())
         pts, st_, err_, it = s0.c.points_download(N_PTS, return_iters=True)
-        ba_stats = s0.last["ba_stats"]
+        ba_stats = s0.ba_stats0()
+        it = it.reshape(-1, it.shape[-1])
         it_mean = [float(np.maximum(it[:, l], 0).mean()) for l in range(it.shape[1])]
         # ALGORITHMIC bytes of one KLT launch: N * sum_l (5120 + 1024 * it_l)
-        klt_bytes = N_PTS * sum(5120.0 + 1024.0 * x for x in it_mean)
+        klt_bytes = N_PTS * s0.B * sum(5120.0 + 1024.0 * x for x in it_mean)     # one launch tracks the whole batch
         klt_avg_s = (klt_ms / max(klt_n, 1)) * 1e-3
         achieved = klt_bytes / klt_avg_s / 1e9 if klt_avg_s > 0 else 0.0
         traffic = None
@@ -268,9 +283,10 @@ def main():
                           "ba_lm_iteration_budget": a.ba_iters, "ba_lm_iterations_run": ba_stats["iters"],
                           "ba_final_cost": round(ba_stats["cost"], 4), "ba_initial_cost": round(ba_stats["cost0"], 2),
                           "launch": "hipGraph replay" if a.graph else "plain", "ba_budget": "fixed" if a.fixed_ba_budget else "adaptive (last + 2)", "host_threads": max(a.host_threads, 1),
-                          "sequences_per_gpu": a.seqs, "frames_per_step": a.seqs * dist.world,
-                          "parallelism": "independent sequences, %d per GPU x %d GPU(s), no collective" % (a.seqs, dist.world)},
-               "stage_ms_single_sequence": stage, "roofline": roof, "cpu_baseline": cpu,
+                          "sequences_per_gpu": a.seqs, "batched_contexts_per_gpu": a.ctxs, "frames_per_step": a.seqs * dist.world,
+                          "parallelism": "independent sequences, %d per GPU in %d batched context(s) x %d GPU(s), no collective"
+                                         % (a.seqs, a.ctxs, dist.world)},
+               "stage_ms_per_batched_launch_group": stage, "roofline": roof, "cpu_baseline": cpu,
                "setup_s": round(t_setup, 2)}
     dist.barrier()
     for s in seqs:
