@@ -8,7 +8,8 @@ metric string names): per frame and per sequence
     Huber, LM with ftol = xtol = 1e-3, at most --ba-iters iterations) -> Shi-Tomasi re-detection (<= 1000 corners,
     2000 exclusion discs).
 One "step" = one such frame for each of the --seqs independent sequences a GPU carries (sequences are the unit
-that shards: frames of ONE sequence are sequential).  All inputs (frames, keypoints, BA problem) are resident in HBM
+that shards: frames of ONE sequence are sequential).  The sequences are carried by --ctxs BATCHED contexts: a context
+advances its sequences in lockstep, every kernel launch serves the whole batch (one sequence alone cannot fill 256 CUs).  All inputs (frames, keypoints, BA problem) are resident in HBM
 before the timed region; per step only the results come back (points, corners, landmarks, poses).
 Multi-GPU: one process per GPU (torch.distributed launch contract), independent sequences per rank, no data-path
 collective -> "scaling": "weak".  torch.distributed (gloo) is used ONLY for the barrier / max-over-ranks timing.
@@ -35,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--seqs", type=int, default=32, help="independent sequences per GPU")
+    ap.add_argument("--seqs", type=int, default=64, help="independent sequences per GPU")
     ap.add_argument("--ctxs", type=int, default=2, help="batched contexts (HIP streams) the sequences are split over")
     ap.add_argument("--ba-iters", type=int, default=10, help="LM iteration budget per adjust")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames per sequence (played ping-pong)")
@@ -44,7 +45,7 @@ def parse():
     ap.add_argument("--fixed-ba-budget", action="store_true",
                     help="always enqueue --ba-iters LM iterations (default: last frame's iteration count + 2, capped)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=40)
     return ap.parse_args()
 
 
