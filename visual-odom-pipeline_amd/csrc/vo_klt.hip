@@ -16,6 +16,8 @@
 //   The template (I, Ix, Iy at 16 pixels per lane) lives in 48 VGPRs across all iterations.
 #include "vo_internal.h"
 
+#include <stdlib.h>
+
 #define W_BITS 14
 
 struct klt_level_args {
@@ -108,7 +110,9 @@ __device__ __forceinline__ int deriv1(uint32_t top, uint32_t bot, uint32_t wt, u
   return dot2(bot, wb, dot2(top, wt, 1 << (W_BITS - 1))) >> W_BITS;
 }
 
-__global__ void __launch_bounds__(64) k_klt_track(klt_args A, const float* __restrict__ p0, float* __restrict__ p1,
+// WAVES = minimum waves per SIMD the register allocation must allow (4: 119 VGPRs, 5: 91, 6: 80 + 32 B scratch)
+template <int WAVES>
+__global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float* __restrict__ p0, float* __restrict__ p1,
                                                   uint8_t* __restrict__ status, float* __restrict__ err,
                                                   int32_t* __restrict__ iters, unsigned long long* __restrict__ dbg) {
   const int pt = blockIdx.x;
@@ -319,9 +323,12 @@ static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, size_t off
   VO_HIP(c, hipMemsetAsync(c->d_iters, 0xff, sizeof(int32_t) * A.iters_seq * c->batch, c->stream));
   {
     vo_prof_scope prof(c, VO_PROF_KLT);   // brackets exactly this launch (bench.py roofline figure)
-    hipLaunchKernelGGL(k_klt_track, dim3(n, c->batch), dim3(64), 0, c->stream, A, vo_slab<const float>(c, off_in),
-                       vo_slab<float>(c, off_out), vo_slab<uint8_t>(c, c->off_status), vo_slab<float>(c, c->off_err),
-                       c->d_iters, c->d_dbg);
+    static const int waves = getenv("VO_KLT_WAVES") ? atoi(getenv("VO_KLT_WAVES")) : 5;
+#define VO_KLT_LAUNCH(WV) hipLaunchKernelGGL(k_klt_track<WV>, dim3(n, c->batch), dim3(64), 0, c->stream, A,                \
+                       vo_slab<const float>(c, off_in), vo_slab<float>(c, off_out), vo_slab<uint8_t>(c, c->off_status),     \
+                       vo_slab<float>(c, c->off_err), c->d_iters, c->d_dbg)
+    if (waves <= 4) VO_KLT_LAUNCH(4); else if (waves == 5) VO_KLT_LAUNCH(5); else VO_KLT_LAUNCH(6);
+#undef VO_KLT_LAUNCH
   }
   VO_HIP(c, hipGetLastError());
   return VO_OK;
