@@ -35,7 +35,7 @@ def test_ba_5000_landmarks_window20_large_workgroups():
     s = syn.make_ba_scene(n_pts=5000, n_slots=20, K=K, seed=1)
     with VoContext(64, 64, max_pts=64) as c:
         po, pt, st = c.ba_adjust(K, s["poses0"], s["points0"], s["obs"], c.ba_params(max_iters=12))
-    assert st["n_obs"] == 100000 and st["cost"] < 0.05 * st["cost0"]
+    assert st["n_obs"] == int((~np.isnan(s["obs"][..., 0])).sum()) > 95000 and st["cost"] < 0.05 * st["cost0"]
     assert abs(bo.cost(K, po, pt, s["obs"]) - st["cost"]) <= 1e-9 * st["cost"]
 
 

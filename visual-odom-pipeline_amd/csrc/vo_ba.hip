@@ -636,6 +636,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
     for (int a = tid; a < n; a += BA_SOLVE_THREADS) probe_S[(size_t)n * n + a] = A[(size_t)a * PT + n];
   }
   if (hpp_out) for (int q = tid; q < W * BA_POSE_VALS; q += BA_SOLVE_THREADS) hpp_out[q] = s_hpp[q];
+  if (probe_S) __syncthreads();   // the factorisation below overwrites A in place
   VO_STAMP(dbgs, 2);   // system assembled
   // ---- 6x6-blocked right-looking Cholesky of the augmented matrix (row n carries rhs -> y) ----
   for (int kb = 0; kb < W; kb++) {
