@@ -66,10 +66,11 @@ struct ba_ptrs {
   double* x[2];
   double* aux; double* posepart; double* gmax; double* tiles; double* dp; double* evalpart;
   double* tilesum; double* posesum;   // k_ba_reduce outputs: n_tiles*256, W*28 + 1 (last = max |g_l|)
+  double* cams;                       // [2][W][21]: R, t, Jr of the poses in x[0] / x[1] (written by k_ba_solve)
   ba_state* state; ba_info* info;
   unsigned long long* dbg;
   // per-problem strides (elements) of the batched buffers
-  size_t s_obs, s_x, s_aux, s_posepart, s_gmax, s_tiles, s_dp, s_evalpart, s_tilesum, s_posesum;
+  size_t s_obs, s_x, s_aux, s_posepart, s_gmax, s_tiles, s_dp, s_evalpart, s_tilesum, s_posesum, s_cams;
   int W, N, LPP, PPB, nblk, RP, RT, n_tiles, pitch;
 };
 
@@ -78,7 +79,7 @@ __device__ __forceinline__ ba_ptrs ba_select(ba_ptrs P, int b) {
   const size_t sb = (size_t)b;
   P.K += sb * 9; P.obs += sb * P.s_obs; P.x0 += sb * P.s_x; P.x[0] += sb * P.s_x; P.x[1] += sb * P.s_x;
   P.aux += sb * P.s_aux; P.posepart += sb * P.s_posepart; P.gmax += sb * P.s_gmax; P.tiles += sb * P.s_tiles;
-  P.dp += sb * P.s_dp; P.evalpart += sb * P.s_evalpart; P.tilesum += sb * P.s_tilesum; P.posesum += sb * P.s_posesum;
+  P.dp += sb * P.s_dp; P.evalpart += sb * P.s_evalpart; P.tilesum += sb * P.s_tilesum; P.posesum += sb * P.s_posesum; P.cams += sb * P.s_cams;
   P.state += 2 * sb; P.info += sb;
   if (b != 0) P.dbg = nullptr;
   return P;
@@ -100,6 +101,7 @@ struct vo_ba_ws {
   double* d_evalpart = nullptr; // nblk * 4
   double* d_tilesum = nullptr;  // n_tiles * 256
   double* d_posesum = nullptr;  // W * 28 + 1
+  double* d_cams = nullptr;     // 2 * W * 21
   double* d_S = nullptr;        // probe: (6W)^2 + 6W
   double* d_Hpp = nullptr;      // W*28 reduced pose values (probe)
   double* d_res = nullptr;      // probe residual W*N
@@ -360,10 +362,16 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   // iteration 0 reads the uploaded x0 and seeds x[0] with it (each workgroup its own landmarks)
   const double* poses = (it == 0) ? P.x0 : P.x[st.cur];
   const double* pts = poses + 6 * W;
-  stage_cameras(poses, W, s_cam, tid, TPB);
+  if (it == 0) {
+    stage_cameras(poses, W, s_cam, tid, TPB);           // nobody has prepared the cameras of x0 yet
+  } else {
+    const double* cg = P.cams + (size_t)st.cur * W * BA_CAM;   // prepared by k_ba_solve of the previous iteration
+    for (int i = tid; i < W * BA_CAM; i += TPB) s_cam[i] = cg[i];
+  }
   if (tid < 9) s_K[tid] = P.K[tid];
   if (it == 0 && blockIdx.x == 0 && tid < 6 * W) P.x[0][tid] = poses[tid];
   __syncthreads();
+  if (it == 0 && blockIdx.x == 0) for (int i = tid; i < W * BA_CAM; i += TPB) P.cams[i] = s_cam[i];   // cams[0] <-> x[0]
 
   const int pl = tid / LPP, slot = tid - pl * LPP;       // landmark (local), window slot
   const int j = blockIdx.x * P.PPB + pl;
@@ -760,6 +768,18 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
   // ---- publish ----
   const int fail = s_fail;
   for (int a = tid; a < n; a += BA_SOLVE_THREADS) P.dp[a] = fail ? 0.0 : s_dp[a];
+  // cameras of the trial poses for k_ba_update / the next k_ba_build: cams[cur ^ 1] <-> x[cur ^ 1]
+  if (tid >= 128 && tid < 128 + W) {
+    const int i = tid - 128;
+    const double* pc = P.x[st.cur] + 6 * i;
+    double pt6[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) pt6[a] = pc[a] + (fail ? 0.0 : s_dp[6 * i + a]);
+    double* cg = P.cams + ((size_t)(st.cur ^ 1) * W + i) * BA_CAM;
+    d_rodrigues(pt6, cg);
+    cg[9] = pt6[3]; cg[10] = pt6[4]; cg[11] = pt6[5];
+    d_right_jacobian(pt6, cg + 12);
+  }
   if (tid < 128) {
     // wave-parallel step statistics of the camera block (lanes = parameters)
     const double* poses = P.x[st.cur];
@@ -819,9 +839,11 @@ __global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs Pall, ba_params_dev p
     if (blockIdx.x == 0) tposes[a] = poses[a] + d;
   }
   if (tid < 9) s_K[tid] = P.K[tid];
-  stage_cameras(poses, W, s_cam, tid, TPB);
-  __syncthreads();
-  stage_cameras(s_pose, W, s_camt, tid, TPB);
+  {
+    const double* cc = P.cams + (size_t)st.cur * W * BA_CAM;          // current poses (k_ba_build it == 0 / k_ba_solve)
+    const double* ct = P.cams + (size_t)(st.cur ^ 1) * W * BA_CAM;    // trial poses (k_ba_solve of this iteration)
+    for (int i = tid; i < W * BA_CAM; i += TPB) { s_cam[i] = cc[i]; s_camt[i] = ct[i]; }
+  }
   __syncthreads();
   const int pl = tid / LPP, slot = tid - pl * LPP;
   const int j = blockIdx.x * P.PPB + pl;
@@ -934,7 +956,7 @@ void vo_ba_destroy(vo_ctx* c) {
   if (!c->ba) return;
   vo_ba_ws* b = c->ba;
   void* bufs[] = {b->d_K, b->d_obs, b->d_x0, b->d_x[0], b->d_x[1], b->d_aux, b->d_posepart, b->d_gmax,
-                  b->d_tiles, b->d_dp, b->d_evalpart, b->d_tilesum, b->d_posesum, b->d_S, b->d_Hpp, b->d_res, b->d_dl, b->d_pub, b->d_state, b->d_info};
+                  b->d_tiles, b->d_dp, b->d_evalpart, b->d_tilesum, b->d_posesum, b->d_cams, b->d_S, b->d_Hpp, b->d_res, b->d_dl, b->d_pub, b->d_state, b->d_info};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (b->h_state) (void)hipHostFree(b->h_state);
   if (b->h_pub) (void)hipHostFree(b->h_pub);
@@ -992,6 +1014,7 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     VO_HIP(c, hipMalloc((void**)&b->d_evalpart, sizeof(double) * b->nblk * BA_EVAL_VALS * B));
     VO_HIP(c, hipMalloc((void**)&b->d_tilesum, sizeof(double) * (size_t)b->n_tiles * 256 * B));
     VO_HIP(c, hipMalloc((void**)&b->d_posesum, sizeof(double) * ((size_t)W * BA_POSE_VALS + 1) * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_cams, sizeof(double) * 2 * W * BA_CAM * B));
     VO_HIP(c, hipMalloc((void**)&b->d_S, sizeof(double) * ((size_t)36 * W * W + 6 * W)));          // probes: problem 0 only
     VO_HIP(c, hipMalloc((void**)&b->d_Hpp, sizeof(double) * (size_t)W * BA_POSE_VALS));
     VO_HIP(c, hipMalloc((void**)&b->d_res, sizeof(double) * (size_t)W * N * B));
@@ -1017,7 +1040,7 @@ static ba_ptrs ba_make_ptrs(vo_ba_ws* b) {
   ba_ptrs P;
   P.K = b->d_K; P.obs = b->d_obs; P.x0 = b->d_x0; P.x[0] = b->d_x[0]; P.x[1] = b->d_x[1]; P.aux = b->d_aux;
   P.posepart = b->d_posepart; P.gmax = b->d_gmax; P.tiles = b->d_tiles; P.dp = b->d_dp; P.evalpart = b->d_evalpart;
-  P.tilesum = b->d_tilesum; P.posesum = b->d_posesum;
+  P.tilesum = b->d_tilesum; P.posesum = b->d_posesum; P.cams = b->d_cams;
   P.state = b->d_state; P.info = b->d_info; P.dbg = nullptr;
   P.W = b->W; P.N = b->N; P.LPP = b->LPP; P.PPB = b->PPB; P.nblk = b->nblk; P.RP = b->RP; P.RT = b->RT;
   P.n_tiles = b->n_tiles; P.pitch = b->pitch;
@@ -1026,6 +1049,7 @@ static ba_ptrs ba_make_ptrs(vo_ba_ws* b) {
   P.s_obs = 2 * W * N; P.s_x = 6 * W + 3 * N; P.s_aux = N * BA_AUX; P.s_posepart = (size_t)b->nblk * W * BA_POSE_VALS;
   P.s_gmax = (size_t)b->nblk; P.s_tiles = (size_t)b->nblk * b->n_tiles * 256; P.s_dp = 6 * W;
   P.s_evalpart = (size_t)b->nblk * BA_EVAL_VALS; P.s_tilesum = (size_t)b->n_tiles * 256; P.s_posesum = W * BA_POSE_VALS + 1;
+  P.s_cams = 2 * W * BA_CAM;
   return P;
 }
 static ba_ptrs ba_make_ptrs_dbg(vo_ctx* c) { ba_ptrs P = ba_make_ptrs(c->ba); P.dbg = c->d_dbg; return P; }
