@@ -59,11 +59,14 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-// exact wave-wide sum of arbitrary int32 per lane as int64 (split into 16-bit halves)
-__device__ __forceinline__ long long wave_sum_i64(int v) {
+// exact wave-wide sum of arbitrary int32 per lane (the total needs up to 36 bits), returned as the float nearest
+// to the exact integer: the two 16-bit-split partial sums are combined in float64 (exact, < 2^53) and rounded ONCE,
+// which is bit-identical to converting the 64-bit integer sum to float (what the CPU oracle does) and far cheaper
+// than the software int64 -> float conversion.
+__device__ __forceinline__ float wave_sum_exact_f32(int v) {
   const int lo = wave_sum_i32(v & 0xFFFF);
   const int hi = wave_sum_i32(v >> 16);
-  return ((long long)hi << 16) + (long long)lo;
+  return (float)((double)hi * 65536.0 + (double)lo);
 }
 
 __device__ __forceinline__ void lk_weights(float a, float b, int& iw00, int& iw01, int& iw10, int& iw11) {
@@ -191,9 +194,9 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
         a12 = dot2(xp, yp, a12);
         a22 = dot2(yp, yp, a22);
       }
-      const long long iA11 = wave_sum_i64(a11), iA12 = wave_sum_i64(a12), iA22 = wave_sum_i64(a22);
+      const float A11 = wave_sum_exact_f32(a11) * FLT_SCALE, A12 = wave_sum_exact_f32(a12) * FLT_SCALE,
+                  A22 = wave_sum_exact_f32(a22) * FLT_SCALE;
       if (level == A.top) VO_STAMP(dbgk, 1);   // first template
-      const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
       float D = A11 * A22 - A12 * A12;
       const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
       if (minEig < A.min_eig || D < 1.1920929e-07f) {
@@ -228,8 +231,8 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
           b1 = dot2(d, tX[s], b1);
           b2 = dot2(d, tY[s], b2);
         }
-        const float fb1 = (float)wave_sum_i64(b1) * FLT_SCALE;
-        const float fb2 = (float)wave_sum_i64(b2) * FLT_SCALE;
+        const float fb1 = wave_sum_exact_f32(b1) * FLT_SCALE;
+        const float fb2 = wave_sum_exact_f32(b2) * FLT_SCALE;
         const float dx = (A12 * fb2 - A22 * fb1) * D;
         const float dy = (A12 * fb1 - A11 * fb2) * D;
         nextx += dx; nexty += dy;
