@@ -63,7 +63,7 @@ struct ba_params_dev {
 
 struct ba_ptrs {
   const double* K; const double* obs; const double* x0;
-  double* x[2];
+  double* xa; double* xb;             // x[0] / x[1] (two named members: a dynamically indexed array would push the struct into scratch)
   double* aux; double* posepart; double* gmax; double* tiles; double* dp; double* evalpart;
   double* tilesum; double* posesum;   // k_ba_reduce outputs: n_tiles*256, W*28 + 1 (last = max |g_l|)
   double* cams;                       // [2][W][21]: R, t, Jr of the poses in x[0] / x[1] (written by k_ba_solve)
@@ -74,10 +74,12 @@ struct ba_ptrs {
   int W, N, LPP, PPB, nblk, RP, RT, n_tiles, pitch;
 };
 
+__device__ __forceinline__ double* ba_x(const ba_ptrs& P, int k) { return k ? P.xb : P.xa; }
+
 // pointers of problem b of the batch
 __device__ __forceinline__ ba_ptrs ba_select(ba_ptrs P, int b) {
   const size_t sb = (size_t)b;
-  P.K += sb * 9; P.obs += sb * P.s_obs; P.x0 += sb * P.s_x; P.x[0] += sb * P.s_x; P.x[1] += sb * P.s_x;
+  P.K += sb * 9; P.obs += sb * P.s_obs; P.x0 += sb * P.s_x; P.xa += sb * P.s_x; P.xb += sb * P.s_x;
   P.aux += sb * P.s_aux; P.posepart += sb * P.s_posepart; P.gmax += sb * P.s_gmax; P.tiles += sb * P.s_tiles;
   P.dp += sb * P.s_dp; P.evalpart += sb * P.s_evalpart; P.tilesum += sb * P.s_tilesum; P.posesum += sb * P.s_posesum; P.cams += sb * P.s_cams;
   P.state += 2 * sb; P.info += sb;
@@ -360,7 +362,7 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   VO_STAMP(dbgb, 0);
   const int W = P.W, N = P.N, LPP = P.LPP;
   // iteration 0 reads the uploaded x0 and seeds x[0] with it (each workgroup its own landmarks)
-  const double* poses = (it == 0) ? P.x0 : P.x[st.cur];
+  const double* poses = (it == 0) ? P.x0 : ba_x(P, st.cur);
   const double* pts = poses + 6 * W;
   if (it == 0) {
     stage_cameras(poses, W, s_cam, tid, TPB);           // nobody has prepared the cameras of x0 yet
@@ -369,7 +371,7 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
     for (int i = tid; i < W * BA_CAM; i += TPB) s_cam[i] = cg[i];
   }
   if (tid < 9) s_K[tid] = P.K[tid];
-  if (it == 0 && blockIdx.x == 0 && tid < 6 * W) P.x[0][tid] = poses[tid];
+  if (it == 0 && blockIdx.x == 0 && tid < 6 * W) P.xa[tid] = poses[tid];
   __syncthreads();
   if (it == 0 && blockIdx.x == 0) for (int i = tid; i < W * BA_CAM; i += TPB) P.cams[i] = s_cam[i];   // cams[0] <-> x[0]
 
@@ -378,7 +380,7 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   ba_obs_lin o;
   bool have = false;
   if (it == 0 && slot == 0 && j < N) {
-    double* dst = P.x[0] + 6 * W + 3 * j;
+    double* dst = P.xa + 6 * W + 3 * j;
     dst[0] = pts[3 * j]; dst[1] = pts[3 * j + 1]; dst[2] = pts[3 * j + 2];
   }
   if (slot < W && j < N) {
@@ -771,7 +773,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
   // cameras of the trial poses for k_ba_update / the next k_ba_build: cams[cur ^ 1] <-> x[cur ^ 1]
   if (tid >= 128 && tid < 128 + W) {
     const int i = tid - 128;
-    const double* pc = P.x[st.cur] + 6 * i;
+    const double* pc = ba_x(P, st.cur) + 6 * i;
     double pt6[6];
 #pragma unroll
     for (int a = 0; a < 6; a++) pt6[a] = pc[a] + (fail ? 0.0 : s_dp[6 * i + a]);
@@ -782,7 +784,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
   }
   if (tid < 128) {
     // wave-parallel step statistics of the camera block (lanes = parameters)
-    const double* poses = P.x[st.cur];
+    const double* poses = ba_x(P, st.cur);
     double pred = 0, step2 = 0, x2 = 0, gabs = 0, cost = 0;
     if (tid < n) {
       const int i = tid / 6, a = tid - 6 * i;
@@ -828,10 +830,10 @@ __global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs Pall, ba_params_dev p
   const ba_state st = P.state[it & 1];
   if (st.done) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, W = P.W, N = P.N, LPP = P.LPP;
-  const double* poses = P.x[st.cur];
-  const double* pts = P.x[st.cur] + 6 * W;
-  double* tposes = P.x[st.cur ^ 1];
-  double* tpts = P.x[st.cur ^ 1] + 6 * W;
+  const double* poses = ba_x(P, st.cur);
+  const double* pts = poses + 6 * W;
+  double* tposes = ba_x(P, st.cur ^ 1);
+  double* tpts = tposes + 6 * W;
   for (int a = tid; a < 6 * W; a += TPB) {
     const double d = P.dp[a];
     s_dp[a] = d;
@@ -920,7 +922,7 @@ __global__ void __launch_bounds__(256) k_ba_finalize(ba_ptrs Pall, ba_params_dev
     *reinterpret_cast<ba_state*>(reinterpret_cast<unsigned char*>(x_out) - 64) = st;   // pub header of this problem
   }
   __syncthreads();
-  const double* x = (n_it == 0) ? P.x0 : P.x[s_st.cur];
+  const double* x = (n_it == 0) ? P.x0 : ba_x(P, s_st.cur);
   const int total = 6 * P.W + 3 * P.N;
   for (int i = threadIdx.x; i < total; i += blockDim.x) x_out[i] = x[i];
 }
@@ -1038,7 +1040,7 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
 
 static ba_ptrs ba_make_ptrs(vo_ba_ws* b) {
   ba_ptrs P;
-  P.K = b->d_K; P.obs = b->d_obs; P.x0 = b->d_x0; P.x[0] = b->d_x[0]; P.x[1] = b->d_x[1]; P.aux = b->d_aux;
+  P.K = b->d_K; P.obs = b->d_obs; P.x0 = b->d_x0; P.xa = b->d_x[0]; P.xb = b->d_x[1]; P.aux = b->d_aux;
   P.posepart = b->d_posepart; P.gmax = b->d_gmax; P.tiles = b->d_tiles; P.dp = b->d_dp; P.evalpart = b->d_evalpart;
   P.tilesum = b->d_tilesum; P.posesum = b->d_posesum; P.cams = b->d_cams;
   P.state = b->d_state; P.info = b->d_info; P.dbg = nullptr;
