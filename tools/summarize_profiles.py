@@ -1,0 +1,78 @@
+"""Condenses the rocprofv3 outputs of tools/profile_round.sh into the small files kept under profiles/.
+
+  gpurun_out/<tag>_kernel_stats.csv      per-kernel calls / total / average / percentage (the --stats summary)
+  gpurun_out/<tag>_pmc_traffic.csv       per-kernel mean FETCH_SIZE / WRITE_SIZE (KB) and HBM bytes per launch
+  gpurun_out/klt_traffic.json            the figure bench.py reports as roofline.traffic
+
+Corrections follow /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KB, and gfx950 reports
+half of the fetched bytes (so fetch is doubled); the two counters come from separate passes.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = "gpurun_out"
+
+
+def find(pattern):
+    hits = sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+    return hits[-1] if hits else None
+
+
+def short(name):
+    name = name.split("(")[0]
+    for pre in ("void ",):
+        if name.startswith(pre):
+            name = name[len(pre):]
+    return name
+
+
+stats = find(f"{tag}_stats/**/*kernel_stats.csv")
+if stats:
+    with open(stats) as f, open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as g:
+        g.write(f.read())
+
+means = {}
+for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+    path = find(f"{tag}_pmc_{sub}/**/*counter_collection.csv")
+    if not path:
+        continue
+    acc = defaultdict(lambda: [0.0, 0])
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != ctr:
+                continue
+            a = acc[short(row["Kernel_Name"])]
+            a[0] += float(row["Counter_Value"])
+            a[1] += 1
+    means[ctr] = {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
+
+if means:
+    kernels = sorted(set().union(*[set(m) for m in means.values()]))
+    with open(os.path.join(out, f"{tag}_pmc_traffic.csv"), "w") as g:
+        g.write("kernel,launches,fetch_size_kb_raw,write_size_kb,hbm_bytes_per_launch\n")
+        for k in kernels:
+            fe, n = means.get("FETCH_SIZE", {}).get(k, (0.0, 0))
+            wr, n2 = means.get("WRITE_SIZE", {}).get(k, (0.0, 0))
+            g.write(f"{k},{max(n, n2)},{fe:.1f},{wr:.1f},{int((2 * fe + wr) * 1024)}\n")
+    klt = [k for k in kernels if "k_klt_track" in k]
+    if klt:
+        k = klt[0]
+        fe = means["FETCH_SIZE"][k][0] if "FETCH_SIZE" in means else 0.0
+        wr = means["WRITE_SIZE"][k][0] if "WRITE_SIZE" in means else 0.0
+        json.dump({
+            "kernel": k,
+            "config": "bench.py default: 64 sequences in 2 batched contexts (one launch tracks 32 sequences x 2000 points)",
+            "fetch_size_kb_per_launch": 2 * fe,
+            "write_size_kb_per_launch": wr,
+            "hbm_bytes_per_launch": int((2 * fe + wr) * 1024),
+            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 4 "
+                    "--warmup 2 --no-cpu-baseline` (tools/profile_round.sh), mean over the k_klt_track launches; "
+                    "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of the fetched bytes); counts "
+                    "L2 fills incl. Infinity-Cache hits (each XCD L2 pulls its own copy of the pyramids it touches)",
+        }, open(os.path.join(out, "klt_traffic.json"), "w"), indent=1)
+print("summaries written for", tag)
