@@ -193,6 +193,31 @@ int32_t vo_ba_probe(vo_ctx* ctx, double lambda, double huber_delta, double* resi
                     double* cost, double* Hpp, double* gp, double* Hll, double* gl, double* S,
                     double* rhs, double* dposes, double* dpoints);
 
+/* ---- landmark-sharded bundle adjustment of ONE problem (BASELINE config 5) -------
+ * The reference has no multi-device path (single Python process, src/pipeline/pipeline.py:155-156 calls adjust once
+ * per frame); this is the exchange step north_star names ("RCCL over xGMI only for the shared-landmark BA
+ * reduction").  The landmarks of one window are dealt round-robin to S = n_ranks x batch shards: shard s = rank *
+ * batch + b owns landmarks j with j % S == s together with ALL their observations; the W poses are replicated.
+ * Every shard eliminates its own landmarks; the shared quantity is the reduced camera system every landmark
+ * contributes to.  Per LM iteration: ONE in-place RCCL all-reduce (sum, f64) of the packed
+ * [Gram tiles of Y^ (E and r) | camera sums H_pp, g_p, cost | per-rank max|g_l| slots] (~59 KB at W = 10, ~155 KB at
+ * W = 20) and one of the 4 step statistics; every rank then solves the 6W x 6W system redundantly and takes the
+ * same accept/reject decision.  The batch dimension of a batched context acts as `batch` shards on one GPU (summed
+ * by a kernel) -- useful on its own for tests and for filling one GPU with a single large problem.
+ *   vo_comm_unique_id: 128-byte RCCL id made by rank 0; distribute it to the other ranks by any means.
+ *   vo_comm_init:      one communicator per context (one process per GPU); n_ranks = 1 is valid.
+ *   vo_ba_set_sharded: on = 1: the `batch` problems of vo_ba_upload / vo_ba_adjust are shards of one problem
+ *                      (same K and poses in every entry, shard-local points / obs, all shards padded to the same
+ *                      N with unobserved landmarks at the origin).
+ *   vo_ba_gather_points: points of every shard of every rank after a solve, [n_ranks][batch][N][3]. */
+#define VO_COMM_ID_BYTES 128
+#define VO_COMM_MAX_RANKS 16
+int32_t vo_comm_unique_id(uint8_t* id_out /* VO_COMM_ID_BYTES */);
+int32_t vo_comm_init(vo_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t* id);
+int32_t vo_comm_destroy(vo_ctx* ctx);
+int32_t vo_ba_set_sharded(vo_ctx* ctx, int32_t on);
+int32_t vo_ba_gather_points(vo_ctx* ctx, double* points_all);
+
 /* ---- fused per-frame step on resident data ---------------------------------------------------
  * One call enqueues the hot path of one frame in the order of Pipeline.step (src/pipeline/pipeline.py:92-167):
  * frame `frame_idx` of the uploaded sequence -> pyramid/Scharr -> KLT of the resident points -> [DLT of the

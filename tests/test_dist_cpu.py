@@ -18,3 +18,39 @@ def test_bench_dist_plumbing_world2():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def _launch(worker, nproc=2):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", worker)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+
+
+def test_sharded_ba_partition_world2():
+    """config 5's exchange pattern (packet all-reduce + 4 statistics per LM iteration, all-gather of the points) over
+    gloo with the product's shard bookkeeping and the numpy oracle's arithmetic: equals the unsharded solve."""
+    r = _launch("shard_worker.py")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def test_shard_bookkeeping_roundtrip():
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "visual-odom-pipeline_amd"))
+    from vo_mi355x import sharding
+    rng = np.random.default_rng(0)
+    for N, S in [(10, 3), (2000, 8), (7, 8), (5000, 16)]:
+        pts = rng.normal(size=(N, 3)); obs = rng.normal(size=(4, N, 2)); poses = rng.normal(size=(4, 6))
+        K = np.eye(3)
+        Ks, po, pt, ob = sharding.shard_problem(K, poses, pts, obs, S)
+        assert pt.shape == (S, sharding.shard_size(N, S), 3) and ob.shape == (S, 4, pt.shape[1], 2)
+        assert np.array_equal(sharding.unshard_points(pt, N), pts)
+        assert int((~np.isnan(ob[..., 0])).sum()) == 4 * N            # padding is unobserved
+        # a rank's slice equals the corresponding rows of the full dealing
+        _, _, pt1, ob1 = sharding.shard_problem(K, poses, pts, obs, S, first=1, count=2) if S > 2 else (0, 0, pt[1:3], ob[1:3])
+        assert np.array_equal(pt1, pt[1:3]) and np.array_equal(np.isnan(ob1), np.isnan(ob[1:3]))

@@ -65,13 +65,16 @@ struct ba_ptrs {
   const double* K; const double* obs; const double* x0;
   double* xa; double* xb;             // x[0] / x[1] (two named members: a dynamically indexed array would push the struct into scratch)
   double* aux; double* posepart; double* gmax; double* tiles; double* dp; double* evalpart;
-  double* tilesum; double* posesum;   // k_ba_reduce outputs: n_tiles*256, W*28 + 1 (last = max |g_l|)
+  double* tilesum; double* posesum;   // k_ba_reduce outputs: n_tiles*256, W*28 + 1 (last = max |g_l|); ONE allocation per problem:
+                                      // [tilesum | posesum | max|g_l| slot per rank] = the all-reduced packet of a sharded solve
+  double* xstat;                      // sharded solve: [4] step statistics summed over all shards (every entry holds the total)
   double* cams;                       // [2][W][21]: R, t, Jr of the poses in x[0] / x[1] (written by k_ba_solve)
   ba_state* state; ba_info* info;
   unsigned long long* dbg;
   // per-problem strides (elements) of the batched buffers
   size_t s_obs, s_x, s_aux, s_posepart, s_gmax, s_tiles, s_dp, s_evalpart, s_tilesum, s_posesum, s_cams;
   int W, N, LPP, PPB, nblk, RP, RT, n_tiles, pitch;
+  int sharded, rank, n_ranks, batch;  // sharded: the batch entries (x the ranks) are landmark shards of one problem
 };
 
 __device__ __forceinline__ double* ba_x(const ba_ptrs& P, int k) { return k ? P.xb : P.xa; }
@@ -82,6 +85,7 @@ __device__ __forceinline__ ba_ptrs ba_select(ba_ptrs P, int b) {
   P.K += sb * 9; P.obs += sb * P.s_obs; P.x0 += sb * P.s_x; P.xa += sb * P.s_x; P.xb += sb * P.s_x;
   P.aux += sb * P.s_aux; P.posepart += sb * P.s_posepart; P.gmax += sb * P.s_gmax; P.tiles += sb * P.s_tiles;
   P.dp += sb * P.s_dp; P.evalpart += sb * P.s_evalpart; P.tilesum += sb * P.s_tilesum; P.posesum += sb * P.s_posesum; P.cams += sb * P.s_cams;
+  P.xstat += sb * BA_EVAL_VALS;
   P.state += 2 * sb; P.info += sb;
   if (b != 0) P.dbg = nullptr;
   return P;
@@ -101,8 +105,13 @@ struct vo_ba_ws {
   double* d_tiles = nullptr;    // nblk * n_tiles * 256
   double* d_dp = nullptr;       // 6W
   double* d_evalpart = nullptr; // nblk * 4
-  double* d_tilesum = nullptr;  // n_tiles * 256
-  double* d_posesum = nullptr;  // W * 28 + 1
+  double* d_tilesum = nullptr;  // n_tiles * 256                  } one allocation, red_stride doubles per problem:
+  double* d_posesum = nullptr;  // W * 28 + 1 (+ 16 rank slots)    } d_posesum = d_tilesum + n_tiles * 256
+  size_t red_stride = 0;
+  double* d_xstat = nullptr;    // [batch][4] sharded solve: summed step statistics
+  double* d_gather = nullptr;   // vo_ba_gather_points: send [batch][N][3] | recv [n_ranks][batch][N][3]
+  double* h_gather = nullptr;   // pinned mirror of recv
+  size_t gather_cap = 0;
   double* d_cams = nullptr;     // 2 * W * 21
   double* d_S = nullptr;        // probe: (6W)^2 + 6W
   double* d_Hpp = nullptr;      // W*28 reduced pose values (probe)
@@ -346,7 +355,7 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   __shared__ double s_esum[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // ---- state for this iteration (every workgroup derives it from the same inputs) ----
-  if (it > 0) ba_reduce_evalpart<TPB>(P.evalpart, P.nblk, dyn, s_esum);
+  if (it > 0) ba_reduce_evalpart<TPB>(P.sharded ? P.xstat : P.evalpart, P.sharded ? 1 : P.nblk, dyn, s_esum);
   if (tid == 0) {
     ba_state st;
     if (it == 0) st = ba_init_state(prm);
@@ -592,6 +601,45 @@ __global__ void __launch_bounds__(256) k_ba_reduce(ba_ptrs Pall, int it) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// sharded solve: the local half of the exchange.  k_ba_xsum sums the reduced packets of the `batch` shards of this
+// GPU in shard order and stores the total in every entry (element-wise: one thread owns element e of all entries);
+// max |g_l| is a maximum, so it travels as one slot per rank (own slot = local maximum, others 0) and the all-reduce
+// SUM that follows delivers every rank's value to everybody.  k_ba_xstat does the same for the 4 step statistics.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ba_xsum(ba_ptrs Pall, int it) {
+  if (Pall.state[it & 1].done) return;       // all shards hold the same state
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int n_sum = Pall.n_tiles * 256 + Pall.W * BA_POSE_VALS;      // tilesum | posesum are contiguous
+  const size_t stride = Pall.s_tilesum;
+  if (e < n_sum) {
+    double s = 0;
+    for (int b = 0; b < Pall.batch; b++) s += Pall.tilesum[(size_t)b * stride + e];
+    for (int b = 0; b < Pall.batch; b++) Pall.tilesum[(size_t)b * stride + e] = s;
+  } else if (e > n_sum && e <= n_sum + Pall.n_ranks) {
+    const int r = e - n_sum - 1;             // rank slot; element n_sum itself (the local maximum) is left alone
+    double m = 0;
+    for (int b = 0; b < Pall.batch; b++) m = fmax(m, Pall.tilesum[(size_t)b * stride + n_sum]);
+    const double v = (r == Pall.rank) ? m : 0.0;
+    for (int b = 0; b < Pall.batch; b++) Pall.tilesum[(size_t)b * stride + e] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_ba_xstat(ba_ptrs Pall, int it) {
+  if (Pall.state[it & 1].done) return;
+  __shared__ double s_part[4 * 640];
+  __shared__ double s_sum[4];
+  __shared__ double s_tot[4];
+  if (threadIdx.x < 4) s_tot[threadIdx.x] = 0;
+  for (int b = 0; b < Pall.batch; b++) {
+    __syncthreads();
+    ba_reduce_evalpart<256>(Pall.evalpart + (size_t)b * Pall.s_evalpart, Pall.nblk, s_part, s_sum);
+    if (threadIdx.x < 4) s_tot[threadIdx.x] += s_sum[threadIdx.x];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * Pall.batch; i += 256) Pall.xstat[i] = s_tot[i & 3];
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_ba_solve : one workgroup
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_params_dev prm, int it, double* __restrict__ probe_S,
@@ -807,7 +855,10 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
     const double* w0 = s_dp + n; const double* w1 = s_dp + n + 8;
     ba_info inf;
     inf.cost_cur = w0[3] + w1[3]; inf.pred_pose = w0[0] + w1[0]; inf.step2_pose = w0[1] + w1[1]; inf.x2_pose = w0[2] + w1[2];
-    inf.ginf = fmax(fmax(w0[4], w1[4]), P.posesum[W * BA_POSE_VALS]);
+    double gl_max = 0;                       // max |g_l| over all landmarks
+    if (P.sharded) { for (int r = 0; r < P.n_ranks; r++) gl_max = fmax(gl_max, P.posesum[W * BA_POSE_VALS + 1 + r]); }
+    else gl_max = P.posesum[W * BA_POSE_VALS];
+    inf.ginf = fmax(fmax(w0[4], w1[4]), gl_max);
     inf.chol_fail = fail; inf.pad = 0;
     *P.info = inf;
   }
@@ -911,7 +962,7 @@ __global__ void __launch_bounds__(256) k_ba_finalize(ba_ptrs Pall, ba_params_dev
   __shared__ ba_state s_st;
   __shared__ double s_esum[4];
   __shared__ double s_part[4 * 640];
-  if (n_it > 0) ba_reduce_evalpart<256>(P.evalpart, P.nblk, s_part, s_esum);
+  if (n_it > 0) ba_reduce_evalpart<256>(P.sharded ? P.xstat : P.evalpart, P.sharded ? 1 : P.nblk, s_part, s_esum);
   if (threadIdx.x == 0) {
     ba_state st;
     if (n_it == 0) st = ba_init_state(prm);
@@ -958,8 +1009,9 @@ void vo_ba_destroy(vo_ctx* c) {
   if (!c->ba) return;
   vo_ba_ws* b = c->ba;
   void* bufs[] = {b->d_K, b->d_obs, b->d_x0, b->d_x[0], b->d_x[1], b->d_aux, b->d_posepart, b->d_gmax,
-                  b->d_tiles, b->d_dp, b->d_evalpart, b->d_tilesum, b->d_posesum, b->d_cams, b->d_S, b->d_Hpp, b->d_res, b->d_dl, b->d_pub, b->d_state, b->d_info};
+                  b->d_tiles, b->d_dp, b->d_evalpart, b->d_tilesum, b->d_xstat, b->d_gather, b->d_cams, b->d_S, b->d_Hpp, b->d_res, b->d_dl, b->d_pub, b->d_state, b->d_info};
   for (void* p : bufs) if (p) (void)hipFree(p);
+  if (b->h_gather) (void)hipHostFree(b->h_gather);
   if (b->h_state) (void)hipHostFree(b->h_state);
   if (b->h_pub) (void)hipHostFree(b->h_pub);
   delete b;
@@ -1014,8 +1066,11 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     VO_HIP(c, hipMalloc((void**)&b->d_tiles, sizeof(double) * (size_t)b->nblk * b->n_tiles * 256 * B));
     VO_HIP(c, hipMalloc((void**)&b->d_dp, sizeof(double) * 6 * W * B));
     VO_HIP(c, hipMalloc((void**)&b->d_evalpart, sizeof(double) * b->nblk * BA_EVAL_VALS * B));
-    VO_HIP(c, hipMalloc((void**)&b->d_tilesum, sizeof(double) * (size_t)b->n_tiles * 256 * B));
-    VO_HIP(c, hipMalloc((void**)&b->d_posesum, sizeof(double) * ((size_t)W * BA_POSE_VALS + 1) * B));
+    b->red_stride = (size_t)b->n_tiles * 256 + (size_t)W * BA_POSE_VALS + 1 + VO_COMM_MAX_RANKS;
+    VO_HIP(c, hipMalloc((void**)&b->d_tilesum, sizeof(double) * b->red_stride * B));
+    VO_HIP(c, hipMemsetAsync(b->d_tilesum, 0, sizeof(double) * b->red_stride * B, c->stream));
+    b->d_posesum = b->d_tilesum + (size_t)b->n_tiles * 256;
+    VO_HIP(c, hipMalloc((void**)&b->d_xstat, sizeof(double) * BA_EVAL_VALS * B));
     VO_HIP(c, hipMalloc((void**)&b->d_cams, sizeof(double) * 2 * W * BA_CAM * B));
     VO_HIP(c, hipMalloc((void**)&b->d_S, sizeof(double) * ((size_t)36 * W * W + 6 * W)));          // probes: problem 0 only
     VO_HIP(c, hipMalloc((void**)&b->d_Hpp, sizeof(double) * (size_t)W * BA_POSE_VALS));
@@ -1038,11 +1093,12 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
   return VO_OK;
 }
 
-static ba_ptrs ba_make_ptrs(vo_ba_ws* b) {
+static ba_ptrs ba_make_ptrs(const vo_ctx* c) {
+  vo_ba_ws* b = c->ba;
   ba_ptrs P;
   P.K = b->d_K; P.obs = b->d_obs; P.x0 = b->d_x0; P.xa = b->d_x[0]; P.xb = b->d_x[1]; P.aux = b->d_aux;
   P.posepart = b->d_posepart; P.gmax = b->d_gmax; P.tiles = b->d_tiles; P.dp = b->d_dp; P.evalpart = b->d_evalpart;
-  P.tilesum = b->d_tilesum; P.posesum = b->d_posesum; P.cams = b->d_cams;
+  P.tilesum = b->d_tilesum; P.posesum = b->d_posesum; P.cams = b->d_cams; P.xstat = b->d_xstat;
   P.state = b->d_state; P.info = b->d_info; P.dbg = nullptr;
   P.W = b->W; P.N = b->N; P.LPP = b->LPP; P.PPB = b->PPB; P.nblk = b->nblk; P.RP = b->RP; P.RT = b->RT;
   P.n_tiles = b->n_tiles; P.pitch = b->pitch;
@@ -1050,11 +1106,12 @@ static ba_ptrs ba_make_ptrs(vo_ba_ws* b) {
   const size_t W = (size_t)b->W, N = (size_t)b->N;
   P.s_obs = 2 * W * N; P.s_x = 6 * W + 3 * N; P.s_aux = N * BA_AUX; P.s_posepart = (size_t)b->nblk * W * BA_POSE_VALS;
   P.s_gmax = (size_t)b->nblk; P.s_tiles = (size_t)b->nblk * b->n_tiles * 256; P.s_dp = 6 * W;
-  P.s_evalpart = (size_t)b->nblk * BA_EVAL_VALS; P.s_tilesum = (size_t)b->n_tiles * 256; P.s_posesum = W * BA_POSE_VALS + 1;
+  P.s_evalpart = (size_t)b->nblk * BA_EVAL_VALS; P.s_tilesum = b->red_stride; P.s_posesum = b->red_stride;
   P.s_cams = 2 * W * BA_CAM;
+  P.sharded = c->ba_sharded; P.rank = c->comm_rank; P.n_ranks = c->comm_ranks; P.batch = c->batch;
   return P;
 }
-static ba_ptrs ba_make_ptrs_dbg(vo_ctx* c) { ba_ptrs P = ba_make_ptrs(c->ba); P.dbg = c->d_dbg; return P; }
+static ba_ptrs ba_make_ptrs_dbg(vo_ctx* c) { ba_ptrs P = ba_make_ptrs(c); P.dbg = c->d_dbg; return P; }
 
 static ba_params_dev ba_dev_params(const vo_ba_params* p) {
   ba_params_dev d;
@@ -1082,23 +1139,39 @@ extern "C" int32_t vo_ba_upload(vo_ctx* c, const double* K, const double* poses,
   return VO_OK;
 }
 
-static void ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& prm, int it, double probe_lambda,
-                           double* probe_S, double* hpp_out, double* probe_dl) {
+static int32_t ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& prm, int it, double probe_lambda,
+                              double* probe_S, double* hpp_out, double* probe_dl) {
   vo_ba_ws* b = c->ba;
   const int B = c->batch;
   if (b->tpb == 256) hipLaunchKernelGGL(k_ba_build<256>, dim3(b->nblk, B), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
   else hipLaunchKernelGGL(k_ba_build<1024>, dim3(b->nblk, B), dim3(1024), b->build_lds, c->stream, P, prm, it, probe_lambda);
   hipLaunchKernelGGL(k_ba_reduce, dim3(vo_div_up(b->n_tiles * 256 + b->W * BA_POSE_VALS + 1, 64), B), dim3(256), 0, c->stream, P, it);
+  if (P.sharded) {
+    // exchange 1: every shard's reduced packet -> the sum over all shards of all ranks, in every entry
+    hipLaunchKernelGGL(k_ba_xsum, dim3(vo_div_up((int)b->red_stride, 256)), dim3(256), 0, c->stream, P, it);
+    const int32_t r = vo_comm_allreduce_f64(c, b->d_tilesum, b->red_stride * B);
+    if (r != VO_OK) return r;
+  }
   hipLaunchKernelGGL(k_ba_solve, dim3(B), dim3(BA_SOLVE_THREADS), b->solve_lds, c->stream, P, prm, it, probe_S, hpp_out);
   if (b->tpb == 256) hipLaunchKernelGGL(k_ba_update<256>, dim3(b->nblk, B), dim3(256), 0, c->stream, P, prm, it, probe_dl);
   else hipLaunchKernelGGL(k_ba_update<1024>, dim3(b->nblk, B), dim3(1024), 0, c->stream, P, prm, it, probe_dl);
+  if (P.sharded) {
+    // exchange 2: the 4 step statistics the next decision needs
+    hipLaunchKernelGGL(k_ba_xstat, dim3(1), dim3(256), 0, c->stream, P, it);
+    const int32_t r = vo_comm_allreduce_f64(c, b->d_xstat, (size_t)BA_EVAL_VALS * B);
+    if (r != VO_OK) return r;
+  }
+  return VO_OK;
 }
 
 // enqueue `n_it` LM iterations starting at iteration index `it0`
 static int32_t ba_enqueue_iters(vo_ctx* c, const ba_params_dev& prm, int it0, int n_it) {
   vo_prof_scope prof(c, VO_PROF_BA);
-  const ba_ptrs P = ba_make_ptrs(c->ba);
-  for (int it = it0; it < it0 + n_it; it++) ba_launch_iter(c, P, prm, it, -1.0, nullptr, nullptr, nullptr);
+  const ba_ptrs P = ba_make_ptrs(c);
+  for (int it = it0; it < it0 + n_it; it++) {
+    const int32_t r = ba_launch_iter(c, P, prm, it, -1.0, nullptr, nullptr, nullptr);
+    if (r != VO_OK) return r;
+  }
   VO_HIP(c, hipGetLastError());
   return VO_OK;
 }
@@ -1119,7 +1192,7 @@ extern "C" int32_t vo_ba_solve_resident(vo_ctx* c, const vo_ba_params* prm) {
   int32_t r = ba_enqueue_iters(c, d, 0, prm->max_iters);
   if (r != VO_OK) return r;
   vo_ba_ws* b = c->ba;
-  const ba_ptrs P = ba_make_ptrs(b);
+  const ba_ptrs P = ba_make_ptrs(c);
   ba_launch_finalize(c, P, d, prm->max_iters, b->d_state + (prm->max_iters & 1), 2);
   VO_HIP(c, hipGetLastError());
   return VO_OK;
@@ -1160,6 +1233,40 @@ extern "C" int32_t vo_ba_fetch(vo_ctx* c, double* poses_out, double* points_out,
   return VO_OK;
 }
 
+extern "C" int32_t vo_ba_set_sharded(vo_ctx* c, int32_t on) {
+  if (!c) return VO_E_INVALID;
+  c->ba_sharded = on ? 1 : 0;
+  return VO_OK;
+}
+
+// points of every shard of every rank after a solve: points_all [n_ranks][batch][N][3]
+extern "C" int32_t vo_ba_gather_points(vo_ctx* c, double* points_all) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, points_all, VO_E_INVALID, "null output");
+  VO_CHECK(c, c->ba && c->ba->uploaded, VO_E_STATE, "nothing to gather");
+  VO_HIP(c, hipSetDevice(c->device));
+  vo_ba_ws* b = c->ba;
+  const size_t B = c->batch, R = c->comm_ranks, cnt = B * 3 * (size_t)b->N;
+  if (b->gather_cap < cnt * (1 + R)) {
+    if (b->d_gather) (void)hipFree(b->d_gather);
+    if (b->h_gather) (void)hipHostFree(b->h_gather);
+    b->d_gather = nullptr; b->h_gather = nullptr; b->gather_cap = 0;
+    VO_HIP(c, hipMalloc((void**)&b->d_gather, sizeof(double) * cnt * (1 + R)));
+    VO_HIP(c, hipHostMalloc((void**)&b->h_gather, sizeof(double) * cnt * R, hipHostMallocDefault));
+    b->gather_cap = cnt * (1 + R);
+  }
+  double* send = b->d_gather; double* recv = b->d_gather + cnt;
+  // points part of the published x of every problem -> packed send buffer
+  VO_HIP(c, hipMemcpy2DAsync(send, sizeof(double) * 3 * b->N, b->d_pub + 64 + sizeof(double) * 6 * b->W, b->pub_bytes,
+                             sizeof(double) * 3 * b->N, B, hipMemcpyDeviceToDevice, c->stream));
+  const int32_t r = vo_comm_allgather_f64(c, send, recv, cnt);
+  if (r != VO_OK) return r;
+  VO_HIP(c, hipMemcpyAsync(b->h_gather, recv, sizeof(double) * cnt * R, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  memcpy(points_all, b->h_gather, sizeof(double) * cnt * R);
+  return VO_OK;
+}
+
 // arrays with a leading batch dimension; stats [batch]
 extern "C" int32_t vo_ba_adjust(vo_ctx* c, const double* K, const double* poses, const double* points, const double* obs,
                                 int32_t n_slots, int32_t n_pts, const vo_ba_params* prm, double* poses_out,
@@ -1173,7 +1280,7 @@ extern "C" int32_t vo_ba_adjust(vo_ctx* c, const double* K, const double* poses,
   if (r != VO_OK) return r;
   vo_ba_ws* b = c->ba;
   const ba_params_dev d = ba_dev_params(prm);
-  const ba_ptrs P = ba_make_ptrs(b);
+  const ba_ptrs P = ba_make_ptrs(c);
   const int B = c->batch;
   // iterations are enqueued in chunks; between chunks the host peeks at the states to stop early
   const int CH = 4;
@@ -1226,7 +1333,7 @@ extern "C" int32_t vo_ba_probe(vo_ctx* c, double lambda, double huber_delta, dou
   const ba_params_dev d = ba_dev_params(&prm);
   const ba_ptrs P = ba_make_ptrs_dbg(c);
   hipLaunchKernelGGL(k_ba_residual, dim3(vo_div_up(N, 128), c->batch), dim3(128), 0, c->stream, P, b->d_x0, huber_delta, b->d_res);
-  ba_launch_iter(c, P, d, 0, lambda, b->d_S, b->d_Hpp, b->d_dl);
+  { const int32_t r = ba_launch_iter(c, P, d, 0, lambda, b->d_S, b->d_Hpp, b->d_dl); if (r != VO_OK) return r; }
   VO_HIP(c, hipGetLastError());
   VO_HIP(c, hipStreamSynchronize(c->stream));
   // ---- copy out ----

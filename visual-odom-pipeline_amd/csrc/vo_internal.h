@@ -81,6 +81,10 @@ struct vo_ctx {
   int32_t* h_frame_idx = nullptr;        // pinned ring of frame indices (H2D source must outlive the copy)
   int frame_ring = 0;
   int use_graph = 0;                     // hipGraph replay is opt-in (vo_set_graph_mode): on ROCm 7.2 it is slower than plain launches
+  // landmark-sharded bundle adjustment (vo_comm.hip): RCCL communicator of this context, one process per GPU
+  void* comm = nullptr;                  // ncclComm_t
+  int comm_rank = 0, comm_ranks = 1;
+  int ba_sharded = 0;                    // batch entries (and ranks) are landmark shards of ONE problem
   std::string err;
 };
 
@@ -134,6 +138,10 @@ bool vo_ba_ready(const vo_ctx* c);
 bool vo_st_ready(const vo_ctx* c);
 int vo_st_last_max_corners(const vo_ctx* c);
 int32_t vo_st_prepare(vo_ctx* c);
+
+// collectives on the ctx stream (vo_comm.hip); identity / device copy without a communicator
+int32_t vo_comm_allreduce_f64(vo_ctx* c, double* buf, size_t count);
+int32_t vo_comm_allgather_f64(vo_ctx* c, const double* send, double* recv, size_t count);
 
 // sub-workspace lifetime hooks
 void vo_st_destroy(vo_ctx* c);

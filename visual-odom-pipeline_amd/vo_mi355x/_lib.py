@@ -93,6 +93,11 @@ SIGNATURES = {
     "vo_ba_upload": (C.c_int32, [_ctx, _f64p, _f64p, _f64p, _f64p, C.c_int32, C.c_int32]),
     "vo_ba_solve_resident": (C.c_int32, [_ctx, C.POINTER(BaParams)]),
     "vo_ba_fetch": (C.c_int32, [_ctx, _f64p, _f64p, C.POINTER(BaStats)]),
+    "vo_comm_unique_id": (C.c_int32, [_u8p]),
+    "vo_comm_init": (C.c_int32, [_ctx, C.c_int32, C.c_int32, _u8p]),
+    "vo_comm_destroy": (C.c_int32, [_ctx]),
+    "vo_ba_set_sharded": (C.c_int32, [_ctx, C.c_int32]),
+    "vo_ba_gather_points": (C.c_int32, [_ctx, _f64p]),
     "vo_ba_probe": (C.c_int32, [_ctx, C.c_double, C.c_double, _f64p, _i32p, _f64p, _f64p, _f64p, _f64p, _f64p,
                                 _f64p, _f64p, _f64p, _f64p]),
 }

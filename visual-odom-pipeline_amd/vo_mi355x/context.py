@@ -27,6 +27,7 @@ class VoContext:
         self.max_level, self.win, self.device, self.batch = max_level, win, device, batch
         self._st_max_corners = 1000
         self._klt_levels = max_level + 1
+        self.comm_ranks, self.comm_rank = 1, 0
 
     # -- lifetime -------------------------------------------------------------------------------
     def close(self):
@@ -365,6 +366,40 @@ class VoContext:
         self._ck(self._L.vo_ba_fetch(self._h, ptr(po, C.c_double), ptr(pt, C.c_double), st))
         stats = [self._stats(st[b]) for b in range(B)]
         return self._out(po), self._out(pt), stats[0] if B == 1 else stats
+
+    # -- landmark-sharded BA of one problem (config 5) -------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id (rank 0 makes it, every rank passes it to comm_init)."""
+        L = _lib.load()
+        uid = np.zeros(128, np.uint8)
+        rc = L.vo_comm_unique_id(ptr(uid, C.c_uint8))
+        if rc != 0:
+            raise RuntimeError("vo_comm_unique_id failed (%d): librccl not loadable?" % rc)
+        return uid
+
+    def comm_init(self, n_ranks, rank, uid):
+        uid = np.ascontiguousarray(uid, np.uint8)
+        assert uid.size == 128
+        self._ck(self._L.vo_comm_init(self._h, int(n_ranks), int(rank), ptr(uid, C.c_uint8)))
+        self.comm_ranks, self.comm_rank = int(n_ranks), int(rank)
+
+    def comm_destroy(self):
+        self._ck(self._L.vo_comm_destroy(self._h))
+        self.comm_ranks, self.comm_rank = 1, 0
+
+    def ba_set_sharded(self, on=True):
+        """The `batch` problems of ba_upload / ba_adjust (x the ranks of the communicator) are landmark shards of
+        ONE problem (see sharding.shard_problem)."""
+        self._ck(self._L.vo_ba_set_sharded(self._h, 1 if on else 0))
+
+    def ba_gather_points(self):
+        """-> points of every shard of every rank, (n_ranks, batch, N, 3)."""
+        W, N = self._ba_shape
+        R = getattr(self, "comm_ranks", 1)
+        out = np.zeros((R, self.batch, N, 3))
+        self._ck(self._L.vo_ba_gather_points(self._h, ptr(out, C.c_double)))
+        return out
 
     def ba_probe(self, lam=1e-4, huber_delta=1.0):
         """Parity probe of problem 0 at the uploaded x0: residuals, normal equations, reduced system, one LM step."""
