@@ -27,7 +27,9 @@ sys.path.insert(0, os.path.join(ROOT, "visual-odom-pipeline_amd"))
 
 import numpy as np  # noqa: E402
 
-W_IMG, H_IMG, N_PTS, N_NEW, BA_N, BA_W = 1241, 376, 2000, 1000, 2000, 10
+W_IMG, H_IMG, N_PTS, N_NEW, BA_N, BA_W = 1241, 376, 2000, 1000, 2000, 10       # --workload A (the metric's configuration)
+WORKLOAD = "kitti_shaped_1241x376_2000pts_ba10"
+K_CAM = None                                                                # None: synthetic.KITTI_K
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
@@ -44,6 +46,10 @@ def parse():
     ap.add_argument("--host-threads", type=int, default=2, help="enqueue/fetch the contexts from this many host threads")
     ap.add_argument("--fixed-ba-budget", action="store_true",
                     help="always enqueue --ba-iters LM iterations (default: last frame's iteration count + 2, capped)")
+    ap.add_argument("--workload", choices=("A", "config5"), default="A",
+                    help="A: BASELINE configs[2], the metric's configuration (default).  config5: ONE 1920x1080 sequence, 5000 "
+                         "points, 20-frame BA whose landmarks are sharded over the ranks with an RCCL all-reduce per LM "
+                         "iteration (front end replicated); strong scaling, not the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=40)
     return ap.parse_args()
@@ -82,6 +88,14 @@ class Dist:
         self.td.all_reduce(t, op=self.td.ReduceOp.SUM)
         return float(t[0])
 
+    def bcast_bytes(self, arr):
+        """rank 0's uint8 array to everybody (the RCCL unique id of the sharded-BA communicator)"""
+        if not self.td:
+            return arr
+        t = self.torch.from_numpy(np.ascontiguousarray(arr, np.uint8).copy())
+        self.td.broadcast(t, 0)
+        return t.numpy()
+
     def close(self):
         if self.td:
             self.td.destroy_process_group()
@@ -98,8 +112,9 @@ class Group:
     """`batch` independent VO sequences carried in lockstep by ONE batched context (one HIP stream): every launch of
     the hot path serves all of them.  Everything is resident in HBM."""
 
-    def __init__(self, device, frame_sets, seed0, batch, ba_iters):
-        from vo_mi355x import VoContext, synthetic as syn
+    def __init__(self, device, frame_sets, seed0, batch, ba_iters, shard=None):
+        """shard = (rank, n_ranks, unique_id): config 5 -- this context holds landmark shard `rank` of ONE BA problem"""
+        from vo_mi355x import VoContext, sharding, synthetic as syn
         self.B = batch
         self.c = VoContext(W_IMG, H_IMG, max_pts=max(N_PTS, N_NEW), device=device, batch=batch)
         c = self.c
@@ -107,7 +122,8 @@ class Group:
         self.nf = frame_sets[0].shape[0]
         c.points_upload(np.stack([syn.grid_points(N_PTS, W_IMG, H_IMG, seed=seed0 + b) for b in range(batch)]))
         # DLT: 1000 new tracks between two window poses of each BA scene; BA: N = 2000, W = 10 per sequence
-        scenes = [syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=seed0 + b) for b in range(batch)]
+        kw = {} if K_CAM is None else dict(K=K_CAM, width=W_IMG, height=H_IMG)
+        scenes = [syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=seed0 + b, **kw) for b in range(batch)]
         P0s, P1s, u0, u1, Ks, H0s, H1s = [], [], [], [], [], [], []
         for s in scenes:
             K = s["K"]
@@ -118,8 +134,27 @@ class Group:
             u0.append(s["obs"][3, :N_NEW].astype(np.float32)); u1.append(s["obs"][0, :N_NEW].astype(np.float32))
             Ks.append(K); H0s.append(H0); H1s.append(H1)
         c.dlt_upload(np.stack(P0s), np.stack(P1s), np.stack(u0), np.stack(u1), np.stack(Ks), np.stack(H0s), np.stack(H1s))
-        c.ba_upload(np.stack(Ks), np.stack([s["poses0"] for s in scenes]), np.stack([s["points0"] for s in scenes]),
-                    np.stack([s["obs"] for s in scenes]))
+        if shard is None:
+            c.ba_upload(np.stack(Ks), np.stack([s["poses0"] for s in scenes]), np.stack([s["points0"] for s in scenes]),
+                        np.stack([s["obs"] for s in scenes]))
+        else:
+            rank, n_ranks, uid = shard
+            s = scenes[0]
+            # RCCL writes a version banner to C stdout when the first communicator is made; stdout carries the ONE JSON
+            # line, so the banner is sent to stderr
+            import ctypes
+            libc, saved = ctypes.CDLL(None), os.dup(1)
+            sys.stdout.flush()
+            os.dup2(2, 1)
+            try:
+                c.comm_init(n_ranks, rank, uid)
+                c.sync()
+            finally:
+                libc.fflush(None)
+                os.dup2(saved, 1)
+                os.close(saved)
+            c.ba_set_sharded(True)
+            c.ba_upload(*sharding.shard_problem(s["K"], s["poses0"], s["points0"], s["obs"], n_ranks, first=rank, count=1))
         self.ba_prm = c.ba_params(max_iters=ba_iters, ftol=1e-3, xtol=1e-3)
         self.ba_iters_cap, self.adaptive = ba_iters, True
         self.klt_prm = c.klt_params()
@@ -176,15 +211,28 @@ def cpu_baseline(frames, n_frames, ba_iters):
 
 
 def main():
+    global W_IMG, H_IMG, N_PTS, N_NEW, BA_N, BA_W, WORKLOAD, K_CAM
     a = parse()
     dist = Dist()
-    from vo_mi355x import synthetic as syn
+    from vo_mi355x import VoContext, synthetic as syn
     t_gen = time.perf_counter()
-    a.ctxs = max(1, min(a.ctxs, a.seqs))
-    per = [a.seqs // a.ctxs + (1 if i < a.seqs % a.ctxs else 0) for i in range(a.ctxs)]
-    frame_sets = [syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + 16 * dist.rank + k)[0] for k in range(min(4, a.seqs))]
-    seqs = [Group(dist.local_rank, frame_sets, seed0=1000 * dist.rank + 100 * i, batch=per[i], ba_iters=a.ba_iters)
-            for i in range(a.ctxs)]
+    c5 = a.workload == "config5"
+    if c5:
+        # ONE sequence over all ranks: every rank runs the (launch-bound) front end on the whole frame redundantly and
+        # owns 1/n_ranks of the landmarks of the 20-frame bundle adjustment
+        W_IMG, H_IMG, N_PTS, N_NEW, BA_N, BA_W = 1920, 1080, 5000, 1000, 5000, 20
+        WORKLOAD = "single_seq_1920x1080_5000pts_ba20_landmark_sharded"
+        K_CAM = np.array([[1100.0, 0, 960.0], [0, 1100.0, 540.0], [0, 0, 1]])
+        a.seqs, a.ctxs, a.host_threads, a.fixed_ba_budget, a.no_cpu_baseline = 1, 1, 1, True, True
+        uid = dist.bcast_bytes(VoContext.comm_unique_id() if dist.rank == 0 else np.zeros(128, np.uint8))
+        frame_sets = [syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234, margin=96)[0]]
+        seqs = [Group(dist.local_rank, frame_sets, seed0=0, batch=1, ba_iters=a.ba_iters, shard=(dist.rank, dist.world, uid))]
+    else:
+        a.ctxs = max(1, min(a.ctxs, a.seqs))
+        per = [a.seqs // a.ctxs + (1 if i < a.seqs % a.ctxs else 0) for i in range(a.ctxs)]
+        frame_sets = [syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + 16 * dist.rank + k)[0] for k in range(min(4, a.seqs))]
+        seqs = [Group(dist.local_rank, frame_sets, seed0=1000 * dist.rank + 100 * i, batch=per[i], ba_iters=a.ba_iters)
+                for i in range(a.ctxs)]
     t_setup = time.perf_counter() - t_gen
     for s in seqs:
         s.c.set_graph_mode(bool(a.graph))
@@ -232,7 +280,7 @@ def main():
         klt_ms += ms
         klt_n += n
         s.c.profile_enable(())
-    frames_total = dist.sum(float(a.steps * a.seqs))
+    frames_total = float(a.steps) if c5 else dist.sum(float(a.steps * a.seqs))     # config 5: ONE sequence on all ranks
     fps = frames_total / dt
 
     out = None
@@ -270,23 +318,27 @@ def main():
                 "klt_mean_iters_per_level": [round(x, 3) for x in it_mean]}
         cpu = None
         if not a.no_cpu_baseline:
-            v, secs = cpu_baseline(frames, a.cpu_frames, a.ba_iters)
+            v, secs = cpu_baseline(frame_sets[0], a.cpu_frames, a.ba_iters)
             cpu = {"value": round(v, 4), "unit": "frames/s", "cores": 1, "kind": "port",
                    "sample": "%d frames of the same workload on the CPU oracle (C: pyramid+KLT+Shi-Tomasi+DLT, numpy: BA), "
                              "%.1f s, host has %d cores" % (a.cpu_frames, secs, os.cpu_count() or 0)}
-        out = {"metric": "frames/sec @1241x376, 2000 KLT pts, 10-frame BA window", "value": round(fps, 2),
+        out = {"metric": ("frames/sec @1920x1080, 5000 KLT pts, 20-frame sharded BA (config 5)" if c5 else
+                          "frames/sec @1241x376, 2000 KLT pts, 10-frame BA window"), "value": round(fps, 2),
                "unit": "frames/s", "n_gpus": dist.world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if c5 else "weak",
                "vs_baseline": None, "dtype": "u8/i32 (KLT, Shi-Tomasi) + f64 (DLT, BA)", "data": "synthetic",
-               "config": {"workload": "kitti_shaped_1241x376_2000pts_ba10", "width": W_IMG, "height": H_IMG,
+               "config": {"workload": WORKLOAD, "width": W_IMG, "height": H_IMG,
                           "klt_points": N_PTS, "klt_win": 31, "klt_levels": 4, "dlt_points": N_NEW,
                           "ba_landmarks": BA_N, "ba_window": BA_W, "ba_observations": BA_N * BA_W,
                           "ba_lm_iteration_budget": a.ba_iters, "ba_lm_iterations_run": ba_stats["iters"],
                           "ba_final_cost": round(ba_stats["cost"], 4), "ba_initial_cost": round(ba_stats["cost0"], 2),
                           "launch": "hipGraph replay" if a.graph else "plain", "ba_budget": "fixed" if a.fixed_ba_budget else "adaptive (last + 2)", "host_threads": max(a.host_threads, 1),
-                          "sequences_per_gpu": a.seqs, "batched_contexts_per_gpu": a.ctxs, "frames_per_step": a.seqs * dist.world,
-                          "parallelism": "independent sequences, %d per GPU in %d batched context(s) x %d GPU(s), no collective"
-                                         % (a.seqs, a.ctxs, dist.world)},
+                          "sequences_per_gpu": a.seqs, "batched_contexts_per_gpu": a.ctxs,
+                          "frames_per_step": 1 if c5 else a.seqs * dist.world,
+                          "parallelism": ("one sequence, BA landmarks sharded over %d GPU(s), RCCL all-reduce of the reduced camera "
+                                          "packet + 4 statistics per LM iteration, front end replicated" % dist.world) if c5 else
+                                         ("independent sequences, %d per GPU in %d batched context(s) x %d GPU(s), no collective"
+                                          % (a.seqs, a.ctxs, dist.world))},
                "stage_ms_per_batched_launch_group": stage, "roofline": roof, "cpu_baseline": cpu,
                "setup_s": round(t_setup, 2)}
     dist.barrier()
