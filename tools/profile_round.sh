@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for one round on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r01
+#   tools/profile_round.sh r01 ["extra bench args"]
 # 1. kernel trace + stats of the default bench command   -> gpurun_out/<tag>_stats
 # 2. PMC FETCH_SIZE and WRITE_SIZE in two separate passes -> gpurun_out/<tag>_pmc_{fetch,write}
 # 3. tools/summarize_profiles.py condenses them into gpurun_out/<tag>_* files that are copied to profiles/ by hand.
@@ -10,11 +10,12 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out
 export TMPDIR=/tmp
 BENCH="$PWD/bench.py"
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline"
+EXTRA=${2:-}
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline $EXTRA"
 cd /tmp
 rm -rf $OUT/${TAG}_stats $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o stats -- python3 $BENCH $ARGS > $OUT/${TAG}_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o fetch -- python3 $BENCH --steps 4 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o write -- python3 $BENCH --steps 4 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o fetch -- python3 $BENCH --steps 4 --warmup 2 --no-cpu-baseline $EXTRA > $OUT/${TAG}_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o write -- python3 $BENCH --steps 4 --warmup 2 --no-cpu-baseline $EXTRA > $OUT/${TAG}_pmc_write.log 2>&1
 cd - > /dev/null
 python3 tools/summarize_profiles.py $TAG

@@ -354,6 +354,11 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   __shared__ ba_state s_st;
   __shared__ double s_esum[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // ---- a problem that finished in an earlier iteration only carries its state forward ----
+  if (it > 0 && P.state[(it - 1) & 1].done) {
+    if (blockIdx.x == 0 && tid == 0) P.state[it & 1] = P.state[(it - 1) & 1];
+    return;
+  }
   // ---- state for this iteration (every workgroup derives it from the same inputs) ----
   if (it > 0) ba_reduce_evalpart<TPB>(P.sharded ? P.xstat : P.evalpart, P.sharded ? 1 : P.nblk, dyn, s_esum);
   if (tid == 0) {

@@ -102,13 +102,16 @@ __global__ void __launch_bounds__(256) k_st_discs(const float* __restrict__ pts,
   for (int x = xa; x <= xb; x++) mask[(size_t)y * W + x] = 0;
 }
 
-#define ST_RG 8   // output rows per thread in the vertical pass
+#define ST_RG 8       // output rows per load group in the vertical pass
+#define ST_GROUPS 6   // groups per thread: a thread walks 48 rows with running sums, so the 31 start-up rows are read once
+                      // per 48 outputs (7.8 loads per pixel instead of 16.9 at 8 rows; the pass is HBM / MALL bound)
+#define ST_ROWS (ST_RG * ST_GROUPS)
 __global__ void __launch_bounds__(256) k_st_vsum_eig(const int32_t* __restrict__ hbase, const uint8_t* __restrict__ mask,
                                                      int W, int H, int r, float s2, float* __restrict__ eig,
                                                      float* __restrict__ blockmax) {
   __shared__ float s_m[4];
   const int x = blockIdx.x * 256 + threadIdx.x;
-  const int y0 = blockIdx.y * ST_RG;
+  const int y0 = blockIdx.y * ST_ROWS;
   const int bseq = blockIdx.z;
   const size_t np = (size_t)W * H;
   const int32_t* hxx = hbase + (size_t)bseq * 3 * np; const int32_t* hxy = hxx + np; const int32_t* hyy = hxy + np;
@@ -130,26 +133,30 @@ __global__ void __launch_bounds__(256) k_st_vsum_eig(const int32_t* __restrict__
       const size_t o = (size_t)st_reflect101(y0 + j, H) * W + x;
       sa += hxx[o]; sb += hxy[o]; sc += hyy[o];
     }
-    // sliding window: all 6 * (ST_RG - 1) loads are independent of the running sums -> issue them up front
-    int32_t da[ST_RG], db[ST_RG], dc[ST_RG];
-    uint8_t mk[ST_RG];
+    // sliding window: the 6 loads per row are independent of the running sums -> a group's loads are issued up front
+    for (int g = 0; g < ST_GROUPS; g++) {
+      const int yb = y0 + g * ST_RG;
+      if (yb >= H) break;
+      int32_t da[ST_RG], db[ST_RG], dc[ST_RG];
+      uint8_t mk[ST_RG];
 #pragma unroll
-    for (int k = 0; k < ST_RG; k++) {
-      const int y = min(y0 + k, H - 1);
-      mk[k] = mask[(size_t)y * W + x];
-      if (k == 0) { da[0] = db[0] = dc[0] = 0; continue; }
-      const size_t on = (size_t)st_reflect101(y + r, H) * W + x, oo = (size_t)st_reflect101(y - r - 1, H) * W + x;
-      da[k] = hxx[on] - hxx[oo]; db[k] = hxy[on] - hxy[oo]; dc[k] = hyy[on] - hyy[oo];
-    }
+      for (int k = 0; k < ST_RG; k++) {
+        const int y = min(yb + k, H - 1);
+        mk[k] = mask[(size_t)y * W + x];
+        if (g == 0 && k == 0) { da[0] = db[0] = dc[0] = 0; continue; }
+        const size_t on = (size_t)st_reflect101(y + r, H) * W + x, oo = (size_t)st_reflect101(y - r - 1, H) * W + x;
+        da[k] = hxx[on] - hxx[oo]; db[k] = hxy[on] - hxy[oo]; dc[k] = hyy[on] - hyy[oo];
+      }
 #pragma unroll
-    for (int k = 0; k < ST_RG; k++) {
-      const int y = y0 + k;
-      sa += da[k]; sb += db[k]; sc += dc[k];
-      if (y < H) {
-        const float a = ((float)sa * s2) * 0.5f, b = (float)sb * s2, c = ((float)sc * s2) * 0.5f;
-        const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-        eig[(size_t)y * W + x] = e;
-        if (mk[k] && e > lmax) lmax = e;
+      for (int k = 0; k < ST_RG; k++) {
+        const int y = yb + k;
+        sa += da[k]; sb += db[k]; sc += dc[k];
+        if (y < H) {
+          const float a = ((float)sa * s2) * 0.5f, b = (float)sb * s2, c = ((float)sc * s2) * 0.5f;
+          const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+          eig[(size_t)y * W + x] = e;
+          if (mk[k] && e > lmax) lmax = e;
+        }
       }
     }
   }
@@ -468,7 +475,7 @@ static int32_t st_init(vo_ctx* c) {
   VO_HIP(c, hipMalloc((void**)&s->d_eig, np * sizeof(float) * B));
   s->d_scalars = vo_slab<uint32_t>(c, c->off_st_scalars);
   VO_HIP(c, hipMalloc((void**)&s->d_cand, sizeof(unsigned long long) * ST_CAND_CAP * B));
-  s->n_blockmax = vo_div_up(c->width, 256) * vo_div_up(c->height, ST_RG);
+  s->n_blockmax = vo_div_up(c->width, 256) * vo_div_up(c->height, ST_ROWS);
   VO_HIP(c, hipMalloc((void**)&s->d_blockmax, sizeof(float) * (size_t)s->n_blockmax * B));
   s->d_out = vo_slab<float>(c, c->off_st_out);
   VO_HIP(c, hipMalloc((void**)&s->d_pts, sizeof(float) * 2 * (size_t)c->max_pts * B));
@@ -528,7 +535,7 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
   const double scale_d = 1.0 / ((double)(1 << 2) * prm->block_size * 255.0);
   const float sf = (float)scale_d;
   const float s2 = sf * sf;
-  hipLaunchKernelGGL(k_st_vsum_eig, dim3(vo_div_up(W, 256), vo_div_up(H, ST_RG), B), dim3(256), 0, c->stream, s->d_h,
+  hipLaunchKernelGGL(k_st_vsum_eig, dim3(vo_div_up(W, 256), vo_div_up(H, ST_ROWS), B), dim3(256), 0, c->stream, s->d_h,
                      s->d_mask, W, H, r, s2, s->d_eig, s->d_blockmax);
   hipLaunchKernelGGL(k_st_nms, dim3(vo_div_up(W - 2, 256), vo_div_up(H - 2, ST_NMS_ROWS), B), dim3(256), 0, c->stream, s->d_eig,
                      s->d_mask, W, H, prm->quality_level, s->d_blockmax, s->n_blockmax, s->d_cand, s->d_scalars, c->slab_seq);
