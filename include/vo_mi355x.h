@@ -200,7 +200,7 @@ int32_t vo_ba_probe(vo_ctx* ctx, double lambda, double huber_delta, double* resi
  * batch + b owns landmarks j with j % S == s together with ALL their observations; the W poses are replicated.
  * Every shard eliminates its own landmarks; the shared quantity is the reduced camera system every landmark
  * contributes to.  Per LM iteration: ONE in-place RCCL all-reduce (sum, f64) of the packed
- * [Gram tiles of Y^ (E and r) | camera sums H_pp, g_p, cost | per-rank max|g_l| slots] (~59 KB at W = 10, ~155 KB at
+ * [Gram tiles of Y^ (E and r) | camera sums H_pp, g_p, cost | per-rank max|g_l| slots] (23 KB at W = 10, 78 KB at
  * W = 20) and one of the 4 step statistics; every rank then solves the 6W x 6W system redundantly and takes the
  * same accept/reject decision.  The batch dimension of a batched context acts as `batch` shards on one GPU (summed
  * by a kernel) -- useful on its own for tests and for filling one GPU with a single large problem.
