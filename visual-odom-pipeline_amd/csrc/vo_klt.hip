@@ -8,12 +8,13 @@
 // results are bit-identical to the CPU oracle independent of summation order.
 //
 // Lane <-> window mapping (window <= 31x31, read footprint 32 rows x 34 bytes):
-//   lane = cp*4 + r,  cp = 0..15 (column pair), r = 0..3;  step s = 0..7 covers window row 4s + r,
+//   lane = cp*4 + r,  cp = 0..15 (column pair), r = 0..3;  step s = 0..7 covers window row 8r + s,
 //   columns 2cp and 2cp+1.  One unaligned dword load per lane per step fetches the 3 bytes the two
-//   bilinear footprints need from the top row; the bottom row is the quad neighbour's top row
-//   (DPP quad_perm rotate, no memory traffic).  => 8 dword loads per lane per LK iteration for a
-//   1 KB window, served by L1/L2 (a pyramid level is <= 0.6 MB; HBM sees it once).
-//   The template (I, Ix, Iy at 16 pixels per lane) lives in 48 VGPRs across all iterations.
+//   bilinear footprints need from the top row; the bottom row of step s is the SAME lane's top row of
+//   step s + 1 (already in a register, its byte gathers are shared), only step 7 takes it from the
+//   quad neighbour's step 0 (one DPP quad_perm rotate per iteration).  => 8 dword loads per lane per
+//   LK iteration for a 1 KB window, served by L1/L2 (a pyramid level is <= 0.6 MB; HBM sees it once).
+//   The template (I, Ix, Iy at 16 pixels per lane) lives in 24 VGPRs across all iterations.
 #include "vo_internal.h"
 
 #include <stdlib.h>
@@ -167,27 +168,28 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
     uint32_t tI[8], tX[8], tY[8];
     {
       uint32_t T[8], D0[8], D1[8], D2[8];
-      const size_t base = (size_t)(ipy + VO_PAD + r) * L.pitch + (size_t)(ipx + VO_PAD + 2 * cp);
+      const size_t base = (size_t)(ipy + VO_PAD + 8 * r) * L.pitch + (size_t)(ipx + VO_PAD + 2 * cp);
 #pragma unroll
       for (int s = 0; s < 8; s++) {
-        const size_t off = base + (size_t)(4 * s) * L.pitch;
+        const size_t off = base + (size_t)s * L.pitch;
         T[s] = ld_u32_any(L.imgI + off);
         D0[s] = L.derI[off]; D1[s] = L.derI[off + 1]; D2[s] = L.derI[off + 2];
       }
+      // row 8r + 8 = step 0 of the quad neighbour r + 1 (lanes r == 3 receive a row that only masked pixels use)
+      const uint32_t T8 = quad_rot1(T[0]), D08 = quad_rot1(D0[0]), D18 = quad_rot1(D1[0]), D28 = quad_rot1(D2[0]);
       int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
       for (int s = 0; s < 8; s++) {
-        const int sn = (s < 7) ? s + 1 : 7;
-        const uint32_t B = quad_rot1(r == 0 ? T[sn] : T[s]);
-        const uint32_t E0 = quad_rot1(r == 0 ? D0[sn] : D0[s]);
-        const uint32_t E1 = quad_rot1(r == 0 ? D1[sn] : D1[s]);
-        const uint32_t E2 = quad_rot1(r == 0 ? D2[sn] : D2[s]);
+        const uint32_t B = (s < 7) ? T[(s + 1) & 7] : T8;
+        const uint32_t E0 = (s < 7) ? D0[(s + 1) & 7] : D08;
+        const uint32_t E1 = (s < 7) ? D1[(s + 1) & 7] : D18;
+        const uint32_t E2 = (s < 7) ? D2[(s + 1) & 7] : D28;
         tI[s] = sample2(T[s], B, wt, wb);
         const int x0 = deriv1(pack_lo(D0[s], D1[s]), pack_lo(E0, E1), wt, wb);
         const int y0 = deriv1(pack_hi(D0[s], D1[s]), pack_hi(E0, E1), wt, wb);
         const int x1 = deriv1(pack_lo(D1[s], D2[s]), pack_lo(E1, E2), wt, wb);
         const int y1 = deriv1(pack_hi(D1[s], D2[s]), pack_hi(E1, E2), wt, wb);
-        const uint32_t m = (4 * s + r < win) ? colmask : 0u;    // rows / columns outside the window contribute nothing
+        const uint32_t m = (8 * r + s < win) ? colmask : 0u;    // rows / columns outside the window contribute nothing
         const uint32_t xp = pack_lo((uint32_t)x0, (uint32_t)x1) & m, yp = pack_lo((uint32_t)y0, (uint32_t)y1) & m;
         tX[s] = xp; tY[s] = yp;
         a11 = dot2(xp, xp, a11);
@@ -219,14 +221,14 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
         lk_weights(nextx - (float)inx, nexty - (float)iny, jw00, jw01, jw10, jw11);
         const uint32_t jt = pack_lo((uint32_t)jw00, (uint32_t)jw01), jb = pack_lo((uint32_t)jw10, (uint32_t)jw11);
         uint32_t Tj[8];
-        const uint8_t* pj = L.imgJ + (size_t)(iny + VO_PAD + r) * L.pitch + (size_t)(inx + VO_PAD + 2 * cp);
+        const uint8_t* pj = L.imgJ + (size_t)(iny + VO_PAD + 8 * r) * L.pitch + (size_t)(inx + VO_PAD + 2 * cp);
 #pragma unroll
-        for (int s = 0; s < 8; s++) Tj[s] = ld_u32_any(pj + (size_t)(4 * s) * L.pitch);
+        for (int s = 0; s < 8; s++) Tj[s] = ld_u32_any(pj + (size_t)s * L.pitch);
+        const uint32_t Tj8 = quad_rot1(Tj[0]);
         int b1 = 0, b2 = 0;
 #pragma unroll
         for (int s = 0; s < 8; s++) {
-          const int sn = (s < 7) ? s + 1 : 7;
-          const uint32_t B = quad_rot1(r == 0 ? Tj[sn] : Tj[s]);
+          const uint32_t B = (s < 7) ? Tj[(s + 1) & 7] : Tj8;
           const uint32_t d = pk_sub(sample2(Tj[s], B, jt, jb), tI[s]);   // (diff0 | diff1 << 16), |diff| <= 8160
           b1 = dot2(d, tX[s], b1);
           b2 = dot2(d, tY[s], b2);
@@ -261,16 +263,16 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
           lk_weights(nx - (float)inx, ny - (float)iny, jw00, jw01, jw10, jw11);
           const uint32_t jt = pack_lo((uint32_t)jw00, (uint32_t)jw01), jb = pack_lo((uint32_t)jw10, (uint32_t)jw11);
           uint32_t Tj[8];
-          const uint8_t* pj = L.imgJ + (size_t)(iny + VO_PAD + r) * L.pitch + (size_t)(inx + VO_PAD + 2 * cp);
+          const uint8_t* pj = L.imgJ + (size_t)(iny + VO_PAD + 8 * r) * L.pitch + (size_t)(inx + VO_PAD + 2 * cp);
 #pragma unroll
-          for (int s = 0; s < 8; s++) Tj[s] = ld_u32_any(pj + (size_t)(4 * s) * L.pitch);
+          for (int s = 0; s < 8; s++) Tj[s] = ld_u32_any(pj + (size_t)s * L.pitch);
+          const uint32_t Tj8 = quad_rot1(Tj[0]);
           int e = 0;
 #pragma unroll
           for (int s = 0; s < 8; s++) {
-            const int sn = (s < 7) ? s + 1 : 7;
-            const uint32_t B = quad_rot1(r == 0 ? Tj[sn] : Tj[s]);
+            const uint32_t B = (s < 7) ? Tj[(s + 1) & 7] : Tj8;
             const uint32_t d = pk_abs(pk_sub(sample2(Tj[s], B, jt, jb), tI[s]));
-            e = dot2(d, (4 * s + r < win) ? colones : 0u, e);
+            e = dot2(d, (8 * r + s < win) ? colones : 0u, e);
           }
           const int ierr = wave_sum_i32(e);
           errv = (float)ierr * 1.f / (float)(32 * win * win);
