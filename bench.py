@@ -161,15 +161,29 @@ class Group:
         self.st_prm = c.st_params()
         c.push_frame_resident(0)
         self.t = 1
+        self.inflight = 0
 
     def enqueue(self):
         # one C call: pyramid + KLT + DLT + BA + Shi-Tomasi + result copies for the whole batch
         self.c.frame_step_resident(pingpong(self.t, self.nf), N_PTS, True, True, True, 7, self.klt_prm, self.st_prm,
                                    self.ba_prm)
         self.t += 1
+        self.inflight += 1
+
+    def step(self):
+        # software pipeline: frame t + 1 is enqueued before frame t's results are waited for, so the stream never drains
+        # while the host unpacks (the library keeps two pinned result mirrors for exactly this)
+        self.enqueue()
+        if self.inflight == 2:
+            self.fetch()
+
+    def drain(self):
+        while self.inflight:
+            self.fetch()
 
     def fetch(self):
         self.last = self.c.frame_fetch()
+        self.inflight -= 1
         if self.adaptive:
             # the LM stops by its own ftol/xtol tests; the budget only bounds how many (early-exiting) launches are
             # enqueued blindly.  Next frame: what this frame needed (max over the batch) + 2, never more than --ba-iters.
@@ -247,21 +261,29 @@ def main():
 
         def run_chunk(ch):
             for s in ch:
-                s.enqueue()
+                s.step()
+
+        def drain_chunk(ch):
             for s in ch:
-                s.fetch()
+                s.drain()
 
     def step():
         if pool is not None:
             list(pool.map(run_chunk, chunks))     # ctypes releases the GIL inside the C calls
             return
         for s in seqs:
-            s.enqueue()
+            s.step()
+
+    def drain():
+        if pool is not None:
+            list(pool.map(drain_chunk, chunks))
+            return
         for s in seqs:
-            s.fetch()
+            s.drain()
 
     for _ in range(a.warmup):
         step()
+    drain()
     # ---- timed region: exactly K steps; KLT kernel bracketed by hipEvents on its own stream ----
     for s in seqs:
         s.c.profile_enable((s.c.PROF_KLT,))
@@ -270,6 +292,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    drain()                                        # every one of the K frames is complete and fetched inside the timed region
     for s in seqs:
         s.c.sync()
     dist.barrier()

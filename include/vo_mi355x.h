@@ -224,7 +224,10 @@ int32_t vo_ba_gather_points(vo_ctx* ctx, double* points_all);
  * uploaded pairs] -> [BA of the uploaded problem] -> [Shi-Tomasi re-detection around the tracked points] ->
  * result copies.  With vo_set_graph_mode(ctx, 1) the launch sequence is captured once per buffer parity and replayed
  * as a hipGraph (bit-identical results; off by default: on ROCm 7.2 the replay costs more than ~45 plain launches).
- * vo_frame_fetch waits and unpacks the results. */
+ * Up to TWO steps may be in flight (one in graph mode): step t + 1 can be enqueued before step t is fetched, the
+ * results of consecutive steps land in alternating pinned mirrors, so the GPU queue never drains while the host
+ * unpacks.  vo_frame_fetch waits for the OLDEST step not fetched yet (an event, not the whole stream) and unpacks it;
+ * with nothing in flight it returns the last step's results again. */
 int32_t vo_frame_step_resident(vo_ctx* ctx, int32_t frame_idx, int32_t n_pts, int32_t do_dlt, int32_t do_ba,
                                int32_t do_st, int32_t mask_radius, const vo_klt_params* klt,
                                const vo_st_params* st, const vo_ba_params* ba);               /* async */

@@ -52,3 +52,42 @@ def test_frame_step_matches_individual_calls(graph):
             assert np.array_equal(got["poses"], po) and np.array_equal(got["landmarks"], pt)
             assert got["ba_stats"]["cost"] == bst["cost"] and got["ba_stats"]["iters"] == bst["iters"]
             assert np.array_equal(got["corners"], corners), k
+
+
+def test_two_steps_in_flight_match_one_at_a_time():
+    """step t + 1 may be enqueued before step t is fetched (alternating pinned mirrors); results are those of the
+    one-at-a-time loop, fetched oldest first; a third step without a fetch is refused"""
+    from vo_mi355x import VoContext, VoError, synthetic as syn
+    w, h, n, n_new = 640, 240, 600, 200
+    frames, _ = syn.make_sequence(5, w=w, h=h, seed=23, margin=64)
+    pts = syn.grid_points(n, w, h, seed=5)
+    scene = syn.make_ba_scene(n_pts=300, n_slots=6, seed=3, visibility=0.9)
+    order = [1, 2, 3, 4, 3, 2, 1, 0]
+    keys = ("points2d", "status", "err", "X4", "depth1", "reproj", "poses", "landmarks", "corners")
+    with VoContext(w, h, max_pts=1024) as c:
+        _setup(c, frames, pts, scene, n_new)
+        bap = c.ba_params(max_iters=6)
+        ref = []
+        for f in order:
+            c.frame_step_resident(f, n, ba=bap)
+            ref.append(c.frame_fetch())
+    with VoContext(w, h, max_pts=1024) as c:
+        _setup(c, frames, pts, scene, n_new)
+        bap = c.ba_params(max_iters=6)
+        got = []
+        c.frame_step_resident(order[0], n, ba=bap)
+        for f in order[1:]:
+            c.frame_step_resident(f, n, ba=bap)       # two in flight
+            got.append(c.frame_fetch())               # the older one
+        with pytest.raises(VoError):
+            c.frame_step_resident(1, n, ba=bap)       # 1 in flight is fine ...
+            c.frame_step_resident(2, n, ba=bap)       # ... a third is refused
+        got.append(c.frame_fetch())
+        got.append(c.frame_fetch())                   # the accepted extra step
+        again = c.frame_fetch()                       # nothing in flight: the last step again
+    for k in range(len(order)):
+        for key in keys:
+            assert np.array_equal(got[k][key], ref[k][key], equal_nan=True), (k, key)
+        assert got[k]["ba_stats"] == ref[k]["ba_stats"]
+    for key in keys:
+        assert np.array_equal(again[key], got[-1][key], equal_nan=True)

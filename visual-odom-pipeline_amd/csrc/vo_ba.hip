@@ -1083,7 +1083,7 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     VO_HIP(c, hipMalloc((void**)&b->d_dl, sizeof(double) * (size_t)3 * N));
     b->pub_bytes = 64 + sizeof(double) * nx;                                                        // per problem
     VO_HIP(c, hipMalloc((void**)&b->d_pub, b->pub_bytes * B));
-    VO_HIP(c, hipHostMalloc((void**)&b->h_pub, b->pub_bytes * B, hipHostMallocDefault));
+    VO_HIP(c, hipHostMalloc((void**)&b->h_pub, 2 * b->pub_bytes * B, hipHostMallocDefault));   // two halves (pipelined frame steps)
     b->d_xout = reinterpret_cast<double*>(b->d_pub + 64);
     VO_HIP(c, hipMalloc((void**)&b->d_state, sizeof(ba_state) * 2 * B));
     VO_HIP(c, hipMalloc((void**)&b->d_info, sizeof(ba_info) * B));
@@ -1209,17 +1209,17 @@ static void ba_fill_stats(const ba_state& s, int n_obs, vo_ba_stats* st) {
 }
 
 // internal: enqueue the D2H copy of the published results into the pinned mirror (used by the frame step)
-int32_t vo_ba_enqueue_pub_copy(vo_ctx* c) {
+int32_t vo_ba_enqueue_pub_copy(vo_ctx* c, int half) {
   vo_ba_ws* b = c->ba;
-  VO_HIP(c, hipMemcpyAsync(b->h_pub, b->d_pub, b->pub_bytes * c->batch, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipMemcpyAsync(b->h_pub + (size_t)half * b->pub_bytes * c->batch, b->d_pub, b->pub_bytes * c->batch, hipMemcpyDeviceToHost, c->stream));
   return VO_OK;
 }
 
 // internal: unpack the pinned mirror (after a stream sync): poses_out [batch][W][6], points_out [batch][N][3], stats [batch]
-void vo_ba_unpack_pub(vo_ctx* c, double* poses_out, double* points_out, vo_ba_stats* stats) {
+void vo_ba_unpack_pub(vo_ctx* c, int half, double* poses_out, double* points_out, vo_ba_stats* stats) {
   vo_ba_ws* b = c->ba;
   for (int q = 0; q < c->batch; q++) {
-    const uint8_t* pub = b->h_pub + (size_t)q * b->pub_bytes;
+    const uint8_t* pub = b->h_pub + (size_t)half * b->pub_bytes * c->batch + (size_t)q * b->pub_bytes;
     const double* x = reinterpret_cast<const double*>(pub + 64);
     if (poses_out) memcpy(poses_out + (size_t)q * 6 * b->W, x, sizeof(double) * 6 * b->W);
     if (points_out) memcpy(points_out + (size_t)q * 3 * b->N, x + 6 * b->W, sizeof(double) * 3 * b->N);
@@ -1231,10 +1231,10 @@ extern "C" int32_t vo_ba_fetch(vo_ctx* c, double* poses_out, double* points_out,
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->ba && c->ba->uploaded, VO_E_STATE, "nothing to fetch");
   VO_HIP(c, hipSetDevice(c->device));
-  int32_t r = vo_ba_enqueue_pub_copy(c);
+  int32_t r = vo_ba_enqueue_pub_copy(c, 0);
   if (r != VO_OK) return r;
   VO_HIP(c, hipStreamSynchronize(c->stream));
-  vo_ba_unpack_pub(c, poses_out, points_out, stats);
+  vo_ba_unpack_pub(c, 0, poses_out, points_out, stats);
   return VO_OK;
 }
 
@@ -1305,10 +1305,10 @@ extern "C" int32_t vo_ba_adjust(vo_ctx* c, const double* K, const double* poses,
     all_done = true;
     for (int q = 0; q < B; q++) all_done = all_done && b->h_state[q].done;
   } while (!all_done && it < prm->max_iters);
-  r = vo_ba_enqueue_pub_copy(c);
+  r = vo_ba_enqueue_pub_copy(c, 0);
   if (r != VO_OK) return r;
   VO_HIP(c, hipStreamSynchronize(c->stream));
-  vo_ba_unpack_pub(c, poses_out, points_out, stats);
+  vo_ba_unpack_pub(c, 0, poses_out, points_out, stats);
   bool bad = false;
   for (int q = 0; q < B; q++) {
     if (stats) {

@@ -186,6 +186,10 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
   if (c->h_slab) (void)hipHostFree(c->h_slab);
   if (c->h_frame_idx) (void)hipHostFree(c->h_frame_idx);
   for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
+  for (int k = 0; k < 2; k++) if (c->ev_step[k]) (void)hipEventDestroy(c->ev_step[k]);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return VO_OK;
@@ -221,6 +225,12 @@ extern "C" int32_t vo_ctx_create_batched(int32_t device, int32_t width, int32_t 
 #define CR(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { c->err = std::string(#expr) + " -> " + hipGetErrorString(_e); return fail(VO_E_HIP); } } while (0)
   CR(hipSetDevice(device));
   CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CR(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  if (const char* e = getenv("VO_SIDE_STREAM")) c->side_stream = atoi(e) != 0;
+  CR(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  CR(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  CR(hipEventCreateWithFlags(&c->ev_step[0], hipEventDisableTiming));
+  CR(hipEventCreateWithFlags(&c->ev_step[1], hipEventDisableTiming));
   // pyramid geometry (buildOpticalFlowPyramid truncation rule)
   int w = width, h = height, top = 0;
   for (int l = 0; l <= max_level; l++) {
@@ -259,7 +269,7 @@ extern "C" int32_t vo_ctx_create_batched(int32_t device, int32_t width, int32_t 
     c->slab_bytes = off * (size_t)batch;
     CR(hipMalloc((void**)&c->d_slab, c->slab_bytes));
     CR(hipMemsetAsync(c->d_slab, 0, c->slab_bytes, c->stream));
-    CR(hipHostMalloc((void**)&c->h_slab, c->slab_bytes, hipHostMallocDefault));
+    CR(hipHostMalloc((void**)&c->h_slab, 2 * c->slab_bytes, hipHostMallocDefault));
   }
   CR(hipMalloc((void**)&c->d_iters, sizeof(int32_t) * (size_t)max_pts * VO_MAX_LEVELS * batch));
   CR(hipMalloc((void**)&c->d_uv0, sizeof(float) * 2 * (size_t)max_pts * batch));

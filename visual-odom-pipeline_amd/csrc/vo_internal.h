@@ -42,6 +42,9 @@ struct vo_dlt_cam;  // per-sequence DLT camera data (vo_dlt.hip)
 struct vo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;     // side stream of the fused frame step: Shi-Tomasi runs beside DLT + BA (fork / join by events)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int side_stream = 1;               // env VO_SIDE_STREAM=0 keeps the frame step on one stream
   int batch = 1;
   int width = 0, height = 0, max_pts = 0, max_level = 0, win = 0;
   int top = 0;                       // highest pyramid level index built
@@ -69,7 +72,11 @@ struct vo_ctx {
   // result slab: every per-frame output of the front end lives in ONE device allocation (mirrored in pinned host
   // memory) so that a frame's results come back with a single D2H copy instead of ten.
   uint8_t* d_slab = nullptr;             // [batch][slab_seq]
-  uint8_t* h_slab = nullptr;
+  uint8_t* h_slab = nullptr;             // pinned, 2 x slab_bytes: steps alternate between the halves so that step t + 1 can
+                                         // be enqueued while the host still reads step t (vo_frame_step_resident / vo_frame_fetch)
+  hipEvent_t ev_step[2] = {nullptr, nullptr};   // recorded after the result copies of the step using half k
+  size_t step_off_p[2] = {0, 0};         // slab offset of the tracked points of that step
+  long steps_enq = 0, steps_fetched = 0;
   size_t slab_seq = 0;                   // bytes per sequence
   size_t slab_bytes = 0;                 // batch * slab_seq
   size_t off_pa = 0, off_pb = 0, off_status = 0, off_err = 0, off_X4 = 0, off_depth = 0, off_reproj = 0,
@@ -132,8 +139,8 @@ static inline int vo_div_up(int a, int b) { return (a + b - 1) / b; }
 
 // cross-unit internals used by the fused frame step (vo_step.hip)
 int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, size_t raw_seq_stride, const int32_t* d_frame_idx);
-int32_t vo_ba_enqueue_pub_copy(vo_ctx* c);
-void vo_ba_unpack_pub(vo_ctx* c, double* poses_out, double* points_out, vo_ba_stats* stats);   // arrays over the batch
+int32_t vo_ba_enqueue_pub_copy(vo_ctx* c, int half);     // half: which pinned mirror (0 / 1)
+void vo_ba_unpack_pub(vo_ctx* c, int half, double* poses_out, double* points_out, vo_ba_stats* stats);   // arrays over the batch
 bool vo_ba_ready(const vo_ctx* c);
 bool vo_st_ready(const vo_ctx* c);
 int vo_st_last_max_corners(const vo_ctx* c);

@@ -17,7 +17,7 @@ struct step_cfg {
 };
 
 // enqueue everything of one frame on the ctx stream (also used under stream capture)
-static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame_idx, int frame_idx) {
+static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame_idx, int frame_idx, int half) {
   int32_t r;
   const size_t fr = (size_t)c->width * c->height;
   if (d_frame_idx) r = vo_build_pyramid(c, c->d_seq, fr * c->seq_n, d_frame_idx);
@@ -25,11 +25,27 @@ static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame
   if (r != VO_OK) return r;
   r = vo_klt_track_resident(c, s.n_pts, &s.klt);
   if (r != VO_OK) return r;
+  // Re-detection needs only the new frame and the tracked points, DLT + BA only the tracked points: the two branches
+  // run side by side (the BA iterations are chains of narrow latency-bound launches, Shi-Tomasi is wide streaming
+  // kernels).  Under graph capture everything stays on the one captured stream.
+  const bool fork = s.do_st && (s.do_dlt || s.do_ba) && !d_frame_idx && c->side_stream;
+  if (fork) {
+    VO_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+    VO_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    hipStream_t main_stream = c->stream;
+    c->stream = c->stream2;
+    r = vo_shi_tomasi_resident(c, s.n_pts, s.mask_radius, &s.st);
+    c->stream = main_stream;
+    if (r != VO_OK) return r;
+    VO_HIP(c, hipEventRecord(c->ev_join, c->stream2));
+  }
   if (s.do_dlt) { r = vo_dlt_resident(c); if (r != VO_OK) return r; }
   if (s.do_ba) { r = vo_ba_solve_resident(c, &s.ba); if (r != VO_OK) return r; }
-  if (s.do_st) { r = vo_shi_tomasi_resident(c, s.n_pts, s.mask_radius, &s.st); if (r != VO_OK) return r; }
-  VO_HIP(c, hipMemcpyAsync(c->h_slab, c->d_slab, c->slab_bytes, hipMemcpyDeviceToHost, c->stream));
-  if (s.do_ba) { r = vo_ba_enqueue_pub_copy(c); if (r != VO_OK) return r; }
+  if (fork) VO_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  else if (s.do_st) { r = vo_shi_tomasi_resident(c, s.n_pts, s.mask_radius, &s.st); if (r != VO_OK) return r; }
+  VO_HIP(c, hipMemcpyAsync(c->h_slab + (size_t)half * c->slab_bytes, c->d_slab, c->slab_bytes, hipMemcpyDeviceToHost, c->stream));
+  if (s.do_ba) { r = vo_ba_enqueue_pub_copy(c, half); if (r != VO_OK) return r; }
+  c->step_off_p[half] = vo_off_p(c);
   return VO_OK;
 }
 
@@ -57,8 +73,18 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
   if (s.do_ba) VO_CHECK(c, vo_ba_ready(c), VO_E_STATE, "vo_ba_upload first");
   if (s.do_st) { int32_t r = vo_st_prepare(c); if (r != VO_OK) return r; }    // allocations happen outside any capture
 
+  // up to two steps may be in flight: step t + 1 is enqueued while the host still reads step t's (pinned) results.
+  // A captured graph has its host destination baked in, so graph mode keeps one step in flight and one mirror half.
+  VO_CHECK(c, c->steps_enq - c->steps_fetched < (c->use_graph ? 1 : 2), VO_E_STATE, "vo_frame_fetch the previous step(s) first");
+  const int half = c->use_graph ? 0 : (int)(c->steps_enq & 1);
   const bool graph_ok = c->use_graph && c->prof.mask == 0 && c->n_pushed >= 2;
-  if (!graph_ok) return step_enqueue(c, s, nullptr, frame_idx);
+  if (!graph_ok) {
+    const int32_t r = step_enqueue(c, s, nullptr, frame_idx, half);
+    if (r != VO_OK) return r;
+    VO_HIP(c, hipEventRecord(c->ev_step[half], c->stream));
+    c->steps_enq++;
+    return VO_OK;
+  }
 
   const int parity = c->cur;                 // frame-store parity BEFORE this step
   int sig[8];
@@ -68,7 +94,7 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
     if (c->step_graph[parity]) { (void)hipGraphExecDestroy(c->step_graph[parity]); c->step_graph[parity] = nullptr; }
     hipGraph_t g = nullptr;
     VO_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    const int32_t r = step_enqueue(c, s, c->d_frame_idx, frame_idx);
+    const int32_t r = step_enqueue(c, s, c->d_frame_idx, frame_idx, 0);
     const hipError_t e = hipStreamEndCapture(c->stream, &g);
     if (r != VO_OK) { if (g) (void)hipGraphDestroy(g); return r; }
     VO_HIP(c, e);
@@ -84,6 +110,9 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
   c->h_frame_idx[c->frame_ring] = frame_idx;
   VO_HIP(c, hipMemcpyAsync(c->d_frame_idx, &c->h_frame_idx[c->frame_ring], sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
   VO_HIP(c, hipGraphLaunch(c->step_graph[parity], c->stream));
+  c->step_off_p[0] = vo_off_p(c);
+  VO_HIP(c, hipEventRecord(c->ev_step[0], c->stream));
+  c->steps_enq++;
   return VO_OK;
 }
 
@@ -96,12 +125,22 @@ extern "C" int32_t vo_frame_fetch(vo_ctx* c, int32_t n_pts, float* p, uint8_t* s
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, n_pts >= 0 && n_pts <= c->max_pts, VO_E_INVALID, "bad n_pts");
   VO_HIP(c, hipSetDevice(c->device));
-  VO_HIP(c, hipStreamSynchronize(c->stream));
-  const size_t off_p = vo_off_p(c);
+  // the OLDEST step not fetched yet; with nothing in flight: the last one again
+  int half;
+  if (c->steps_fetched < c->steps_enq) {
+    half = c->use_graph ? 0 : (int)(c->steps_fetched & 1);
+    VO_HIP(c, hipEventSynchronize(c->ev_step[half]));
+    c->steps_fetched++;
+  } else {
+    VO_CHECK(c, c->steps_enq > 0, VO_E_STATE, "no step to fetch");
+    half = c->use_graph ? 0 : (int)((c->steps_enq - 1) & 1);
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  const size_t off_p = c->step_off_p[half];
   const int mc = vo_st_last_max_corners(c) > 0 ? vo_st_last_max_corners(c) : 4096;
   int32_t rc = VO_OK;
   for (int b = 0; b < c->batch; b++) {
-    const uint8_t* h = c->h_slab + (size_t)b * c->slab_seq;
+    const uint8_t* h = c->h_slab + (size_t)half * c->slab_bytes + (size_t)b * c->slab_seq;
     if (p) memcpy(p + (size_t)b * 2 * n_pts, h + off_p, sizeof(float) * 2 * n_pts);
     if (status) memcpy(status + (size_t)b * n_pts, h + c->off_status, n_pts);
     if (err) memcpy(err + (size_t)b * n_pts, h + c->off_err, sizeof(float) * n_pts);
@@ -118,12 +157,13 @@ extern "C" int32_t vo_frame_fetch(vo_ctx* c, int32_t n_pts, float* p, uint8_t* s
       if (corners && n_corners[b] > 0) memcpy(corners + (size_t)b * 2 * mc, h + c->off_st_out, sizeof(float) * 2 * (size_t)n_corners[b]);
     }
   }
-  if ((poses || points || stats) && vo_ba_ready(c)) vo_ba_unpack_pub(c, poses, points, stats);
+  if ((poses || points || stats) && vo_ba_ready(c)) vo_ba_unpack_pub(c, half, poses, points, stats);
   return rc;
 }
 
 extern "C" int32_t vo_set_graph_mode(vo_ctx* c, int32_t on) {
   if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->steps_enq == c->steps_fetched, VO_E_STATE, "fetch the steps in flight before switching the launch mode");
   c->use_graph = on ? 1 : 0;
   return VO_OK;
 }
