@@ -534,15 +534,22 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
     }
     const double* base = dyn + (size_t)(lane >> 4) * pitch + (lane & 15);
     d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0;
-#pragma unroll 2
-    for (int k0 = 0; k0 < krows; k0 += 4) {
-      const double* rowp = base + (size_t)k0 * pitch;
-      const double a0 = rowp[16 * tas[0]], b0 = rowp[16 * tbs[0]];
-      const double a1 = rowp[16 * tas[1]], b1 = rowp[16 * tbs[1]];
-      const double a2 = rowp[16 * tas[2]], b2 = rowp[16 * tbs[2]];
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
-      if (on[1]) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
-      if (on[2]) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc2, 0, 0, 0);
+    // krows = 3 PPB is a multiple of 8 (PPB = 8, 16 or 32): two k-steps per trip, their 12 LDS reads issued before the 6 MFMAs
+    for (int k0 = 0; k0 < krows; k0 += 8) {
+      double av[2][3], bv[2][3];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const double* rowp = base + (size_t)(k0 + 4 * q) * pitch;
+#pragma unroll
+        for (int u = 0; u < 3; u++) { av[q][u] = rowp[16 * tas[u]]; bv[q][u] = rowp[16 * tbs[u]]; }
+      }
+      // all three chains run unconditionally (a wave without a 2nd / 3rd tile recomputes tile 0 and drops it)
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][0], bv[q][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][1], bv[q][1], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][2], bv[q][2], acc2, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 3; u++) {
