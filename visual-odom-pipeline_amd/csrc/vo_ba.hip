@@ -668,7 +668,18 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
   double* A = sm;                              // column-major lower triangle of [S rhs; rhs^T .], A[col * PT + row]
   double* s_hpp = A + (size_t)n1 * PT;         // W * 28 reduced camera sums
   double* s_invd = s_hpp + W * BA_POSE_VALS;   // n inverse diagonal of L
-  double* s_dp = s_invd + n1;                  // n
+  double* s_dp = s_invd + n1;                  // n (+ 24 scratch)
+  // (row | col << 8) of the lower-triangle elements ordered by column DESCENDING (rows ascending inside a column):
+  // the trailing submatrix of every block column is then a prefix of the table, and consecutive threads get
+  // consecutive rows of one column (conflict-free LDS) without any index arithmetic in the factorisation loop
+  unsigned short* s_tab = reinterpret_cast<unsigned short*>(s_dp + n1 + 24);
+  for (int e = tid; e < (n1 * (n1 + 1)) / 2; e += BA_SOLVE_THREADS) {
+    int k = (int)((sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);     // column n - k holds k + 1 elements
+    while (k > 0 && (k * (k + 1)) / 2 > e) k--;
+    while (((k + 1) * (k + 2)) / 2 <= e) k++;
+    const int col = n - k, row = col + (e - (k * (k + 1)) / 2);
+    s_tab[e] = (unsigned short)(row | (col << 8));
+  }
   if (tid == 0) s_fail = 0;
   unsigned long long* dbgs = P.dbg ? P.dbg + 8 : nullptr;
   VO_STAMP(dbgs, 0);
@@ -738,42 +749,26 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
         }
       }
       if (bad && tid == 0) s_fail = 1;
-      if (tid < 6) {
-        // rows of the diagonal block itself
+      if (tid == 0) {
 #pragma unroll
-        for (int c = 0; c < 6; c++) if (c <= tid) {
-          double v = 0;
+        for (int c = 0; c < 6; c++) s_invd[c0 + c] = inv[c];
+      }
+      // x L_kk^T = a  (forward substitution along the row).  The rows of the diagonal block itself take the same
+      // path: for them it reproduces the factor's own row operation for operation (only the lower part is stored).
 #pragma unroll
-          for (int t6 = 0; t6 < 6; t6++) if (t6 == tid) v = D[t6][c];
-          A[(size_t)(c0 + c) * PT + r] = v;
-        }
-        if (tid == 0) {
+      for (int c = 0; c < 6; c++) {
+        double t = x[c];
 #pragma unroll
-          for (int c = 0; c < 6; c++) s_invd[c0 + c] = inv[c];
-        }
-      } else {
-        // x L_kk^T = a  (forward substitution along the row)
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-          double t = x[c];
-#pragma unroll
-          for (int d = 0; d < c; d++) t -= x[d] * D[c][d];
-          x[c] = t * inv[c];
-          A[(size_t)(c0 + c) * PT + r] = x[c];
-        }
+        for (int d = 0; d < c; d++) t -= x[d] * D[c][d];
+        x[c] = t * inv[c];
+        if (r >= c0 + c) A[(size_t)(c0 + c) * PT + r] = x[c];
       }
     }
     __syncthreads();
     const int s0 = c0 + 6, m = n1 - s0;
-    for (int idx = tid; idx < (m * (m + 1)) / 2; idx += BA_SOLVE_THREADS) {
-      // idx -> (column jj, row ii >= jj) of the lower triangle, column-major packed: rows of a column are
-      // consecutive threads (conflict-free LDS)
-      int jj = (int)((2.f * m + 1.f - sqrtf((2.f * m + 1.f) * (2.f * m + 1.f) - 8.f * (float)idx)) * 0.5f);
-      while (jj > 0 && jj * m - (jj * (jj - 1)) / 2 > idx) jj--;
-      while ((jj + 1) * m - ((jj + 1) * jj) / 2 <= idx) jj++;
-      const int ii = jj + (idx - (jj * m - (jj * (jj - 1)) / 2));
-      const int i = s0 + ii, jcol = s0 + jj;
-      if (i == n && jcol == n) continue;
+    for (int idx = tid + 1; idx < (m * (m + 1)) / 2; idx += BA_SOLVE_THREADS) {   // entry 0 is (n, n): not needed
+      const int ij = s_tab[idx];
+      const int i = ij & 255, jcol = ij >> 8;
       double acc = A[(size_t)jcol * PT + i];
 #pragma unroll
       for (int c = 0; c < 6; c++) acc -= A[(size_t)(c0 + c) * PT + i] * A[(size_t)(c0 + c) * PT + jcol];
@@ -1052,7 +1047,7 @@ static void ba_geometry(vo_ba_ws* b, int W, int N) {
   const size_t scratch = sizeof(double) * (size_t)(b->tpb / 64) * b->LPP * BA_POSE_VALS;
   b->build_lds = panel > scratch ? panel : scratch;
   const int n1 = 6 * W + 1, PT = n1 | 1;
-  b->solve_lds = sizeof(double) * ((size_t)n1 * PT + (size_t)W * BA_POSE_VALS + n1 + n1 + 24);
+  b->solve_lds = sizeof(double) * ((size_t)n1 * PT + (size_t)W * BA_POSE_VALS + n1 + n1 + 24) + sizeof(unsigned short) * ((size_t)n1 * (n1 + 1) / 2 + 8);
 }
 
 // every buffer: [batch] x per-problem size
@@ -1097,10 +1092,10 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     VO_HIP(c, hipHostMalloc((void**)&b->h_state, sizeof(ba_state) * B, hipHostMallocDefault));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
+    VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   }
   ba_geometry(c->ba, W, N);
-  VO_CHECK(c, c->ba->build_lds <= 130 * 1024 && c->ba->solve_lds <= 130 * 1024, VO_E_CAPACITY, "window too large for LDS");
+  VO_CHECK(c, c->ba->build_lds <= 130 * 1024 && c->ba->solve_lds <= 150 * 1024, VO_E_CAPACITY, "window too large for LDS");
   VO_CHECK(c, c->ba->nblk <= 640, VO_E_CAPACITY, "too many landmarks for one adjust (raise the partial capacity)");
   return VO_OK;
 }
