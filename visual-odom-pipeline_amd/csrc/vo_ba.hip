@@ -378,6 +378,16 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   // iteration 0 reads the uploaded x0 and seeds x[0] with it (each workgroup its own landmarks)
   const double* poses = (it == 0) ? P.x0 : ba_x(P, st.cur);
   const double* pts = poses + 6 * W;
+  // this lane's landmark and observation: issued before the camera staging so that the two HBM round trips overlap
+  const int pl = tid / LPP, slot = tid - pl * LPP;       // landmark (local), window slot
+  const int j = blockIdx.x * P.PPB + pl;
+  double X[3] = {0, 0, 0};
+  double uo = __builtin_nan(""), vo = 0;
+  if (slot < W && j < N) {
+    X[0] = pts[3 * j]; X[1] = pts[3 * j + 1]; X[2] = pts[3 * j + 2];
+    const double* ob = P.obs + ((size_t)slot * N + j) * 2;
+    uo = ob[0]; vo = ob[1];
+  }
   if (it == 0) {
     stage_cameras(poses, W, s_cam, tid, TPB);           // nobody has prepared the cameras of x0 yet
   } else {
@@ -389,19 +399,13 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   __syncthreads();
   if (it == 0 && blockIdx.x == 0) for (int i = tid; i < W * BA_CAM; i += TPB) P.cams[i] = s_cam[i];   // cams[0] <-> x[0]
 
-  const int pl = tid / LPP, slot = tid - pl * LPP;       // landmark (local), window slot
-  const int j = blockIdx.x * P.PPB + pl;
   ba_obs_lin o;
   bool have = false;
   if (it == 0 && slot == 0 && j < N) {
     double* dst = P.xa + 6 * W + 3 * j;
-    dst[0] = pts[3 * j]; dst[1] = pts[3 * j + 1]; dst[2] = pts[3 * j + 2];
+    dst[0] = X[0]; dst[1] = X[1]; dst[2] = X[2];
   }
-  if (slot < W && j < N) {
-    const double X[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
-    const double* ob = P.obs + ((size_t)slot * N + j) * 2;
-    have = ba_linearize_obs<true>(s_K, s_cam + BA_CAM * slot, X, ob[0], ob[1], prm.delta, o);
-  }
+  if (slot < W && j < N) have = ba_linearize_obs<true>(s_K, s_cam + BA_CAM * slot, X, uo, vo, prm.delta, o);
   if (!have) {
     o.e0 = o.e1 = o.w = o.rho = 0;
 #pragma unroll
@@ -892,6 +896,18 @@ __global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs Pall, ba_params_dev p
   const double* pts = poses + 6 * W;
   double* tposes = ba_x(P, st.cur ^ 1);
   double* tpts = tposes + 6 * W;
+  // this lane's landmark and observation first: their HBM latency overlaps the staging below
+  const int pl = tid / LPP, slot = tid - pl * LPP;
+  const int j = blockIdx.x * P.PPB + pl;
+  double X[3] = {0, 0, 0};
+  double uo = __builtin_nan(""), vo = 0;
+  if (j < N) {
+    X[0] = pts[3 * j]; X[1] = pts[3 * j + 1]; X[2] = pts[3 * j + 2];
+    if (slot < W) {
+      const double* ob = P.obs + ((size_t)slot * N + j) * 2;
+      uo = ob[0]; vo = ob[1];
+    }
+  }
   for (int a = tid; a < 6 * W; a += TPB) {
     const double d = P.dp[a];
     s_dp[a] = d;
@@ -905,16 +921,9 @@ __global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs Pall, ba_params_dev p
     for (int i = tid; i < W * BA_CAM; i += TPB) { s_cam[i] = cc[i]; s_camt[i] = ct[i]; }
   }
   __syncthreads();
-  const int pl = tid / LPP, slot = tid - pl * LPP;
-  const int j = blockIdx.x * P.PPB + pl;
-  double X[3] = {0, 0, 0};
-  double uo = __builtin_nan(""), vo = 0;
   double v0 = 0, v1 = 0, v2 = 0;
   if (j < N) {
-    X[0] = pts[3 * j]; X[1] = pts[3 * j + 1]; X[2] = pts[3 * j + 2];
     if (slot < W) {
-      const double* ob = P.obs + ((size_t)slot * N + j) * 2;
-      uo = ob[0]; vo = ob[1];
       ba_obs_lin o;
       if (ba_linearize_obs<true>(s_K, s_cam + BA_CAM * slot, X, uo, vo, prm.delta, o)) {
         const double* d = s_dp + 6 * slot;
