@@ -36,6 +36,12 @@
 #include <math.h>
 #include <string.h>
 
+// The library is built with -ffp-contract=off because the float32 front end (KLT update, Shi-Tomasi, DLT output) must
+// round exactly like the CPU oracle.  The bundle adjustment is float64 against tolerances (and bitwise reproducible
+// against itself): here a*b+c may fuse -- one v_fma_f64 instead of v_mul_f64 + v_add_f64 in kernels that are bound by
+// f64 VALU issue.
+#pragma clang fp contract(fast)
+
 #define BA_SOLVE_THREADS 1024
 #define BA_AUX 18            // per landmark: Hll(6) gl(3) Cinv(6) z(3)
 #define BA_POSE_VALS 28      // Hpp upper (21) + gp (6) + cost (1)
