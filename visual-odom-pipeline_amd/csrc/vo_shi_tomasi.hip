@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, c
   __shared__ float s_m[4];
   __shared__ unsigned int s_cnt, s_base;
   __shared__ unsigned long long s_list[256 * ST_NMS_ROWS / 2];
+  __shared__ float s_tile[ST_NMS_ROWS + 2][260];
   const int tid = threadIdx.x;
   {
     const int bseq = blockIdx.z;
@@ -191,19 +192,46 @@ __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, c
   const float maxv = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) scalars[0] = __float_as_uint(maxv);
   const float thr = (float)((double)maxv * quality);
-  const int x = blockIdx.x * 256 + tid + 1;
+  // ---- stage the (ST_NMS_ROWS + 2) x 258 eigenvalue tile through LDS: every load is issued up front and coalesced,
+  // the 3x3 tests then read LDS (the direct form chained a dependent global load behind a branch per row) ----
+  const int x0 = blockIdx.x * 256, y0 = blockIdx.y * ST_NMS_ROWS;      // tile origin = pixel (x0, y0); outputs at +1
+  {
+    float v[ST_NMS_ROWS + 2], vh[ST_NMS_ROWS + 2];
+    const int xc = x0 + tid, xh = x0 + 256 + tid;                       // halo columns 256, 257 by threads 0, 1
+#pragma unroll
+    for (int r = 0; r < ST_NMS_ROWS + 2; r++) {
+      const int yy = y0 + r;
+      v[r] = (yy < H && xc < W) ? eig[(size_t)yy * W + xc] : 0.f;
+      vh[r] = (tid < 2 && yy < H && xh < W) ? eig[(size_t)yy * W + xh] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < ST_NMS_ROWS + 2; r++) {
+      s_tile[r][tid] = v[r];
+      if (tid < 2) s_tile[r][256 + tid] = vh[r];
+    }
+  }
+  const int x = x0 + tid + 1;
+  uint8_t mk[ST_NMS_ROWS];
+#pragma unroll
+  for (int ry = 0; ry < ST_NMS_ROWS; ry++) {
+    const int y = y0 + ry + 1;
+    mk[ry] = (x < W - 1 && y < H - 1) ? mask[(size_t)y * W + x] : (uint8_t)0;
+  }
+  __syncthreads();
   if (x < W - 1) {
 #pragma unroll
     for (int ry = 0; ry < ST_NMS_ROWS; ry++) {
-      const int y = blockIdx.y * ST_NMS_ROWS + ry + 1;
+      const int y = y0 + ry + 1;
       if (y >= H - 1) break;
-      const size_t o = (size_t)y * W + x;
-      const float v = eig[o];
-      if (!(v > thr) || v == 0.f || !mask[o]) continue;
-      const float* e = eig + o;
-      const bool ismax = e[-W - 1] <= v && e[-W] <= v && e[-W + 1] <= v && e[-1] <= v && e[1] <= v &&
-                         e[W - 1] <= v && e[W] <= v && e[W + 1] <= v;
+      const float v = s_tile[ry + 1][tid + 1];
+      if (!(v > thr) || v == 0.f || !mk[ry]) continue;
+      const float* e0 = &s_tile[ry][tid];
+      const float* e1 = &s_tile[ry + 1][tid];
+      const float* e2 = &s_tile[ry + 2][tid];
+      const bool ismax = e0[0] <= v && e0[1] <= v && e0[2] <= v && e1[0] <= v && e1[2] <= v &&
+                         e2[0] <= v && e2[1] <= v && e2[2] <= v;
       if (!ismax) continue;
+      const size_t o = (size_t)y * W + x;
       const unsigned int pos = atomicAdd(&s_cnt, 1u);        // LDS; 3x3 maxima cannot be adjacent -> <= 1/4 of the pixels
       s_list[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(uint32_t)o;
     }
