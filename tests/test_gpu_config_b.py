@@ -59,3 +59,25 @@ def test_frontend_1080p_5000_points():
         ref, _, nc = o.good_features(frames[1], mask, return_aux=True)
         assert nc <= 16384, "candidate capacity of k_st_select"
         assert np.array_equal(corners, ref)
+
+
+def test_shi_tomasi_more_candidates_than_the_lds_sort_holds():
+    """> 16384 NMS candidates (1080p, no exclusion discs, tiny quality level): the selection runs on the 16384 strongest
+    (radix select) and is exact because it fills max_corners; when it cannot fill them the call is refused."""
+    import vo_oracle as o
+    from vo_mi355x import VoContext, VoError
+    rng = np.random.default_rng(12)
+    h, w = 1080, 1920
+    img = rng.integers(0, 256, (h, w)).astype(np.float32)
+    img = (img + np.roll(img, 1, 0) + np.roll(img, 1, 1)) / 3.0          # slightly correlated noise: maxima everywhere
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    with VoContext(w, h, max_pts=64) as c:
+        c.push_frame(img)
+        prm = c.st_params(max_corners=1000, quality_level=1e-4, min_distance=5)
+        corners = c.shi_tomasi(None, 7, params=prm)
+        _, _, nc = c.shi_tomasi_read()
+        assert nc > 16384, nc
+        ref = o.good_features(img, None, maxCorners=1000, qualityLevel=1e-4, minDistance=5, blockSize=31)
+        assert len(corners) == 1000 and np.array_equal(corners, ref)
+        with pytest.raises(VoError):     # min distance 60 px: fewer than 1000 corners fit, the dropped candidates could matter
+            c.shi_tomasi(None, 7, params=c.st_params(max_corners=1000, quality_level=1e-4, min_distance=60))

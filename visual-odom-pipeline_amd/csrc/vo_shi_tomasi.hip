@@ -20,6 +20,9 @@
 #include "vo_internal.h"
 
 #define ST_CAND_CAP 16384        // keys sorted in LDS (128 KB of the CU's 160 KB)
+#define ST_GLOBAL_CAP (1 << 18)  // NMS candidates kept per sequence in HBM; above ST_CAND_CAP the selection works on the
+                                 // ST_CAND_CAP strongest (radix select) and is exact whenever it fills max_corners
+#define ST_CAND_STRIDE (ST_GLOBAL_CAP + ST_CAND_CAP)   // + the compacted strongest-K list
 #define ST_OUT_CAP 4096
 #define ST_MAX_RADIUS 31
 
@@ -180,7 +183,7 @@ __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, c
     const int bseq = blockIdx.z;
     const size_t np = (size_t)W * H;
     eig += (size_t)bseq * np; mask += (size_t)bseq * np; blockmax += (size_t)bseq * n_blockmax;
-    cand += (size_t)bseq * ST_CAND_CAP; scalars = vo_seq(scalars, slab_seq, bseq);
+    cand += (size_t)bseq * ST_CAND_STRIDE; scalars = vo_seq(scalars, slab_seq, bseq);
   }
   // ---- global masked maximum (minMaxLoc) from the per-block maxima ----
   float m = 0.f;
@@ -242,7 +245,7 @@ __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, c
   __syncthreads();
   for (unsigned int i = tid; i < cnt; i += 256) {
     const unsigned int pos = s_base + i;
-    if (pos < ST_CAND_CAP) cand[pos] = s_list[i];
+    if (pos < ST_GLOBAL_CAP) cand[pos] = s_list[i];
   }
 }
 
@@ -327,12 +330,12 @@ __device__ __forceinline__ void st_sort_dispatch(const unsigned long long* __res
   }
 }
 
-__global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __restrict__ cand,
+__global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restrict__ cand,
                                                     uint32_t* __restrict__ scalars, int W, int H, int cell, int gw, int gh,
                                                     double md2, int use_dist, int max_corners, float* __restrict__ out,
                                                     size_t slab_seq, unsigned long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  cand += (size_t)blockIdx.x * ST_CAND_CAP;             // one workgroup per sequence
+  cand += (size_t)blockIdx.x * ST_CAND_STRIDE;          // one workgroup per sequence
   scalars = vo_seq(scalars, slab_seq, blockIdx.x); out = vo_seq(out, slab_seq, blockIdx.x);
   if (blockIdx.x != 0) dbg = nullptr;
   __shared__ int s_flags[3];
@@ -345,8 +348,48 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
   const int tid = threadIdx.x;
   VO_STAMP(dbg, 0);
   const uint32_t ncand = scalars[1];
-  if (ncand > ST_CAND_CAP) { if (tid == 0) scalars[2] = 0xFFFFFFFFu; return; }   // host reports VO_E_CAPACITY
-  const int n = (int)ncand;
+  if (ncand > ST_GLOBAL_CAP) { if (tid == 0) scalars[2] = 0xFFFFFFFFu; return; }   // host reports VO_E_CAPACITY
+  const bool truncated = ncand > ST_CAND_CAP;
+  if (truncated) {
+    // ---- more local maxima than the LDS sort holds: keep the ST_CAND_CAP strongest.  Keys are unique (value bits |
+    // pixel index), so the K-th largest key is found exactly by an 8-pass radix select (256-bin LDS histogram of the
+    // next byte among the keys that share the prefix); keys >= it are compacted behind the candidate list.  OpenCV's
+    // greedy scan visits candidates in descending order and stops at max_corners, so the result is exact whenever
+    // max_corners corners come out of these K; otherwise the kernel reports the capacity error below. ----
+    uint32_t* hist = reinterpret_cast<uint32_t*>(s_scan);
+    __shared__ unsigned long long s_prefix;
+    __shared__ uint32_t s_need, s_fill;
+    unsigned long long prefix = 0;
+    uint32_t need = ST_CAND_CAP;
+    for (int byte = 7; byte >= 0; byte--) {
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      const int sh = 8 * byte;
+      for (uint32_t i = tid; i < ncand; i += 1024) {
+        const unsigned long long k = cand[i];
+        if (byte == 7 || (k >> (sh + 8)) == (prefix >> (sh + 8))) atomicAdd(&hist[(uint32_t)(k >> sh) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t nd = need;
+        int d = 255;
+        for (; d > 0; d--) { const uint32_t cnt = hist[d]; if (nd <= cnt) break; nd -= cnt; }
+        s_prefix = prefix | ((unsigned long long)d << sh);
+        s_need = nd;
+        s_fill = 0;
+      }
+      __syncthreads();
+      prefix = s_prefix; need = s_need;
+    }
+    unsigned long long* top = cand + ST_GLOBAL_CAP;
+    for (uint32_t i = tid; i < ncand; i += 1024) {
+      const unsigned long long k = cand[i];
+      if (k >= prefix) { const uint32_t pos = atomicAdd(&s_fill, 1u); if (pos < ST_CAND_CAP) top[pos] = k; }
+    }
+    __syncthreads();
+    cand = top;
+  }
+  const int n = truncated ? ST_CAND_CAP : (int)ncand;
   // ---- sort by (value desc, index desc) = OpenCV's greaterThanPtr order; result: xy[] in rank order ----
   if (n <= 1024) st_sort_dispatch<1>(cand, n, keys, xy, W, tid);
   else if (n <= 2048) st_sort_dispatch<2>(cand, n, keys, xy, W, tid);
@@ -476,7 +519,8 @@ __global__ void __launch_bounds__(1024) k_st_select(const unsigned long long* __
       }
       pos++;
     }
-  if (tid == 0) scalars[2] = (uint32_t)min(total, limit);
+  // truncated candidate list that did not fill max_corners: lower-ranked candidates could still have been selected
+  if (tid == 0) scalars[2] = (truncated && total < limit) ? 0xFFFFFFFFu : (uint32_t)min(total, limit);
   VO_STAMP(dbg, 4);
 }
 
@@ -502,7 +546,7 @@ static int32_t st_init(vo_ctx* c) {
   VO_HIP(c, hipMalloc((void**)&s->d_h, np * 3 * sizeof(int32_t) * B));
   VO_HIP(c, hipMalloc((void**)&s->d_eig, np * sizeof(float) * B));
   s->d_scalars = vo_slab<uint32_t>(c, c->off_st_scalars);
-  VO_HIP(c, hipMalloc((void**)&s->d_cand, sizeof(unsigned long long) * ST_CAND_CAP * B));
+  VO_HIP(c, hipMalloc((void**)&s->d_cand, sizeof(unsigned long long) * ST_CAND_STRIDE * B));
   s->n_blockmax = vo_div_up(c->width, 256) * vo_div_up(c->height, ST_ROWS);
   VO_HIP(c, hipMalloc((void**)&s->d_blockmax, sizeof(float) * (size_t)s->n_blockmax * B));
   s->d_out = vo_slab<float>(c, c->off_st_out);
@@ -592,7 +636,7 @@ static int32_t st_fetch(vo_ctx* c, float* out_pts, int32_t* n_out) {
                              sizeof(float) * 2 * (size_t)mc, B, hipMemcpyDeviceToHost, c->stream));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   for (int b = 0; b < B; b++) {
-    if (sc[4 * b + 2] == 0xFFFFFFFFu) { n_out[b] = 0; return vo_fail(c, VO_E_CAPACITY, "shi_tomasi: more than 16384 NMS candidates"); }
+    if (sc[4 * b + 2] == 0xFFFFFFFFu) { n_out[b] = 0; return vo_fail(c, VO_E_CAPACITY, "shi_tomasi: the 16384 strongest of the NMS candidates did not yield max_corners corners (or more than 262144 candidates)"); }
     n_out[b] = (int32_t)sc[4 * b + 2];
   }
   return VO_OK;

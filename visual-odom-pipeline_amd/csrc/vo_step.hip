@@ -152,7 +152,7 @@ extern "C" int32_t vo_frame_fetch(vo_ctx* c, int32_t n_pts, float* p, uint8_t* s
     }
     if (n_corners) {
       const uint32_t* sc = reinterpret_cast<const uint32_t*>(h + c->off_st_scalars);
-      if (sc[2] == 0xFFFFFFFFu) { n_corners[b] = 0; rc = vo_fail(c, VO_E_CAPACITY, "shi_tomasi: more than 16384 NMS candidates"); continue; }
+      if (sc[2] == 0xFFFFFFFFu) { n_corners[b] = 0; rc = vo_fail(c, VO_E_CAPACITY, "shi_tomasi: the 16384 strongest of the NMS candidates did not yield max_corners corners (or more than 262144 candidates)"); continue; }
       n_corners[b] = (int32_t)sc[2];
       if (corners && n_corners[b] > 0) memcpy(corners + (size_t)b * 2 * mc, h + c->off_st_out, sizeof(float) * 2 * (size_t)n_corners[b]);
     }
