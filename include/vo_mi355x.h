@@ -108,6 +108,11 @@ int32_t vo_sync(vo_ctx* ctx);
  * (extractor.py:44-45,65-66 rebuild it on each of 4 calls per frame; here once per frame).
  * Pushing a frame rotates cur -> prev.  `stride` in bytes (>= width). */
 int32_t vo_frame_push(vo_ctx* ctx, const uint8_t* img, int32_t stride);
+/* Loader pre-filter (SURVEY.md 8f "next" row 2): cv2.bilateralFilter(img, d=5, sigmaColor=1.5, sigmaSpace=1.5) that
+ * Loader.getImage applies to every frame (src/loader/loader.py:16-20,86), fused into the kernel that writes pyramid
+ * level 0, so a raw frame can be pushed as read from disk.  d = 0: off (default; the drop-in classes receive frames the
+ * reference's loader has already filtered); d < 0: diameter from sigma_space as OpenCV does; diameter <= 7. */
+int32_t vo_set_prefilter(vo_ctx* ctx, int32_t d, double sigma_color, double sigma_space);
 /* frames preloaded into HBM (bench: inputs resident before the timed region); frames: [batch][n_frames][h][w] */
 int32_t vo_seq_upload(vo_ctx* ctx, const uint8_t* frames, int32_t n_frames);
 int32_t vo_frame_push_resident(vo_ctx* ctx, int32_t frame_index);           /* async */

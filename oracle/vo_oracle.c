@@ -20,6 +20,8 @@
  *        (maxCorners 1000, quality 0.03, minDistance, blockSize 31: extractor.py:21-24)
  *   cv2.circle(mask, ...)      /root/reference/src/extractor/extractor.py:104-107
  *   cv2.triangulatePoints      /root/reference/src/extractor/extractor.py:270
+ *   cv2.bilateralFilter        /root/reference/src/loader/loader.py:16-20,86   (d 5, sigmaColor 1.5, sigmaSpace 1.5;
+ *        SURVEY.md 8f "next" row 2: the loader's pre-filter, immediately before the frame enters the path)
  *
  * Stated deviations from OpenCV (both are exact-arithmetic refinements, made so
  * that the GPU path can be compared BIT-EXACTLY with this oracle):
@@ -570,4 +572,61 @@ void vo_oracle_triangulate(const float* P0, const float* P1, const float* uv0, c
     svd4_smallest(A, v);
     for (int k = 0; k < 4; k++) X4[(size_t)k * n + i] = (float)v[k];
   }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * cv2.bilateralFilter(src, d, sigmaColor, sigmaSpace) for 8-bit single-channel images, borderType
+ * BORDER_DEFAULT (reflect-101) -- OpenCV 4.4 imgproc/bilateral_filter.dispatch.cpp (bilateralFilter_8u) and the
+ * scalar form of BilateralFilter_8u_Invoker: radius = d/2 (d > 0) else round(1.5 sigmaSpace), at least 1; the taps
+ * are the offsets (i, j) of the (2 radius + 1)^2 square with sqrt(i^2 + j^2) <= radius, rows outer / columns inner;
+ * space_weight[k] = (float)exp(r^2 * -0.5 / sigmaSpace^2), color_weight[a] = (float)exp(a^2 * -0.5 / sigmaColor^2)
+ * (double exp, rounded to float); per pixel, in tap order and in float:
+ *     w = space_weight[k] * color_weight[|val - val0|];  sum += val * w;  wsum += w;
+ * dst = (uchar) cvRound(sum / wsum)  (round half to even).
+ * (OpenCV's SIMD rows use v_muladd, i.e. an FMA where the build has one; this restatement is the scalar,
+ * unfused order -- parity at this boundary is unpinned like the other OpenCV calls.)
+ * ------------------------------------------------------------------------------------------------ */
+int vo_oracle_bilateral_taps(int d, double sigma_color, double sigma_space, int* ofs_xy /* 2 x max taps */,
+                             float* space_w, float* color_w /* 256 */) {
+  if (sigma_color <= 0) sigma_color = 1;
+  if (sigma_space <= 0) sigma_space = 1;
+  const double gc = -0.5 / (sigma_color * sigma_color), gs = -0.5 / (sigma_space * sigma_space);
+  int radius = d <= 0 ? (int)lrint(sigma_space * 1.5) : d / 2;
+  if (radius < 1) radius = 1;
+  for (int i = 0; i < 256; i++) color_w[i] = (float)exp((double)i * i * gc);
+  int maxk = 0;
+  for (int i = -radius; i <= radius; i++)
+    for (int j = -radius; j <= radius; j++) {
+      const double r = sqrt((double)i * i + (double)j * j);
+      if (r > radius) continue;
+      space_w[maxk] = (float)exp(r * r * gs);
+      ofs_xy[2 * maxk] = j; ofs_xy[2 * maxk + 1] = i;
+      maxk++;
+    }
+  return maxk;
+}
+
+int vo_oracle_bilateral(const uint8_t* src, int w, int h, int d, double sigma_color, double sigma_space, uint8_t* dst) {
+  int radius = d <= 0 ? (int)lrint((sigma_space <= 0 ? 1 : sigma_space) * 1.5) : d / 2;
+  if (radius < 1) radius = 1;
+  const int side = 2 * radius + 1;
+  int* ofs = (int*)malloc(sizeof(int) * 2 * side * side);
+  float* sw = (float*)malloc(sizeof(float) * side * side);
+  float cw[256];
+  if (!ofs || !sw) { free(ofs); free(sw); return -1; }
+  const int maxk = vo_oracle_bilateral_taps(d, sigma_color, sigma_space, ofs, sw, cw);
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      const int val0 = src[(size_t)y * w + x];
+      float sum = 0.f, wsum = 0.f;
+      for (int k = 0; k < maxk; k++) {
+        const int val = pix101(src, w, h, x + ofs[2 * k], y + ofs[2 * k + 1]);
+        const float wt = sw[k] * cw[abs(val - val0)];
+        sum += (float)val * wt;
+        wsum += wt;
+      }
+      dst[(size_t)y * w + x] = (uint8_t)lrintf(sum / wsum);
+    }
+  free(ofs); free(sw);
+  return maxk;
 }

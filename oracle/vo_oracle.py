@@ -52,6 +52,8 @@ def lib():
                                               C.c_int, C.c_int, f32p, f32p, i32p]
         L.vo_oracle_good_features.restype = C.c_int
         L.vo_oracle_triangulate.argtypes = [f32p, f32p, f32p, f32p, C.c_int, f32p]
+        L.vo_oracle_bilateral.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, u8p]
+        L.vo_oracle_bilateral.restype = C.c_int
         L.vo_oracle_triangulate.restype = None
         _lib = L
     return _lib
@@ -172,3 +174,14 @@ def triangulate(P0, P1, uv0, uv1):
     lib().vo_oracle_triangulate(_p(P0, C.c_float), _p(P1, C.c_float), _p(uv0, C.c_float), _p(uv1, C.c_float), n,
                                 _p(X4, C.c_float))
     return X4
+
+
+def bilateral(img, d=5, sigmaColor=1.5, sigmaSpace=1.5):
+    """cv2.bilateralFilter(img, d, sigmaColor, sigmaSpace) for uint8 gray images (the loader's pre-filter,
+    /root/reference/src/loader/loader.py:16-20,86)."""
+    img = _img(img)
+    h, w = img.shape
+    out = np.empty_like(img)
+    n = lib().vo_oracle_bilateral(_p(img, C.c_uint8), w, h, int(d), float(sigmaColor), float(sigmaSpace), _p(out, C.c_uint8))
+    assert n > 0
+    return out

@@ -212,3 +212,40 @@ def test_good_features_invariants(seq_small):
     # maxCorners = 0 -> unlimited; minDistance < 1 -> no spacing rule
     assert len(o.good_features(img, None, maxCorners=0)) >= len(c)
     assert len(o.good_features(img, None, maxCorners=0, minDistance=0.5)) == nc
+
+
+def test_bilateral_prefilter_restatement():
+    """cv2.bilateralFilter (loader.py:16-20,86) restated in C against an independent numpy float32 statement of the same
+    OpenCV 4.4 recipe (13 circular taps for d = 5, float accumulation in tap order, round half to even)."""
+    import vo_oracle as o
+
+    def ref(img, d, sc, ss):
+        h, w = img.shape
+        r = d // 2
+        pad = np.pad(img, r, mode="reflect").astype(np.int32)
+        cw = np.exp(np.arange(256, dtype=np.float64) ** 2 * (-0.5 / (sc * sc))).astype(np.float32)
+        s, ws, taps = np.zeros((h, w), np.float32), np.zeros((h, w), np.float32), 0
+        c = pad[r:r + h, r:r + w]
+        for i in range(-r, r + 1):
+            for j in range(-r, r + 1):
+                rr = np.sqrt(float(i * i + j * j))
+                if rr > r:
+                    continue
+                taps += 1
+                sw = np.float32(np.exp(rr * rr * (-0.5 / (ss * ss))))
+                v = pad[r + i:r + i + h, r + j:r + j + w]
+                wt = sw * cw[np.abs(v - c)]
+                s = s + v.astype(np.float32) * wt
+                ws = ws + wt
+        return np.rint(s / ws).astype(np.uint8), taps
+
+    rng = np.random.default_rng(1)
+    smooth = np.clip(np.cumsum(rng.normal(0, 1.2, (60, 90)), axis=1) + 128, 0, 255).astype(np.uint8)
+    for img in (rng.integers(0, 256, (41, 57)).astype(np.uint8), smooth):
+        for d, sc, ss in ((5, 1.5, 1.5), (3, 12.0, 2.0), (7, 30.0, 3.0)):
+            want, taps = ref(img, d, sc, ss)
+            assert np.array_equal(o.bilateral(img, d, sc, ss), want)
+            assert taps == {3: 5, 5: 13, 7: 29}[d]
+    assert (o.bilateral(smooth) != smooth).mean() > 0.1          # it does smooth
+    flat = np.full((9, 11), 93, np.uint8)
+    assert np.array_equal(o.bilateral(flat), flat)

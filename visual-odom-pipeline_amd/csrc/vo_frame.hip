@@ -27,6 +27,44 @@ __device__ __forceinline__ int d_reflect101(int p, int len) {
 // Level 0: raw (w x h, tight) -> padded image with reflect-101 border.  grid (x blocks, padded rows, batch).
 // `raw` is the frame of sequence 0 (frame_idx == nullptr) or the base of the resident sequences, in which case the
 // frame index is read from device memory (lets a captured graph be replayed for any frame).
+// taps of the loader's bilateral pre-filter (passed by value)
+struct bil_args {
+  int maxk;
+  signed char dx[49], dy[49];
+  float sw[49];
+};
+
+// Level 0 of the frame store WITH the loader's pre-filter, cv2.bilateralFilter(img, d, sigmaColor, sigmaSpace) at
+// /root/reference/src/loader/loader.py:16-20,86 (OpenCV 4.4 bilateralFilter_8u, scalar tap order; oracle:
+// vo_oracle_bilateral): every padded pixel evaluates the filter at its reflected source position, so the filtered
+// image never makes a round trip through HBM.  Float arithmetic in the oracle's order (the unit is built
+// contract-off), IEEE division, round half to even.
+__global__ void __launch_bounds__(256) k_pad_level0_bilateral(const uint8_t* __restrict__ raw, size_t raw_seq_stride,
+                                                              const int32_t* __restrict__ frame_idx, int w, int h,
+                                                              uint8_t* __restrict__ dst, size_t dst_seq_stride, int pitch,
+                                                              int ph, bil_args A, const float* __restrict__ color_w) {
+  __shared__ float s_cw[256];
+  s_cw[threadIdx.x] = color_w[threadIdx.x];
+  __syncthreads();
+  const int X = blockIdx.x * blockDim.x + threadIdx.x;   // padded column
+  const int Y = blockIdx.y;
+  if (X >= w + 2 * VO_PAD || Y >= ph) return;
+  raw += (size_t)blockIdx.z * raw_seq_stride;
+  dst += (size_t)blockIdx.z * dst_seq_stride;
+  if (frame_idx) raw += (size_t)(*frame_idx) * w * h;
+  const int x = d_reflect101(X - VO_PAD, w), y = d_reflect101(Y - VO_PAD, h);
+  const int val0 = raw[(size_t)y * w + x];
+  float sum = 0.f, wsum = 0.f;
+  for (int k = 0; k < A.maxk; k++) {
+    const int val = raw[(size_t)d_reflect101(y + A.dy[k], h) * w + d_reflect101(x + A.dx[k], w)];
+    const int ad = val > val0 ? val - val0 : val0 - val;
+    const float wt = A.sw[k] * s_cw[ad];
+    sum += (float)val * wt;
+    wsum += wt;
+  }
+  dst[(size_t)Y * pitch + X] = (uint8_t)(int)__builtin_rintf(sum / wsum);
+}
+
 __global__ void __launch_bounds__(256) k_pad_level0(const uint8_t* __restrict__ raw, size_t raw_seq_stride,
                                                     const int32_t* __restrict__ frame_idx, int w, int h,
                                                     uint8_t* __restrict__ dst, size_t dst_seq_stride, int pitch, int ph) {
@@ -181,7 +219,7 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
       if (c->fr[f].der[l]) (void)hipFree(c->fr[f].der[l]);
     }
   for (int g = 0; g < 2; g++) if (c->step_graph[g]) (void)hipGraphExecDestroy(c->step_graph[g]);
-  void* bufs[] = {c->d_dbg, c->d_raw, c->d_seq, c->d_iters, c->d_uv0, c->d_uv1, c->d_slab, c->d_frame_idx, c->d_dlt_cam};
+  void* bufs[] = {c->d_bil_cw, c->d_dbg, c->d_raw, c->d_seq, c->d_iters, c->d_uv0, c->d_uv1, c->d_slab, c->d_frame_idx, c->d_dlt_cam};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_slab) (void)hipHostFree(c->h_slab);
   if (c->h_frame_idx) (void)hipHostFree(c->h_frame_idx);
@@ -300,8 +338,16 @@ int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, size_t raw_seq_str
   {
     const vo_level& L = c->lv[0];
     dim3 grid(vo_div_up(L.w + 2 * VO_PAD, 256), L.ph, B);
-    hipLaunchKernelGGL(k_pad_level0, grid, dim3(256), 0, c->stream, d_raw_img, raw_seq_stride, d_frame_idx, L.w, L.h,
-                       F.img[0], c->lvl_px[0], L.pitch, L.ph);
+    if (c->bil_maxk > 0) {
+      bil_args A;
+      A.maxk = c->bil_maxk;
+      for (int k = 0; k < 49; k++) { A.dx[k] = c->bil_dx[k]; A.dy[k] = c->bil_dy[k]; A.sw[k] = c->bil_sw[k]; }
+      hipLaunchKernelGGL(k_pad_level0_bilateral, grid, dim3(256), 0, c->stream, d_raw_img, raw_seq_stride, d_frame_idx, L.w,
+                         L.h, F.img[0], c->lvl_px[0], L.pitch, L.ph, A, c->d_bil_cw);
+    } else {
+      hipLaunchKernelGGL(k_pad_level0, grid, dim3(256), 0, c->stream, d_raw_img, raw_seq_stride, d_frame_idx, L.w, L.h,
+                         F.img[0], c->lvl_px[0], L.pitch, L.ph);
+    }
   }
   for (int l = 0; l <= c->top; l++) {
     const vo_level& L = c->lv[l];
@@ -381,5 +427,36 @@ extern "C" int32_t vo_pyramid_read_seq(vo_ctx* c, int32_t seq, int32_t which, in
   if (deriv_out)
     VO_HIP(c, hipMemcpy2D(deriv_out, (size_t)L.w * 4, F.der[level] + ((size_t)seq * c->lvl_px[level] + (size_t)VO_PAD * L.pitch + VO_PAD) * 2,
                           (size_t)L.pitch * 4, (size_t)L.w * 4, L.h, hipMemcpyDeviceToHost));
+  return VO_OK;
+}
+
+// Loader pre-filter of every frame entering the frame store: cv2.bilateralFilter(img, d, sigmaColor, sigmaSpace),
+// /root/reference/src/loader/loader.py:16-20 (d 5, sigmas 1.5), :86.  d = 0 switches it off (default).  The tap list and
+// the weight tables are built exactly like OpenCV 4.4 bilateralFilter_8u does (double exp rounded to float).
+extern "C" int32_t vo_set_prefilter(vo_ctx* c, int32_t d, double sigma_color, double sigma_space) {
+  if (!c) return VO_E_INVALID;
+  if (d == 0) { c->bil_maxk = 0; return VO_OK; }
+  if (sigma_color <= 0) sigma_color = 1;
+  if (sigma_space <= 0) sigma_space = 1;
+  int radius = d < 0 ? (int)lrint(sigma_space * 1.5) : d / 2;
+  if (radius < 1) radius = 1;
+  VO_CHECK(c, radius <= 3, VO_E_CAPACITY, "bilateral pre-filter: diameter up to 7");
+  VO_HIP(c, hipSetDevice(c->device));
+  const double gc = -0.5 / (sigma_color * sigma_color), gs = -0.5 / (sigma_space * sigma_space);
+  float cw[256];
+  for (int i = 0; i < 256; i++) cw[i] = (float)exp((double)i * i * gc);
+  int maxk = 0;
+  for (int i = -radius; i <= radius; i++)
+    for (int j = -radius; j <= radius; j++) {
+      const double r = sqrt((double)i * i + (double)j * j);
+      if (r > radius) continue;
+      c->bil_sw[maxk] = (float)exp(r * r * gs);
+      c->bil_dx[maxk] = (signed char)j; c->bil_dy[maxk] = (signed char)i;
+      maxk++;
+    }
+  if (!c->d_bil_cw) VO_HIP(c, hipMalloc((void**)&c->d_bil_cw, sizeof(cw)));
+  VO_HIP(c, hipMemcpyAsync(c->d_bil_cw, cw, sizeof(cw), hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  c->bil_maxk = maxk;
   return VO_OK;
 }

@@ -44,6 +44,11 @@ struct vo_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;     // side stream of the fused frame step: Shi-Tomasi runs beside DLT + BA (fork / join by events)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // loader pre-filter (vo_set_prefilter): cv2.bilateralFilter taps applied while a frame enters the frame store
+  int bil_maxk = 0;                  // 0 = off
+  signed char bil_dx[49], bil_dy[49];
+  float bil_sw[49];
+  float* d_bil_cw = nullptr;         // [256] colour weights
   int side_stream = 1;               // env VO_SIDE_STREAM=0 keeps the frame step on one stream
   int batch = 1;
   int width = 0, height = 0, max_pts = 0, max_level = 0, win = 0;

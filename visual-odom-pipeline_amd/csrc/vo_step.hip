@@ -50,7 +50,7 @@ static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame
 }
 
 static void step_signature(const vo_ctx* c, const step_cfg& s, int sig[8]) {
-  sig[0] = s.n_pts; sig[1] = s.do_dlt | (s.do_ba << 1) | (s.do_st << 2); sig[2] = s.mask_radius;
+  sig[0] = s.n_pts; sig[1] = s.do_dlt | (s.do_ba << 1) | (s.do_st << 2) | (c->bil_maxk << 8) | (c->ba_sharded << 16); sig[2] = s.mask_radius;
   sig[3] = s.klt.win | (s.klt.max_level << 8) | (s.klt.max_count << 16);
   sig[4] = s.ba.max_iters; sig[5] = s.st.max_corners | (s.st.block_size << 16);
   sig[6] = c->p_parity;   // point ping-pong parity

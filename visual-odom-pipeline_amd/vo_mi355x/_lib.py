@@ -60,6 +60,7 @@ SIGNATURES = {
     "vo_last_error": (C.c_char_p, [_ctx]),
     "vo_sync": (C.c_int32, [_ctx]),
     "vo_frame_push": (C.c_int32, [_ctx, _u8p, C.c_int32]),
+    "vo_set_prefilter": (C.c_int32, [_ctx, C.c_int32, C.c_double, C.c_double]),
     "vo_seq_upload": (C.c_int32, [_ctx, _u8p, C.c_int32]),
     "vo_frame_push_resident": (C.c_int32, [_ctx, C.c_int32]),
     "vo_pyramid_level_size": (C.c_int32, [_ctx, C.c_int32, _i32p, _i32p]),

@@ -71,6 +71,11 @@ class VoContext:
         return a[0] if self.batch == 1 else a
 
     # -- frames ---------------------------------------------------------------------------------
+    def set_prefilter(self, d=5, sigma_color=1.5, sigma_space=1.5):
+        """cv2.bilateralFilter(img, d, sigmaColor, sigmaSpace) on every frame entering the frame store (the reference
+        loader's pre-filter, loader.py:16-20,86); d = 0 switches it off."""
+        self._ck(self._L.vo_set_prefilter(self._h, int(d), float(sigma_color), float(sigma_space)))
+
     def push_frame(self, img):
         img = np.asarray(img)
         if img.dtype != np.uint8:
