@@ -68,58 +68,111 @@ __global__ void __launch_bounds__(256) k_pad_level0_bilateral(const uint8_t* __r
 __global__ void __launch_bounds__(256) k_pad_level0(const uint8_t* __restrict__ raw, size_t raw_seq_stride,
                                                     const int32_t* __restrict__ frame_idx, int w, int h,
                                                     uint8_t* __restrict__ dst, size_t dst_seq_stride, int pitch, int ph) {
-  const int X = blockIdx.x * blockDim.x + threadIdx.x;   // padded column
+  // 4 consecutive padded columns per thread, one dword store (pitch and VO_PAD are multiples of 4)
+  const int X = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int Y = blockIdx.y;
   if (X >= w + 2 * VO_PAD || Y >= ph) return;
   raw += (size_t)blockIdx.z * raw_seq_stride;
   dst += (size_t)blockIdx.z * dst_seq_stride;
   if (frame_idx) raw += (size_t)(*frame_idx) * w * h;
-  const int x = d_reflect101(X - VO_PAD, w), y = d_reflect101(Y - VO_PAD, h);
-  dst[(size_t)Y * pitch + X] = raw[(size_t)y * w + x];
+  const int y = d_reflect101(Y - VO_PAD, h);
+  const uint8_t* row = raw + (size_t)y * w;
+  uint32_t v;
+  if (X >= VO_PAD && X + 3 - VO_PAD < w) {
+    __builtin_memcpy(&v, row + (X - VO_PAD), 4);          // interior: one unaligned dword load
+  } else {
+    v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v |= (uint32_t)row[d_reflect101(X + k - VO_PAD, w)] << (8 * k);
+  }
+  *reinterpret_cast<uint32_t*>(dst + (size_t)Y * pitch + X) = v;
 }
 
 // One launch per level l, two block roles (grid.y = batch):
 //   blocks [0, nb_scharr)            : Scharr derivative of level l (interior only)
 //   blocks [nb_scharr, gridDim.x)    : pyrDown level l -> l+1 including its reflect-101 border
 // Both only READ level l, so they are independent inside the launch.
+__device__ __forceinline__ int d_byte(uint32_t v, int k) { return (int)((v >> (8 * k)) & 0xFFu); }
+
 __global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restrict__ src, size_t src_seq_px, int w, int h, int pitch,
                                                         int16_t* __restrict__ der, int nb_scharr,
                                                         uint8_t* __restrict__ dst, size_t dst_seq_px, int dw, int dh, int dpitch) {
   src += (size_t)blockIdx.y * src_seq_px;
   if ((int)blockIdx.x < nb_scharr) {
-    // ---- Scharr: Ix = [3 10 3]^T (x) [-1 0 1], Iy = [-1 0 1]^T (x) [3 10 3], un-normalised ----
-    const int per_row = (w + 255) / 256;
+    // ---- Scharr: Ix = [3 10 3]^T (x) [-1 0 1], Iy = [-1 0 1]^T (x) [3 10 3], un-normalised.
+    //      4 pixels per thread: 3 aligned dwords per source row, one 16-byte store of 4 (Ix | Iy << 16) ----
+    const int per_row = (w + 1023) / 1024;
     const int y = blockIdx.x / per_row;
-    const int x = (blockIdx.x - y * per_row) * 256 + threadIdx.x;
-    if (x >= w) return;
-    const uint8_t* p = src + (size_t)(y + VO_PAD) * pitch + (x + VO_PAD);
-    const int a00 = p[-pitch - 1], a01 = p[-pitch], a02 = p[-pitch + 1];
-    const int a10 = p[-1], a12 = p[1];
-    const int a20 = p[pitch - 1], a21 = p[pitch], a22 = p[pitch + 1];
-    const int ix = (a02 + a22 - a00 - a20) * 3 + (a12 - a10) * 10;
-    const int iy = (a20 + a22 - a00 - a02) * 3 + (a21 - a01) * 10;
-    const uint32_t packed = ((uint32_t)(uint16_t)(int16_t)ix) | ((uint32_t)(uint16_t)(int16_t)iy << 16);
-    reinterpret_cast<uint32_t*>(der)[(size_t)blockIdx.y * src_seq_px + (size_t)(y + VO_PAD) * pitch + (x + VO_PAD)] = packed;
+    const int x0 = ((blockIdx.x - y * per_row) * 256 + threadIdx.x) * 4;
+    if (x0 >= w) return;
+    const size_t o = (size_t)(y + VO_PAD) * pitch + (x0 + VO_PAD);       // multiple of 4
+    int a[3][6];                                                          // columns x0 - 1 .. x0 + 4 of rows y - 1 .. y + 1
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(src + o + (size_t)(r - 1) * pitch);
+      const uint32_t L = q[-1], M = q[0], R = q[1];
+      a[r][0] = d_byte(L, 3);
+      a[r][1] = d_byte(M, 0); a[r][2] = d_byte(M, 1); a[r][3] = d_byte(M, 2); a[r][4] = d_byte(M, 3);
+      a[r][5] = d_byte(R, 0);
+    }
+    uint32_t out[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int ix = (a[0][k + 2] + a[2][k + 2] - a[0][k] - a[2][k]) * 3 + (a[1][k + 2] - a[1][k]) * 10;
+      const int iy = (a[2][k] + a[2][k + 2] - a[0][k] - a[0][k + 2]) * 3 + (a[2][k + 1] - a[0][k + 1]) * 10;
+      // columns >= w belong to the zero (BORDER_CONSTANT) frame of the derivative image
+      out[k] = (x0 + k < w) ? (((uint32_t)(uint16_t)(int16_t)ix) | ((uint32_t)(uint16_t)(int16_t)iy << 16)) : 0u;
+    }
+    uint4 pk; pk.x = out[0]; pk.y = out[1]; pk.z = out[2]; pk.w = out[3];
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(der) + (size_t)blockIdx.y * src_seq_px + o) = pk;
   } else {
-    // ---- pyrDown: 5x5 [1 4 6 4 1]^2, (sum + 128) >> 8, output padded domain ----
+    // ---- pyrDown: 5x5 [1 4 6 4 1]^2, (sum + 128) >> 8, output padded domain, 4 outputs per thread ----
     const int b = blockIdx.x - nb_scharr;
     const int pw = dw + 2 * VO_PAD;
-    const int per_row = (pw + 255) / 256;
+    const int per_row = (pw + 1023) / 1024;
     const int Y = b / per_row;
-    const int X = (b - Y * per_row) * 256 + threadIdx.x;
-    if (X >= pw || Y >= dh + 2 * VO_PAD) return;
-    const int x = d_reflect101(X - VO_PAD, dw), y = d_reflect101(Y - VO_PAD, dh);
+    const int X0 = ((b - Y * per_row) * 256 + threadIdx.x) * 4;
+    if (X0 >= pw || Y >= dh + 2 * VO_PAD) return;
+    const int y = d_reflect101(Y - VO_PAD, dh);
     // source is padded by 32 with reflect-101, so 2x-2 .. 2x+2 never needs index reflection
-    const uint8_t* p = src + (size_t)(2 * y + VO_PAD) * pitch + (2 * x + VO_PAD);
-    int sum = 0;
+    const uint8_t* prow = src + (size_t)(2 * y + VO_PAD) * pitch + VO_PAD;
+    uint32_t res = 0;
+    if (X0 >= VO_PAD && X0 + 3 - VO_PAD < dw) {
+      // interior: outputs x0 .. x0 + 3 read source columns 2 x0 - 2 .. 2 x0 + 8: 4 aligned dwords per source row
+      const int x0 = X0 - VO_PAD;
+      int acc[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int j = -2; j <= 2; j++) {
-      const uint8_t* r = p + j * pitch;
-      const int row = r[-2] + 4 * r[-1] + 6 * r[0] + 4 * r[1] + r[2];
-      const int wj = (j == 0) ? 6 : ((j == -1 || j == 1) ? 4 : 1);
-      sum += wj * row;
+      for (int j = -2; j <= 2; j++) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(prow + (ptrdiff_t)j * pitch + 2 * x0);
+        const uint32_t d0 = q[-1], d1 = q[0], d2 = q[1], d3 = q[2];
+        int c[11];                                     // columns 2 x0 - 2 .. 2 x0 + 8
+        c[0] = d_byte(d0, 2); c[1] = d_byte(d0, 3);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { c[2 + k] = d_byte(d1, k); c[6 + k] = d_byte(d2, k); }
+        c[10] = d_byte(d3, 0);
+        const int wj = (j == 0) ? 6 : ((j == -1 || j == 1) ? 4 : 1);
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] += wj * (c[2 * k] + 4 * c[2 * k + 1] + 6 * c[2 * k + 2] + 4 * c[2 * k + 3] + c[2 * k + 4]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) res |= (uint32_t)((acc[k] + 128) >> 8) << (8 * k);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int x = d_reflect101(X0 + k - VO_PAD, dw);
+        const uint8_t* p = prow + 2 * x;
+        int sum = 0;
+#pragma unroll
+        for (int j = -2; j <= 2; j++) {
+          const uint8_t* r = p + (ptrdiff_t)j * pitch;
+          const int row = r[-2] + 4 * r[-1] + 6 * r[0] + 4 * r[1] + r[2];
+          const int wj = (j == 0) ? 6 : ((j == -1 || j == 1) ? 4 : 1);
+          sum += wj * row;
+        }
+        res |= (uint32_t)((sum + 128) >> 8) << (8 * k);
+      }
     }
-    dst[(size_t)blockIdx.y * dst_seq_px + (size_t)Y * dpitch + X] = (uint8_t)((sum + 128) >> 8);
+    *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.y * dst_seq_px + (size_t)Y * dpitch + X0) = res;
   }
 }
 
@@ -337,12 +390,13 @@ int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, size_t raw_seq_str
   const int B = c->batch;
   {
     const vo_level& L = c->lv[0];
-    dim3 grid(vo_div_up(L.w + 2 * VO_PAD, 256), L.ph, B);
+    dim3 grid(vo_div_up(L.w + 2 * VO_PAD, 1024), L.ph, B);     // 4 columns per thread
+    dim3 grid1(vo_div_up(L.w + 2 * VO_PAD, 256), L.ph, B);    // bilateral variant: 1 column per thread
     if (c->bil_maxk > 0) {
       bil_args A;
       A.maxk = c->bil_maxk;
       for (int k = 0; k < 49; k++) { A.dx[k] = c->bil_dx[k]; A.dy[k] = c->bil_dy[k]; A.sw[k] = c->bil_sw[k]; }
-      hipLaunchKernelGGL(k_pad_level0_bilateral, grid, dim3(256), 0, c->stream, d_raw_img, raw_seq_stride, d_frame_idx, L.w,
+      hipLaunchKernelGGL(k_pad_level0_bilateral, grid1, dim3(256), 0, c->stream, d_raw_img, raw_seq_stride, d_frame_idx, L.w,
                          L.h, F.img[0], c->lvl_px[0], L.pitch, L.ph, A, c->d_bil_cw);
     } else {
       hipLaunchKernelGGL(k_pad_level0, grid, dim3(256), 0, c->stream, d_raw_img, raw_seq_stride, d_frame_idx, L.w, L.h,
@@ -351,13 +405,13 @@ int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, size_t raw_seq_str
   }
   for (int l = 0; l <= c->top; l++) {
     const vo_level& L = c->lv[l];
-    const int nb_scharr = vo_div_up(L.w, 256) * L.h;
+    const int nb_scharr = vo_div_up(L.w, 1024) * L.h;
     int nb_down = 0;
     uint8_t* dst = nullptr; int dw = 0, dh = 0, dpitch = 0; size_t dpx = 0;
     if (l < c->top) {
       const vo_level& D = c->lv[l + 1];
       dst = F.img[l + 1]; dw = D.w; dh = D.h; dpitch = D.pitch; dpx = c->lvl_px[l + 1];
-      nb_down = vo_div_up(D.w + 2 * VO_PAD, 256) * D.ph;
+      nb_down = vo_div_up(D.w + 2 * VO_PAD, 1024) * D.ph;
     }
     hipLaunchKernelGGL(k_scharr_pyrdown, dim3(nb_scharr + nb_down, B), dim3(256), 0, c->stream,
                        F.img[l], c->lvl_px[l], L.w, L.h, L.pitch, F.der[l], nb_scharr, dst, dpx, dw, dh, dpitch);
