@@ -49,12 +49,17 @@ __device__ __forceinline__ int st_reflect101(int p, int len) {
 }
 
 // grid (x blocks, rows, batch); per-sequence strides: img_seq_px pixels, plane = W * H elements
+#define ST_HS_RUN 5                      // consecutive outputs per thread in the row-sum pass (odd stride: conflict-free LDS)
+#define ST_HS_COLS (256 * ST_HS_RUN)     // columns per workgroup
 __global__ void __launch_bounds__(256) k_st_sobel_hsum(const uint8_t* __restrict__ img, size_t img_seq_px, int pitch, int W, int H, int r,
                                                        int32_t* __restrict__ hbase, uint8_t* __restrict__ mask,
                                                        const uint8_t* __restrict__ user_mask,
                                                        uint32_t* __restrict__ scalars, size_t slab_seq) {
-  __shared__ int32_t sxx[256 + 2 * 15 + 2], sxy[256 + 2 * 15 + 2], syy[256 + 2 * 15 + 2];
-  const int y = blockIdx.y, x0 = blockIdx.x * 256, t = threadIdx.x;
+  // products of one row segment (+ the box radius on both sides), then SLIDING row sums: a thread owns ST_HS_RUN
+  // consecutive outputs, so it reads 2 r + 1 + 2 (RUN - 1) products per plane instead of RUN (2 r + 1); the sums go
+  // back through LDS so that the global stores are coalesced
+  __shared__ int32_t sxx[ST_HS_COLS + 2 * 15 + 2], sxy[ST_HS_COLS + 2 * 15 + 2], syy[ST_HS_COLS + 2 * 15 + 2];
+  const int y = blockIdx.y, x0 = blockIdx.x * ST_HS_COLS, t = threadIdx.x;
   const int bseq = blockIdx.z;
   const size_t np = (size_t)W * H;
   img += (size_t)bseq * img_seq_px;
@@ -63,7 +68,8 @@ __global__ void __launch_bounds__(256) k_st_sobel_hsum(const uint8_t* __restrict
   if (user_mask) user_mask += (size_t)bseq * np;
   scalars = vo_seq(scalars, slab_seq, bseq);
   if (blockIdx.x == 0 && blockIdx.y == 0 && t < 4) scalars[t] = 0;
-  const int span = 256 + 2 * r;
+  const int ncol = min(ST_HS_COLS, W - x0);          // outputs of this workgroup
+  const int span = ncol + 2 * r;
   for (int i = t; i < span; i += 256) {
     const int xs = st_reflect101(x0 - r + i, W);   // box filter reflects the PRODUCT image
     const uint8_t* p = img + (size_t)(y + VO_PAD) * pitch + (xs + VO_PAD);
@@ -75,12 +81,28 @@ __global__ void __launch_bounds__(256) k_st_sobel_hsum(const uint8_t* __restrict
     sxx[i] = dx * dx; sxy[i] = dx * dy; syy[i] = dy * dy;
   }
   __syncthreads();
-  const int x = x0 + t;
-  if (x < W) {
+  int32_t oa[ST_HS_RUN], ob[ST_HS_RUN], oc[ST_HS_RUN];
+  const int c0 = t * ST_HS_RUN;                      // first output column (local) of this thread
+  if (c0 < ncol) {
     int32_t a = 0, b = 0, c = 0;
-    for (int i = 0; i <= 2 * r; i++) { a += sxx[t + i]; b += sxy[t + i]; c += syy[t + i]; }
-    const size_t o = (size_t)y * W + x;
-    hxx[o] = a; hxy[o] = b; hyy[o] = c;
+    for (int i = 0; i <= 2 * r; i++) { a += sxx[c0 + i]; b += sxy[c0 + i]; c += syy[c0 + i]; }
+    oa[0] = a; ob[0] = b; oc[0] = c;
+#pragma unroll
+    for (int k = 1; k < ST_HS_RUN; k++) {
+      // columns past the end of the row read stale LDS; those outputs are never stored
+      a += sxx[c0 + 2 * r + k] - sxx[c0 + k - 1]; b += sxy[c0 + 2 * r + k] - sxy[c0 + k - 1]; c += syy[c0 + 2 * r + k] - syy[c0 + k - 1];
+      oa[k] = a; ob[k] = b; oc[k] = c;
+    }
+  }
+  __syncthreads();                                   // every product has been consumed: reuse the arrays for the sums
+  if (c0 < ncol) {
+#pragma unroll
+    for (int k = 0; k < ST_HS_RUN; k++) { sxx[c0 + k] = oa[k]; sxy[c0 + k] = ob[k]; syy[c0 + k] = oc[k]; }
+  }
+  __syncthreads();
+  for (int i = t; i < ncol; i += 256) {
+    const size_t o = (size_t)y * W + x0 + i;
+    hxx[o] = sxx[i]; hxy[o] = sxy[i]; hyy[o] = syy[i];
     mask[o] = user_mask ? user_mask[o] : (uint8_t)255;
   }
 }
@@ -595,7 +617,7 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
   vo_prof_scope prof(c, VO_PROF_ST);
   const int W = c->width, H = c->height, r = prm->block_size / 2, B = c->batch;
   const vo_frame& F = c->fr[c->cur];
-  hipLaunchKernelGGL(k_st_sobel_hsum, dim3(vo_div_up(W, 256), H, B), dim3(256), 0, c->stream, F.img[0], c->lvl_px[0],
+  hipLaunchKernelGGL(k_st_sobel_hsum, dim3(vo_div_up(W, ST_HS_COLS), H, B), dim3(256), 0, c->stream, F.img[0], c->lvl_px[0],
                      c->lv[0].pitch, W, H, r, s->d_h, s->d_mask, d_user_mask, s->d_scalars, c->slab_seq);
   if (n_cur > 0) {
     disc_rows rows;
