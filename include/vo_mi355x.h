@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VO_ABI_VERSION 1
+#define VO_ABI_VERSION 2
 
 enum {
   VO_OK = 0,
@@ -70,6 +70,10 @@ typedef struct {
   double  gtol;              /* 1e-8 (scipy default) */
   double  lambda0;           /* initial Marquardt damping, 1e-4 */
   double  huber_delta;       /* 1.0 px */
+  double  lambda_min;        /* floor of the damping, 1e-3.  The reference fixes no gauge, so the normal equations
+                                have a 7-dimensional near-null space; without a floor the Nielsen schedule drives
+                                lambda to ~1e-5 after two good steps and then spends 4-6 iterations on rejected
+                                steps along the gauge directions before it has doubled its way back. */
 } vo_ba_params;
 
 typedef struct {

@@ -229,8 +229,9 @@ def lm_step(ne, lam):
 
 
 def solve(K, poses0, points0, obs, max_iters=50, lam0=1e-4, ftol=1e-3, xtol=1e-3, gtol=1e-8,
-          delta=HUBER_DELTA, trace=None):
-    """Levenberg-Marquardt with Nielsen damping.  One 'iteration' = linearise at the current x,
+          delta=HUBER_DELTA, trace=None, lam_min=1e-3):
+    """Levenberg-Marquardt with Nielsen damping and a damping floor `lam_min` (the reference fixes no gauge: without a
+    floor lambda decays to ~1e-5 and the solver then burns iterations on rejected steps along the 7 gauge directions).  One 'iteration' = linearise at the current x,
     solve one damped step, evaluate the trial cost, accept/reject -- exactly the GPU's loop.
     status: 1 gtol, 2 ftol, 3 xtol, 0 max_iters, 4 damping overflow."""
     poses, points = np.array(poses0, np.float64), np.array(points0, np.float64)
@@ -257,7 +258,7 @@ def solve(K, poses0, points0, obs, max_iters=50, lam0=1e-4, ftol=1e-3, xtol=1e-3
             poses, points, F = tp, tl, Ft
             n_acc += 1
             lam = lam * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3); nu = 2.0
-            lam = max(lam, 1e-12)
+            lam = max(lam, lam_min)
             if dF < ftol * F:
                 status = 2
                 break

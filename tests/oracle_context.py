@@ -61,12 +61,13 @@ class OracleContext:
             e.append(np.linalg.norm(uv - p[:, :2] / p[:, 2:3], axis=1))
         return X4, depth1, (e[0] + e[1]) / 2
 
-    def ba_params(self, max_iters=50, ftol=1e-3, xtol=1e-3, gtol=1e-8, lambda0=1e-4, huber_delta=1.0):
-        return SimpleNamespace(max_iters=max_iters, ftol=ftol, xtol=xtol, gtol=gtol, lambda0=lambda0, huber_delta=huber_delta)
+    def ba_params(self, max_iters=50, ftol=1e-3, xtol=1e-3, gtol=1e-8, lambda0=1e-4, huber_delta=1.0, lambda_min=1e-3):
+        return SimpleNamespace(max_iters=max_iters, ftol=ftol, xtol=xtol, gtol=gtol, lambda0=lambda0, huber_delta=huber_delta,
+                               lambda_min=lambda_min)
 
     def ba_adjust(self, K, poses, points, obs, params=None):
         prm = params or self.ba_params()
         r = bo.solve(K, poses, points, obs, max_iters=prm.max_iters, lam0=prm.lambda0, ftol=prm.ftol, xtol=prm.xtol,
-                     gtol=prm.gtol, delta=prm.huber_delta)
+                     gtol=prm.gtol, delta=prm.huber_delta, lam_min=prm.lambda_min)
         return r["poses"], r["points"], dict(cost0=r["cost0"], cost=r["cost"], lam=r["lam"], iters=r["iters"],
                                              accepted=r["accepted"], status=r["status"], n_obs=int(bo.valid_mask(obs).sum()))

@@ -88,7 +88,7 @@ for it in range(1, 31):
         dF = F - Ft
         poses, pts, F = poses + dpw, tpts, Ft
         n_acc += 1
-        lam = max(lam * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), 1e-12); nu = 2.0
+        lam = max(lam * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), 1e-3); nu = 2.0
         if dF < ftol * F:
             status = 2
             break

@@ -26,13 +26,13 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libvo_mi355x.so does not export %s" % n
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert _lib.load().vo_abi_version() == 1
+    assert _lib.load().vo_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
     from vo_mi355x import _lib
     assert ctypes.sizeof(_lib.KltParams) == 32 and ctypes.sizeof(_lib.StParams) == 24
-    assert ctypes.sizeof(_lib.BaParams) == 48 and ctypes.sizeof(_lib.BaStats) == 40
+    assert ctypes.sizeof(_lib.BaParams) == 56 and ctypes.sizeof(_lib.BaStats) == 40
     L = _lib.load()
     k = _lib.KltParams(); L.vo_klt_default_params(ctypes.byref(k))
     assert (k.win, k.max_level, k.max_count) == (31, 3, 30) and abs(k.epsilon - 0.03) < 1e-15

@@ -63,7 +63,7 @@ struct ba_info {            // written by k_ba_solve for the iteration
 };
 
 struct ba_params_dev {
-  double ftol, xtol, gtol, lambda0, delta;
+  double ftol, xtol, gtol, lambda0, lambda_min, delta;
   int max_iters;
 };
 
@@ -326,7 +326,7 @@ __device__ inline void ba_decide(const ba_state& in, const ba_info& info, const 
     double f = 1.0 - q * q * q;
     if (f < 1.0 / 3.0) f = 1.0 / 3.0;
     double lam = in.lambda * f;
-    if (lam < 1e-12) lam = 1e-12;
+    if (lam < prm.lambda_min) lam = prm.lambda_min;
     out.lambda = lam; out.nu = 2.0;
     if ((F - Ft) < prm.ftol * Ft) { out.done = 1; out.status = 2; }
     else if (step < prm.xtol * (prm.xtol + xn)) { out.done = 1; out.status = 3; }
@@ -1044,7 +1044,7 @@ bool vo_ba_ready(const vo_ctx* c) { return c->ba && c->ba->uploaded; }
 
 extern "C" int32_t vo_ba_default_params(vo_ba_params* p) {
   if (!p) return VO_E_INVALID;
-  p->max_iters = 50; p->_pad = 0; p->ftol = 1e-3; p->xtol = 1e-3; p->gtol = 1e-8; p->lambda0 = 1e-4; p->huber_delta = 1.0;
+  p->max_iters = 50; p->_pad = 0; p->ftol = 1e-3; p->xtol = 1e-3; p->gtol = 1e-8; p->lambda0 = 1e-4; p->huber_delta = 1.0; p->lambda_min = 1e-3;
   return VO_OK;
 }
 
@@ -1138,6 +1138,7 @@ static ba_ptrs ba_make_ptrs_dbg(vo_ctx* c) { ba_ptrs P = ba_make_ptrs(c); P.dbg 
 static ba_params_dev ba_dev_params(const vo_ba_params* p) {
   ba_params_dev d;
   d.ftol = p->ftol; d.xtol = p->xtol; d.gtol = p->gtol; d.lambda0 = p->lambda0; d.delta = p->huber_delta;
+  d.lambda_min = (p->lambda_min > 1e-12) ? p->lambda_min : 1e-12;
   d.max_iters = p->max_iters;
   return d;
 }

@@ -37,7 +37,7 @@ class StParams(C.Structure):
 
 class BaParams(C.Structure):
     _fields_ = [("max_iters", C.c_int32), ("_pad", C.c_int32), ("ftol", C.c_double), ("xtol", C.c_double),
-                ("gtol", C.c_double), ("lambda0", C.c_double), ("huber_delta", C.c_double)]
+                ("gtol", C.c_double), ("lambda0", C.c_double), ("huber_delta", C.c_double), ("lambda_min", C.c_double)]
 
 
 class BaStats(C.Structure):

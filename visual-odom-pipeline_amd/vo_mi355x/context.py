@@ -320,10 +320,11 @@ class VoContext:
         return out
 
     # -- BA -------------------------------------------------------------------------------------
-    def ba_params(self, max_iters=50, ftol=1e-3, xtol=1e-3, gtol=1e-8, lambda0=1e-4, huber_delta=1.0):
+    def ba_params(self, max_iters=50, ftol=1e-3, xtol=1e-3, gtol=1e-8, lambda0=1e-4, huber_delta=1.0, lambda_min=1e-3):
         p = BaParams()
         self._L.vo_ba_default_params(C.byref(p))
         p.max_iters, p.ftol, p.xtol, p.gtol, p.lambda0, p.huber_delta = max_iters, ftol, xtol, gtol, lambda0, huber_delta
+        p.lambda_min = lambda_min
         return p
 
     @staticmethod
