@@ -38,12 +38,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--seqs", type=int, default=64, help="independent sequences per GPU")
-    ap.add_argument("--ctxs", type=int, default=2, help="batched contexts (HIP streams) the sequences are split over")
+    ap.add_argument("--seqs", type=int, default=96, help="independent sequences per GPU")
+    ap.add_argument("--ctxs", type=int, default=3, help="batched contexts (HIP streams) the sequences are split over")
     ap.add_argument("--ba-iters", type=int, default=10, help="LM iteration budget per adjust")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames per sequence (played ping-pong)")
     ap.add_argument("--graph", action="store_true", help="replay each frame from a captured hipGraph instead of plain launches")
-    ap.add_argument("--host-threads", type=int, default=2, help="enqueue/fetch the contexts from this many host threads")
+    ap.add_argument("--host-threads", type=int, default=3, help="enqueue/fetch the contexts from this many host threads")
     ap.add_argument("--fixed-ba-budget", action="store_true",
                     help="always enqueue --ba-iters LM iterations (default: last frame's iteration count + 2, capped)")
     ap.add_argument("--workload", choices=("A", "config5"), default="A",
