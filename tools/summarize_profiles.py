@@ -66,7 +66,7 @@ if means:
         wr = means["WRITE_SIZE"][k][0] if "WRITE_SIZE" in means else 0.0
         json.dump({
             "kernel": k,
-            "config": "bench.py default: 64 sequences in 2 batched contexts (one launch tracks 32 sequences x 2000 points)",
+            "config": "one k_klt_track launch of a batched context: 32 sequences x 2000 points (bench.py default: 96 sequences in 3 such contexts)",
             "fetch_size_kb_per_launch": 2 * fe,
             "write_size_kb_per_launch": wr,
             "hbm_bytes_per_launch": int((2 * fe + wr) * 1024),
