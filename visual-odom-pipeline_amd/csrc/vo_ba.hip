@@ -34,6 +34,7 @@
 #include "vo_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 // The library is built with -ffp-contract=off because the float32 front end (KLT update, Shi-Tomasi, DLT output) must
@@ -1054,6 +1055,7 @@ static void ba_geometry(vo_ba_ws* b, int W, int N) {
   // workgroup size: 256 lanes (more workgroups -> more CUs, less contention on the f64 pipes) unless that would
   // produce more than 160 partial sets, then 1024
   b->tpb = (vo_div_up(N, 256 / b->LPP) <= 160) ? 256 : 1024;
+  if (const char* e = getenv("VO_BA_TPB")) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) b->tpb = t; }   // experiment knob
   b->PPB = b->tpb / b->LPP;
   b->nblk = vo_div_up(N, b->PPB);
   b->RP = ((6 * W + 1 + 15) / 16) * 16; b->RT = b->RP / 16; b->n_tiles = b->RT * (b->RT + 1) / 2;
@@ -1107,6 +1109,7 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     VO_HIP(c, hipHostMalloc((void**)&b->h_state, sizeof(ba_state) * B, hipHostMallocDefault));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   }
   ba_geometry(c->ba, W, N);
@@ -1167,6 +1170,7 @@ static int32_t ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& 
   vo_ba_ws* b = c->ba;
   const int B = c->batch;
   if (b->tpb == 256) hipLaunchKernelGGL(k_ba_build<256>, dim3(b->nblk, B), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
+  else if (b->tpb == 512) hipLaunchKernelGGL(k_ba_build<512>, dim3(b->nblk, B), dim3(512), b->build_lds, c->stream, P, prm, it, probe_lambda);
   else hipLaunchKernelGGL(k_ba_build<1024>, dim3(b->nblk, B), dim3(1024), b->build_lds, c->stream, P, prm, it, probe_lambda);
   hipLaunchKernelGGL(k_ba_reduce, dim3(vo_div_up(b->n_tiles * 256 + b->W * BA_POSE_VALS + 1, 64), B), dim3(256), 0, c->stream, P, it);
   if (P.sharded) {
@@ -1177,6 +1181,7 @@ static int32_t ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& 
   }
   hipLaunchKernelGGL(k_ba_solve, dim3(B), dim3(BA_SOLVE_THREADS), b->solve_lds, c->stream, P, prm, it, probe_S, hpp_out);
   if (b->tpb == 256) hipLaunchKernelGGL(k_ba_update<256>, dim3(b->nblk, B), dim3(256), 0, c->stream, P, prm, it, probe_dl);
+  else if (b->tpb == 512) hipLaunchKernelGGL(k_ba_update<512>, dim3(b->nblk, B), dim3(512), 0, c->stream, P, prm, it, probe_dl);
   else hipLaunchKernelGGL(k_ba_update<1024>, dim3(b->nblk, B), dim3(1024), 0, c->stream, P, prm, it, probe_dl);
   if (P.sharded) {
     // exchange 2: the 4 step statistics the next decision needs
