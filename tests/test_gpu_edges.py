@@ -1,0 +1,85 @@
+"""GPU: error behaviour of the C ABI (codes + messages, no crash, context stays usable) and degenerate problem shapes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_error_codes_and_context_survives():
+    from vo_mi355x import VoContext, VoError, synthetic as syn
+    frames, _ = syn.make_sequence(2, w=320, h=240, seed=1, margin=48)
+    pts = syn.grid_points(100, 320, 240, seed=1)
+    with VoContext(320, 240, max_pts=128) as c:
+        with pytest.raises(VoError) as e:
+            c.klt_track(pts)                                   # no frames yet
+        assert e.value.code == -4 and "two pushed frames" in str(e.value)       # VO_E_STATE
+        c.push_frame(frames[0])
+        with pytest.raises(VoError) as e:
+            c.klt_track(pts)                                   # one frame only
+        assert e.value.code == -4
+        c.push_frame(frames[1])
+        with pytest.raises(VoError) as e:
+            c.klt_track(syn.grid_points(200, 320, 240))        # more points than max_pts
+        assert e.value.code == -5                              # VO_E_CAPACITY
+        with pytest.raises(VoError) as e:
+            c.klt_track(pts, c.klt_params(win=32))             # even / too large window
+        assert e.value.code == -1                              # VO_E_INVALID
+        with pytest.raises(VoError) as e:
+            c.frame_step_resident(0, 100)                      # no resident sequence
+        assert e.value.code == -4
+        with pytest.raises(VoError) as e:
+            c.ba_solve_resident()                              # nothing uploaded
+        assert e.value.code == -4
+        s = syn.make_ba_scene(n_pts=50, n_slots=21, seed=0)
+        with pytest.raises(VoError) as e:
+            c.ba_adjust(s["K"], s["poses0"], s["points0"], s["obs"])             # window > 20 slots
+        assert e.value.code == -5
+        with pytest.raises(VoError) as e:
+            c.set_prefilter(9, 1.5, 1.5)                       # diameter > 7
+        assert e.value.code == -5
+        # the context is still good
+        p1, st, err = c.klt_track(pts)
+        assert st.sum() > 90
+        p_empty, st_empty, err_empty = c.klt_track(np.zeros((0, 2), np.float32))
+        assert p_empty.shape == (0, 2) and st_empty.shape == (0,)
+    with pytest.raises(VoError):
+        VoContext(320, 240, device=99)                         # no such device: fails loudly, no fallback
+
+
+def test_ba_degenerate_shapes():
+    import ba_oracle as bo
+    from vo_mi355x import VoContext, synthetic as syn
+    with VoContext(64, 64, max_pts=64) as c:
+        # one landmark, two frames; a landmark seen once; a frame that sees nothing; zero iterations
+        s = syn.make_ba_scene(n_pts=1, n_slots=2, seed=3)
+        po, pt, st = c.ba_adjust(s["K"], s["poses0"], s["points0"], s["obs"], c.ba_params(max_iters=8))
+        ref = bo.solve(s["K"], s["poses0"], s["points0"], s["obs"], max_iters=8)
+        assert st["iters"] == ref["iters"] and abs(st["cost"] - ref["cost"]) <= 1e-9 * max(ref["cost"], 1e-12) + 1e-15
+        s = syn.make_ba_scene(n_pts=40, n_slots=5, seed=4)
+        obs = s["obs"].copy()
+        obs[1:, 7] = np.nan            # landmark 7 observed once
+        obs[:, 9] = np.nan             # landmark 9 never observed
+        obs[3] = np.nan                # slot 3 observes nothing
+        po, pt, st = c.ba_adjust(s["K"], s["poses0"], s["points0"], obs, c.ba_params(max_iters=10))
+        ref = bo.solve(s["K"], s["poses0"], s["points0"], obs, max_iters=10)
+        assert st["n_obs"] == int((~np.isnan(obs[..., 0])).sum())
+        assert (st["iters"], st["status"]) == (ref["iters"], ref["status"]) and abs(st["cost"] - ref["cost"]) <= 1e-7 * ref["cost"]
+        assert np.array_equal(pt[9], s["points0"][9]) and np.array_equal(po[3], s["poses0"][3])   # untouched: no information
+        assert np.isfinite(po).all() and np.isfinite(pt).all()
+        po0, pt0, st0 = c.ba_adjust(s["K"], s["poses0"], s["points0"], obs, c.ba_params(max_iters=0))
+        assert np.array_equal(po0, s["poses0"]) and np.array_equal(pt0, s["points0"]) and st0["iters"] == 0
+
+
+def test_klt_points_outside_and_on_the_border():
+    import vo_oracle as o
+    from vo_mi355x import VoContext, synthetic as syn
+    w, h = 320, 240
+    frames, _ = syn.make_sequence(2, w=w, h=h, seed=8, margin=48)
+    pts = np.array([[-40.0, 10.0], [0.0, 0.0], [w - 1.0, h - 1.0], [w + 50.0, h / 2], [w / 2, -33.0], [5.5, h - 0.25],
+                    [1e6, 1e6], [-1e6, 12.0], [w / 2, h / 2]], np.float32)
+    with VoContext(w, h, max_pts=64) as c:
+        c.push_frame(frames[0]); c.push_frame(frames[1])
+        p1, st, err, it = c.klt_track(pts, return_iters=True)
+        q1, qs, qe, qi = o.klt(frames[0], frames[1], pts, return_iters=True)
+        assert np.array_equal(p1, q1) and np.array_equal(st, qs) and np.array_equal(err, qe) and np.array_equal(it, qi)
+        assert st[0] == 0 and st[6] == 0 and st[-1] == 1
