@@ -5,9 +5,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_batched_context_equals_single_contexts():
+@pytest.mark.parametrize("B", [3, 8])     # 8: the XCD-aware KLT block mapping (batch % 8 == 0) is in effect
+def test_batched_context_equals_single_contexts(B):
     from vo_mi355x import VoContext, synthetic as syn
-    B, w, h, n, n_new = 3, 480, 200, 300, 120
+    w, h, n, n_new = 480, 200, 300, 120
     seqs = [syn.make_sequence(4, w=w, h=h, seed=60 + b, margin=64)[0] for b in range(B)]
     pts = [syn.grid_points(n, w, h, seed=10 + b, margin=8) for b in range(B)]
     scenes = [syn.make_ba_scene(n_pts=150 + 0 * b, n_slots=5, seed=30 + b, visibility=0.9) for b in range(B)]

@@ -34,6 +34,7 @@ struct klt_args {
   size_t slab_seq;        // byte stride between the sequences' point / status / err arrays
   size_t iters_seq;       // int32 stride between the sequences' iteration tables
   int top, win, max_count, n, iters_stride;
+  int xcd_remap;             // batch % 8 == 0: keep every sequence on ONE XCD (see k_klt_track)
   float min_eig;
   double eps2;
 };
@@ -119,10 +120,19 @@ template <int WAVES>
 __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float* __restrict__ p0, float* __restrict__ p1,
                                                   uint8_t* __restrict__ status, float* __restrict__ err,
                                                   int32_t* __restrict__ iters, unsigned long long* __restrict__ dbg) {
-  const int pt = blockIdx.x;
+  // Workgroups are dealt to the 8 XCDs round-robin in dispatch order and every XCD has its own 4 MB L2.  With the
+  // plain (point, sequence) grid all XCDs work on the same sequence and each pulls its own copy of that pyramid
+  // (3.7 MB) from HBM / MALL -- 8x the bytes.  Remapped, XCD k tracks sequences k, k + 8, ... on its own: one
+  // sequence's pyramids fit its L2 and cross the fabric once.
+  int pt = blockIdx.x, bseq = blockIdx.y;
+  if (A.xcd_remap) {
+    const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned q = id >> 3;
+    bseq = (int)(id & 7u) + 8 * (int)(q / (unsigned)A.n);
+    pt = (int)(q % (unsigned)A.n);
+  }
   if (pt >= A.n) return;
   const int lane = threadIdx.x;
-  const int bseq = blockIdx.y;            // sequence of the batch
   p0 = vo_seq(p0, A.slab_seq, bseq); p1 = vo_seq(p1, A.slab_seq, bseq);
   status = vo_seq(status, A.slab_seq, bseq); err = vo_seq(err, A.slab_seq, bseq);
   if (iters) iters += (size_t)bseq * A.iters_seq;
@@ -318,6 +328,7 @@ static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, size_t off
     A.lv[l].w = c->lv[l].w; A.lv[l].h = c->lv[l].h; A.lv[l].pitch = c->lv[l].pitch;
   }
   A.top = top; A.win = prm->win;
+  { static const int remap = getenv("VO_KLT_XCD_REMAP") ? atoi(getenv("VO_KLT_XCD_REMAP")) : 1; A.xcd_remap = (remap && c->batch % 8 == 0) ? 1 : 0; }
   int mc = prm->max_count; if (mc < 0) mc = 0; if (mc > 100) mc = 100;
   double eps = prm->epsilon; if (eps < 0) eps = 0; if (eps > 10) eps = 10;
   A.max_count = mc; A.eps2 = eps * eps; A.min_eig = prm->min_eig_threshold; A.n = n;
