@@ -14,6 +14,23 @@ struct vo_dlt_cam {          // per sequence
   double H1z[4];           // third row of H1
 };
 
+// 1/sqrt(x) and 1/x from the hardware estimates + two Newton steps (relative error ~1e-16): the IEEE-exact sqrt / divide
+// expansions are ~30 dependent f64 instructions each and a Jacobi rotation needs three of each; the kernel is one long
+// dependent chain per point (500 waves on 1024 SIMDs), so their latency IS the run time.  Parity here is by tolerance
+// (1e-4 relative on X), not bit-exact.
+__device__ __forceinline__ double dlt_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * y, y, 1.0);
+  y = fma(0.5 * y, e, y);
+  e = fma(-x * y, y, 1.0);
+  return fma(0.5 * y, e, y);
+}
+__device__ __forceinline__ double dlt_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return fma(fma(-x, y, 1.0), y, y);
+}
+
 // grid (ceil(n / 64), batch)
 __global__ void __launch_bounds__(64) k_dlt(const vo_dlt_cam* __restrict__ cams, int n, int want_stats, size_t uv_seq,
                                             size_t slab_seq, const float* __restrict__ uv0, const float* __restrict__ uv1,
@@ -47,11 +64,13 @@ __global__ void __launch_bounds__(64) k_dlt(const vo_dlt_cam* __restrict__ cams,
         double al = 0, be = 0, ga = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) { al += U[k][p] * U[k][p]; be += U[k][q] * U[k][q]; ga += U[k][p] * U[k][q]; }
-        if (fabs(ga) > 2.220446049250313e-16 * sqrt(al * be)) {
+        // |ga| > eps sqrt(al be)  <=>  ga^2 > eps^2 al be  (no square root in the test)
+        if (ga * ga > 4.930380657631324e-32 * (al * be)) {
           changed = true;
-          const double zeta = (be - al) / (2.0 * ga);
-          const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-          const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+          const double zeta = (be - al) * (0.5 * dlt_rcp(ga));
+          const double z2 = 1.0 + zeta * zeta;
+          const double t = (zeta >= 0 ? 1.0 : -1.0) * dlt_rcp(fabs(zeta) + z2 * dlt_rsqrt(z2));
+          const double c = dlt_rsqrt(1.0 + t * t), s = c * t;
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const double up = U[k][p], uq = U[k][q];
