@@ -62,6 +62,8 @@ class Dist:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if "VO_BENCH_FORCE_DEVICE" in os.environ:      # plumbing tests: several ranks on one GPU
+            self.local_rank = int(os.environ["VO_BENCH_FORCE_DEVICE"])
         self.td = None
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
