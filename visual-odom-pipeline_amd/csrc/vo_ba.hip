@@ -742,21 +742,25 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
         for (int d = 0; d < 6; d++) D[c][d] = (d <= c) ? A[(size_t)(c0 + d) * PT + c0 + c] : 0.0;
 #pragma unroll
       for (int c = 0; c < 6; c++) x[c] = (r >= c0 + c) ? A[(size_t)(c0 + c) * PT + r] : 0.0;
+      // RIGHT-LOOKING inside the block: as soon as column c is known it is subtracted from everything to its right,
+      // so every pivot waits for one FMA after the previous column instead of a c-term dot product (a dependent f64
+      // op costs ~30 cycles for a lone wave; this chain is the critical path of the whole kernel).  The row x
+      // (this thread's row of the panel below / inside the block) is eliminated the same way.
       bool bad = false;
 #pragma unroll
       for (int c = 0; c < 6; c++) {
         double s = D[c][c];
-#pragma unroll
-        for (int d = 0; d < c; d++) s -= D[c][d] * D[c][d];
         if (!(s > 0)) { bad = true; s = 1.0; }
         const double rs = rsqrt_nr(s);
-        D[c][c] = s * rs; inv[c] = rs;
+        inv[c] = rs;
+        x[c] *= rs;
+#pragma unroll
+        for (int e = c + 1; e < 6; e++) D[e][c] *= rs;
 #pragma unroll
         for (int e = c + 1; e < 6; e++) {
-          double t = D[e][c];
+          x[e] -= x[c] * D[e][c];
 #pragma unroll
-          for (int d = 0; d < c; d++) t -= D[e][d] * D[c][d];
-          D[e][c] = t * rs;
+          for (int f = c + 1; f <= e; f++) D[e][f] -= D[e][c] * D[f][c];
         }
       }
       if (bad && tid == 0) s_fail = 1;
@@ -764,16 +768,11 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
 #pragma unroll
         for (int c = 0; c < 6; c++) s_invd[c0 + c] = inv[c];
       }
-      // x L_kk^T = a  (forward substitution along the row).  The rows of the diagonal block itself take the same
-      // path: for them it reproduces the factor's own row operation for operation (only the lower part is stored).
+      // store the row (for the rows of the diagonal block itself only the lower part: there x reproduces the factor's
+      // own row, operation for operation)
 #pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double t = x[c];
-#pragma unroll
-        for (int d = 0; d < c; d++) t -= x[d] * D[c][d];
-        x[c] = t * inv[c];
+      for (int c = 0; c < 6; c++)
         if (r >= c0 + c) A[(size_t)(c0 + c) * PT + r] = x[c];
-      }
     }
     __syncthreads();
     const int s0 = c0 + 6, m = n1 - s0;
@@ -797,31 +796,34 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
     double y1 = (lane + 64 < n) ? A[(size_t)(lane + 64) * PT + n] : 0.0;
     for (int kb = W - 1; kb >= 0; kb--) {
       const int c0 = 6 * kb;
+      // every LDS operand of this block first (none depends on the running y): the diagonal block's 15 sub-diagonal
+      // entries + 6 inverse pivots (wave-uniform addresses) and this lane's 2 x 6 column entries
+      double Lk[6][6], iv[6], ca[6], cb[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        iv[c] = s_invd[c0 + c];
+#pragma unroll
+        for (int e = c + 1; e < 6; e++) Lk[e][c] = A[(size_t)(c0 + c) * PT + c0 + e];
+        ca[c] = (lane < c0) ? A[(size_t)lane * PT + c0 + c] : 0.0;
+        cb[c] = (lane + 64 < c0) ? A[(size_t)(lane + 64) * PT + c0 + c] : 0.0;
+      }
       double yb[6], d[6];
 #pragma unroll
       for (int c = 0; c < 6; c++) {
         const int k = c0 + c;
         yb[c] = (k < 64) ? readlane_f64(y0, k & 63) : readlane_f64(y1, k & 63);
       }
-      // solve L_kk^T d = yb  (L_kk[e][c] = A[(c0 + c) * PT + c0 + e], e >= c)
+      // solve L_kk^T d = yb
 #pragma unroll
       for (int c = 5; c >= 0; c--) {
         double t = yb[c];
 #pragma unroll
-        for (int e = 5; e > c; e--) t -= A[(size_t)(c0 + c) * PT + c0 + e] * d[e];
-        d[c] = t * s_invd[c0 + c];
+        for (int e = 5; e > c; e--) t -= Lk[e][c] * d[e];
+        d[c] = t * iv[c];
       }
-      // rows above the block: y_i -= sum_c L[c0 + c][i] d_c,  L[k][i] = A[i * PT + k]
-      if (lane < c0) {
-        const double* col = A + (size_t)lane * PT + c0;
+      // rows above the block: y_i -= sum_c L[c0 + c][i] d_c
 #pragma unroll
-        for (int c = 0; c < 6; c++) y0 -= col[c] * d[c];
-      }
-      if (lane + 64 < c0) {
-        const double* col = A + (size_t)(lane + 64) * PT + c0;
-#pragma unroll
-        for (int c = 0; c < 6; c++) y1 -= col[c] * d[c];
-      }
+      for (int c = 0; c < 6; c++) { y0 -= ca[c] * d[c]; y1 -= cb[c] * d[c]; }
 #pragma unroll
       for (int c = 0; c < 6; c++) {
         const int k = c0 + c;
