@@ -81,6 +81,7 @@ struct ba_ptrs {
   // per-problem strides (elements) of the batched buffers
   size_t s_obs, s_x, s_aux, s_posepart, s_gmax, s_tiles, s_dp, s_evalpart, s_tilesum, s_posesum, s_cams;
   int W, N, LPP, PPB, nblk, RP, RT, n_tiles, pitch;
+  int cam_off;                        // k_ba_build: offset (doubles) of the staged cameras inside the dynamic LDS
   int sharded, rank, n_ranks, batch;  // sharded: the batch entries (x the ranks) are landmark shards of one problem
 };
 
@@ -102,6 +103,7 @@ struct vo_ba_ws {
   int W = 0, N = 0, LPP = 0, PPB = 0, nblk = 0, RP = 0, RT = 0, n_tiles = 0, pitch = 0, tpb = 0;
   int cap_W = 0, cap_N = 0;
   size_t build_lds = 0, solve_lds = 0;
+  int cam_off = 0;
   double* d_K = nullptr;        // 9
   double* d_obs = nullptr;      // W*N*2
   double* d_x0 = nullptr;       // W*6 + N*3
@@ -355,7 +357,9 @@ template <int TPB>
 __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev prm, int it, double probe_lambda) {
   const ba_ptrs P = ba_select(Pall, blockIdx.y);
   extern __shared__ double dyn[];   // phase A: camera-sum scratch [wave][LPP][28]; phase B: Y^ panel [3 PPB][pitch]
-  __shared__ double s_cam[BA_CAM * BA_MAX_SLOTS];
+  // the staged cameras live behind the panel, sized by the actual window (W x 21 doubles): with a static 20-slot array
+  // the W = 10 kernel needed 34.3 KB of LDS -> 4 workgroups per CU; now 32.6 KB -> 5
+  double* s_cam = dyn + P.cam_off;
   __shared__ double s_K[9];
   __shared__ double s_gmax[(TPB / 64)];
   __shared__ ba_state s_st;
@@ -1065,6 +1069,8 @@ static void ba_geometry(vo_ba_ws* b, int W, int N) {
   const size_t panel = sizeof(double) * (size_t)3 * b->PPB * b->pitch;
   const size_t scratch = sizeof(double) * (size_t)(b->tpb / 64) * b->LPP * BA_POSE_VALS;
   b->build_lds = panel > scratch ? panel : scratch;
+  b->cam_off = (int)(b->build_lds / sizeof(double));
+  b->build_lds += sizeof(double) * (size_t)BA_CAM * W;
   const int n1 = 6 * W + 1, PT = n1 | 1;
   b->solve_lds = sizeof(double) * ((size_t)n1 * PT + (size_t)W * BA_POSE_VALS + n1 + n1 + 24) + sizeof(unsigned short) * ((size_t)n1 * (n1 + 1) / 2 + 8);
 }
@@ -1127,7 +1133,7 @@ static ba_ptrs ba_make_ptrs(const vo_ctx* c) {
   P.posepart = b->d_posepart; P.gmax = b->d_gmax; P.tiles = b->d_tiles; P.dp = b->d_dp; P.evalpart = b->d_evalpart;
   P.tilesum = b->d_tilesum; P.posesum = b->d_posesum; P.cams = b->d_cams; P.xstat = b->d_xstat;
   P.state = b->d_state; P.info = b->d_info; P.dbg = nullptr;
-  P.W = b->W; P.N = b->N; P.LPP = b->LPP; P.PPB = b->PPB; P.nblk = b->nblk; P.RP = b->RP; P.RT = b->RT;
+  P.W = b->W; P.N = b->N; P.LPP = b->LPP; P.PPB = b->PPB; P.nblk = b->nblk; P.cam_off = b->cam_off; P.RP = b->RP; P.RT = b->RT;
   P.n_tiles = b->n_tiles; P.pitch = b->pitch;
   // strides use the ALLOCATED capacity for N-dependent buffers? no: they are packed for the current problem size
   const size_t W = (size_t)b->W, N = (size_t)b->N;
