@@ -227,6 +227,30 @@ int32_t vo_comm_destroy(vo_ctx* ctx);
 int32_t vo_ba_set_sharded(vo_ctx* ctx, int32_t on);
 int32_t vo_ba_gather_points(vo_ctx* ctx, double* points_all);
 
+/* ---- device-resident track table (SURVEY.md 8f "next" row 3) -----------------------------------
+ * The bookkeeping Extractor.extend_tracks / extend_landmarks / extract do on Python lists of Keypoint objects
+ * (src/extractor/extractor.py:38-88, 90-132; src/state/keypoint.py:4-21), as a structure of arrays in HBM: per
+ * sequence an ORDERED list (survivors keep their order, detections are appended) of uv (the resident point set),
+ * uv_first, t_first, t_total, a stable tag, and a ring of the last 32 positions by absolute frame index.
+ *   vo_tracks_seed    initial tracks born at frame t (t_total = 1, history = [uv]);  pts [batch][n][2]
+ *   vo_tracks_track   KLT prev -> cur of every live track, then the reference's rule: keep iff 0 <= x <= W and
+ *                     0 <= y <= H (ends included; KLT status ignored, bidirectional test off: pipeline.py:98-100);
+ *                     survivors: uv, t_total + 1, history append; the others go to the dead list        (async)
+ *   vo_tracks_detect  exclusion discs at the live tracks + Shi-Tomasi on the current frame, up to max_new corners per
+ *                     sequence appended as tracks born at t (extractor.py:103-132)                      (async)
+ *   vo_tracks_read    synchronous read-back: n / n_dead [batch]; uv, uv_first [batch][max_pts][2]; t_first, t_total,
+ *                     tag, dead_tag [batch][max_pts]; any pointer may be NULL
+ *   vo_tracks_obs     the bundle adjuster's observation table of the live tracks (bundle_adjuster.py:150-158 with
+ *                     t_latest = t_now): obs [batch][window][max_pts][2] f64, slot s <-> frame t_now - s, NaN = not
+ *                     observed -- the layout vo_ba_upload / vo_ba_adjust take (N = max_pts)
+ * Counts differ per sequence of a batch; they stay on the device and the KLT / disc kernels skip the rest. */
+int32_t vo_tracks_seed(vo_ctx* ctx, const float* pts, int32_t n, int32_t t);
+int32_t vo_tracks_track(vo_ctx* ctx, int32_t t, const vo_klt_params* prm);
+int32_t vo_tracks_detect(vo_ctx* ctx, int32_t t, int32_t mask_radius, const vo_st_params* st, int32_t max_new);
+int32_t vo_tracks_read(vo_ctx* ctx, int32_t* n, float* uv, float* uv_first, int32_t* t_first, int32_t* t_total,
+                       int32_t* tag, int32_t* n_dead, int32_t* dead_tag);
+int32_t vo_tracks_obs(vo_ctx* ctx, int32_t t_now, int32_t window, double* obs);
+
 /* ---- fused per-frame step on resident data ---------------------------------------------------
  * One call enqueues the hot path of one frame in the order of Pipeline.step (src/pipeline/pipeline.py:92-167):
  * frame `frame_idx` of the uploaded sequence -> pyramid/Scharr -> KLT of the resident points -> [DLT of the

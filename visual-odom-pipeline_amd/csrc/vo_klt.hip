@@ -119,7 +119,8 @@ __device__ __forceinline__ int deriv1(uint32_t top, uint32_t bot, uint32_t wt, u
 template <int WAVES>
 __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float* __restrict__ p0, float* __restrict__ p1,
                                                   uint8_t* __restrict__ status, float* __restrict__ err,
-                                                  int32_t* __restrict__ iters, unsigned long long* __restrict__ dbg) {
+                                                  int32_t* __restrict__ iters, unsigned long long* __restrict__ dbg,
+                                                  const int32_t* __restrict__ counts) {
   // Workgroups are dealt to the 8 XCDs round-robin in dispatch order and every XCD has its own 4 MB L2.  With the
   // plain (point, sequence) grid all XCDs work on the same sequence and each pulls its own copy of that pyramid
   // (3.7 MB) from HBM / MALL -- 8x the bytes.  Remapped, XCD k tracks sequences k, k + 8, ... on its own: one
@@ -132,6 +133,7 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
     pt = (int)(q % (unsigned)A.n);
   }
   if (pt >= A.n) return;
+  if (counts && pt >= counts[bseq]) return;          // track table: this sequence has fewer live points
   const int lane = threadIdx.x;
   p0 = vo_seq(p0, A.slab_seq, bseq); p1 = vo_seq(p1, A.slab_seq, bseq);
   status = vo_seq(status, A.slab_seq, bseq); err = vo_seq(err, A.slab_seq, bseq);
@@ -307,7 +309,7 @@ extern "C" int32_t vo_klt_default_params(vo_klt_params* p) {
   return VO_OK;
 }
 
-static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, size_t off_in, size_t off_out) {
+static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, size_t off_in, size_t off_out, const int32_t* counts) {
   VO_CHECK(c, c->n_pushed >= 2, VO_E_STATE, "need two pushed frames");
   VO_CHECK(c, n >= 0 && n <= c->max_pts, VO_E_CAPACITY, "n exceeds max_pts");
   VO_CHECK(c, prm && prm->win >= 3 && prm->win <= VO_MAX_WIN && (prm->win & 1), VO_E_INVALID, "win must be odd, 3..31");
@@ -342,7 +344,7 @@ static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, size_t off
     static const int waves = getenv("VO_KLT_WAVES") ? atoi(getenv("VO_KLT_WAVES")) : 5;
 #define VO_KLT_LAUNCH(WV) hipLaunchKernelGGL(k_klt_track<WV>, dim3(n, c->batch), dim3(64), 0, c->stream, A,                \
                        vo_slab<const float>(c, off_in), vo_slab<float>(c, off_out), vo_slab<uint8_t>(c, c->off_status),     \
-                       vo_slab<float>(c, c->off_err), c->d_iters, c->d_dbg)
+                       vo_slab<float>(c, c->off_err), c->d_iters, c->d_dbg, counts)
     if (waves <= 4) VO_KLT_LAUNCH(4); else if (waves == 5) VO_KLT_LAUNCH(5); else VO_KLT_LAUNCH(6);
 #undef VO_KLT_LAUNCH
   }
@@ -369,7 +371,7 @@ extern "C" int32_t vo_klt_track(vo_ctx* c, const float* p0, int32_t n, const vo_
   VO_HIP(c, hipSetDevice(c->device));
   const size_t off_in = vo_off_p(c), off_out = vo_off_p_next(c);
   VO_HIP(c, slab_h2d(c, off_in, p0, sizeof(float) * 2 * n));
-  int32_t r = klt_launch(c, n, prm, off_in, off_out);
+  int32_t r = klt_launch(c, n, prm, off_in, off_out, nullptr);
   if (r != VO_OK) return r;
   VO_HIP(c, slab_d2h(c, p1, off_out, sizeof(float) * 2 * n));
   VO_HIP(c, slab_d2h(c, status, c->off_status, n));
@@ -417,7 +419,7 @@ extern "C" int32_t vo_klt_track_resident(vo_ctx* c, int32_t n, const vo_klt_para
   if (!prm) { vo_klt_default_params(&def); prm = &def; }
   VO_CHECK(c, n >= 0 && n <= c->n_resident, VO_E_INVALID, "n exceeds the resident point set");
   VO_HIP(c, hipSetDevice(c->device));
-  int32_t r = klt_launch(c, n, prm, vo_off_p(c), vo_off_p_next(c));
+  int32_t r = klt_launch(c, n, prm, vo_off_p(c), vo_off_p_next(c), c->d_pt_counts);   // track table: per-sequence counts
   if (r != VO_OK) return r;
   c->p_parity ^= 1;   // tracked positions become the resident set
   return VO_OK;

@@ -109,13 +109,14 @@ __global__ void __launch_bounds__(256) k_st_sobel_hsum(const uint8_t* __restrict
 
 // grid (blocks, batch); pts of sequence b at + b * pts_seq bytes
 __global__ void __launch_bounds__(256) k_st_discs(const float* __restrict__ pts, size_t pts_seq, int n, int radius, disc_rows rows,
-                                                  uint8_t* __restrict__ mask, int W, int H) {
+                                                  uint8_t* __restrict__ mask, int W, int H, const int32_t* __restrict__ counts) {
   const int nrows = 2 * radius + 1;
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= n * nrows) return;
   pts = vo_seq(pts, pts_seq, blockIdx.y);
   mask += (size_t)blockIdx.y * W * H;
   const int k = gid / nrows, dy = gid - k * nrows - radius;
+  if (counts && k >= counts[blockIdx.y]) return;
   const int cx = (int)pts[2 * k], cy = (int)pts[2 * k + 1];   // np.int32(): truncation toward zero
   const int y = cy + dy;
   if (y < 0 || y >= H) return;
@@ -607,7 +608,7 @@ extern "C" int32_t vo_st_default_params(vo_st_params* p) {
 
 // pts: sequence-0 pointer of the exclusion-disc centres, pts_seq: byte stride between sequences
 static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cur, int mask_radius, const uint8_t* d_user_mask,
-                         const vo_st_params* prm) {
+                         const vo_st_params* prm, const int32_t* counts) {
   VO_CHECK(c, c->n_pushed >= 1, VO_E_STATE, "no frame pushed");
   VO_CHECK(c, prm->block_size >= 1 && prm->block_size <= 31 && (prm->block_size & 1), VO_E_INVALID,
            "block_size must be odd, <= 31");
@@ -624,7 +625,7 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
     circle_rows(mask_radius, &rows);
     const int total = n_cur * (2 * mask_radius + 1);
     hipLaunchKernelGGL(k_st_discs, dim3(vo_div_up(total, 256), B), dim3(256), 0, c->stream, d_pts, pts_seq, n_cur, mask_radius,
-                       rows, s->d_mask, W, H);
+                       rows, s->d_mask, W, H, counts);
   }
   const double scale_d = 1.0 / ((double)(1 << 2) * prm->block_size * 255.0);
   const float sf = (float)scale_d;
@@ -681,7 +682,7 @@ extern "C" int32_t vo_shi_tomasi(vo_ctx* c, const float* cur_pts, int32_t n_cur,
     VO_HIP(c, hipMemcpy2DAsync(s->d_pts, pts_seq, cur_pts, sizeof(float) * 2 * n_cur, sizeof(float) * 2 * n_cur, c->batch,
                                hipMemcpyHostToDevice, c->stream));
   if (mask) VO_HIP(c, hipMemcpyAsync(s->d_user_mask, mask, (size_t)c->width * c->height * c->batch, hipMemcpyHostToDevice, c->stream));
-  r = st_launch(c, s->d_pts, pts_seq, n_cur, mask_radius, mask ? s->d_user_mask : nullptr, prm);
+  r = st_launch(c, s->d_pts, pts_seq, n_cur, mask_radius, mask ? s->d_user_mask : nullptr, prm, nullptr);
   if (r != VO_OK) return r;
   return st_fetch(c, out_pts, n_out);
 }
@@ -694,7 +695,7 @@ extern "C" int32_t vo_shi_tomasi_resident(vo_ctx* c, int32_t n_cur, int32_t mask
   VO_HIP(c, hipSetDevice(c->device));
   int32_t r = st_init(c);
   if (r != VO_OK) return r;
-  return st_launch(c, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq, n_cur, mask_radius, nullptr, prm);
+  return st_launch(c, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq, n_cur, mask_radius, nullptr, prm, c->d_pt_counts);
 }
 
 extern "C" int32_t vo_shi_tomasi_fetch(vo_ctx* c, float* out_pts, int32_t* n_out) {

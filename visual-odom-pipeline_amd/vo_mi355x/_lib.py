@@ -99,6 +99,11 @@ SIGNATURES = {
     "vo_comm_destroy": (C.c_int32, [_ctx]),
     "vo_ba_set_sharded": (C.c_int32, [_ctx, C.c_int32]),
     "vo_ba_gather_points": (C.c_int32, [_ctx, _f64p]),
+    "vo_tracks_seed": (C.c_int32, [_ctx, _f32p, C.c_int32, C.c_int32]),
+    "vo_tracks_track": (C.c_int32, [_ctx, C.c_int32, C.POINTER(KltParams)]),
+    "vo_tracks_detect": (C.c_int32, [_ctx, C.c_int32, C.c_int32, C.POINTER(StParams), C.c_int32]),
+    "vo_tracks_read": (C.c_int32, [_ctx, _i32p, _f32p, _f32p, _i32p, _i32p, _i32p, _i32p, _i32p]),
+    "vo_tracks_obs": (C.c_int32, [_ctx, C.c_int32, C.c_int32, _f64p]),
     "vo_ba_probe": (C.c_int32, [_ctx, C.c_double, C.c_double, _f64p, _i32p, _f64p, _f64p, _f64p, _f64p, _f64p,
                                 _f64p, _f64p, _f64p, _f64p]),
 }

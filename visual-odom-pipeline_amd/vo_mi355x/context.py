@@ -373,6 +373,42 @@ class VoContext:
         stats = [self._stats(st[b]) for b in range(B)]
         return self._out(po), self._out(pt), stats[0] if B == 1 else stats
 
+    # -- device-resident track table ------------------------------------------------------------
+    def tracks_seed(self, pts, t=0):
+        """Initial tracks born at frame t; pts (n,2) [(B,n,2)]."""
+        pts, n = self._npts(pts)
+        self._ck(self._L.vo_tracks_seed(self._h, ptr(pts, C.c_float), n, int(t)))
+
+    def tracks_track(self, t, params=None):
+        """KLT prev -> cur of every live track + the reference's pruning / bookkeeping (async)."""
+        prm = params if params is not None else self.klt_params()
+        self._ck(self._L.vo_tracks_track(self._h, int(t), C.byref(prm)))
+
+    def tracks_detect(self, t, mask_radius=7, params=None, max_new=1000):
+        """Shi-Tomasi re-detection around the live tracks; corners become tracks born at t (async)."""
+        prm = params if params is not None else self.st_params()
+        self._ck(self._L.vo_tracks_detect(self._h, int(t), int(mask_radius), C.byref(prm), int(max_new)))
+
+    def tracks_read(self):
+        """-> list (one dict per sequence; a dict if batch == 1) of uv, uv_first (n,2) f32, t_first, t_total, tag (n,),
+        dead_tag (n_dead,)."""
+        B, cap = self.batch, self.max_pts
+        n, nd = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        uv, uf = np.zeros((B, cap, 2), np.float32), np.zeros((B, cap, 2), np.float32)
+        tf, tt, tag, dead = (np.zeros((B, cap), np.int32) for _ in range(4))
+        i, f = C.c_int32, C.c_float
+        self._ck(self._L.vo_tracks_read(self._h, ptr(n, i), ptr(uv, f), ptr(uf, f), ptr(tf, i), ptr(tt, i), ptr(tag, i),
+                                        ptr(nd, i), ptr(dead, i)))
+        out = [dict(uv=uv[b, :n[b]].copy(), uv_first=uf[b, :n[b]].copy(), t_first=tf[b, :n[b]].copy(),
+                    t_total=tt[b, :n[b]].copy(), tag=tag[b, :n[b]].copy(), dead_tag=dead[b, :nd[b]].copy()) for b in range(B)]
+        return out[0] if B == 1 else out
+
+    def tracks_obs(self, t_now, window):
+        """BA observation table of the live tracks -> (B, window, max_pts, 2) f64 [(window, max_pts, 2) if batch == 1]."""
+        obs = np.zeros((self.batch, window, self.max_pts, 2))
+        self._ck(self._L.vo_tracks_obs(self._h, int(t_now), int(window), ptr(obs, C.c_double)))
+        return obs[0] if self.batch == 1 else obs
+
     # -- landmark-sharded BA of one problem (config 5) -------------------------------------------
     @staticmethod
     def comm_unique_id():
