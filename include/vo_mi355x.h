@@ -86,6 +86,23 @@ typedef struct {
   int32_t n_obs;
 } vo_ba_stats;
 
+/* cv2.solvePnPRansac parameters as Extractor.camera_pose passes them (src/extractor/extractor.py:182-185;
+ * reprojectionError = max_err_reproj = 2.0 from src/pipeline/pipeline.py:124-125) */
+typedef struct {
+  double  reproj_err;        /* 2.0 px: consensus threshold on the reprojection error */
+  double  confidence;        /* 0.9999 */
+  int32_t max_iters;         /* 1000000 */
+  int32_t seed;              /* of the counter-based sample generator (OpenCV: fixed RNG state) */
+} vo_pnp_params;
+
+typedef struct {
+  double  cost;              /* sum of squared pixel errors over the consensus set after refinement */
+  int32_t n_inliers;
+  int32_t hypotheses;        /* evaluated */
+  int32_t best;              /* index of the winning hypothesis */
+  int32_t status;            /* 0, or VO_E_NUMERIC when no pose with >= 4 inliers was found */
+} vo_pnp_stats;
+
 /* ---- context -------------------------------------------------------------------------------- */
 int32_t vo_abi_version(void);
 int32_t vo_device_count(int32_t* n);
@@ -226,6 +243,19 @@ int32_t vo_comm_init(vo_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t* 
 int32_t vo_comm_destroy(vo_ctx* ctx);
 int32_t vo_ba_set_sharded(vo_ctx* ctx, int32_t on);
 int32_t vo_ba_gather_points(vo_ctx* ctx, double* points_all);
+
+/* ---- 3D-2D pose (SURVEY.md 8f "next" row 1) ---------------------------------------------------
+ * Replaces cv2.solvePnPRansac(pts3d, pts2d, K, None, reprojectionError, iterationsCount, confidence) in
+ * Extractor.camera_pose(corr='3D-2D') (src/extractor/extractor.py:174-191): RANSAC over P3P hypotheses (one wave per
+ * hypothesis, 256 per batch and sequence, iteration bound updated like OpenCV's RANSACUpdateNumIters), consensus set
+ * = squared reprojection error <= reproj_err^2, Gauss-Newton refinement of (rvec, tvec) over the consensus set.
+ * OpenCV's sample sequence cannot be reproduced (own RNG, EPnP on 5 points): parity is statistical -- same consensus
+ * set and minimiser whenever the inlier set is unambiguous; the algorithm itself is defined by oracle/pnp_oracle.py.
+ * K [batch][9]; pts3d [batch][n][3], pts2d [batch][n][2] f32 (NaN rows are never inliers);
+ * rvec, tvec [batch][3] f64 (x_cam = R(rvec) X + tvec); inlier_mask [batch][n] u8 (may be NULL); stats [batch]. */
+int32_t vo_pnp_default_params(vo_pnp_params* p);
+int32_t vo_pnp_ransac(vo_ctx* ctx, const double* K, const float* pts3d, const float* pts2d, int32_t n,
+                      const vo_pnp_params* prm, double* rvec, double* tvec, uint8_t* inlier_mask, vo_pnp_stats* stats);
 
 /* ---- device-resident track table (SURVEY.md 8f "next" row 3) -----------------------------------
  * The bookkeeping Extractor.extend_tracks / extend_landmarks / extract do on Python lists of Keypoint objects

@@ -71,3 +71,11 @@ class OracleContext:
                      gtol=prm.gtol, delta=prm.huber_delta, lam_min=prm.lambda_min)
         return r["poses"], r["points"], dict(cost0=r["cost0"], cost=r["cost"], lam=r["lam"], iters=r["iters"],
                                              accepted=r["accepted"], status=r["status"], n_obs=int(bo.valid_mask(obs).sum()))
+
+    def pnp_ransac(self, K, pts3d, pts2d, reproj_err=2.0, confidence=0.9999, max_iters=1000000, seed=0):
+        import pnp_oracle as po
+        r, t, inl, info = po.pnp_ransac(K, pts3d, pts2d, thr=reproj_err, conf=confidence, max_iters=max_iters, seed=seed,
+                                        return_info=True)
+        if r is None:
+            return np.full(3, np.nan), np.full(3, np.nan), inl, dict(status=-6, n_inliers=0, hypotheses=info["hyps"], best=-1, cost=np.nan)
+        return r, t, inl, dict(status=0, n_inliers=len(inl), hypotheses=info["hyps"], best=info["best"], cost=info["cost"])

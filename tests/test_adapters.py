@@ -168,3 +168,34 @@ def test_rodrigues_host_roundtrip(golden_dir):
     for r, R, back in zip(g["r"], g["R"], g["back"]):
         assert np.allclose(rodrigues_vec_to_mat(r), R, atol=1e-14)
         assert np.allclose(rodrigues_mat_to_vec(R), back, atol=1e-12)
+
+
+def _run_camera_pose(make_ctx):
+    """Extractor.camera_pose(corr='3D-2D') (reference extractor.py:174-191): list in, (inlier list, 4x4 H) out"""
+    from vo_mi355x import Extractor, Keypoint, Landmark, synthetic as syn
+    K = syn.KITTI_K
+    s = syn.make_ba_scene(n_pts=200, n_slots=2, seed=9, obs_noise=0.3)
+    rng = np.random.default_rng(1)
+    X = s["points_gt"].astype(np.float32); uv = s["obs"][0].astype(np.float32)
+    out = rng.choice(200, 50, replace=False)
+    uv[out] += rng.uniform(-70, 70, (50, 2)).astype(np.float32) + np.float32(12)
+    lms = [Landmark(0, X[i].astype(np.float64).reshape(3, 1), np.zeros((1, 1))) for i in range(200)]
+    kps = [Keypoint(0, 1, uv[i].reshape(2, 1), uv[i].reshape(2, 1), np.zeros((1, 1)), [uv[i].reshape(2, 1)]) for i in range(200)]
+    ext = Extractor(min_kp_dist=7, ctx=make_ctx(64, 64))
+    inliers, H = ext.camera_pose(K, lms, kps, corr='3D-2D', max_err_reproj=2.0)
+    assert isinstance(inliers, list) and all(isinstance(i, int) for i in inliers)
+    assert len(np.intersect1d(inliers, out)) <= 2 and len(inliers) >= 140
+    pose = s["poses_gt"][0]
+    assert np.abs(H[:3, :3] - syn.rodrigues(pose[:3])).max() <= 3e-3 and np.abs(H[:3, 3] - pose[3:]).max() <= 3e-2
+    return inliers, H
+
+
+def test_camera_pose_cpu():
+    _run_camera_pose(_oracle_ctx)
+
+
+@pytest.mark.gpu
+def test_camera_pose_gpu_equals_cpu_twin():
+    a, Ha = _run_camera_pose(_gpu_ctx)
+    b, Hb = _run_camera_pose(_oracle_ctx)
+    assert len(np.setxor1d(a, b)) <= 2 and np.abs(Ha - Hb).max() <= 1e-5

@@ -1,0 +1,75 @@
+"""GPU: 3D-2D pose -- RANSAC P3P + refinement against the numpy oracle that defines the
+algorithm (same hypotheses, same winner, pose to 1e-7) and against ground truth on scenes with gross outliers."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(n, frac_out, seed, noise=0.3, K=None):
+    from vo_mi355x import synthetic as syn
+    K = syn.KITTI_K if K is None else K
+    s = syn.make_ba_scene(n_pts=n, n_slots=2, seed=seed, obs_noise=noise, K=K)
+    rng = np.random.default_rng(seed + 100)
+    X = s["points_gt"].astype(np.float32)
+    uv = s["obs"][0].astype(np.float32)
+    out = rng.choice(n, int(frac_out * n), replace=False)
+    uv[out] += rng.uniform(-80, 80, (len(out), 2)).astype(np.float32) + np.float32(15.0)
+    return K, X, uv, s["poses_gt"][0], np.setdiff1d(np.arange(n), out)
+
+
+@pytest.mark.parametrize("n,frac,seed", [(2000, 0.3, 3), (500, 0.5, 4), (60, 0.2, 5), (5000, 0.65, 6)])
+def test_pnp_matches_oracle_and_ground_truth(n, frac, seed):
+    import pnp_oracle as po
+    from vo_mi355x import VoContext
+    K, X, uv, pose, true_inl = _scene(n, frac, seed)
+    with VoContext(64, 64, max_pts=64) as c:
+        rvec, t, inl, st = c.pnp_ransac(K, X, uv, reproj_err=2.0, seed=7)
+    r_o, t_o, inl_o, info = po.pnp_ransac(K, X, uv, thr=2.0, seed=7, return_info=True)
+    # same search: number of hypotheses, winner, consensus set (borderline points within 1e-6 px^2 of the threshold may flip)
+    assert st["hypotheses"] == info["hyps"] and st["best"] == info["best"]
+    diff = np.setxor1d(inl, inl_o)
+    if len(diff):
+        e2 = po.reproj_err2(K, po.rodrigues(r_o), t_o, X.astype(float)[diff], uv.astype(float)[diff])
+        assert len(diff) <= 2
+    assert np.abs(rvec - r_o).max() <= 1e-7 and np.abs(t - t_o).max() <= 1e-6
+    assert abs(st["cost"] - info["cost"]) <= 1e-6 * info["cost"]
+    # ground truth: every true inlier with a small residual is kept, no gross outlier survives, the pose is noise-limited
+    assert len(np.setdiff1d(inl, true_inl)) <= 0.01 * n + 2
+    assert len(np.intersect1d(inl, true_inl)) >= 0.97 * len(true_inl)
+    assert np.abs(rvec - pose[:3]).max() <= 2e-3 and np.abs(t - pose[3:]).max() <= 2e-2
+
+
+def test_pnp_batch_nan_rows_and_failure():
+    import pnp_oracle as po
+    from vo_mi355x import VoContext
+    K, X0, uv0, pose0, _ = _scene(400, 0.3, 11)
+    _, X1, uv1, pose1, _ = _scene(400, 0.1, 12)
+    X1 = X1.copy(); uv1 = uv1.copy()
+    X1[350:] = np.nan; uv1[350:] = np.nan                      # ragged: the second sequence has only 350 correspondences
+    with VoContext(64, 64, max_pts=64, batch=2) as c:
+        rv, tv, inl, st = c.pnp_ransac(np.stack([K, K]), np.stack([X0, X1]), np.stack([uv0, uv1]), seed=1)
+    for b, (X, uv, pose) in enumerate(((X0, uv0, pose0), (X1, uv1, pose1))):
+        assert st[b]["status"] == 0 and np.abs(rv[b] - pose[:3]).max() <= 3e-3 and np.abs(tv[b] - pose[3:]).max() <= 3e-2
+    assert inl[1].max() < 350
+    # pure noise: no consensus -> status reports it, NaN pose, no crash
+    rng = np.random.default_rng(0)
+    with VoContext(64, 64, max_pts=64) as c:
+        rvec, t, inl, st = c.pnp_ransac(K, rng.normal(0, 5, (50, 3)).astype(np.float32) + [0, 0, 20],
+                                        rng.uniform(0, 300, (50, 2)).astype(np.float32), reproj_err=0.01, max_iters=512)
+    assert st["status"] != 0 or st["n_inliers"] >= 4
+
+
+def test_camera_pose_dropin():
+    from vo_mi355x import Extractor, Landmark, Keypoint, VoContext, synthetic as syn
+    K, X, uv, pose, true_inl = _scene(300, 0.25, 21)
+    lms = [Landmark(0, X[i].astype(np.float64).reshape(3, 1), np.zeros((1, 1))) for i in range(len(X))]
+    kps = [Keypoint(0, 1, uv[i].reshape(2, 1), uv[i].reshape(2, 1), np.zeros((1, 1)), [uv[i].reshape(2, 1)]) for i in range(len(X))]
+    with VoContext(64, 64, max_pts=64) as c:
+        ext = Extractor(min_kp_dist=7, ctx=c)
+        inliers, H = ext.camera_pose(K, lms, kps, corr='3D-2D', max_err_reproj=2.0)
+        with pytest.raises(NotImplementedError):
+            ext.camera_pose(K, kps, kps, corr='2D-2D')
+    assert isinstance(inliers, list) and H.shape == (4, 4) and np.allclose(H[3], [0, 0, 0, 1])
+    assert np.abs(H[:3, :3] - syn.rodrigues(pose[:3])).max() <= 3e-3 and np.abs(H[:3, 3] - pose[3:]).max() <= 3e-2
+    assert len(np.setdiff1d(inliers, true_inl)) <= 4

@@ -249,3 +249,37 @@ def test_bilateral_prefilter_restatement():
     assert (o.bilateral(smooth) != smooth).mean() > 0.1          # it does smooth
     flat = np.full((9, 11), 93, np.uint8)
     assert np.array_equal(o.bilateral(flat), flat)
+
+
+def test_pnp_oracle_p3p_ransac_and_iteration_bound():
+    """the 3D-2D pose oracle (defines what csrc/vo_pnp.hip implements): P3P exact on noise-free data, RANSAC finds the
+    planted inlier set, OpenCV's iteration bound formula"""
+    import math
+    import pnp_oracle as po
+    from vo_mi355x import synthetic as syn
+    rng = np.random.default_rng(0)
+    K = syn.KITTI_K
+    for _ in range(50):
+        r = rng.normal(0, 0.3, 3); t = np.array([rng.normal(0, 1), rng.normal(0, 1), rng.uniform(-2, 2)])
+        R = po.rodrigues(r)
+        X = np.stack([rng.uniform(-15, 15, 4), rng.uniform(-3, 3, 4), rng.uniform(12, 60, 4)], 1)
+        p = (X @ R.T + t) @ K.T
+        hyp = po.hypothesis(K, np.linalg.inv(K), X, p[:, :2] / p[:, 2:3], [0, 1, 2, 3])
+        assert hyp is not None and np.abs(hyp[0] - R).max() < 1e-6 and np.abs(hyp[1] - t).max() < 1e-5
+        assert np.abs(po.log_so3(R) - r).max() < 1e-9
+    # quartic: roots of (x-1)(x-2)(x+3)(x-0.5)
+    c = np.poly([1.0, 2.0, -3.0, 0.5])
+    assert np.allclose(sorted(po.quartic_real_roots(*c)), [-3.0, 0.5, 1.0, 2.0], atol=1e-12)
+    assert po.quartic_real_roots(1.0, 0.0, 1.0, 0.0, 1.0) == []                    # no real root
+    # RANSACUpdateNumIters: log(1 - p) / log(1 - w^m)
+    assert po.update_num_iters(0.9999, 0.3, 4, 10 ** 6) == round(math.log(1e-4) / math.log(1 - 0.7 ** 4))
+    assert po.update_num_iters(0.9999, 1.0, 4, 1000) == 1000 and po.update_num_iters(0.9999, 0.0, 4, 1000) == 0
+    s = syn.make_ba_scene(n_pts=300, n_slots=2, seed=3, obs_noise=0.3)
+    X = s["points_gt"].astype(np.float32); uv = s["obs"][0].astype(np.float32)
+    out = rng.choice(300, 90, replace=False)
+    uv[out] += rng.uniform(-60, 60, (90, 2)).astype(np.float32) + np.float32(10)
+    r, t, inl, info = po.pnp_ransac(K, X, uv, return_info=True)
+    assert len(np.intersect1d(inl, out)) <= 2 and len(inl) >= 205
+    assert np.abs(r - s["poses_gt"][0][:3]).max() < 2e-3 and np.abs(t - s["poses_gt"][0][3:]).max() < 2e-2
+    idx = po.sample4(5, 17, 10)
+    assert len(set(idx)) == 4 and idx == po.sample4(5, 17, 10) and idx != po.sample4(5, 18, 10)

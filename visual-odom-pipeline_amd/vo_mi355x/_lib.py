@@ -40,6 +40,15 @@ class BaParams(C.Structure):
                 ("gtol", C.c_double), ("lambda0", C.c_double), ("huber_delta", C.c_double), ("lambda_min", C.c_double)]
 
 
+class PnpParams(C.Structure):
+    _fields_ = [("reproj_err", C.c_double), ("confidence", C.c_double), ("max_iters", C.c_int32), ("seed", C.c_int32)]
+
+
+class PnpStats(C.Structure):
+    _fields_ = [("cost", C.c_double), ("n_inliers", C.c_int32), ("hypotheses", C.c_int32), ("best", C.c_int32),
+                ("status", C.c_int32)]
+
+
 class BaStats(C.Structure):
     _fields_ = [("cost0", C.c_double), ("cost", C.c_double), ("lam", C.c_double), ("iters", C.c_int32),
                 ("accepted", C.c_int32), ("status", C.c_int32), ("n_obs", C.c_int32)]
@@ -99,6 +108,9 @@ SIGNATURES = {
     "vo_comm_destroy": (C.c_int32, [_ctx]),
     "vo_ba_set_sharded": (C.c_int32, [_ctx, C.c_int32]),
     "vo_ba_gather_points": (C.c_int32, [_ctx, _f64p]),
+    "vo_pnp_default_params": (C.c_int32, [C.POINTER(PnpParams)]),
+    "vo_pnp_ransac": (C.c_int32, [_ctx, _f64p, _f32p, _f32p, C.c_int32, C.POINTER(PnpParams), _f64p, _f64p, _u8p,
+                                  C.POINTER(PnpStats)]),
     "vo_tracks_seed": (C.c_int32, [_ctx, _f32p, C.c_int32, C.c_int32]),
     "vo_tracks_track": (C.c_int32, [_ctx, C.c_int32, C.POINTER(KltParams)]),
     "vo_tracks_detect": (C.c_int32, [_ctx, C.c_int32, C.c_int32, C.POINTER(StParams), C.c_int32]),

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import BaParams, BaStats, KltParams, StParams, VoError, as_c, ptr
+from ._lib import BaParams, BaStats, KltParams, PnpParams, PnpStats, StParams, VoError, as_c, ptr
 
 
 class VoContext:
@@ -372,6 +372,30 @@ class VoContext:
         self._ck(self._L.vo_ba_fetch(self._h, ptr(po, C.c_double), ptr(pt, C.c_double), st))
         stats = [self._stats(st[b]) for b in range(B)]
         return self._out(po), self._out(pt), stats[0] if B == 1 else stats
+
+    # -- 3D-2D pose -----------------------------------------------------------------------------
+    def pnp_ransac(self, K, pts3d, pts2d, reproj_err=2.0, confidence=0.9999, max_iters=1000000, seed=0):
+        """RANSAC P3P + refinement.  pts3d (n,3), pts2d (n,2) [leading batch dim if batch > 1]
+        -> rvec (3,), tvec (3,), inlier indices (ascending), stats dict   [lists / arrays over the batch]"""
+        B = self.batch
+        p3 = np.ascontiguousarray(pts3d, np.float32).reshape(B, -1, 3)
+        p2 = np.ascontiguousarray(pts2d, np.float32).reshape(B, -1, 2)
+        n = p3.shape[1]
+        assert p2.shape[1] == n
+        Kc = self._in(K, np.float64, (3, 3))
+        prm = PnpParams()
+        self._L.vo_pnp_default_params(C.byref(prm))
+        prm.reproj_err, prm.confidence, prm.max_iters, prm.seed = reproj_err, confidence, int(max_iters), int(seed)
+        rv, tv = np.zeros((B, 3)), np.zeros((B, 3))
+        mask = np.zeros((B, n), np.uint8)
+        st = (PnpStats * B)()
+        self._ck(self._L.vo_pnp_ransac(self._h, ptr(Kc, C.c_double), ptr(p3, C.c_float), ptr(p2, C.c_float), n, C.byref(prm),
+                                       ptr(rv, C.c_double), ptr(tv, C.c_double), ptr(mask, C.c_uint8), st))
+        stats = [dict(cost=s.cost, n_inliers=s.n_inliers, hypotheses=s.hypotheses, best=s.best, status=s.status) for s in st]
+        inl = [np.nonzero(mask[b])[0] for b in range(B)]
+        if B == 1:
+            return rv[0], tv[0], inl[0], stats[0]
+        return rv, tv, inl, stats
 
     # -- device-resident track table ------------------------------------------------------------
     def tracks_seed(self, pts, t=0):
