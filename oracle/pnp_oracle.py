@@ -203,27 +203,25 @@ def update_num_iters(p, ep, model_points, max_iters):
 
 
 def refine(K, rvec, t, X, uv, iters=20):
-    """Gauss-Newton on (rvec, t), step halving, over the given points -> rvec, t, cost (sum of squared pixel errors)"""
-    def cost(r, tt):
-        return float(reproj_err2(K, rodrigues(r), tt, X, uv).sum())
-    r, tt = np.array(rvec, float), np.array(t, float)
-    c = cost(r, tt)
+    """Gauss-Newton on the pose (left rotation update exp(w) R, translation), step halving, over the given points
+    -> rvec, t, cost (sum of squared pixel errors)"""
+    def cost(Rm, tt):
+        return float(reproj_err2(K, Rm, tt, X, uv).sum())
+    R, tt = rodrigues(np.array(rvec, float)), np.array(t, float)
+    c = cost(R, tt)
     for _ in range(iters):
-        R = rodrigues(r)
         Xc = X @ R.T + tt
         p = Xc @ K.T
         ip2 = 1.0 / p[:, 2]
         u, v = p[:, 0] * ip2, p[:, 1] * ip2
         e = np.stack([u - uv[:, 0], v - uv[:, 1]], 1)
-        # d(u,v)/dXc = A (2x3)
-        A = np.zeros((len(X), 2, 3))
+        A = np.zeros((len(X), 2, 3))                      # d(u, v) / d x_cam
         for cidx in range(3):
             A[:, 0, cidx] = (K[0, cidx] - u * K[2, cidx]) * ip2
             A[:, 1, cidx] = (K[1, cidx] - v * K[2, cidx]) * ip2
-        # numeric-free rotation derivative: dXc/dr via finite rotation generators applied on the left: Xc' = exp(w) R X + t
         J = np.zeros((len(X), 2, 6))
         RX = X @ R.T
-        for k in range(3):
+        for k in range(3):                                # d(exp(w) R X) / d w_k = e_k x (R X)
             G = np.zeros((3, 3)); G[(k + 1) % 3, (k + 2) % 3] = -1; G[(k + 2) % 3, (k + 1) % 3] = 1
             J[:, :, k] = np.einsum("nij,nj->ni", A, RX @ G.T)
         J[:, :, 3:] = A
@@ -234,20 +232,19 @@ def refine(K, rvec, t, X, uv, iters=20):
             break
         step, ok = 1.0, False
         for _h in range(6):
-            Rn = rodrigues(step * d[:3]) @ R
-            rn, tn = log_so3(Rn), tt + step * d[3:]
-            cn = cost(rn, tn)
+            Rn, tn = rodrigues(step * d[:3]) @ R, tt + step * d[3:]
+            cn = cost(Rn, tn)
             if cn < c:
                 ok = True
                 break
             step *= 0.5
         if not ok:
             break
-        small = (c - cn) <= 1e-14 * max(c, 1e-300)
-        r, tt, c = rn, tn, cn
+        small = (c - cn) <= 1e-12 * max(c, 1e-300)
+        R, tt, c = Rn, tn, cn
         if small:
             break
-    return r, tt, c
+    return log_so3(R), tt, c
 
 
 def pnp_ransac(K, X, uv, thr=2.0, conf=0.9999, max_iters=1000000, seed=0, batch=256, return_info=False):
