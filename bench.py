@@ -166,6 +166,7 @@ class Group:
         c.push_frame_resident(0)
         self.t = 1
         self.inflight = 0
+        self.max_inflight = 2          # 1 when the step is replayed from a hipGraph (its host destinations are baked in)
 
     def enqueue(self):
         # one C call: pyramid + KLT + DLT + BA + Shi-Tomasi + result copies for the whole batch
@@ -178,7 +179,7 @@ class Group:
         # software pipeline: frame t + 1 is enqueued before frame t's results are waited for, so the stream never drains
         # while the host unpacks (the library keeps two pinned result mirrors for exactly this)
         self.enqueue()
-        if self.inflight == 2:
+        if self.inflight == self.max_inflight:
             self.fetch()
 
     def drain(self):
@@ -293,6 +294,7 @@ def main():
     t_setup = time.perf_counter() - t_gen
     for s in seqs:
         s.c.set_graph_mode(bool(a.graph))
+        s.max_inflight = 1 if a.graph else 2
         s.adaptive = not a.fixed_ba_budget
 
     pool = None
