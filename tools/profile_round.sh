@@ -2,7 +2,7 @@
 # Collects the rocprofv3 evidence for one round on the GPU box (run through gpurun from the repo root):
 #   tools/profile_round.sh r01 ["extra bench args"]
 # 1. kernel trace + stats of the default bench command   -> gpurun_out/<tag>_stats
-# 2. PMC FETCH_SIZE and WRITE_SIZE in two separate passes -> gpurun_out/<tag>_pmc_{fetch,write}
+# 2. PMC FETCH_SIZE and WRITE_SIZE in two separate passes -> gpurun_out/<tag>_pmc_{fetch,write}; MFMA counters in a third
 # 3. tools/summarize_profiles.py condenses them into gpurun_out/<tag>_* files that are copied to profiles/ by hand.
 # The program itself follows `--` (no env / bash -c hops under the profiler).
 set -u
@@ -13,9 +13,10 @@ BENCH="$PWD/bench.py"
 EXTRA=${2:-}
 ARGS="--steps 20 --warmup 5 --no-cpu-baseline $EXTRA"
 cd /tmp
-rm -rf $OUT/${TAG}_stats $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write
+rm -rf $OUT/${TAG}_stats $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o stats -- python3 $BENCH $ARGS > $OUT/${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o fetch -- python3 $BENCH --steps 4 --warmup 2 --no-cpu-baseline $EXTRA > $OUT/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o write -- python3 $BENCH --steps 4 --warmup 2 --no-cpu-baseline $EXTRA > $OUT/${TAG}_pmc_write.log 2>&1
+rocprofv3 --pmc MfmaUtil MfmaFlopsF64 --output-format csv -d $OUT/${TAG}_pmc_mfma -o mfma -- python3 $BENCH --steps 4 --warmup 2 --no-cpu-baseline $EXTRA > $OUT/${TAG}_pmc_mfma.log 2>&1
 cd - > /dev/null
 python3 tools/summarize_profiles.py $TAG
