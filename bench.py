@@ -383,7 +383,9 @@ def main():
         roof = {"bound": "hbm", "kernel": "k_klt_track", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_launch_us": round(klt_avg_s * 1e6, 3), "algorithmic_bytes_per_launch": int(klt_bytes),
-                "klt_mean_iters_per_level": [round(x, 3) for x in it_mean]}
+                "klt_mean_iters_per_level": [round(x, 3) for x in it_mean],
+                "note": "HBM figure = algorithmic bytes / launch time as the contract defines it; the kernel itself is vector-ALU bound "
+                        "(rocprofv3 VALUBusy 96 %, profiles/r01_pmc_valu_batch32.csv) and moves 0.13 GB per launch through HBM"}
         out = {"metric": ("frames/sec @1920x1080, 5000 KLT pts, 20-frame sharded BA (config 5)" if c5 else
                           "frames/sec @1241x376, 2000 KLT pts, 10-frame BA window"), "value": round(fps, 2),
                "unit": "frames/s", "n_gpus": dist.world, "steps": a.steps, "warmup": a.warmup,
