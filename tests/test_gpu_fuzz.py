@@ -1,0 +1,94 @@
+"""GPU: randomised parity sweeps (hypothesis) -- KLT and Shi-Tomasi bit-exact against the C oracle over random image
+sizes, contents, parameters and point sets; bundle adjustment against the numpy oracle over random scene shapes and
+visibility patterns.  Deterministic (derandomised) so that a failure reproduces."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+pytestmark = pytest.mark.gpu
+FUZZ = dict(max_examples=80, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+
+
+def _image(rng, w, h, kind):
+    if kind == 0:                                         # smooth texture
+        a = rng.normal(0, 1, (h // 4 + 2, w // 4 + 2))
+        img = np.kron(a, np.ones((4, 4)))[:h, :w]
+        img = (img - img.min()) / (np.ptp(img) + 1e-9) * 255
+    elif kind == 1:                                       # white noise
+        img = rng.integers(0, 256, (h, w)).astype(float)
+    elif kind == 2:                                       # blocks with hard edges and flat areas (zero-gradient windows)
+        img = np.kron(rng.integers(0, 2, (h // 16 + 1, w // 16 + 1)) * 200.0 + 20, np.ones((16, 16)))[:h, :w]
+    else:                                                 # saturated gradients
+        img = np.clip(np.add.outer(np.arange(h) * 3.0, np.arange(w) * 2.0) + rng.normal(0, 8, (h, w)), 0, 255)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@settings(**FUZZ)
+@given(st.integers(40, 400), st.integers(40, 300), st.integers(0, 3), st.integers(0, 2 ** 31 - 1), st.sampled_from([5, 9, 15, 21, 31]),
+       st.integers(0, 4), st.integers(1, 30), st.sampled_from([0.003, 0.03, 0.3]))
+def test_klt_fuzz(w, h, kind, seed, win, max_level, max_count, eps):
+    import vo_oracle as o
+    from vo_mi355x import VoContext
+    rng = np.random.default_rng(seed)
+    im0 = _image(rng, w, h, kind)
+    sh = rng.integers(-3, 4, 2)
+    im1 = np.clip(np.roll(im0, tuple(sh), (0, 1)).astype(int) + rng.integers(-4, 5, (h, w)), 0, 255).astype(np.uint8)
+    n = int(rng.integers(1, 120))
+    pts = np.stack([rng.uniform(-20, w + 20, n), rng.uniform(-20, h + 20, n)], 1).astype(np.float32)
+    with VoContext(w, h, max_pts=128, max_level=max_level, win=win) as c:
+        c.push_frame(im0); c.push_frame(im1)
+        prm = c.klt_params(win=win, max_level=max_level, max_count=max_count, epsilon=eps)
+        p1, s1, e1, it = c.klt_track(pts, prm, return_iters=True)
+    q1, qs, qe, qi = o.klt(im0, im1, pts, winSize=(win, win), maxLevel=max_level, criteria=(3, max_count, eps), return_iters=True)
+    assert np.array_equal(p1, q1) and np.array_equal(s1, qs) and np.array_equal(e1, qe) and np.array_equal(it, qi)
+
+
+@settings(**FUZZ)
+@given(st.integers(40, 500), st.integers(40, 300), st.integers(0, 3), st.integers(0, 2 ** 31 - 1), st.sampled_from([3, 7, 15, 31]),
+       st.sampled_from([0.5, 1.0, 3.0, 7.0, 20.0]), st.sampled_from([0.001, 0.03, 0.5]), st.integers(0, 9), st.integers(1, 400))
+def test_shi_tomasi_fuzz(w, h, kind, seed, bs, md, q, radius, maxc):
+    import vo_oracle as o
+    from vo_mi355x import VoContext
+    if min(w, h) <= bs + 2:
+        return
+    rng = np.random.default_rng(seed)
+    img = _image(rng, w, h, kind)
+    n = int(rng.integers(0, 80))
+    pts = np.stack([rng.uniform(-5, w + 5, n), rng.uniform(-5, h + 5, n)], 1).astype(np.float32)
+    with VoContext(w, h, max_pts=128) as c:
+        c.push_frame(img)
+        corners = c.shi_tomasi(pts if n else None, radius, params=c.st_params(max_corners=maxc, quality_level=q, min_distance=md, block_size=bs))
+        eig, mask, nc = c.shi_tomasi_read()
+    m = np.full((h, w), 255, np.uint8)
+    for x, y in np.int32(pts):
+        o.circle_mask(m, (int(x), int(y)), radius, 0)
+    ref, reig, rnc = o.good_features(img, m, maxCorners=maxc, qualityLevel=q, minDistance=md, blockSize=bs, return_aux=True)
+    assert np.array_equal(mask, m) and np.array_equal(eig, reig) and nc == rnc and np.array_equal(corners, ref)
+
+
+@settings(**dict(FUZZ, max_examples=50))
+@given(st.integers(1, 400), st.integers(1, 20), st.integers(0, 2 ** 31 - 1), st.sampled_from([1.0, 0.9, 0.6, 0.3]), st.sampled_from([0.1, 0.5, 3.0]))
+def test_ba_fuzz(n_pts, n_slots, seed, vis, noise):
+    import ba_oracle as bo
+    from vo_mi355x import VoContext, synthetic as syn
+    s = syn.make_ba_scene(n_pts=n_pts, n_slots=n_slots, seed=seed % 1000, visibility=vis, obs_noise=noise)
+    rng = np.random.default_rng(seed)
+    obs = s["obs"].copy()
+    if n_pts > 3:
+        obs[:, rng.integers(0, n_pts)] = np.nan                      # a landmark nobody sees
+    if n_slots > 2:
+        obs[rng.integers(0, n_slots)] = np.nan                       # a frame that sees nothing
+    if np.isfinite(obs[..., 0]).sum() < 1:
+        return
+    with VoContext(64, 64, max_pts=64) as c:
+        c.ba_upload(s["K"], s["poses0"], s["points0"], obs)
+        pr = c.ba_probe(lam=1e-3)
+        po, pt, stt = c.ba_adjust(s["K"], s["poses0"], s["points0"], obs, c.ba_params(max_iters=8))
+    ne = bo.normal_equations(s["K"], s["poses0"], s["points0"], obs)
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+    assert rel(pr["Hpp"], ne["Hpp"]) <= 1e-9 and rel(pr["Hll"], ne["Hll"]) <= 1e-9 and rel(pr["gp"], ne["gp"]) <= 1e-9
+    assert abs(pr["cost"] - ne["cost"]) <= 1e-10 * ne["cost"] + 1e-14
+    assert np.isfinite(po).all() and np.isfinite(pt).all() and np.isfinite(stt["cost"])
+    assert abs(bo.cost(s["K"], po, pt, obs) - stt["cost"]) <= 1e-9 * stt["cost"] + 1e-14    # the reported cost is the cost of the returned x
+    # (absolute slack: exactly solvable problems end at a cost ~1e-10 px^2 where the residuals are rounding noise)
+    assert stt["cost"] <= stt["cost0"] * (1 + 1e-12)                                                 # LM never returns a worse point
