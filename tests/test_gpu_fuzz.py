@@ -92,3 +92,52 @@ def test_ba_fuzz(n_pts, n_slots, seed, vis, noise):
     assert abs(bo.cost(s["K"], po, pt, obs) - stt["cost"]) <= 1e-9 * stt["cost"] + 1e-14    # the reported cost is the cost of the returned x
     # (absolute slack: exactly solvable problems end at a cost ~1e-10 px^2 where the residuals are rounding noise)
     assert stt["cost"] <= stt["cost0"] * (1 + 1e-12)                                                 # LM never returns a worse point
+
+
+@settings(**dict(FUZZ, max_examples=40))
+@given(st.integers(8, 300), st.integers(8, 200), st.integers(0, 3), st.integers(0, 2 ** 31 - 1), st.sampled_from([-1, 3, 5, 7]),
+       st.sampled_from([0.5, 1.5, 10.0, 60.0]), st.sampled_from([0.5, 1.5, 3.0]))
+def test_prefilter_fuzz(w, h, kind, seed, d, sc, ss):
+    import vo_oracle as o
+    from vo_mi355x import VoContext
+    if d == -1 and ss > 2.0:
+        return                                            # diameter from sigma_space would exceed 7
+    img = _image(np.random.default_rng(seed), w, h, kind)
+    with VoContext(w, h, max_pts=64, max_level=0, win=5) as c:
+        c.set_prefilter(d, sc, ss)
+        c.push_frame(img)
+        got = c.pyramid_read(1, 0)[0]
+    assert np.array_equal(got, o.bilateral(img, d, sc, ss))
+
+
+@settings(**dict(FUZZ, max_examples=40))
+@given(st.integers(1, 500), st.integers(0, 2 ** 31 - 1), st.sampled_from([0.05, 0.5, 3.0]), st.sampled_from([0.0, 0.3, 2.0]))
+def test_dlt_fuzz(n, seed, baseline, noise):
+    """DLT-1 (SURVEY.md 8a'): relative position error <= 1e-4 against the oracle's SVD for well-conditioned pairs, the
+    filter statistics (camera-1 depth, mean reprojection error) consistent for all"""
+    import vo_oracle as o
+    from vo_mi355x import VoContext, synthetic as syn
+    rng = np.random.default_rng(seed)
+    K = syn.KITTI_K
+    X = np.stack([rng.uniform(-15, 15, n), rng.uniform(-3, 3, n), rng.uniform(6, 80, n)], 1)
+    H0, H1 = np.eye(4), np.eye(4)
+    H1[:3, :3] = syn.rodrigues(rng.normal(0, 0.02, 3)); H1[:3, 3] = [baseline, 0.05 * baseline, 0.3 * baseline]
+    def proj(H):
+        p = (X @ H[:3, :3].T + H[:3, 3]) @ K.T
+        return (p[:, :2] / p[:, 2:3] + rng.normal(0, noise, (n, 2))).astype(np.float32)
+    uv0, uv1 = proj(H0), proj(H1)
+    P0, P1 = (K @ H0[:3]).astype(np.float32), (K @ H1[:3]).astype(np.float32)
+    with VoContext(64, 64, max_pts=512) as c:
+        X4, depth1, reproj = c.triangulate(P0, P1, uv0, uv1, K, H0, H1)
+    R4 = o.triangulate(P0, P1, uv0, uv1)
+    Xg, Xr = (X4[:3] / X4[3]).T.astype(np.float64), (R4[:3] / R4[3]).T.astype(np.float64)
+    par = np.degrees(np.arccos(np.clip(np.sum((X / np.linalg.norm(X, axis=1, keepdims=True)) *
+                                              ((X - (-H1[:3, :3].T @ H1[:3, 3])) / np.linalg.norm(X - (-H1[:3, :3].T @ H1[:3, 3]), axis=1, keepdims=True)), 1), -1, 1)))
+    good = (par >= 1.0) & np.isfinite(Xr).all(1) & (np.linalg.norm(Xr, axis=1) < 100 * max(baseline, 1e-9) * 100)
+    if good.any():
+        assert (np.linalg.norm(Xg[good] - Xr[good], axis=1) / np.linalg.norm(Xr[good], axis=1)).max() <= 1e-4
+    # statistics recomputed from the returned float32 point exactly as the reference does (extractor.py:271, triangulate.py:15-29)
+    Xf = (X4[:3] / X4[3]).T.astype(np.float64)
+    d1 = Xf @ H1[2, :3] + H1[2, 3]
+    ok = np.isfinite(d1) & np.isfinite(depth1)
+    assert np.allclose(depth1[ok], d1[ok], rtol=1e-9, atol=1e-9)
