@@ -6,7 +6,8 @@ import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
 
 pytestmark = pytest.mark.gpu
-FUZZ = dict(max_examples=80, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+import os
+FUZZ = dict(max_examples=int(os.environ.get("VO_FUZZ_EXAMPLES", "80")), deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 
 
 def _image(rng, w, h, kind):
@@ -66,7 +67,7 @@ def test_shi_tomasi_fuzz(w, h, kind, seed, bs, md, q, radius, maxc):
     assert np.array_equal(mask, m) and np.array_equal(eig, reig) and nc == rnc and np.array_equal(corners, ref)
 
 
-@settings(**dict(FUZZ, max_examples=50))
+@settings(**dict(FUZZ, max_examples=max(10, FUZZ["max_examples"] * 5 // 8)))
 @given(st.integers(1, 400), st.integers(1, 20), st.integers(0, 2 ** 31 - 1), st.sampled_from([1.0, 0.9, 0.6, 0.3]), st.sampled_from([0.1, 0.5, 3.0]))
 def test_ba_fuzz(n_pts, n_slots, seed, vis, noise):
     import ba_oracle as bo
@@ -94,7 +95,7 @@ def test_ba_fuzz(n_pts, n_slots, seed, vis, noise):
     assert stt["cost"] <= stt["cost0"] * (1 + 1e-12)                                                 # LM never returns a worse point
 
 
-@settings(**dict(FUZZ, max_examples=40))
+@settings(**dict(FUZZ, max_examples=max(10, FUZZ["max_examples"] // 2)))
 @given(st.integers(8, 300), st.integers(8, 200), st.integers(0, 3), st.integers(0, 2 ** 31 - 1), st.sampled_from([-1, 3, 5, 7]),
        st.sampled_from([0.5, 1.5, 10.0, 60.0]), st.sampled_from([0.5, 1.5, 3.0]))
 def test_prefilter_fuzz(w, h, kind, seed, d, sc, ss):
@@ -110,7 +111,7 @@ def test_prefilter_fuzz(w, h, kind, seed, d, sc, ss):
     assert np.array_equal(got, o.bilateral(img, d, sc, ss))
 
 
-@settings(**dict(FUZZ, max_examples=40))
+@settings(**dict(FUZZ, max_examples=max(10, FUZZ["max_examples"] // 2)))
 @given(st.integers(1, 500), st.integers(0, 2 ** 31 - 1), st.sampled_from([0.05, 0.5, 3.0]), st.sampled_from([0.0, 0.3, 2.0]))
 def test_dlt_fuzz(n, seed, baseline, noise):
     """DLT-1 (SURVEY.md 8a'): relative position error <= 1e-4 against the oracle's SVD for well-conditioned pairs, the
