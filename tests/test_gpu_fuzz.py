@@ -142,3 +142,52 @@ def test_dlt_fuzz(n, seed, baseline, noise):
     d1 = Xf @ H1[2, :3] + H1[2, 3]
     ok = np.isfinite(d1) & np.isfinite(depth1)
     assert np.allclose(depth1[ok], d1[ok], rtol=1e-9, atol=1e-9)
+
+
+@settings(**dict(FUZZ, max_examples=max(6, FUZZ["max_examples"] // 6)))
+@given(st.integers(8, 1500), st.sampled_from([0.0, 0.2, 0.5, 0.7]), st.integers(0, 2 ** 31 - 1), st.sampled_from([0.1, 0.5, 1.0]),
+       st.sampled_from([1.0, 2.0, 4.0]))
+def test_pnp_fuzz(n, frac, seed, noise, thr):
+    """same search as the oracle (hypothesis count, winner, consensus set up to borderline points) and the same refined pose"""
+    import pnp_oracle as po
+    from vo_mi355x import VoContext, synthetic as syn
+    rng = np.random.default_rng(seed)
+    s = syn.make_ba_scene(n_pts=n, n_slots=2, seed=seed % 997, obs_noise=noise)
+    X = s["points_gt"].astype(np.float32); uv = s["obs"][0].astype(np.float32)
+    out = rng.choice(n, int(frac * n), replace=False)
+    uv[out] += rng.uniform(-90, 90, (len(out), 2)).astype(np.float32) + np.float32(20)
+    sd = int(seed % 1000)
+    with VoContext(64, 64, max_pts=64) as c:
+        rvec, t, inl, stt = c.pnp_ransac(s["K"], X, uv, reproj_err=thr, seed=sd, max_iters=4096)
+    r_o, t_o, inl_o, info = po.pnp_ransac(s["K"], X, uv, thr=thr, seed=sd, max_iters=4096, return_info=True)
+    if r_o is None:
+        assert stt["status"] != 0
+        return
+    assert stt["hypotheses"] == info["hyps"]
+    if stt["best"] == info["best"]:                          # (two hypotheses with equal support can swap on a borderline point)
+        assert len(np.setxor1d(inl, inl_o)) <= 2
+        if len(np.setxor1d(inl, inl_o)) == 0:
+            assert np.abs(rvec - r_o).max() <= 1e-6 and np.abs(t - t_o).max() <= 1e-5
+    else:
+        assert abs(len(inl) - len(inl_o)) <= 2
+
+
+@settings(**dict(FUZZ, max_examples=max(6, FUZZ["max_examples"] // 6)))
+@given(st.integers(2, 8), st.integers(9, 700), st.integers(2, 20), st.integers(0, 999), st.sampled_from([1.0, 0.8, 0.5]))
+def test_sharded_ba_fuzz(V, N, W, seed, vis):
+    """landmark shards on one GPU (batch dimension) reproduce the unsharded solve"""
+    from vo_mi355x import VoContext, sharding, synthetic as syn
+    s = syn.make_ba_scene(n_pts=N, n_slots=W, seed=seed, visibility=vis)
+    kw = dict(max_iters=12)
+    with VoContext(64, 64, max_pts=64) as c:
+        po, pt, st0 = c.ba_adjust(s["K"], s["poses0"], s["points0"], s["obs"], c.ba_params(**kw))
+    Ks, po_s, pt_s, ob_s = sharding.shard_problem(s["K"], s["poses0"], s["points0"], s["obs"], V)
+    with VoContext(64, 64, max_pts=64, batch=V) as c:
+        c.ba_set_sharded(True)
+        po2, pt2, st2 = c.ba_adjust(Ks, po_s, pt_s, ob_s, c.ba_params(**kw))
+        pts = sharding.unshard_points(c.ba_gather_points(), N)
+    st2 = st2 if isinstance(st2, list) else [st2]
+    assert sum(x["n_obs"] for x in st2) == st0["n_obs"]
+    assert (st2[0]["iters"], st2[0]["accepted"], st2[0]["status"]) == (st0["iters"], st0["accepted"], st0["status"])
+    assert abs(st2[0]["cost"] - st0["cost"]) <= 1e-9 * st0["cost"] + 1e-14
+    assert np.abs(np.asarray(po2)[0] - po).max() <= 1e-7 and np.abs(pts - pt).max() <= 1e-7
