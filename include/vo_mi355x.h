@@ -280,6 +280,8 @@ int32_t vo_tracks_detect(vo_ctx* ctx, int32_t t, int32_t mask_radius, const vo_s
 int32_t vo_tracks_read(vo_ctx* ctx, int32_t* n, float* uv, float* uv_first, int32_t* t_first, int32_t* t_total,
                        int32_t* tag, int32_t* n_dead, int32_t* dead_tag);
 int32_t vo_tracks_obs(vo_ctx* ctx, int32_t t_now, int32_t window, double* obs);
+/* the same table written into the RESIDENT BA problem (uploaded with N = max_pts landmarks): no host round trip (async) */
+int32_t vo_ba_obs_from_tracks(vo_ctx* ctx, int32_t t_now);
 
 /* ---- fused per-frame step on resident data ---------------------------------------------------
  * One call enqueues the hot path of one frame in the order of Pipeline.step (src/pipeline/pipeline.py:92-167):

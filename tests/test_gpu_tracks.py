@@ -135,3 +135,28 @@ def test_tracks_long_sequence_vs_list_model_and_ragged_batch():
                 check(rs[b], obs[b], want if b == 0 else [dict(k, tag=k["tag"] + (25 if k["tag"] >= 35 else 0)) for k in want],
                       dead if b == 0 else [d + (25 if d >= 35 else 0) for d in dead], t, 20)
     assert max(len(x[0]) for x in logs[0]) > 60 and any(x[1] for x in logs[0])      # the scenario exercises growth and deaths
+
+
+def test_ba_observations_straight_from_the_track_ring():
+    """vo_ba_obs_from_tracks fills the resident BA problem on the device; solving it equals solving the host-gathered table"""
+    from vo_mi355x import VoContext, synthetic as syn
+    w, h, cap, W = 240, 180, 64, 5
+    frames, _ = syn.make_sequence(W + 1, w=w, h=h, seed=9, margin=64)
+    seeds = syn.grid_points(50, w, h, seed=2, margin=20)
+    s = syn.make_ba_scene(n_pts=cap, n_slots=W, seed=4)
+    with VoContext(w, h, max_pts=cap) as c:
+        c.push_frame(frames[0])
+        c.tracks_seed(seeds, t=0)
+        for t in range(1, W + 1):
+            c.push_frame(frames[t])
+            c.tracks_track(t)
+        obs_host = c.tracks_obs(W, W)
+        n_live = len(c.tracks_read()["tag"])
+        assert 0 < n_live <= 50 and np.isfinite(obs_host[:, :n_live]).all() and np.isnan(obs_host[:, n_live:]).all()
+        # resident problem with placeholder observations, then the device gather
+        c.ba_upload(s["K"], s["poses0"], s["points0"], np.full((W, cap, 2), np.nan))
+        c.ba_obs_from_tracks(W)
+        c.ba_solve_resident(c.ba_params(max_iters=3))
+        po_a, pt_a, st_a = c.ba_fetch()
+        po_b, pt_b, st_b = c.ba_adjust(s["K"], s["poses0"], s["points0"], obs_host, c.ba_params(max_iters=3))
+    assert np.array_equal(po_a, po_b) and np.array_equal(pt_a, pt_b) and st_a["cost"] == st_b["cost"] and st_a["iters"] == st_b["iters"]

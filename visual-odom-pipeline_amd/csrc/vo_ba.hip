@@ -1048,6 +1048,11 @@ void vo_ba_destroy(vo_ctx* c) {
 }
 
 bool vo_ba_ready(const vo_ctx* c) { return c->ba && c->ba->uploaded; }
+double* vo_ba_obs_device(vo_ctx* c, int* n_slots, int* n_pts) {
+  if (!vo_ba_ready(c)) return nullptr;
+  *n_slots = c->ba->W; *n_pts = c->ba->N;
+  return c->ba->d_obs;
+}
 
 extern "C" int32_t vo_ba_default_params(vo_ba_params* p) {
   if (!p) return VO_E_INVALID;

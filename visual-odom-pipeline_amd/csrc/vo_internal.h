@@ -150,6 +150,7 @@ int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, size_t raw_seq_str
 int32_t vo_ba_enqueue_pub_copy(vo_ctx* c, int half);     // half: which pinned mirror (0 / 1)
 void vo_ba_unpack_pub(vo_ctx* c, int half, double* poses_out, double* points_out, vo_ba_stats* stats);   // arrays over the batch
 bool vo_ba_ready(const vo_ctx* c);
+double* vo_ba_obs_device(vo_ctx* c, int* n_slots, int* n_pts);   // resident observation table [batch][W][N][2] of the uploaded problem
 bool vo_st_ready(const vo_ctx* c);
 int vo_st_last_max_corners(const vo_ctx* c);
 int32_t vo_st_prepare(vo_ctx* c);

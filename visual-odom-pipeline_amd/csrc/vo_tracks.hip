@@ -304,3 +304,18 @@ extern "C" int32_t vo_tracks_obs(vo_ctx* c, int32_t t_now, int32_t window, doubl
   VO_HIP(c, hipStreamSynchronize(c->stream));
   return VO_OK;
 }
+
+// The same table written straight into the resident bundle-adjustment problem (vo_ba_upload with N = max_pts landmarks
+// = the track slots and W window poses): the observations of the next vo_ba_solve_resident never leave the GPU.  (async)
+extern "C" int32_t vo_ba_obs_from_tracks(vo_ctx* c, int32_t t_now) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->trk, VO_E_STATE, "vo_tracks_seed first");
+  int W = 0, N = 0;
+  double* d_obs = vo_ba_obs_device(c, &W, &N);
+  VO_CHECK(c, d_obs, VO_E_STATE, "vo_ba_upload first");
+  VO_CHECK(c, N == c->trk->cap && W <= VO_TRK_HIST, VO_E_INVALID, "the resident BA problem must have max_pts landmarks and <= 32 slots");
+  VO_HIP(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_trk_obs, dim3(vo_div_up(N, 256), W, c->batch), dim3(256), 0, c->stream, trk_make(c->trk), t_now, W, d_obs);
+  VO_HIP(c, hipGetLastError());
+  return VO_OK;
+}

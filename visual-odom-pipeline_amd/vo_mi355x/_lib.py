@@ -116,6 +116,7 @@ SIGNATURES = {
     "vo_tracks_detect": (C.c_int32, [_ctx, C.c_int32, C.c_int32, C.POINTER(StParams), C.c_int32]),
     "vo_tracks_read": (C.c_int32, [_ctx, _i32p, _f32p, _f32p, _i32p, _i32p, _i32p, _i32p, _i32p]),
     "vo_tracks_obs": (C.c_int32, [_ctx, C.c_int32, C.c_int32, _f64p]),
+    "vo_ba_obs_from_tracks": (C.c_int32, [_ctx, C.c_int32]),
     "vo_ba_probe": (C.c_int32, [_ctx, C.c_double, C.c_double, _f64p, _i32p, _f64p, _f64p, _f64p, _f64p, _f64p,
                                 _f64p, _f64p, _f64p, _f64p]),
 }

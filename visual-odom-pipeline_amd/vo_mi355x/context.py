@@ -433,6 +433,10 @@ class VoContext:
         self._ck(self._L.vo_tracks_obs(self._h, int(t_now), int(window), ptr(obs, C.c_double)))
         return obs[0] if self.batch == 1 else obs
 
+    def ba_obs_from_tracks(self, t_now):
+        """Fill the observation table of the resident BA problem (N = max_pts, W slots) from the track ring (async)."""
+        self._ck(self._L.vo_ba_obs_from_tracks(self._h, int(t_now)))
+
     # -- landmark-sharded BA of one problem (config 5) -------------------------------------------
     @staticmethod
     def comm_unique_id():
