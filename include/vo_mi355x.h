@@ -256,6 +256,12 @@ int32_t vo_ba_gather_points(vo_ctx* ctx, double* points_all);
 int32_t vo_pnp_default_params(vo_pnp_params* p);
 int32_t vo_pnp_ransac(vo_ctx* ctx, const double* K, const float* pts3d, const float* pts2d, int32_t n,
                       const vo_pnp_params* prm, double* rvec, double* tvec, uint8_t* inlier_mask, vo_pnp_stats* stats);
+/* resident form: correspondences uploaded once, a solve enqueued per frame with no host synchronisation (`blind_batches`
+ * batches of 256 hypotheses, early-exiting once the iteration bound is reached: 2 cover down to ~37 % inliers), results
+ * fetched later; a sequence whose bound was not reached reports status VO_E_CAPACITY (pose = best so far). */
+int32_t vo_pnp_upload(vo_ctx* ctx, const double* K, const float* pts3d, const float* pts2d, int32_t n);
+int32_t vo_pnp_solve_resident(vo_ctx* ctx, const vo_pnp_params* prm, int32_t blind_batches);        /* async */
+int32_t vo_pnp_fetch(vo_ctx* ctx, double* rvec, double* tvec, uint8_t* inlier_mask, vo_pnp_stats* stats);
 
 /* ---- device-resident track table (SURVEY.md 8f "next" row 3) -----------------------------------
  * The bookkeeping Extractor.extend_tracks / extend_landmarks / extract do on Python lists of Keypoint objects

@@ -73,3 +73,24 @@ def test_camera_pose_dropin():
     assert isinstance(inliers, list) and H.shape == (4, 4) and np.allclose(H[3], [0, 0, 0, 1])
     assert np.abs(H[:3, :3] - syn.rodrigues(pose[:3])).max() <= 3e-3 and np.abs(H[:3, 3] - pose[3:]).max() <= 3e-2
     assert len(np.setdiff1d(inliers, true_inl)) <= 4
+
+
+def test_pnp_resident_equals_synchronous():
+    from vo_mi355x import VoContext
+    K, X0, uv0, pose0, _ = _scene(800, 0.3, 31)
+    _, X1, uv1, pose1, _ = _scene(800, 0.5, 32)
+    Ks, Xs, uvs = np.stack([K, K]), np.stack([X0, X1]), np.stack([uv0, uv1])
+    with VoContext(64, 64, max_pts=64, batch=2) as c:
+        rv, tv, inl, st = c.pnp_ransac(Ks, Xs, uvs, seed=3)
+        c.pnp_upload(Ks, Xs, uvs)
+        for _ in range(2):                                   # re-solving the resident problem is repeatable
+            c.pnp_solve_resident(c.pnp_params(seed=3), blind_batches=2)
+            rv2, tv2, inl2, st2 = c.pnp_fetch()
+            assert np.array_equal(rv, rv2) and np.array_equal(tv, tv2) and all(np.array_equal(a, b) for a, b in zip(inl, inl2))
+            assert [s["status"] for s in st2] == [0, 0] and [s["best"] for s in st2] == [s["best"] for s in st]
+        # one blind batch is not enough for a 20 % inlier ratio: reported, pose = best so far
+        _, Xh, uvh, _, _ = _scene(800, 0.8, 33)
+        c.pnp_upload(Ks, np.stack([X0, Xh]), np.stack([uv0, uvh]))
+        c.pnp_solve_resident(c.pnp_params(seed=3), blind_batches=1)
+        _, _, _, st3 = c.pnp_fetch()
+        assert st3[0]["status"] == 0 and st3[1]["status"] == -5 and st3[1]["hypotheses"] == 256

@@ -34,6 +34,8 @@ struct vo_pnp_ws {
   uint8_t* d_mask = nullptr;    // [B][cap]
   double* d_out = nullptr;      // [B][8]: rvec, t, cost, n_inliers
   pnp_ctrl* h_ctrl = nullptr;   // pinned
+  double* h_out = nullptr;      // pinned
+  int n = 0;                    // resident correspondences per sequence
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -551,6 +553,7 @@ void vo_pnp_destroy(vo_ctx* c) {
   void* bufs[] = {w->d_K, w->d_X, w->d_uv, w->d_hyp, w->d_ctrl, w->d_mask, w->d_out};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (w->h_ctrl) (void)hipHostFree(w->h_ctrl);
+  if (w->h_out) (void)hipHostFree(w->h_out);
   delete w;
   c->pnp = nullptr;
 }
@@ -561,17 +564,7 @@ extern "C" int32_t vo_pnp_default_params(vo_pnp_params* p) {
   return VO_OK;
 }
 
-// K [batch][9], pts3d [batch][n][3] f32, pts2d [batch][n][2] f32 -> rvec, tvec [batch][3] f64 (world -> camera),
-// inlier_mask [batch][n] u8, stats [batch].  Points with NaN coordinates are never inliers.
-extern "C" int32_t vo_pnp_ransac(vo_ctx* c, const double* K, const float* pts3d, const float* pts2d, int32_t n, const vo_pnp_params* prm,
-                                 double* rvec, double* tvec, uint8_t* inlier_mask, vo_pnp_stats* stats) {
-  if (!c) return VO_E_INVALID;
-  vo_pnp_params def;
-  if (!prm) { vo_pnp_default_params(&def); prm = &def; }
-  VO_CHECK(c, K && pts3d && pts2d && rvec && tvec, VO_E_INVALID, "null buffer");
-  VO_CHECK(c, n >= 4, VO_E_INVALID, "at least 4 correspondences");
-  VO_CHECK(c, prm->max_iters >= 1 && prm->reproj_err > 0, VO_E_INVALID, "bad parameters");
-  VO_HIP(c, hipSetDevice(c->device));
+static int32_t pnp_alloc(vo_ctx* c, int n) {
   const size_t B = c->batch;
   if (c->pnp && c->pnp->cap < n) vo_pnp_destroy(c);
   if (!c->pnp) {
@@ -586,39 +579,118 @@ extern "C" int32_t vo_pnp_ransac(vo_ctx* c, const double* K, const float* pts3d,
     VO_HIP(c, hipMalloc((void**)&w->d_mask, B * w->cap));
     VO_HIP(c, hipMalloc((void**)&w->d_out, sizeof(double) * 8 * B));
     VO_HIP(c, hipHostMalloc((void**)&w->h_ctrl, sizeof(pnp_ctrl) * B, hipHostMallocDefault));
+    VO_HIP(c, hipHostMalloc((void**)&w->h_out, sizeof(double) * 8 * B, hipHostMallocDefault));
   }
+  return VO_OK;
+}
+
+static void pnp_enqueue_batch(vo_ctx* c, const vo_pnp_params* prm) {
   vo_pnp_ws* w = c->pnp;
+  const unsigned B = (unsigned)c->batch;
+  const double thr2 = prm->reproj_err * prm->reproj_err;
+  hipLaunchKernelGGL(k_pnp_solve, dim3(PNP_BATCH / 64, B), dim3(64), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n, (unsigned)prm->seed,
+                     w->d_hyp, w->d_ctrl);
+  hipLaunchKernelGGL(k_pnp_score, dim3(PNP_BATCH, B), dim3(64), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n, thr2, w->d_hyp);
+  hipLaunchKernelGGL(k_pnp_select, dim3(B), dim3(PNP_BATCH), 0, c->stream, w->d_hyp, w->d_ctrl, w->n, prm->confidence, prm->max_iters);
+}
+
+static int32_t pnp_enqueue_refine(vo_ctx* c, const vo_pnp_params* prm) {
+  vo_pnp_ws* w = c->pnp;
+  const size_t B = c->batch;
+  hipLaunchKernelGGL(k_pnp_refine, dim3((unsigned)B), dim3(256), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n,
+                     prm->reproj_err * prm->reproj_err, w->d_ctrl, w->d_mask, w->d_out);
+  VO_HIP(c, hipGetLastError());
+  VO_HIP(c, hipMemcpyAsync(w->h_out, w->d_out, sizeof(double) * 8 * B, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipMemcpyAsync(w->h_ctrl, w->d_ctrl, sizeof(pnp_ctrl) * B, hipMemcpyDeviceToHost, c->stream));
+  return VO_OK;
+}
+
+// resident form: the correspondences stay in HBM (vo_pnp_upload), a solve is enqueued per frame without any host
+// synchronisation (vo_pnp_solve_resident), the results come back with vo_pnp_fetch
+extern "C" int32_t vo_pnp_upload(vo_ctx* c, const double* K, const float* pts3d, const float* pts2d, int32_t n) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, K && pts3d && pts2d, VO_E_INVALID, "null buffer");
+  VO_CHECK(c, n >= 4, VO_E_INVALID, "at least 4 correspondences");
+  VO_HIP(c, hipSetDevice(c->device));
+  int32_t r = pnp_alloc(c, n);
+  if (r != VO_OK) return r;
+  vo_pnp_ws* w = c->pnp;
+  const size_t B = c->batch;
   const int cap = w->cap;
   VO_HIP(c, hipMemcpyAsync(w->d_K, K, sizeof(double) * 9 * B, hipMemcpyHostToDevice, c->stream));
   VO_HIP(c, hipMemcpy2DAsync(w->d_X, sizeof(float) * 3 * cap, pts3d, sizeof(float) * 3 * n, sizeof(float) * 3 * n, B, hipMemcpyHostToDevice, c->stream));
   VO_HIP(c, hipMemcpy2DAsync(w->d_uv, sizeof(float) * 2 * cap, pts2d, sizeof(float) * 2 * n, sizeof(float) * 2 * n, B, hipMemcpyHostToDevice, c->stream));
-  const double thr2 = prm->reproj_err * prm->reproj_err;
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  w->n = n;
+  return VO_OK;
+}
+
+// Enqueues `blind_batches` batches of 256 hypotheses (a batch exits at once for sequences that have reached their
+// iteration bound) and the refinement.  Two batches cover the bound down to ~37 % inliers (0.9999 confidence); a
+// sequence that would need more keeps the best pose found so far -- vo_pnp_fetch reports hypotheses < the bound through
+// status VO_E_CAPACITY so that the caller can fall back to the synchronous vo_pnp_ransac.
+extern "C" int32_t vo_pnp_solve_resident(vo_ctx* c, const vo_pnp_params* prm, int32_t blind_batches) {
+  if (!c) return VO_E_INVALID;
+  vo_pnp_params def;
+  if (!prm) { vo_pnp_default_params(&def); prm = &def; }
+  VO_CHECK(c, c->pnp && c->pnp->n >= 4, VO_E_STATE, "vo_pnp_upload first");
+  VO_CHECK(c, prm->max_iters >= 1 && prm->reproj_err > 0 && blind_batches >= 1 && blind_batches <= 64, VO_E_INVALID, "bad parameters");
+  VO_HIP(c, hipSetDevice(c->device));
+  vo_pnp_ws* w = c->pnp;
+  hipLaunchKernelGGL(k_pnp_init, dim3((unsigned)c->batch), dim3(1), 0, c->stream, w->d_ctrl, prm->max_iters);
+  for (int k = 0; k < blind_batches; k++) pnp_enqueue_batch(c, prm);
+  return pnp_enqueue_refine(c, prm);
+}
+
+extern "C" int32_t vo_pnp_fetch(vo_ctx* c, double* rvec, double* tvec, uint8_t* inlier_mask, vo_pnp_stats* stats) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->pnp && c->pnp->n >= 4, VO_E_STATE, "nothing to fetch");
+  VO_HIP(c, hipSetDevice(c->device));
+  vo_pnp_ws* w = c->pnp;
+  const size_t B = c->batch;
+  if (inlier_mask) VO_HIP(c, hipMemcpy2DAsync(inlier_mask, w->n, w->d_mask, w->cap, w->n, B, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  for (size_t b = 0; b < B; b++) {
+    const double* out = w->h_out + 8 * b;
+    if (rvec) for (int k = 0; k < 3; k++) rvec[3 * b + k] = out[k];
+    if (tvec) for (int k = 0; k < 3; k++) tvec[3 * b + k] = out[3 + k];
+    if (stats) {
+      stats[b].n_inliers = (int32_t)out[7]; stats[b].hypotheses = w->h_ctrl[b].h_done; stats[b].best = w->h_ctrl[b].best.h;
+      stats[b].cost = out[6];
+      stats[b].status = !(out[7] >= 4) ? VO_E_NUMERIC : (w->h_ctrl[b].done ? 0 : VO_E_CAPACITY);
+    }
+  }
+  return VO_OK;
+}
+
+// K [batch][9], pts3d [batch][n][3] f32, pts2d [batch][n][2] f32 -> rvec, tvec [batch][3] f64 (world -> camera),
+// inlier_mask [batch][n] u8, stats [batch].  Points with NaN coordinates are never inliers.
+extern "C" int32_t vo_pnp_ransac(vo_ctx* c, const double* K, const float* pts3d, const float* pts2d, int32_t n, const vo_pnp_params* prm,
+                                 double* rvec, double* tvec, uint8_t* inlier_mask, vo_pnp_stats* stats) {
+  if (!c) return VO_E_INVALID;
+  vo_pnp_params def;
+  if (!prm) { vo_pnp_default_params(&def); prm = &def; }
+  VO_CHECK(c, rvec && tvec, VO_E_INVALID, "null buffer");
+  VO_CHECK(c, prm->max_iters >= 1 && prm->reproj_err > 0, VO_E_INVALID, "bad parameters");
+  int32_t r = vo_pnp_upload(c, K, pts3d, pts2d, n);
+  if (r != VO_OK) return r;
+  vo_pnp_ws* w = c->pnp;
+  const size_t B = c->batch;
   hipLaunchKernelGGL(k_pnp_init, dim3((unsigned)B), dim3(1), 0, c->stream, w->d_ctrl, prm->max_iters);
   // batches of 256 hypotheses per sequence until every sequence has reached its iteration bound (typically one or
   // two batches: the bound is 33 iterations at 70 % inliers, 145 at 50 %)
   for (int guard = 0; guard < (prm->max_iters + PNP_BATCH - 1) / PNP_BATCH; guard++) {
-    hipLaunchKernelGGL(k_pnp_solve, dim3(PNP_BATCH / 64, (unsigned)B), dim3(64), 0, c->stream, w->d_K, w->d_X, w->d_uv, cap, n, (unsigned)prm->seed,
-                       w->d_hyp, w->d_ctrl);
-    hipLaunchKernelGGL(k_pnp_score, dim3(PNP_BATCH, (unsigned)B), dim3(64), 0, c->stream, w->d_K, w->d_X, w->d_uv, cap, n, thr2, w->d_hyp);
-    hipLaunchKernelGGL(k_pnp_select, dim3((unsigned)B), dim3(PNP_BATCH), 0, c->stream, w->d_hyp, w->d_ctrl, n, prm->confidence, prm->max_iters);
+    pnp_enqueue_batch(c, prm);
     VO_HIP(c, hipMemcpyAsync(w->h_ctrl, w->d_ctrl, sizeof(pnp_ctrl) * B, hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipStreamSynchronize(c->stream));
     bool all = true;
     for (size_t b = 0; b < B; b++) all = all && w->h_ctrl[b].done;
     if (all) break;
   }
-  hipLaunchKernelGGL(k_pnp_refine, dim3((unsigned)B), dim3(256), 0, c->stream, w->d_K, w->d_X, w->d_uv, cap, n, thr2, w->d_ctrl, w->d_mask, w->d_out);
-  VO_HIP(c, hipGetLastError());
-  std::vector<double> out(8 * B);
-  VO_HIP(c, hipMemcpyAsync(out.data(), w->d_out, sizeof(double) * 8 * B, hipMemcpyDeviceToHost, c->stream));
-  if (inlier_mask) VO_HIP(c, hipMemcpy2DAsync(inlier_mask, n, w->d_mask, cap, n, B, hipMemcpyDeviceToHost, c->stream));
-  VO_HIP(c, hipStreamSynchronize(c->stream));
-  for (size_t b = 0; b < B; b++) {
-    for (int k = 0; k < 3; k++) { rvec[3 * b + k] = out[8 * b + k]; tvec[3 * b + k] = out[8 * b + 3 + k]; }
-    if (stats) {
-      stats[b].n_inliers = (int32_t)out[8 * b + 7]; stats[b].hypotheses = w->h_ctrl[b].h_done; stats[b].best = w->h_ctrl[b].best.h;
-      stats[b].status = (out[8 * b + 7] >= 4) ? 0 : VO_E_NUMERIC; stats[b].cost = out[8 * b + 6];
-    }
-  }
+  r = pnp_enqueue_refine(c, prm);
+  if (r != VO_OK) return r;
+  r = vo_pnp_fetch(c, rvec, tvec, inlier_mask, stats);
+  if (r != VO_OK) return r;
+  if (stats) for (size_t b = 0; b < B; b++) if (stats[b].status == VO_E_CAPACITY) stats[b].status = 0;   // max_iters reached = a valid RANSAC outcome
   return VO_OK;
 }

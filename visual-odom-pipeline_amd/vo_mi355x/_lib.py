@@ -111,6 +111,9 @@ SIGNATURES = {
     "vo_pnp_default_params": (C.c_int32, [C.POINTER(PnpParams)]),
     "vo_pnp_ransac": (C.c_int32, [_ctx, _f64p, _f32p, _f32p, C.c_int32, C.POINTER(PnpParams), _f64p, _f64p, _u8p,
                                   C.POINTER(PnpStats)]),
+    "vo_pnp_upload": (C.c_int32, [_ctx, _f64p, _f32p, _f32p, C.c_int32]),
+    "vo_pnp_solve_resident": (C.c_int32, [_ctx, C.POINTER(PnpParams), C.c_int32]),
+    "vo_pnp_fetch": (C.c_int32, [_ctx, _f64p, _f64p, _u8p, C.POINTER(PnpStats)]),
     "vo_tracks_seed": (C.c_int32, [_ctx, _f32p, C.c_int32, C.c_int32]),
     "vo_tracks_track": (C.c_int32, [_ctx, C.c_int32, C.POINTER(KltParams)]),
     "vo_tracks_detect": (C.c_int32, [_ctx, C.c_int32, C.c_int32, C.POINTER(StParams), C.c_int32]),

@@ -397,6 +397,34 @@ class VoContext:
             return rv[0], tv[0], inl[0], stats[0]
         return rv, tv, inl, stats
 
+    def pnp_params(self, reproj_err=2.0, confidence=0.9999, max_iters=1000000, seed=0):
+        prm = PnpParams()
+        self._L.vo_pnp_default_params(C.byref(prm))
+        prm.reproj_err, prm.confidence, prm.max_iters, prm.seed = reproj_err, confidence, int(max_iters), int(seed)
+        return prm
+
+    def pnp_upload(self, K, pts3d, pts2d):
+        B = self.batch
+        p3 = np.ascontiguousarray(pts3d, np.float32).reshape(B, -1, 3)
+        p2 = np.ascontiguousarray(pts2d, np.float32).reshape(B, -1, 2)
+        self._pnp_n = p3.shape[1]
+        Kc = self._in(K, np.float64, (3, 3))
+        self._ck(self._L.vo_pnp_upload(self._h, ptr(Kc, C.c_double), ptr(p3, C.c_float), ptr(p2, C.c_float), self._pnp_n))
+
+    def pnp_solve_resident(self, params=None, blind_batches=2):
+        prm = params if params is not None else self.pnp_params()
+        self._ck(self._L.vo_pnp_solve_resident(self._h, C.byref(prm), int(blind_batches)))
+
+    def pnp_fetch(self):
+        B, n = self.batch, self._pnp_n
+        rv, tv, mask, st = np.zeros((B, 3)), np.zeros((B, 3)), np.zeros((B, n), np.uint8), (PnpStats * B)()
+        self._ck(self._L.vo_pnp_fetch(self._h, ptr(rv, C.c_double), ptr(tv, C.c_double), ptr(mask, C.c_uint8), st))
+        stats = [dict(cost=s.cost, n_inliers=s.n_inliers, hypotheses=s.hypotheses, best=s.best, status=s.status) for s in st]
+        inl = [np.nonzero(mask[b])[0] for b in range(B)]
+        if B == 1:
+            return rv[0], tv[0], inl[0], stats[0]
+        return rv, tv, inl, stats
+
     # -- device-resident track table ------------------------------------------------------------
     def tracks_seed(self, pts, t=0):
         """Initial tracks born at frame t; pts (n,2) [(B,n,2)]."""
