@@ -46,10 +46,12 @@ def parse():
     ap.add_argument("--host-threads", type=int, default=3, help="enqueue/fetch the contexts from this many host threads")
     ap.add_argument("--fixed-ba-budget", action="store_true",
                     help="always enqueue --ba-iters LM iterations (default: last frame's iteration count + 2, capped)")
-    ap.add_argument("--workload", choices=("A", "config5"), default="A",
+    ap.add_argument("--workload", choices=("A", "config5", "pipeline"), default="A",
                     help="A: BASELINE configs[2], the metric's configuration (default).  config5: ONE 1920x1080 sequence, 5000 "
                          "points, 20-frame BA whose landmarks are sharded over the ranks with an RCCL all-reduce per LM "
-                         "iteration (front end replicated); strong scaling, not the headline metric")
+                         "iteration (front end replicated); strong scaling, not the headline metric.  pipeline: workload A plus the "
+                         "steps of Pipeline.step around it on the device -- track table (KLT + pruning + history + re-detection "
+                         "spawn) and RANSAC-P3P pose -- issued as separate calls with one sync per frame; informational")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames each CPU-baseline worker process runs")
     ap.add_argument("--cpu-procs", type=int, default=16, help="CPU-baseline worker processes (one core each), capped by the host's cores")
@@ -116,7 +118,7 @@ class Group:
     """`batch` independent VO sequences carried in lockstep by ONE batched context (one HIP stream): every launch of
     the hot path serves all of them.  Everything is resident in HBM."""
 
-    def __init__(self, device, frame_sets, seed0, batch, ba_iters, shard=None):
+    def __init__(self, device, frame_sets, seed0, batch, ba_iters, shard=None, pipeline=False):
         """shard = (rank, n_ranks, unique_id): config 5 -- this context holds landmark shard `rank` of ONE BA problem"""
         from vo_mi355x import VoContext, sharding, synthetic as syn
         self.B = batch
@@ -124,7 +126,10 @@ class Group:
         c = self.c
         c.upload_sequence(np.stack([frame_sets[b % len(frame_sets)] for b in range(batch)]))
         self.nf = frame_sets[0].shape[0]
-        c.points_upload(np.stack([syn.grid_points(N_PTS, W_IMG, H_IMG, seed=seed0 + b) for b in range(batch)]))
+        self.pipeline = pipeline
+        pts0 = np.stack([syn.grid_points(N_PTS, W_IMG, H_IMG, seed=seed0 + b) for b in range(batch)])
+        if not pipeline:
+            c.points_upload(pts0)
         # DLT: 1000 new tracks between two window poses of each BA scene; BA: N = 2000, W = 10 per sequence
         kw = {} if K_CAM is None else dict(K=K_CAM, width=W_IMG, height=H_IMG)
         scenes = [syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=seed0 + b, **kw) for b in range(batch)]
@@ -164,11 +169,35 @@ class Group:
         self.klt_prm = c.klt_params()
         self.st_prm = c.st_params()
         c.push_frame_resident(0)
+        if pipeline:
+            # track table seeded with the keypoints; 3D-2D correspondences of the newest BA frame with 30 % gross outliers
+            c.tracks_seed(pts0, t=0)
+            rng = np.random.default_rng(seed0)
+            X = np.stack([s["points_gt"] for s in scenes]).astype(np.float32)
+            uv = np.stack([s["obs"][0] for s in scenes]).astype(np.float32)
+            for b in range(batch):
+                out = rng.choice(BA_N, int(0.3 * BA_N), replace=False)
+                uv[b, out] += rng.uniform(-80, 80, (len(out), 2)).astype(np.float32) + np.float32(15)
+            c.pnp_upload(np.stack(Ks), X, uv)
+            self.pnp_prm = c.pnp_params(reproj_err=2.0, confidence=0.9999, max_iters=1000000, seed=seed0)
         self.t = 1
         self.inflight = 0
         self.max_inflight = 2          # 1 when the step is replayed from a hipGraph (its host destinations are baked in)
 
     def enqueue(self):
+        if self.pipeline:
+            # Pipeline.step (reference pipeline.py:92-167) as separate device calls: frame -> extend tracks -> 3D-2D pose ->
+            # triangulate -> bundle adjust -> re-detect
+            c, t = self.c, self.t
+            c.push_frame_resident(pingpong(t, self.nf))
+            c.tracks_track(t, self.klt_prm)
+            c.pnp_solve_resident(self.pnp_prm, 2)
+            c.dlt_resident()
+            c.ba_solve_resident(self.ba_prm)
+            c.tracks_detect(t, 7, self.st_prm, max_new=1000)
+            self.t += 1
+            self.inflight += 1
+            return
         # one C call: pyramid + KLT + DLT + BA + Shi-Tomasi + result copies for the whole batch
         self.c.frame_step_resident(pingpong(self.t, self.nf), N_PTS, True, True, True, 7, self.klt_prm, self.st_prm,
                                    self.ba_prm)
@@ -187,7 +216,14 @@ class Group:
             self.fetch()
 
     def fetch(self):
-        self.last = self.c.frame_fetch()
+        if self.pipeline:
+            rv, tv, inl, pst = self.c.pnp_fetch()                  # waits for the frame
+            po, pt, bst = self.c.ba_fetch()
+            tr = self.c.tracks_read()
+            tr = tr if isinstance(tr, list) else [tr]
+            self.last = {"ba_stats": bst, "pnp_stats": pst, "n_tracks": [len(x["tag"]) for x in tr]}
+        else:
+            self.last = self.c.frame_fetch()
         self.inflight -= 1
         if self.adaptive:
             # the LM stops by its own ftol/xtol tests; the budget only bounds how many (early-exiting) launches are
@@ -264,7 +300,7 @@ def main():
         return
     dist = Dist()
     cpu = None
-    if dist.rank == 0 and dist.world == 1 and not a.no_cpu_baseline and a.workload == "A":
+    if dist.rank == 0 and dist.world == 1 and not a.no_cpu_baseline and a.workload == "A" and a.cpu_worker < 0:
         # before anything initialises the GPU in this process (child processes are started here)
         n_procs = max(1, min(a.cpu_procs, os.cpu_count() or 1))
         v, secs, cores = cpu_baseline_parallel(n_procs, a.cpu_frames, a.ba_iters)
@@ -275,6 +311,9 @@ def main():
     from vo_mi355x import VoContext, synthetic as syn
     t_gen = time.perf_counter()
     c5 = a.workload == "config5"
+    pl = a.workload == "pipeline"
+    if pl:
+        a.no_cpu_baseline = True
     if c5:
         # ONE sequence over all ranks: every rank runs the (launch-bound) front end on the whole frame redundantly and
         # owns 1/n_ranks of the landmarks of the 20-frame bundle adjustment
@@ -289,12 +328,12 @@ def main():
         a.ctxs = max(1, min(a.ctxs, a.seqs))
         per = [a.seqs // a.ctxs + (1 if i < a.seqs % a.ctxs else 0) for i in range(a.ctxs)]
         frame_sets = [syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + 16 * dist.rank + k)[0] for k in range(min(4, a.seqs))]
-        seqs = [Group(dist.local_rank, frame_sets, seed0=1000 * dist.rank + 100 * i, batch=per[i], ba_iters=a.ba_iters)
+        seqs = [Group(dist.local_rank, frame_sets, seed0=1000 * dist.rank + 100 * i, batch=per[i], ba_iters=a.ba_iters, pipeline=pl)
                 for i in range(a.ctxs)]
     t_setup = time.perf_counter() - t_gen
     for s in seqs:
         s.c.set_graph_mode(bool(a.graph))
-        s.max_inflight = 1 if a.graph else 2
+        s.max_inflight = 1 if (a.graph or pl) else 2
         s.adaptive = not a.fixed_ba_budget
 
     pool = None
@@ -369,8 +408,14 @@ def main():
         ba_stats = s0.ba_stats0()
         it = it.reshape(-1, it.shape[-1])
         it_mean = [float(np.maximum(it[:, l], 0).mean()) for l in range(it.shape[1])]
-        # ALGORITHMIC bytes of one KLT launch: N * sum_l (5120 + 1024 * it_l)
-        klt_bytes = N_PTS * s0.B * sum(5120.0 + 1024.0 * x for x in it_mean)     # one launch tracks the whole batch
+        # ALGORITHMIC bytes of one KLT launch: sum over the tracked points and levels of 5120 + 1024 * it_l
+        # (one launch tracks the whole batch; with the track table only the live slots count)
+        if s0.pipeline:
+            live = (it >= 0).any(axis=1)
+            klt_bytes = float(((5120.0 + 1024.0 * np.maximum(it[live], 0))).sum())
+            it_mean = [float(np.maximum(it[live][:, l], 0).mean()) for l in range(it.shape[1])]
+        else:
+            klt_bytes = N_PTS * s0.B * sum(5120.0 + 1024.0 * x for x in it_mean)
         klt_avg_s = (klt_ms / max(klt_n, 1)) * 1e-3
         achieved = klt_bytes / klt_avg_s / 1e9 if klt_avg_s > 0 else 0.0
         traffic = None
@@ -387,11 +432,12 @@ def main():
                 "note": "HBM figure = algorithmic bytes / launch time as the contract defines it; the kernel itself is vector-ALU bound "
                         "(rocprofv3 VALUBusy 96 %, profiles/r01_pmc_valu_batch32.csv) and moves 0.13 GB per launch through HBM"}
         out = {"metric": ("frames/sec @1920x1080, 5000 KLT pts, 20-frame sharded BA (config 5)" if c5 else
+                          "frames/sec, Pipeline.step on the device @1241x376 (track table <= 2000 pts, PnP, DLT, 10-frame BA, re-detection)" if pl else
                           "frames/sec @1241x376, 2000 KLT pts, 10-frame BA window"), "value": round(fps, 2),
                "unit": "frames/s", "n_gpus": dist.world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if c5 else "weak",
                "vs_baseline": None, "dtype": "u8/i32 (KLT, Shi-Tomasi) + f64 (DLT, BA)", "data": "synthetic",
-               "config": {"workload": WORKLOAD, "width": W_IMG, "height": H_IMG,
+               "config": {"workload": ("pipeline_step_" + WORKLOAD) if pl else WORKLOAD, "width": W_IMG, "height": H_IMG,
                           "klt_points": N_PTS, "klt_win": 31, "klt_levels": 4, "dlt_points": N_NEW,
                           "ba_landmarks": BA_N, "ba_window": BA_W, "ba_observations": BA_N * BA_W,
                           "ba_lm_iteration_budget": a.ba_iters, "ba_lm_iterations_run": ba_stats["iters"],
@@ -403,6 +449,10 @@ def main():
                                           "packet + 4 statistics per LM iteration, front end replicated" % dist.world) if c5 else
                                          ("independent sequences, %d per GPU in %d batched context(s) x %d GPU(s), no collective"
                                           % (a.seqs, a.ctxs, dist.world))},
+               "pipeline": ({"mean_live_tracks": round(float(np.mean(s0.last["n_tracks"])), 1),
+                             "pnp_inliers": (s0.last["pnp_stats"][0] if isinstance(s0.last["pnp_stats"], list) else s0.last["pnp_stats"])["n_inliers"],
+                             "pnp_status_ok": all(x["status"] == 0 for x in (s0.last["pnp_stats"] if isinstance(s0.last["pnp_stats"], list) else [s0.last["pnp_stats"]]))}
+                            if pl else None),
                "stage_ms_per_batched_launch_group": stage, "roofline": roof, "cpu_baseline": cpu,
                "setup_s": round(t_setup, 2)}
     dist.barrier()
