@@ -75,19 +75,28 @@ class Extractor:
         return p1, good
 
     # -- KLT ------------------------------------------------------------------------------------
+    def _survivors(self, im_curr, p1, good):
+        """keep mask of the reference's rule (0 <= x <= W and 0 <= y <= H, ends included, and the 'bidirectional' flag)
+        plus two independent (n, 2, 1) float32 blocks whose rows become k.uv and the new history entry -- one allocation
+        each instead of two small arrays per keypoint; every keypoint still owns its own values (separate rows, and the
+        history entry is not the same memory as uv, exactly like the reference's two np.array(...) calls)."""
+        h, w = im_curr.shape[0], im_curr.shape[1]
+        keep = good & (p1[:, 0] >= 0) & (p1[:, 0] <= w) & (p1[:, 1] >= 0) & (p1[:, 1] <= h)
+        uv = p1.reshape(-1, 2, 1).copy()
+        return keep, uv, uv.copy()
+
     def extend_tracks(self, im_curr, kp, max_bidir_error=30):
         new_tracks = []
         if len(kp):
             p0 = np.float32([k.uv.T for k in kp]).reshape(-1, 2)
             p1, good = self._track(im_curr, p0, max_bidir_error)
-            for k, (x, y), good_flag in zip(kp, p1, good):
-                if not good_flag:
-                    continue
-                if 0 <= x <= im_curr.shape[1] and 0 <= y <= im_curr.shape[0]:
-                    k.uv = np.array([x, y]).reshape((2, 1))
-                    k.t_total += 1
-                    k.uv_history.append(np.array([x, y]).reshape((2, 1)))
-                    new_tracks.append(k)
+            keep, uv, hist = self._survivors(im_curr, p1, good)
+            for i in np.nonzero(keep)[0]:
+                k = kp[i]
+                k.uv = uv[i]
+                k.t_total += 1
+                k.uv_history.append(hist[i])
+                new_tracks.append(k)
         return new_tracks
 
     def extend_landmarks(self, im_curr, landmarks, landmarks_kp, max_bidir_error=30):
@@ -96,16 +105,18 @@ class Extractor:
             return landmarks_new, kp_new, landmarks_dead, kp_dead
         p0 = np.float32([k.uv for k in landmarks_kp]).reshape(-1, 2)
         p1, good = self._track(im_curr, p0, max_bidir_error)
-        p1 = p1.tolist()
+        keep, uv, hist = self._survivors(im_curr, p1, good)
+        # the reference converts p1 with .tolist() here (python floats): uv / history entries are float64 in this method
+        uv, hist = uv.astype(np.float64), hist.astype(np.float64)
         for i in range(len(landmarks)):
-            l, k, (x, y), good_flag = landmarks[i], landmarks_kp[i], p1[i], good[i]
-            if (not good_flag) or not (0 <= x <= im_curr.shape[1] and 0 <= y <= im_curr.shape[0]):
+            l, k = landmarks[i], landmarks_kp[i]
+            if not keep[i]:
                 landmarks_dead.append(l)
                 kp_dead.append(k)
                 continue
-            k.uv = np.array([x, y]).reshape((2, 1))
+            k.uv = uv[i]
             k.t_total += 1
-            k.uv_history.append(np.array([x, y]).reshape((2, 1)))
+            k.uv_history.append(hist[i])
             l.t_latest += 1
             kp_new.append(deepcopy(k))
             landmarks_new.append(l)
@@ -123,13 +134,16 @@ class Extractor:
         prm = c.st_params(max_corners=sp["maxCorners"], quality_level=sp["qualityLevel"],
                           min_distance=sp["minDistance"], block_size=sp["blockSize"])
         # np.int32(kp.uv) truncation happens on the device; float32 carries every pixel coordinate exactly
-        cur = np.float32([np.asarray(k.uv, np.float64).reshape(2) for k in current_kp]).reshape(-1, 2)
+        cur = (np.array([k.uv for k in current_kp], dtype=np.float64).reshape(-1, 2).astype(np.float32) if len(current_kp)
+               else np.zeros((0, 2), np.float32))
         kp = c.shi_tomasi(cur if len(cur) else None, mask_radius=mask_radius, params=prm)
         if kp.shape[0] == 0:
             return []
-        desc = np.zeros((kp.shape[0], 1))
-        return [Keypoint(t_first=t, t_total=1, uv_first=kp[i, :].reshape((2, 1)), uv=kp[i, :].reshape((2, 1)),
-                         des=desc[i, :].reshape((-1, 1)), uv_history=[kp[i, :].reshape((2, 1))])
+        # like the reference (extractor.py:127-131) uv_first, uv and the first history entry of a new keypoint are three
+        # VIEWS of the same row of the detector output (kp[i, :].reshape((2, 1)) is a view); des a view of the zero column
+        kp3 = kp.reshape(-1, 2, 1)
+        desc = np.zeros((kp.shape[0], 1, 1))
+        return [Keypoint(t_first=t, t_total=1, uv_first=kp3[i], uv=kp3[i], des=desc[i], uv_history=[kp3[i]])
                 for i in range(len(kp))]
 
     # -- triangulation --------------------------------------------------------------------------
