@@ -41,16 +41,17 @@ class BundleAdjuster:
                 unrefined_landmarks.append(l)
                 unrefined_landmarks_kp.append(landmarks_kp_dead[i])
         N = len(refine_landmarks)
+        # observation of landmark j in window slot t <-> history index (t_now - t) - t_latest + L - 1 (:56-59, :150-158):
+        # valid slots are one contiguous run, read back to front -> one slice per landmark instead of W lookups
         obs = np.full((W, N, 2), np.nan)
         for j, (l, k) in enumerate(zip(refine_landmarks, refine_landmarks_kp)):
             L = len(k.uv_history)
-            for t in range(W):
-                hi = (t_now - t) - l.t_latest + (L - 1)
-                if 0 <= hi <= L - 1:
-                    obs[t, j] = np.asarray(k.uv_history[hi], np.float64).reshape(2)
-        points = np.zeros((N, 3))
-        for i, l in enumerate(refine_landmarks):
-            points[i] = np.asarray(l.p, np.float64).reshape(3)
+            base = t_now - l.t_latest + (L - 1)              # history index of slot 0
+            t_lo, t_hi = max(0, base - (L - 1)), min(W - 1, base)
+            if t_lo <= t_hi:
+                h = np.array(k.uv_history[base - t_hi:base - t_lo + 1], dtype=np.float64).reshape(-1, 2)
+                obs[t_lo:t_hi + 1, j] = h[::-1]
+        points = (np.array([l.p for l in refine_landmarks], dtype=np.float64).reshape(N, 3) if N else np.zeros((0, 3)))
         poses = np.zeros((W, 6))        # poses missing at the start of a sequence stay identity (:169-171)
         T = len(state._trajectory)
         for i in range(W):
@@ -73,8 +74,9 @@ class BundleAdjuster:
         else:
             poses_out, points_out = poses, points
         # write back exactly like the reference (:197-213)
+        p_new = np.ascontiguousarray(points_out, np.float64).reshape(N, 3, 1).copy()     # each landmark gets its own row
         for i in range(N):
-            refine_landmarks[i].p = points_out[i].reshape((3, 1)).copy()
+            refine_landmarks[i].p = p_new[i]
         landmarks_dead = [refine_landmarks[i] for i in range(n_active, N)] + unref_l
         landmarks_kp_dead = [refine_landmarks_kp[i] for i in range(n_active, N)] + unref_k
         for i in range(W):
