@@ -103,6 +103,25 @@ typedef struct {
   int32_t status;            /* 0, or VO_E_NUMERIC when no pose with >= 4 inliers was found */
 } vo_pnp_stats;
 
+/* cv2.findEssentialMat(p1, p2, K, prob=0.9999, method=RANSAC, threshold=1.0) + cv2.recoverPose(E, p1, p2, K) as
+ * Extractor.camera_pose(corr='2D-2D') calls them (src/extractor/extractor.py:162-172) */
+typedef struct {
+  double  threshold;         /* 1.0 px: consensus threshold on the Sampson distance (divided by (fx + fy) / 2 internally) */
+  double  prob;              /* 0.9999 */
+  double  distance_thresh;   /* 50: recoverPose keeps triangulated depths in (0, distance_thresh) baselines */
+  int32_t max_iters;         /* 1000 (OpenCV's default bound for findEssentialMat) */
+  int32_t seed;              /* of the counter-based sample generator */
+} vo_ess_params;
+
+typedef struct {
+  int32_t n_inliers;         /* consensus set of the returned E */
+  int32_t n_good;            /* inliers in front of both cameras for the returned (R, t) */
+  int32_t hypotheses;        /* five-point samples evaluated */
+  int32_t best;              /* index of the winning sample */
+  int32_t status;            /* 0, or VO_E_NUMERIC when no model with >= 5 inliers was found */
+  int32_t pad;
+} vo_ess_stats;
+
 /* ---- context -------------------------------------------------------------------------------- */
 int32_t vo_abi_version(void);
 int32_t vo_device_count(int32_t* n);
@@ -262,6 +281,21 @@ int32_t vo_pnp_ransac(vo_ctx* ctx, const double* K, const float* pts3d, const fl
 int32_t vo_pnp_upload(vo_ctx* ctx, const double* K, const float* pts3d, const float* pts2d, int32_t n);
 int32_t vo_pnp_solve_resident(vo_ctx* ctx, const vo_pnp_params* prm, int32_t blind_batches);        /* async */
 int32_t vo_pnp_fetch(vo_ctx* ctx, double* rvec, double* tvec, uint8_t* inlier_mask, vo_pnp_stats* stats);
+
+/* ---- 2D-2D bootstrap pose (SURVEY.md 8f "next" row 4, pose part) ---------------------------------
+ * Replaces cv2.findEssentialMat(..., method=RANSAC) + cv2.recoverPose in Extractor.camera_pose(corr='2D-2D')
+ * (src/extractor/extractor.py:162-172; Pipeline._get_init_state, src/pipeline/pipeline.py:63): RANSAC over Nister
+ * five-point essential matrices (a lane per sample, <= 10 models each, a wave per model for the consensus count),
+ * consensus = squared Sampson distance <= (threshold / mean focal length)^2, iteration bound as RANSACUpdateNumIters
+ * with 5 model points; the best model is returned as found (OpenCV does not re-fit); then the four (R, t)
+ * candidates of E and OpenCV's cheirality vote by DLT triangulation of the inliers.  Sample draws differ from
+ * OpenCV's: statistical parity; the algorithm is defined by oracle/essential_oracle.py.
+ * K [batch][9]; pts1, pts2 [batch][n][2] f32 pixels (NaN rows are never inliers); E [batch][9] (unit Frobenius norm,
+ * may be NULL), R [batch][9], t [batch][3] (|t| = 1, x2 ~ R x1 + t); inlier_mask [batch][n] u8 (may be NULL). */
+int32_t vo_essential_default_params(vo_ess_params* p);
+int32_t vo_essential_ransac(vo_ctx* ctx, const double* K, const float* pts1, const float* pts2, int32_t n,
+                            const vo_ess_params* prm, double* E, double* R, double* t, uint8_t* inlier_mask,
+                            vo_ess_stats* stats);
 
 /* ---- device-resident track table (SURVEY.md 8f "next" row 3) -----------------------------------
  * The bookkeeping Extractor.extend_tracks / extend_landmarks / extract do on Python lists of Keypoint objects

@@ -72,6 +72,15 @@ class OracleContext:
         return r["poses"], r["points"], dict(cost0=r["cost0"], cost=r["cost"], lam=r["lam"], iters=r["iters"],
                                              accepted=r["accepted"], status=r["status"], n_obs=int(bo.valid_mask(obs).sum()))
 
+    def essential_ransac(self, K, pts1, pts2, threshold=1.0, prob=0.9999, max_iters=1000, seed=0, distance_thresh=50.0):
+        import essential_oracle as eo
+        E, R, t, inl, info = eo.essential_ransac(K, pts1, pts2, thr=threshold, prob=prob, max_iters=max_iters, seed=seed,
+                                                 dist=distance_thresh, return_info=True)
+        if E is None:
+            return (np.full((3, 3), np.nan), np.full((3, 3), np.nan), np.full(3, np.nan), inl,
+                    dict(status=-6, n_inliers=0, n_good=0, hypotheses=info["hyps"], best=-1))
+        return E, R, t, inl, dict(status=0, n_inliers=len(inl), n_good=info["n_good"], hypotheses=info["hyps"], best=info["best"])
+
     def pnp_ransac(self, K, pts3d, pts2d, reproj_err=2.0, confidence=0.9999, max_iters=1000000, seed=0):
         import pnp_oracle as po
         r, t, inl, info = po.pnp_ransac(K, pts3d, pts2d, thr=reproj_err, conf=confidence, max_iters=max_iters, seed=seed,

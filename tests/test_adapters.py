@@ -199,3 +199,38 @@ def test_camera_pose_gpu_equals_cpu_twin():
     a, Ha = _run_camera_pose(_gpu_ctx)
     b, Hb = _run_camera_pose(_oracle_ctx)
     assert len(np.setxor1d(a, b)) <= 2 and np.abs(Ha - Hb).max() <= 1e-5
+
+
+def _run_camera_pose_2d2d(make_ctx):
+    """Extractor.camera_pose(corr='2D-2D') (reference extractor.py:162-172): findEssentialMat + recoverPose"""
+    from vo_mi355x import Extractor, Keypoint, synthetic as syn
+    import pnp_oracle as po
+    K = syn.KITTI_K
+    rng = np.random.default_rng(5)
+    n = 300
+    R = po.rodrigues(np.array([0.02, -0.03, 0.01])); t = np.array([0.3, 0.02, -0.8])
+    X = np.stack([rng.uniform(-15, 15, n), rng.uniform(-3, 3, n), rng.uniform(8, 40, n)], 1)
+    p1 = X @ K.T; p1 = p1[:, :2] / p1[:, 2:3] + rng.normal(0, 0.3, (n, 2))
+    Xc = X @ R.T + t; p2 = Xc @ K.T; p2 = p2[:, :2] / p2[:, 2:3] + rng.normal(0, 0.3, (n, 2))
+    out = rng.choice(n, 75, replace=False)
+    p2[out] += rng.uniform(-70, 70, (75, 2)) + 12
+    mk = lambda p: [Keypoint(0, 1, p[i].astype(np.float32).reshape(2, 1), p[i].astype(np.float32).reshape(2, 1), np.zeros((1, 1)), [])
+                    for i in range(n)]
+    ext = Extractor(min_kp_dist=7, ctx=make_ctx(64, 64))
+    inliers, H = ext.camera_pose(K, mk(p1), mk(p2), corr='2D-2D')
+    assert isinstance(inliers, list) and all(isinstance(i, int) for i in inliers)
+    assert len(np.intersect1d(inliers, out)) <= 8 and len(inliers) >= 170
+    assert np.abs(H[:3, :3] - R).max() <= 1e-2 and np.abs(H[:3, 3] - t / np.linalg.norm(t)).max() <= 0.15
+    assert np.allclose(H[3], [0, 0, 0, 1])
+    return inliers, H
+
+
+def test_camera_pose_2d2d_cpu():
+    _run_camera_pose_2d2d(_oracle_ctx)
+
+
+@pytest.mark.gpu
+def test_camera_pose_2d2d_gpu_equals_cpu_twin():
+    a, Ha = _run_camera_pose_2d2d(_gpu_ctx)
+    b, Hb = _run_camera_pose_2d2d(_oracle_ctx)
+    assert len(np.setxor1d(a, b)) <= 2 and np.abs(Ha - Hb).max() <= 1e-6

@@ -68,8 +68,6 @@ def test_camera_pose_dropin():
     with VoContext(64, 64, max_pts=64) as c:
         ext = Extractor(min_kp_dist=7, ctx=c)
         inliers, H = ext.camera_pose(K, lms, kps, corr='3D-2D', max_err_reproj=2.0)
-        with pytest.raises(NotImplementedError):
-            ext.camera_pose(K, kps, kps, corr='2D-2D')
     assert isinstance(inliers, list) and H.shape == (4, 4) and np.allclose(H[3], [0, 0, 0, 1])
     assert np.abs(H[:3, :3] - syn.rodrigues(pose[:3])).max() <= 3e-3 and np.abs(H[:3, 3] - pose[3:]).max() <= 3e-2
     assert len(np.setdiff1d(inliers, true_inl)) <= 4

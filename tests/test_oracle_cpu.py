@@ -283,3 +283,57 @@ def test_pnp_oracle_p3p_ransac_and_iteration_bound():
     assert np.abs(r - s["poses_gt"][0][:3]).max() < 2e-3 and np.abs(t - s["poses_gt"][0][3:]).max() < 2e-2
     idx = po.sample4(5, 17, 10)
     assert len(set(idx)) == 4 and idx == po.sample4(5, 17, 10) and idx != po.sample4(5, 18, 10)
+
+
+def test_essential_oracle_five_point_ransac_and_recover_pose():
+    """the 2D-2D pose oracle (defines what csrc/vo_essential.hip implements): the true E is among the five-point
+    solutions and every solution satisfies the ten cubic constraints; real-root isolation agrees with numpy's companion
+    eigenvalues; RANSAC finds the planted inlier set; recoverPose picks the candidate with the points in front"""
+    import essential_oracle as eo
+    import pnp_oracle as po
+    from vo_mi355x import synthetic as syn
+    rng = np.random.default_rng(0)
+    for _ in range(100):
+        p = rng.normal(size=rng.integers(1, 11) + 1)
+        r = eo.real_roots(list(p))
+        rr = np.roots(p[::-1]); rr = np.sort(rr[np.abs(rr.imag) < 1e-9].real)
+        assert len(r) == len(rr) and np.allclose(r, rr, rtol=1e-7, atol=1e-9)
+    assert np.allclose(eo.real_roots(list(np.poly([1.0, 2.0, -3.0, 0.5])[::-1])), [-3.0, 0.5, 1.0, 2.0], atol=1e-12)
+    assert eo.real_roots([1.0, 0.0, 1.0]) == [] and eo.real_roots([0.0, 0.0]) == []
+    dists = []
+    for _ in range(60):
+        R = po.rodrigues(rng.normal(0, 0.2, 3)); t = rng.normal(0, 1, 3); t /= np.linalg.norm(t)
+        X = np.stack([rng.uniform(-5, 5, 5), rng.uniform(-3, 3, 5), rng.uniform(4, 20, 5)], 1)
+        x1 = X[:, :2] / X[:, 2:3]; Xc = X @ R.T + t; x2 = Xc[:, :2] / Xc[:, 2:3]
+        Et = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
+        Et /= np.linalg.norm(Et)
+        sols = eo.five_point(x1.tolist(), x2.tolist())
+        assert 1 <= len(sols) <= 10
+        dists.append(min(min(np.abs(E - Et).max(), np.abs(E + Et).max()) for E in sols))
+        for E in sols:
+            assert abs(np.linalg.norm(E) - 1) < 1e-12 and abs(np.linalg.det(E)) < 1e-4
+            assert np.abs(np.einsum('ni,ij,nj->n', np.c_[x2, np.ones(5)], E, np.c_[x1, np.ones(5)])).max() < 1e-9
+    assert np.median(dists) < 1e-10 and max(dists) < 1e-3
+    assert eo.five_point([[0.0, 0.0]] * 5, [[0.0, 0.0]] * 5) == []                      # rank-deficient sample
+    # decomposition + cheirality: the true motion wins with all points in front
+    R = po.rodrigues(np.array([0.02, -0.04, 0.01])); t = np.array([0.6, 0.0, -0.8])
+    X = np.stack([rng.uniform(-5, 5, 50), rng.uniform(-3, 3, 50), rng.uniform(4, 20, 50)], 1)
+    x1 = X[:, :2] / X[:, 2:3]; Xc = X @ R.T + t; x2 = Xc[:, :2] / Xc[:, 2:3]
+    Et = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
+    Rr, tr, g, good = eo.recover_pose(Et, x1, x2)
+    assert np.abs(Rr - R).max() < 1e-9 and np.abs(tr - t).max() < 1e-9 and g == 50 and sorted(good)[:3] == [0, 0, 0]
+    assert np.abs(eo.sampson_err2(Et, x1, x2)).max() < 1e-20
+    # RANSAC on pixels with 30 % gross outliers
+    K = syn.KITTI_K
+    n = 300
+    X = np.stack([rng.uniform(-15, 15, n), rng.uniform(-3, 3, n), rng.uniform(8, 45, n)], 1)
+    p1 = X @ K.T; p1 = p1[:, :2] / p1[:, 2:3] + rng.normal(0, 0.3, (n, 2))
+    Xc = X @ R.T + t; p2 = Xc @ K.T; p2 = p2[:, :2] / p2[:, 2:3] + rng.normal(0, 0.3, (n, 2))
+    out = rng.choice(n, 90, replace=False)
+    p2[out] += rng.uniform(-60, 60, (90, 2)) + 10
+    E, Rr, tr, inl, info = eo.essential_ransac(K, p1.astype(np.float32), p2.astype(np.float32), return_info=True)
+    assert len(np.intersect1d(inl, out)) <= 6 and len(inl) >= 170 and info["hyps"] == 256
+    assert np.abs(Rr - R).max() < 1e-2 and np.abs(tr - t).max() < 0.1
+    idx = eo.sample5(5, 17, 10)
+    assert len(set(idx)) == 5 and idx == eo.sample5(5, 17, 10) and idx != eo.sample5(5, 18, 10)
+    assert eo.essential_ransac(K, p1[:4], p2[:4])[0] is None

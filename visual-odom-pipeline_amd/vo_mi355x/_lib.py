@@ -49,6 +49,16 @@ class PnpStats(C.Structure):
                 ("status", C.c_int32)]
 
 
+class EssParams(C.Structure):
+    _fields_ = [("threshold", C.c_double), ("prob", C.c_double), ("distance_thresh", C.c_double), ("max_iters", C.c_int32),
+                ("seed", C.c_int32)]
+
+
+class EssStats(C.Structure):
+    _fields_ = [("n_inliers", C.c_int32), ("n_good", C.c_int32), ("hypotheses", C.c_int32), ("best", C.c_int32),
+                ("status", C.c_int32), ("_pad", C.c_int32)]
+
+
 class BaStats(C.Structure):
     _fields_ = [("cost0", C.c_double), ("cost", C.c_double), ("lam", C.c_double), ("iters", C.c_int32),
                 ("accepted", C.c_int32), ("status", C.c_int32), ("n_obs", C.c_int32)]
@@ -111,6 +121,9 @@ SIGNATURES = {
     "vo_pnp_default_params": (C.c_int32, [C.POINTER(PnpParams)]),
     "vo_pnp_ransac": (C.c_int32, [_ctx, _f64p, _f32p, _f32p, C.c_int32, C.POINTER(PnpParams), _f64p, _f64p, _u8p,
                                   C.POINTER(PnpStats)]),
+    "vo_essential_default_params": (C.c_int32, [C.POINTER(EssParams)]),
+    "vo_essential_ransac": (C.c_int32, [_ctx, _f64p, _f32p, _f32p, C.c_int32, C.POINTER(EssParams), _f64p, _f64p, _f64p, _u8p,
+                                        C.POINTER(EssStats)]),
     "vo_pnp_upload": (C.c_int32, [_ctx, _f64p, _f32p, _f32p, C.c_int32]),
     "vo_pnp_solve_resident": (C.c_int32, [_ctx, C.POINTER(PnpParams), C.c_int32]),
     "vo_pnp_fetch": (C.c_int32, [_ctx, _f64p, _f64p, _u8p, C.POINTER(PnpStats)]),

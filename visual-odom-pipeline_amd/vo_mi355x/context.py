@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import BaParams, BaStats, KltParams, PnpParams, PnpStats, StParams, VoError, as_c, ptr
+from ._lib import BaParams, BaStats, EssParams, EssStats, KltParams, PnpParams, PnpStats, StParams, VoError, as_c, ptr
 
 
 class VoContext:
@@ -396,6 +396,30 @@ class VoContext:
         if B == 1:
             return rv[0], tv[0], inl[0], stats[0]
         return rv, tv, inl, stats
+
+    # -- 2D-2D bootstrap pose ---------------------------------------------------------------------
+    def essential_ransac(self, K, pts1, pts2, threshold=1.0, prob=0.9999, max_iters=1000, seed=0, distance_thresh=50.0):
+        """findEssentialMat(RANSAC) + recoverPose.  pts1, pts2 (n,2) pixels [leading batch dim if batch > 1]
+        -> E (3,3) unit norm, R (3,3), t (3,) with x2 ~ R x1 + t, inlier indices (ascending), stats dict"""
+        B = self.batch
+        p1 = np.ascontiguousarray(pts1, np.float32).reshape(B, -1, 2)
+        p2 = np.ascontiguousarray(pts2, np.float32).reshape(B, -1, 2)
+        n = p1.shape[1]
+        assert p2.shape[1] == n
+        Kc = self._in(K, np.float64, (3, 3))
+        prm = EssParams()
+        self._L.vo_essential_default_params(C.byref(prm))
+        prm.threshold, prm.prob, prm.distance_thresh, prm.max_iters, prm.seed = threshold, prob, distance_thresh, int(max_iters), int(seed)
+        E, R, t = np.zeros((B, 3, 3)), np.zeros((B, 3, 3)), np.zeros((B, 3))
+        mask = np.zeros((B, n), np.uint8)
+        st = (EssStats * B)()
+        self._ck(self._L.vo_essential_ransac(self._h, ptr(Kc, C.c_double), ptr(p1, C.c_float), ptr(p2, C.c_float), n, C.byref(prm),
+                                             ptr(E, C.c_double), ptr(R, C.c_double), ptr(t, C.c_double), ptr(mask, C.c_uint8), st))
+        stats = [dict(n_inliers=s.n_inliers, n_good=s.n_good, hypotheses=s.hypotheses, best=s.best, status=s.status) for s in st]
+        inl = [np.nonzero(mask[b])[0] for b in range(B)]
+        if B == 1:
+            return E[0], R[0], t[0], inl[0], stats[0]
+        return E, R, t, inl, stats
 
     def pnp_params(self, reproj_err=2.0, confidence=0.9999, max_iters=1000000, seed=0):
         prm = PnpParams()

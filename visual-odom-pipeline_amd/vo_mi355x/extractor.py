@@ -222,17 +222,30 @@ class Extractor:
     match_lists = match_list = match
 
     def camera_pose(self, K, list_1, list_2, corr='2D-2D', max_err_reproj=4.0):
-        """3D-2D pose of the current frame from the tracked landmarks (reference extractor.py:174-191:
-        cv2.solvePnPRansac(..., reprojectionError=max_err_reproj, iterationsCount=1e6, confidence=0.9999) + Rodrigues)
-        -> (inlier indices as a list, H 4x4 world -> camera).  RANSAC draws differ from OpenCV's (statistical parity,
-        see include/vo_mi355x.h); '2D-2D' (essential matrix, bootstrap only) is outside the accelerated path."""
+        """Pose from correspondences -> (inlier indices as a list, H 4x4).
+        corr='3D-2D' (reference extractor.py:174-191): cv2.solvePnPRansac(..., reprojectionError=max_err_reproj,
+        iterationsCount=1e6, confidence=0.9999) + Rodrigues; H maps world -> camera.
+        corr='2D-2D' (reference extractor.py:162-172, the bootstrap): cv2.findEssentialMat(prob=0.9999, RANSAC,
+        threshold=1.0) + cv2.recoverPose on its inliers; H maps view-1 -> view-2 coordinates, |t| = 1.
+        RANSAC draws differ from OpenCV's (statistical parity, see include/vo_mi355x.h)."""
+        if self._ctx is None:
+            raise RuntimeError("camera_pose needs the device context: track a frame first (or pass ctx=)")
+        if corr == '2D-2D':
+            kp_1_pts = np.array([kp.uv.T for kp in list_1]).astype(np.float32).reshape(-1, 2)
+            kp_2_pts = np.array([kp.uv.T for kp in list_2]).astype(np.float32).reshape(-1, 2)
+            _E, R, t, inliers, st = self._ctx.essential_ransac(np.asarray(K, np.float64), kp_1_pts, kp_2_pts, threshold=1.0,
+                                                               prob=0.9999)
+            if st["status"] != 0:
+                raise RuntimeError("findEssentialMat found no model")     # cv2 returns E = None -> the reference crashes in recoverPose
+            H = np.eye(4)
+            H[:3, :3] = R
+            H[:3, 3] = t.reshape((3,))
+            return inliers.reshape((-1,)).tolist(), H
         if corr != '3D-2D':
-            raise NotImplementedError("2D-2D essential-matrix pose is bootstrap-only (reference extractor.py:162-172)")
+            raise ValueError("corr must be '2D-2D' or '3D-2D'")
         from .so3 import rodrigues_vec_to_mat
         pts3d = np.array([kp.p.T for kp in list_1]).astype(np.float32).reshape(-1, 3)
         pts2d = np.array([kp.uv.T for kp in list_2]).astype(np.float32).reshape(-1, 2)
-        if self._ctx is None:
-            raise RuntimeError("camera_pose needs the device context: track a frame first (or pass ctx=)")
         rvec, t, inliers, st = self._ctx.pnp_ransac(np.asarray(K, np.float64), pts3d, pts2d, reproj_err=max_err_reproj,
                                                     confidence=0.9999, max_iters=1000000)
         if st["status"] != 0:
