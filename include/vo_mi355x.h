@@ -297,6 +297,14 @@ int32_t vo_essential_ransac(vo_ctx* ctx, const double* K, const float* pts1, con
                             const vo_ess_params* prm, double* E, double* R, double* t, uint8_t* inlier_mask,
                             vo_ess_stats* stats);
 
+/* ---- descriptor matching (SURVEY.md 8f "next" row 4, matching part) -----------------------------
+ * Replaces cv2.BFMatcher().knnMatch(desc_1, desc_2, k=2) in Extractor.match (src/extractor/extractor.py:134-145;
+ * match_lists :147-154, Pipeline._get_init_state src/pipeline/pipeline.py:52): for every query descriptor the two
+ * nearest train descriptors under the L2 norm, ordered by (distance, train index).  The ratio test stays with the caller.
+ * desc1 [batch][n1][dim], desc2 [batch][n2][dim] f32; idx [batch][n1][2] (-1 = no such neighbour), dist [batch][n1][2] f32. */
+int32_t vo_match_knn2(vo_ctx* ctx, const float* desc1, int32_t n1, const float* desc2, int32_t n2, int32_t dim,
+                      int32_t* idx, float* dist);
+
 /* ---- device-resident track table (SURVEY.md 8f "next" row 3) -----------------------------------
  * The bookkeeping Extractor.extend_tracks / extend_landmarks / extract do on Python lists of Keypoint objects
  * (src/extractor/extractor.py:38-88, 90-132; src/state/keypoint.py:4-21), as a structure of arrays in HBM: per

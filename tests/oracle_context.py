@@ -72,6 +72,10 @@ class OracleContext:
         return r["poses"], r["points"], dict(cost0=r["cost0"], cost=r["cost"], lam=r["lam"], iters=r["iters"],
                                              accepted=r["accepted"], status=r["status"], n_obs=int(bo.valid_mask(obs).sum()))
 
+    def match_knn2(self, desc1, desc2):
+        import match_oracle as mo
+        return mo.knn2(desc1, desc2)
+
     def essential_ransac(self, K, pts1, pts2, threshold=1.0, prob=0.9999, max_iters=1000, seed=0, distance_thresh=50.0):
         import essential_oracle as eo
         E, R, t, inl, info = eo.essential_ransac(K, pts1, pts2, thr=threshold, prob=prob, max_iters=max_iters, seed=seed,

@@ -90,7 +90,7 @@ def _run_extractor_glue(make_ctx, golden_dir, dlt_tol):
     _check_lms(ln, g, "tt_l", tol=dlt_tol); _check_kps(lk, g, "tt_k"); _check_kps(rest, g, "tt_rest")
     assert all(k.uv.dtype == np.float64 for k in lk)    # like the reference, refine() hands back float64 keypoints
     with pytest.raises(NotImplementedError):
-        ext.extract(frames[0], 1, [], detector='custom')
+        ext.extract(frames[0], 1, [], detector='custom')          # SIFT itself is not rebuilt
 
 
 def _run_ba_glue(make_ctx, golden_dir, name):
@@ -234,3 +234,37 @@ def test_camera_pose_2d2d_gpu_equals_cpu_twin():
     a, Ha = _run_camera_pose_2d2d(_gpu_ctx)
     b, Hb = _run_camera_pose_2d2d(_oracle_ctx)
     assert len(np.setxor1d(a, b)) <= 2 and np.abs(Ha - Hb).max() <= 1e-6
+
+
+def _sift_like(rng, n, dim=128):
+    d = rng.gamma(0.6, 1.0, (n, dim))
+    d = np.minimum(d / np.linalg.norm(d, axis=1, keepdims=True), 0.2)
+    return np.floor(512 * d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)      # OpenCV SIFT: integer-valued floats
+
+
+def _run_match_lists(make_ctx):
+    """Extractor.match_lists (reference extractor.py:147-154): descriptor lists in, DMatch list (ratio test) out"""
+    from vo_mi355x import Extractor, Keypoint
+    rng = np.random.default_rng(3)
+    d1 = _sift_like(rng, 150)
+    perm = rng.permutation(150)[:110]
+    d2 = np.concatenate([d1[perm] + rng.integers(-3, 4, (110, 128)).astype(np.float32), _sift_like(rng, 60)])
+    mk = lambda d: [Keypoint(0, 1, np.zeros((2, 1)), np.zeros((2, 1)), d[i].reshape(-1, 1), []) for i in range(len(d))]
+    ext = Extractor(min_kp_dist=7, ctx=make_ctx(64, 64))
+    ms = ext.match_lists(mk(d1), mk(d2))
+    got = {m.queryIdx: m.trainIdx for m in ms}
+    assert len(got) == len(ms) and sum(1 for j, q in enumerate(perm) if got.get(int(q)) == j) >= 105     # the planted pairs
+    assert all(isinstance(m.queryIdx, int) and isinstance(m.trainIdx, int) for m in ms)
+    assert len(ms) <= 115                                                                              # the rest fails the ratio test
+    with pytest.raises(ValueError):
+        ext.match(d1, d2[:1])                               # the reference fails to unpack (m, n) with a single train descriptor
+    return [(m.queryIdx, m.trainIdx, m.distance) for m in ms]
+
+
+def test_match_lists_cpu():
+    _run_match_lists(_oracle_ctx)
+
+
+@pytest.mark.gpu
+def test_match_lists_gpu_equals_cpu_twin():
+    assert _run_match_lists(_gpu_ctx) == _run_match_lists(_oracle_ctx)

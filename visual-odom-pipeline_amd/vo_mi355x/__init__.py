@@ -7,8 +7,8 @@ interfaces (JonasFrey96/Visual-Odom-Pipeline, src/extractor, src/bundle_adjuster
 from ._lib import LIB_PATH, VoError  # noqa: F401
 from .bundle_adjuster import BundleAdjuster  # noqa: F401
 from .context import VoContext  # noqa: F401
-from .extractor import Extractor  # noqa: F401
+from .extractor import DMatch, Extractor  # noqa: F401
 from .state import Keypoint, Landmark, State, Trajectory  # noqa: F401
 
-__all__ = ["VoContext", "VoError", "LIB_PATH", "Extractor", "BundleAdjuster", "Keypoint", "Landmark", "State",
+__all__ = ["VoContext", "VoError", "LIB_PATH", "Extractor", "DMatch", "BundleAdjuster", "Keypoint", "Landmark", "State",
            "Trajectory"]

@@ -124,6 +124,7 @@ SIGNATURES = {
     "vo_essential_default_params": (C.c_int32, [C.POINTER(EssParams)]),
     "vo_essential_ransac": (C.c_int32, [_ctx, _f64p, _f32p, _f32p, C.c_int32, C.POINTER(EssParams), _f64p, _f64p, _f64p, _u8p,
                                         C.POINTER(EssStats)]),
+    "vo_match_knn2": (C.c_int32, [_ctx, _f32p, C.c_int32, _f32p, C.c_int32, C.c_int32, _i32p, _f32p]),
     "vo_pnp_upload": (C.c_int32, [_ctx, _f64p, _f32p, _f32p, C.c_int32]),
     "vo_pnp_solve_resident": (C.c_int32, [_ctx, C.POINTER(PnpParams), C.c_int32]),
     "vo_pnp_fetch": (C.c_int32, [_ctx, _f64p, _f64p, _u8p, C.POINTER(PnpStats)]),

@@ -397,6 +397,20 @@ class VoContext:
             return rv[0], tv[0], inl[0], stats[0]
         return rv, tv, inl, stats
 
+    # -- descriptor matching ----------------------------------------------------------------------
+    def match_knn2(self, desc1, desc2):
+        """two nearest train descriptors (L2) of every query descriptor.  desc1 (n1,dim), desc2 (n2,dim) f32
+        [leading batch dim if batch > 1] -> idx (n1,2) int32 (-1 = none), dist (n1,2) float32"""
+        B = self.batch
+        dim = np.shape(desc1)[-1]
+        d1 = np.ascontiguousarray(desc1, np.float32).reshape(B, -1, dim)
+        d2 = np.ascontiguousarray(desc2, np.float32).reshape(B, -1, dim)
+        n1, n2 = d1.shape[1], d2.shape[1]
+        idx = np.zeros((B, n1, 2), np.int32); dist = np.zeros((B, n1, 2), np.float32)
+        self._ck(self._L.vo_match_knn2(self._h, ptr(d1, C.c_float), n1, ptr(d2, C.c_float), n2, dim, ptr(idx, C.c_int32),
+                                       ptr(dist, C.c_float)))
+        return (idx[0], dist[0]) if B == 1 else (idx, dist)
+
     # -- 2D-2D bootstrap pose ---------------------------------------------------------------------
     def essential_ransac(self, K, pts1, pts2, threshold=1.0, prob=0.9999, max_iters=1000, seed=0, distance_thresh=50.0):
         """findEssentialMat(RANSAC) + recoverPose.  pts1, pts2 (n,2) pixels [leading batch dim if batch > 1]

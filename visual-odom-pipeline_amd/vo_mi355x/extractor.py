@@ -3,14 +3,26 @@
 Same method names, argument order, defaults, return arities and in-place mutation semantics as the reference
 (extend_tracks :38-59, extend_landmarks :61-88, extract :90-132, triangulate_tracks :193-242,
 triangulate_nonlinear :244-253, triangulate :255-277), but every OpenCV call is replaced by the HIP library
-(VoContext).  The SIFT / matching / RANSAC pose methods of the reference are outside the hot path and raise
-NotImplementedError here.
+(VoContext).  Of the bootstrap (reference :114-172) the descriptor matching (match / match_lists) and both RANSAC poses
+(camera_pose) run on the GPU too; SIFT detection / description (extract(detector='custom'), cv2.SIFT_create) is not
+rebuilt and raises NotImplementedError -- descriptors come from the caller.
 """
 from copy import deepcopy
 
 import numpy as np
 
 from .state import Keypoint, Landmark
+
+
+class DMatch:
+    """the fields of cv2.DMatch the reference reads (queryIdx, trainIdx; extractor.py:147-150, pipeline.py:56-63)"""
+    __slots__ = ("queryIdx", "trainIdx", "imgIdx", "distance")
+
+    def __init__(self, queryIdx, trainIdx, distance, imgIdx=0):
+        self.queryIdx, self.trainIdx, self.imgIdx, self.distance = int(queryIdx), int(trainIdx), int(imgIdx), float(distance)
+
+    def __repr__(self):
+        return "DMatch(queryIdx=%d, trainIdx=%d, distance=%.6g)" % (self.queryIdx, self.trainIdx, self.distance)
 
 
 class Extractor:
@@ -215,11 +227,37 @@ class Extractor:
                         landmarks_kp_new += kp_1
         return landmarks_new, landmarks_kp_new, candidates_kp_new
 
-    # -- outside the hot path -------------------------------------------------------------------
-    def match(self, *a, **k):
-        raise NotImplementedError("SIFT matching is bootstrap-only (reference extractor.py:134-154)")
+    # -- bootstrap (reference extractor.py:134-191) -------------------------------------------------
+    _feature_method = 'sift'
+    _sift_ratio = 0.80                                   # reference extractor.py:29
 
-    match_lists = match_list = match
+    def match(self, desc_1, desc_2):
+        """cv2.BFMatcher().knnMatch(desc_1, desc_2, k=2) + Lowe's ratio test (reference extractor.py:134-145): the
+        list of DMatch whose nearest neighbour is closer than _sift_ratio x the second nearest."""
+        if self._ctx is None:
+            raise RuntimeError("match needs the device context: track a frame first (or pass ctx=)")
+        desc_1 = np.ascontiguousarray(desc_1, np.float32); desc_2 = np.ascontiguousarray(desc_2, np.float32)
+        if len(desc_2) < 2:
+            raise ValueError("not enough values to unpack (expected 2, got %d)" % len(desc_2))   # the reference's `for m, n in matches`
+        idx, dist = self._ctx.match_knn2(desc_1, desc_2)
+        good = []
+        for q in range(len(desc_1)):
+            m_d, n_d = float(dist[q, 0]), float(dist[q, 1])
+            if m_d < self._sift_ratio * n_d:
+                good.append(DMatch(q, idx[q, 0], m_d))
+        return good
+
+    def match_lists(self, list_1, list_2):
+        """Match two lists of keypoints/landmarks based on their descriptors (reference extractor.py:147-154).
+        Returns a list of matches. Each match has m.queryIdx for list_1, and m.trainIdx for list_2."""
+        desc_dim = len(list_1[0].des)
+        desc_1 = np.array([pt.des.reshape(1, desc_dim) for pt in list_1]).reshape((len(list_1), -1))
+        desc_2 = np.array([pt.des.reshape(1, desc_dim) for pt in list_2]).reshape((len(list_2), -1))
+        return self.match(desc_1, desc_2)
+
+    def match_list(self, kp_1, desc_1, keypoints):
+        # the reference's match_list (extractor.py:156-160) calls self.match with four arguments and always raises
+        raise TypeError("match() takes 3 positional arguments but 5 were given")
 
     def camera_pose(self, K, list_1, list_2, corr='2D-2D', max_err_reproj=4.0):
         """Pose from correspondences -> (inlier indices as a list, H 4x4).
