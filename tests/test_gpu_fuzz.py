@@ -191,3 +191,69 @@ def test_sharded_ba_fuzz(V, N, W, seed, vis):
     assert (st2[0]["iters"], st2[0]["accepted"], st2[0]["status"]) == (st0["iters"], st0["accepted"], st0["status"])
     assert abs(st2[0]["cost"] - st0["cost"]) <= 1e-9 * st0["cost"] + 1e-14
     assert np.abs(np.asarray(po2)[0] - po).max() <= 1e-7 and np.abs(pts - pt).max() <= 1e-7
+
+
+@settings(**dict(FUZZ, max_examples=max(6, FUZZ["max_examples"] // 6)))
+@given(st.integers(6, 900), st.sampled_from([0.0, 0.2, 0.5]), st.integers(0, 2 ** 31 - 1), st.sampled_from([0.0, 0.3, 1.0]),
+       st.sampled_from([0.5, 1.0, 3.0]), st.integers(0, 3))
+def test_essential_fuzz(n, frac, seed, noise, thr, motion):
+    """five-point RANSAC + recoverPose: same search as the oracle (sample count, winner, model, consensus up to borderline
+    points) and the same pose; motions: forward, sideways, rotation-dominant, planar scene"""
+    import essential_oracle as eo
+    import pnp_oracle as po
+    from vo_mi355x import VoContext, synthetic as syn
+    rng = np.random.default_rng(seed)
+    K = syn.KITTI_K
+    rv, tv = [((0.01, 0.03, -0.005), (0.1, -0.02, -0.9)), ((0.0, -0.05, 0.01), (1.0, 0.05, 0.1)), ((0.05, 0.2, -0.1), (0.05, 0.02, 0.05)),
+              ((0.01, 0.02, 0.0), (0.4, 0.0, -0.6))][motion]
+    R = po.rodrigues(np.asarray(rv, float)); t = np.asarray(tv, float)
+    X = np.stack([rng.uniform(-15, 15, n), rng.uniform(-3, 3, n), rng.uniform(8, 45, n)], 1)
+    if motion == 3:
+        X[:, 2] = 20.0 + 0.3 * X[:, 0]                        # all points on one plane: degenerate for linear solvers, not for five-point
+    p1 = X @ K.T; p1 = p1[:, :2] / p1[:, 2:3] + rng.normal(0, noise, (n, 2))
+    Xc = X @ R.T + t; p2 = Xc @ K.T; p2 = p2[:, :2] / p2[:, 2:3] + rng.normal(0, noise, (n, 2))
+    out = rng.choice(n, int(frac * n), replace=False)
+    p2[out] += rng.uniform(-90, 90, (len(out), 2)) + 20
+    p1 = p1.astype(np.float32); p2 = p2.astype(np.float32)
+    sd = int(seed % 1000)
+    with VoContext(64, 64, max_pts=64) as c:
+        E, Rg, tg, inl, stt = c.essential_ransac(K, p1, p2, threshold=thr, seed=sd, max_iters=512)
+    E_o, R_o, t_o, inl_o, info = eo.essential_ransac(K, p1, p2, thr=thr, seed=sd, max_iters=512, return_info=True)
+    if E_o is None:
+        assert stt["status"] != 0
+        return
+    assert stt["status"] == 0 and stt["hypotheses"] == info["hyps"]
+    if stt["best"] == info["best"] and min(np.abs(E - E_o).max(), np.abs(E + E_o).max()) <= 1e-6:
+        assert len(np.setxor1d(inl, inl_o)) <= 2
+        if len(np.setxor1d(inl, inl_o)) == 0 and min([g for g in info["good"] if g != info["n_good"]], default=-10) < info["n_good"] - 2 \
+                and sorted(info["good"])[-2] < info["n_good"] - 2:
+            assert np.abs(Rg - R_o).max() <= 1e-5 and np.abs(tg - t_o).max() <= 1e-5
+    else:                                                    # two models with equal support can swap on a borderline point
+        assert abs(len(inl) - len(inl_o)) <= 2
+    assert abs(np.linalg.det(Rg) - 1) <= 1e-9 and abs(np.linalg.norm(tg) - 1) <= 1e-9
+
+
+@settings(**dict(FUZZ, max_examples=max(10, FUZZ["max_examples"] // 3)))
+@given(st.integers(1, 300), st.integers(1, 400), st.sampled_from([1, 3, 8, 32, 64, 128, 130]), st.integers(0, 2 ** 31 - 1), st.integers(0, 2))
+def test_match_fuzz(n1, n2, dim, seed, kind):
+    import match_oracle as mo
+    from vo_mi355x import VoContext
+    rng = np.random.default_rng(seed)
+    if kind == 0:                                             # integer-valued (SIFT-like): many exact ties
+        d1 = rng.integers(0, 6, (n1, dim)).astype(np.float32); d2 = rng.integers(0, 6, (n2, dim)).astype(np.float32)
+    elif kind == 1:
+        d1 = rng.normal(0, 1, (n1, dim)).astype(np.float32); d2 = rng.normal(0, 1, (n2, dim)).astype(np.float32)
+    else:                                                     # wide dynamic range
+        d1 = (rng.normal(0, 1, (n1, dim)) * 10.0 ** rng.uniform(-3, 3, (n1, 1))).astype(np.float32)
+        d2 = (rng.normal(0, 1, (n2, dim)) * 10.0 ** rng.uniform(-3, 3, (n2, 1))).astype(np.float32)
+    with VoContext(64, 64, max_pts=64) as c:
+        idx, dist = c.match_knn2(d1, d2)
+    i_o, d_o = mo.knn2(d1, d2)
+    same = idx == i_o
+    # the float64 sum is rounded to float32 once on both sides; a sum within one float64 ulp of a rounding boundary may
+    # differ in the last float32 bit and then swap two neighbours that are equal to float32 precision
+    assert np.allclose(dist, d_o, rtol=2e-7, atol=0) or np.array_equal(dist, d_o)
+    assert same.mean() >= 0.995
+    if not same.all():
+        q = np.nonzero(~same.all(1))[0]
+        assert np.allclose(dist[q], d_o[q], rtol=2e-7)
