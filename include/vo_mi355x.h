@@ -122,6 +122,16 @@ typedef struct {
   int32_t pad;
 } vo_ess_stats;
 
+/* the fields of cv2.KeyPoint that cv2.SIFT fills (the reference reads pt through cv2.KeyPoint_convert and hands the
+ * objects back to compute(), src/extractor/extractor.py:114-122) */
+typedef struct {
+  float   x, y;              /* pt, pixels of the input image */
+  float   size;              /* diameter of the meaningful neighbourhood */
+  float   angle;             /* degrees, [0, 360) */
+  float   response;          /* |contrast| of the refined extremum */
+  int32_t octave;            /* packed: octave (low byte, signed), layer (second byte), sub-layer offset (third byte) */
+} vo_sift_kp;
+
 /* ---- context -------------------------------------------------------------------------------- */
 int32_t vo_abi_version(void);
 int32_t vo_device_count(int32_t* n);
@@ -296,6 +306,18 @@ int32_t vo_essential_default_params(vo_ess_params* p);
 int32_t vo_essential_ransac(vo_ctx* ctx, const double* K, const float* pts1, const float* pts2, int32_t n,
                             const vo_ess_params* prm, double* E, double* R, double* t, uint8_t* inlier_mask,
                             vo_ess_stats* stats);
+
+/* ---- SIFT features (SURVEY.md 8f "next" row 4, feature part) -----------------------------------
+ * Replaces cv2.SIFT_create(nfeatures=1000).detect(img, mask) + .compute(img, kps) in
+ * Extractor.extract(detector='custom', describe=True) (src/extractor/extractor.py:26-28, 114-122; the two bootstrap
+ * frames of Pipeline._get_init_state, src/pipeline/pipeline.py:48-49): doubled base image, Gaussian / DoG scale space
+ * (3 layers per octave, sigma 1.6), 26-neighbour extrema, quadratic refinement with contrast (0.04) and edge (10)
+ * tests, orientation histogram peaks, removeDuplicatedSorted + retainBest(nfeatures), 4 x 4 x 8 descriptors scaled to
+ * 0..255.  The float32 operation order is defined by oracle/sift_oracle.py (parity with OpenCV itself is unpinned).
+ * img [batch][height][stride] u8 (the context's image size); mask the same layout or NULL (0 = drop the keypoint);
+ * kps [batch][max_out]; desc [batch][max_out][128] f32; n_out [batch].  VO_E_CAPACITY if max_out is too small. */
+int32_t vo_sift_detect_compute(vo_ctx* ctx, const uint8_t* img, int32_t stride, const uint8_t* mask, int32_t nfeatures,
+                               int32_t max_out, vo_sift_kp* kps, float* desc, int32_t* n_out);
 
 /* ---- descriptor matching (SURVEY.md 8f "next" row 4, matching part) -----------------------------
  * Replaces cv2.BFMatcher().knnMatch(desc_1, desc_2, k=2) in Extractor.match (src/extractor/extractor.py:134-145;

@@ -72,6 +72,10 @@ class OracleContext:
         return r["poses"], r["points"], dict(cost0=r["cost0"], cost=r["cost"], lam=r["lam"], iters=r["iters"],
                                              accepted=r["accepted"], status=r["status"], n_obs=int(bo.valid_mask(obs).sum()))
 
+    def sift_detect_compute(self, img, mask=None, nfeatures=1000, max_out=None):
+        import sift_oracle as so
+        return so.detect_and_compute(img, nfeatures=nfeatures, mask=mask)
+
     def match_knn2(self, desc1, desc2):
         import match_oracle as mo
         return mo.knn2(desc1, desc2)

@@ -90,7 +90,7 @@ def _run_extractor_glue(make_ctx, golden_dir, dlt_tol):
     _check_lms(ln, g, "tt_l", tol=dlt_tol); _check_kps(lk, g, "tt_k"); _check_kps(rest, g, "tt_rest")
     assert all(k.uv.dtype == np.float64 for k in lk)    # like the reference, refine() hands back float64 keypoints
     with pytest.raises(NotImplementedError):
-        ext.extract(frames[0], 1, [], detector='custom')          # SIFT itself is not rebuilt
+        ext.extract(frames[0], 1, [], detector='shi-tomasi', describe=True)
 
 
 def _run_ba_glue(make_ctx, golden_dir, name):

@@ -63,3 +63,39 @@ def test_bootstrap_flow_gpu_equals_cpu_twin_and_ground_truth():
 
 def test_bootstrap_flow_cpu():
     _bootstrap(_oracle_ctx)
+
+
+def _bootstrap_from_images(make_ctx, w=416, h=240):
+    """the whole of Pipeline._get_init_state (reference pipeline.py:42-90) from two IMAGES: SIFT on both frames,
+    ratio-test matching, five-point pose, triangulation -- the scene is a textured plane under a known image motion"""
+    from vo_mi355x import Extractor, synthetic as syn
+    frames, motions = syn.make_sequence(7, w=w, h=h, seed=77, margin=64)
+    im0, im1, A = frames[0], frames[6], motions[6]
+    K = np.array([[400.0, 0, (w - 1) / 2], [0, 400.0, (h - 1) / 2], [0, 0, 1]])
+    ext = Extractor(min_kp_dist=7, ctx=make_ctx(w, h))
+    kp0 = ext.extract(im0, 0, detector='custom', describe=True)
+    kp1 = ext.extract(im1, 1, detector='custom', describe=True)
+    matches = ext.match_lists(kp0, kp1)
+    kp0_m = [copy.deepcopy(kp0[m.queryIdx]) for m in matches]
+    kp1_m = [copy.deepcopy(kp1[m.trainIdx]) for m in matches]
+    p0 = np.array([k.uv.reshape(2) for k in kp0_m], np.float64); p1 = np.array([k.uv.reshape(2) for k in kp1_m], np.float64)
+    err = np.linalg.norm(p0 @ A[:, :2].T + A[:, 2] - p1, axis=1)
+    assert len(matches) >= 150 and (err < 1.5).mean() >= 0.95                 # SIFT + ratio test find the true image motion
+    inliers, H1 = ext.camera_pose(K, kp0_m, kp1_m, corr='2D-2D')
+    assert len(inliers) >= 0.8 * len(matches) and (err[inliers] < 1.5).mean() >= 0.98
+    kp0_i = [kp0_m[i] for i in inliers]; kp1_i = [kp1_m[i] for i in inliers]
+    landmarks, k0, k1 = ext.triangulate_nonlinear(K, np.eye(4), H1, kp0_i, kp1_i, 1, max_err_reproj=2.0)
+    assert len(landmarks) >= 0.5 * len(inliers) and all(l.p[2, 0] > 0 for l in landmarks)
+    return ([(k.uv.reshape(2).tolist(), k.des.reshape(-1).tolist()) for k in kp0], [(m.queryIdx, m.trainIdx) for m in matches], inliers, H1)
+
+
+@pytest.mark.gpu
+def test_bootstrap_from_images_gpu_equals_cpu_twin():
+    kg, mg, ig, Hg = _bootstrap_from_images(_gpu_ctx)
+    kc, mc, ic, Hc = _bootstrap_from_images(_oracle_ctx)
+    assert kg == kc and mg == mc                                              # SIFT keypoints, descriptors and matches identical
+    assert len(np.setxor1d(ig, ic)) <= 2 and np.abs(Hg - Hc).max() <= 1e-6
+
+
+def test_bootstrap_from_images_cpu():
+    _bootstrap_from_images(_oracle_ctx, w=256, h=160)

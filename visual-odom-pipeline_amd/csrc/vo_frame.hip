@@ -268,6 +268,7 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
   vo_pnp_destroy(c);
   vo_ess_destroy(c);
   vo_match_destroy(c);
+  vo_sift_destroy(c);
   vo_st_destroy(c);
   vo_ba_destroy(c);
   for (int f = 0; f < 2; f++)

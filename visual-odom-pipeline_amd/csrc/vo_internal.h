@@ -72,6 +72,7 @@ struct vo_ctx {
   int dlt_n = 0, dlt_stats = 0;
   vo_st_ws* st = nullptr;
   struct vo_pnp_ws* pnp = nullptr;   // PnP-RANSAC workspace (vo_pnp.hip)
+  struct vo_sift_ws* sift = nullptr;     // SIFT scale space and lists (vo_sift.hip)
   struct vo_match_ws* match = nullptr;   // descriptor matcher buffers (vo_match.hip)
   struct vo_ess_ws* ess = nullptr;   // essential-matrix RANSAC workspace (vo_essential.hip)
   struct vo_trk_ws* trk = nullptr;   // device-resident track table (vo_tracks.hip)
@@ -165,6 +166,7 @@ void vo_trk_destroy(vo_ctx* c);
 void vo_pnp_destroy(vo_ctx* c);
 void vo_ess_destroy(vo_ctx* c);
 void vo_match_destroy(vo_ctx* c);
+void vo_sift_destroy(vo_ctx* c);
 // sub-workspace lifetime hooks
 void vo_st_destroy(vo_ctx* c);
 void vo_ba_destroy(vo_ctx* c);

@@ -59,6 +59,11 @@ class EssStats(C.Structure):
                 ("status", C.c_int32), ("_pad", C.c_int32)]
 
 
+class SiftKp(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float), ("response", C.c_float),
+                ("octave", C.c_int32)]
+
+
 class BaStats(C.Structure):
     _fields_ = [("cost0", C.c_double), ("cost", C.c_double), ("lam", C.c_double), ("iters", C.c_int32),
                 ("accepted", C.c_int32), ("status", C.c_int32), ("n_obs", C.c_int32)]
@@ -124,6 +129,7 @@ SIGNATURES = {
     "vo_essential_default_params": (C.c_int32, [C.POINTER(EssParams)]),
     "vo_essential_ransac": (C.c_int32, [_ctx, _f64p, _f32p, _f32p, C.c_int32, C.POINTER(EssParams), _f64p, _f64p, _f64p, _u8p,
                                         C.POINTER(EssStats)]),
+    "vo_sift_detect_compute": (C.c_int32, [_ctx, _u8p, C.c_int32, _u8p, C.c_int32, C.c_int32, C.POINTER(SiftKp), _f32p, _i32p]),
     "vo_match_knn2": (C.c_int32, [_ctx, _f32p, C.c_int32, _f32p, C.c_int32, C.c_int32, _i32p, _f32p]),
     "vo_pnp_upload": (C.c_int32, [_ctx, _f64p, _f32p, _f32p, C.c_int32]),
     "vo_pnp_solve_resident": (C.c_int32, [_ctx, C.POINTER(PnpParams), C.c_int32]),

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import BaParams, BaStats, EssParams, EssStats, KltParams, PnpParams, PnpStats, StParams, VoError, as_c, ptr
+from ._lib import BaParams, BaStats, EssParams, EssStats, KltParams, SiftKp, PnpParams, PnpStats, StParams, VoError, as_c, ptr
 
 
 class VoContext:
@@ -396,6 +396,28 @@ class VoContext:
         if B == 1:
             return rv[0], tv[0], inl[0], stats[0]
         return rv, tv, inl, stats
+
+    # -- SIFT ---------------------------------------------------------------------------------------
+    def sift_detect_compute(self, img, mask=None, nfeatures=1000, max_out=None):
+        """cv2.SIFT_create(nfeatures).detect(img, mask) + compute.  img (h, w) u8 [leading batch dim if batch > 1]
+        -> keypoints (n, 6) float64 [x, y, size, angle, response, octave], descriptors (n, 128) float32   [lists over the batch]"""
+        B = self.batch
+        im = np.ascontiguousarray(img, np.uint8).reshape(B, self.height, self.width)
+        mk = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(B, self.height, self.width)
+        cap = int(max_out) if max_out else (2 * nfeatures + 64 if nfeatures > 0 else 1 << 16)
+        kps = (SiftKp * (B * cap))()
+        desc = np.zeros((B, cap, 128), np.float32)
+        n_out = np.zeros(B, np.int32)
+        self._ck(self._L.vo_sift_detect_compute(self._h, ptr(im, C.c_uint8), self.width, None if mk is None else ptr(mk, C.c_uint8),
+                                                int(nfeatures), cap, kps, ptr(desc, C.c_float), ptr(n_out, C.c_int32)))
+        raw = np.frombuffer(kps, dtype=np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                                                 ("octave", "<i4")])).reshape(B, cap)
+        outs = []
+        for b in range(B):
+            r = raw[b, :n_out[b]]
+            k = np.stack([r["x"], r["y"], r["size"], r["angle"], r["response"], r["octave"]], 1).astype(np.float64).reshape(-1, 6)
+            outs.append((k, desc[b, :n_out[b]].copy()))
+        return outs[0] if B == 1 else outs
 
     # -- descriptor matching ----------------------------------------------------------------------
     def match_knn2(self, desc1, desc2):

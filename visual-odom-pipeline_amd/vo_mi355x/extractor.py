@@ -4,8 +4,8 @@ Same method names, argument order, defaults, return arities and in-place mutatio
 (extend_tracks :38-59, extend_landmarks :61-88, extract :90-132, triangulate_tracks :193-242,
 triangulate_nonlinear :244-253, triangulate :255-277), but every OpenCV call is replaced by the HIP library
 (VoContext).  Of the bootstrap (reference :114-172) the descriptor matching (match / match_lists) and both RANSAC poses
-(camera_pose) run on the GPU too; SIFT detection / description (extract(detector='custom'), cv2.SIFT_create) is not
-rebuilt and raises NotImplementedError -- descriptors come from the caller.
+(camera_pose) and the SIFT detector / descriptor (extract(detector='custom'), cv2.SIFT_create(nfeatures=1000)) run on the
+GPU too.
 """
 from copy import deepcopy
 
@@ -136,9 +136,12 @@ class Extractor:
 
     # -- re-detection ---------------------------------------------------------------------------
     def extract(self, img, t, current_kp=[], detector='custom', mask_radius=5, describe=False):
-        if detector != 'shi-tomasi' or describe:
-            raise NotImplementedError("only detector='shi-tomasi', describe=False is on the hot path "
-                                      "(SIFT bootstrap: reference extractor.py:114-122)")
+        if detector == 'custom':
+            return self._extract_sift(img, t, current_kp, describe)
+        if detector != 'shi-tomasi':
+            raise ValueError("detector must be 'shi-tomasi' or 'custom'")
+        if describe:
+            raise NotImplementedError("describe=True needs detector='custom' (SIFT): a Shi-Tomasi corner has no SIFT scale")
         self._context(img)
         self._ensure_cur(img)
         c = self._ctx
@@ -226,6 +229,20 @@ class Extractor:
                         landmarks_new += l
                         landmarks_kp_new += kp_1
         return landmarks_new, landmarks_kp_new, candidates_kp_new
+
+    def _extract_sift(self, img, t, current_kp, describe):
+        """detector='custom' (reference extractor.py:114-131): cv2.SIFT_create(nfeatures=1000).detect(img, mask) and,
+        with describe=True, .compute(img, kps) -> Keypoints whose `des` is the (128, 1) float32 descriptor column
+        (a (1, 1) zero column without describe).  The bootstrap calls it with no current keypoints (pipeline.py:48-49)."""
+        if len(current_kp):
+            raise NotImplementedError("SIFT detection with a keypoint mask is not used by the reference pipeline")
+        self._context(img)
+        kps, desc = self._ctx.sift_detect_compute(img, nfeatures=1000)
+        kp = np.ascontiguousarray(kps[:, :2], np.float32)          # cv2.KeyPoint_convert: (n, 2) float32
+        if not describe:
+            desc = np.zeros((kp.shape[0], 1))
+        return [Keypoint(t_first=t, t_total=1, uv_first=kp[i, :].reshape((2, 1)), uv=kp[i, :].reshape((2, 1)),
+                         des=desc[i, :].reshape((-1, 1)), uv_history=[kp[i, :].reshape((2, 1))]) for i in range(len(kp))]
 
     # -- bootstrap (reference extractor.py:134-191) -------------------------------------------------
     _feature_method = 'sift'
