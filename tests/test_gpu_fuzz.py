@@ -257,3 +257,27 @@ def test_match_fuzz(n1, n2, dim, seed, kind):
     if not same.all():
         q = np.nonzero(~same.all(1))[0]
         assert np.allclose(dist[q], d_o[q], rtol=2e-7)
+
+
+@settings(**dict(FUZZ, max_examples=max(6, FUZZ["max_examples"] // 8)))
+@given(st.integers(24, 260), st.integers(24, 200), st.integers(0, 4), st.integers(0, 2 ** 31 - 1), st.sampled_from([0, 40, 300]))
+def test_sift_fuzz(w, h, kind, seed, nfeatures):
+    """SIFT keypoints and descriptors bit-identical to the oracle over random sizes (odd sizes exercise the decimation and
+    the reflection of kernels wider than the top octaves), contents and feature limits"""
+    import sift_oracle as so
+    from vo_mi355x import VoContext
+    rng = np.random.default_rng(seed)
+    if kind == 4:                                            # blurred blobs: strong, well-separated extrema
+        img = np.zeros((h, w))
+        for _ in range(12):
+            cx, cy, s = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(1.5, 9)
+            yy, xx = np.mgrid[0:h, 0:w]
+            img += rng.uniform(-1, 1) * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+        img = np.clip(128 + 120 * img, 0, 255).astype(np.uint8)
+    else:
+        img = _image(rng, w, h, kind)
+    with VoContext(w, h, max_pts=64) as c:
+        kp, desc = c.sift_detect_compute(img, nfeatures=nfeatures, max_out=1 << 16)
+    kp_o, desc_o = so.detect_and_compute(img, nfeatures=nfeatures)
+    assert kp.shape == kp_o.shape and np.array_equal(kp, kp_o)
+    assert np.array_equal(desc, desc_o)
