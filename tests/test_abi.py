@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.KltParams) == 32 and ctypes.sizeof(_lib.StParams) == 24
     assert ctypes.sizeof(_lib.BaParams) == 56 and ctypes.sizeof(_lib.BaStats) == 40
     assert ctypes.sizeof(_lib.PnpParams) == 24 and ctypes.sizeof(_lib.PnpStats) == 24
-    assert ctypes.sizeof(_lib.EssParams) == 32 and ctypes.sizeof(_lib.EssStats) == 24
+    assert ctypes.sizeof(_lib.EssParams) == 32 and ctypes.sizeof(_lib.EssStats) == 24 and ctypes.sizeof(_lib.SiftKp) == 24
     L = _lib.load()
     k = _lib.KltParams(); L.vo_klt_default_params(ctypes.byref(k))
     assert (k.win, k.max_level, k.max_count) == (31, 3, 30) and abs(k.epsilon - 0.03) < 1e-15
