@@ -72,6 +72,9 @@ class OracleContext:
         return r["poses"], r["points"], dict(cost0=r["cost0"], cost=r["cost"], lam=r["lam"], iters=r["iters"],
                                              accepted=r["accepted"], status=r["status"], n_obs=int(bo.valid_mask(obs).sum()))
 
+    def bilateral(self, img, d=5, sigma_color=1.5, sigma_space=1.5):
+        return o.bilateral(np.ascontiguousarray(img, np.uint8), d, sigma_color, sigma_space)
+
     def sift_detect_compute(self, img, mask=None, nfeatures=1000, max_out=None):
         import sift_oracle as so
         return so.detect_and_compute(img, nfeatures=nfeatures, mask=mask)

@@ -76,6 +76,17 @@ class VoContext:
         loader's pre-filter, loader.py:16-20,86); d = 0 switches it off."""
         self._ck(self._L.vo_set_prefilter(self._h, int(d), float(sigma_color), float(sigma_space)))
 
+    def bilateral(self, img, d=5, sigma_color=1.5, sigma_space=1.5):
+        """cv2.bilateralFilter(img, d, sigmaColor, sigmaSpace) -> filtered uint8 image (Loader.getImage, reference
+        loader.py:86).  Runs the fused pre-filter of the frame store and reads level 0 back, i.e. it PUSHES a frame: use a
+        context of its own (vo_mi355x.Loader does), not the one an Extractor is tracking with."""
+        self.set_prefilter(d, sigma_color, sigma_space)
+        try:
+            self.push_frame(img)
+            return self.pyramid_read(1, 0)[0]
+        finally:
+            self.set_prefilter(0)
+
     def push_frame(self, img):
         img = np.asarray(img)
         if img.dtype != np.uint8:

@@ -161,3 +161,38 @@ def make_ba_scene(n_pts=2000, n_slots=10, K=KITTI_K, seed=0, obs_noise=0.3, pt_n
     poses0[:-2, 3:] += rng.normal(0, pose_noise, (W - 2, 3)) if W > 2 else 0.0
     return dict(K=np.array(K, np.float64), poses0=poses0, points0=points0, obs=obs,
                 poses_gt=poses_gt, points_gt=pts)
+
+
+def make_two_plane_sequence(n_frames, w=640, h=480, f=500.0, seed=2024, z_bg=10.0, z_fg=6.5, roll=0.004,
+                            step=(0.10, 0.03, -0.06), margin=128):
+    """A rendered sequence with a KNOWN camera trajectory and real parallax: two textured fronto-parallel planes (the near
+    one covers the central rectangle of frame 0); under a camera that rolls by `roll` rad and moves by `step` per frame
+    the image motion of the plane at depth Z is the similarity  p' - c = Z / (Z + Tz) R2 (p - c) + f T_xy / (Z + Tz),
+    which render_frame renders exactly.  -> frames uint8 [n, h, w], K (principal point at the image centre),
+    poses [n, 4, 4] mapping frame-0 camera coordinates to frame-t camera coordinates."""
+    K = np.array([[f, 0, (w - 1) / 2], [0, f, (h - 1) / 2], [0, 0, 1]])
+    c = K[:2, 2]
+    tex_bg = make_texture(h + 2 * margin, w + 2 * margin, seed)
+    tex_fg = make_texture(h + 2 * margin, w + 2 * margin, seed + 1)
+    rect = (0.29 * w, 0.25 * h, 0.72 * w, 0.77 * h)
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    frames = np.empty((n_frames, h, w), np.uint8)
+    poses = np.empty((n_frames, 4, 4))
+    for t in range(n_frames):
+        ang = roll * t
+        Hm = np.eye(4)
+        Hm[:2, :2] = [[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]]
+        Hm[:3, 3] = np.asarray(step, float) * t
+        poses[t] = Hm
+        A = []
+        for Z in (z_bg, z_fg):
+            s_ = Z / (Z + Hm[2, 3])
+            Ak = np.zeros((2, 3)); Ak[:, :2] = s_ * Hm[:2, :2]; Ak[:, 2] = c - s_ * Hm[:2, :2] @ c + f * Hm[:2, 3] / (Z + Hm[2, 3])
+            A.append(Ak)
+        bg = render_frame(tex_bg, A[0], w, h, margin)
+        fg = render_frame(tex_fg, A[1], w, h, margin)
+        Ainv = np.linalg.inv(np.vstack([A[1], [0, 0, 1]]))[:2]
+        x0 = Ainv[0, 0] * xs + Ainv[0, 1] * ys + Ainv[0, 2]; y0 = Ainv[1, 0] * xs + Ainv[1, 1] * ys + Ainv[1, 2]
+        inside = (x0 >= rect[0]) & (x0 < rect[2]) & (y0 >= rect[1]) & (y0 < rect[3])
+        frames[t] = np.where(inside, fg, bg)
+    return frames, K, poses
