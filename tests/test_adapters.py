@@ -268,3 +268,23 @@ def test_match_lists_cpu():
 @pytest.mark.gpu
 def test_match_lists_gpu_equals_cpu_twin():
     assert _run_match_lists(_gpu_ctx) == _run_match_lists(_oracle_ctx)
+
+
+def test_state_deepcopy_fast_path_keeps_deepcopy_semantics():
+    """Keypoint / Landmark implement __deepcopy__ (the reference's loop deep-copies every landmark every frame): result must
+    equal the generic one -- independent arrays, views become standalone copies, objects that were identical stay identical"""
+    from vo_mi355x import Keypoint, Landmark
+    base = np.arange(6, dtype=np.float32).reshape(3, 2)
+    v = base[1, :].reshape(2, 1)
+    k = Keypoint(3, 2, v, v, np.zeros((128, 1), np.float32), [v, np.ones((2, 1))])
+    k2 = copy.deepcopy(k)
+    assert k2 is not k and k2.uv is k2.uv_first and k2.uv_history[0] is k2.uv and k2.uv is not k.uv and np.array_equal(k2.uv, k.uv)
+    assert k2.uv.base is None and k2.uv.shape == (2, 1) and k2.uv.dtype == np.float32
+    assert k2.uv_history is not k.uv_history and len(k2.uv_history) == 2 and (k2.t_first, k2.t_total) == (3, 2)
+    k2.uv_history.append(1); k2.uv[0, 0] = 99
+    assert len(k.uv_history) == 2 and k.uv[0, 0] == 2 and base[1, 0] == 2
+    both = copy.deepcopy([k, k])
+    assert both[0] is both[1]
+    lm = Landmark(5, np.ones((3, 1)), k.des)
+    pair = copy.deepcopy((k, lm))
+    assert pair[1].des is pair[0].des and pair[1].p is not lm.p and np.array_equal(pair[1].p, lm.p) and pair[1].t_latest == 5

@@ -2,9 +2,22 @@
 src/state/{keypoint,landmark,trajectory,state}.py (keypoint.py:4-21, landmark.py:4-13,
 trajectory.py:3-31, state.py:4-10), so objects of either package can be passed to
 the drop-in Extractor / BundleAdjuster (they only rely on attribute names)."""
+from copy import deepcopy
 from dataclasses import dataclass
 
 import numpy as np
+
+
+def _dc(a, memo):
+    """copy.deepcopy of one field with the memo protocol (objects that were the same stay the same: a new keypoint's
+    uv_first, uv and first history entry are views of one array), arrays through ndarray.copy -- the generic
+    deepcopy machinery costs ~10x more per object and the reference's loop deep-copies every landmark every frame
+    (extractor.py:86, pipeline.py:101-102)"""
+    r = memo.get(id(a))
+    if r is None:
+        r = a.copy() if type(a) is np.ndarray else deepcopy(a, memo)
+        memo[id(a)] = r
+    return r
 
 
 @dataclass
@@ -17,6 +30,24 @@ class Keypoint:
     des: np.ndarray
     uv_history: list
 
+    def __deepcopy__(self, memo):
+        new = Keypoint.__new__(Keypoint)
+        memo[id(self)] = new
+        new.t_first, new.t_total = self.t_first, self.t_total
+        new.uv_first, new.uv, new.des = _dc(self.uv_first, memo), _dc(self.uv, memo), _dc(self.des, memo)
+        h = self.uv_history
+        if type(h) is list:
+            hist = memo.get(id(h))
+            if hist is None:
+                hist = []
+                memo[id(h)] = hist
+                for e in h:
+                    hist.append(_dc(e, memo))
+            new.uv_history = hist
+        else:
+            new.uv_history = deepcopy(h, memo)
+        return new
+
 
 @dataclass
 class Landmark:
@@ -24,6 +55,13 @@ class Landmark:
     t_latest: int
     p: np.ndarray
     des: np.ndarray
+
+    def __deepcopy__(self, memo):
+        new = Landmark.__new__(Landmark)
+        memo[id(self)] = new
+        new.t_latest = self.t_latest
+        new.p, new.des = _dc(self.p, memo), _dc(self.des, memo)
+        return new
 
 
 class Trajectory:
