@@ -38,6 +38,7 @@ struct vo_st_ws {
   float* d_pts = nullptr;          // uploaded cur_pts (non-resident call)
   int n_blockmax = 0;
   int last_max_corners = 0;
+  bool fused = true;               // block_size 31: k_st_eig_fused instead of k_st_sobel_hsum + k_st_vsum_eig (VO_ST_FUSED=0: off)
 };
 
 struct disc_rows { int hw[ST_MAX_RADIUS + 1]; };
@@ -191,6 +192,141 @@ __global__ void __launch_bounds__(256) k_st_vsum_eig(const int32_t* __restrict__
   if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = lmax;
   __syncthreads();
   if (threadIdx.x == 0) blockmax[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_st_eig_fused : Sobel products, 31 x 31 box sums and the min-eigenvalue map in ONE pass over the image.
+// The two-kernel form above moves 12 B/px of row sums through HBM twice (0.19 GB written + 0.62 GB read per batched
+// launch); this one reads 1 B/px and writes 4.  A workgroup owns 256 - 2 R product columns x `rb` output rows and walks
+// down the band: a thread = one product column (reflected like the box filter reflects the product image); the 3-row
+// Sobel window rolls through registers (3 byte loads per row), the VERTICAL box sum is a running sum over a ring of the
+// last 2 R + 1 products held in registers (ring index = unrolled loop counter), the HORIZONTAL box sum of the running
+// sums is a wave prefix scan (DPP) + one LDS exchange: S(x) = P(x + R) - P(x - R - 1), wave totals added where the
+// window straddles two waves.  All sums are uint32 modulo 2^32 -- the prefix overflows, the window sum (< 2^31) does not --
+// so the result is bit-identical to the two-kernel form and to the oracle.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t st_ld_u32_any(const uint8_t* p) {     // unaligned dword load (one global_load_dword)
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+
+#define ST_DPP_ADD(v, ctrl, rmask, bc) v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, bc)
+// inclusive wave prefix sums of three values; the three chains are interleaved so that each DPP read is two VALU
+// instructions behind the write it depends on (no hazard s_nops)
+__device__ __forceinline__ void st_scan64x3(unsigned& a, unsigned& b, unsigned& c) {
+  ST_DPP_ADD(a, 0x111, 0xf, true); ST_DPP_ADD(b, 0x111, 0xf, true); ST_DPP_ADD(c, 0x111, 0xf, true);      // row_shr:1
+  ST_DPP_ADD(a, 0x112, 0xf, true); ST_DPP_ADD(b, 0x112, 0xf, true); ST_DPP_ADD(c, 0x112, 0xf, true);      // row_shr:2
+  ST_DPP_ADD(a, 0x114, 0xf, true); ST_DPP_ADD(b, 0x114, 0xf, true); ST_DPP_ADD(c, 0x114, 0xf, true);      // row_shr:4
+  ST_DPP_ADD(a, 0x118, 0xf, true); ST_DPP_ADD(b, 0x118, 0xf, true); ST_DPP_ADD(c, 0x118, 0xf, true);      // row_shr:8
+  ST_DPP_ADD(a, 0x142, 0xa, false); ST_DPP_ADD(b, 0x142, 0xa, false); ST_DPP_ADD(c, 0x142, 0xa, false);   // row_bcast:15 -> rows 1, 3
+  ST_DPP_ADD(a, 0x143, 0xc, false); ST_DPP_ADD(b, 0x143, 0xc, false); ST_DPP_ADD(c, 0x143, 0xc, false);   // row_bcast:31 -> rows 2, 3
+}
+
+__global__ void __launch_bounds__(256) k_st_mask_init(uint8_t* __restrict__ mask, const uint8_t* __restrict__ user_mask, size_t np,
+                                                      uint32_t* __restrict__ scalars, size_t slab_seq) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;      // 16 bytes per thread (np * batch offsets keep 4-byte alignment only)
+  const int bseq = blockIdx.y;
+  if (blockIdx.x == 0 && threadIdx.x < 4) vo_seq(scalars, slab_seq, bseq)[threadIdx.x] = 0;
+  mask += (size_t)bseq * np;
+  if (i >= np) return;
+  if (!user_mask && ((reinterpret_cast<uintptr_t>(mask + i) & 3) == 0) && i + 16 <= np) {
+    uint32_t* m4 = reinterpret_cast<uint32_t*>(mask + i);
+    m4[0] = 0xFFFFFFFFu; m4[1] = 0xFFFFFFFFu; m4[2] = 0xFFFFFFFFu; m4[3] = 0xFFFFFFFFu;
+    return;
+  }
+  if (user_mask) user_mask += (size_t)bseq * np;
+  for (int k = 0; k < 16; k++)
+    if (i + k < np) mask[i + k] = user_mask ? user_mask[i + k] : (uint8_t)255;
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict__ img, size_t img_seq_px, int pitch, int W, int H, int rb, float s2,
+                                                      const uint8_t* __restrict__ mask, float* __restrict__ eig, float* __restrict__ blockmax) {
+  constexpr int D = 2 * R + 1, OUTC = 256 - 2 * R;
+  __shared__ uint4 s_p[2][256];
+  __shared__ float s_m[4];
+  const int t = threadIdx.x;
+  const int x0 = blockIdx.x * OUTC, y0 = blockIdx.y * rb, bseq = blockIdx.z;
+  const int rows_out = min(rb, H - y0);
+  const int total = rows_out + 2 * R;
+  const int xs = st_reflect101(x0 - R + t, W);                      // product column of this thread
+  const uint8_t* base = img + (size_t)bseq * img_seq_px + (size_t)VO_PAD * pitch + VO_PAD;    // pixel (0, 0), uniform
+  const int xo = x0 + t - R;                                          // output column
+  const bool outt = (t >= R) && (t < 256 - R) && (xo < W);
+  const int xo_c = outt ? xo : 0;
+  const size_t np = (size_t)W * H;
+  mask += (size_t)bseq * np; eig += (size_t)bseq * np;
+  unsigned ring[D][3];
+#pragma unroll
+  for (int u = 0; u < D; u++) { ring[u][0] = 0; ring[u][1] = 0; ring[u][2] = 0; }
+  unsigned V0 = 0, V1 = 0, V2 = 0;
+  float lmax = 0.f;
+  // the three image rows of a product row arrive as unaligned dwords (bytes xs - 1 .. xs + 2), fetched PF product rows
+  // ahead: with one round trip to L2 per row and three waves per SIMD the kernel was bound by that latency
+  constexpr int PF = 3;
+  uint32_t q[PF][3];
+  auto fetch = [&](int k, uint32_t (&w)[3]) {
+    int rp = y0 - R + min(k, total - 1);                            // product row (uniform); one reflection is enough: overshoot <= R < H
+    rp = rp < 0 ? -rp : (rp >= H ? 2 * (H - 1) - rp : rp);
+    const uint8_t* r1 = base + (size_t)rp * pitch + (xs - 1);
+    w[0] = st_ld_u32_any(r1 - pitch); w[1] = st_ld_u32_any(r1); w[2] = st_ld_u32_any(r1 + pitch);
+  };
+#pragma unroll
+  for (int i = 0; i < PF; i++) fetch(i, q[i]);
+  uint8_t mk_next = mask[(size_t)y0 * W + xo_c];
+  for (int kb = 0; kb < total; kb += D) {
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+      const int k = kb + u;
+      if (k < total) {
+        const uint32_t w0 = q[0][0], w1 = q[0][1], w2 = q[0][2];
+        // the mask byte of a row's output is requested one iteration ahead: waiting for it then leaves the prefetched
+        // image rows in flight (loads return in order).  Unconditional, clamped address: a load under a divergent branch
+        // would be waited for at the end of the branch.
+        const uint8_t mk = mk_next;
+        mk_next = mask[(size_t)(y0 + min(max(k + 1 - 2 * R, 0), rows_out - 1)) * W + xo_c];
+#pragma unroll
+        for (int i = 0; i + 1 < PF; i++) { q[i][0] = q[i + 1][0]; q[i][1] = q[i + 1][1]; q[i][2] = q[i + 1][2]; }
+        fetch(k + PF, q[PF - 1]);
+        const int a0 = w0 & 0xff, c0 = (w0 >> 16) & 0xff, b0 = (w0 >> 8) & 0xff;
+        const int a1 = w1 & 0xff, c1 = (w1 >> 16) & 0xff;
+        const int a2 = w2 & 0xff, c2 = (w2 >> 16) & 0xff, b2 = (w2 >> 8) & 0xff;
+        const int dx = ((c0 - a0) + (c2 - a2)) + 2 * (c1 - a1);
+        const int dy = (a2 + 2 * b2 + c2) - (a0 + 2 * b0 + c0);
+        const unsigned pxx = (unsigned)(dx * dx), pxy = (unsigned)(dx * dy), pyy = (unsigned)(dy * dy);
+        V0 += pxx - ring[u][0]; V1 += pxy - ring[u][1]; V2 += pyy - ring[u][2];
+        ring[u][0] = pxx; ring[u][1] = pxy; ring[u][2] = pyy;
+        if (k >= 2 * R) {
+          unsigned P0 = V0, P1 = V1, P2 = V2;
+          st_scan64x3(P0, P1, P2);
+          uint4* buf = s_p[k & 1];
+          buf[t] = make_uint4(P0, P1, P2, 0u);
+          __syncthreads();
+          if (outt) {
+            const int ia = t + R, ib = t - R - 1;
+            const uint4 A = buf[ia];
+            uint4 Bv = make_uint4(0u, 0u, 0u, 0u), T = Bv;
+            if (ib >= 0) {
+              Bv = buf[ib];
+              if ((ia >> 6) != (ib >> 6)) T = buf[(ib | 63)];         // total of the wave the window starts in
+            }
+            const int sa = (int)(A.x - Bv.x + T.x), sb = (int)(A.y - Bv.y + T.y), sc = (int)(A.z - Bv.z + T.z);
+            const int y = y0 + k - 2 * R;
+            const float a = ((float)sa * s2) * 0.5f, b = (float)sb * s2, c = ((float)sc * s2) * 0.5f;
+            const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+            const size_t o = (size_t)y * W + xo;
+            eig[o] = e;
+            if (mk && e > lmax) lmax = e;
+          }
+        }
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+  if ((t & 63) == 0) s_m[t >> 6] = lmax;
+  __syncthreads();
+  if (t == 0) blockmax[(size_t)bseq * gridDim.x * gridDim.y + blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
 }
 
 #define ST_NMS_ROWS 8
@@ -566,11 +702,11 @@ static int32_t st_init(vo_ctx* c) {
   const size_t np = (size_t)c->width * c->height, B = (size_t)c->batch;
   VO_HIP(c, hipMalloc((void**)&s->d_mask, np * B));
   VO_HIP(c, hipMalloc((void**)&s->d_user_mask, np * B));
-  VO_HIP(c, hipMalloc((void**)&s->d_h, np * 3 * sizeof(int32_t) * B));
+  s->fused = !(getenv("VO_ST_FUSED") && atoi(getenv("VO_ST_FUSED")) == 0);
   VO_HIP(c, hipMalloc((void**)&s->d_eig, np * sizeof(float) * B));
   s->d_scalars = vo_slab<uint32_t>(c, c->off_st_scalars);
   VO_HIP(c, hipMalloc((void**)&s->d_cand, sizeof(unsigned long long) * ST_CAND_STRIDE * B));
-  s->n_blockmax = vo_div_up(c->width, 256) * vo_div_up(c->height, ST_ROWS);
+  s->n_blockmax = vo_div_up(c->width, 256 - 30) * vo_div_up(c->height, 16);      // upper bound over both eigenvalue paths
   VO_HIP(c, hipMalloc((void**)&s->d_blockmax, sizeof(float) * (size_t)s->n_blockmax * B));
   s->d_out = vo_slab<float>(c, c->off_st_out);
   VO_HIP(c, hipMalloc((void**)&s->d_pts, sizeof(float) * 2 * (size_t)c->max_pts * B));
@@ -618,8 +754,18 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
   vo_prof_scope prof(c, VO_PROF_ST);
   const int W = c->width, H = c->height, r = prm->block_size / 2, B = c->batch;
   const vo_frame& F = c->fr[c->cur];
-  hipLaunchKernelGGL(k_st_sobel_hsum, dim3(vo_div_up(W, ST_HS_COLS), H, B), dim3(256), 0, c->stream, F.img[0], c->lvl_px[0],
-                     c->lv[0].pitch, W, H, r, s->d_h, s->d_mask, d_user_mask, s->d_scalars, c->slab_seq);
+  const double scale_d = 1.0 / ((double)(1 << 2) * prm->block_size * 255.0);
+  const float sf = (float)scale_d;
+  const float s2 = sf * sf;
+  const bool fused = s->fused && r == 15 && H > 31 && W > 31;    // (single border reflection per row inside the kernel)
+  int n_blockmax;
+  if (fused) hipLaunchKernelGGL(k_st_mask_init, dim3(vo_div_up((int)(((size_t)W * H + 15) / 16), 256), B), dim3(256), 0, c->stream, s->d_mask, d_user_mask,
+                                (size_t)W * H, s->d_scalars, c->slab_seq);
+  else {
+    if (!s->d_h) VO_HIP(c, hipMalloc((void**)&s->d_h, (size_t)W * H * 3 * sizeof(int32_t) * B));
+    hipLaunchKernelGGL(k_st_sobel_hsum, dim3(vo_div_up(W, ST_HS_COLS), H, B), dim3(256), 0, c->stream, F.img[0], c->lvl_px[0],
+                       c->lv[0].pitch, W, H, r, s->d_h, s->d_mask, d_user_mask, s->d_scalars, c->slab_seq);
+  }
   if (n_cur > 0) {
     disc_rows rows;
     circle_rows(mask_radius, &rows);
@@ -627,13 +773,22 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
     hipLaunchKernelGGL(k_st_discs, dim3(vo_div_up(total, 256), B), dim3(256), 0, c->stream, d_pts, pts_seq, n_cur, mask_radius,
                        rows, s->d_mask, W, H, counts);
   }
-  const double scale_d = 1.0 / ((double)(1 << 2) * prm->block_size * 255.0);
-  const float sf = (float)scale_d;
-  const float s2 = sf * sf;
-  hipLaunchKernelGGL(k_st_vsum_eig, dim3(vo_div_up(W, 256), vo_div_up(H, ST_ROWS), B), dim3(256), 0, c->stream, s->d_h,
-                     s->d_mask, W, H, r, s2, s->d_eig, s->d_blockmax);
+  if (fused) {
+    // rows per band: few bands keep the 30-row start-up small; with few sequences in flight more, shorter bands fill the GPU
+    const int gx = vo_div_up(W, 256 - 30);
+    int rb = 94;
+    while (rb > 16 && gx * vo_div_up(H, rb) * B < 512) rb = (rb + 1) / 2;
+    const int gy = vo_div_up(H, rb);
+    n_blockmax = gx * gy;
+    hipLaunchKernelGGL(k_st_eig_fused<15>, dim3(gx, gy, B), dim3(256), 0, c->stream, F.img[0], c->lvl_px[0], c->lv[0].pitch, W, H, rb, s2,
+                       s->d_mask, s->d_eig, s->d_blockmax);
+  } else {
+    n_blockmax = vo_div_up(W, 256) * vo_div_up(H, ST_ROWS);
+    hipLaunchKernelGGL(k_st_vsum_eig, dim3(vo_div_up(W, 256), vo_div_up(H, ST_ROWS), B), dim3(256), 0, c->stream, s->d_h,
+                       s->d_mask, W, H, r, s2, s->d_eig, s->d_blockmax);
+  }
   hipLaunchKernelGGL(k_st_nms, dim3(vo_div_up(W - 2, 256), vo_div_up(H - 2, ST_NMS_ROWS), B), dim3(256), 0, c->stream, s->d_eig,
-                     s->d_mask, W, H, prm->quality_level, s->d_blockmax, s->n_blockmax, s->d_cand, s->d_scalars, c->slab_seq);
+                     s->d_mask, W, H, prm->quality_level, s->d_blockmax, n_blockmax, s->d_cand, s->d_scalars, c->slab_seq);
   const int use_dist = prm->min_distance >= 1.0 ? 1 : 0;
   // grid cell: >= min_distance (3x3 neighbourhood then covers the exclusion radius), coarse enough to fit LDS
   int cell = use_dist ? (int)ceil(prm->min_distance) : 1;
