@@ -83,3 +83,24 @@ def test_klt_points_outside_and_on_the_border():
         q1, qs, qe, qi = o.klt(frames[0], frames[1], pts, return_iters=True)
         assert np.array_equal(p1, q1) and np.array_equal(st, qs) and np.array_equal(err, qe) and np.array_equal(it, qi)
         assert st[0] == 0 and st[6] == 0 and st[-1] == 1
+
+
+def test_shi_tomasi_plateaus_every_pixel_a_local_maximum():
+    """block images give large exactly-flat regions of the eigenvalue map; under OpenCV's `value == dilated` rule every pixel of
+    a plateau is a candidate, so a 256 x 8 NMS tile can yield 2048 of them (regression: its LDS list held half of that)"""
+    import vo_oracle as o
+    from vo_mi355x import VoContext
+    rng = np.random.default_rng(1)
+    w, h = 500, 400
+    img = np.kron(rng.integers(0, 2, (h // 16 + 1, w // 16 + 1)) * 200.0 + 20, np.ones((16, 16)))[:h, :w].astype(np.uint8)
+    for B in (1, 3):
+        with VoContext(w, h, max_pts=128, batch=B) as c:
+            c.push_frame(np.stack([img] * B) if B > 1 else img)
+            corners = c.shi_tomasi(None, 7, params=c.st_params(max_corners=300, quality_level=0.03, min_distance=7.0, block_size=31))
+            eig, mask, nc = c.shi_tomasi_read()
+        ref, reig, rnc = o.good_features(img, np.full((h, w), 255, np.uint8), maxCorners=300, qualityLevel=0.03, minDistance=7.0,
+                                         blockSize=31, return_aux=True)
+        assert rnc > 16384
+        for b in range(B):
+            assert np.array_equal(eig[b] if B > 1 else eig, reig) and int(nc[b] if B > 1 else nc) == rnc
+            assert np.array_equal(np.asarray(corners[b] if B > 1 else corners).reshape(-1, 2), ref.reshape(-1, 2))

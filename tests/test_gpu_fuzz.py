@@ -3,11 +3,13 @@ sizes, contents, parameters and point sets; bundle adjustment against the numpy 
 visibility patterns.  Deterministic (derandomised) so that a failure reproduces."""
 import numpy as np
 import pytest
-from hypothesis import HealthCheck, given, settings, strategies as st
+from hypothesis import HealthCheck, Phase, given, settings, strategies as st
 
 pytestmark = pytest.mark.gpu
 import os
-FUZZ = dict(max_examples=int(os.environ.get("VO_FUZZ_EXAMPLES", "80")), deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+# no shrink phase: an example costs a context creation + an oracle run, shrinking a failure would take tens of minutes of GPU time
+FUZZ = dict(max_examples=int(os.environ.get("VO_FUZZ_EXAMPLES", "80")), deadline=None, derandomize=True, suppress_health_check=list(HealthCheck),
+            phases=(Phase.explicit, Phase.reuse, Phase.generate))
 
 
 def _image(rng, w, h, kind):
@@ -56,15 +58,25 @@ def test_shi_tomasi_fuzz(w, h, kind, seed, bs, md, q, radius, maxc):
     img = _image(rng, w, h, kind)
     n = int(rng.integers(0, 80))
     pts = np.stack([rng.uniform(-5, w + 5, n), rng.uniform(-5, h + 5, n)], 1).astype(np.float32)
+    from vo_mi355x import VoError
     with VoContext(w, h, max_pts=128) as c:
         c.push_frame(img)
-        corners = c.shi_tomasi(pts if n else None, radius, params=c.st_params(max_corners=maxc, quality_level=q, min_distance=md, block_size=bs))
+        try:
+            corners = c.shi_tomasi(pts if n else None, radius, params=c.st_params(max_corners=maxc, quality_level=q, min_distance=md, block_size=bs))
+        except VoError as e:
+            corners = e
         eig, mask, nc = c.shi_tomasi_read()
     m = np.full((h, w), 255, np.uint8)
     for x, y in np.int32(pts):
         o.circle_mask(m, (int(x), int(y)), radius, 0)
     ref, reig, rnc = o.good_features(img, m, maxCorners=maxc, qualityLevel=q, minDistance=md, blockSize=bs, return_aux=True)
-    assert np.array_equal(mask, m) and np.array_equal(eig, reig) and nc == rnc and np.array_equal(corners, ref)
+    assert np.array_equal(mask, m) and np.array_equal(eig, reig) and nc == rnc
+    if isinstance(corners, VoError):
+        # flat plateaus (every pixel a 3x3 maximum): more candidates than the LDS sort holds and the strongest 16384 do not
+        # fill max_corners -> the library reports it instead of returning a possibly different list
+        assert corners.code == -5 and rnc > 16384
+    else:
+        assert np.array_equal(corners, ref)
 
 
 @settings(**dict(FUZZ, max_examples=max(10, FUZZ["max_examples"] * 5 // 8)))
@@ -281,3 +293,40 @@ def test_sift_fuzz(w, h, kind, seed, nfeatures):
     kp_o, desc_o = so.detect_and_compute(img, nfeatures=nfeatures)
     assert kp.shape == kp_o.shape and np.array_equal(kp, kp_o)
     assert np.array_equal(desc, desc_o)
+
+
+@settings(**dict(FUZZ, max_examples=max(10, FUZZ["max_examples"] // 2)))
+@given(st.integers(33, 760), st.integers(33, 420), st.integers(0, 3), st.integers(0, 2 ** 31 - 1), st.sampled_from([0, 1, 16, 31, 47, 94, 200]),
+       st.sampled_from([1, 2, 5]))
+def test_shi_tomasi_fused_kernel_fuzz(w, h, kind, seed, rb, batch):
+    """block size 31 goes through k_st_eig_fused: image widths across 1..4 column strips, every band height (the launch picks
+    it from the batch size; VO_ST_RB forces it here), batches -- eigenvalue map, mask, candidates and corners bit-exact"""
+    import os
+    import vo_oracle as o
+    from vo_mi355x import VoContext
+    rng = np.random.default_rng(seed)
+    imgs = [_image(rng, w, h, (kind + b) % 4) for b in range(batch)]
+    n = int(rng.integers(0, 60))
+    pts = np.stack([rng.uniform(-5, w + 5, (batch, n)), rng.uniform(-5, h + 5, (batch, n))], 2).astype(np.float32)
+    if rb:
+        os.environ["VO_ST_RB"] = str(rb)
+    try:
+        with VoContext(w, h, max_pts=128, batch=batch) as c:
+            prm = c.st_params(max_corners=300, quality_level=0.03, min_distance=7.0, block_size=31)
+            if batch == 1:
+                c.push_frame(imgs[0])
+                corners = [c.shi_tomasi(pts[0] if n else None, 7, params=prm)]
+                eig, mask, nc = (x[None] if isinstance(x, np.ndarray) else np.array([x]) for x in c.shi_tomasi_read())
+            else:
+                c.push_frame(np.stack(imgs))
+                corners = c.shi_tomasi(pts if n else None, 7, params=prm)
+                eig, mask, nc = c.shi_tomasi_read()
+    finally:
+        os.environ.pop("VO_ST_RB", None)
+    for b in range(batch):
+        m = np.full((h, w), 255, np.uint8)
+        for x, y in np.int32(pts[b]):
+            o.circle_mask(m, (int(x), int(y)), 7, 0)
+        ref, reig, rnc = o.good_features(imgs[b], m, maxCorners=300, qualityLevel=0.03, minDistance=7.0, blockSize=31, return_aux=True)
+        assert np.array_equal(mask[b], m) and np.array_equal(eig[b], reig) and int(nc[b]) == rnc
+        assert np.array_equal(np.asarray(corners[b]).reshape(-1, 2), ref.reshape(-1, 2))

@@ -38,6 +38,7 @@ struct vo_st_ws {
   float* d_pts = nullptr;          // uploaded cur_pts (non-resident call)
   int n_blockmax = 0;
   int last_max_corners = 0;
+  int force_rb = 0;
   bool fused = true;               // block_size 31: k_st_eig_fused instead of k_st_sobel_hsum + k_st_vsum_eig (VO_ST_FUSED=0: off)
 };
 
@@ -335,7 +336,7 @@ __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, c
                                                 unsigned long long* __restrict__ cand, uint32_t* __restrict__ scalars, size_t slab_seq) {
   __shared__ float s_m[4];
   __shared__ unsigned int s_cnt, s_base;
-  __shared__ unsigned long long s_list[256 * ST_NMS_ROWS / 2];
+  __shared__ unsigned long long s_list[256 * ST_NMS_ROWS];     // every pixel of the tile can qualify: the test is v >= neighbours, a flat plateau passes everywhere
   __shared__ float s_tile[ST_NMS_ROWS + 2][260];
   const int tid = threadIdx.x;
   {
@@ -703,10 +704,11 @@ static int32_t st_init(vo_ctx* c) {
   VO_HIP(c, hipMalloc((void**)&s->d_mask, np * B));
   VO_HIP(c, hipMalloc((void**)&s->d_user_mask, np * B));
   s->fused = !(getenv("VO_ST_FUSED") && atoi(getenv("VO_ST_FUSED")) == 0);
+  s->force_rb = getenv("VO_ST_RB") ? atoi(getenv("VO_ST_RB")) : 0;       // test knob: rows per band of the fused kernel
   VO_HIP(c, hipMalloc((void**)&s->d_eig, np * sizeof(float) * B));
   s->d_scalars = vo_slab<uint32_t>(c, c->off_st_scalars);
   VO_HIP(c, hipMalloc((void**)&s->d_cand, sizeof(unsigned long long) * ST_CAND_STRIDE * B));
-  s->n_blockmax = vo_div_up(c->width, 256 - 30) * vo_div_up(c->height, 16);      // upper bound over both eigenvalue paths
+  s->n_blockmax = vo_div_up(c->width, 256 - 30) * c->height;                     // upper bound over both eigenvalue paths (1-row bands)
   VO_HIP(c, hipMalloc((void**)&s->d_blockmax, sizeof(float) * (size_t)s->n_blockmax * B));
   s->d_out = vo_slab<float>(c, c->off_st_out);
   VO_HIP(c, hipMalloc((void**)&s->d_pts, sizeof(float) * 2 * (size_t)c->max_pts * B));
@@ -778,6 +780,7 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
     const int gx = vo_div_up(W, 256 - 30);
     int rb = 94;
     while (rb > 16 && gx * vo_div_up(H, rb) * B < 512) rb = (rb + 1) / 2;
+    if (s->force_rb > 0) rb = s->force_rb < H ? s->force_rb : H;
     const int gy = vo_div_up(H, rb);
     n_blockmax = gx * gy;
     hipLaunchKernelGGL(k_st_eig_fused<15>, dim3(gx, gy, B), dim3(256), 0, c->stream, F.img[0], c->lvl_px[0], c->lv[0].pitch, W, H, rb, s2,
