@@ -336,7 +336,8 @@ __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, c
                                                 unsigned long long* __restrict__ cand, uint32_t* __restrict__ scalars, size_t slab_seq) {
   __shared__ float s_m[4];
   __shared__ unsigned int s_cnt, s_base;
-  __shared__ unsigned long long s_list[256 * ST_NMS_ROWS];     // every pixel of the tile can qualify: the test is v >= neighbours, a flat plateau passes everywhere
+  __shared__ uint16_t s_list[256 * ST_NMS_ROWS];     // tile positions (row << 8 | column); EVERY pixel of the tile can qualify: the test is
+                                                     // v >= neighbours, a flat plateau passes everywhere
   __shared__ float s_tile[ST_NMS_ROWS + 2][260];
   const int tid = threadIdx.x;
   {
@@ -394,9 +395,8 @@ __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, c
       const bool ismax = e0[0] <= v && e0[1] <= v && e0[2] <= v && e1[0] <= v && e1[2] <= v &&
                          e2[0] <= v && e2[1] <= v && e2[2] <= v;
       if (!ismax) continue;
-      const size_t o = (size_t)y * W + x;
-      const unsigned int pos = atomicAdd(&s_cnt, 1u);        // LDS; 3x3 maxima cannot be adjacent -> <= 1/4 of the pixels
-      s_list[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(uint32_t)o;
+      const unsigned int pos = atomicAdd(&s_cnt, 1u);        // LDS
+      s_list[pos] = (uint16_t)((ry << 8) | tid);
     }
   }
   __syncthreads();
@@ -405,7 +405,10 @@ __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, c
   __syncthreads();
   for (unsigned int i = tid; i < cnt; i += 256) {
     const unsigned int pos = s_base + i;
-    if (pos < ST_GLOBAL_CAP) cand[pos] = s_list[i];
+    const int ry = s_list[i] >> 8, tx = s_list[i] & 255;
+    const float v = s_tile[ry + 1][tx + 1];
+    const size_t o = (size_t)(y0 + ry + 1) * W + (x0 + tx + 1);
+    if (pos < ST_GLOBAL_CAP) cand[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(uint32_t)o;
   }
 }
 
