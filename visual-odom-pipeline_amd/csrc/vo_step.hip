@@ -29,17 +29,21 @@ static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame
   // run side by side (the BA iterations are chains of narrow latency-bound launches, Shi-Tomasi is wide streaming
   // kernels).  Under graph capture everything stays on the one captured stream.
   const bool fork = s.do_st && (s.do_dlt || s.do_ba) && !d_frame_idx && c->side_stream;
+  const bool dlt_side = fork && s.do_dlt && s.do_ba;
   if (fork) {
     VO_HIP(c, hipEventRecord(c->ev_fork, c->stream));
     VO_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     hipStream_t main_stream = c->stream;
     c->stream = c->stream2;
     r = vo_shi_tomasi_resident(c, s.n_pts, s.mask_radius, &s.st);
+    // the triangulation does not feed this frame's bundle adjustment (the BA problem is resident): beside a BA it goes to
+    // the side branch too, off the KLT -> BA critical path (48 us of latency-bound work per step)
+    if (r == VO_OK && dlt_side) r = vo_dlt_resident(c);
     c->stream = main_stream;
     if (r != VO_OK) return r;
     VO_HIP(c, hipEventRecord(c->ev_join, c->stream2));
   }
-  if (s.do_dlt) { r = vo_dlt_resident(c); if (r != VO_OK) return r; }
+  if (s.do_dlt && !dlt_side) { r = vo_dlt_resident(c); if (r != VO_OK) return r; }
   if (s.do_ba) { r = vo_ba_solve_resident(c, &s.ba); if (r != VO_OK) return r; }
   if (fork) VO_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
   else if (s.do_st) { r = vo_shi_tomasi_resident(c, s.n_pts, s.mask_radius, &s.st); if (r != VO_OK) return r; }
