@@ -68,10 +68,14 @@ __global__ void __launch_bounds__(256) k_pad_level0_bilateral(const uint8_t* __r
 __global__ void __launch_bounds__(256) k_pad_level0(const uint8_t* __restrict__ raw, size_t raw_seq_stride,
                                                     const int32_t* __restrict__ frame_idx, int w, int h,
                                                     uint8_t* __restrict__ dst, size_t dst_seq_stride, int pitch, int ph) {
-  // 4 consecutive padded columns per thread, one dword store (pitch and VO_PAD are multiples of 4)
-  const int X = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  const int Y = blockIdx.y;
-  if (X >= w + 2 * VO_PAD || Y >= ph) return;
+  // 4 consecutive padded columns per thread, one dword store (pitch and VO_PAD are multiples of 4); the threads of the grid
+  // run over (row, dword) pairs in one flat index so that every workgroup is full (a row is 326 dwords at w = 1241: with a
+  // row per block-row the second 256-thread block of every row was three quarters empty)
+  const int dpr = (w + 2 * VO_PAD + 3) / 4;                          // dwords per padded row
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Y = (int)(gid / (unsigned)dpr);
+  const int X = (int)(gid - (unsigned)Y * (unsigned)dpr) * 4;
+  if (Y >= ph) return;
   raw += (size_t)blockIdx.z * raw_seq_stride;
   dst += (size_t)blockIdx.z * dst_seq_stride;
   if (frame_idx) raw += (size_t)(*frame_idx) * w * h;
@@ -395,7 +399,7 @@ int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, size_t raw_seq_str
   const int B = c->batch;
   {
     const vo_level& L = c->lv[0];
-    dim3 grid(vo_div_up(L.w + 2 * VO_PAD, 1024), L.ph, B);     // 4 columns per thread
+    dim3 grid(vo_div_up(((L.w + 2 * VO_PAD + 3) / 4) * L.ph, 256), 1, B);     // 4 columns per thread, flat (row, dword) index
     dim3 grid1(vo_div_up(L.w + 2 * VO_PAD, 256), L.ph, B);    // bilateral variant: 1 column per thread
     if (c->bil_maxk > 0) {
       bil_args A;
