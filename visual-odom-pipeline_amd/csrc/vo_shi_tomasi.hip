@@ -9,9 +9,10 @@
 // oracle/vo_oracle.c (exact_int = 1).
 //
 // Launches (one stream, no host round trip):
-//   k_st_sobel_hsum : Sobel 3x3 products -> LDS -> horizontal box sums (3 int32 planes) + mask init
+//   k_st_mask_init  : mask = 255 (or the caller's mask), scalars zeroed
 //   k_st_discs      : filled midpoint circles of the tracked keypoints into the mask
-//   k_st_vsum_eig   : sliding vertical box sums -> min-eigenvalue map + masked global max
+//   k_st_eig_fused  : Sobel products, 31 x 31 box sums, min-eigenvalue map + masked maxima in one pass (block size 31;
+//                     other block sizes, tiny images or VO_ST_FUSED=0: k_st_sobel_hsum -> 3 int32 planes -> k_st_vsum_eig)
 //   k_st_nms        : threshold + 3x3 non-max suppression + mask -> compacted (value, index) keys
 //   k_st_select     : ONE workgroup: bitonic sort of the keys in LDS (value desc, index desc) and the
 //                     greedy min-distance selection done as parallel fixed-point rounds (a candidate is
