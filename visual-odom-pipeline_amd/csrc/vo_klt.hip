@@ -71,6 +71,46 @@ __device__ __forceinline__ float wave_sum_exact_f32(int v) {
   return (float)((double)hi * 65536.0 + (double)lo);
 }
 
+// Four (two) wave-wide int32 sums at once as a reduce-scatter: after two quad exchanges lane l holds the quad sum of value
+// number l & 3, the remaining steps (row rotations, row swaps) are multiples of 4 lanes and keep that assignment -- 15 + 4
+// instructions instead of 4 x 7.  Totals must fit int32 (callers pass 16-bit halves).
+template <int CTRL>
+__device__ __forceinline__ int klt_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+
+__device__ __forceinline__ int klt_rows_sum(int z) {            // sum over the 16 quads, class (lane & 3) preserved
+  z += klt_dpp<0x124>(z);                                       // row_ror:4
+  z += klt_dpp<0x128>(z);                                       // row_ror:8
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)z, (unsigned)z, false, false);
+    z = (int)r[0] + (int)r[1];
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)z, (unsigned)z, false, false);
+    z = (int)r[0] + (int)r[1];
+  }
+  return z;
+}
+
+__device__ __forceinline__ void wave_sum4_i32(int a, int b, int c, int d, int lane, int& sa, int& sb, int& sc, int& sd) {
+  const bool odd = lane & 1, up = lane & 2;
+  const int x = (odd ? b : a) + klt_dpp<0xB1>(odd ? a : b);     // quad_perm [1,0,3,2]: even lanes sum a, odd lanes sum b (pairs)
+  const int y = (odd ? d : c) + klt_dpp<0xB1>(odd ? c : d);     //                      even lanes sum c, odd lanes sum d
+  int z = (up ? y : x) + klt_dpp<0x4E>(up ? x : y);             // quad_perm [2,3,0,1]: lane & 3 = 0, 1, 2, 3 <-> a, b, c, d (quads)
+  z = klt_rows_sum(z);
+  sa = __builtin_amdgcn_readlane(z, 0); sb = __builtin_amdgcn_readlane(z, 1);
+  sc = __builtin_amdgcn_readlane(z, 2); sd = __builtin_amdgcn_readlane(z, 3);
+}
+
+__device__ __forceinline__ void wave_sum2_i32(int a, int b, int lane, int& sa, int& sb) {
+  const bool odd = lane & 1;
+  int z = (odd ? b : a) + klt_dpp<0xB1>(odd ? a : b);           // even lanes sum a, odd lanes sum b (pairs)
+  z += klt_dpp<0x4E>(z);                                        // quads
+  z = klt_rows_sum(z);
+  sa = __builtin_amdgcn_readlane(z, 0); sb = __builtin_amdgcn_readlane(z, 1);
+}
+
+__device__ __forceinline__ float klt_combine(int hi, int lo) { return (float)((double)hi * 65536.0 + (double)lo); }
+
 __device__ __forceinline__ void lk_weights(float a, float b, int& iw00, int& iw01, int& iw10, int& iw11) {
   iw00 = (int)rintf((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
   iw01 = (int)rintf(a * (1.f - b) * (float)(1 << W_BITS));
@@ -208,8 +248,13 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
         a12 = dot2(xp, yp, a12);
         a22 = dot2(yp, yp, a22);
       }
-      const float A11 = wave_sum_exact_f32(a11) * FLT_SCALE, A12 = wave_sum_exact_f32(a12) * FLT_SCALE,
-                  A22 = wave_sum_exact_f32(a22) * FLT_SCALE;
+      float A11, A12, A22;
+      {
+        int l11, h11, l12, h12, l22, h22;
+        wave_sum4_i32(a11 & 0xFFFF, a11 >> 16, a12 & 0xFFFF, a12 >> 16, lane, l11, h11, l12, h12);
+        wave_sum2_i32(a22 & 0xFFFF, a22 >> 16, lane, l22, h22);
+        A11 = klt_combine(h11, l11) * FLT_SCALE; A12 = klt_combine(h12, l12) * FLT_SCALE; A22 = klt_combine(h22, l22) * FLT_SCALE;
+      }
       if (level == A.top) VO_STAMP(dbgk, 1);   // first template
       float D = A11 * A22 - A12 * A12;
       const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
@@ -245,8 +290,10 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
           b1 = dot2(d, tX[s], b1);
           b2 = dot2(d, tY[s], b2);
         }
-        const float fb1 = wave_sum_exact_f32(b1) * FLT_SCALE;
-        const float fb2 = wave_sum_exact_f32(b2) * FLT_SCALE;
+        int l1, h1, l2, h2;
+        wave_sum4_i32(b1 & 0xFFFF, b1 >> 16, b2 & 0xFFFF, b2 >> 16, lane, l1, h1, l2, h2);
+        const float fb1 = klt_combine(h1, l1) * FLT_SCALE;
+        const float fb2 = klt_combine(h2, l2) * FLT_SCALE;
         const float dx = (A12 * fb2 - A22 * fb1) * D;
         const float dy = (A12 * fb1 - A11 * fb2) * D;
         nextx += dx; nexty += dy;
