@@ -429,8 +429,13 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_launch_us": round(klt_avg_s * 1e6, 3), "algorithmic_bytes_per_launch": int(klt_bytes),
                 "klt_mean_iters_per_level": [round(x, 3) for x in it_mean],
+                # the same launch when context 0 runs its steps alone after the timed region (no other context's kernels beside it)
+                "alone_avg_launch_us": round(stage["klt"] * 1e3, 3),
+                "alone_frac": round(klt_bytes / max(stage["klt"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 5),
                 "note": "HBM figure = algorithmic bytes / launch time as the contract defines it; the kernel itself is vector-ALU bound "
-                        "(rocprofv3 VALUBusy 96 %, profiles/r01_pmc_valu_batch32.csv) and moves 0.13 GB per launch through HBM"}
+                        "(rocprofv3 VALUBusy 96 %, profiles/r01_pmc_valu_batch32.csv) and moves 0.13 GB per launch through HBM. "
+                        "`frac` is the launch as timed INSIDE the run: with several batched contexts it shares the vector ALUs with the "
+                        "Shi-Tomasi / BA kernels of the other contexts and takes longer than on its own (`alone_*`)"}
         out = {"metric": ("frames/sec @1920x1080, 5000 KLT pts, 20-frame sharded BA (config 5)" if c5 else
                           "frames/sec, Pipeline.step on the device @1241x376 (track table <= 2000 pts, PnP, DLT, 10-frame BA, re-detection)" if pl else
                           "frames/sec @1241x376, 2000 KLT pts, 10-frame BA window"), "value": round(fps, 2),
