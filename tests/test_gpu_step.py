@@ -19,8 +19,10 @@ def _setup(c, frames, pts, scene, n_new):
     c.push_frame_resident(0)
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_frame_step_matches_individual_calls(graph):
+@pytest.mark.parametrize("graph,block_size", [(False, 31), (True, 31), (True, 15), (False, 7)])
+def test_frame_step_matches_individual_calls(graph, block_size):
+    """block size 31 takes the fused Shi-Tomasi eigenvalue kernel, the others the two-kernel form whose row-sum planes are
+    allocated on demand (before a graph capture starts)"""
     from vo_mi355x import VoContext, synthetic as syn
     w, h, n, n_new = 640, 240, 600, 200
     frames, _ = syn.make_sequence(5, w=w, h=h, seed=21, margin=64)
@@ -36,14 +38,14 @@ def test_frame_step_matches_individual_calls(graph):
             c.klt_track_resident(n)
             c.dlt_resident()
             c.ba_solve_resident(bap)
-            c.shi_tomasi_resident(n, 7)
+            c.shi_tomasi_resident(n, 7, params=c.st_params(block_size=block_size))
             ref.append((c.points_download(n), c.dlt_fetch(), c.ba_fetch(), c.shi_tomasi_fetch()))
     with VoContext(w, h, max_pts=1024) as c:
         c.set_graph_mode(graph)
         _setup(c, frames, pts, scene, n_new)
         bap = c.ba_params(max_iters=6)
         for k, f in enumerate(order):
-            c.frame_step_resident(f, n, ba=bap)
+            c.frame_step_resident(f, n, ba=bap, st=c.st_params(block_size=block_size))
             got = c.frame_fetch()
             (p, st, err), (X4, depth, reproj), (po, pt, bst), corners = ref[k]
             assert np.array_equal(got["points2d"], p) and np.array_equal(got["status"], st) and np.array_equal(got["err"], err), k

@@ -740,7 +740,15 @@ static void circle_rows(int radius, disc_rows* rows) {
 
 bool vo_st_ready(const vo_ctx* c) { return c->st != nullptr; }
 int vo_st_last_max_corners(const vo_ctx* c) { return c->st ? c->st->last_max_corners : 0; }
-int32_t vo_st_prepare(vo_ctx* c) { return st_init(c); }
+// all allocations a launch with these parameters needs (called outside any graph capture)
+int32_t vo_st_prepare(vo_ctx* c, const vo_st_params* prm) {
+  int32_t r = st_init(c);
+  if (r != VO_OK) return r;
+  vo_st_ws* s = c->st;
+  const bool fused = s->fused && prm && prm->block_size == 31 && c->height > 31 && c->width > 31;
+  if (!fused && !s->d_h) VO_HIP(c, hipMalloc((void**)&s->d_h, (size_t)c->width * c->height * 3 * sizeof(int32_t) * c->batch));
+  return VO_OK;
+}
 
 extern "C" int32_t vo_st_default_params(vo_st_params* p) {
   if (!p) return VO_E_INVALID;

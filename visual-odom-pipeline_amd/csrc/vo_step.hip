@@ -75,7 +75,7 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
   if (ba) s.ba = *ba; else vo_ba_default_params(&s.ba);
   if (s.do_dlt) VO_CHECK(c, c->dlt_n > 0, VO_E_STATE, "vo_dlt_upload first");
   if (s.do_ba) VO_CHECK(c, vo_ba_ready(c), VO_E_STATE, "vo_ba_upload first");
-  if (s.do_st) { int32_t r = vo_st_prepare(c); if (r != VO_OK) return r; }    // allocations happen outside any capture
+  if (s.do_st) { int32_t r = vo_st_prepare(c, &s.st); if (r != VO_OK) return r; }    // allocations happen outside any capture
 
   // up to two steps may be in flight: step t + 1 is enqueued while the host still reads step t's (pinned) results.
   // A captured graph has its host destination baked in, so graph mode keeps one step in flight and one mirror half.
