@@ -992,19 +992,23 @@ __global__ void __launch_bounds__(256) k_ba_finalize(ba_ptrs Pall, ba_params_dev
   __shared__ double s_esum[4];
   __shared__ double s_part[4 * 640];
   if (n_it > 0) ba_reduce_evalpart<256>(P.sharded ? P.xstat : P.evalpart, P.sharded ? 1 : P.nblk, s_part, s_esum);
+  // gridDim.y workgroups per problem share the copy of x (one 256-thread workgroup took 10 us for 6 000 doubles, at the end of
+  // the critical path of a step); each derives the final state itself (deterministic), the first one publishes it
   if (threadIdx.x == 0) {
     ba_state st;
     if (n_it == 0) st = ba_init_state(prm);
     else ba_decide(P.state[(n_it - 1) & 1], *P.info, s_esum, prm, st);
     s_st = st;
-    *st_out = st;
-    P.state[n_it & 1] = st;
-    *reinterpret_cast<ba_state*>(reinterpret_cast<unsigned char*>(x_out) - 64) = st;   // pub header of this problem
+    if (blockIdx.y == 0) {
+      *st_out = st;
+      P.state[n_it & 1] = st;
+      *reinterpret_cast<ba_state*>(reinterpret_cast<unsigned char*>(x_out) - 64) = st;   // pub header of this problem
+    }
   }
   __syncthreads();
   const double* x = (n_it == 0) ? P.x0 : ba_x(P, s_st.cur);
   const int total = 6 * P.W + 3 * P.N;
-  for (int i = threadIdx.x; i < total; i += blockDim.x) x_out[i] = x[i];
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < total; i += blockDim.x * gridDim.y) x_out[i] = x[i];
 }
 
 // per-observation residual norms at x (dense [W][N], NaN where unobserved) -- parity probe
@@ -1219,7 +1223,7 @@ static int32_t ba_enqueue_iters(vo_ctx* c, const ba_params_dev& prm, int it0, in
 
 static void ba_launch_finalize(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& d, int n_it, ba_state* st_out, int st_stride) {
   vo_ba_ws* b = c->ba;
-  hipLaunchKernelGGL(k_ba_finalize, dim3(c->batch), dim3(256), 0, c->stream, P, d, n_it, b->d_pub, b->pub_bytes, st_out, st_stride);
+  hipLaunchKernelGGL(k_ba_finalize, dim3(c->batch, 8), dim3(256), 0, c->stream, P, d, n_it, b->d_pub, b->pub_bytes, st_out, st_stride);
 }
 
 extern "C" int32_t vo_ba_solve_resident(vo_ctx* c, const vo_ba_params* prm) {
