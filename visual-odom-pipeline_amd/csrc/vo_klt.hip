@@ -173,11 +173,15 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
     pt = (int)(q % (unsigned)A.n);
   }
   if (pt >= A.n) return;
-  if (counts && pt >= counts[bseq]) return;          // track table: this sequence has fewer live points
   const int lane = threadIdx.x;
+  if (iters) iters += (size_t)bseq * A.iters_seq;
+  const bool dead = counts && pt >= counts[bseq];    // track table: this sequence has fewer live points
+  // levels the call does not visit (above `top`, or every level of a dead slot) are reported as -1 by the wave itself
+  // (a memset of the whole table used to precede every launch)
+  if (iters && lane < A.iters_stride && (dead || lane > A.top)) iters[pt * A.iters_stride + lane] = -1;
+  if (dead) return;
   p0 = vo_seq(p0, A.slab_seq, bseq); p1 = vo_seq(p1, A.slab_seq, bseq);
   status = vo_seq(status, A.slab_seq, bseq); err = vo_seq(err, A.slab_seq, bseq);
-  if (iters) iters += (size_t)bseq * A.iters_seq;
   unsigned long long* dbgk = (pt == A.n / 2 && bseq == 0 && dbg) ? dbg + 24 : nullptr;   // diagnostic stamps of one wave
   VO_STAMP(dbgk, 0);
   const int cp = lane >> 2, r = lane & 3;
@@ -384,8 +388,6 @@ static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, size_t off
   A.iters_stride = prm->max_level + 1;
   A.slab_seq = c->slab_seq; A.iters_seq = (size_t)c->max_pts * VO_MAX_LEVELS;
   c->iters_stride = A.iters_stride;
-  // levels above `top` are reported as skipped (-1)
-  VO_HIP(c, hipMemsetAsync(c->d_iters, 0xff, sizeof(int32_t) * A.iters_seq * c->batch, c->stream));
   {
     vo_prof_scope prof(c, VO_PROF_KLT);   // brackets exactly this launch (bench.py roofline figure)
     static const int waves = getenv("VO_KLT_WAVES") ? atoi(getenv("VO_KLT_WAVES")) : 5;
