@@ -166,3 +166,25 @@ def triangulatePoints(projMatr1, projMatr2, projPoints1, projPoints2):
     return _need_backend("triangulatePoints").triangulate(
         np.asarray(projMatr1), np.asarray(projMatr2),
         np.asarray(projPoints1).reshape(-1, 2), np.asarray(projPoints2).reshape(-1, 2))
+
+
+def buildOpticalFlowPyramid(img, winSize, maxLevel, withDerivatives=True, pyrBorder=4, derivBorder=0, tryReuseInputImage=True):
+    """(maxLevel actually built, [level 0 image, level 0 derivatives, level 1 image, ...]) -- interiors only (no border)"""
+    b = _need_backend("buildOpticalFlowPyramid")
+    levels = b.build_pyramid(img, int(winSize[0]), int(maxLevel))
+    out = []
+    for lv in levels:
+        out.append(lv)
+        if withDerivatives:
+            out.append(b.scharr(lv))
+    return len(levels) - 1, out
+
+
+def cornerMinEigenVal(src, blockSize, ksize=3, borderType=4):
+    if ksize != 3:
+        raise NotImplementedError
+    return _need_backend("cornerMinEigenVal").min_eig(src, int(blockSize))
+
+
+def bilateralFilter(src, d, sigmaColor, sigmaSpace, borderType=4):
+    return _need_backend("bilateralFilter").bilateral(src, int(d), float(sigmaColor), float(sigmaSpace))

@@ -4,8 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (os.path.join(ROOT, "visual-odom-pipeline_amd"), os.path.join(ROOT, "oracle"),
-          os.path.join(ROOT, "oracle", "ref_stub"), ROOT):
+# NB: oracle/ref_stub (our stand-in `cv2` package) is deliberately NOT on the path: a real OpenCV on the box must stay importable
+# as `cv2` (tests/test_gpu_live_cv2.py); tests that need the stub's Rodrigues load it by file (helpers.ref_stub_cv2)
+for p in (os.path.join(ROOT, "visual-odom-pipeline_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 

@@ -99,3 +99,9 @@ class OracleContext:
         if r is None:
             return np.full(3, np.nan), np.full(3, np.nan), inl, dict(status=-6, n_inliers=0, hypotheses=info["hyps"], best=-1, cost=np.nan)
         return r, t, inl, dict(status=0, n_inliers=len(inl), hypotheses=info["hyps"], best=info["best"], cost=info["cost"])
+
+    # -- read-backs used by the live-OpenCV comparison harness (tests/live_cv2.py) -----------------
+    def pyramid_read(self, which, level, seq=0):
+        img = (self._prev, self._cur)[which]
+        lv = o.build_pyramid(img, self.win, self.max_level)[level]
+        return lv, o.scharr(lv)

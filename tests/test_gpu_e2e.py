@@ -55,10 +55,12 @@ def _frames(n):
     return out
 
 
-def _run(make_ctx, n_steps, t_init=(0, 4)):
+def _run(make_ctx, n_steps, t_init=(0, 4), frames=None, K=K):
+    """`frames`: list of (image, ground-truth pose) -- default: the rendered two-plane scene of this module"""
     from vo_mi355x import BundleAdjuster, Extractor, State, Trajectory
-    frames = _frames(t_init[1] + n_steps + 1)
-    ctx = make_ctx(W, H)
+    if frames is None:
+        frames = _frames(t_init[1] + n_steps + 1)
+    ctx = make_ctx(frames[0][0].shape[1], frames[0][0].shape[0])
     # ---- Pipeline.__init__ (pipeline.py:17-31) ----
     ba_window, min_kp_dist, max_bidir, max_reproj, min_angle = 4, 7, np.inf, 2.0, 0.5
     extractor = Extractor(min_kp_dist=min_kp_dist, ctx=ctx)

@@ -1,5 +1,5 @@
-"""Config 1: the reference's main loop -- Loader + Pipeline (src/loader/loader.py, src/pipeline/pipeline.py)
--- through the drop-in classes on a 'parking'-shaped dataset written to disk (640 x 480 PNGs, K.txt with cx = 320 and
+"""Config 1: the reference's main loop -- Loader (src/loader/loader.py) feeding the Pipeline loop (src/pipeline/pipeline.py,
+restated in tests/test_gpu_e2e.py) -- through the drop-in classes on a 'parking'-shaped dataset written to disk (640 x 480 PNGs, K.txt with cx = 320 and
 cy = 240, poses.txt; the real set is not available offline): file decoding, GPU bilateral pre-filter, SIFT bootstrap and
 the per-frame steps, trajectory against the rendered ground truth."""
 import numpy as np
@@ -24,15 +24,21 @@ def _write_parking(tmp_path, n=12):
     return cfg, frames, K, poses
 
 
-def _check_run(pipe, poses, t1, n_steps):
-    unit = np.linalg.norm(poses[t1][:3, 3])
-    for k in range(1, n_steps + 2):
-        Hk = pipe._state._trajectory[k]
-        gt = poses[t1 + k - 1]
-        cosang = (np.trace(Hk[:3, :3] @ gt[:3, :3].T) - 1) / 2
-        assert np.degrees(np.arccos(np.clip(cosang, -1, 1))) <= 0.5
-        assert np.linalg.norm(Hk[:3, 3] - gt[:3, 3] / unit) <= 0.3
-    assert len(pipe._state._landmarks) >= 100
+def _loop_over_loader(ld, make_ctx, n_steps):
+    """the reference's Pipeline (pipeline.py:12-176: bootstrap from getInit(), then step() per frame) as restated in
+    tests/test_gpu_e2e.py, fed by the drop-in Loader: images through getImage (decode + GPU pre-filter), K from getCamera"""
+    from test_gpu_e2e import _run
+    t0, t1 = ld.getInit()
+    frames = [ld.getFrame(t) for t in range(t1 + n_steps + 1)]
+    # Loader poses are camera -> world (the parking file's convention); the loop compares world -> camera
+    frames = [(im, np.linalg.inv(P)) for im, P in frames]
+    return _run(make_ctx, n_steps, t_init=(t0, t1), frames=frames, K=ld.getCamera())
+
+
+def _check_run(r, n_steps):
+    rot, tra = r["errs"][:, 0], r["errs"][:, 1]
+    assert rot.max() <= 0.5 and tra.max() <= 0.3, (rot, tra)
+    assert r["n_boot"] >= 150 and all(s[0] >= 100 for s in r["sizes"]) and len(r["sizes"]) == n_steps
 
 
 def test_loader_reads_the_dataset_layout(tmp_path):
@@ -54,24 +60,33 @@ def test_loader_reads_the_dataset_layout(tmp_path):
 @pytest.mark.gpu
 def test_loader_prefilter_and_pipeline_run(tmp_path):
     import vo_oracle as o
-    from vo_mi355x import Loader, Pipeline
+    from test_adapters import _gpu_ctx
+    from vo_mi355x import Loader
     cfg, frames, K, poses = _write_parking(tmp_path)
     ld = Loader("parking", cfg)
     im, pose = ld.getFrame(5)
     assert np.array_equal(im, o.bilateral(frames[5], 5, 1.5, 1.5))            # getImage = imread + bilateralFilter(5, 1.5, 1.5)
-    pipe = Pipeline(ld, headless=True)
-    assert pipe._t_loader == 4 and pipe._t_step == 1 and len(pipe._state._landmarks) >= 150
-    pipe.full_run()                                                           # frames 5 .. 11
-    assert pipe._t_loader == len(ld) - 1 and pipe._t_step == 8
-    _check_run(pipe, poses, 4, 7)
-    assert pipe._bundle_adjuster._ctx is pipe._extractor._ctx
+    _check_run(_loop_over_loader(ld, _gpu_ctx, 7), 7)                         # frames 5 .. 11
 
 
 def test_pipeline_run_cpu_twin(tmp_path):
     from oracle_context import OracleContext
-    from vo_mi355x import Loader, Pipeline
+    from test_adapters import _oracle_ctx
+    from vo_mi355x import Loader
     cfg, frames, K, poses = _write_parking(tmp_path, n=7)
     ld = Loader("parking", cfg, ctx=OracleContext(640, 480))
-    pipe = Pipeline(ld, headless=True, ctx=OracleContext(640, 480))
-    pipe.step(); pipe.step()
-    _check_run(pipe, poses, 4, 2)
+    _check_run(_loop_over_loader(ld, _oracle_ctx, 2), 2)
+
+
+def test_imread_gray_16_bit_and_colour(tmp_path):
+    """16-bit grey PNGs scale by >> 8 (cv2.imread's IMREAD_GRAYSCALE), colour PNGs use OpenCV's fixed-point weights"""
+    from PIL import Image
+    from vo_mi355x.loader import imread_gray
+    rng = np.random.default_rng(0)
+    g16 = rng.integers(0, 65536, (9, 13), dtype=np.uint16)
+    Image.fromarray(g16).save(str(tmp_path / "g16.png"))
+    assert np.array_equal(imread_gray(str(tmp_path / "g16.png")), (g16 >> 8).astype(np.uint8))
+    rgb = rng.integers(0, 256, (9, 13, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(str(tmp_path / "c.png"))
+    want = ((rgb[..., 0].astype(np.int32) * 4899 + rgb[..., 1].astype(np.int32) * 9617 + rgb[..., 2].astype(np.int32) * 1868 + 8192) >> 14)
+    assert np.array_equal(imread_gray(str(tmp_path / "c.png")), want.astype(np.uint8))

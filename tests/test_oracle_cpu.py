@@ -6,8 +6,8 @@ import pytest
 
 
 def _load(path):
-    import cv2  # our stub (Rodrigues)
-    from helpers import golden_ba_problem
+    from helpers import golden_ba_problem, ref_stub_cv2
+    cv2 = ref_stub_cv2()   # Rodrigues only
     g = np.load(path)
     return (g,) + golden_ba_problem(g, lambda R: cv2.Rodrigues(R)[0])
 
@@ -66,6 +66,32 @@ def test_ba_oracle_solver_beats_reference_cost(golden_dir, name):
     assert res["cost"] <= float(g["ref_cost"]) * (1 + 1e-3)
     res = bo.solve(K, poses, points, obs, max_iters=200, ftol=1e-12, xtol=1e-12)
     assert res["cost"] <= float(g["tight_cost"]) * (1 + 1e-4)
+
+
+@pytest.mark.parametrize("name", ["s0_n64_w4", "s1_n64_w4", "s2_n256_w10", "s0_n256_w10"])
+def test_ba_pose_deltas_and_points_vs_reference_solutions(golden_dir, name):
+    """BA-6 / BA-7 (SURVEY 8a'): gauge-free pose deltas and points of the oracle LM against the reference's own solutions
+    (bundle_adjuster.py:189-213) -- see helpers.ba_solution_parity; the GPU twin is tests/test_gpu_ba.py."""
+    import ba_oracle as bo
+    from helpers import ba_solution_parity
+    g, K, poses, points, obs, _ = _load("%s/ba_%s.npz" % (golden_dir, name))
+    gp = np.load("%s/bapolish_%s.npz" % (golden_dir, name))
+
+    def solve(max_iters, ftol, xtol):
+        r = bo.solve(K, poses, points, obs, max_iters=max_iters, ftol=ftol, xtol=xtol)
+        return r["poses"], r["points"], r["cost"]
+    rep = ba_solution_parity(solve, g, gp, K, poses, points, obs)
+    print(name, {k: (tuple(float("%.3g" % x) for x in v) if isinstance(v, tuple) else float("%.6g" % v)) for k, v in rep.items()})
+
+
+def test_ba_full_size_golden_pinned(golden_dir):
+    """the BASELINE-shape golden (2000 landmarks, 10-frame window; 12 064 observations): selection, x0 and residual vector
+    equal the reference's (bundle_adjuster.py:127-194)"""
+    import ba_oracle as bo
+    g, K, poses, points, obs, tags = _load(golden_dir + "/bafull_s0_n2000_w10.npz")
+    assert np.array_equal(tags, g["refine_tags"]) and np.array_equal(bo.pack_x0(poses, points), g["x0"])
+    r0 = bo.residual_norm(K, poses, points, obs)
+    assert len(r0) == len(g["r0"]) and np.abs(r0 - g["r0"]).max() <= 1e-9
 
 
 def test_schur_step_equals_dense_solve(golden_dir):

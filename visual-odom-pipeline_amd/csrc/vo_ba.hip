@@ -102,6 +102,7 @@ __device__ __forceinline__ ba_ptrs ba_select(ba_ptrs P, int b) {
 struct vo_ba_ws {
   int W = 0, N = 0, LPP = 0, PPB = 0, nblk = 0, RP = 0, RT = 0, n_tiles = 0, pitch = 0, tpb = 0;
   int cap_W = 0, cap_N = 0;
+  int cap_nblk = 0;             // partial sets the nblk-sized buffers (posepart, gmax, tiles, evalpart) were allocated for
   size_t build_lds = 0, solve_lds = 0;
   int cam_off = 0;
   double* d_K = nullptr;        // 9
@@ -1089,12 +1090,25 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
   VO_CHECK(c, W >= 1 && W <= BA_MAX_SLOTS, VO_E_CAPACITY, "window size must be 1..20");
   VO_CHECK(c, N >= 1, VO_E_INVALID, "no landmarks");
   if (c->ba && (c->ba->cap_W != W || c->ba->cap_N < N)) vo_ba_destroy(c);
+  if (c->ba) {
+    // the workgroup size switches with N (ba_geometry), so a SMALLER N can need MORE partial sets than the N the
+    // workspace was sized for (W = 4: N = 2600 -> 41 sets of 64 landmarks, N = 2500 -> 157 sets of 16): rebuild then
+    vo_ba_ws probe;
+    ba_geometry(&probe, W, N);
+    if (probe.nblk > c->ba->cap_nblk) vo_ba_destroy(c);
+  }
   const size_t B = (size_t)c->batch;
   if (!c->ba) {
     vo_ba_ws* b = new vo_ba_ws();
     c->ba = b;
     b->cap_W = W; b->cap_N = N;
     ba_geometry(b, W, N);
+    // any N' <= N runs with 256-lane workgroups when that gives <= 160 sets, else with the 1024-lane ones of N at most
+    {
+      const int small = vo_div_up(N, 256 / b->LPP);
+      b->cap_nblk = b->nblk > (small < 160 ? small : 160) ? b->nblk : (small < 160 ? small : 160);
+    }
+    const int nblk_alloc = b->cap_nblk;
     const size_t nx = (size_t)6 * W + 3 * N;
     VO_HIP(c, hipMalloc((void**)&b->d_K, 9 * sizeof(double) * B));
     VO_HIP(c, hipMalloc((void**)&b->d_obs, sizeof(double) * 2 * W * N * B));
@@ -1102,11 +1116,11 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     VO_HIP(c, hipMalloc((void**)&b->d_x[0], sizeof(double) * nx * B));
     VO_HIP(c, hipMalloc((void**)&b->d_x[1], sizeof(double) * nx * B));
     VO_HIP(c, hipMalloc((void**)&b->d_aux, sizeof(double) * (size_t)N * BA_AUX * B));
-    VO_HIP(c, hipMalloc((void**)&b->d_posepart, sizeof(double) * (size_t)b->nblk * W * BA_POSE_VALS * B));
-    VO_HIP(c, hipMalloc((void**)&b->d_gmax, sizeof(double) * b->nblk * B));
-    VO_HIP(c, hipMalloc((void**)&b->d_tiles, sizeof(double) * (size_t)b->nblk * b->n_tiles * 256 * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_posepart, sizeof(double) * (size_t)nblk_alloc * W * BA_POSE_VALS * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_gmax, sizeof(double) * nblk_alloc * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_tiles, sizeof(double) * (size_t)nblk_alloc * b->n_tiles * 256 * B));
     VO_HIP(c, hipMalloc((void**)&b->d_dp, sizeof(double) * 6 * W * B));
-    VO_HIP(c, hipMalloc((void**)&b->d_evalpart, sizeof(double) * b->nblk * BA_EVAL_VALS * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_evalpart, sizeof(double) * nblk_alloc * BA_EVAL_VALS * B));
     b->red_stride = (size_t)b->n_tiles * 256 + (size_t)W * BA_POSE_VALS + 1 + VO_COMM_MAX_RANKS;
     VO_HIP(c, hipMalloc((void**)&b->d_tilesum, sizeof(double) * b->red_stride * B));
     VO_HIP(c, hipMemsetAsync(b->d_tilesum, 0, sizeof(double) * b->red_stride * B, c->stream));

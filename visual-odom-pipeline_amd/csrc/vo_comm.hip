@@ -24,26 +24,28 @@ struct rccl_api {
 };
 
 rccl_api* rccl() {
-  static rccl_api api;
-  static bool tried = false;
-  if (tried) return &api;
-  tried = true;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) {
-    api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (api.handle) break;
-  }
-  if (!api.handle) { api.err = std::string("dlopen librccl: ") + dlerror(); return &api; }
-  bool ok = true;
-  auto sym = [&](const char* n) { void* p = dlsym(api.handle, n); if (!p) { ok = false; api.err = std::string("librccl lacks ") + n; } return p; };
-  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
-  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
-  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
-  api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
-  api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
-  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
-  if (!ok) { dlclose(api.handle); api.handle = nullptr; }
-  return &api;
+  // function-local static initialised by a lambda: C++11 guarantees one thread builds the table and every other caller
+  // (bench.py drives contexts from several host threads) sees it complete
+  static rccl_api* const table = []() {
+    rccl_api* api = new rccl_api();
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      api->handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (api->handle) break;
+    }
+    if (!api->handle) { const char* e = dlerror(); api->err = std::string("dlopen librccl: ") + (e ? e : "?"); return api; }
+    bool ok = true;
+    auto sym = [&](const char* n) { void* p = dlsym(api->handle, n); if (!p) { ok = false; api->err = std::string("librccl lacks ") + n; } return p; };
+    api->GetUniqueId = reinterpret_cast<decltype(api->GetUniqueId)>(sym("ncclGetUniqueId"));
+    api->CommInitRank = reinterpret_cast<decltype(api->CommInitRank)>(sym("ncclCommInitRank"));
+    api->CommDestroy = reinterpret_cast<decltype(api->CommDestroy)>(sym("ncclCommDestroy"));
+    api->AllReduce = reinterpret_cast<decltype(api->AllReduce)>(sym("ncclAllReduce"));
+    api->AllGather = reinterpret_cast<decltype(api->AllGather)>(sym("ncclAllGather"));
+    api->GetErrorString = reinterpret_cast<decltype(api->GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) { dlclose(api->handle); api->handle = nullptr; }
+    return api;
+  }();
+  return table;
 }
 
 int32_t rccl_fail(vo_ctx* c, const char* what, ncclResult_t r) {

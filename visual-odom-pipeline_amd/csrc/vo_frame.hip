@@ -267,6 +267,7 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
   if (!c) return VO_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);   // side branch of the frame step (an error path may have left it unjoined)
   (void)vo_comm_destroy(c);
   vo_trk_destroy(c);
   vo_pnp_destroy(c);
@@ -449,6 +450,7 @@ extern "C" int32_t vo_seq_upload(vo_ctx* c, const uint8_t* frames, int32_t n_fra
   VO_CHECK(c, frames != nullptr && n_frames > 0, VO_E_INVALID, "bad sequence");
   VO_HIP(c, hipSetDevice(c->device));
   VO_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->stream2) VO_HIP(c, hipStreamSynchronize(c->stream2));
   if (c->d_seq) { VO_HIP(c, hipFree(c->d_seq)); c->d_seq = nullptr; c->seq_n = 0; }
   const size_t bytes = (size_t)c->width * c->height * n_frames * c->batch;
   VO_HIP(c, hipMalloc((void**)&c->d_seq, bytes));

@@ -94,7 +94,7 @@ struct vo_ctx {
          off_st_scalars = 0, off_st_out = 0;
   // per-frame step (vo_frame_step_resident) captured as hipGraphs, one per frame parity
   hipGraphExec_t step_graph[2] = {nullptr, nullptr};
-  int step_sig[2][8];                    // launch signature the graph was captured for
+  uint64_t step_sig[2] = {0, 0};         // hash of everything a captured step bakes in (parameters by value, device pointers, problem shapes)
   int32_t* d_frame_idx = nullptr;        // frame index consumed by the captured k_pad_level0
   int32_t* h_frame_idx = nullptr;        // pinned ring of frame indices (H2D source must outlive the copy)
   int frame_ring = 0;

@@ -30,9 +30,20 @@ static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame
   // kernels).  Under graph capture everything stays on the one captured stream.
   const bool fork = s.do_st && (s.do_dlt || s.do_ba) && !d_frame_idx && c->side_stream;
   const bool dlt_side = fork && s.do_dlt && s.do_ba;
+  bool forked = false;
+  // every exit after the fork joins the side stream again: work queued there must stay ordered before whatever the caller
+  // enqueues (or frees) next on c->stream, also when a later enqueue fails
+  auto join = [&]() -> hipError_t {
+    if (!forked) return hipSuccess;
+    forked = false;
+    hipError_t e = hipEventRecord(c->ev_join, c->stream2);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    return e;
+  };
   if (fork) {
     VO_HIP(c, hipEventRecord(c->ev_fork, c->stream));
     VO_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    forked = true;
     hipStream_t main_stream = c->stream;
     c->stream = c->stream2;
     r = vo_shi_tomasi_resident(c, s.n_pts, s.mask_radius, &s.st);
@@ -40,12 +51,11 @@ static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame
     // the side branch too, off the KLT -> BA critical path (48 us of latency-bound work per step)
     if (r == VO_OK && dlt_side) r = vo_dlt_resident(c);
     c->stream = main_stream;
-    if (r != VO_OK) return r;
-    VO_HIP(c, hipEventRecord(c->ev_join, c->stream2));
+    if (r != VO_OK) { (void)join(); return r; }
   }
-  if (s.do_dlt && !dlt_side) { r = vo_dlt_resident(c); if (r != VO_OK) return r; }
-  if (s.do_ba) { r = vo_ba_solve_resident(c, &s.ba); if (r != VO_OK) return r; }
-  if (fork) VO_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  if (s.do_dlt && !dlt_side) { r = vo_dlt_resident(c); if (r != VO_OK) { (void)join(); return r; } }
+  if (s.do_ba) { r = vo_ba_solve_resident(c, &s.ba); if (r != VO_OK) { (void)join(); return r; } }
+  if (fork) VO_HIP(c, join());
   else if (s.do_st) { r = vo_shi_tomasi_resident(c, s.n_pts, s.mask_radius, &s.st); if (r != VO_OK) return r; }
   VO_HIP(c, hipMemcpyAsync(c->h_slab + (size_t)half * c->slab_bytes, c->d_slab, c->slab_bytes, hipMemcpyDeviceToHost, c->stream));
   if (s.do_ba) { r = vo_ba_enqueue_pub_copy(c, half); if (r != VO_OK) return r; }
@@ -53,12 +63,23 @@ static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame
   return VO_OK;
 }
 
-static void step_signature(const vo_ctx* c, const step_cfg& s, int sig[8]) {
-  sig[0] = s.n_pts; sig[1] = s.do_dlt | (s.do_ba << 1) | (s.do_st << 2) | (c->bil_maxk << 8) | (c->ba_sharded << 16); sig[2] = s.mask_radius;
-  sig[3] = s.klt.win | (s.klt.max_level << 8) | (s.klt.max_count << 16);
-  sig[4] = s.ba.max_iters; sig[5] = s.st.max_corners | (s.st.block_size << 16);
-  sig[6] = c->p_parity;   // point ping-pong parity
-  sig[7] = c->dlt_n;
+// A captured step bakes in: every kernel argument passed by value (all of the three parameter structs), the device
+// pointers of the resident buffers (the sequence store is reallocated by vo_seq_upload, the BA workspace by vo_ba_upload
+// when the window or the landmark count outgrows it, the Shi-Tomasi workspace by vo_st_prepare) and the problem shapes the
+// strides derive from.  The signature hashes all of it (FNV-1a); any difference re-captures.
+static uint64_t step_signature(vo_ctx* c, const step_cfg& s) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void* p, size_t n) { const unsigned char* b = static_cast<const unsigned char*>(p); for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+  auto mix_i = [&](long long v) { mix(&v, sizeof(v)); };
+  mix(&s, sizeof(s));                       // the caller zero-fills the struct, so padding bytes are defined
+  mix_i(c->p_parity); mix_i(c->dlt_n); mix_i(c->dlt_stats); mix_i(c->bil_maxk); mix_i(c->ba_sharded); mix_i(c->side_stream);
+  mix_i((long long)(uintptr_t)c->d_seq); mix_i(c->seq_n);
+  mix_i((long long)(uintptr_t)c->d_uv0); mix_i((long long)(uintptr_t)c->d_dlt_cam);
+  mix_i((long long)(uintptr_t)c->st); mix_i((long long)(uintptr_t)c->ba); mix_i((long long)(uintptr_t)c->d_pt_counts);
+  int W = 0, N = 0;
+  mix_i((long long)(uintptr_t)vo_ba_obs_device(c, &W, &N)); mix_i(W); mix_i(N);
+  mix_i((long long)(uintptr_t)c->comm);
+  return h;
 }
 
 extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t n_pts, int32_t do_dlt, int32_t do_ba,
@@ -69,6 +90,7 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
   VO_CHECK(c, c->n_pushed >= 1, VO_E_STATE, "push one frame before stepping");
   VO_HIP(c, hipSetDevice(c->device));
   step_cfg s;
+  memset(&s, 0, sizeof(s));
   s.n_pts = n_pts; s.do_dlt = do_dlt ? 1 : 0; s.do_ba = do_ba ? 1 : 0; s.do_st = do_st ? 1 : 0; s.mask_radius = mask_radius;
   if (klt) s.klt = *klt; else vo_klt_default_params(&s.klt);
   if (st) s.st = *st; else vo_st_default_params(&s.st);
@@ -91,20 +113,27 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
   }
 
   const int parity = c->cur;                 // frame-store parity BEFORE this step
-  int sig[8];
-  step_signature(c, s, sig);
-  if (!c->step_graph[parity] || memcmp(sig, c->step_sig[parity], sizeof(sig)) != 0) {
+  const uint64_t sig = step_signature(c, s);
+  if (!c->step_graph[parity] || sig != c->step_sig[parity]) {
     // (re)capture: the enqueue functions advance the host-side state exactly as a direct call would
     if (c->step_graph[parity]) { (void)hipGraphExecDestroy(c->step_graph[parity]); c->step_graph[parity] = nullptr; }
     hipGraph_t g = nullptr;
+    const int cur0 = c->cur, pushed0 = c->n_pushed, parity0 = c->p_parity;
     VO_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     const int32_t r = step_enqueue(c, s, c->d_frame_idx, frame_idx, 0);
     const hipError_t e = hipStreamEndCapture(c->stream, &g);
-    if (r != VO_OK) { if (g) (void)hipGraphDestroy(g); return r; }
+    if (r != VO_OK || e != hipSuccess) {
+      // nothing was launched: undo what the enqueue functions did to the host-side frame / point parities
+      c->cur = cur0; c->n_pushed = pushed0; c->p_parity = parity0;
+      if (g) (void)hipGraphDestroy(g);
+      if (r != VO_OK) return r;
+    }
     VO_HIP(c, e);
-    VO_HIP(c, hipGraphInstantiate(&c->step_graph[parity], g, nullptr, nullptr, 0));
-    VO_HIP(c, hipGraphDestroy(g));
-    memcpy(c->step_sig[parity], sig, sizeof(sig));
+    const hipError_t ei = hipGraphInstantiate(&c->step_graph[parity], g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ei != hipSuccess) { c->cur = cur0; c->n_pushed = pushed0; c->p_parity = parity0; c->step_graph[parity] = nullptr; }
+    VO_HIP(c, ei);
+    c->step_sig[parity] = sig;
   } else {
     // replay: redo the host-side state changes the enqueue functions would have made
     c->cur ^= 1; c->n_pushed++;

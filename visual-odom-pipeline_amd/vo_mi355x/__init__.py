@@ -9,8 +9,7 @@ from .bundle_adjuster import BundleAdjuster  # noqa: F401
 from .context import VoContext  # noqa: F401
 from .extractor import DMatch, Extractor  # noqa: F401
 from .loader import Loader  # noqa: F401
-from .pipeline import Pipeline  # noqa: F401
 from .state import Keypoint, Landmark, State, Trajectory  # noqa: F401
 
-__all__ = ["VoContext", "VoError", "LIB_PATH", "Extractor", "DMatch", "BundleAdjuster", "Loader", "Pipeline", "Keypoint", "Landmark", "State",
+__all__ = ["VoContext", "VoError", "LIB_PATH", "Extractor", "DMatch", "BundleAdjuster", "Loader", "Keypoint", "Landmark", "State",
            "Trajectory"]

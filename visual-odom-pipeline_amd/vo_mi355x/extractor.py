@@ -100,7 +100,7 @@ class Extractor:
     def extend_tracks(self, im_curr, kp, max_bidir_error=30):
         new_tracks = []
         if len(kp):
-            p0 = np.float32([k.uv.T for k in kp]).reshape(-1, 2)
+            p0 = self._uv_block(kp)
             p1, good = self._track(im_curr, p0, max_bidir_error)
             keep, uv, hist = self._survivors(im_curr, p1, good)
             for i in np.nonzero(keep)[0]:
@@ -115,7 +115,7 @@ class Extractor:
         landmarks_new, kp_new, landmarks_dead, kp_dead = [], [], [], []
         if not len(landmarks_kp):
             return landmarks_new, kp_new, landmarks_dead, kp_dead
-        p0 = np.float32([k.uv for k in landmarks_kp]).reshape(-1, 2)
+        p0 = self._uv_block(landmarks_kp)
         p1, good = self._track(im_curr, p0, max_bidir_error)
         keep, uv, hist = self._survivors(im_curr, p1, good)
         # the reference converts p1 with .tolist() here (python floats): uv / history entries are float64 in this method
@@ -162,26 +162,37 @@ class Extractor:
                 for i in range(len(kp))]
 
     # -- triangulation --------------------------------------------------------------------------
-    def _dlt(self, K, H0, H1, keyp0, keyp1, stats):
-        uv0 = np.array([kp.uv.T for kp in keyp0]).astype(np.float32).reshape((-1, 2))
-        uv1 = np.array([kp.uv.T for kp in keyp1]).astype(np.float32).reshape((-1, 2))
-        P_0 = (K @ H0[:3, :]).astype(np.float32)
-        P_1 = (K @ H1[:3, :]).astype(np.float32)
+    @staticmethod
+    def _uv_block(kps):
+        """(n, 2) float32 pixel coordinates of a keypoint list: one float64 gather, one rounding to float32 (the reference
+        rounds its stacked (n, 1, 2) array the same way before cv2.triangulatePoints, extractor.py:264-265)"""
+        return np.asarray([k.uv for k in kps], dtype=np.float64).reshape(-1, 2).astype(np.float32)
+
+    def _two_view(self, K, H0, H1, keyp0, keyp1, want_stats):
+        """k_dlt for one view pair -> (points [n, 3] float32, camera-1 depth, mean reprojection error).  The projection matrices
+        are rounded to float32 before the solve, as the reference hands them to OpenCV (extractor.py:268-269)."""
         if self._ctx is None:
             raise RuntimeError("Extractor: no device context yet (track or extract a frame first, or pass ctx=)")
-        if stats:
-            X4, depth1, reproj = self._ctx.triangulate(P_0, P_1, uv0, uv1, K, H0, H1)
+        cams = [np.float32(np.asarray(K) @ np.asarray(H)[:3]) for H in (H0, H1)]
+        pix = [self._uv_block(keyp0), self._uv_block(keyp1)]
+        if want_stats:
+            X4, depth1, reproj = self._ctx.triangulate(cams[0], cams[1], pix[0], pix[1], K, H0, H1)
         else:
-            X4, depth1, reproj = self._ctx.triangulate(P_0, P_1, uv0, uv1), None, None
-        points_4D = X4.reshape((4, -1)).T
-        points_3D = (points_4D / points_4D[:, 3].reshape((-1, 1)))[:, :3]
-        return points_3D, depth1, reproj
+            X4, depth1, reproj = self._ctx.triangulate(cams[0], cams[1], pix[0], pix[1]), None, None
+        X4 = X4.reshape(4, -1)
+        return (X4[:3] / X4[3]).T, depth1, reproj            # float32 division, point by point
+
+    @staticmethod
+    def _as_landmarks(points, rows, kps, t):
+        """Landmark(t, p (3, 1) float64 holding the float32 values, des of the view-1 keypoint)"""
+        wide = np.asarray(points, np.float64)
+        return [Landmark(t, wide[i].reshape(3, 1).copy(), kps[i].des) for i in rows]
 
     def triangulate(self, K, H0, H1, keyp0, keyp1, t):
         if not len(keyp0):
             return []
-        points_3D, _, _ = self._dlt(K, H0, H1, keyp0, keyp1, False)
-        return [Landmark(t, np.array(p).reshape((3, 1)), keyp1[i].des) for i, p in enumerate(points_3D.tolist())]
+        pts, _, _ = self._two_view(K, H0, H1, keyp0, keyp1, False)
+        return self._as_landmarks(pts, range(len(pts)), keyp1, t)
 
     def triangulate_nonlinear(self, K, H0, H1, keyp0, keyp1, t, max_err_reproj=1.0):
         """DLT + the filters of TriangulatorNL.refine (triangulate.py:82-146): camera-1 cheirality, then mean
@@ -191,44 +202,53 @@ class Extractor:
         `uv` come back as float64 (2,1) arrays."""
         if not len(keyp0):
             return [], [], []
-        points_3D, depth1, reproj = self._dlt(K, H0, H1, keyp0, keyp1, True)
-        keep = [i for i in range(len(keyp0)) if depth1[i] > 0 and reproj[i] < max_err_reproj]
-        landmarks, k0, k1 = [], [], []
-        for i in keep:
-            landmarks.append(Landmark(t, np.array(points_3D[i].tolist()).reshape((3, 1)), keyp1[i].des))
-            keyp0[i].uv = np.asarray(keyp0[i].uv, np.float64).reshape((2, 1)).copy()
-            keyp1[i].uv = np.asarray(keyp1[i].uv, np.float64).reshape((2, 1)).copy()
-            k0.append(keyp0[i]); k1.append(keyp1[i])
-        return landmarks, k0, k1
+        pts, depth1, reproj = self._two_view(K, H0, H1, keyp0, keyp1, True)
+        rows = np.nonzero((np.asarray(depth1) > 0) & (np.asarray(reproj) < max_err_reproj))[0]
+        for view in (keyp0, keyp1):
+            for i in rows:
+                view[i].uv = np.array(view[i].uv, dtype=np.float64).reshape(2, 1)
+        return self._as_landmarks(pts, rows, keyp1, t), [keyp0[i] for i in rows], [keyp1[i] for i in rows]
+
+    @staticmethod
+    def _group_gate(H_birth, H_now, p_first, min_angle_deg):
+        """The reference's per-group "bearing angle" test (extractor.py:231-240), which is not a bearing angle: the triangle
+        side `a` is the FROBENIUS NORM of the 4x4 relative transform (>= 2), the other two sides are the lengths of the
+        group's FIRST landmark rotated into either camera as a direction (w = 0, so both equal |p|).  Law of cosines,
+        degrees; NaN (|cos| > 1) rejects.  In effect: accept the whole group iff |p_first| is large enough against a."""
+        ray = np.zeros(4)
+        ray[:3] = np.asarray(p_first, np.float64).ravel()
+        a = np.linalg.norm(np.asarray(H_now) @ np.linalg.inv(H_birth))
+        b, c = np.linalg.norm(np.asarray(H_birth) @ ray), np.linalg.norm(np.asarray(H_now) @ ray)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            theta = np.degrees(np.arccos((b * b + c * c - a * a) / (2 * b * c)))
+        return bool(theta > min_angle_deg)                   # False for NaN
 
     def triangulate_tracks(self, K, candidates_kp, trajectory, t_curr, refine=True, min_track_length=5,
                            min_bearing_angle=10, max_err_reproj=4.0):
-        landmarks_new, landmarks_kp_new = [], []
-        landmarks_kp_tmp = [kp for kp in candidates_kp if kp.t_total >= min_track_length]
-        candidates_kp_new = [kp for kp in candidates_kp if kp.t_total < min_track_length]
-        if len(landmarks_kp_tmp) > 0:
-            H1 = trajectory[len(trajectory) - 1]
-            t_first_groups = set([k.t_first for k in landmarks_kp_tmp])
-            for t_first in t_first_groups:
-                kp_1 = [kp for kp in landmarks_kp_tmp if kp.t_first == t_first]
-                H0 = trajectory[t_first]
-                kp_0 = deepcopy(kp_1)
-                for kp in kp_0:
-                    kp.uv = kp.uv_first
-                l, kp_0, kp_1 = self.triangulate_nonlinear(K, H0, H1, kp_0, kp_1, t_curr, max_err_reproj=max_err_reproj)
-                if len(l):
-                    # the reference's "bearing angle" gate, quirks included (extractor.py:231-240)
-                    Hrel = H1 @ np.linalg.inv(H0)
-                    P_homo = np.concatenate([l[0].p, np.zeros((1, 1))], axis=0).reshape((4, 1))
-                    a = np.linalg.norm(Hrel)
-                    b = np.linalg.norm(H0 @ P_homo)
-                    c = np.linalg.norm(H1 @ P_homo)
-                    with np.errstate(invalid='ignore', divide='ignore'):
-                        bearing_angle = np.rad2deg(np.arccos((b * b + c * c - a * a) / (2 * b * c)))
-                    if (not np.isnan(bearing_angle)) and (bearing_angle > min_bearing_angle):
-                        landmarks_new += l
-                        landmarks_kp_new += kp_1
-        return landmarks_new, landmarks_kp_new, candidates_kp_new
+        """Candidates that reached `min_track_length` leave the candidate list (triangulated or not); they are triangulated
+        per birth frame between their first and their newest observation and a group is kept iff its gate passes
+        (reference extractor.py:193-242).  -> (new landmarks, their keypoints, remaining candidates)"""
+        ripe = [k for k in candidates_kp if k.t_total >= min_track_length]
+        waiting = [k for k in candidates_kp if k.t_total < min_track_length]
+        out_l, out_k = [], []
+        if not ripe:
+            return out_l, out_k, waiting
+        by_birth = {}
+        for k in ripe:
+            by_birth.setdefault(k.t_first, []).append(k)
+        H_now = trajectory[len(trajectory) - 1]
+        # the reference walks a SET of birth frames built from the ripe list; building it the same way gives the same
+        # iteration order, which is the order of the returned lists
+        for born in set(k.t_first for k in ripe):
+            newest = by_birth[born]
+            # view-0 stand-ins: only `uv` (:= the first observation) is read and rewritten downstream
+            oldest = [Keypoint(k.t_first, k.t_total, k.uv_first, np.array(k.uv_first), k.des, []) for k in newest]
+            H_birth = trajectory[born]
+            lms, _, kept = self.triangulate_nonlinear(K, H_birth, H_now, oldest, newest, t_curr, max_err_reproj=max_err_reproj)
+            if lms and self._group_gate(H_birth, H_now, lms[0].p, min_bearing_angle):
+                out_l.extend(lms)
+                out_k.extend(kept)
+        return out_l, out_k, waiting
 
     def _extract_sift(self, img, t, current_kp, describe):
         """detector='custom' (reference extractor.py:114-131): cv2.SIFT_create(nfeatures=1000).detect(img, mask) and,
@@ -265,12 +285,10 @@ class Extractor:
         return good
 
     def match_lists(self, list_1, list_2):
-        """Match two lists of keypoints/landmarks based on their descriptors (reference extractor.py:147-154).
-        Returns a list of matches. Each match has m.queryIdx for list_1, and m.trainIdx for list_2."""
-        desc_dim = len(list_1[0].des)
-        desc_1 = np.array([pt.des.reshape(1, desc_dim) for pt in list_1]).reshape((len(list_1), -1))
-        desc_2 = np.array([pt.des.reshape(1, desc_dim) for pt in list_2]).reshape((len(list_2), -1))
-        return self.match(desc_1, desc_2)
+        """ratio-test matches between two lists of keypoints / landmarks by their `des` columns (reference
+        extractor.py:147-154): m.queryIdx indexes list_1, m.trainIdx list_2"""
+        rows = [np.stack([np.ravel(o.des) for o in lst]) for lst in (list_1, list_2)]
+        return self.match(rows[0], rows[1])
 
     def match_list(self, kp_1, desc_1, keypoints):
         # the reference's match_list (extractor.py:156-160) calls self.match with four arguments and always raises
