@@ -14,6 +14,13 @@ before the timed region; per step only the results come back (points, corners, l
 Multi-GPU: one process per GPU (torch.distributed launch contract), independent sequences per rank, no data-path
 collective -> "scaling": "weak".  torch.distributed (gloo) is used ONLY for the barrier / max-over-ranks timing.
 
+`--gpus N` (N > 1) without a torch.distributed environment starts the N ranks itself (a `python -m torch.distributed.run`
+child process, before this process touches the GPU) and relays rank 0's line.
+
+The timed region (exactly --steps steps between barrier + sync on both sides) is repeated --regions times; `value` /
+`ms_per_step` are the MEDIAN region, `regions` carries min / median / max.  After the timed regions rank 0 of a 1-GPU run adds
+informational measurements of the other BASELINE configurations (`single_sequence`, `klt_only`, `pipeline_step`).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -37,6 +44,9 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--regions", type=int, default=5, help="the K-step timed region is repeated this many times; the median is reported")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational single-sequence / KLT-only / pipeline measurements")
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)     # launcher plumbing test: no GPU work
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--seqs", type=int, default=96, help="independent sequences per GPU")
     ap.add_argument("--ctxs", type=int, default=3, help="batched contexts (HIP streams) the sequences are split over")
@@ -54,7 +64,7 @@ def parse():
                          "spawn) and RANSAC-P3P pose -- issued as separate calls with one sync per frame; informational")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames each CPU-baseline worker process runs")
-    ap.add_argument("--cpu-procs", type=int, default=16, help="CPU-baseline worker processes (one core each), capped by the host's cores")
+    ap.add_argument("--cpu-procs", type=int, default=64, help="CPU-baseline worker processes (one core each), capped by the host's cores")
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)     # internal: run as CPU-baseline worker with this seed
     return ap.parse_args()
 
@@ -180,6 +190,7 @@ class Group:
                 uv[b, out] += rng.uniform(-80, 80, (len(out), 2)).astype(np.float32) + np.float32(15)
             c.pnp_upload(np.stack(Ks), X, uv)
             self.pnp_prm = c.pnp_params(reproj_err=2.0, confidence=0.9999, max_iters=1000000, seed=seed0)
+        self.stages = (True, True, True)   # (DLT, BA, Shi-Tomasi) of the fused step
         self.t = 1
         self.inflight = 0
         self.max_inflight = 2          # 1 when the step is replayed from a hipGraph (its host destinations are baked in)
@@ -199,8 +210,8 @@ class Group:
             self.inflight += 1
             return
         # one C call: pyramid + KLT + DLT + BA + Shi-Tomasi + result copies for the whole batch
-        self.c.frame_step_resident(pingpong(self.t, self.nf), N_PTS, True, True, True, 7, self.klt_prm, self.st_prm,
-                                   self.ba_prm)
+        self.c.frame_step_resident(pingpong(self.t, self.nf), N_PTS, self.stages[0], self.stages[1], self.stages[2], 7, self.klt_prm,
+                                   self.st_prm, self.ba_prm)
         self.t += 1
         self.inflight += 1
 
@@ -225,7 +236,7 @@ class Group:
         else:
             self.last = self.c.frame_fetch()
         self.inflight -= 1
-        if self.adaptive:
+        if self.adaptive and self.stages[1]:
             # the LM stops by its own ftol/xtol tests; the budget only bounds how many (early-exiting) launches are
             # enqueued blindly.  Next frame: what this frame needed (max over the batch) + 2, never more than --ba-iters.
             st = self.last["ba_stats"]
@@ -248,6 +259,7 @@ def cpu_baseline_parallel(n_procs, n_frames, ba_iters):
     t0 = time.perf_counter()
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--cpu-frames", str(n_frames),
                                "--ba-iters", str(ba_iters)], stdout=subprocess.PIPE, env=env, text=True) for i in range(n_procs)]
+    side = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "10000"], stdout=subprocess.PIPE, env=env, text=True)
     done, slowest = 0, 0.0
     for pr in procs:
         out, _ = pr.communicate()
@@ -256,9 +268,72 @@ def cpu_baseline_parallel(n_procs, n_frames, ba_iters):
             done += r["frames"]
             slowest = max(slowest, r["seconds"])
     wall = time.perf_counter() - t0
+    extra = {}
+    try:
+        so, _ = side.communicate(timeout=600)
+        if side.returncode == 0 and so.strip():
+            extra = json.loads(so.strip().splitlines()[-1])
+    except Exception:           # noqa: BLE001
+        side.kill()
     if done == 0:
-        return 0.0, wall, 0
-    return done / slowest, wall, n_procs
+        return 0.0, wall, 0, extra
+    return done / slowest, wall, n_procs, extra
+
+
+def reference_recipe_ba_seconds():
+    """ONE bundle adjustment of the workload's shape (2000 landmarks x 10 poses, every landmark seen in every frame) solved with
+    the REFERENCE'S SOLVER RECIPE -- scipy least_squares(method='trf', 2-point finite differences with jac_sparsity, loss='huber',
+    x_scale='jac', ftol = xtol = 1e-3: bundle_adjuster.py:189-194 as configured by pipeline.py:28-29) -- over the oracle's
+    vectorised restatement of its objective (the reference's own objective is a Python double loop, 22 ms per evaluation;
+    this one takes ~2 ms, so the figure is a LOWER bound of the reference's time: SURVEY.md section 6 measured 9.3 s per call).
+    -> dict or None without scipy."""
+    try:
+        from scipy.optimize import least_squares
+        from scipy.sparse import coo_matrix
+    except Exception:           # noqa: BLE001
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ba_oracle as bo
+    from vo_mi355x import synthetic as syn
+    s = syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=0)
+    K, obs = s["K"], s["obs"]
+    x0 = bo.pack_x0(s["poses0"], s["points0"])
+    rows, cols = bo.sparsity_coo(obs)
+    m = int(bo.valid_mask(obs).sum())
+    A = coo_matrix((np.ones(len(rows), np.int8), (rows, cols)), shape=(m, len(x0))).tocsr()
+
+    def fun(x):
+        po, pt = bo.unpack_x(x, BA_N, BA_W)
+        return bo.residual_norm(K, po, pt, obs)
+    t0 = time.perf_counter()
+    res = least_squares(fun, x0, jac_sparsity=A, method="trf", loss="huber", x_scale="jac", ftol=1e-3, xtol=1e-3, verbose=0)
+    dt = time.perf_counter() - t0
+    return {"seconds_per_adjust": round(dt, 3), "nfev": int(res.nfev), "njev": int(res.njev), "cost": round(float(res.cost), 3),
+            "cost0": round(float(0.5 * bo.huber_rho(fun(x0) ** 2).sum()), 3), "cores": 1,
+            "what": "scipy TRF, 2-point FD + jac_sparsity, huber, x_scale='jac', ftol=xtol=1e-3 over the oracle's vectorised objective"}
+
+
+def opencv_baseline(frames):
+    """When a real OpenCV is importable on this box: the reference's cv2 calls in its call pattern on one frame pair (4 x
+    calcOpticalFlowPyrLK, mask loop + goodFeaturesToTrack, triangulatePoints; tests/live_cv2.py).  None otherwise."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import live_cv2 as lv
+        cv2 = lv.find_real_cv2()
+        if cv2 is None:
+            return None
+        from vo_mi355x import synthetic as syn
+        p = syn.grid_points(N_PTS, W_IMG, H_IMG, seed=7).astype(np.float32)
+        s = syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=0)
+        K = s["K"]
+        P0 = np.float32(K @ np.hstack([syn.rodrigues(s["poses_gt"][3, :3]), s["poses_gt"][3, 3:, None]]))
+        P1 = np.float32(K @ np.hstack([syn.rodrigues(s["poses_gt"][0, :3]), s["poses_gt"][0, 3:, None]]))
+        t = lv.time_reference_call_pattern(cv2, frames[0], frames[1], p[:N_PTS // 2], p[N_PTS // 2:], p, P0, P1,
+                                           s["obs"][3, :N_NEW].astype(np.float32), s["obs"][0, :N_NEW].astype(np.float32))
+        return dict({k: round(v, 6) if isinstance(v, float) else v for k, v in t.items()}, version=cv2.__version__,
+                    frames_per_s_front_end=round(1.0 / t["frame_s"], 2))
+    except Exception as e:      # noqa: BLE001
+        return {"error": str(e)}
 
 
 def cpu_baseline(frames, n_frames, ba_iters):
@@ -288,9 +363,131 @@ def cpu_baseline(frames, n_frames, ba_iters):
     return n_frames / dt, dt
 
 
+def measure_extras(device, frame_sets, a):
+    """Informational, after the timed regions, rank 0 of a 1-GPU run: the other BASELINE configurations on the same device.
+    single_sequence: configs[2] / [3] literally -- ONE sequence in one context (launch-latency bound).
+    klt_only: configs[1] -- pyramid + Scharr + KLT of 2000 points per frame, maxLevel 3 (4 levels) and 2, one sequence and a
+    batch of 32.  pipeline_step: workload A plus the device-resident track table and the RANSAC-P3P pose (Pipeline.step)."""
+    out = {}
+
+    def run(g, n, warm=10):
+        for _ in range(warm):
+            g.step()
+        g.drain(); g.c.sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            g.step()
+        g.drain(); g.c.sync()
+        return time.perf_counter() - t0
+    g = Group(device, frame_sets, seed0=7000, batch=1, ba_iters=a.ba_iters)
+    dt = run(g, 300)
+    out["single_sequence"] = {"frames_per_s": round(300 / dt, 1), "ms_per_frame": round(dt / 300 * 1e3, 4), "sequences": 1, "contexts": 1,
+                              "workload": WORKLOAD}
+    kl = {}
+    for batch in (1, 32):
+        gk = g if batch == 1 else Group(device, frame_sets, seed0=7100, batch=32, ba_iters=a.ba_iters)
+        for lvl in (3, 2):
+            gk.klt_prm = gk.c.klt_params(max_level=lvl)
+            gk.stages = (False, False, False)
+            n = 300 if batch == 1 else 100
+            dt = run(gk, n)
+            kl["maxLevel%d_batch%d" % (lvl, batch)] = {"frames_per_s": round(n * batch / dt, 1), "ms_per_step": round(dt / n * 1e3, 4)}
+        if gk is not g:
+            gk.c.close()
+    out["klt_only"] = dict(kl, workload="synthetic_1241x376_2000pts_klt_only (BASELINE configs[1]: pyramid + Scharr + KLT, no BA)")
+    g.c.close()
+    gp = Group(device, frame_sets, seed0=7200, batch=32, ba_iters=a.ba_iters, pipeline=True)
+    gp.max_inflight = 1
+    dt = run(gp, 40, warm=6)
+    out["pipeline_step"] = {"frames_per_s": round(40 * 32 / dt, 1), "ms_per_step": round(dt / 40 * 1e3, 4), "sequences": 32, "contexts": 1,
+                            "mean_live_tracks": round(float(np.mean(gp.last["n_tracks"])), 1)}
+    gp.c.close()
+    return out
+
+
+def _klt_source_digest():
+    import hashlib
+    with open(os.path.join(ROOT, "visual-odom-pipeline_amd", "csrc", "vo_klt.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def profile_constant(fname, key):
+    """a per-launch figure of k_klt_track that only rocprofv3 --pmc can measure (tools/profile_round.sh writes it under profiles/
+    together with the digest of the kernel source it was measured on).  -> (value, provenance); the value is None when the
+    kernel source has changed since, so a stale constant is never reported as current."""
+    path = os.path.join(ROOT, "profiles", fname)
+    if not os.path.exists(path):
+        return None, "profiles/%s missing" % fname
+    try:
+        d = json.load(open(path))
+    except Exception as e:          # noqa: BLE001
+        return None, "profiles/%s unreadable: %s" % (fname, e)
+    if d.get("klt_source_sha256_16") != _klt_source_digest():
+        return None, "profiles/%s was measured on another version of vo_klt.hip (stale): re-run tools/profile_round.sh" % fname
+    return d.get(key), "profiles/%s (rocprofv3 --pmc, %s)" % (fname, d.get("measured", "this round"))
+
+
+VALU_ISSUE_PER_CLK_PER_SIMD = 0.5     # MI355X_MICROARCH.md: a wave64 VALU instruction passes a SIMD-32 in 2 cycles (full-rate ops)
+N_SIMDS, CLK_HZ = 1024, 2.4e9         # 256 CUs x 4 SIMDs, 2.4 GHz peak clock
+
+
+def valu_roofline(launch_s, n_waves):
+    """the roof that actually binds k_klt_track: vector-instruction issue.  SQ_INSTS_VALU per launch comes from the committed
+    rocprofv3 --pmc summary (profiles/klt_valu.json); launch time is measured live in this run."""
+    insts, src = profile_constant("klt_valu.json", "sq_insts_valu_per_launch")
+    if insts is None or launch_s <= 0:
+        return {"wave_insts_per_launch": None, "source": src}
+    rate = insts / launch_s
+    peak = VALU_ISSUE_PER_CLK_PER_SIMD * N_SIMDS * CLK_HZ
+    return {"wave_insts_per_launch": int(insts), "wave_insts_per_wave": round(insts / max(n_waves, 1), 1),
+            "achieved_ginst_s": round(rate / 1e9, 2), "peak_ginst_s": round(peak / 1e9, 2), "frac": round(rate / peak, 4),
+            "cycles_per_inst_per_simd": round(N_SIMDS * CLK_HZ * launch_s / insts, 3),
+            "peak_note": "1 wave-instruction / 2 clk / SIMD x 1024 SIMDs x 2.4 GHz (full-rate 32-bit ops; the chip clocks lower under load)",
+            "source": src}
+
+
+def self_launch(a):
+    """`bench.py --gpus N` outside a torch.distributed launch: start the N ranks as a CHILD process tree (one process per GPU,
+    the command the driver itself uses) and relay rank 0's JSON line.  This process never initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line)
+    else:
+        sys.stderr.write(r.stdout[-2000:])
+    sys.exit(r.returncode if r.returncode else (0 if line is not None else 1))
+
+
 def main():
     global W_IMG, H_IMG, N_PTS, N_NEW, BA_N, BA_W, WORKLOAD, K_CAM
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and a.cpu_worker < 0:
+        self_launch(a)
+    if a.dry_run:                  # launcher / rendezvous plumbing only (tests/test_dist_cpu.py): no GPU library, no kernels
+        d = Dist()
+        d.barrier()
+        tot = d.sum(1.0)
+        if d.rank == 0:
+            print(json.dumps({"metric": "dry-run", "n_gpus": d.world, "ranks_seen": int(tot), "gpus_arg": a.gpus}))
+        d.close()
+        return
+    if a.cpu_worker == 10_000:     # CPU-baseline side job: the reference's solver recipe + (if present) live OpenCV timings
+        from vo_mi355x import synthetic as syn
+        frames = syn.make_sequence(2, W_IMG, H_IMG, seed=1234)[0]
+        print(json.dumps({"reference_recipe_ba": reference_recipe_ba_seconds(), "opencv": opencv_baseline(frames)}))
+        return
     if a.cpu_worker >= 0:          # CPU-baseline worker process: never touches the GPU library
         from vo_mi355x import synthetic as syn
         frames = syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + a.cpu_worker)[0]
@@ -303,8 +500,10 @@ def main():
     if dist.rank == 0 and dist.world == 1 and not a.no_cpu_baseline and a.workload == "A" and a.cpu_worker < 0:
         # before anything initialises the GPU in this process (child processes are started here)
         n_procs = max(1, min(a.cpu_procs, os.cpu_count() or 1))
-        v, secs, cores = cpu_baseline_parallel(n_procs, a.cpu_frames, a.ba_iters)
-        cpu = {"value": round(v, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+        v, secs, cores, extra = cpu_baseline_parallel(n_procs, a.cpu_frames, a.ba_iters)
+        cpu = {"value": round(v, 3), "unit": "frames/s", "cores": cores, "cores_available": os.cpu_count() or 0, "kind": "port",
+               "per_core": round(v / max(cores, 1), 3),
+               "reference_recipe_ba": extra.get("reference_recipe_ba"), "opencv": extra.get("opencv"),
                "sample": "%d worker processes (1 core each, independent sequences) x %d frames of the same workload on the CPU "
                          "oracle (C: pyramid+KLT+Shi-Tomasi+DLT, numpy: BA), %.1f s wall; %.2f frames/s per core; host has %d cores"
                          % (cores, a.cpu_frames, secs, v / max(cores, 1), os.cpu_count() or 0)}
@@ -368,26 +567,32 @@ def main():
     for _ in range(a.warmup):
         step()
     drain()
-    # ---- timed region: exactly K steps; KLT kernel bracketed by hipEvents on its own stream ----
+    # ---- timed regions: exactly K steps each, barrier + sync on both sides; KLT kernel bracketed by hipEvents on its stream ----
     for s in seqs:
         s.c.profile_enable((s.c.PROF_KLT,))
         s.c.sync()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    drain()                                        # every one of the K frames is complete and fetched inside the timed region
-    for s in seqs:
-        s.c.sync()
-    dist.barrier()
-    dt = dist.max(time.perf_counter() - t0)
+    region_dt = []
+    for _ in range(max(1, a.regions)):
+        for s in seqs:
+            s.c.sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        drain()                                    # every one of the K frames is complete and fetched inside the timed region
+        for s in seqs:
+            s.c.sync()
+        dist.barrier()
+        region_dt.append(dist.max(time.perf_counter() - t0))
+    dt = float(np.median(region_dt))               # an odd --regions makes this one actual region
     klt_ms, klt_n = 0.0, 0
     for s in seqs:
         ms, n = s.c.profile_read(s.c.PROF_KLT)
         klt_ms += ms
         klt_n += n
         s.c.profile_enable(())
-    frames_total = float(a.steps) if c5 else dist.sum(float(a.steps * a.seqs))     # config 5: ONE sequence on all ranks
+    frames_step = 1.0 if c5 else dist.sum(float(a.seqs))                             # config 5: ONE sequence on all ranks
+    frames_total = frames_step * a.steps
     fps = frames_total / dt
 
     out = None
@@ -418,22 +623,17 @@ def main():
             klt_bytes = N_PTS * s0.B * sum(5120.0 + 1024.0 * x for x in it_mean)
         klt_avg_s = (klt_ms / max(klt_n, 1)) * 1e-3
         achieved = klt_bytes / klt_avg_s / 1e9 if klt_avg_s > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "klt_traffic.json")     # HBM bytes per k_klt_track launch from rocprofv3 --pmc
-        if os.path.exists(tf):                                      # passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), see DESIGN.md
-            try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = profile_constant("klt_traffic.json", "hbm_bytes_per_launch")
+        valu = valu_roofline(klt_avg_s, s0.B * N_PTS)
         roof = {"bound": "hbm", "kernel": "k_klt_track", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "valu": valu,
                 "avg_launch_us": round(klt_avg_s * 1e6, 3), "algorithmic_bytes_per_launch": int(klt_bytes),
                 "klt_mean_iters_per_level": [round(x, 3) for x in it_mean],
                 # the same launch when context 0 runs its steps alone after the timed region (no other context's kernels beside it)
                 "alone_avg_launch_us": round(stage["klt"] * 1e3, 3),
                 "alone_frac": round(klt_bytes / max(stage["klt"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 5),
                 "note": "HBM figure = algorithmic bytes / launch time as the contract defines it; the kernel itself is vector-ALU bound "
-                        "(rocprofv3 VALUBusy 96 %, profiles/r01_pmc_valu_batch32.csv) and moves 0.13 GB per launch through HBM. "
+                        "(see `valu`: instructions issued per launch against the SIMDs' issue rate) and moves `traffic` bytes per launch through HBM. "
                         "`frac` is the launch as timed INSIDE the run: with several batched contexts it shares the vector ALUs with the "
                         "Shi-Tomasi / BA kernels of the other contexts and takes longer than on its own (`alone_*`)"}
         out = {"metric": ("frames/sec @1920x1080, 5000 KLT pts, 20-frame sharded BA (config 5)" if c5 else
@@ -458,11 +658,19 @@ def main():
                              "pnp_inliers": (s0.last["pnp_stats"][0] if isinstance(s0.last["pnp_stats"], list) else s0.last["pnp_stats"])["n_inliers"],
                              "pnp_status_ok": all(x["status"] == 0 for x in (s0.last["pnp_stats"] if isinstance(s0.last["pnp_stats"], list) else [s0.last["pnp_stats"]]))}
                             if pl else None),
+               "regions": {"n": len(region_dt), "frames_per_s_min": round(frames_total / max(region_dt), 2),
+                           "frames_per_s_median": round(fps, 2), "frames_per_s_max": round(frames_total / min(region_dt), 2),
+                           "ms_per_step_each": [round(x / a.steps * 1e3, 4) for x in region_dt]},
                "stage_ms_per_batched_launch_group": stage, "roofline": roof, "cpu_baseline": cpu,
                "setup_s": round(t_setup, 2)}
     dist.barrier()
     for s in seqs:
         s.c.close()
+    if out is not None and dist.world == 1 and a.workload == "A" and not a.no_extras:
+        try:
+            out.update(measure_extras(dist.local_rank, frame_sets, a))
+        except Exception as e:      # noqa: BLE001  (informational keys must never cost the bench line)
+            out["extras_error"] = str(e)
     dist.close()
     if out is not None:
         print(json.dumps(out))

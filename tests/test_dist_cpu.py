@@ -54,3 +54,22 @@ def test_shard_bookkeeping_roundtrip():
         # a rank's slice equals the corresponding rows of the full dealing
         _, _, pt1, ob1 = sharding.shard_problem(K, poses, pts, obs, S, first=1, count=2) if S > 2 else (0, 0, pt[1:3], ob[1:3])
         assert np.array_equal(pt1, pt[1:3]) and np.array_equal(np.isnan(ob1), np.isnan(ob[1:3]))
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` with no torch.distributed environment must start 2 ranks on its own (a child
+    torch.distributed.run, before anything touches a GPU) and relay rank 0's single JSON line; --dry-run stops each rank
+    after the rendezvous, so this runs without a GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["gpus_arg"] == 2
+    # one rank needs no launcher
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1

@@ -7,13 +7,13 @@ export TMPDIR=/tmp VO_SIDE_STREAM=0
 BENCH="$PWD/bench.py"
 cd /tmp
 rm -rf $OUT/${TAG}_ks
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_ks -o ks -- python3 $BENCH --steps 30 --warmup 5 --seqs 32 --ctxs 1 --host-threads 1 --no-cpu-baseline > $OUT/${TAG}_ks.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_ks -o ks -- python3 $BENCH --steps 30 --warmup 5 --regions 1 --no-extras --seqs 32 --ctxs 1 --host-threads 1 --no-cpu-baseline > $OUT/${TAG}_ks.log 2>&1
 cd - > /dev/null
 python3 - <<PY > $OUT/${TAG}_kstats.txt
 import csv, glob
 f = sorted(glob.glob("$OUT/${TAG}_ks/**/*kernel_stats.csv", recursive=True))[-1]
 tot = 0
-steps = 35 + 20 + 1
+steps = 35 + 20 + 1   # warm-up + timed + the 20 untimed stage-breakdown steps + the first push
 for r in csv.DictReader(open(f)):
     n = r["Name"].split("(")[0].replace("void ", "")[:24]
     t = float(r["TotalDurationNs"]) / 1e3
