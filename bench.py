@@ -64,7 +64,7 @@ def parse():
                          "spawn) and RANSAC-P3P pose -- issued as separate calls with one sync per frame; informational")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames each CPU-baseline worker process runs")
-    ap.add_argument("--cpu-procs", type=int, default=64, help="CPU-baseline worker processes (one core each), capped by the host's cores")
+    ap.add_argument("--cpu-procs", type=int, default=16, help="CPU-baseline worker processes (one core each), capped by the host's cores")
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)     # internal: run as CPU-baseline worker with this seed
     return ap.parse_args()
 

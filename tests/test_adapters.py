@@ -139,7 +139,7 @@ def _oracle_ctx(w, h):
 
 def _gpu_ctx(w, h):
     from vo_mi355x import VoContext
-    return VoContext(w, h, max_pts=2048)
+    return VoContext(w, h, max_pts=8192)      # the Extractor's own default capacity (landmarks + candidates of a 640 x 480 run exceed 2048)
 
 
 def test_extractor_glue_matches_reference_cpu(golden_dir):
