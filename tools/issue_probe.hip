@@ -1,78 +1,149 @@
-// Diagnostic: vector-instruction ISSUE RATE of the instruction kinds k_klt_track is made of, per SIMD, as a function of the
-// number of waves that share the SIMD.  Answers "what is the VALU roof for THIS instruction mix" (bench.py roofline.valu).
+// Diagnostic: vector-instruction ISSUE RATE of the instruction kinds the hot kernels are made of, per SIMD, as a function of
+// the number of waves that share the SIMD.  Answers "what is the VALU roof for THIS instruction mix" (bench.py roofline.valu).
 // Build: hipcc --offload-arch=gfx950 -O3 tools/issue_probe.hip -o /tmp/issue_probe ; run: /tmp/issue_probe
-// Every test body is 32 independent instructions (distinct destination registers) inside a loop; all 256 CUs run it with
-// W waves per SIMD; cycles come from s_memtime around the loop of each wave (median over waves).
+// A test body is 64 instructions in 8 independent dependency chains inside a long loop; one workgroup of 4 W waves per CU puts W
+// waves on every SIMD of all 256 CUs.  The whole launch is timed with hipEvents (milliseconds of work, so launch overheads
+// vanish) and converted to shader cycles with the clock the kernel itself observes (s_memtime ticks per s_memrealtime tick).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
 #include <vector>
 
-#define REP8(x) x x x x x x x x
-#define BODY32(INS) asm volatile(REP8(INS "\n") REP8(INS "\n") REP8(INS "\n") REP8(INS "\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f) :);
+#define R8(x) x x x x x x x x
+// eight chains: operands %0..%7 read-write, %8 / %9 read-only
+#define BODY(I0, I1, I2, I3, I4, I5, I6, I7) \
+  asm volatile(R8(I0 "\n" I1 "\n" I2 "\n" I3 "\n" I4 "\n" I5 "\n" I6 "\n" I7 "\n") \
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(e), "v"(f) :);
+#define SAME(INS) BODY(INS(0), INS(1), INS(2), INS(3), INS(4), INS(5), INS(6), INS(7))
+
+#define I_FMA32(k) "v_fma_f32 %" #k ", %8, %9, %" #k
+#define I_ADD(k) "v_add_u32 %" #k ", %8, %" #k
+#define I_AND(k) "v_and_b32 %" #k ", %8, %" #k
+#define I_LSHL(k) "v_lshlrev_b32 %" #k ", 3, %" #k
+#define I_ASHR(k) "v_ashrrev_i32 %" #k ", 9, %" #k
+#define I_DOT2C(k) "v_dot2c_i32_i16 %" #k ", %8, %9"
+#define I_DOT4(k) "v_dot4_u32_u8 %" #k ", %8, %9, %" #k
+#define I_PERM(k) "v_perm_b32 %" #k ", %8, %9, %" #k
+#define I_ADDDPP(k) "v_add_u32_dpp %" #k ", %8, %" #k " row_ror:4 row_mask:0xf bank_mask:0xf"
+#define I_MOVDPP(k) "v_mov_b32_dpp %" #k ", %8 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf"
+#define I_PKSUB(k) "v_pk_sub_i16 %" #k ", %8, %" #k
+#define I_MAD24(k) "v_mad_i32_i24 %" #k ", %8, %9, %" #k
+#define I_MULLO(k) "v_mul_lo_u32 %" #k ", %8, %" #k
+#define I_CVT(k) "v_cvt_f32_i32 %" #k ", %" #k
+#define I_RNDNE(k) "v_rndne_f32 %" #k ", %" #k
+#define I_FMA64(k) "v_fma_f64 %" #k ", %8, %9, %" #k
+#define I_MUL64(k) "v_mul_f64 %" #k ", %8, %" #k
+#define I_ADD64(k) "v_add_f64 %" #k ", %8, %" #k
+#define I_RSQ64(k) "v_rsq_f64 %" #k ", %" #k
+#define I_RCP64(k) "v_rcp_f64 %" #k ", %" #k
 
 template <int OP>
 __global__ void probe(unsigned long long* out, int iters, unsigned seed) {
-  unsigned a = threadIdx.x * 3 + seed, b = threadIdx.x * 5 + 1, c = threadIdx.x + 7, d = threadIdx.x * 11 + 3, e = threadIdx.x ^ 0x5555u, f = 0x01020304u + threadIdx.x;
-  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  for (int i = 0; i < iters; i++) {
-    if (OP == 0) BODY32("v_dot2c_i32_i16 %0, %4, %5\n v_dot2c_i32_i16 %1, %4, %5\n v_dot2c_i32_i16 %2, %4, %5\n v_dot2c_i32_i16 %3, %4, %5")
-    if (OP == 1) BODY32("v_perm_b32 %0, %4, %5, %0\n v_perm_b32 %1, %4, %5, %1\n v_perm_b32 %2, %4, %5, %2\n v_perm_b32 %3, %4, %5, %3")
-    if (OP == 2) BODY32("v_add_u32_dpp %0, %4, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %1, %4, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %2, %4, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %3, %4, %3 row_ror:4 row_mask:0xf bank_mask:0xf")
-    if (OP == 3) BODY32("v_pk_sub_i16 %0, %4, %0\n v_pk_sub_i16 %1, %4, %1\n v_pk_sub_i16 %2, %4, %2\n v_pk_sub_i16 %3, %4, %3")
-    if (OP == 4) BODY32("v_ashrrev_i32 %0, 9, %0\n v_ashrrev_i32 %1, 9, %1\n v_ashrrev_i32 %2, 9, %2\n v_ashrrev_i32 %3, 9, %3")
-    if (OP == 5) BODY32("v_add_u32 %0, %4, %0\n v_add_u32 %1, %4, %1\n v_add_u32 %2, %4, %2\n v_add_u32 %3, %4, %3")
-    if (OP == 6) BODY32("v_fma_f32 %0, %4, %5, %0\n v_fma_f32 %1, %4, %5, %1\n v_fma_f32 %2, %4, %5, %2\n v_fma_f32 %3, %4, %5, %3")
-    if (OP == 7) BODY32("v_mad_i32_i24 %0, %4, %5, %0\n v_mad_i32_i24 %1, %4, %5, %1\n v_mad_i32_i24 %2, %4, %5, %2\n v_mad_i32_i24 %3, %4, %5, %3")
-    if (OP == 8) BODY32("v_dot4_u32_u8 %0, %4, %5, %0\n v_dot4_u32_u8 %1, %4, %5, %1\n v_dot4_u32_u8 %2, %4, %5, %2\n v_dot4_u32_u8 %3, %4, %5, %3")
-    if (OP == 9) BODY32("v_pk_mad_i16 %0, %4, %5, %0\n v_pk_mad_i16 %1, %4, %5, %1\n v_pk_mad_i16 %2, %4, %5, %2\n v_pk_mad_i16 %3, %4, %5, %3")
-    if (OP == 10) BODY32("v_mov_b32_dpp %0, %4 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %4 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %4 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf")
-    if (OP == 11) BODY32("v_fma_f64 %0, %4, %5, %0\n v_add_u32 %1, %4, %1\n v_add_u32 %2, %4, %2\n v_add_u32 %3, %4, %3")   // placeholder, unused
-    if (OP == 12) BODY32("v_cndmask_b32 %0, %4, %0, vcc\n v_cndmask_b32 %1, %4, %1, vcc\n v_cndmask_b32 %2, %4, %2, vcc\n v_cndmask_b32 %3, %4, %3, vcc")
-    if (OP == 13) BODY32("v_and_b32 %0, %4, %0\n v_lshlrev_b32 %1, 3, %1\n v_and_b32 %2, %4, %2\n v_lshlrev_b32 %3, 3, %3")
+  const unsigned t = threadIdx.x;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  if (OP < 100) {
+    unsigned a0 = t + seed, a1 = t * 3 + 1, a2 = t * 5 + 2, a3 = t * 7 + 3, a4 = t * 11, a5 = t * 13, a6 = t ^ 0x3333u, a7 = t + 99;
+    unsigned e = t ^ 0x5555u, f = 0x01020304u + t;
+    for (int i = 0; i < iters; i++) {
+      if (OP == 0) SAME(I_FMA32)
+      if (OP == 1) SAME(I_ADD)
+      if (OP == 2) SAME(I_AND)
+      if (OP == 3) SAME(I_LSHL)
+      if (OP == 4) SAME(I_ASHR)
+      if (OP == 5) SAME(I_DOT2C)
+      if (OP == 6) SAME(I_DOT4)
+      if (OP == 7) SAME(I_PERM)
+      if (OP == 8) SAME(I_ADDDPP)
+      if (OP == 9) SAME(I_MOVDPP)
+      if (OP == 10) SAME(I_PKSUB)
+      if (OP == 11) SAME(I_MAD24)
+      if (OP == 12) SAME(I_MULLO)
+      if (OP == 13) SAME(I_CVT)
+      if (OP == 14) SAME(I_RNDNE)
+      // the inner loop of k_klt_track per pixel pair: 3 byte gathers / packs, 6 dot products, 2 shifts, 1 packed subtract
+      if (OP == 20) BODY(I_PERM(0), I_DOT2C(1), I_DOT2C(2), I_ASHR(1), I_PERM(3), I_DOT2C(4), I_DOT2C(5), I_ASHR(4))
+      if (OP == 21) BODY(I_PERM(0), I_DOT2C(1), I_DOT2C(2), I_PKSUB(3), I_PERM(4), I_DOT2C(5), I_DOT2C(6), I_ASHR(7))
+      // half fast-class, half slow-class
+      if (OP == 22) BODY(I_ADD(0), I_DOT2C(1), I_ADD(2), I_DOT2C(3), I_ADD(4), I_DOT2C(5), I_ADD(6), I_DOT2C(7))
+    }
+    if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 0x12345678u) out[1 << 20] = a0;
+  } else {
+    double a0 = t + seed, a1 = t * 3 + 1, a2 = t * 5 + 2, a3 = t * 7 + 3, a4 = t * 11 + 1, a5 = t * 13 + 1, a6 = t + 0.5, a7 = t + 99;
+    double e = 1.0 + 1e-9 * t, f = 1e-12;
+    for (int i = 0; i < iters; i++) {
+      if (OP == 100) SAME(I_FMA64)
+      if (OP == 101) SAME(I_MUL64)
+      if (OP == 102) SAME(I_ADD64)
+      if (OP == 103) SAME(I_RSQ64)
+      if (OP == 104) SAME(I_RCP64)
+    }
+    if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 0.12345) out[1 << 20] = 1;
   }
-  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
-  if (a + b + c + d == 0x12345678u) out[0] = a;     // keep the results alive
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if ((t & 63) == 0) {
+    const size_t w = (size_t)blockIdx.x * (blockDim.x / 64) + t / 64;
+    out[2 * w] = t1 - t0; out[2 * w + 1] = r1 - r0;
+  }
 }
 
 template <int OP>
 static void run(const char* name, unsigned long long* d) {
-  const int iters = 200, per_iter = 128;
-  for (int w : {1, 2, 4, 8}) {
-    const int threads = 64 * 4 * w;            // one workgroup per CU, w waves on each of its 4 SIMDs
-    if (threads > 1024) {                      // 8 waves per SIMD: two workgroups of 1024 per CU
-      hipLaunchKernelGGL(probe<OP>, dim3(512), dim3(1024), 0, 0, d, iters, 1u);
-    } else {
-      hipLaunchKernelGGL(probe<OP>, dim3(256), dim3(threads), 0, 0, d, iters, 1u);
-    }
-    hipDeviceSynchronize();
-    const int nw = (threads > 1024) ? 512 * 16 : 256 * 4 * w;
-    std::vector<unsigned long long> h(nw);
-    hipMemcpy(h.data(), d, sizeof(unsigned long long) * nw, hipMemcpyDeviceToHost);
-    std::sort(h.begin(), h.end());
-    const double cyc = (double)h[nw / 2];
-    printf("%-18s waves/SIMD %d : %.2f cycles per instruction per wave, %.2f cycles per instruction per SIMD\n", name, w,
-           cyc / (iters * per_iter), cyc / (iters * per_iter) / w);
+  const int iters = 4000, per_iter = 64;
+  printf("%-22s", name);
+  for (int w : {1, 2, 3, 4, 5, 8}) {
+    const int wg = (w == 8) ? 2 : 1, threads = 64 * 4 * w / wg;     // w waves on each SIMD of every CU
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(probe<OP>, dim3(256 * wg), dim3(threads), 0, 0, d, 50, 1u);      // warm
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(probe<OP>, dim3(256 * wg), dim3(threads), 0, 0, d, iters, 1u);
+    (void)hipEventRecord(e1, 0);
+    (void)hipDeviceSynchronize();
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const int nw = 256 * 4 * w;
+    std::vector<unsigned long long> h(2 * nw);
+    (void)hipMemcpy(h.data(), d, sizeof(unsigned long long) * 2 * nw, hipMemcpyDeviceToHost);
+    std::vector<double> cyc(nw), clk(nw);
+    for (int i = 0; i < nw; i++) { cyc[i] = (double)h[2 * i]; clk[i] = (double)h[2 * i] / ((double)h[2 * i + 1] / 100.0); }
+    std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
+    const double mhz = clk[nw / 2];
+    const double inst = (double)iters * per_iter;
+    // per SIMD: W waves x inst instructions in (ms) of wall time at mhz
+    const double cps_wall = (ms * 1e-3 * mhz * 1e6) / (inst * w), cps_wave = cyc[nw / 2] / inst / w;
+    printf(" | W=%d %.2f (%.2f) @%4.0f", w, cps_wall, cps_wave, mhz);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   }
+  printf("\n");
 }
 
 int main() {
   unsigned long long* d;
-  hipMalloc(&d, sizeof(unsigned long long) * 16384);
-  run<6>("v_fma_f32", d);
-  run<5>("v_add_u32", d);
-  run<0>("v_dot2c_i32_i16", d);
-  run<8>("v_dot4_u32_u8", d);
-  run<1>("v_perm_b32", d);
-  run<2>("v_add_u32 dpp", d);
-  run<10>("v_mov_b32 dpp quad", d);
-  run<3>("v_pk_sub_i16", d);
-  run<9>("v_pk_mad_i16", d);
+  (void)hipMalloc(&d, sizeof(unsigned long long) * ((1 << 20) + 64));
+  printf("cycles per wave-instruction per SIMD: from the launch's wall time (from the median wave's own s_memtime span) @ in-kernel MHz\n");
+  run<0>("v_fma_f32", d);
+  run<1>("v_add_u32", d);
+  run<2>("v_and_b32", d);
+  run<3>("v_lshlrev_b32", d);
   run<4>("v_ashrrev_i32", d);
-  run<7>("v_mad_i32_i24", d);
-  run<12>("v_cndmask_b32", d);
-  run<13>("v_and/v_lshl", d);
+  run<5>("v_dot2c_i32_i16", d);
+  run<6>("v_dot4_u32_u8", d);
+  run<7>("v_perm_b32", d);
+  run<8>("v_add_u32 dpp row_ror", d);
+  run<9>("v_mov_b32 dpp quad", d);
+  run<10>("v_pk_sub_i16", d);
+  run<11>("v_mad_i32_i24", d);
+  run<12>("v_mul_lo_u32", d);
+  run<13>("v_cvt_f32_i32", d);
+  run<14>("v_rndne_f32", d);
+  run<20>("klt mix A (sample2)", d);
+  run<21>("klt mix B (+pk_sub)", d);
+  run<22>("add/dot2c alternating", d);
+  run<100>("v_fma_f64", d);
+  run<101>("v_mul_f64", d);
+  run<102>("v_add_f64", d);
+  run<103>("v_rsq_f64", d);
+  run<104>("v_rcp_f64", d);
   return 0;
 }

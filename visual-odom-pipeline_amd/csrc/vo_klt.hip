@@ -18,6 +18,7 @@
 #include "vo_internal.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 #define W_BITS 14
 
@@ -35,7 +36,8 @@ struct klt_args {
   size_t iters_seq;       // int32 stride between the sequences' iteration tables
   int top, win, max_count, n, iters_stride;
   int xcd_remap;             // batch % 8 == 0: keep every sequence on ONE XCD (see k_klt_track)
-  float min_eig;
+  float min_eig_num;         // minEig < threshold  <=>  numerator < min_eig_num  (klt_min_eig_numerator: no division per level)
+  float eps_lo, eps_hi;      // |delta|^2 in float below / above these decides the convergence test; in between: float64
   double eps2;
 };
 
@@ -109,12 +111,47 @@ __device__ __forceinline__ void wave_sum2_i32(int a, int b, int lane, int& sa, i
   sa = __builtin_amdgcn_readlane(z, 0); sb = __builtin_amdgcn_readlane(z, 1);
 }
 
-__device__ __forceinline__ float klt_combine(int hi, int lo) { return (float)((double)hi * 65536.0 + (double)lo); }
+// Two / three wave-wide sums whose QUAD partial sums still fit int32 (callers guarantee |per-lane value| < 2^29): the first
+// two butterfly stages run on the full 32-bit values as a reduce-scatter (lane & 1 selects the value), and only the 16 quad
+// sums are split into 16-bit halves -- the spare lane class of every quad carries the high halves, so ONE row reduction
+// delivers low and high totals of both values (15 vector instructions instead of 21 for the four pre-split halves).
+__device__ __forceinline__ void wave_sum2_wide(int a, int b, int lane, int& la, int& ha, int& lb, int& hb) {
+  const bool odd = lane & 1, up = lane & 2;
+  int z = (odd ? b : a) + klt_dpp<0xB1>(odd ? a : b);           // pairs: even lanes a, odd lanes b
+  z += klt_dpp<0x4E>(z);                                        // quads: lanes 0, 2 hold a's quad sum, lanes 1, 3 b's
+  int w = up ? (z >> 16) : (z & 0xFFFF);                        // lane & 3 = 0: lo a, 1: lo b, 2: hi a, 3: hi b
+  w = klt_rows_sum(w);
+  la = __builtin_amdgcn_readlane(w, 0); lb = __builtin_amdgcn_readlane(w, 1);
+  ha = __builtin_amdgcn_readlane(w, 2); hb = __builtin_amdgcn_readlane(w, 3);
+}
+
+__device__ __forceinline__ void wave_sum3_wide(int a, int b, int c, int lane, int& la, int& ha, int& lb, int& hb, int& lc, int& hc) {
+  const bool odd = lane & 1, up = lane & 2;
+  const int x = (odd ? b : a) + klt_dpp<0xB1>(odd ? a : b);     // pairs: even lanes a, odd lanes b
+  const int y = c + klt_dpp<0xB1>(c);                           // pairs of c in every lane
+  const int z = (up ? y : x) + klt_dpp<0x4E>(up ? x : y);       // quads: lane & 3 = 0: a, 1: b, 2 and 3: c
+  const int w0 = klt_rows_sum(((lane & 3) == 3) ? (z >> 16) : (z & 0xFFFF));   // lo a, lo b, lo c, hi c
+  const int w1 = klt_rows_sum(z >> 16);                                        // hi a, hi b
+  la = __builtin_amdgcn_readlane(w0, 0); lb = __builtin_amdgcn_readlane(w0, 1);
+  lc = __builtin_amdgcn_readlane(w0, 2); hc = __builtin_amdgcn_readlane(w0, 3);
+  ha = __builtin_amdgcn_readlane(w1, 0); hb = __builtin_amdgcn_readlane(w1, 1);
+}
+
+// float nearest to the exact integer hi * 2^16 + lo (lo < 2^20).  It fits int32 whenever |hi| < 2^14 -- always, except for
+// gross mismatches -- and then ONE v_cvt_f32_i32 rounds it exactly like the float64 route (5 quarter-rate instructions).
+__device__ __forceinline__ float klt_combine(int hi, int lo) {
+  if ((unsigned)(hi + 16384) < 32768u) return (float)(hi * 65536 + lo);
+  return (float)((double)hi * 65536.0 + (double)lo);
+}
+
+// cvRound(x) for 0 <= x <= 2^14: adding 1.5 * 2^23 leaves round-to-nearest-even(x) in the low mantissa bits (one float add and one
+// integer subtract at full rate instead of v_rndne_f32 + v_cvt_i32_f32 at quarter rate)
+__device__ __forceinline__ int klt_round(float x) { return __float_as_int(x + 12582912.f) - 0x4B400000; }
 
 __device__ __forceinline__ void lk_weights(float a, float b, int& iw00, int& iw01, int& iw10, int& iw11) {
-  iw00 = (int)rintf((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
-  iw01 = (int)rintf(a * (1.f - b) * (float)(1 << W_BITS));
-  iw10 = (int)rintf((1.f - a) * b * (float)(1 << W_BITS));
+  iw00 = klt_round((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
+  iw01 = klt_round(a * (1.f - b) * (float)(1 << W_BITS));
+  iw10 = klt_round((1.f - a) * b * (float)(1 << W_BITS));
   iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 }
 
@@ -127,6 +164,13 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 // D = a.lo * b.lo + a.hi * b.hi + c  (signed 16-bit halves) -> v_dot2c_i32_i16
 __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c) {
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+}
+// The same product with the accumulator taken from a THIRD operand (VOP3P v_dot2_i32_i16): hipcc selects the two-address
+// v_dot2c form for the plain builtin and then needs a v_mov to preload every rounding constant / zero (16 per LK iteration);
+// the clamp bit exists only in the three-address encoding, so asking for it selects that form.  No sum here comes near
+// the int32 range (|taps| <= 255 * 2^14), so the saturation never acts and the value is the plain dot product.
+__device__ __forceinline__ int dot2k(uint32_t a, uint32_t b, int c) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, true);
 }
 // (lo16(a) | lo16(b) << 16) -> one v_perm_b32
 __device__ __forceinline__ uint32_t pack_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
@@ -145,14 +189,14 @@ __device__ __forceinline__ uint32_t pk_abs(uint32_t a) {
 // bilinear samples (5 fractional bits) of the two pixels a lane owns in one step, packed (v0 | v1 << 16).
 // T/B: top / bottom row dwords (3 useful bytes each); wt = iw00 | iw01 << 16, wb = iw10 | iw11 << 16.
 __device__ __forceinline__ uint32_t sample2(uint32_t T, uint32_t B, uint32_t wt, uint32_t wb) {
-  const int v0 = dot2(bytes01(B), wb, dot2(bytes01(T), wt, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-  const int v1 = dot2(bytes12(B), wb, dot2(bytes12(T), wt, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+  const int v0 = dot2(bytes01(B), wb, dot2k(bytes01(T), wt, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+  const int v1 = dot2(bytes12(B), wb, dot2k(bytes12(T), wt, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
   return pack_lo((uint32_t)v0, (uint32_t)v1);
 }
 
 // interpolated derivative of one pixel: top pair / bottom pair already gathered as (left | right << 16)
 __device__ __forceinline__ int deriv1(uint32_t top, uint32_t bot, uint32_t wt, uint32_t wb) {
-  return dot2(bot, wb, dot2(top, wt, 1 << (W_BITS - 1))) >> W_BITS;
+  return dot2(bot, wb, dot2k(top, wt, 1 << (W_BITS - 1))) >> W_BITS;
 }
 
 // WAVES = minimum waves per SIMD the register allocation must allow (4: 119 VGPRs, 5: 91, 6: 80 + 32 B scratch)
@@ -201,7 +245,7 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
   for (int level = A.top; level >= 0; level--) {
     klt_level_args L = A.lv[level];
     L.imgI += (size_t)bseq * L.seq_px; L.derI += (size_t)bseq * L.seq_px; L.imgJ += (size_t)bseq * L.seq_px;
-    const float scale = 1.f / (float)(1 << level);
+    const float scale = __int_as_float((127 - level) << 23);       // 2^-level, exactly what 1.f / (float)(1 << level) gives (no division)
     float prevx = p0x * scale, prevy = p0y * scale;
     float nextx, nexty;
     if (level == A.top) { nextx = prevx; nexty = prevy; }
@@ -210,26 +254,31 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
     int n_it = -1;
 
     prevx -= half; prevy -= half;
-    const int ipx = (int)floorf(prevx), ipy = (int)floorf(prevy);
+    const float fpx = floorf(prevx), fpy = floorf(prevy);        // (float)(int)floorf(x) == floorf(x): the fraction needs no int -> float convert
+    const int ipx = (int)fpx, ipy = (int)fpy;
     if (ipx < -win || ipx >= L.w || ipy < -win || ipy >= L.h) {
       if (level == 0) { st = 0; errv = 0.f; }
       if (iters && lane == 0) iters[pt * A.iters_stride + level] = n_it;
       continue;
     }
+    const uint32_t lane_off = (uint32_t)(8 * r * L.pitch + 2 * cp);    // the lane's corner of the 32 x 34 footprint
     int iw00, iw01, iw10, iw11;
-    lk_weights(prevx - (float)ipx, prevy - (float)ipy, iw00, iw01, iw10, iw11);
+    lk_weights(prevx - fpx, prevy - fpy, iw00, iw01, iw10, iw11);
     const uint32_t wt = pack_lo((uint32_t)iw00, (uint32_t)iw01), wb = pack_lo((uint32_t)iw10, (uint32_t)iw11);
 
     // ---- template: packed pairs of I (5 frac bits), Ix, Iy for the lane's 16 pixels; exact A11, A12, A22 ----
     uint32_t tI[8], tX[8], tY[8];
     {
       uint32_t T[8], D0[8], D1[8], D2[8];
-      const size_t base = (size_t)(ipy + VO_PAD + 8 * r) * L.pitch + (size_t)(ipx + VO_PAD + 2 * cp);
+      // addresses = level base (scalar registers) + a 32-bit offset: the wave-uniform window origin, advanced per row on the
+      // scalar unit, plus ONE per-lane offset that is fixed for the level (it was a chain of 64-bit vector adds per row)
+      const uint32_t uo = (uint32_t)(ipy + VO_PAD) * (uint32_t)L.pitch + (uint32_t)(ipx + VO_PAD);
 #pragma unroll
       for (int s = 0; s < 8; s++) {
-        const size_t off = base + (size_t)s * L.pitch;
-        T[s] = ld_u32_any(L.imgI + off);
-        D0[s] = L.derI[off]; D1[s] = L.derI[off + 1]; D2[s] = L.derI[off + 2];
+        const uint32_t o = uo + (uint32_t)s * (uint32_t)L.pitch + lane_off;
+        T[s] = ld_u32_any(L.imgI + o);
+        const uint32_t* d3 = L.derI + o;                 // three consecutive pixels: one 12-byte load
+        D0[s] = d3[0]; D1[s] = d3[1]; D2[s] = d3[2];
       }
       // row 8r + 8 = step 0 of the quad neighbour r + 1 (lanes r == 3 receive a row that only masked pixels use)
       const uint32_t T8 = quad_rot1(T[0]), D08 = quad_rot1(D0[0]), D18 = quad_rot1(D1[0]), D28 = quad_rot1(D2[0]);
@@ -248,21 +297,23 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
         const uint32_t m = (8 * r + s < win) ? colmask : 0u;    // rows / columns outside the window contribute nothing
         const uint32_t xp = pack_lo((uint32_t)x0, (uint32_t)x1) & m, yp = pack_lo((uint32_t)y0, (uint32_t)y1) & m;
         tX[s] = xp; tY[s] = yp;
-        a11 = dot2(xp, xp, a11);
-        a12 = dot2(xp, yp, a12);
-        a22 = dot2(yp, yp, a22);
+        // the first step starts the three sums from an inline zero (three-address form: no preload)
+        a11 = s ? dot2(xp, xp, a11) : dot2k(xp, xp, 0);
+        a12 = s ? dot2(xp, yp, a12) : dot2k(xp, yp, 0);
+        a22 = s ? dot2(yp, yp, a22) : dot2k(yp, yp, 0);
       }
       float A11, A12, A22;
       {
+        // per lane 16 products of two int16 derivatives (|Scharr| <= 4080): < 2^28.01, a quad's sum < 2^30.01
         int l11, h11, l12, h12, l22, h22;
-        wave_sum4_i32(a11 & 0xFFFF, a11 >> 16, a12 & 0xFFFF, a12 >> 16, lane, l11, h11, l12, h12);
-        wave_sum2_i32(a22 & 0xFFFF, a22 >> 16, lane, l22, h22);
+        wave_sum3_wide(a11, a12, a22, lane, l11, h11, l12, h12, l22, h22);
         A11 = klt_combine(h11, l11) * FLT_SCALE; A12 = klt_combine(h12, l12) * FLT_SCALE; A22 = klt_combine(h22, l22) * FLT_SCALE;
       }
       if (level == A.top) VO_STAMP(dbgk, 1);   // first template
       float D = A11 * A22 - A12 * A12;
-      const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
-      if (minEig < A.min_eig || D < 1.1920929e-07f) {
+      // minEig = num / (2 win^2) < minEigThreshold, decided on the numerator (threshold pre-divided exactly on the host)
+      const float num = A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12);
+      if (num < A.min_eig_num || D < 1.1920929e-07f) {
         if (level == 0) st = 0;
         if (iters && lane == 0) iters[pt * A.iters_stride + level] = n_it;
         continue;
@@ -273,37 +324,47 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
       float pdx = 0.f, pdy = 0.f;
       int j = 0;
       for (; j < A.max_count; j++) {
-        const int inx = (int)floorf(nextx), iny = (int)floorf(nexty);
+        const float fnx = floorf(nextx), fny = floorf(nexty);
+        const int inx = (int)fnx, iny = (int)fny;
         if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) {
           if (level == 0) st = 0;
           break;
         }
         int jw00, jw01, jw10, jw11;
-        lk_weights(nextx - (float)inx, nexty - (float)iny, jw00, jw01, jw10, jw11);
+        lk_weights(nextx - fnx, nexty - fny, jw00, jw01, jw10, jw11);
         const uint32_t jt = pack_lo((uint32_t)jw00, (uint32_t)jw01), jb = pack_lo((uint32_t)jw10, (uint32_t)jw11);
         uint32_t Tj[8];
-        const uint8_t* pj = L.imgJ + (size_t)(iny + VO_PAD + 8 * r) * L.pitch + (size_t)(inx + VO_PAD + 2 * cp);
+        const uint32_t uj = (uint32_t)(iny + VO_PAD) * (uint32_t)L.pitch + (uint32_t)(inx + VO_PAD);
 #pragma unroll
-        for (int s = 0; s < 8; s++) Tj[s] = ld_u32_any(pj + (size_t)s * L.pitch);
+        for (int s = 0; s < 8; s++) Tj[s] = ld_u32_any(L.imgJ + (uj + (uint32_t)s * (uint32_t)L.pitch + lane_off));
         const uint32_t Tj8 = quad_rot1(Tj[0]);
         int b1 = 0, b2 = 0;
 #pragma unroll
         for (int s = 0; s < 8; s++) {
           const uint32_t B = (s < 7) ? Tj[(s + 1) & 7] : Tj8;
           const uint32_t d = pk_sub(sample2(Tj[s], B, jt, jb), tI[s]);   // (diff0 | diff1 << 16), |diff| <= 8160
-          b1 = dot2(d, tX[s], b1);
-          b2 = dot2(d, tY[s], b2);
+          b1 = s ? dot2(d, tX[s], b1) : dot2k(d, tX[0], 0);
+          b2 = s ? dot2(d, tY[s], b2) : dot2k(d, tY[0], 0);
         }
+        // per lane 16 products |diff| <= 8160 (255 << 5) times |derivative| <= 4080: < 2^28.99, a quad's sum < 2^30.99
         int l1, h1, l2, h2;
-        wave_sum4_i32(b1 & 0xFFFF, b1 >> 16, b2 & 0xFFFF, b2 >> 16, lane, l1, h1, l2, h2);
+        wave_sum2_wide(b1, b2, lane, l1, h1, l2, h2);
         const float fb1 = klt_combine(h1, l1) * FLT_SCALE;
         const float fb2 = klt_combine(h2, l2) * FLT_SCALE;
         const float dx = (A12 * fb2 - A22 * fb1) * D;
         const float dy = (A12 * fb1 - A11 * fb2) * D;
         nextx += dx; nexty += dy;
         outx = nextx + half; outy = nexty + half;
-        if ((double)dx * (double)dx + (double)dy * (double)dy <= A.eps2) { j++; break; }
-        if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+        // |delta|^2 <= eps^2 is OpenCV's float64 test; its float32 value is within 2^-22 of it, so only a value between the
+        // two guard constants needs the float64 evaluation
+        const float d2 = dx * dx + dy * dy;
+        bool conv;
+        if (d2 < A.eps_lo) conv = true;
+        else if (d2 > A.eps_hi) conv = false;
+        else conv = (double)dx * (double)dx + (double)dy * (double)dy <= A.eps2;
+        if (conv) { j++; break; }
+        // fabs((double)x) < 0.01 for a float x  <=>  fabsf(x) <= (float)0.01: 0.01 lies strictly between that float and the next
+        if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
           outx -= dx * 0.5f; outy -= dy * 0.5f;
           j++;
           break;
@@ -318,24 +379,26 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
 
       if (st && level == 0) {
         const float nx = outx - half, ny = outy - half;
-        const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+        const float fnx = floorf(nx), fny = floorf(ny);
+        const int inx = (int)fnx, iny = (int)fny;
         if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) {
           st = 0;
         } else {
           int jw00, jw01, jw10, jw11;
-          lk_weights(nx - (float)inx, ny - (float)iny, jw00, jw01, jw10, jw11);
+          lk_weights(nx - fnx, ny - fny, jw00, jw01, jw10, jw11);
           const uint32_t jt = pack_lo((uint32_t)jw00, (uint32_t)jw01), jb = pack_lo((uint32_t)jw10, (uint32_t)jw11);
           uint32_t Tj[8];
-          const uint8_t* pj = L.imgJ + (size_t)(iny + VO_PAD + 8 * r) * L.pitch + (size_t)(inx + VO_PAD + 2 * cp);
+          const uint32_t uj = (uint32_t)(iny + VO_PAD) * (uint32_t)L.pitch + (uint32_t)(inx + VO_PAD);
 #pragma unroll
-          for (int s = 0; s < 8; s++) Tj[s] = ld_u32_any(pj + (size_t)s * L.pitch);
+          for (int s = 0; s < 8; s++) Tj[s] = ld_u32_any(L.imgJ + (uj + (uint32_t)s * (uint32_t)L.pitch + lane_off));
           const uint32_t Tj8 = quad_rot1(Tj[0]);
           int e = 0;
 #pragma unroll
           for (int s = 0; s < 8; s++) {
             const uint32_t B = (s < 7) ? Tj[(s + 1) & 7] : Tj8;
             const uint32_t d = pk_abs(pk_sub(sample2(Tj[s], B, jt, jb), tI[s]));
-            e = dot2(d, (8 * r + s < win) ? colones : 0u, e);
+            const uint32_t ones = (8 * r + s < win) ? colones : 0u;
+            e = s ? dot2(d, ones, e) : dot2k(d, ones, 0);
           }
           const int ierr = wave_sum_i32(e);
           errv = (float)ierr * 1.f / (float)(32 * win * win);
@@ -358,6 +421,26 @@ extern "C" int32_t vo_klt_default_params(vo_klt_params* p) {
   if (!p) return VO_E_INVALID;
   p->win = 31; p->max_level = 3; p->max_count = 30; p->epsilon = 0.03; p->min_eig_threshold = 1e-4f; p->_pad = 0;
   return VO_OK;
+}
+
+// smallest float x with x / c >= thr in float arithmetic (c > 0): "num / c < thr" and "num < x" are the same predicate because
+// a correctly rounded division is monotone in its numerator.  Bisection over the ordered float encodings.
+static float klt_min_eig_numerator(float thr, float c) {
+  auto from_ord = [](int64_t k) {            // order-preserving map of [-2^31 + 1, 2^31 - 1] onto the floats (NaNs excluded by the range)
+    const uint32_t u = (k >= 0) ? (uint32_t)k : (0x80000000u | (uint32_t)(-k));
+    float f; memcpy(&f, &u, 4); return f;
+  };
+  const int64_t inf = 0x7F800000ll;          // +infinity; -inf = -0x7F800000
+  if (!(thr == thr)) return __builtin_nanf("");                                  // NaN threshold: the comparison is always false
+  int64_t lo = -inf, hi = inf;               // invariant: f(lo) fails (or lo = -inf boundary), f(hi) holds
+  { volatile float q = from_ord(lo) / c; if (q >= thr) return from_ord(lo); }    // every numerator passes
+  { volatile float q = from_ord(hi) / c; if (!(q >= thr)) return from_ord(hi); } // only +inf ... none passes below it
+  while (hi - lo > 1) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    volatile float q = from_ord(mid) / c;
+    if (q >= thr) hi = mid; else lo = mid;
+  }
+  return from_ord(hi);
 }
 
 static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, size_t off_in, size_t off_out, const int32_t* counts) {
@@ -384,7 +467,9 @@ static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, size_t off
   { static const int remap = getenv("VO_KLT_XCD_REMAP") ? atoi(getenv("VO_KLT_XCD_REMAP")) : 1; A.xcd_remap = (remap && c->batch % 8 == 0) ? 1 : 0; }
   int mc = prm->max_count; if (mc < 0) mc = 0; if (mc > 100) mc = 100;
   double eps = prm->epsilon; if (eps < 0) eps = 0; if (eps > 10) eps = 10;
-  A.max_count = mc; A.eps2 = eps * eps; A.min_eig = prm->min_eig_threshold; A.n = n;
+  A.max_count = mc; A.eps2 = eps * eps; A.n = n;
+  A.min_eig_num = klt_min_eig_numerator(prm->min_eig_threshold, (float)(2 * prm->win * prm->win));
+  A.eps_lo = (float)(A.eps2 * (1.0 - 1e-6)); A.eps_hi = (float)(A.eps2 * (1.0 + 1e-6));
   A.iters_stride = prm->max_level + 1;
   A.slab_seq = c->slab_seq; A.iters_seq = (size_t)c->max_pts * VO_MAX_LEVELS;
   c->iters_stride = A.iters_stride;
