@@ -8,12 +8,15 @@ BENCH="$PWD/bench.py"
 ARGS="--steps 4 --warmup 2 --regions 1 --no-extras --no-cpu-baseline --seqs 32 --ctxs 1 --host-threads 1"
 cd /tmp
 i=0
-for CTRS in "TA_TA_BUSY TA_FLAT_READ_WAVEFRONTS TA_TOTAL_WAVEFRONTS TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES GRBM_GUI_ACTIVE" \
-            "TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ TCP_PENDING_STALL_CYCLES TCP_TCP_TA_DATA_STALL_CYCLES TD_TD_BUSY TCP_TOTAL_READ" \
+# at most 2 texture-addresser counters per pass (more: "Request exceeds the capabilities of the hardware" and the run hangs);
+# every pass under its own timeout
+for CTRS in "TA_TA_BUSY TA_FLAT_READ_WAVEFRONTS GRBM_GUI_ACTIVE" \
+            "TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES" \
+            "TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ TD_TD_BUSY" \
             "SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY"; do
   i=$((i+1))
   rm -rf $OUT/${TAG}_pmck$i
-  rocprofv3 --pmc $CTRS --output-format csv -d $OUT/${TAG}_pmck$i -o p -- python3 $BENCH $ARGS > $OUT/${TAG}_pmck$i.log 2>&1
+  timeout 200 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/${TAG}_pmck$i -o p -- python3 $BENCH $ARGS > $OUT/${TAG}_pmck$i.log 2>&1
 done
 cd - > /dev/null
 python3 - <<PY > $OUT/${TAG}_pmc_klt.txt

@@ -156,6 +156,7 @@ bool vo_ba_ready(const vo_ctx* c);
 double* vo_ba_obs_device(vo_ctx* c, int* n_slots, int* n_pts);   // resident observation table [batch][W][N][2] of the uploaded problem
 bool vo_st_ready(const vo_ctx* c);
 int vo_st_last_max_corners(const vo_ctx* c);
+int vo_st_launch_state(const vo_ctx* c);
 int32_t vo_st_prepare(vo_ctx* c, const vo_st_params* prm);
 
 // collectives on the ctx stream (vo_comm.hip); identity / device copy without a communicator

@@ -8,12 +8,16 @@
 // results are bit-identical to the CPU oracle independent of summation order.
 //
 // Lane <-> window mapping (window <= 31x31, read footprint 32 rows x 34 bytes):
-//   lane = cp*4 + r,  cp = 0..15 (column pair), r = 0..3;  step s = 0..7 covers window row 8r + s,
+//   lane = r*16 + cp,  cp = 0..15 (column pair), r = 0..3;  step s = 0..7 covers window row 8r + s,
 //   columns 2cp and 2cp+1.  One unaligned dword load per lane per step fetches the 3 bytes the two
 //   bilinear footprints need from the top row; the bottom row of step s is the SAME lane's top row of
 //   step s + 1 (already in a register, its byte gathers are shared), only step 7 takes it from the
-//   quad neighbour's step 0 (one DPP quad_perm rotate per iteration).  => 8 dword loads per lane per
-//   LK iteration for a 1 KB window, served by L1/L2 (a pyramid level is <= 0.6 MB; HBM sees it once).
+//   lane 16 further up (row group r + 1, step 0: one ds_bpermute per iteration).  => 8 dword loads per
+//   lane per LK iteration for a 1 KB window, served by L1/L2 (a pyramid level is <= 0.6 MB; HBM sees it once).
+//   The 16 lanes of a row group read 34 CONSECUTIVE bytes, so a load instruction touches 4 rows = 4-8 cache lines and each
+//   quad of lanes one line.  (With lane = cp*4 + r -- a quad = four different rows, chosen in round 1 for a one-instruction
+//   DPP neighbour exchange -- the texture addresser issued 28 cache accesses per load instruction and was busy 91 % of the
+//   kernel: the kernel was bound by it, not by the vector ALUs; profiles/r02_pmc_klt_*.txt.)
 //   The template (I, Ix, Iy at 16 pixels per lane) lives in 24 VGPRs across all iterations.
 #include "vo_internal.h"
 
@@ -47,9 +51,10 @@ __device__ __forceinline__ uint32_t ld_u32_any(const uint8_t* p) {
   return v;
 }
 
-// lane q of every quad receives the value of lane (q+1)&3 of the same quad
-__device__ __forceinline__ uint32_t quad_rot1(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x39 /* quad_perm:[1,2,3,0] */, 0xf, 0xf, true);
+// every lane receives the value of the lane 16 further up (the same column pair of the next row group; lanes 48..63 wrap
+// around to rows that only masked pixels use): ds_bpermute_b32, the LDS crossbar -- no vector-ALU or memory-pipe slot
+__device__ __forceinline__ uint32_t row_next(uint32_t v, int lane) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, (int)v);
 }
 
 // exact wave-wide sum of an int32 per lane whose total fits in int32; result uniform
@@ -228,7 +233,7 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
   status = vo_seq(status, A.slab_seq, bseq); err = vo_seq(err, A.slab_seq, bseq);
   unsigned long long* dbgk = (pt == A.n / 2 && bseq == 0 && dbg) ? dbg + 24 : nullptr;   // diagnostic stamps of one wave
   VO_STAMP(dbgk, 0);
-  const int cp = lane >> 2, r = lane & 3;
+  const int cp = lane & 15, r = lane >> 4;
   const int win = A.win;
   const float half = (float)(win - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (float)(1 << 20);
@@ -280,8 +285,8 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
         const uint32_t* d3 = L.derI + o;                 // three consecutive pixels: one 12-byte load
         D0[s] = d3[0]; D1[s] = d3[1]; D2[s] = d3[2];
       }
-      // row 8r + 8 = step 0 of the quad neighbour r + 1 (lanes r == 3 receive a row that only masked pixels use)
-      const uint32_t T8 = quad_rot1(T[0]), D08 = quad_rot1(D0[0]), D18 = quad_rot1(D1[0]), D28 = quad_rot1(D2[0]);
+      // row 8r + 8 = step 0 of row group r + 1 (lanes of r == 3 receive a row that only masked pixels use)
+      const uint32_t T8 = row_next(T[0], lane), D08 = row_next(D0[0], lane), D18 = row_next(D1[0], lane), D28 = row_next(D2[0], lane);
       int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
       for (int s = 0; s < 8; s++) {
@@ -337,7 +342,7 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
         const uint32_t uj = (uint32_t)(iny + VO_PAD) * (uint32_t)L.pitch + (uint32_t)(inx + VO_PAD);
 #pragma unroll
         for (int s = 0; s < 8; s++) Tj[s] = ld_u32_any(L.imgJ + (uj + (uint32_t)s * (uint32_t)L.pitch + lane_off));
-        const uint32_t Tj8 = quad_rot1(Tj[0]);
+        const uint32_t Tj8 = row_next(Tj[0], lane);
         int b1 = 0, b2 = 0;
 #pragma unroll
         for (int s = 0; s < 8; s++) {
@@ -391,7 +396,7 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
           const uint32_t uj = (uint32_t)(iny + VO_PAD) * (uint32_t)L.pitch + (uint32_t)(inx + VO_PAD);
 #pragma unroll
           for (int s = 0; s < 8; s++) Tj[s] = ld_u32_any(L.imgJ + (uj + (uint32_t)s * (uint32_t)L.pitch + lane_off));
-          const uint32_t Tj8 = quad_rot1(Tj[0]);
+          const uint32_t Tj8 = row_next(Tj[0], lane);
           int e = 0;
 #pragma unroll
           for (int s = 0; s < 8; s++) {

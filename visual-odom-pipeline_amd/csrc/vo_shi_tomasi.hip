@@ -23,7 +23,7 @@
 #define ST_CAND_CAP 16384        // keys sorted in LDS (128 KB of the CU's 160 KB)
 #define ST_GLOBAL_CAP (1 << 18)  // NMS candidates kept per sequence in HBM; above ST_CAND_CAP the selection works on the
                                  // ST_CAND_CAP strongest (radix select) and is exact whenever it fills max_corners
-#define ST_CAND_STRIDE (ST_GLOBAL_CAP + ST_CAND_CAP)   // + the compacted strongest-K list
+#define ST_CAND_STRIDE (ST_GLOBAL_CAP + ST_CAND_CAP)   // raw list (conservative threshold) | staging of one rank-ordered chunk
 #define ST_OUT_CAP 4096
 #define ST_MAX_RADIUS 31
 
@@ -34,6 +34,10 @@ struct vo_st_ws {
   float* d_eig = nullptr;
   uint32_t* d_scalars = nullptr;   // [0] max eig bits, [1] n candidates, [2] n out (int), [3] rounds
   unsigned long long* d_cand = nullptr;
+  uint32_t* d_nraw = nullptr;      // [batch] raw candidate counters (appended to by the NMS stage, re-armed by k_st_select)
+  bool keep_default = false;       // VO_ST_KEEP_EIG=1: resident launches store the eigenvalue map and keep the mask too (diagnostics)
+  bool mask_clean = false;         // the mask is all 255 (k_st_eig_fused restored it): the next resident launch needs no k_st_mask_init
+  bool eig_valid = false;          // the last launch stored the eigenvalue map (vo_shi_tomasi_read)
   float* d_blockmax = nullptr;     // per-workgroup masked maxima of the eigenvalue pass
   float* d_out = nullptr;          // ST_OUT_CAP x 2
   float* d_pts = nullptr;          // uploaded cur_pts (non-resident call)
@@ -242,41 +246,103 @@ __global__ void __launch_bounds__(256) k_st_mask_init(uint8_t* __restrict__ mask
     if (i + k < np) mask[i + k] = user_mask ? user_mask[i + k] : (uint8_t)255;
 }
 
+// k_st_eig_fused also does the 3 x 3 non-maximum suppression of goodFeaturesToTrack (dilate + compare, featureselect.cpp) and
+// appends the surviving pixels to the candidate list, so the eigenvalue map is never re-read (k_st_nms read it back: 107 MB per
+// batched launch) and need not be WRITTEN at all unless somebody asks for it (`eig` may be null).
+//   * a workgroup owns OUTC = 256 - 2 R - 2 output columns and `rb` output rows; it computes one eigenvalue column / row more
+//     on every side (halo), so every 3 x 3 neighbourhood of its outputs is its own;
+//   * a thread keeps the last three eigenvalues of its column; the column-wise maxima go through LDS once per row
+//     (double-buffered, the existing barrier of the row orders it) and the test of row y runs one row later;
+//   * the quality threshold needs the GLOBAL masked maximum, unknown during the pass: candidates are kept against a RUNNING
+//     maximum (this column and, spreading one column per row, its neighbours) -- a lower bound, so the list is a superset;
+//     k_st_select drops the entries below the true threshold before ranking;
+//   * candidates go out with one atomic per wave and row (ballot + prefix), keys (value bits << 32 | pixel index) are unique, the
+//     ranking sorts them, so the append order does not matter;
+//   * `restore_mask`: the exclusion mask is consumed exactly once per pixel here; writing 255 back leaves it clean for the next
+//     frame's discs (no separate k_st_mask_init launch on the resident path).
 template <int R>
 __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict__ img, size_t img_seq_px, int pitch, int W, int H, int rb, float s2,
-                                                      const uint8_t* __restrict__ mask, float* __restrict__ eig, float* __restrict__ blockmax) {
-  constexpr int D = 2 * R + 1, OUTC = 256 - 2 * R;
+                                                      uint8_t* __restrict__ mask, float* __restrict__ eig, float* __restrict__ blockmax,
+                                                      double quality, unsigned long long* __restrict__ cand, uint32_t* __restrict__ nraw,
+                                                      int restore_mask) {
+  constexpr int D = 2 * R + 1, OUTC = 256 - 2 * R - 2;
   __shared__ uint4 s_p[2][256];
+  __shared__ float2 s_c[2][256];                                      // (max of the column's three rows, running masked maximum)
   __shared__ float s_m[4];
-  const int t = threadIdx.x;
+  // candidates are collected in LDS (one LDS atomic per wave and row) and flushed with ONE global atomic when the list could
+  // overflow on the next row and at the end: a returning global atomic per wave and row stalled the row loop (3.6x slower)
+  constexpr int LCAP = 1024;
+  __shared__ unsigned long long s_keys[LCAP];
+  __shared__ unsigned int s_cnt, s_gbase;
+  const int t = threadIdx.x, lane = t & 63;
+  if (t == 0) s_cnt = 0;
   const int x0 = blockIdx.x * OUTC, y0 = blockIdx.y * rb, bseq = blockIdx.z;
   const int rows_out = min(rb, H - y0);
-  const int total = rows_out + 2 * R;
-  const int xs = st_reflect101(x0 - R + t, W);                      // product column of this thread
+  const int total = rows_out + 2 + 2 * R;                             // product rows y0 - 1 - R .. y0 + rows_out + R
+  const int xs = st_reflect101(x0 - 1 - R + t, W);                    // product column of this thread
   const uint8_t* base = img + (size_t)bseq * img_seq_px + (size_t)VO_PAD * pitch + VO_PAD;    // pixel (0, 0), uniform
-  const int xo = x0 + t - R;                                          // output column
-  const bool outt = (t >= R) && (t < 256 - R) && (xo < W);
-  const int xo_c = outt ? xo : 0;
+  const int xe = x0 - 1 + t - R;                                      // eigenvalue column of this thread (halo: x0 - 1 and x0 + OUTC)
+  const bool evalid = (t >= R) && (t < 256 - R) && xe >= 0 && xe < W; // an eigenvalue of the image is formed here
+  const bool outt = evalid && (t > R) && (t < 255 - R);               // ... and it is one of this workgroup's outputs
+  const int xo_c = outt ? xe : 0;
   const size_t np = (size_t)W * H;
-  mask += (size_t)bseq * np; eig += (size_t)bseq * np;
+  mask += (size_t)bseq * np;
+  if (eig) eig += (size_t)bseq * np;
+  cand += (size_t)bseq * ST_CAND_STRIDE; nraw += bseq;
   unsigned ring[D][3];
 #pragma unroll
   for (int u = 0; u < D; u++) { ring[u][0] = 0; ring[u][1] = 0; ring[u][2] = 0; }
   unsigned V0 = 0, V1 = 0, V2 = 0;
-  float lmax = 0.f;
+  float lmax = 0.f;                                                   // masked maximum of the outputs of this column (exact part of the global maximum)
+  float rmax = 0.f;                                                   // running lower bound of the global maximum used for the candidate threshold
+  float e1 = 0.f, e2 = 0.f;                                           // eigenvalues of the two previous rows of this column
+  float pv = 0.f, pcm = 0.f; bool pok = false; int py = 0;            // pending 3 x 3 test: centre value, max of the rows above / below, validity, row
+  uint8_t mk1 = 0;
   // the three image rows of a product row arrive as unaligned dwords (bytes xs - 1 .. xs + 2), fetched PF product rows
   // ahead: with one round trip to L2 per row and three waves per SIMD the kernel was bound by that latency
   constexpr int PF = 3;
   uint32_t q[PF][3];
   auto fetch = [&](int k, uint32_t (&w)[3]) {
-    int rp = y0 - R + min(k, total - 1);                            // product row (uniform); one reflection is enough: overshoot <= R < H
+    int rp = y0 - 1 - R + min(k, total - 1);                        // product row (uniform); one reflection is enough: overshoot <= R + 1 < H
     rp = rp < 0 ? -rp : (rp >= H ? 2 * (H - 1) - rp : rp);
     const uint8_t* r1 = base + (size_t)rp * pitch + (xs - 1);
     w[0] = st_ld_u32_any(r1 - pitch); w[1] = st_ld_u32_any(r1); w[2] = st_ld_u32_any(r1 + pitch);
   };
+  // the pending test of row `py`: neighbours' column maxima of the slot written one row ago
+  auto test_pending = [&](int slot) {
+    bool c = false;
+    if (pok) {
+      const float2 l = s_c[slot][t - 1], r = s_c[slot][t + 1];
+      rmax = fmaxf(rmax, fmaxf(l.y, r.y));
+      const float nmax = fmaxf(fmaxf(l.x, r.x), pcm);
+      const float thr = (float)((double)rmax * quality);
+      c = (pv > thr) && (pv != 0.f) && (pv >= nmax);
+    }
+    const unsigned long long bal = __ballot(c);
+    if (bal) {
+      unsigned int basep = 0;
+      if (lane == 0) basep = atomicAdd(&s_cnt, (unsigned int)__popcll(bal));     // LDS
+      basep = (unsigned int)__builtin_amdgcn_readfirstlane((int)basep);
+      if (c) s_keys[basep + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull))] =
+               ((unsigned long long)__float_as_uint(pv) << 32) | (unsigned long long)(uint32_t)((size_t)py * W + xe);
+    }
+  };
+  // call where every thread sees the same s_cnt (right after a barrier): empties the list when the next row could overflow it
+  auto flush = [&](bool force) {
+    const unsigned int n = s_cnt;
+    if (n == 0 || (!force && n <= (unsigned int)(LCAP - 256))) return;
+    if (t == 0) s_gbase = atomicAdd(nraw, n);
+    __syncthreads();
+    const unsigned int gb = s_gbase;
+    for (unsigned int i = t; i < n; i += 256) if (gb + i < ST_GLOBAL_CAP) cand[gb + i] = s_keys[i];
+    __syncthreads();
+    if (t == 0) s_cnt = 0;
+    __syncthreads();
+  };
 #pragma unroll
   for (int i = 0; i < PF; i++) fetch(i, q[i]);
-  uint8_t mk_next = mask[(size_t)y0 * W + xo_c];
+  auto mask_row = [&](int ke) { return min(max(y0 - 1 + ke, 0), H - 1); };   // image row of eigenvalue row index ke (clamped: halo rows of the image border)
+  uint8_t mk_next = mask[(size_t)mask_row(0) * W + xo_c];
   for (int kb = 0; kb < total; kb += D) {
 #pragma unroll
     for (int u = 0; u < D; u++) {
@@ -287,7 +353,7 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
         // image rows in flight (loads return in order).  Unconditional, clamped address: a load under a divergent branch
         // would be waited for at the end of the branch.
         const uint8_t mk = mk_next;
-        mk_next = mask[(size_t)(y0 + min(max(k + 1 - 2 * R, 0), rows_out - 1)) * W + xo_c];
+        mk_next = mask[(size_t)mask_row(max(k + 1 - 2 * R, 0)) * W + xo_c];
 #pragma unroll
         for (int i = 0; i + 1 < PF; i++) { q[i][0] = q[i + 1][0]; q[i][1] = q[i + 1][1]; q[i][2] = q[i + 1][2]; }
         fetch(k + PF, q[PF - 1]);
@@ -305,7 +371,11 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
           uint4* buf = s_p[k & 1];
           buf[t] = make_uint4(P0, P1, P2, 0u);
           __syncthreads();
-          if (outt) {
+          flush(false);
+          test_pending((k - 1) & 1);                                 // row ye - 2 against the maxima written one row ago
+          const int ke = k - 2 * R, ye = y0 - 1 + ke;                // eigenvalue row of this iteration (-1 and H are halo rows of nothing)
+          float e0 = 0.f;
+          if (evalid) {
             const int ia = t + R, ib = t - R - 1;
             const uint4 A = buf[ia];
             uint4 Bv = make_uint4(0u, 0u, 0u, 0u), T = Bv;
@@ -314,17 +384,33 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
               if ((ia >> 6) != (ib >> 6)) T = buf[(ib | 63)];         // total of the wave the window starts in
             }
             const int sa = (int)(A.x - Bv.x + T.x), sb = (int)(A.y - Bv.y + T.y), sc = (int)(A.z - Bv.z + T.z);
-            const int y = y0 + k - 2 * R;
             const float a = ((float)sa * s2) * 0.5f, b = (float)sb * s2, c = ((float)sc * s2) * 0.5f;
-            const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-            const size_t o = (size_t)y * W + xo;
-            eig[o] = e;
-            if (mk && e > lmax) lmax = e;
+            e0 = (a + c) - sqrtf((a - c) * (a - c) + b * b);
           }
+          const bool own_row = (ke >= 1) && (ke <= rows_out);        // ye is one of this workgroup's output rows
+          if (outt && own_row) {
+            const size_t o = (size_t)ye * W + xe;
+            if (eig) eig[o] = e0;
+            if (mk && e0 > lmax) lmax = e0;
+            if (restore_mask && mk != 255) mask[o] = 255;
+          }
+          rmax = fmaxf(rmax, lmax);
+          // publish: max of the column over rows ye - 2 .. ye, and the running maximum
+          const float cm = fmaxf(e2, e0);
+          s_c[k & 1][t] = make_float2(fmaxf(cm, e1), rmax);
+          // the centre row ye - 1 becomes the pending test (decided next iteration, when the neighbours' maxima are visible)
+          pv = e1; pcm = cm; py = ye - 1;
+          pok = outt && (ke >= 2) && (ke - 1 <= rows_out) && mk1 && (py >= 1) && (py < H - 1) && (xe >= 1) && (xe < W - 1);
+          e2 = e1; e1 = e0; mk1 = (outt && own_row) ? mk : (uint8_t)0;
         }
       }
     }
   }
+  __syncthreads();
+  flush(false);
+  test_pending((total - 1) & 1);
+  __syncthreads();
+  flush(true);
   for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
   if ((t & 63) == 0) s_m[t >> 6] = lmax;
   __syncthreads();
@@ -334,7 +420,8 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
 #define ST_NMS_ROWS 8
 __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, const uint8_t* __restrict__ mask, int W,
                                                 int H, double quality, const float* __restrict__ blockmax, int n_blockmax,
-                                                unsigned long long* __restrict__ cand, uint32_t* __restrict__ scalars, size_t slab_seq) {
+                                                unsigned long long* __restrict__ cand, uint32_t* __restrict__ scalars, size_t slab_seq,
+                                                uint32_t* __restrict__ nraw) {
   __shared__ float s_m[4];
   __shared__ unsigned int s_cnt, s_base;
   __shared__ uint16_t s_list[256 * ST_NMS_ROWS];     // tile positions (row << 8 | column); EVERY pixel of the tile can qualify: the test is
@@ -345,7 +432,7 @@ __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, c
     const int bseq = blockIdx.z;
     const size_t np = (size_t)W * H;
     eig += (size_t)bseq * np; mask += (size_t)bseq * np; blockmax += (size_t)bseq * n_blockmax;
-    cand += (size_t)bseq * ST_CAND_STRIDE; scalars = vo_seq(scalars, slab_seq, bseq);
+    cand += (size_t)bseq * ST_CAND_STRIDE; scalars = vo_seq(scalars, slab_seq, bseq); nraw += bseq;
   }
   // ---- global masked maximum (minMaxLoc) from the per-block maxima ----
   float m = 0.f;
@@ -402,7 +489,7 @@ __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, c
   }
   __syncthreads();
   const unsigned int cnt = s_cnt;
-  if (tid == 0 && cnt) s_base = atomicAdd(&scalars[1], cnt);   // one global atomic per workgroup
+  if (tid == 0 && cnt) s_base = atomicAdd(nraw, cnt);   // one global atomic per workgroup
   __syncthreads();
   for (unsigned int i = tid; i < cnt; i += 256) {
     const unsigned int pos = s_base + i;
@@ -473,13 +560,18 @@ __device__ __forceinline__ void st_sort_regs(unsigned long long (&kr)[KP], unsig
   }
 }
 
+// sorts the keys of cand[0 .. n_load) that exceed `floor_key` (the others count as absent: key 0 sorts last); n of them exist
 template <int KP>
-__device__ __forceinline__ void st_sort_dispatch(const unsigned long long* __restrict__ cand, int n, unsigned long long* keys,
-                                                 uint32_t* xy, int W, int tid) {
+__device__ __forceinline__ void st_sort_dispatch(const unsigned long long* __restrict__ cand, int n_load, unsigned long long floor_key, int n,
+                                                 unsigned long long* keys, uint32_t* xy, int W, int tid) {
   unsigned long long kr[KP];
   const int ibase = (tid >> 6) * (KP * 64) + (tid & 63);
 #pragma unroll
-  for (int q = 0; q < KP; q++) { const int i = ibase + q * 64; kr[q] = (i < n) ? cand[i] : 0ull; }
+  for (int q = 0; q < KP; q++) {
+    const int i = ibase + q * 64;
+    const unsigned long long k = (i < n_load) ? cand[i] : 0ull;
+    kr[q] = (k > floor_key) ? k : 0ull;
+  }
   st_sort_regs<KP>(kr, keys, tid);
   __syncthreads();   // the exchange buffer aliases xy
   // keys -> packed (x, y) in rank order
@@ -497,7 +589,9 @@ __device__ __forceinline__ void st_sort_dispatch(const unsigned long long* __res
 __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restrict__ cand,
                                                     uint32_t* __restrict__ scalars, int W, int H, int cell, int gw, int gh,
                                                     double md2, int use_dist, int max_corners, float* __restrict__ out,
-                                                    size_t slab_seq, unsigned long long* __restrict__ dbg) {
+                                                    size_t slab_seq, unsigned long long* __restrict__ dbg,
+                                                    const float* __restrict__ blockmax, int n_blockmax, double quality,
+                                                    uint32_t* __restrict__ nraw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cand += (size_t)blockIdx.x * ST_CAND_STRIDE;          // one workgroup per sequence
   scalars = vo_seq(scalars, slab_seq, blockIdx.x); out = vo_seq(out, slab_seq, blockIdx.x);
@@ -511,180 +605,250 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
   uint8_t* state = smem + 128 * 1024;   // plain LDS bytes (a volatile pointer here degrades to FLAT sc0 sc1 accesses)
   const int tid = threadIdx.x;
   VO_STAMP(dbg, 0);
-  const uint32_t ncand = scalars[1];
-  if (ncand > ST_GLOBAL_CAP) { if (tid == 0) scalars[2] = 0xFFFFFFFFu; return; }   // host reports VO_E_CAPACITY
-  const bool truncated = ncand > ST_CAND_CAP;
-  if (truncated) {
-    // ---- more local maxima than the LDS sort holds: keep the ST_CAND_CAP strongest.  Keys are unique (value bits |
-    // pixel index), so the K-th largest key is found exactly by an 8-pass radix select (256-bin LDS histogram of the
-    // next byte among the keys that share the prefix); keys >= it are compacted behind the candidate list.  OpenCV's
-    // greedy scan visits candidates in descending order and stops at max_corners, so the result is exact whenever
-    // max_corners corners come out of these K; otherwise the kernel reports the capacity error below. ----
-    uint32_t* hist = reinterpret_cast<uint32_t*>(s_scan);
-    __shared__ unsigned long long s_prefix;
-    __shared__ uint32_t s_need, s_fill;
-    unsigned long long prefix = 0;
-    uint32_t need = ST_CAND_CAP;
-    for (int byte = 7; byte >= 0; byte--) {
-      if (tid < 256) hist[tid] = 0;
-      __syncthreads();
-      const int sh = 8 * byte;
-      for (uint32_t i = tid; i < ncand; i += 1024) {
-        const unsigned long long k = cand[i];
-        if (byte == 7 || (k >> (sh + 8)) == (prefix >> (sh + 8))) atomicAdd(&hist[(uint32_t)(k >> sh) & 255u], 1u);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        uint32_t nd = need;
-        int d = 255;
-        for (; d > 0; d--) { const uint32_t cnt = hist[d]; if (nd <= cnt) break; nd -= cnt; }
-        s_prefix = prefix | ((unsigned long long)d << sh);
-        s_need = nd;
-        s_fill = 0;
-      }
-      __syncthreads();
-      prefix = s_prefix; need = s_need;
-    }
-    unsigned long long* top = cand + ST_GLOBAL_CAP;
-    for (uint32_t i = tid; i < ncand; i += 1024) {
-      const unsigned long long k = cand[i];
-      if (k >= prefix) { const uint32_t pos = atomicAdd(&s_fill, 1u); if (pos < ST_CAND_CAP) top[pos] = k; }
-    }
-    __syncthreads();
-    cand = top;
+  // ---- global masked maximum (minMaxLoc) from the per-workgroup maxima, the quality threshold, and the candidates that pass it:
+  //      the NMS stage appended against a running lower bound of the maximum (a superset, in arbitrary order) ----
+  __shared__ float s_mx[16];
+  __shared__ uint32_t s_nvalid;
+  blockmax += (size_t)blockIdx.x * n_blockmax; nraw += blockIdx.x;
+  {
+    float m = 0.f;
+    for (int i = tid; i < n_blockmax; i += 1024) m = fmaxf(m, blockmax[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) s_mx[tid >> 6] = m;
+    if (tid == 0) s_nvalid = 0;
   }
-  const int n = truncated ? ST_CAND_CAP : (int)ncand;
-  // ---- sort by (value desc, index desc) = OpenCV's greaterThanPtr order; result: xy[] in rank order ----
-  if (n <= 1024) st_sort_dispatch<1>(cand, n, keys, xy, W, tid);
-  else if (n <= 2048) st_sort_dispatch<2>(cand, n, keys, xy, W, tid);
-  else if (n <= 4096) st_sort_dispatch<4>(cand, n, keys, xy, W, tid);
-  else if (n <= 8192) st_sort_dispatch<8>(cand, n, keys, xy, W, tid);
-  else st_sort_dispatch<16>(cand, n, keys, xy, W, tid);
-  for (int i = tid; i < n; i += 1024) state[i] = use_dist ? 0 : 1;
-  for (int i = tid; i < gw * gh; i += 1024) heads[i] = 0xFFFFu;
-  if (tid < 3) s_flags[tid] = 0;
   __syncthreads();
-  VO_STAMP(dbg, 1);   // sort done
-  if (use_dist) {
-    // ---- grid of linked lists (acceleration structure only: any cell size >= min_distance gives the same result) ----
-    for (int i = tid; i < n; i += 1024) {
-      const uint32_t p = xy[i];
-      const int x = p & 0xFFFF, y = p >> 16;
-      nxt[i] = (uint16_t)atomicExch(&heads[(y / cell) * gw + (x / cell)], (uint32_t)i);
-    }
-    __syncthreads();
-    VO_STAMP(dbg, 2);   // grid built
-    // ---- conflict lists: for each own candidate the (<= 4) higher-ranked candidates closer than min_distance,
-    //      found by ONE walk over the 3x3 cells (9 independent head reads, then the short chains) and kept in
-    //      registers, so that the selection rounds below touch one LDS byte per conflict ----
-    unsigned long long nb[ST_KP_MAX];
-    uint32_t over = 0, mine = 0, undec = 0;   // bit q: list overflowed / candidate exists / still undecided
+  float maxv = 0.f;
 #pragma unroll
-    for (int q = 0; q < ST_KP_MAX; q++) {
-      nb[q] = ~0ull;
-      const int i = tid + q * 1024;
-      if (i < n) {
-        mine |= 1u << q; undec |= 1u << q;
+  for (int i = 0; i < 16; i++) maxv = fmaxf(maxv, s_mx[i]);
+  const float thr = (float)((double)maxv * quality);
+  const uint32_t n_raw = *nraw;
+  if (n_raw > ST_GLOBAL_CAP) {                            // host reports VO_E_CAPACITY
+    __syncthreads();
+    if (tid == 0) { scalars[0] = __float_as_uint(maxv); scalars[1] = n_raw; scalars[2] = 0xFFFFFFFFu; *nraw = 0; }
+    return;
+  }
+  // candidates that pass the true threshold: positive floats order like their bit patterns, so "value > thr" is one 64-bit
+  // compare of the key against (bits(thr) << 32 | ~0); the list is neither copied nor compacted, every later stage applies it
+  const unsigned long long thr_key = ((unsigned long long)__float_as_uint(thr) << 32) | 0xFFFFFFFFull;
+  {
+    uint32_t cnt = 0;
+    for (uint32_t i = tid; i < n_raw; i += 1024) cnt += (cand[i] > thr_key) ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((tid & 63) == 0 && cnt) atomicAdd(&s_nvalid, cnt);
+    __syncthreads();
+  }
+  const uint32_t ncand = s_nvalid;
+  if (tid == 0) { scalars[0] = __float_as_uint(maxv); scalars[1] = ncand; *nraw = 0; }   // the raw counter is re-armed for the next launch
+  // ---- OpenCV scans the candidates in rank order (value desc, index desc) and accepts one iff no accepted corner lies closer
+  //      than min_distance, until max_corners are out.  The LDS structures hold ST_CAND_CAP entries, so the list is consumed in
+  //      rank-ordered CHUNKS: the corners accepted so far (they outrank everything that follows) + the strongest remaining keys.
+  //      One chunk is the whole list in practice; more are needed only when > ST_CAND_CAP maxima pass the threshold AND the
+  //      strongest of them do not fill max_corners (flat or noisy images with a large min_distance). ----
+  uint32_t* hist = reinterpret_cast<uint32_t*>(s_scan);
+  __shared__ unsigned long long s_prefix;
+  __shared__ uint32_t s_need, s_fill;
+  const int limit = (max_corners > 0) ? min(max_corners, ST_OUT_CAP) : ST_OUT_CAP;
+  unsigned long long* const src = cand;                   // raw list (entries <= thr_key do not count)
+  unsigned long long* const top = cand + ST_GLOBAL_CAP;   // chunk staging (behind the raw list)
+  unsigned long long upper = ~0ull;                       // keys >= upper have been consumed by earlier chunks
+  uint32_t remaining = ncand;
+  int n_acc = 0;                                          // corners accepted so far: out[0 .. n_acc) in rank order
+  uint32_t rounds_total = 0;
+  for (int pass = 0;; pass++) {
+    const int K = ST_CAND_CAP - n_acc;
+    const unsigned long long* chunk = src;
+    int n_new = (int)remaining, n_load = (int)n_raw;
+    unsigned long long next_upper = 0;
+    if (remaining > (uint32_t)K) {
+      // the K strongest keys below `upper`: keys are unique (value bits | pixel index), so the K-th largest is found exactly by
+      // an 8-pass radix select (256-bin LDS histogram of the next byte among the keys that share the prefix)
+      unsigned long long prefix = 0;
+      uint32_t need = (uint32_t)K;
+      for (int byte = 7; byte >= 0; byte--) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const int sh = 8 * byte;
+        for (uint32_t i = tid; i < n_raw; i += 1024) {
+          const unsigned long long k = src[i];
+          if (k > thr_key && k < upper && (byte == 7 || (k >> (sh + 8)) == (prefix >> (sh + 8)))) atomicAdd(&hist[(uint32_t)(k >> sh) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          uint32_t nd = need;
+          int d = 255;
+          for (; d > 0; d--) { const uint32_t cnt = hist[d]; if (nd <= cnt) break; nd -= cnt; }
+          s_prefix = prefix | ((unsigned long long)d << sh);
+          s_need = nd;
+          s_fill = 0;
+        }
+        __syncthreads();
+        prefix = s_prefix; need = s_need;
+      }
+      for (uint32_t i = tid; i < n_raw; i += 1024) {
+        const unsigned long long k = src[i];
+        if (k >= prefix && k < upper) { const uint32_t pos = atomicAdd(&s_fill, 1u); if (pos < ST_CAND_CAP) top[pos] = k; }   // prefix > thr_key
+      }
+      __syncthreads();
+      chunk = top; n_new = K; n_load = K; next_upper = prefix;
+    } else if (pass > 0) {
+      if (tid == 0) s_fill = 0;
+      __syncthreads();
+      for (uint32_t i = tid; i < n_raw; i += 1024) {
+        const unsigned long long k = src[i];
+        if (k > thr_key && k < upper) top[atomicAdd(&s_fill, 1u)] = k;
+      }
+      __syncthreads();
+      chunk = top; n_load = n_new;
+    } else if (n_raw > ST_CAND_CAP) {
+      // first and only chunk, but the raw list is longer than the sort holds: compact the valid keys (<= ST_CAND_CAP of them)
+      if (tid == 0) s_fill = 0;
+      __syncthreads();
+      for (uint32_t i = tid; i < n_raw; i += 1024) {
+        const unsigned long long k = src[i];
+        if (k > thr_key) top[atomicAdd(&s_fill, 1u)] = k;
+      }
+      __syncthreads();
+      chunk = top; n_load = n_new;
+    }
+    const int n = n_acc + n_new;
+    // ---- sort the chunk by (value desc, index desc) = OpenCV's greaterThanPtr order; result: xy[n_acc ..] in rank order ----
+    if (n_load <= 1024) st_sort_dispatch<1>(chunk, n_load, thr_key, n_new, keys, xy + n_acc, W, tid);
+    else if (n_load <= 2048) st_sort_dispatch<2>(chunk, n_load, thr_key, n_new, keys, xy + n_acc, W, tid);
+    else if (n_load <= 4096) st_sort_dispatch<4>(chunk, n_load, thr_key, n_new, keys, xy + n_acc, W, tid);
+    else if (n_load <= 8192) st_sort_dispatch<8>(chunk, n_load, thr_key, n_new, keys, xy + n_acc, W, tid);
+    else st_sort_dispatch<16>(chunk, n_load, thr_key, n_new, keys, xy + n_acc, W, tid);
+    __syncthreads();
+    for (int i = tid; i < n_acc; i += 1024) xy[i] = (uint32_t)out[2 * i] | ((uint32_t)out[2 * i + 1] << 16);   // earlier chunks' corners
+    for (int i = tid; i < n; i += 1024) state[i] = (i < n_acc || !use_dist) ? 1 : 0;
+    for (int i = tid; i < gw * gh; i += 1024) heads[i] = 0xFFFFu;
+    if (tid < 3) s_flags[tid] = 0;
+    __syncthreads();
+    if (pass == 0) VO_STAMP(dbg, 1);   // sort done
+    if (use_dist) {
+      // ---- grid of linked lists (acceleration structure only: any cell size >= min_distance gives the same result) ----
+      for (int i = tid; i < n; i += 1024) {
         const uint32_t p = xy[i];
         const int x = p & 0xFFFF, y = p >> 16;
-        const int xc = x / cell, yc = y / cell;
-        uint32_t hd[9];
-#pragma unroll
-        for (int c9 = 0; c9 < 9; c9++) {
-          const int xx = xc + (c9 % 3) - 1, yy = yc + (c9 / 3) - 1;
-          hd[c9] = (xx >= 0 && xx < gw && yy >= 0 && yy < gh) ? heads[yy * gw + xx] : 0xFFFFu;
-        }
-        int cnt = 0;
-        unsigned long long list = ~0ull;
-#pragma unroll
-        for (int c9 = 0; c9 < 9; c9++)
-          for (uint32_t qn = hd[c9]; qn != 0xFFFFu; qn = nxt[qn]) {
-            if ((int)qn >= i) continue;   // only higher-ranked candidates matter
-            const uint32_t pq = xy[qn];
-            const int ddx = x - (int)(pq & 0xFFFF), ddy = y - (int)(pq >> 16);
-            if ((double)(ddx * ddx + ddy * ddy) < md2) {
-              if (cnt < 4) list = (list << 16) | (unsigned long long)qn;
-              cnt++;
-            }
-          }
-        nb[q] = list;
-        if (cnt > 4) over |= 1u << q;
+        nxt[i] = (uint16_t)atomicExch(&heads[(y / cell) * gw + (x / cell)], (uint32_t)i);
       }
-    }
-    // ---- greedy min-distance selection as monotone parallel rounds: a candidate is accepted iff every
-    //      higher-ranked candidate closer than min_distance is rejected (== OpenCV's sequential scan) ----
-    for (int round = 0; round <= n; round++) {
-      if (tid == 0) s_flags[(round + 1) % 3] = 0;   // re-arm the flag last read two rounds ago
+      __syncthreads();
+      if (pass == 0) VO_STAMP(dbg, 2);   // grid built
+      // ---- conflict lists: for each own candidate the (<= 4) higher-ranked candidates closer than min_distance,
+      //      found by ONE walk over the 3x3 cells (9 independent head reads, then the short chains) and kept in
+      //      registers, so that the selection rounds below touch one LDS byte per conflict ----
+      unsigned long long nb[ST_KP_MAX];
+      uint32_t over = 0, undec = 0;   // bit q: list overflowed / still undecided
 #pragma unroll
       for (int q = 0; q < ST_KP_MAX; q++) {
-        if (!((undec >> q) & 1)) continue;
+        nb[q] = ~0ull;
         const int i = tid + q * 1024;
-        bool any_acc = false, any_und = false;
-        if (!((over >> q) & 1)) {
-          const unsigned long long list = nb[q];
-#pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const uint32_t qn = (uint32_t)(list >> (16 * t)) & 0xFFFFu;
-            if (qn != 0xFFFFu) {
-              const uint8_t sq = state[qn];
-              any_acc |= (sq == 1); any_und |= (sq == 0);
-            }
-          }
-        } else {
-          // rare: more than 4 conflicts -> walk the grid again
+        if (i >= n_acc && i < n) {
+          undec |= 1u << q;
           const uint32_t p = xy[i];
           const int x = p & 0xFFFF, y = p >> 16;
           const int xc = x / cell, yc = y / cell;
-          const int x1 = max(xc - 1, 0), y1 = max(yc - 1, 0), x2 = min(xc + 1, gw - 1), y2 = min(yc + 1, gh - 1);
-          for (int yy = y1; yy <= y2; yy++)
-            for (int xx = x1; xx <= x2; xx++)
-              for (uint32_t qn = heads[yy * gw + xx]; qn != 0xFFFFu; qn = nxt[qn]) {
-                if ((int)qn >= i) continue;
-                const uint32_t pq = xy[qn];
-                const int ddx = x - (int)(pq & 0xFFFF), ddy = y - (int)(pq >> 16);
-                if ((double)(ddx * ddx + ddy * ddy) < md2) {
-                  const uint8_t sq = state[qn];
-                  any_acc |= (sq == 1); any_und |= (sq == 0);
-                }
+          uint32_t hd[9];
+#pragma unroll
+          for (int c9 = 0; c9 < 9; c9++) {
+            const int xx = xc + (c9 % 3) - 1, yy = yc + (c9 / 3) - 1;
+            hd[c9] = (xx >= 0 && xx < gw && yy >= 0 && yy < gh) ? heads[yy * gw + xx] : 0xFFFFu;
+          }
+          int cnt = 0;
+          unsigned long long list = ~0ull;
+#pragma unroll
+          for (int c9 = 0; c9 < 9; c9++)
+            for (uint32_t qn = hd[c9]; qn != 0xFFFFu; qn = nxt[qn]) {
+              if ((int)qn >= i) continue;   // only higher-ranked candidates matter
+              const uint32_t pq = xy[qn];
+              const int ddx = x - (int)(pq & 0xFFFF), ddy = y - (int)(pq >> 16);
+              if ((double)(ddx * ddx + ddy * ddy) < md2) {
+                if (cnt < 4) list = (list << 16) | (unsigned long long)qn;
+                cnt++;
               }
+            }
+          nb[q] = list;
+          if (cnt > 4) over |= 1u << q;
         }
-        if (any_acc) { state[i] = 2; undec &= ~(1u << q); }
-        else if (!any_und) { state[i] = 1; undec &= ~(1u << q); }
       }
-      if (undec) s_flags[round % 3] = 1;
+      // ---- greedy min-distance selection as monotone parallel rounds: a candidate is accepted iff every
+      //      higher-ranked candidate closer than min_distance is rejected (== OpenCV's sequential scan) ----
+      for (int round = 0; round <= n; round++) {
+        if (tid == 0) s_flags[(round + 1) % 3] = 0;   // re-arm the flag last read two rounds ago
+#pragma unroll
+        for (int q = 0; q < ST_KP_MAX; q++) {
+          if (!((undec >> q) & 1)) continue;
+          const int i = tid + q * 1024;
+          bool any_acc = false, any_und = false;
+          if (!((over >> q) & 1)) {
+            const unsigned long long list = nb[q];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              const uint32_t qn = (uint32_t)(list >> (16 * t)) & 0xFFFFu;
+              if (qn != 0xFFFFu) {
+                const uint8_t sq = state[qn];
+                any_acc |= (sq == 1); any_und |= (sq == 0);
+              }
+            }
+          } else {
+            // rare: more than 4 conflicts -> walk the grid again
+            const uint32_t p = xy[i];
+            const int x = p & 0xFFFF, y = p >> 16;
+            const int xc = x / cell, yc = y / cell;
+            const int x1 = max(xc - 1, 0), y1 = max(yc - 1, 0), x2 = min(xc + 1, gw - 1), y2 = min(yc + 1, gh - 1);
+            for (int yy = y1; yy <= y2; yy++)
+              for (int xx = x1; xx <= x2; xx++)
+                for (uint32_t qn = heads[yy * gw + xx]; qn != 0xFFFFu; qn = nxt[qn]) {
+                  if ((int)qn >= i) continue;
+                  const uint32_t pq = xy[qn];
+                  const int ddx = x - (int)(pq & 0xFFFF), ddy = y - (int)(pq >> 16);
+                  if ((double)(ddx * ddx + ddy * ddy) < md2) {
+                    const uint8_t sq = state[qn];
+                    any_acc |= (sq == 1); any_und |= (sq == 0);
+                  }
+                }
+          }
+          if (any_acc) { state[i] = 2; undec &= ~(1u << q); }
+          else if (!any_und) { state[i] = 1; undec &= ~(1u << q); }
+        }
+        if (undec) s_flags[round % 3] = 1;
+        __syncthreads();
+        if (round == 0 && pass == 0) VO_STAMP(dbg, 5);
+        if (!s_flags[round % 3]) { rounds_total += (uint32_t)round + 1; break; }
+      }
+    }
+    if (pass == 0) VO_STAMP(dbg, 3);   // rounds done
+    // ---- ordered compaction of the chunk's accepted candidates (rank order) behind the earlier ones, up to max_corners ----
+    const int per = (n_new + 1023) / 1024;
+    const int b0 = n_acc + min(tid * per, n_new), b1 = min(b0 + per, n);
+    int cnt = 0;
+    for (int i = b0; i < b1; i++) cnt += (state[i] == 1);
+    __syncthreads();                 // hist (the radix select) aliases s_scan
+    s_scan[tid] = cnt;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int v = (tid >= o) ? s_scan[tid - o] : 0;
       __syncthreads();
-      if (round == 0) VO_STAMP(dbg, 5);
-      if (!s_flags[round % 3]) { if (tid == 0) { scalars[3] = (uint32_t)round + 1; if (dbg) dbg[6] = (unsigned long long)(round + 1); } break; }
+      s_scan[tid] += v;
+      __syncthreads();
     }
-    (void)mine;
-  }
-  VO_STAMP(dbg, 3);   // rounds done
-  // ---- ordered compaction of the accepted candidates (rank order), first max_corners ----
-  const int per = (n + 1023) / 1024;
-  const int b0 = min(tid * per, n), b1 = min(b0 + per, n);
-  int cnt = 0;
-  for (int i = b0; i < b1; i++) cnt += (state[i] == 1);
-  s_scan[tid] = cnt;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int v = (tid >= o) ? s_scan[tid - o] : 0;
-    __syncthreads();
-    s_scan[tid] += v;
-    __syncthreads();
-  }
-  int pos = s_scan[tid] - cnt;
-  const int total = s_scan[1023];
-  const int limit = (max_corners > 0) ? min(max_corners, ST_OUT_CAP) : ST_OUT_CAP;
-  for (int i = b0; i < b1; i++)
-    if (state[i] == 1) {
-      if (pos < limit) {
-        const uint32_t p = xy[i];
-        out[2 * pos] = (float)(p & 0xFFFF); out[2 * pos + 1] = (float)(p >> 16);
+    int pos = n_acc + s_scan[tid] - cnt;
+    const int total = n_acc + s_scan[1023];
+    for (int i = b0; i < b1; i++)
+      if (state[i] == 1) {
+        if (pos < limit) {
+          const uint32_t p = xy[i];
+          out[2 * pos] = (float)(p & 0xFFFF); out[2 * pos + 1] = (float)(p >> 16);
+        }
+        pos++;
       }
-      pos++;
-    }
-  // truncated candidate list that did not fill max_corners: lower-ranked candidates could still have been selected
-  if (tid == 0) scalars[2] = (truncated && total < limit) ? 0xFFFFFFFFu : (uint32_t)min(total, limit);
+    n_acc = min(total, limit);
+    remaining -= (uint32_t)n_new;
+    __syncthreads();                 // out[] and s_scan are re-read / re-used by the next chunk
+    if (n_acc >= limit || remaining == 0) break;
+    upper = next_upper;
+  }
+  if (tid == 0) { scalars[2] = (uint32_t)n_acc; scalars[3] = rounds_total; if (dbg) dbg[6] = (unsigned long long)rounds_total; }
   VO_STAMP(dbg, 4);
 }
 
@@ -694,7 +858,7 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
 void vo_st_destroy(vo_ctx* c) {
   if (!c->st) return;
   vo_st_ws* s = c->st;
-  void* bufs[] = {s->d_mask, s->d_user_mask, s->d_h, s->d_eig, s->d_cand, s->d_blockmax, s->d_pts};   // scalars / out live in the ctx slab
+  void* bufs[] = {s->d_mask, s->d_user_mask, s->d_h, s->d_eig, s->d_cand, s->d_nraw, s->d_blockmax, s->d_pts};   // scalars / out live in the ctx slab
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete s;
   c->st = nullptr;
@@ -712,7 +876,10 @@ static int32_t st_init(vo_ctx* c) {
   VO_HIP(c, hipMalloc((void**)&s->d_eig, np * sizeof(float) * B));
   s->d_scalars = vo_slab<uint32_t>(c, c->off_st_scalars);
   VO_HIP(c, hipMalloc((void**)&s->d_cand, sizeof(unsigned long long) * ST_CAND_STRIDE * B));
-  s->n_blockmax = vo_div_up(c->width, 256 - 30) * c->height;                     // upper bound over both eigenvalue paths (1-row bands)
+  VO_HIP(c, hipMalloc((void**)&s->d_nraw, sizeof(uint32_t) * B));
+  VO_HIP(c, hipMemsetAsync(s->d_nraw, 0, sizeof(uint32_t) * B, c->stream));
+  s->keep_default = getenv("VO_ST_KEEP_EIG") && atoi(getenv("VO_ST_KEEP_EIG")) != 0;
+  s->n_blockmax = vo_div_up(c->width, 256 - 32) * c->height;                     // upper bound over both eigenvalue paths (1-row bands)
   VO_HIP(c, hipMalloc((void**)&s->d_blockmax, sizeof(float) * (size_t)s->n_blockmax * B));
   s->d_out = vo_slab<float>(c, c->off_st_out);
   VO_HIP(c, hipMalloc((void**)&s->d_pts, sizeof(float) * 2 * (size_t)c->max_pts * B));
@@ -740,6 +907,7 @@ static void circle_rows(int radius, disc_rows* rows) {
 
 bool vo_st_ready(const vo_ctx* c) { return c->st != nullptr; }
 int vo_st_last_max_corners(const vo_ctx* c) { return c->st ? c->st->last_max_corners : 0; }
+int vo_st_launch_state(const vo_ctx* c) { return c->st ? (c->st->mask_clean ? 1 : 0) | (c->st->keep_default ? 2 : 0) : 0; }   // decides which kernels a resident launch enqueues
 // all allocations a launch with these parameters needs (called outside any graph capture)
 int32_t vo_st_prepare(vo_ctx* c, const vo_st_params* prm) {
   int32_t r = st_init(c);
@@ -757,8 +925,10 @@ extern "C" int32_t vo_st_default_params(vo_st_params* p) {
 }
 
 // pts: sequence-0 pointer of the exclusion-disc centres, pts_seq: byte stride between sequences
+// keep: store the eigenvalue map and leave the exclusion mask in place (vo_shi_tomasi_read); otherwise the fused kernel writes
+// no map and hands the mask back clean, which saves the k_st_mask_init launch of the next call
 static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cur, int mask_radius, const uint8_t* d_user_mask,
-                         const vo_st_params* prm, const int32_t* counts) {
+                         const vo_st_params* prm, const int32_t* counts, bool keep) {
   VO_CHECK(c, c->n_pushed >= 1, VO_E_STATE, "no frame pushed");
   VO_CHECK(c, prm->block_size >= 1 && prm->block_size <= 31 && (prm->block_size & 1), VO_E_INVALID,
            "block_size must be odd, <= 31");
@@ -773,9 +943,11 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
   const float s2 = sf * sf;
   const bool fused = s->fused && r == 15 && H > 31 && W > 31;    // (single border reflection per row inside the kernel)
   int n_blockmax;
-  if (fused) hipLaunchKernelGGL(k_st_mask_init, dim3(vo_div_up((int)(((size_t)W * H + 15) / 16), 256), B), dim3(256), 0, c->stream, s->d_mask, d_user_mask,
-                                (size_t)W * H, s->d_scalars, c->slab_seq);
-  else {
+  if (fused) {
+    if (keep || d_user_mask || !s->mask_clean)
+      hipLaunchKernelGGL(k_st_mask_init, dim3(vo_div_up((int)(((size_t)W * H + 15) / 16), 256), B), dim3(256), 0, c->stream, s->d_mask, d_user_mask,
+                         (size_t)W * H, s->d_scalars, c->slab_seq);
+  } else {
     if (!s->d_h) VO_HIP(c, hipMalloc((void**)&s->d_h, (size_t)W * H * 3 * sizeof(int32_t) * B));
     hipLaunchKernelGGL(k_st_sobel_hsum, dim3(vo_div_up(W, ST_HS_COLS), H, B), dim3(256), 0, c->stream, F.img[0], c->lvl_px[0],
                        c->lv[0].pitch, W, H, r, s->d_h, s->d_mask, d_user_mask, s->d_scalars, c->slab_seq);
@@ -789,21 +961,24 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
   }
   if (fused) {
     // rows per band: few bands keep the 30-row start-up small; with few sequences in flight more, shorter bands fill the GPU
-    const int gx = vo_div_up(W, 256 - 30);
+    const int gx = vo_div_up(W, 256 - 32);
     int rb = 94;
     while (rb > 16 && gx * vo_div_up(H, rb) * B < 512) rb = (rb + 1) / 2;
     if (s->force_rb > 0) rb = s->force_rb < H ? s->force_rb : H;
     const int gy = vo_div_up(H, rb);
     n_blockmax = gx * gy;
+    const bool restore = !keep && !d_user_mask;
     hipLaunchKernelGGL(k_st_eig_fused<15>, dim3(gx, gy, B), dim3(256), 0, c->stream, F.img[0], c->lvl_px[0], c->lv[0].pitch, W, H, rb, s2,
-                       s->d_mask, s->d_eig, s->d_blockmax);
+                       s->d_mask, keep ? s->d_eig : nullptr, s->d_blockmax, prm->quality_level, s->d_cand, s->d_nraw, restore ? 1 : 0);
+    s->mask_clean = restore; s->eig_valid = keep;
   } else {
     n_blockmax = vo_div_up(W, 256) * vo_div_up(H, ST_ROWS);
     hipLaunchKernelGGL(k_st_vsum_eig, dim3(vo_div_up(W, 256), vo_div_up(H, ST_ROWS), B), dim3(256), 0, c->stream, s->d_h,
                        s->d_mask, W, H, r, s2, s->d_eig, s->d_blockmax);
+    hipLaunchKernelGGL(k_st_nms, dim3(vo_div_up(W - 2, 256), vo_div_up(H - 2, ST_NMS_ROWS), B), dim3(256), 0, c->stream, s->d_eig,
+                       s->d_mask, W, H, prm->quality_level, s->d_blockmax, n_blockmax, s->d_cand, s->d_scalars, c->slab_seq, s->d_nraw);
+    s->mask_clean = false; s->eig_valid = true;
   }
-  hipLaunchKernelGGL(k_st_nms, dim3(vo_div_up(W - 2, 256), vo_div_up(H - 2, ST_NMS_ROWS), B), dim3(256), 0, c->stream, s->d_eig,
-                     s->d_mask, W, H, prm->quality_level, s->d_blockmax, n_blockmax, s->d_cand, s->d_scalars, c->slab_seq);
   const int use_dist = prm->min_distance >= 1.0 ? 1 : 0;
   // grid cell: >= min_distance (3x3 neighbourhood then covers the exclusion radius), coarse enough to fit LDS
   int cell = use_dist ? (int)ceil(prm->min_distance) : 1;
@@ -812,7 +987,8 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
   const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
   const double md2 = prm->min_distance * prm->min_distance;
   hipLaunchKernelGGL(k_st_select, dim3(B), dim3(1024), ST_SEL_LDS, c->stream, s->d_cand,
-                     s->d_scalars, W, H, cell, gw, gh, md2, use_dist, prm->max_corners, s->d_out, c->slab_seq, c->d_dbg);
+                     s->d_scalars, W, H, cell, gw, gh, md2, use_dist, prm->max_corners, s->d_out, c->slab_seq, c->d_dbg,
+                     s->d_blockmax, n_blockmax, prm->quality_level, s->d_nraw);
   VO_HIP(c, hipGetLastError());
   s->last_max_corners = prm->max_corners;
   return VO_OK;
@@ -852,7 +1028,7 @@ extern "C" int32_t vo_shi_tomasi(vo_ctx* c, const float* cur_pts, int32_t n_cur,
     VO_HIP(c, hipMemcpy2DAsync(s->d_pts, pts_seq, cur_pts, sizeof(float) * 2 * n_cur, sizeof(float) * 2 * n_cur, c->batch,
                                hipMemcpyHostToDevice, c->stream));
   if (mask) VO_HIP(c, hipMemcpyAsync(s->d_user_mask, mask, (size_t)c->width * c->height * c->batch, hipMemcpyHostToDevice, c->stream));
-  r = st_launch(c, s->d_pts, pts_seq, n_cur, mask_radius, mask ? s->d_user_mask : nullptr, prm, nullptr);
+  r = st_launch(c, s->d_pts, pts_seq, n_cur, mask_radius, mask ? s->d_user_mask : nullptr, prm, nullptr, true);
   if (r != VO_OK) return r;
   return st_fetch(c, out_pts, n_out);
 }
@@ -865,7 +1041,8 @@ extern "C" int32_t vo_shi_tomasi_resident(vo_ctx* c, int32_t n_cur, int32_t mask
   VO_HIP(c, hipSetDevice(c->device));
   int32_t r = st_init(c);
   if (r != VO_OK) return r;
-  return st_launch(c, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq, n_cur, mask_radius, nullptr, prm, c->d_pt_counts);
+  return st_launch(c, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq, n_cur, mask_radius, nullptr, prm, c->d_pt_counts,
+                   c->st->keep_default);
 }
 
 extern "C" int32_t vo_shi_tomasi_fetch(vo_ctx* c, float* out_pts, int32_t* n_out) {
@@ -879,8 +1056,11 @@ extern "C" int32_t vo_shi_tomasi_fetch(vo_ctx* c, float* out_pts, int32_t* n_out
 extern "C" int32_t vo_shi_tomasi_read(vo_ctx* c, float* eig_out, uint8_t* mask_out, int32_t* n_candidates) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->st, VO_E_STATE, "no shi_tomasi call yet");
+  VO_CHECK(c, c->st->eig_valid || (!eig_out && !mask_out), VO_E_STATE,
+           "the last launch was a resident one: it keeps neither the eigenvalue map nor the mask (VO_ST_KEEP_EIG=1 makes it)");
   VO_HIP(c, hipSetDevice(c->device));
   VO_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->stream2) VO_HIP(c, hipStreamSynchronize(c->stream2));
   const size_t np = (size_t)c->width * c->height * c->batch;
   if (eig_out) VO_HIP(c, hipMemcpy(eig_out, c->st->d_eig, np * sizeof(float), hipMemcpyDeviceToHost));
   if (mask_out) VO_HIP(c, hipMemcpy(mask_out, c->st->d_mask, np, hipMemcpyDeviceToHost));

@@ -79,6 +79,7 @@ static uint64_t step_signature(vo_ctx* c, const step_cfg& s) {
   int W = 0, N = 0;
   mix_i((long long)(uintptr_t)vo_ba_obs_device(c, &W, &N)); mix_i(W); mix_i(N);
   mix_i((long long)(uintptr_t)c->comm);
+  mix_i(vo_st_launch_state(c));             // a clean exclusion mask drops k_st_mask_init from the launch list
   return h;
 }
 
