@@ -282,7 +282,9 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
       for (int s = 0; s < 8; s++) {
         const uint32_t o = uo + (uint32_t)s * (uint32_t)L.pitch + lane_off;
         T[s] = ld_u32_any(L.imgI + o);
-        const uint32_t* d3 = L.derI + o;                 // three consecutive pixels: one 12-byte load
+        // three consecutive pixels: one 12-byte load.  (8 bytes + the neighbour lane's first pixel through a DPP row shift was
+        // measured: the same kernel time -- the data path is not priced per byte.)
+        const uint32_t* d3 = L.derI + o;
         D0[s] = d3[0]; D1[s] = d3[1]; D2[s] = d3[2];
       }
       // row 8r + 8 = step 0 of row group r + 1 (lanes of r == 3 receive a row that only masked pixels use)

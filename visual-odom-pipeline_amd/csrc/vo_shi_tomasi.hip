@@ -276,6 +276,7 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
   __shared__ unsigned int s_cnt, s_gbase;
   const int t = threadIdx.x, lane = t & 63;
   if (t == 0) s_cnt = 0;
+  s_c[0][t] = make_float2(0.f, 0.f); s_c[1][t] = make_float2(0.f, 0.f);    // the first row's (unconditional) neighbour reads
   const int x0 = blockIdx.x * OUTC, y0 = blockIdx.y * rb, bseq = blockIdx.z;
   const int rows_out = min(rb, H - y0);
   const int total = rows_out + 2 + 2 * R;                             // product rows y0 - 1 - R .. y0 + rows_out + R
@@ -308,16 +309,16 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
     const uint8_t* r1 = base + (size_t)rp * pitch + (xs - 1);
     w[0] = st_ld_u32_any(r1 - pitch); w[1] = st_ld_u32_any(r1); w[2] = st_ld_u32_any(r1 + pitch);
   };
-  // the pending test of row `py`: neighbours' column maxima of the slot written one row ago
+  // the pending test of row `py`: neighbours' column maxima of the slot written one row ago.  Branch-free up to the ballot (the
+  // LDS reads use clamped indices; `pok` is false wherever they would be meaningless).  The threshold here only thins the list --
+  // k_st_select applies the exact one -- so a float product rounded DOWN replaces the float64 product of the reference formula.
+  const float q_lo = (float)(quality * (1.0 - 1e-6));
+  const int tl = max(t - 1, 0), tr = min(t + 1, 255);
   auto test_pending = [&](int slot) {
-    bool c = false;
-    if (pok) {
-      const float2 l = s_c[slot][t - 1], r = s_c[slot][t + 1];
-      rmax = fmaxf(rmax, fmaxf(l.y, r.y));
-      const float nmax = fmaxf(fmaxf(l.x, r.x), pcm);
-      const float thr = (float)((double)rmax * quality);
-      c = (pv > thr) && (pv != 0.f) && (pv >= nmax);
-    }
+    const float2 l = s_c[slot][tl], r = s_c[slot][tr];
+    rmax = fmaxf(rmax, fmaxf(l.y, r.y));
+    const float nmax = fmaxf(fmaxf(l.x, r.x), pcm);
+    const bool c = pok && (pv > rmax * q_lo) && (pv >= nmax);            // pv > threshold >= 0 excludes the zeros as well
     const unsigned long long bal = __ballot(c);
     if (bal) {
       unsigned int basep = 0;
@@ -374,24 +375,25 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
           flush(false);
           test_pending((k - 1) & 1);                                 // row ye - 2 against the maxima written one row ago
           const int ke = k - 2 * R, ye = y0 - 1 + ke;                // eigenvalue row of this iteration (-1 and H are halo rows of nothing)
-          float e0 = 0.f;
-          if (evalid) {
-            const int ia = t + R, ib = t - R - 1;
+          float e0;
+          {
+            // every thread forms a value (clamped LDS indices: no divergent branch); the ones outside the eigenvalue columns drop it
+            const int ia = min(t + R, 255), ib = t - R - 1, ibc = max(ib, 0);
             const uint4 A = buf[ia];
-            uint4 Bv = make_uint4(0u, 0u, 0u, 0u), T = Bv;
-            if (ib >= 0) {
-              Bv = buf[ib];
-              if ((ia >> 6) != (ib >> 6)) T = buf[(ib | 63)];         // total of the wave the window starts in
-            }
-            const int sa = (int)(A.x - Bv.x + T.x), sb = (int)(A.y - Bv.y + T.y), sc = (int)(A.z - Bv.z + T.z);
+            uint4 Bv = buf[ibc], T = buf[ibc | 63];                  // T: total of the wave the window starts in
+            const bool hasb = ib >= 0, cross = hasb && ((ia >> 6) != (ib >> 6));
+            const unsigned bx = hasb ? Bv.x : 0u, by = hasb ? Bv.y : 0u, bz = hasb ? Bv.z : 0u;
+            const unsigned tx = cross ? T.x : 0u, ty = cross ? T.y : 0u, tz = cross ? T.z : 0u;
+            const int sa = (int)(A.x - bx + tx), sb = (int)(A.y - by + ty), sc = (int)(A.z - bz + tz);
             const float a = ((float)sa * s2) * 0.5f, b = (float)sb * s2, c = ((float)sc * s2) * 0.5f;
-            e0 = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+            e0 = evalid ? (a + c) - sqrtf((a - c) * (a - c) + b * b) : 0.f;
           }
           const bool own_row = (ke >= 1) && (ke <= rows_out);        // ye is one of this workgroup's output rows
-          if (outt && own_row) {
+          const bool mine = outt && own_row;
+          lmax = (mine && mk) ? fmaxf(lmax, e0) : lmax;
+          if (mine) {
             const size_t o = (size_t)ye * W + xe;
             if (eig) eig[o] = e0;
-            if (mk && e0 > lmax) lmax = e0;
             if (restore_mask && mk != 255) mask[o] = 255;
           }
           rmax = fmaxf(rmax, lmax);
@@ -498,6 +500,13 @@ __global__ void __launch_bounds__(256) k_st_nms(const float* __restrict__ eig, c
     const size_t o = (size_t)(y0 + ry + 1) * W + (x0 + tx + 1);
     if (pos < ST_GLOBAL_CAP) cand[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(uint32_t)o;
   }
+}
+
+// wave-uniform values that come out of LDS / global memory arrive in vector registers; pinning them into scalar registers keeps
+// the loop-carried state of k_st_select (counts, bounds, the 64-bit rank limits) out of the 128-VGPR budget of a 1024-thread workgroup
+__device__ __forceinline__ uint32_t st_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long st_uniform64(unsigned long long v) {
+  return ((unsigned long long)st_uniform((uint32_t)(v >> 32)) << 32) | st_uniform((uint32_t)v);
 }
 
 // LDS map of k_st_select (144 KB): exchange buffer of the sort: keys u64 [n2 <= 16384] at 0.
@@ -621,8 +630,8 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
   float maxv = 0.f;
 #pragma unroll
   for (int i = 0; i < 16; i++) maxv = fmaxf(maxv, s_mx[i]);
-  const float thr = (float)((double)maxv * quality);
-  const uint32_t n_raw = *nraw;
+  const float thr = __uint_as_float(st_uniform(__float_as_uint((float)((double)maxv * quality))));
+  const uint32_t n_raw = st_uniform(*nraw);
   if (n_raw > ST_GLOBAL_CAP) {                            // host reports VO_E_CAPACITY
     __syncthreads();
     if (tid == 0) { scalars[0] = __float_as_uint(maxv); scalars[1] = n_raw; scalars[2] = 0xFFFFFFFFu; *nraw = 0; }
@@ -638,7 +647,7 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
     if ((tid & 63) == 0 && cnt) atomicAdd(&s_nvalid, cnt);
     __syncthreads();
   }
-  const uint32_t ncand = s_nvalid;
+  const uint32_t ncand = st_uniform(s_nvalid);
   if (tid == 0) { scalars[0] = __float_as_uint(maxv); scalars[1] = ncand; *nraw = 0; }   // the raw counter is re-armed for the next launch
   // ---- OpenCV scans the candidates in rank order (value desc, index desc) and accepts one iff no accepted corner lies closer
   //      than min_distance, until max_corners are out.  The LDS structures hold ST_CAND_CAP entries, so the list is consumed in
@@ -655,6 +664,7 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
   uint32_t remaining = ncand;
   int n_acc = 0;                                          // corners accepted so far: out[0 .. n_acc) in rank order
   uint32_t rounds_total = 0;
+#pragma unroll 1
   for (int pass = 0;; pass++) {
     const int K = ST_CAND_CAP - n_acc;
     const unsigned long long* chunk = src;
@@ -683,7 +693,7 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
           s_fill = 0;
         }
         __syncthreads();
-        prefix = s_prefix; need = s_need;
+        prefix = st_uniform64(s_prefix); need = st_uniform(s_need);
       }
       for (uint32_t i = tid; i < n_raw; i += 1024) {
         const unsigned long long k = src[i];
@@ -833,7 +843,7 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
       __syncthreads();
     }
     int pos = n_acc + s_scan[tid] - cnt;
-    const int total = n_acc + s_scan[1023];
+    const int total = n_acc + (int)st_uniform((uint32_t)s_scan[1023]);
     for (int i = b0; i < b1; i++)
       if (state[i] == 1) {
         if (pos < limit) {
