@@ -197,7 +197,11 @@ int32_t vo_shi_tomasi(vo_ctx* ctx, const float* cur_pts, int32_t n_cur, int32_t 
 int32_t vo_shi_tomasi_resident(vo_ctx* ctx, int32_t n_cur, int32_t mask_radius,
                                const vo_st_params* prm);                      /* async; uses the resident points */
 int32_t vo_shi_tomasi_fetch(vo_ctx* ctx, float* out_pts, int32_t* n_out);     /* sync + copy out */
-/* parity probes: min-eigenvalue map (h x w f32) and the mask actually used (h x w u8) of the last call */
+/* parity probes: min-eigenvalue map (h x w f32) and the mask actually used (h x w u8) of the last SYNCHRONOUS call
+ * (vo_shi_tomasi).  The resident forms keep neither -- the map never leaves the kernel that forms it and the mask is handed
+ * back clean for the next frame -- and eig_out / mask_out then return VO_E_STATE (environment VO_ST_KEEP_EIG=1 makes the
+ * resident forms keep them); n_candidates (local maxima above the quality threshold) is always available.
+ * More than 16384 candidates are consumed in rank-ordered chunks, like OpenCV's scan; VO_E_CAPACITY only beyond 262144. */
 int32_t vo_shi_tomasi_read(vo_ctx* ctx, float* eig_out, uint8_t* mask_out, int32_t* n_candidates);
 
 /* ---- DLT triangulation ----------------------------------------------------------------------

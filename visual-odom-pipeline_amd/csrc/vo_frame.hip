@@ -13,6 +13,8 @@
 // All arithmetic here is integer and bit-exact against oracle/vo_oracle.c.
 #include "vo_internal.h"
 
+#include <stdlib.h>
+
 #include <new>
 
 // ------------------------------------------------------------------------------------------------
@@ -67,17 +69,19 @@ __global__ void __launch_bounds__(256) k_pad_level0_bilateral(const uint8_t* __r
 
 __global__ void __launch_bounds__(256) k_pad_level0(const uint8_t* __restrict__ raw, size_t raw_seq_stride,
                                                     const int32_t* __restrict__ frame_idx, int w, int h,
-                                                    uint8_t* __restrict__ dst, size_t dst_seq_stride, int pitch, int ph) {
+                                                    uint8_t* __restrict__ dst, size_t dst_seq_stride, int pitch, int ph, int remap) {
   // 4 consecutive padded columns per thread, one dword store (pitch and VO_PAD are multiples of 4); the threads of the grid
   // run over (row, dword) pairs in one flat index so that every workgroup is full (a row is 326 dwords at w = 1241: with a
   // row per block-row the second 256-thread block of every row was three quarters empty)
+  int blk, bseq;
+  vo_xcd_assign(blockIdx.z * gridDim.x + blockIdx.x, gridDim.x, remap, blk, bseq);
   const int dpr = (w + 2 * VO_PAD + 3) / 4;                          // dwords per padded row
-  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned gid = (unsigned)blk * blockDim.x + threadIdx.x;
   const int Y = (int)(gid / (unsigned)dpr);
   const int X = (int)(gid - (unsigned)Y * (unsigned)dpr) * 4;
   if (Y >= ph) return;
-  raw += (size_t)blockIdx.z * raw_seq_stride;
-  dst += (size_t)blockIdx.z * dst_seq_stride;
+  raw += (size_t)bseq * raw_seq_stride;
+  dst += (size_t)bseq * dst_seq_stride;
   if (frame_idx) raw += (size_t)(*frame_idx) * w * h;
   const int y = d_reflect101(Y - VO_PAD, h);
   const uint8_t* row = raw + (size_t)y * w;
@@ -100,14 +104,16 @@ __device__ __forceinline__ int d_byte(uint32_t v, int k) { return (int)((v >> (8
 
 __global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restrict__ src, size_t src_seq_px, int w, int h, int pitch,
                                                         int16_t* __restrict__ der, int nb_scharr,
-                                                        uint8_t* __restrict__ dst, size_t dst_seq_px, int dw, int dh, int dpitch) {
-  src += (size_t)blockIdx.y * src_seq_px;
-  if ((int)blockIdx.x < nb_scharr) {
+                                                        uint8_t* __restrict__ dst, size_t dst_seq_px, int dw, int dh, int dpitch, int remap) {
+  int bx, bseq;
+  vo_xcd_assign(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, remap, bx, bseq);
+  src += (size_t)bseq * src_seq_px;
+  if (bx < nb_scharr) {
     // ---- Scharr: Ix = [3 10 3]^T (x) [-1 0 1], Iy = [-1 0 1]^T (x) [3 10 3], un-normalised.
     //      4 pixels per thread: 3 aligned dwords per source row, one 16-byte store of 4 (Ix | Iy << 16) ----
     const int per_row = (w + 1023) / 1024;
-    const int y = blockIdx.x / per_row;
-    const int x0 = ((blockIdx.x - y * per_row) * 256 + threadIdx.x) * 4;
+    const int y = bx / per_row;
+    const int x0 = ((bx - y * per_row) * 256 + threadIdx.x) * 4;
     if (x0 >= w) return;
     const size_t o = (size_t)(y + VO_PAD) * pitch + (x0 + VO_PAD);       // multiple of 4
     int a[3][6];                                                          // columns x0 - 1 .. x0 + 4 of rows y - 1 .. y + 1
@@ -128,10 +134,10 @@ __global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restric
       out[k] = (x0 + k < w) ? (((uint32_t)(uint16_t)(int16_t)ix) | ((uint32_t)(uint16_t)(int16_t)iy << 16)) : 0u;
     }
     uint4 pk; pk.x = out[0]; pk.y = out[1]; pk.z = out[2]; pk.w = out[3];
-    *reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(der) + (size_t)blockIdx.y * src_seq_px + o) = pk;
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(der) + (size_t)bseq * src_seq_px + o) = pk;
   } else {
     // ---- pyrDown: 5x5 [1 4 6 4 1]^2, (sum + 128) >> 8, output padded domain, 4 outputs per thread ----
-    const int b = blockIdx.x - nb_scharr;
+    const int b = bx - nb_scharr;
     const int pw = dw + 2 * VO_PAD;
     const int per_row = (pw + 1023) / 1024;
     const int Y = b / per_row;
@@ -176,7 +182,7 @@ __global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restric
         res |= (uint32_t)((sum + 128) >> 8) << (8 * k);
       }
     }
-    *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.y * dst_seq_px + (size_t)Y * dpitch + X0) = res;
+    *reinterpret_cast<uint32_t*>(dst + (size_t)bseq * dst_seq_px + (size_t)Y * dpitch + X0) = res;
   }
 }
 
@@ -398,6 +404,8 @@ int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, size_t raw_seq_str
   c->cur ^= 1;
   vo_frame& F = c->fr[c->cur];
   const int B = c->batch;
+  static const int remap_env = getenv("VO_XCD_REMAP") ? atoi(getenv("VO_XCD_REMAP")) : 1;
+  const int remap = (remap_env && B % 8 == 0) ? 1 : 0;       // every sequence's frame chain on one XCD (vo_xcd_assign)
   {
     const vo_level& L = c->lv[0];
     dim3 grid(vo_div_up(((L.w + 2 * VO_PAD + 3) / 4) * L.ph, 256), 1, B);     // 4 columns per thread, flat (row, dword) index
@@ -410,7 +418,7 @@ int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, size_t raw_seq_str
                          L.h, F.img[0], c->lvl_px[0], L.pitch, L.ph, A, c->d_bil_cw);
     } else {
       hipLaunchKernelGGL(k_pad_level0, grid, dim3(256), 0, c->stream, d_raw_img, raw_seq_stride, d_frame_idx, L.w, L.h,
-                         F.img[0], c->lvl_px[0], L.pitch, L.ph);
+                         F.img[0], c->lvl_px[0], L.pitch, L.ph, remap);
     }
   }
   for (int l = 0; l <= c->top; l++) {
@@ -424,7 +432,7 @@ int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, size_t raw_seq_str
       nb_down = vo_div_up(D.w + 2 * VO_PAD, 1024) * D.ph;
     }
     hipLaunchKernelGGL(k_scharr_pyrdown, dim3(nb_scharr + nb_down, B), dim3(256), 0, c->stream,
-                       F.img[l], c->lvl_px[l], L.w, L.h, L.pitch, F.der[l], nb_scharr, dst, dpx, dw, dh, dpitch);
+                       F.img[l], c->lvl_px[l], L.w, L.h, L.pitch, F.der[l], nb_scharr, dst, dpx, dw, dh, dpitch, remap);
   }
   VO_HIP(c, hipGetLastError());
   c->n_pushed++;

@@ -136,6 +136,23 @@ template <class T> __device__ __forceinline__ T* vo_seq(T* base, size_t stride_b
   return reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(const_cast<typename std::remove_const<T>::type*>(base)) + (size_t)b * stride_bytes);
 }
 
+// XCD-aware (block, sequence) assignment for grids of `nblk` blocks per sequence x `batch` sequences, batch % 8 == 0:
+// workgroups are dealt to the 8 XCDs round-robin in dispatch order and every XCD has its own L2, so with the plain mapping the
+// neighbouring blocks of one image land on eight different L2s and each fetches the rows they share.  Remapped, XCD k works on
+// sequences k, k + 8, ... one after the other: a sequence's rows are fetched by ONE L2, and what one kernel of the frame chain
+// wrote there (plain stores keep the line) the next kernel finds there.  Placement is an observation, not a contract: the
+// mapping is a bijection of the grid, so results never depend on it.  id = linear block index in dispatch order.
+__device__ __forceinline__ void vo_xcd_assign(unsigned id, unsigned nblk, int remap, int& blk, int& bseq) {
+  if (remap) {
+    const unsigned q = id >> 3;
+    bseq = (int)(id & 7u) + 8 * (int)(q / nblk);
+    blk = (int)(q % nblk);
+  } else {
+    bseq = (int)(id / nblk);
+    blk = (int)(id - (unsigned)bseq * nblk);
+  }
+}
+
 // RAII bracket: records an event pair on the ctx stream around a region when profiling is on
 struct vo_prof_scope {
   vo_ctx* c; int region; hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -264,7 +264,7 @@ template <int R>
 __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict__ img, size_t img_seq_px, int pitch, int W, int H, int rb, float s2,
                                                       uint8_t* __restrict__ mask, float* __restrict__ eig, float* __restrict__ blockmax,
                                                       double quality, unsigned long long* __restrict__ cand, uint32_t* __restrict__ nraw,
-                                                      int restore_mask) {
+                                                      int restore_mask, int do_nms, int remap) {
   constexpr int D = 2 * R + 1, OUTC = 256 - 2 * R - 2;
   __shared__ uint4 s_p[2][256];
   __shared__ float2 s_c[2][256];                                      // (max of the column's three rows, running masked maximum)
@@ -277,7 +277,11 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
   const int t = threadIdx.x, lane = t & 63;
   if (t == 0) s_cnt = 0;
   s_c[0][t] = make_float2(0.f, 0.f); s_c[1][t] = make_float2(0.f, 0.f);    // the first row's (unconditional) neighbour reads
-  const int x0 = blockIdx.x * OUTC, y0 = blockIdx.y * rb, bseq = blockIdx.z;
+  // (band, sequence) assignment: a sequence's bands run on the XCD that built its pyramid (vo_xcd_assign); blocks of a band adjacent
+  int bxy, bseq;
+  vo_xcd_assign((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, remap, bxy, bseq);
+  const int bandy = bxy / (int)gridDim.x, bandx = bxy - bandy * (int)gridDim.x;
+  const int x0 = bandx * OUTC, y0 = bandy * rb;
   const int rows_out = min(rb, H - y0);
   const int total = rows_out + 2 + 2 * R;                             // product rows y0 - 1 - R .. y0 + rows_out + R
   const int xs = st_reflect101(x0 - 1 - R + t, W);                    // product column of this thread
@@ -372,8 +376,10 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
           uint4* buf = s_p[k & 1];
           buf[t] = make_uint4(P0, P1, P2, 0u);
           __syncthreads();
-          flush(false);
-          test_pending((k - 1) & 1);                                 // row ye - 2 against the maxima written one row ago
+          if (do_nms) {
+            flush(false);
+            test_pending((k - 1) & 1);                               // row ye - 2 against the maxima written one row ago
+          }
           const int ke = k - 2 * R, ye = y0 - 1 + ke;                // eigenvalue row of this iteration (-1 and H are halo rows of nothing)
           float e0;
           {
@@ -399,7 +405,7 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
           rmax = fmaxf(rmax, lmax);
           // publish: max of the column over rows ye - 2 .. ye, and the running maximum
           const float cm = fmaxf(e2, e0);
-          s_c[k & 1][t] = make_float2(fmaxf(cm, e1), rmax);
+          if (do_nms) s_c[k & 1][t] = make_float2(fmaxf(cm, e1), rmax);
           // the centre row ye - 1 becomes the pending test (decided next iteration, when the neighbours' maxima are visible)
           pv = e1; pcm = cm; py = ye - 1;
           pok = outt && (ke >= 2) && (ke - 1 <= rows_out) && mk1 && (py >= 1) && (py < H - 1) && (xe >= 1) && (xe < W - 1);
@@ -409,14 +415,16 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
     }
   }
   __syncthreads();
-  flush(false);
-  test_pending((total - 1) & 1);
-  __syncthreads();
-  flush(true);
+  if (do_nms) {
+    flush(false);
+    test_pending((total - 1) & 1);
+    __syncthreads();
+    flush(true);
+  }
   for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
   if ((t & 63) == 0) s_m[t >> 6] = lmax;
   __syncthreads();
-  if (t == 0) blockmax[(size_t)bseq * gridDim.x * gridDim.y + blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+  if (t == 0) blockmax[(size_t)bseq * gridDim.x * gridDim.y + bxy] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
 }
 
 #define ST_NMS_ROWS 8
@@ -977,10 +985,18 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
     if (s->force_rb > 0) rb = s->force_rb < H ? s->force_rb : H;
     const int gy = vo_div_up(H, rb);
     n_blockmax = gx * gy;
-    const bool restore = !keep && !d_user_mask;
+    // VO_ST_NMS_FUSED=0 (experiment knob): the eigenvalue map goes through HBM to the separate k_st_nms, as in round 1
+    static const bool nms_fused = !(getenv("VO_ST_NMS_FUSED") && atoi(getenv("VO_ST_NMS_FUSED")) == 0);
+    static const int remap_env = getenv("VO_XCD_REMAP") ? atoi(getenv("VO_XCD_REMAP")) : 1;
+    const int xcd_remap = (remap_env && B % 8 == 0) ? 1 : 0;
+    const bool restore = !keep && !d_user_mask && nms_fused;
     hipLaunchKernelGGL(k_st_eig_fused<15>, dim3(gx, gy, B), dim3(256), 0, c->stream, F.img[0], c->lvl_px[0], c->lv[0].pitch, W, H, rb, s2,
-                       s->d_mask, keep ? s->d_eig : nullptr, s->d_blockmax, prm->quality_level, s->d_cand, s->d_nraw, restore ? 1 : 0);
-    s->mask_clean = restore; s->eig_valid = keep;
+                       s->d_mask, (keep || !nms_fused) ? s->d_eig : nullptr, s->d_blockmax, prm->quality_level, s->d_cand, s->d_nraw,
+                       restore ? 1 : 0, nms_fused ? 1 : 0, xcd_remap);
+    if (!nms_fused)
+      hipLaunchKernelGGL(k_st_nms, dim3(vo_div_up(W - 2, 256), vo_div_up(H - 2, ST_NMS_ROWS), B), dim3(256), 0, c->stream, s->d_eig,
+                         s->d_mask, W, H, prm->quality_level, s->d_blockmax, n_blockmax, s->d_cand, s->d_scalars, c->slab_seq, s->d_nraw);
+    s->mask_clean = restore; s->eig_valid = keep || !nms_fused;
   } else {
     n_blockmax = vo_div_up(W, 256) * vo_div_up(H, ST_ROWS);
     hipLaunchKernelGGL(k_st_vsum_eig, dim3(vo_div_up(W, 256), vo_div_up(H, ST_ROWS), B), dim3(256), 0, c->stream, s->d_h,
