@@ -93,3 +93,30 @@ def test_two_steps_in_flight_match_one_at_a_time():
         assert got[k]["ba_stats"] == ref[k]["ba_stats"]
     for key in keys:
         assert np.array_equal(again[key], got[-1][key], equal_nan=True)
+
+
+def test_resident_shi_tomasi_keeps_no_map_and_hands_the_mask_back_clean(seq3):
+    """The resident path (fused frame step, track table) forms the eigenvalue map and the 3 x 3 suppression in ONE kernel: the map
+    is never stored and the exclusion mask is restored while it is read.  A synchronous call afterwards (which re-initialises
+    and keeps both) still equals the oracle, and so does the resident result before it."""
+    import vo_oracle as o
+    from vo_mi355x import VoContext, VoError, synthetic as syn
+    frames, _ = seq3
+    p0 = syn.grid_points(500, frames[0].shape[1], frames[0].shape[0], seed=3)
+    with VoContext(frames[0].shape[1], frames[0].shape[0], max_pts=1024) as c:
+        c.push_frame(frames[0]); c.push_frame(frames[1])
+        c.points_upload(p0)
+        for rep in range(2):                              # the second launch runs WITHOUT k_st_mask_init on the restored mask
+            c.shi_tomasi_resident(len(p0), 7)
+            got = c.shi_tomasi_fetch()
+            mask = np.full(frames[1].shape, 255, np.uint8)
+            for x, y in np.int32(p0):
+                o.circle_mask(mask, (x, y), 7, 0)
+            ref, _, nc = o.good_features(frames[1], mask, return_aux=True)
+            assert np.array_equal(got, ref), rep
+            with pytest.raises(VoError):
+                c.shi_tomasi_read()                       # neither map nor mask kept
+        got = c.shi_tomasi(p0, 7)
+        eig, m, n = c.shi_tomasi_read()
+        assert np.array_equal(got, ref) and np.array_equal(m, mask) and n == nc
+        assert np.array_equal(eig, o.min_eig(frames[1]))
