@@ -374,6 +374,9 @@ int32_t vo_frame_fetch(vo_ctx* ctx, int32_t n_pts, float* p, uint8_t* status, fl
                        double* depth1, double* reproj, double* poses, double* points, vo_ba_stats* stats,
                        float* corners, int32_t* n_corners);
 int32_t vo_set_graph_mode(vo_ctx* ctx, int32_t on);
+/* Re-detection + triangulation of vo_frame_step_resident on a side stream beside the bundle adjustment (default on; environment
+ * VO_SIDE_STREAM sets the default): +10-20 % for one context, +1-2 % with three.  Fetch the steps in flight first. */
+int32_t vo_set_side_stream(vo_ctx* ctx, int32_t on);
 
 /* ---- in-stream timing (hipEvent pairs recorded on the ctx stream around a region's launches) -----
  * Used by bench.py for the roofline figure: region VO_PROF_KLT brackets exactly the k_klt_track launch.

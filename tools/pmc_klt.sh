@@ -5,7 +5,7 @@ TAG=${1:-k}
 OUT=$PWD/gpurun_out
 export TMPDIR=/tmp
 BENCH="$PWD/bench.py"
-ARGS="--steps 4 --warmup 2 --regions 1 --no-extras --no-cpu-baseline --seqs 32 --ctxs 1 --host-threads 1"
+ARGS="--steps 4 --warmup 2 --regions 1 --no-extras --no-cpu-baseline --seqs 32 --ctxs 1 --host-threads 1 --side-stream off"
 cd /tmp
 i=0
 # at most 2 texture-addresser counters per pass (more: "Request exceeds the capabilities of the hardware" and the run hangs);

@@ -255,6 +255,21 @@ __device__ __forceinline__ double xor32_sum(double v) {
   return __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
 }
 
+// Reduce-scatter forms of the two swaps: x and y are summed over lane pairs at once, half of the lanes keep x's sum, the other
+// half y's -- 3 instructions for two values instead of 3 per value (the all-reduce forms above duplicate every sum).
+//   rs16(x, y): rows 0 and 2 of the wave receive x[row] + x[row + 1], rows 1 and 3 receive y[row - 1] + y[row]
+//   rs32(x, y): lanes 0..31 receive x[l] + x[l + 32], lanes 32..63 receive y[l - 32] + y[l]
+__device__ __forceinline__ double rs16_sum(double x, double y) {
+  const auto l2 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto h2 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
+}
+__device__ __forceinline__ double rs32_sum(double x, double y) {
+  const auto l2 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto h2 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
+}
+
 // sum over the LPP (16 or 32) lanes of a landmark group; every lane of the group gets the total
 __device__ __forceinline__ double group_allreduce(double v, int lpp) {
   v += dpp_f64<0x128>(v);   // row_ror:8
@@ -466,33 +481,30 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   }
   VO_STAMP(dbgb, 2);   // group sums + 3x3 factor
   // ---- camera sums: across the landmarks of the wave by shuffles, across waves through LDS ----
-  // (each value is formed, reduced and stored before the next one to keep the register footprint small)
+  // The 28 values of a slot (21 of the upper H_pp, 6 of g_p, the cost) go four at a time through a REDUCE-SCATTER over the wave's
+  // landmarks: after the two swap stages row r of the wave holds the total of value 4 g + r, so every lane stores one value per
+  // group (7 stores) -- 63 instead of 168 cross-lane instructions per wave, the same additions in the same order as the
+  // all-reduce it replaces (bit-identical sums).  Four values are live at a time.
   {
+    constexpr int QA[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+    constexpr int QC[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+    auto term = [&](int q) -> double {
+      if (q < 21) return o.w * (o.Jp[0][QA[q]] * o.Jp[0][QC[q]] + o.Jp[1][QA[q]] * o.Jp[1][QC[q]]);
+      if (q < 27) return o.w * (o.Jp[0][q - 21] * o.e0 + o.Jp[1][q - 21] * o.e1);
+      return 0.5 * o.rho;
+    };
     double* dst = dyn + (size_t)(wave * LPP + (lane & (LPP - 1))) * BA_POSE_VALS;
-    const bool writer = lane < LPP;
-    int q = 0;
 #pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-      for (int c = a; c < 6; c++) {
-        double s = o.w * (o.Jp[0][a] * o.Jp[0][c] + o.Jp[1][a] * o.Jp[1][c]);
-        if (LPP == 16) s = xor16_sum(s);
-        s = xor32_sum(s);
-        if (writer) dst[q] = s;
-        q++;
+    for (int g = 0; g < BA_POSE_VALS / 4; g++) {
+      const double v0 = term(4 * g), v1 = term(4 * g + 1), v2 = term(4 * g + 2), v3 = term(4 * g + 3);
+      if (LPP == 16) {
+        const double u = rs32_sum(rs16_sum(v0, v1), rs16_sum(v2, v3));      // row r: total of v_r over the wave's four landmarks
+        dst[4 * g + (lane >> 4)] = u;
+      } else {
+        const double u01 = rs32_sum(v0, v1), u23 = rs32_sum(v2, v3);       // lanes 0..31: v0 / v2, lanes 32..63: v1 / v3
+        dst[4 * g + (lane >> 5)] = u01;
+        dst[4 * g + 2 + (lane >> 5)] = u23;
       }
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-      double s = o.w * (o.Jp[0][a] * o.e0 + o.Jp[1][a] * o.e1);
-      if (LPP == 16) s = xor16_sum(s);
-      s = xor32_sum(s);
-      if (writer) dst[21 + a] = s;
-    }
-    {
-      double s = 0.5 * o.rho;
-      if (LPP == 16) s = xor16_sum(s);
-      s = xor32_sum(s);
-      if (writer) dst[27] = s;
     }
   }
   __syncthreads();

@@ -195,6 +195,13 @@ extern "C" int32_t vo_frame_fetch(vo_ctx* c, int32_t n_pts, float* p, uint8_t* s
   return rc;
 }
 
+extern "C" int32_t vo_set_side_stream(vo_ctx* c, int32_t on) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->steps_enq == c->steps_fetched, VO_E_STATE, "fetch the steps in flight before switching the stream layout");
+  c->side_stream = on ? 1 : 0;
+  return VO_OK;
+}
+
 extern "C" int32_t vo_set_graph_mode(vo_ctx* c, int32_t on) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->steps_enq == c->steps_fetched, VO_E_STATE, "fetch the steps in flight before switching the launch mode");

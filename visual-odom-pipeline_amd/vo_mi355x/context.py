@@ -267,6 +267,10 @@ class VoContext:
     def set_graph_mode(self, on=True):
         self._ck(self._L.vo_set_graph_mode(self._h, 1 if on else 0))
 
+    def set_side_stream(self, on=True):
+        """re-detection + triangulation of the fused step on a side stream beside the bundle adjustment (default) or in line"""
+        self._ck(self._L.vo_set_side_stream(self._h, 1 if on else 0))
+
     def frame_step_resident(self, frame_idx, n_pts, do_dlt=True, do_ba=True, do_st=True, mask_radius=7,
                             klt=None, st=None, ba=None):
         """enqueue one whole frame (pyramid, KLT, DLT, BA, re-detection, result copies); async"""
