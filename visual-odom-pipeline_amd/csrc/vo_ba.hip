@@ -700,7 +700,8 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
   // (row | col << 8) of the lower-triangle elements ordered by column DESCENDING (rows ascending inside a column):
   // the trailing submatrix of every block column is then a prefix of the table, and consecutive threads get
   // consecutive rows of one column (conflict-free LDS) without any index arithmetic in the factorisation loop
-  unsigned short* s_tab = reinterpret_cast<unsigned short*>(s_dp + n1 + 24);
+  double* s_linv = s_dp + n1 + 24;             // W x 21: inverse of every diagonal block of the factor (lower triangle, row-major packed)
+  unsigned short* s_tab = reinterpret_cast<unsigned short*>(s_linv + 21 * W);
   for (int e = tid; e < (n1 * (n1 + 1)) / 2; e += BA_SOLVE_THREADS) {
     int k = (int)((sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);     // column n - k holds k + 1 elements
     while (k > 0 && (k * (k + 1)) / 2 > e) k--;
@@ -747,8 +748,13 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
   if (hpp_out) for (int q = tid; q < W * BA_POSE_VALS; q += BA_SOLVE_THREADS) hpp_out[q] = s_hpp[q];
   if (probe_S) __syncthreads();   // the factorisation below overwrites A in place
   VO_STAMP(dbgs, 2);   // system assembled
-  // ---- 6x6-blocked right-looking Cholesky of the augmented matrix (row n carries rhs -> y) ----
-  for (int kb = 0; kb < W; kb++) {
+  // ---- 6x6-blocked right-looking Cholesky of the augmented matrix (row n carries rhs -> y), with LOOKAHEAD: the rank-6 update of
+  //      block column kb is applied to the columns of block kb + 1 first (one short pass of all threads); then wave 0 factorises
+  //      panel kb + 1 -- a chain of dependent float64 operations, the critical path of the kernel -- WHILE the other 15 waves
+  //      apply the update to the rest of the trailing matrix.  Same operations on every element in the same order as the plain
+  //      loop (panel, barrier, whole trailing update, barrier), so the factor is bit-identical; the chain and the bulk update
+  //      now overlap instead of alternating (2.4 k -> 1.4 k cycles per block column). ----
+  auto panel = [&](const int kb) {
     const int c0 = 6 * kb;
     const int r = c0 + tid;
     if (r < n1) {
@@ -791,9 +797,11 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
       for (int c = 0; c < 6; c++)
         if (r >= c0 + c) A[(size_t)(c0 + c) * PT + r] = x[c];
     }
-    __syncthreads();
-    const int s0 = c0 + 6, m = n1 - s0;
-    for (int idx = tid + 1; idx < (m * (m + 1)) / 2; idx += BA_SOLVE_THREADS) {   // entry 0 is (n, n): not needed
+  };
+  // rank-6 update by block column kb of the table entries [lo, hi), shared out over the threads t0, t0 + 1, ... (nt of them)
+  auto trail = [&](const int kb, const int lo, const int hi, const int t0, const int nt) {
+    const int c0 = 6 * kb;
+    for (int idx = lo + (tid - t0); idx < hi; idx += nt) {
       const int ij = s_tab[idx];
       const int i = ij & 255, jcol = ij >> 8;
       double acc = A[(size_t)jcol * PT + i];
@@ -801,8 +809,57 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
       for (int c = 0; c < 6; c++) acc -= A[(size_t)(c0 + c) * PT + i] * A[(size_t)(c0 + c) * PT + jcol];
       A[(size_t)jcol * PT + i] = acc;
     }
+  };
+  // inverse of the factored diagonal block L_kk (lower triangular) for the back substitution, where the 6 x 6 triangular solve is
+  // otherwise a chain of 27 dependent float64 operations per block column; with the inverse it is six independent dot products.
+  // Formed off the critical path: by the LAST wave while wave 0 factorises the next panel.
+  auto linv = [&](const int kb) {
+    const int c0 = 6 * kb;
+    double Lk[6][6], iv[6], Li[6][6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      iv[c] = s_invd[c0 + c];
+#pragma unroll
+      for (int e = c + 1; e < 6; e++) Lk[e][c] = A[(size_t)(c0 + c) * PT + c0 + e];
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      Li[c][c] = iv[c];
+#pragma unroll
+      for (int e = c + 1; e < 6; e++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = c; k < e; k++) acc += Lk[e][k] * Li[k][c];
+        Li[e][c] = -iv[e] * acc;
+      }
+    }
+    if (tid == BA_SOLVE_THREADS - 64) {
+      int q = 0;
+#pragma unroll
+      for (int e = 0; e < 6; e++)
+#pragma unroll
+        for (int c = 0; c <= e; c++) s_linv[21 * kb + q++] = Li[e][c];
+    }
+  };
+  panel(0);
+  __syncthreads();
+  for (int kb = 0; kb + 1 < W; kb++) {
+    // the table lists the lower triangle by column DESCENDING: entries [0, rest) are the columns behind block kb + 1,
+    // [rest, full) the columns of block kb + 1 (entry 0 is (n, n): not needed)
+    const int m = n1 - (6 * kb + 6), mp = m - 6;
+    const int full = (m * (m + 1)) / 2, rest = (mp * (mp + 1)) / 2;
+    trail(kb, rest, full, 0, BA_SOLVE_THREADS);
+    __syncthreads();
+    const int pw = (m + 63) & ~63;                 // the panel of block kb + 1 has m rows: whole waves (one, two above W = 10)
+    if (tid < pw) panel(kb + 1);
+    else {
+      if (tid >= BA_SOLVE_THREADS - 64) linv(kb);
+      trail(kb, 1, rest, pw, BA_SOLVE_THREADS - pw);
+    }
     __syncthreads();
   }
+  if (tid >= BA_SOLVE_THREADS - 64) linv(W - 1);
+  __syncthreads();
   VO_STAMP(dbgs, 3);   // factorised
   // ---- back substitution  L^T dp = y  by wave 0, 6x6 block at a time (lane i holds rows i and i + 64):
   //      every lane solves the 6x6 triangular block redundantly in registers (operands are wave-uniform LDS
@@ -813,14 +870,18 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
     double y1 = (lane + 64 < n) ? A[(size_t)(lane + 64) * PT + n] : 0.0;
     for (int kb = W - 1; kb >= 0; kb--) {
       const int c0 = 6 * kb;
-      // every LDS operand of this block first (none depends on the running y): the diagonal block's 15 sub-diagonal
-      // entries + 6 inverse pivots (wave-uniform addresses) and this lane's 2 x 6 column entries
-      double Lk[6][6], iv[6], ca[6], cb[6];
+      // every LDS operand of this block first (none depends on the running y): the inverse of the diagonal block (21 entries,
+      // wave-uniform addresses) and this lane's 2 x 6 column entries
+      double Li[6][6], ca[6], cb[6];
+      {
+        int q = 0;
+#pragma unroll
+        for (int e = 0; e < 6; e++)
+#pragma unroll
+          for (int c = 0; c <= e; c++) Li[e][c] = s_linv[21 * kb + q++];
+      }
 #pragma unroll
       for (int c = 0; c < 6; c++) {
-        iv[c] = s_invd[c0 + c];
-#pragma unroll
-        for (int e = c + 1; e < 6; e++) Lk[e][c] = A[(size_t)(c0 + c) * PT + c0 + e];
         ca[c] = (lane < c0) ? A[(size_t)lane * PT + c0 + c] : 0.0;
         cb[c] = (lane + 64 < c0) ? A[(size_t)(lane + 64) * PT + c0 + c] : 0.0;
       }
@@ -830,13 +891,13 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
         const int k = c0 + c;
         yb[c] = (k < 64) ? readlane_f64(y0, k & 63) : readlane_f64(y1, k & 63);
       }
-      // solve L_kk^T d = yb
+      // d = L_kk^-T yb: six independent dot products
 #pragma unroll
-      for (int c = 5; c >= 0; c--) {
-        double t = yb[c];
+      for (int c = 0; c < 6; c++) {
+        double t = Li[c][c] * yb[c];
 #pragma unroll
-        for (int e = 5; e > c; e--) t -= Lk[e][c] * d[e];
-        d[c] = t * iv[c];
+        for (int e = c + 1; e < 6; e++) t += Li[e][c] * yb[e];
+        d[c] = t;
       }
       // rows above the block: y_i -= sum_c L[c0 + c][i] d_c
 #pragma unroll
@@ -1094,7 +1155,7 @@ static void ba_geometry(vo_ba_ws* b, int W, int N) {
   b->cam_off = (int)(b->build_lds / sizeof(double));
   b->build_lds += sizeof(double) * (size_t)BA_CAM * W;
   const int n1 = 6 * W + 1, PT = n1 | 1;
-  b->solve_lds = sizeof(double) * ((size_t)n1 * PT + (size_t)W * BA_POSE_VALS + n1 + n1 + 24) + sizeof(unsigned short) * ((size_t)n1 * (n1 + 1) / 2 + 8);
+  b->solve_lds = sizeof(double) * ((size_t)n1 * PT + (size_t)W * BA_POSE_VALS + n1 + n1 + 24 + (size_t)21 * W) + sizeof(unsigned short) * ((size_t)n1 * (n1 + 1) / 2 + 8);
 }
 
 // every buffer: [batch] x per-problem size
