@@ -32,6 +32,28 @@
 #define I_MULLO(k) "v_mul_lo_u32 %" #k ", %8, %" #k
 #define I_CVT(k) "v_cvt_f32_i32 %" #k ", %" #k
 #define I_RNDNE(k) "v_rndne_f32 %" #k ", %" #k
+#define I_LSHLOR(k) "v_lshl_or_b32 %" #k ", %8, 16, %" #k
+#define I_ANDOR(k) "v_and_or_b32 %" #k ", %8, %9, %" #k
+#define I_OR(k) "v_or_b32 %" #k ", %8, %" #k
+#define I_LSHR(k) "v_lshrrev_b32 %" #k ", 9, %" #k
+#define I_BFE(k) "v_bfe_u32 %" #k ", %8, 8, 8"
+#define I_BFI(k) "v_bfi_b32 %" #k ", %8, %9, %" #k
+#define I_ALIGNBIT(k) "v_alignbit_b32 %" #k ", %8, %9, 8"
+#define I_ALIGNBYTE(k) "v_alignbyte_b32 %" #k ", %8, %9, 1"
+#define I_SUB(k) "v_sub_u32 %" #k ", %8, %" #k
+#define I_MAXI(k) "v_max_i32 %" #k ", %8, %" #k
+#define I_MULF(k) "v_mul_f32 %" #k ", %8, %" #k
+#define I_ADDF(k) "v_add_f32 %" #k ", %8, %" #k
+#define I_CVTUB(k) "v_cvt_f32_ubyte1 %" #k ", %8"
+#define I_PACKF16(k) "v_pack_b32_f16 %" #k ", %8, %" #k
+#define I_MULU24(k) "v_mul_u32_u24 %" #k ", %8, %" #k
+#define I_ADD3(k) "v_add3_u32 %" #k ", %8, %9, %" #k
+#define I_LSHLADD(k) "v_lshl_add_u32 %" #k ", %8, 7, %" #k
+#define I_ADDSDWA(k) "v_add_u32_sdwa %" #k ", %8, %" #k " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"
+#define I_XOR(k) "v_xor_b32 %" #k ", %8, %" #k
+#define I_MOV(k) "v_mov_b32 %" #k ", %8"
+#define I_FLOOR(k) "v_floor_f32 %" #k ", %" #k
+#define I_MAD_U16(k) "v_mad_u16 %" #k ", %8, %9, %" #k
 #define I_FMA64(k) "v_fma_f64 %" #k ", %8, %9, %" #k
 #define I_MUL64(k) "v_mul_f64 %" #k ", %8, %" #k
 #define I_ADD64(k) "v_add_f64 %" #k ", %8, %" #k
@@ -61,6 +83,28 @@ __global__ void probe(unsigned long long* out, int iters, unsigned seed) {
       if (OP == 12) SAME(I_MULLO)
       if (OP == 13) SAME(I_CVT)
       if (OP == 14) SAME(I_RNDNE)
+      if (OP == 30) SAME(I_LSHLOR)
+      if (OP == 31) SAME(I_ANDOR)
+      if (OP == 32) SAME(I_OR)
+      if (OP == 33) SAME(I_LSHR)
+      if (OP == 34) SAME(I_BFE)
+      if (OP == 35) SAME(I_BFI)
+      if (OP == 36) SAME(I_ALIGNBIT)
+      if (OP == 37) SAME(I_ALIGNBYTE)
+      if (OP == 38) SAME(I_SUB)
+      if (OP == 39) SAME(I_MAXI)
+      if (OP == 40) SAME(I_MULF)
+      if (OP == 41) SAME(I_ADDF)
+      if (OP == 42) SAME(I_CVTUB)
+      if (OP == 43) SAME(I_PACKF16)
+      if (OP == 44) SAME(I_MULU24)
+      if (OP == 45) SAME(I_ADD3)
+      if (OP == 46) SAME(I_LSHLADD)
+      if (OP == 47) SAME(I_ADDSDWA)
+      if (OP == 48) SAME(I_XOR)
+      if (OP == 49) SAME(I_MOV)
+      if (OP == 50) SAME(I_FLOOR)
+      if (OP == 51) SAME(I_MAD_U16)
       // the inner loop of k_klt_track per pixel pair: 3 byte gathers / packs, 6 dot products, 2 shifts, 1 packed subtract
       if (OP == 20) BODY(I_PERM(0), I_DOT2C(1), I_DOT2C(2), I_ASHR(1), I_PERM(3), I_DOT2C(4), I_DOT2C(5), I_ASHR(4))
       if (OP == 21) BODY(I_PERM(0), I_DOT2C(1), I_DOT2C(2), I_PKSUB(3), I_PERM(4), I_DOT2C(5), I_DOT2C(6), I_ASHR(7))
@@ -91,7 +135,7 @@ template <int OP>
 static void run(const char* name, unsigned long long* d) {
   const int iters = 4000, per_iter = 64;
   printf("%-22s", name);
-  for (int w : {1, 2, 3, 4, 5, 8}) {
+  for (int w : {1, 2, 4, 8}) {
     const int wg = (w == 8) ? 2 : 1, threads = 64 * 4 * w / wg;     // w waves on each SIMD of every CU
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -137,6 +181,11 @@ int main() {
   run<12>("v_mul_lo_u32", d);
   run<13>("v_cvt_f32_i32", d);
   run<14>("v_rndne_f32", d);
+  run<30>("v_lshl_or_b32", d); run<31>("v_and_or_b32", d); run<32>("v_or_b32", d); run<33>("v_lshrrev_b32", d); run<34>("v_bfe_u32", d);
+  run<35>("v_bfi_b32", d); run<36>("v_alignbit_b32", d); run<37>("v_alignbyte_b32", d); run<38>("v_sub_u32", d); run<39>("v_max_i32", d);
+  run<40>("v_mul_f32", d); run<41>("v_add_f32", d); run<42>("v_cvt_f32_ubyte1", d); run<43>("v_pack_b32_f16", d); run<44>("v_mul_u32_u24", d);
+  run<45>("v_add3_u32", d); run<46>("v_lshl_add_u32", d); run<47>("v_add_u32 sdwa byte", d); run<48>("v_xor_b32", d); run<49>("v_mov_b32", d);
+  run<50>("v_floor_f32", d); run<51>("v_mad_u16", d);
   run<20>("klt mix A (sample2)", d);
   run<21>("klt mix B (+pk_sub)", d);
   run<22>("add/dot2c alternating", d);
