@@ -258,6 +258,23 @@ class Group:
         return st[0] if isinstance(st, list) else st
 
 
+def usable_cores():
+    """host cores this process may actually use: os.cpu_count() capped by the cgroup CPU quota (the GPU box shows 256 cores and
+    grants 16: 64 workers there were slower in total than 16)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:           # noqa: BLE001
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:           # noqa: BLE001
+        pass
+    return n
+
+
 def cpu_baseline_parallel(n_procs, n_frames, ba_iters):
     """cpu_baseline on `n_procs` host cores: independent sequences, one single-threaded worker PROCESS per core (this
     file re-run with --cpu-worker), started before this process touches the GPU.  -> (frames/s, seconds, cores)"""
@@ -508,14 +525,14 @@ def main():
     cpu = None
     if dist.rank == 0 and dist.world == 1 and not a.no_cpu_baseline and a.workload == "A" and a.cpu_worker < 0:
         # before anything initialises the GPU in this process (child processes are started here)
-        n_procs = max(1, min(a.cpu_procs, os.cpu_count() or 1))
+        n_procs = max(1, min(a.cpu_procs, usable_cores()))
         v, secs, cores, extra = cpu_baseline_parallel(n_procs, a.cpu_frames, a.ba_iters)
-        cpu = {"value": round(v, 3), "unit": "frames/s", "cores": cores, "cores_available": os.cpu_count() or 0, "kind": "port",
+        cpu = {"value": round(v, 3), "unit": "frames/s", "cores": cores, "cores_available": usable_cores(), "cores_visible": os.cpu_count() or 0, "kind": "port",
                "per_core": round(v / max(cores, 1), 3),
                "reference_recipe_ba": extra.get("reference_recipe_ba"), "opencv": extra.get("opencv"),
                "sample": "%d worker processes (1 core each, independent sequences) x %d frames of the same workload on the CPU "
-                         "oracle (C: pyramid+KLT+Shi-Tomasi+DLT, numpy: BA), %.1f s wall; %.2f frames/s per core; host has %d cores"
-                         % (cores, a.cpu_frames, secs, v / max(cores, 1), os.cpu_count() or 0)}
+                         "oracle (C: pyramid+KLT+Shi-Tomasi+DLT, numpy: BA), %.1f s wall; %.2f frames/s per core; host shows %d cores, "
+                         "its cgroup grants %d" % (cores, a.cpu_frames, secs, v / max(cores, 1), os.cpu_count() or 0, usable_cores())}
     from vo_mi355x import VoContext, synthetic as syn
     t_gen = time.perf_counter()
     c5 = a.workload == "config5"

@@ -1046,8 +1046,16 @@ __global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs Pall, ba_params_dev p
       e3 = X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
     }
   }
-  e0 = wave_allreduce(e0); e1 = wave_allreduce(e1); e2 = wave_allreduce(e2); e3 = wave_allreduce(e3);
-  if (lane == 0) { s_red[wave * 4] = e0; s_red[wave * 4 + 1] = e1; s_red[wave * 4 + 2] = e2; s_red[wave * 4 + 3] = e3; }
+  // four wave-wide sums as a reduce-scatter (21 cross-lane instructions instead of 4 x 18): after the two swap stages the 16-lane
+  // row r of the wave holds, per lane, the column sums of value {e0, e2, e1, e3}[r]; one row all-reduce finishes all four at once
+  {
+    double u = rs16_sum(rs32_sum(e0, e1), rs32_sum(e2, e3));
+    u += dpp_f64<0x128>(u); u += dpp_f64<0x124>(u); u += dpp_f64<0x122>(u); u += dpp_f64<0x121>(u);   // row_ror 8, 4, 2, 1
+    if ((lane & 15) == 0) {
+      const int r = lane >> 4;
+      s_red[wave * 4 + ((r & 1) ? (r == 1 ? 2 : 3) : (r == 0 ? 0 : 1))] = u;
+    }
+  }
   __syncthreads();
   if (tid < BA_EVAL_VALS) {
     double s = 0;
