@@ -147,6 +147,32 @@ def test_shi_tomasi_bit_exact(ctx_big, seq3):
     assert (rmask[c1[:, 1].astype(int), c1[:, 0].astype(int)] == 255).all()
 
 
+def test_shi_tomasi_vs_opencv_float_order(ctx_big, seq3):
+    """the bridge to OpenCV's own arithmetic (ST-1 / ST-2): cv2's boxFilter keeps float running sums, the HIP path and the oracle's
+    default keep exact int32 sums (oracle/vo_oracle.c header).  Against the oracle in OpenCV's float order (exact_int=False):
+    eigenvalue map <= 1e-5 of its maximum, corner sets equal up to near-ties (<= 2 % symmetric difference), with and without discs."""
+    import vo_oracle as o
+    from vo_mi355x import synthetic as syn
+    frames, _ = seq3
+    h, w = frames.shape[1:]
+    cur = frames[1]
+    got = ctx_big.shi_tomasi(None)
+    eig, _, _ = ctx_big.shi_tomasi_read()
+    feig = o.min_eig(cur, exact_int=False)
+    assert np.abs(eig - feig).max() <= 1e-5 * feig.max()
+    want = o.good_features(cur, None, exact_int=False)
+    diff = set(map(tuple, got.tolist())) ^ set(map(tuple, want.tolist()))
+    assert len(diff) <= 0.02 * len(want), (len(diff), len(want))
+    pts = syn.grid_points(2000, w, h, margin=0, seed=9) + np.float32(0.37)
+    rmask = np.full((h, w), 255, np.uint8)
+    for x, y in np.int32(pts):
+        o.circle_mask(rmask, (x, y), 7, 0)
+    got = ctx_big.shi_tomasi(pts, mask_radius=7)
+    want = o.good_features(cur, rmask, exact_int=False)
+    diff = set(map(tuple, got.tolist())) ^ set(map(tuple, want.tolist()))
+    assert len(diff) <= 0.02 * max(len(want), 1), (len(diff), len(want))
+
+
 @pytest.mark.parametrize("maxc,q,md,bs,radius", [(200, 0.05, 12.0, 15, 5), (1000, 0.01, 3.0, 7, 0), (50, 0.2, 0.5, 3, 10), (4000, 0.001, 5.0, 31, 7)])
 def test_shi_tomasi_parameter_sweep(seq_small, maxc, q, md, bs, radius):
     import vo_oracle as o

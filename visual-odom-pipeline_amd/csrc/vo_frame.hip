@@ -8,7 +8,7 @@
 //   img[l] : uint8, (h_l + 64) rows x pitch_l, interior origin at (32, 32), border = the
 //            BORDER_REFLECT_101 extension of the interior (what buildOpticalFlowPyramid pads with),
 //            so the tracker reads windows with plain unaligned dword loads and no index math.
-//   der[l] : int16 x 2 interleaved (Ix, Iy) Scharr, same pixel pitch, border = 0 (BORDER_CONSTANT).
+//   der[l] : int16 x 2 interleaved (4 Ix, 4 Iy) -- Scharr times 4, see k_scharr_pyrdown --, same pixel pitch, border = 0 (BORDER_CONSTANT).
 // pitch_l is a multiple of 64 pixels so rows start on 64 B (img) / 256 B (der) boundaries.
 // All arithmetic here is integer and bit-exact against oracle/vo_oracle.c.
 #include "vo_internal.h"
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restric
   src += (size_t)bseq * src_seq_px;
   if (bx < nb_scharr) {
     // ---- Scharr: Ix = [3 10 3]^T (x) [-1 0 1], Iy = [-1 0 1]^T (x) [3 10 3], un-normalised.
-    //      4 pixels per thread: 3 aligned dwords per source row, one 16-byte store of 4 (Ix | Iy << 16) ----
+    //      4 pixels per thread: 3 aligned dwords per source row, one 16-byte store of 4 (4 Ix | 4 Iy << 16) ----
     const int per_row = (w + 1023) / 1024;
     const int y = bx / per_row;
     const int x0 = ((bx - y * per_row) * 256 + threadIdx.x) * 4;
@@ -128,8 +128,10 @@ __global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restric
     uint32_t out[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int ix = (a[0][k + 2] + a[2][k + 2] - a[0][k] - a[2][k]) * 3 + (a[1][k + 2] - a[1][k]) * 10;
-      const int iy = (a[2][k] + a[2][k + 2] - a[0][k] - a[0][k + 2]) * 3 + (a[2][k + 1] - a[0][k + 1]) * 10;
+      // stored times 4 (|4 Scharr| <= 16 320 fits int16): k_klt_track's interpolation sum then carries its result in the upper
+      // 16 bits (vo_klt.hip deriv1); vo_pyramid_read hands out the plain values
+      const int ix = (a[0][k + 2] + a[2][k + 2] - a[0][k] - a[2][k]) * 12 + (a[1][k + 2] - a[1][k]) * 40;
+      const int iy = (a[2][k] + a[2][k + 2] - a[0][k] - a[0][k + 2]) * 12 + (a[2][k + 1] - a[0][k + 1]) * 40;
       // columns >= w belong to the zero (BORDER_CONSTANT) frame of the derivative image
       out[k] = (x0 + k < w) ? (((uint32_t)(uint16_t)(int16_t)ix) | ((uint32_t)(uint16_t)(int16_t)iy << 16)) : 0u;
     }
@@ -500,6 +502,8 @@ extern "C" int32_t vo_pyramid_read_seq(vo_ctx* c, int32_t seq, int32_t which, in
   if (deriv_out)
     VO_HIP(c, hipMemcpy2D(deriv_out, (size_t)L.w * 4, F.der[level] + ((size_t)seq * c->lvl_px[level] + (size_t)VO_PAD * L.pitch + VO_PAD) * 2,
                           (size_t)L.pitch * 4, (size_t)L.w * 4, L.h, hipMemcpyDeviceToHost));
+  if (deriv_out)
+    for (size_t i = 0, n = (size_t)L.w * L.h * 2; i < n; i++) deriv_out[i] = (int16_t)(deriv_out[i] / 4);   // device keeps 4 x Scharr (exact)
   return VO_OK;
 }
 

@@ -28,7 +28,7 @@
 
 struct klt_level_args {
   const uint8_t* imgI;    // sequence 0; sequence b at + b * seq_px pixels
-  const uint32_t* derI;   // (Ix | Iy << 16) per pixel
+  const uint32_t* derI;   // (4 Ix | 4 Iy << 16) per pixel
   const uint8_t* imgJ;
   size_t seq_px;
   int w, h, pitch;
@@ -45,10 +45,14 @@ struct klt_args {
   double eps2;
 };
 
-__device__ __forceinline__ uint32_t ld_u32_any(const uint8_t* p) {
-  uint32_t v;
-  __builtin_memcpy(&v, p, 4);
-  return v;
+// Window loads go through buffer instructions: address = descriptor base (the level's image: scalar registers) + ONE per-lane
+// offset that is fixed for the level (vector register) + the wave-uniform window origin advanced per row (scalar register).
+// With global_load the compiler kept the row advance in vector registers: one v_add per image load and a 64-bit
+// v_lshl_add_u64 more per derivative load -- 8 / 24 vector instructions per LK iteration / template in a kernel that is bound
+// by vector-instruction issue (tools/vmem_probe.hip).  Unaligned dwords are fine (same rules as global_load).
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t klt_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);   // raw, 4 GB range, no swizzle
 }
 
 // every lane receives the value of the lane 16 further up (the same column pair of the next row group; lanes 48..63 wrap
@@ -153,11 +157,15 @@ __device__ __forceinline__ float klt_combine(int hi, int lo) {
 // integer subtract at full rate instead of v_rndne_f32 + v_cvt_i32_f32 at quarter rate)
 __device__ __forceinline__ int klt_round(float x) { return __float_as_int(x + 12582912.f) - 0x4B400000; }
 
-__device__ __forceinline__ void lk_weights(float a, float b, int& iw00, int& iw01, int& iw10, int& iw11) {
-  iw00 = klt_round((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
-  iw01 = klt_round(a * (1.f - b) * (float)(1 << W_BITS));
-  iw10 = klt_round((1.f - a) * b * (float)(1 << W_BITS));
-  iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+// the four bilinear weights as packed 16-bit pairs wt = iw00 | iw01 << 16, wb = iw10 | iw11 << 16.  The rounded values sit in
+// the low 16 bits of the magic-number sums (weights <= 2^14), so the byte gathers take them from there directly
+__device__ __forceinline__ void lk_weights(float a, float b, uint32_t& wt, uint32_t& wb) {
+  const uint32_t r00 = (uint32_t)__float_as_int((1.f - a) * (1.f - b) * (float)(1 << W_BITS) + 12582912.f);
+  const uint32_t r01 = (uint32_t)__float_as_int(a * (1.f - b) * (float)(1 << W_BITS) + 12582912.f);
+  const uint32_t r10 = (uint32_t)__float_as_int((1.f - a) * b * (float)(1 << W_BITS) + 12582912.f);
+  const uint32_t iw11 = (uint32_t)(1 << W_BITS) + 3u * 0x4B400000u - (r00 + r01 + r10);
+  wt = __builtin_amdgcn_perm(r01, r00, 0x05040100u);
+  wb = __builtin_amdgcn_perm(iw11, r10, 0x05040100u);
 }
 
 __device__ __forceinline__ float uniform_f(float v) {
@@ -194,17 +202,24 @@ __device__ __forceinline__ uint32_t pk_abs(uint32_t a) {
 // bilinear samples (5 fractional bits) of the two pixels a lane owns in one step, packed (v0 | v1 << 16).
 // T/B: top / bottom row dwords (3 useful bytes each); wt = iw00 | iw01 << 16, wb = iw10 | iw11 << 16.
 __device__ __forceinline__ uint32_t sample2(uint32_t T, uint32_t B, uint32_t wt, uint32_t wb) {
-  const int v0 = dot2(bytes01(B), wb, dot2k(bytes01(T), wt, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-  const int v1 = dot2(bytes12(B), wb, dot2k(bytes12(T), wt, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-  return pack_lo((uint32_t)v0, (uint32_t)v1);
+  const int s0 = dot2(bytes01(B), wb, dot2k(bytes01(T), wt, 1 << (W_BITS - 5 - 1)));
+  const int s1 = dot2(bytes12(B), wb, dot2k(bytes12(T), wt, 1 << (W_BITS - 5 - 1)));
+  // (s >> 9) of both sums packed: bytes 1..2 of each sum are s >> 8 (0 <= s < 2^24), one packed 16-bit shift finishes --
+  // two instructions instead of two shifts and a pack
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const u16x2 h = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm((uint32_t)s1, (uint32_t)s0, 0x06050201u));
+  return __builtin_bit_cast(uint32_t, h >> (unsigned short)(W_BITS - 5 - 8));
 }
 
-// interpolated derivative of one pixel: top pair / bottom pair already gathered as (left | right << 16)
-__device__ __forceinline__ int deriv1(uint32_t top, uint32_t bot, uint32_t wt, uint32_t wb) {
-  return dot2(bot, wb, dot2k(top, wt, 1 << (W_BITS - 1))) >> W_BITS;
+// interpolated derivative of one pixel, times 2^16: top pair / bottom pair already gathered as (left | right << 16).  The
+// derivative image holds 4 x Scharr (vo_frame.hip), so the sum is 4 (s + 2^13) and the value OpenCV keeps, (s + 2^13) >> 14, is its
+// UPPER HALF: the byte gather that packs two pixels reads it from there (and zeroes masked pixels): one instruction per pixel pair
+// instead of two shifts, a pack and a mask
+__device__ __forceinline__ uint32_t deriv1(uint32_t top, uint32_t bot, uint32_t wt, uint32_t wb) {
+  return (uint32_t)dot2(bot, wb, dot2k(top, wt, 1 << (W_BITS + 1)));
 }
 
-// WAVES = minimum waves per SIMD the register allocation must allow (4: 119 VGPRs, 5: 91, 6: 80 + 32 B scratch)
+// WAVES = minimum waves per SIMD the register allocation must allow (6: 79 VGPRs, no scratch -- the default; 5: 81; 4 and 5 measured 3 % and 2 % slower)
 template <int WAVES>
 __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float* __restrict__ p0, float* __restrict__ p1,
                                                   uint8_t* __restrict__ status, float* __restrict__ err,
@@ -246,6 +261,8 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
   // validity of the lane's two columns as 16-bit masks (lo = column 2cp, hi = column 2cp + 1)
   const uint32_t colmask = ((2 * cp < win) ? 0x0000FFFFu : 0u) | ((2 * cp + 1 < win) ? 0xFFFF0000u : 0u);
   const uint32_t colones = colmask & 0x00010001u;
+  // v_perm selector "upper halves of (a, b)" with the constant-zero code 0x0c for the columns outside the window
+  const uint32_t colsel = (0x07060302u & colmask) | (0x0c0c0c0cu & ~colmask);
 
   for (int level = A.top; level >= 0; level--) {
     klt_level_args L = A.lv[level];
@@ -267,9 +284,8 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
       continue;
     }
     const uint32_t lane_off = (uint32_t)(8 * r * L.pitch + 2 * cp);    // the lane's corner of the 32 x 34 footprint
-    int iw00, iw01, iw10, iw11;
-    lk_weights(prevx - fpx, prevy - fpy, iw00, iw01, iw10, iw11);
-    const uint32_t wt = pack_lo((uint32_t)iw00, (uint32_t)iw01), wb = pack_lo((uint32_t)iw10, (uint32_t)iw11);
+    uint32_t wt, wb;
+    lk_weights(prevx - fpx, prevy - fpy, wt, wb);
 
     // ---- template: packed pairs of I (5 frac bits), Ix, Iy for the lane's 16 pixels; exact A11, A12, A22 ----
     uint32_t tI[8], tX[8], tY[8];
@@ -278,13 +294,14 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
       // addresses = level base (scalar registers) + a 32-bit offset: the wave-uniform window origin, advanced per row on the
       // scalar unit, plus ONE per-lane offset that is fixed for the level (it was a chain of 64-bit vector adds per row)
       const uint32_t uo = (uint32_t)(ipy + VO_PAD) * (uint32_t)L.pitch + (uint32_t)(ipx + VO_PAD);
+      const __amdgpu_buffer_rsrc_t rI = klt_rsrc(L.imgI), rD = klt_rsrc(L.derI);
 #pragma unroll
       for (int s = 0; s < 8; s++) {
-        const uint32_t o = uo + (uint32_t)s * (uint32_t)L.pitch + lane_off;
-        T[s] = ld_u32_any(L.imgI + o);
+        const uint32_t o = uo + (uint32_t)s * (uint32_t)L.pitch;          // wave-uniform
+        T[s] = __builtin_amdgcn_raw_buffer_load_b32(rI, (int)lane_off, (int)o, 0);
         // three consecutive pixels: one 12-byte load.  (8 bytes + the neighbour lane's first pixel through a DPP row shift was
         // measured: the same kernel time -- the data path is not priced per byte.)
-        const uint32_t* d3 = L.derI + o;
+        const u32x3 d3 = __builtin_amdgcn_raw_buffer_load_b96(rD, (int)(lane_off * 4u), (int)(o * 4u), 0);
         D0[s] = d3[0]; D1[s] = d3[1]; D2[s] = d3[2];
       }
       // row 8r + 8 = step 0 of row group r + 1 (lanes of r == 3 receive a row that only masked pixels use)
@@ -297,12 +314,12 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
         const uint32_t E1 = (s < 7) ? D1[(s + 1) & 7] : D18;
         const uint32_t E2 = (s < 7) ? D2[(s + 1) & 7] : D28;
         tI[s] = sample2(T[s], B, wt, wb);
-        const int x0 = deriv1(pack_lo(D0[s], D1[s]), pack_lo(E0, E1), wt, wb);
-        const int y0 = deriv1(pack_hi(D0[s], D1[s]), pack_hi(E0, E1), wt, wb);
-        const int x1 = deriv1(pack_lo(D1[s], D2[s]), pack_lo(E1, E2), wt, wb);
-        const int y1 = deriv1(pack_hi(D1[s], D2[s]), pack_hi(E1, E2), wt, wb);
-        const uint32_t m = (8 * r + s < win) ? colmask : 0u;    // rows / columns outside the window contribute nothing
-        const uint32_t xp = pack_lo((uint32_t)x0, (uint32_t)x1) & m, yp = pack_lo((uint32_t)y0, (uint32_t)y1) & m;
+        const uint32_t x0 = deriv1(pack_lo(D0[s], D1[s]), pack_lo(E0, E1), wt, wb);
+        const uint32_t y0 = deriv1(pack_hi(D0[s], D1[s]), pack_hi(E0, E1), wt, wb);
+        const uint32_t x1 = deriv1(pack_lo(D1[s], D2[s]), pack_lo(E1, E2), wt, wb);
+        const uint32_t y1 = deriv1(pack_hi(D1[s], D2[s]), pack_hi(E1, E2), wt, wb);
+        const uint32_t sel = (8 * r + s < win) ? colsel : 0x0c0c0c0cu;    // rows / columns outside the window contribute nothing
+        const uint32_t xp = __builtin_amdgcn_perm(x1, x0, sel), yp = __builtin_amdgcn_perm(y1, y0, sel);
         tX[s] = xp; tY[s] = yp;
         // the first step starts the three sums from an inline zero (three-address form: no preload)
         a11 = s ? dot2(xp, xp, a11) : dot2k(xp, xp, 0);
@@ -328,6 +345,7 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
       D = 1.f / D;
 
       nextx -= half; nexty -= half;
+      const __amdgpu_buffer_rsrc_t rJ = klt_rsrc(L.imgJ);
       float pdx = 0.f, pdy = 0.f;
       int j = 0;
       for (; j < A.max_count; j++) {
@@ -337,13 +355,12 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
           if (level == 0) st = 0;
           break;
         }
-        int jw00, jw01, jw10, jw11;
-        lk_weights(nextx - fnx, nexty - fny, jw00, jw01, jw10, jw11);
-        const uint32_t jt = pack_lo((uint32_t)jw00, (uint32_t)jw01), jb = pack_lo((uint32_t)jw10, (uint32_t)jw11);
+        uint32_t jt, jb;
+        lk_weights(nextx - fnx, nexty - fny, jt, jb);
         uint32_t Tj[8];
         const uint32_t uj = (uint32_t)(iny + VO_PAD) * (uint32_t)L.pitch + (uint32_t)(inx + VO_PAD);
 #pragma unroll
-        for (int s = 0; s < 8; s++) Tj[s] = ld_u32_any(L.imgJ + (uj + (uint32_t)s * (uint32_t)L.pitch + lane_off));
+        for (int s = 0; s < 8; s++) Tj[s] = __builtin_amdgcn_raw_buffer_load_b32(rJ, (int)lane_off, (int)(uj + (uint32_t)s * (uint32_t)L.pitch), 0);
         const uint32_t Tj8 = row_next(Tj[0], lane);
         int b1 = 0, b2 = 0;
 #pragma unroll
@@ -391,13 +408,12 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
         if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) {
           st = 0;
         } else {
-          int jw00, jw01, jw10, jw11;
-          lk_weights(nx - fnx, ny - fny, jw00, jw01, jw10, jw11);
-          const uint32_t jt = pack_lo((uint32_t)jw00, (uint32_t)jw01), jb = pack_lo((uint32_t)jw10, (uint32_t)jw11);
+          uint32_t jt, jb;
+          lk_weights(nx - fnx, ny - fny, jt, jb);
           uint32_t Tj[8];
           const uint32_t uj = (uint32_t)(iny + VO_PAD) * (uint32_t)L.pitch + (uint32_t)(inx + VO_PAD);
 #pragma unroll
-          for (int s = 0; s < 8; s++) Tj[s] = ld_u32_any(L.imgJ + (uj + (uint32_t)s * (uint32_t)L.pitch + lane_off));
+          for (int s = 0; s < 8; s++) Tj[s] = __builtin_amdgcn_raw_buffer_load_b32(rJ, (int)lane_off, (int)(uj + (uint32_t)s * (uint32_t)L.pitch), 0);
           const uint32_t Tj8 = row_next(Tj[0], lane);
           int e = 0;
 #pragma unroll
@@ -482,7 +498,7 @@ static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, size_t off
   c->iters_stride = A.iters_stride;
   {
     vo_prof_scope prof(c, VO_PROF_KLT);   // brackets exactly this launch (bench.py roofline figure)
-    static const int waves = getenv("VO_KLT_WAVES") ? atoi(getenv("VO_KLT_WAVES")) : 5;
+    static const int waves = getenv("VO_KLT_WAVES") ? atoi(getenv("VO_KLT_WAVES")) : 6;
 #define VO_KLT_LAUNCH(WV) hipLaunchKernelGGL(k_klt_track<WV>, dim3(n, c->batch), dim3(64), 0, c->stream, A,                \
                        vo_slab<const float>(c, off_in), vo_slab<float>(c, off_out), vo_slab<uint8_t>(c, c->off_status),     \
                        vo_slab<float>(c, c->off_err), c->d_iters, c->d_dbg, counts)
