@@ -309,15 +309,28 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 // LM decision (inputs are identical in every workgroup, so every workgroup derives the same state)
 // ------------------------------------------------------------------------------------------------
 // fixed-order block reduction of the per-workgroup step statistics written by k_ba_update (4 values per
-// workgroup): every thread stages partials in LDS, 4 threads sum them serially.  Call from all threads.
-template <int TPB>
-__device__ __forceinline__ void ba_reduce_evalpart(const double* __restrict__ evalpart, int n_eblk, double* s_part /* 4 * n_eblk */,
+// workgroup): every thread stages partials in LDS, 64 threads sum 16 interleaved sub-sequences per statistic, 4 threads
+// finish (the order is fixed, so every caller derives bit-identical sums).  Call from all threads (TPB >= 64).
+// COHERENT: the statistics were written by other workgroups of the SAME launch with write-through stores; read them past the
+// caches (agent-scope loads).
+template <int TPB, bool COHERENT = false>
+__device__ __forceinline__ void ba_reduce_evalpart(const double* __restrict__ evalpart, int n_eblk, double* s_part /* 4 * n_eblk + 64 */,
                                                    double* s_sum /* 4 */) {
-  for (int i = threadIdx.x; i < 4 * n_eblk; i += TPB) s_part[i] = evalpart[i];
+  for (int i = threadIdx.x; i < 4 * n_eblk; i += TPB)
+    s_part[i] = COHERENT ? __hip_atomic_load(evalpart + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : evalpart[i];
+  __syncthreads();
+  double* s_sub = s_part + 4 * n_eblk;
+  if (threadIdx.x < 64) {
+    const int k = threadIdx.x & 3, g = threadIdx.x >> 2;
+    double s = 0;
+    for (int b = g; b < n_eblk; b += 16) s += s_part[b * BA_EVAL_VALS + k];
+    s_sub[g * 4 + k] = s;
+  }
   __syncthreads();
   if (threadIdx.x < 4) {
     double s = 0;
-    for (int b = 0; b < n_eblk; b++) s += s_part[b * BA_EVAL_VALS + threadIdx.x];
+#pragma unroll
+    for (int g = 0; g < 16; g++) s += s_sub[g * 4 + threadIdx.x];
     s_sum[threadIdx.x] = s;
   }
   __syncthreads();
@@ -386,7 +399,9 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
     if (blockIdx.x == 0 && tid == 0) P.state[it & 1] = P.state[(it - 1) & 1];
     return;
   }
-  // ---- state for this iteration (every workgroup derives it from the same inputs) ----
+  // ---- state for this iteration (every workgroup derives it from the same inputs).  Handing the decision to the workgroup of
+  //      k_ba_update that arrives last (an arrival counter per problem) was measured: k_ba_build 60 -> 54 us, but 125 agent-scope
+  //      atomics on one address serialise (k_ba_update 15 -> 43 us), and an agent-scope release fence writes the L2 back (245 us) ----
   if (it > 0) ba_reduce_evalpart<TPB>(P.sharded ? P.xstat : P.evalpart, P.sharded ? 1 : P.nblk, dyn, s_esum);
   if (tid == 0) {
     ba_state st;
@@ -666,7 +681,7 @@ __global__ void __launch_bounds__(256) k_ba_xsum(ba_ptrs Pall, int it) {
 
 __global__ void __launch_bounds__(256) k_ba_xstat(ba_ptrs Pall, int it) {
   if (Pall.state[it & 1].done) return;
-  __shared__ double s_part[4 * 640];
+  __shared__ double s_part[4 * 640 + 64];
   __shared__ double s_sum[4];
   __shared__ double s_tot[4];
   if (threadIdx.x < 4) s_tot[threadIdx.x] = 0;
@@ -1072,7 +1087,7 @@ __global__ void __launch_bounds__(256) k_ba_finalize(ba_ptrs Pall, ba_params_dev
   st_out += (size_t)blockIdx.x * st_stride;
   __shared__ ba_state s_st;
   __shared__ double s_esum[4];
-  __shared__ double s_part[4 * 640];
+  __shared__ double s_part[4 * 640 + 64];
   if (n_it > 0) ba_reduce_evalpart<256>(P.sharded ? P.xstat : P.evalpart, P.sharded ? 1 : P.nblk, s_part, s_esum);
   // gridDim.y workgroups per problem share the copy of x (one 256-thread workgroup took 10 us for 6 000 doubles, at the end of
   // the critical path of a step); each derives the final state itself (deterministic), the first one publishes it

@@ -116,24 +116,43 @@ __global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restric
     const int x0 = ((bx - y * per_row) * 256 + threadIdx.x) * 4;
     if (x0 >= w) return;
     const size_t o = (size_t)(y + VO_PAD) * pitch + (x0 + VO_PAD);       // multiple of 4
-    int a[3][6];                                                          // columns x0 - 1 .. x0 + 4 of rows y - 1 .. y + 1
+    // columns x0 - 1 .. x0 + 4 of rows y - 1 .. y + 1 as three pairs of 16-bit values per row (one byte gather each); the vertical
+    // parts run on packed pairs, the horizontal 3-tap on v_dot2: 35 vector instructions per 4 pixels (90 with per-byte extraction;
+    // every vector instruction of this mix costs the same issue slot, tools/issue_probe.hip)
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    u16x2 a[3][3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       const uint32_t* q = reinterpret_cast<const uint32_t*>(src + o + (size_t)(r - 1) * pitch);
       const uint32_t L = q[-1], M = q[0], R = q[1];
-      a[r][0] = d_byte(L, 3);
-      a[r][1] = d_byte(M, 0); a[r][2] = d_byte(M, 1); a[r][3] = d_byte(M, 2); a[r][4] = d_byte(M, 3);
-      a[r][5] = d_byte(R, 0);
+      a[r][0] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(M, L, 0x0c040c03u));   // (x0 - 1, x0)
+      a[r][1] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, M, 0x0c020c01u));  // (x0 + 1, x0 + 2)
+      a[r][2] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(R, M, 0x0c040c03u));   // (x0 + 3, x0 + 4)
     }
-    uint32_t out[4];
+    // stored times 4 (|4 Scharr| <= 16 320 fits int16): k_klt_track's interpolation sum then carries its result in the upper
+    // 16 bits (vo_klt.hip deriv1); vo_pyramid_read hands out the plain values
+    s16x2 cs[3], dv[3];                                                   // 4 x [3 10 3]^T column sums, row differences
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      // stored times 4 (|4 Scharr| <= 16 320 fits int16): k_klt_track's interpolation sum then carries its result in the upper
-      // 16 bits (vo_klt.hip deriv1); vo_pyramid_read hands out the plain values
-      const int ix = (a[0][k + 2] + a[2][k + 2] - a[0][k] - a[2][k]) * 12 + (a[1][k + 2] - a[1][k]) * 40;
-      const int iy = (a[2][k] + a[2][k + 2] - a[0][k] - a[0][k + 2]) * 12 + (a[2][k + 1] - a[0][k + 1]) * 40;
-      // columns >= w belong to the zero (BORDER_CONSTANT) frame of the derivative image
-      out[k] = (x0 + k < w) ? (((uint32_t)(uint16_t)(int16_t)ix) | ((uint32_t)(uint16_t)(int16_t)iy << 16)) : 0u;
+    for (int c = 0; c < 3; c++) {
+      cs[c] = __builtin_bit_cast(s16x2, (u16x2)((a[0][c] + a[2][c]) * (unsigned short)12 + a[1][c] * (unsigned short)40));
+      dv[c] = __builtin_bit_cast(s16x2, (u16x2)(a[2][c] - a[0][c]));
+    }
+    const uint32_t ix01 = __builtin_bit_cast(uint32_t, (s16x2)(cs[1] - cs[0]));        // Ix of pixels 0, 1: column k + 2 minus column k
+    const uint32_t ix23 = __builtin_bit_cast(uint32_t, (s16x2)(cs[2] - cs[1]));
+    const s16x2 w_lo = {12, 40}, w_hi = {40, 12}, w_0 = {12, 0}, w_1 = {0, 12};
+    const int iy0 = __builtin_amdgcn_sdot2(dv[1], w_0, __builtin_amdgcn_sdot2(dv[0], w_lo, 0, false), false);   // 12 d0 + 40 d1 + 12 d2
+    const int iy1 = __builtin_amdgcn_sdot2(dv[1], w_hi, __builtin_amdgcn_sdot2(dv[0], w_1, 0, false), false);   // 12 d1 + 40 d2 + 12 d3
+    const int iy2 = __builtin_amdgcn_sdot2(dv[2], w_0, __builtin_amdgcn_sdot2(dv[1], w_lo, 0, false), false);
+    const int iy3 = __builtin_amdgcn_sdot2(dv[2], w_hi, __builtin_amdgcn_sdot2(dv[1], w_1, 0, false), false);
+    uint32_t out[4];
+    out[0] = __builtin_amdgcn_perm((uint32_t)iy0, ix01, 0x05040100u);     // (Ix | Iy << 16)
+    out[1] = __builtin_amdgcn_perm((uint32_t)iy1, ix01, 0x05040302u);
+    out[2] = __builtin_amdgcn_perm((uint32_t)iy2, ix23, 0x05040100u);
+    out[3] = __builtin_amdgcn_perm((uint32_t)iy3, ix23, 0x05040302u);
+    if (x0 + 3 >= w) {                                                    // columns >= w belong to the zero (BORDER_CONSTANT) frame of the derivative image
+#pragma unroll
+      for (int k = 1; k < 4; k++) if (x0 + k >= w) out[k] = 0u;
     }
     uint4 pk; pk.x = out[0]; pk.y = out[1]; pk.z = out[2]; pk.w = out[3];
     *reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(der) + (size_t)bseq * src_seq_px + o) = pk;
@@ -152,22 +171,21 @@ __global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restric
     if (X0 >= VO_PAD && X0 + 3 - VO_PAD < dw) {
       // interior: outputs x0 .. x0 + 3 read source columns 2 x0 - 2 .. 2 x0 + 8: 4 aligned dwords per source row
       const int x0 = X0 - VO_PAD;
-      int acc[4] = {0, 0, 0, 0};
+      // the 25 taps of an output are five dwords-pairs: v_dot4_u32_u8 with the vertical weight folded into the byte weights
+      // (<= 36) does extraction, multiplication and accumulation at once -- 10 instructions per output, no other arithmetic
+      uint32_t acc[4] = {128u, 128u, 128u, 128u};
 #pragma unroll
       for (int j = -2; j <= 2; j++) {
         const uint32_t* q = reinterpret_cast<const uint32_t*>(prow + (ptrdiff_t)j * pitch + 2 * x0);
-        const uint32_t d0 = q[-1], d1 = q[0], d2 = q[1], d3 = q[2];
-        int c[11];                                     // columns 2 x0 - 2 .. 2 x0 + 8
-        c[0] = d_byte(d0, 2); c[1] = d_byte(d0, 3);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { c[2 + k] = d_byte(d1, k); c[6 + k] = d_byte(d2, k); }
-        c[10] = d_byte(d3, 0);
-        const int wj = (j == 0) ? 6 : ((j == -1 || j == 1) ? 4 : 1);
-#pragma unroll
-        for (int k = 0; k < 4; k++) acc[k] += wj * (c[2 * k] + 4 * c[2 * k + 1] + 6 * c[2 * k + 2] + 4 * c[2 * k + 3] + c[2 * k + 4]);
+        const uint32_t d0 = q[-1], d1 = q[0], d2 = q[1], d3 = q[2];   // columns 2 x0 - 4 .. 2 x0 + 11
+        const uint32_t wj = (j == 0) ? 6u : ((j == -1 || j == 1) ? 4u : 1u);
+        acc[0] = __builtin_amdgcn_udot4(d1, wj * 0x00010406u, __builtin_amdgcn_udot4(d0, wj * 0x04010000u, acc[0], false), false);
+        acc[1] = __builtin_amdgcn_udot4(d2, wj * 0x00000001u, __builtin_amdgcn_udot4(d1, wj * 0x04060401u, acc[1], false), false);
+        acc[2] = __builtin_amdgcn_udot4(d2, wj * 0x00010406u, __builtin_amdgcn_udot4(d1, wj * 0x04010000u, acc[2], false), false);
+        acc[3] = __builtin_amdgcn_udot4(d3, wj * 0x00000001u, __builtin_amdgcn_udot4(d2, wj * 0x04060401u, acc[3], false), false);
       }
-#pragma unroll
-      for (int k = 0; k < 4; k++) res |= (uint32_t)((acc[k] + 128) >> 8) << (8 * k);
+      // byte 1 of every sum (255 * 256 + 128 < 2^16)
+      res = __builtin_amdgcn_perm(__builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0501u), __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0501u), 0x05040100u);
     } else {
 #pragma unroll
       for (int k = 0; k < 4; k++) {

@@ -217,6 +217,19 @@ __device__ __forceinline__ uint32_t st_ld_u32_any(const uint8_t* p) {     // una
   return v;
 }
 
+// correctly rounded sqrtf for x = 0 or x >= 2^-100 (here: sums of squares of differences of quantised products, 0 or >= 1e-19):
+// v_sqrt_f32 is within one ulp; the two fused residuals pick the neighbour when it is the nearest -- the compiler's own sequence
+// for sqrtf without its denormal pre-scaling and class test (9 instead of 18 instructions; x = 0 falls through: the lower
+// "neighbour" is a NaN, the comparisons fail)
+__device__ __forceinline__ float st_sqrt_rn(float x) {
+  float y = __builtin_amdgcn_sqrtf(x);
+  const float ym = __int_as_float(__float_as_int(y) - 1), yp = __int_as_float(__float_as_int(y) + 1);
+  const float rm = __builtin_fmaf(-ym, y, x), rp = __builtin_fmaf(-yp, y, x);
+  y = (rm <= 0.f) ? ym : y;
+  y = (rp > 0.f) ? yp : y;
+  return y;
+}
+
 #define ST_DPP_ADD(v, ctrl, rmask, bc) v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, bc)
 // inclusive wave prefix sums of three values; the three chains are interleaved so that each DPP read is two VALU
 // instructions behind the write it depends on (no hazard s_nops)
@@ -266,7 +279,7 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
                                                       double quality, unsigned long long* __restrict__ cand, uint32_t* __restrict__ nraw,
                                                       int restore_mask, int do_nms, int remap) {
   constexpr int D = 2 * R + 1, OUTC = 256 - 2 * R - 2;
-  __shared__ uint4 s_p[2][256];
+  __shared__ uint4 s_p[2][257];                                       // [256]: zeros (the subtrahend of windows that start at the workgroup's / a wave's edge)
   __shared__ float2 s_c[2][256];                                      // (max of the column's three rows, running masked maximum)
   __shared__ float s_m[4];
   // candidates are collected in LDS (one LDS atomic per wave and row) and flushed with ONE global atomic when the list could
@@ -276,6 +289,7 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
   __shared__ unsigned int s_cnt, s_gbase;
   const int t = threadIdx.x, lane = t & 63;
   if (t == 0) s_cnt = 0;
+  if (t < 2) s_p[t][256] = make_uint4(0u, 0u, 0u, 0u);
   s_c[0][t] = make_float2(0.f, 0.f); s_c[1][t] = make_float2(0.f, 0.f);    // the first row's (unconditional) neighbour reads
   // (band, sequence) assignment: a sequence's bands run on the XCD that built its pyramid (vo_xcd_assign); blocks of a band adjacent
   int bxy, bseq;
@@ -285,13 +299,16 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
   const int rows_out = min(rb, H - y0);
   const int total = rows_out + 2 + 2 * R;                             // product rows y0 - 1 - R .. y0 + rows_out + R
   const int xs = st_reflect101(x0 - 1 - R + t, W);                    // product column of this thread
-  const uint8_t* base = img + (size_t)bseq * img_seq_px + (size_t)VO_PAD * pitch + VO_PAD;    // pixel (0, 0), uniform
+  // image rows and mask bytes come through buffer loads: descriptor base + a per-thread column offset that never changes (vector
+  // register) + the row offset (scalar register, scalar arithmetic) -- no vector address arithmetic per row
+  const __amdgpu_buffer_rsrc_t r_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img + (size_t)bseq * img_seq_px), 0, -1, 0x00020000);
   const int xe = x0 - 1 + t - R;                                      // eigenvalue column of this thread (halo: x0 - 1 and x0 + OUTC)
   const bool evalid = (t >= R) && (t < 256 - R) && xe >= 0 && xe < W; // an eigenvalue of the image is formed here
   const bool outt = evalid && (t > R) && (t < 255 - R);               // ... and it is one of this workgroup's outputs
   const int xo_c = outt ? xe : 0;
   const size_t np = (size_t)W * H;
   mask += (size_t)bseq * np;
+  const __amdgpu_buffer_rsrc_t r_mask = __builtin_amdgcn_make_buffer_rsrc(mask, 0, -1, 0x00020000);
   if (eig) eig += (size_t)bseq * np;
   cand += (size_t)bseq * ST_CAND_STRIDE; nraw += bseq;
   unsigned ring[D][3];
@@ -310,12 +327,18 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
   auto fetch = [&](int k, uint32_t (&w)[3]) {
     int rp = y0 - 1 - R + min(k, total - 1);                        // product row (uniform); one reflection is enough: overshoot <= R + 1 < H
     rp = rp < 0 ? -rp : (rp >= H ? 2 * (H - 1) - rp : rp);
-    const uint8_t* r1 = base + (size_t)rp * pitch + (xs - 1);
-    w[0] = st_ld_u32_any(r1 - pitch); w[1] = st_ld_u32_any(r1); w[2] = st_ld_u32_any(r1 + pitch);
+    const int o1 = (rp + VO_PAD) * pitch + (VO_PAD - 1);            // padded row of product row rp, one byte left of the thread's column
+    w[0] = __builtin_amdgcn_raw_buffer_load_b32(r_img, xs, o1 - pitch, 0);
+    w[1] = __builtin_amdgcn_raw_buffer_load_b32(r_img, xs, o1, 0);
+    w[2] = __builtin_amdgcn_raw_buffer_load_b32(r_img, xs, o1 + pitch, 0);
   };
   // the pending test of row `py`: neighbours' column maxima of the slot written one row ago.  Branch-free up to the ballot (the
   // LDS reads use clamped indices; `pok` is false wherever they would be meaningless).  The threshold here only thins the list --
   // k_st_select applies the exact one -- so a float product rounded DOWN replaces the float64 product of the reference formula.
+  // LDS slots of the horizontal window sum S(x) = P(x + R) - P(x - R - 1) (+ the total of the wave the window starts in)
+  const int ia = min(t + R, 255);
+  const int ib_z = (t - R - 1 >= 0) ? t - R - 1 : 256;
+  const int it_z = (t - R - 1 >= 0 && (ia >> 6) != ((t - R - 1) >> 6)) ? ((t - R - 1) | 63) : 256;
   const float q_lo = (float)(quality * (1.0 - 1e-6));
   const int tl = max(t - 1, 0), tr = min(t + 1, 255);
   auto test_pending = [&](int slot) {
@@ -347,26 +370,25 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
 #pragma unroll
   for (int i = 0; i < PF; i++) fetch(i, q[i]);
   auto mask_row = [&](int ke) { return min(max(y0 - 1 + ke, 0), H - 1); };   // image row of eigenvalue row index ke (clamped: halo rows of the image border)
-  uint8_t mk_next = mask[(size_t)mask_row(0) * W + xo_c];
+  uint8_t mk_next = __builtin_amdgcn_raw_buffer_load_b8(r_mask, xo_c, mask_row(0) * W, 0);
   for (int kb = 0; kb < total; kb += D) {
 #pragma unroll
     for (int u = 0; u < D; u++) {
       const int k = kb + u;
       if (k < total) {
-        const uint32_t w0 = q[0][0], w1 = q[0][1], w2 = q[0][2];
+        const uint32_t w0 = q[u % PF][0], w1 = q[u % PF][1], w2 = q[u % PF][2];
         // the mask byte of a row's output is requested one iteration ahead: waiting for it then leaves the prefetched
         // image rows in flight (loads return in order).  Unconditional, clamped address: a load under a divergent branch
         // would be waited for at the end of the branch.
         const uint8_t mk = mk_next;
-        mk_next = mask[(size_t)mask_row(max(k + 1 - 2 * R, 0)) * W + xo_c];
-#pragma unroll
-        for (int i = 0; i + 1 < PF; i++) { q[i][0] = q[i + 1][0]; q[i][1] = q[i + 1][1]; q[i][2] = q[i + 1][2]; }
-        fetch(k + PF, q[PF - 1]);
-        const int a0 = w0 & 0xff, c0 = (w0 >> 16) & 0xff, b0 = (w0 >> 8) & 0xff;
-        const int a1 = w1 & 0xff, c1 = (w1 >> 16) & 0xff;
-        const int a2 = w2 & 0xff, c2 = (w2 >> 16) & 0xff, b2 = (w2 >> 8) & 0xff;
-        const int dx = ((c0 - a0) + (c2 - a2)) + 2 * (c1 - a1);
-        const int dy = (a2 + 2 * b2 + c2) - (a0 + 2 * b0 + c0);
+        mk_next = __builtin_amdgcn_raw_buffer_load_b8(r_mask, xo_c, mask_row(max(k + 1 - 2 * R, 0)) * W, 0);
+        // the slot just consumed receives the row PF ahead: the prefetch queue is indexed by the unrolled counter (no register
+        // shuffling per row); D % PF rows of phase are taken out once per trip of the outer loop, below
+        fetch(k + PF, q[u % PF]);
+        // Sobel as byte dot products: bytes (left, centre, right) of the three rows
+        const int dx = (int)(__builtin_amdgcn_udot4(w2, 0x00010000u, __builtin_amdgcn_udot4(w1, 0x00020000u, __builtin_amdgcn_udot4(w0, 0x00010000u, 0u, false), false), false) -
+                             __builtin_amdgcn_udot4(w2, 0x00000001u, __builtin_amdgcn_udot4(w1, 0x00000002u, __builtin_amdgcn_udot4(w0, 0x00000001u, 0u, false), false), false));
+        const int dy = (int)(__builtin_amdgcn_udot4(w2, 0x00010201u, 0u, false) - __builtin_amdgcn_udot4(w0, 0x00010201u, 0u, false));
         const unsigned pxx = (unsigned)(dx * dx), pxy = (unsigned)(dx * dy), pyy = (unsigned)(dy * dy);
         V0 += pxx - ring[u][0]; V1 += pxy - ring[u][1]; V2 += pyy - ring[u][2];
         ring[u][0] = pxx; ring[u][1] = pxy; ring[u][2] = pyy;
@@ -384,15 +406,11 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
           float e0;
           {
             // every thread forms a value (clamped LDS indices: no divergent branch); the ones outside the eigenvalue columns drop it
-            const int ia = min(t + R, 255), ib = t - R - 1, ibc = max(ib, 0);
-            const uint4 A = buf[ia];
-            uint4 Bv = buf[ibc], T = buf[ibc | 63];                  // T: total of the wave the window starts in
-            const bool hasb = ib >= 0, cross = hasb && ((ia >> 6) != (ib >> 6));
-            const unsigned bx = hasb ? Bv.x : 0u, by = hasb ? Bv.y : 0u, bz = hasb ? Bv.z : 0u;
-            const unsigned tx = cross ? T.x : 0u, ty = cross ? T.y : 0u, tz = cross ? T.z : 0u;
-            const int sa = (int)(A.x - bx + tx), sb = (int)(A.y - by + ty), sc = (int)(A.z - bz + tz);
+            // (ia, ib_z, it_z are fixed per thread; slot 256 holds zeros: no selects)
+            const uint4 A = buf[ia], Bv = buf[ib_z], T = buf[it_z];    // T: total of the wave the window starts in
+            const int sa = (int)(A.x - Bv.x + T.x), sb = (int)(A.y - Bv.y + T.y), sc = (int)(A.z - Bv.z + T.z);
             const float a = ((float)sa * s2) * 0.5f, b = (float)sb * s2, c = ((float)sc * s2) * 0.5f;
-            e0 = evalid ? (a + c) - sqrtf((a - c) * (a - c) + b * b) : 0.f;
+            e0 = evalid ? (a + c) - st_sqrt_rn((a - c) * (a - c) + b * b) : 0.f;
           }
           const bool own_row = (ke >= 1) && (ke <= rows_out);        // ye is one of this workgroup's output rows
           const bool mine = outt && own_row;
@@ -412,6 +430,13 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
           e2 = e1; e1 = e0; mk1 = (outt && own_row) ? mk : (uint8_t)0;
         }
       }
+    }
+    if (D % PF != 0) {                                               // row kb + D sits in slot D % PF: rotate it to slot 0
+      uint32_t tmp[PF][3];
+#pragma unroll
+      for (int i = 0; i < PF; i++) { tmp[i][0] = q[(i + D) % PF][0]; tmp[i][1] = q[(i + D) % PF][1]; tmp[i][2] = q[(i + D) % PF][2]; }
+#pragma unroll
+      for (int i = 0; i < PF; i++) { q[i][0] = tmp[i][0]; q[i][1] = tmp[i][1]; q[i][2] = tmp[i][2]; }
     }
   }
   __syncthreads();
