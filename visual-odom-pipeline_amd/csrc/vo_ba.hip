@@ -308,30 +308,17 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 // ------------------------------------------------------------------------------------------------
 // LM decision (inputs are identical in every workgroup, so every workgroup derives the same state)
 // ------------------------------------------------------------------------------------------------
-// fixed-order block reduction of the per-workgroup step statistics written by k_ba_update (4 values per
-// workgroup): every thread stages partials in LDS, 64 threads sum 16 interleaved sub-sequences per statistic, 4 threads
-// finish (the order is fixed, so every caller derives bit-identical sums).  Call from all threads (TPB >= 64).
-// COHERENT: the statistics were written by other workgroups of the SAME launch with write-through stores; read them past the
-// caches (agent-scope loads).
-template <int TPB, bool COHERENT = false>
-__device__ __forceinline__ void ba_reduce_evalpart(const double* __restrict__ evalpart, int n_eblk, double* s_part /* 4 * n_eblk + 64 */,
-                                                   double* s_sum /* 4 */) {
-  for (int i = threadIdx.x; i < 4 * n_eblk; i += TPB)
-    s_part[i] = COHERENT ? __hip_atomic_load(evalpart + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : evalpart[i];
-  __syncthreads();
-  double* s_sub = s_part + 4 * n_eblk;
-  if (threadIdx.x < 64) {
-    const int k = threadIdx.x & 3, g = threadIdx.x >> 2;
+// fixed-order block reduction of the per-workgroup step statistics written by k_ba_update (4 values per workgroup): wave k sums
+// statistic k -- lane l the workgroups l, l + 64, ... in order, then the fixed cross-lane tree of wave_allreduce -- so every caller
+// derives bit-identical sums without staging anything in LDS (one barrier instead of three).  Call from all threads (TPB >= 256).
+template <int TPB>
+__device__ __forceinline__ void ba_reduce_evalpart(const double* __restrict__ evalpart, int n_eblk, double* s_sum /* 4 */) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave < BA_EVAL_VALS) {
     double s = 0;
-    for (int b = g; b < n_eblk; b += 16) s += s_part[b * BA_EVAL_VALS + k];
-    s_sub[g * 4 + k] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < 4) {
-    double s = 0;
-#pragma unroll
-    for (int g = 0; g < 16; g++) s += s_sub[g * 4 + threadIdx.x];
-    s_sum[threadIdx.x] = s;
+    for (int b = lane; b < n_eblk; b += 64) s += evalpart[b * BA_EVAL_VALS + wave];
+    s = wave_allreduce(s);
+    if (lane == 0) s_sum[wave] = s;
   }
   __syncthreads();
 }
@@ -402,7 +389,7 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   // ---- state for this iteration (every workgroup derives it from the same inputs).  Handing the decision to the workgroup of
   //      k_ba_update that arrives last (an arrival counter per problem) was measured: k_ba_build 60 -> 54 us, but 125 agent-scope
   //      atomics on one address serialise (k_ba_update 15 -> 43 us), and an agent-scope release fence writes the L2 back (245 us) ----
-  if (it > 0) ba_reduce_evalpart<TPB>(P.sharded ? P.xstat : P.evalpart, P.sharded ? 1 : P.nblk, dyn, s_esum);
+  if (it > 0) ba_reduce_evalpart<TPB>(P.sharded ? P.xstat : P.evalpart, P.sharded ? 1 : P.nblk, s_esum);
   if (tid == 0) {
     ba_state st;
     if (it == 0) st = ba_init_state(prm);
@@ -681,13 +668,12 @@ __global__ void __launch_bounds__(256) k_ba_xsum(ba_ptrs Pall, int it) {
 
 __global__ void __launch_bounds__(256) k_ba_xstat(ba_ptrs Pall, int it) {
   if (Pall.state[it & 1].done) return;
-  __shared__ double s_part[4 * 640 + 64];
   __shared__ double s_sum[4];
   __shared__ double s_tot[4];
   if (threadIdx.x < 4) s_tot[threadIdx.x] = 0;
   for (int b = 0; b < Pall.batch; b++) {
     __syncthreads();
-    ba_reduce_evalpart<256>(Pall.evalpart + (size_t)b * Pall.s_evalpart, Pall.nblk, s_part, s_sum);
+    ba_reduce_evalpart<256>(Pall.evalpart + (size_t)b * Pall.s_evalpart, Pall.nblk, s_sum);
     if (threadIdx.x < 4) s_tot[threadIdx.x] += s_sum[threadIdx.x];
   }
   __syncthreads();
@@ -1087,8 +1073,7 @@ __global__ void __launch_bounds__(256) k_ba_finalize(ba_ptrs Pall, ba_params_dev
   st_out += (size_t)blockIdx.x * st_stride;
   __shared__ ba_state s_st;
   __shared__ double s_esum[4];
-  __shared__ double s_part[4 * 640 + 64];
-  if (n_it > 0) ba_reduce_evalpart<256>(P.sharded ? P.xstat : P.evalpart, P.sharded ? 1 : P.nblk, s_part, s_esum);
+  if (n_it > 0) ba_reduce_evalpart<256>(P.sharded ? P.xstat : P.evalpart, P.sharded ? 1 : P.nblk, s_esum);
   // gridDim.y workgroups per problem share the copy of x (one 256-thread workgroup took 10 us for 6 000 doubles, at the end of
   // the critical path of a step); each derives the final state itself (deterministic), the first one publishes it
   if (threadIdx.x == 0) {
