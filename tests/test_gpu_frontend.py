@@ -173,6 +173,25 @@ def test_shi_tomasi_vs_opencv_float_order(ctx_big, seq3):
     assert len(diff) <= 0.02 * max(len(want), 1), (len(diff), len(want))
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_shi_tomasi_dense_candidates_flush_the_band_lists(ctx_big, seq3, seed):
+    """white noise at a tiny quality level: about every ninth pixel survives the 3 x 3 suppression, so every band of the fused kernel
+    fills and empties its LDS candidate list many times (the decision to empty it must be taken identically by all waves of a
+    workgroup).  Corners, candidate count and the eigenvalue map against the oracle, three images."""
+    import vo_oracle as o
+    rng = np.random.default_rng(100 + seed)
+    img = rng.integers(0, 256, (376, 1241), dtype=np.uint8)
+    ctx_big.push_frame(img)
+    prm = ctx_big.st_params(max_corners=1000, quality_level=1e-4, min_distance=7.0, block_size=31)
+    got = ctx_big.shi_tomasi(None, params=prm)
+    eig, _, nc = ctx_big.shi_tomasi_read()
+    want, weig, wnc = o.good_features(img, None, 1000, 1e-4, 7.0, 31, return_aux=True)
+    frames, _ = seq3
+    ctx_big.push_frame(frames[0]); ctx_big.push_frame(frames[1])       # the module's context goes back to its two frames
+    assert np.array_equal(eig, weig) and nc == wnc and nc > 20000, (nc, wnc)
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("maxc,q,md,bs,radius", [(200, 0.05, 12.0, 15, 5), (1000, 0.01, 3.0, 7, 0), (50, 0.2, 0.5, 3, 10), (4000, 0.001, 5.0, 31, 7)])
 def test_shi_tomasi_parameter_sweep(seq_small, maxc, q, md, bs, radius):
     import vo_oracle as o

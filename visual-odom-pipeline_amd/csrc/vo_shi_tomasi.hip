@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) k_st_mask_init(uint8_t* __restrict__ mask
 //   * `restore_mask`: the exclusion mask is consumed exactly once per pixel here; writing 255 back leaves it clean for the next
 //     frame's discs (no separate k_st_mask_init launch on the resident path).
 template <int R>
-__global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict__ img, size_t img_seq_px, int pitch, int W, int H, int rb, float s2,
+__global__ void __launch_bounds__(256, 4) k_st_eig_fused(const uint8_t* __restrict__ img, size_t img_seq_px, int pitch, int W, int H, int rb, float s2,
                                                       uint8_t* __restrict__ mask, float* __restrict__ eig, float* __restrict__ blockmax,
                                                       double quality, unsigned long long* __restrict__ cand, uint32_t* __restrict__ nraw,
                                                       int restore_mask, int do_nms, int remap) {
@@ -284,12 +284,13 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
   __shared__ float s_m[4];
   // candidates are collected in LDS (one LDS atomic per wave and row) and flushed with ONE global atomic when the list could
   // overflow on the next row and at the end: a returning global atomic per wave and row stalled the row loop (3.6x slower)
-  constexpr int LCAP = 1024;
+  constexpr int LCAP = 2048;
   __shared__ unsigned long long s_keys[LCAP];
   __shared__ unsigned int s_cnt, s_gbase;
+  __shared__ unsigned int s_flag[2];                                  // "empty the list before this row's appends", by row parity
   const int t = threadIdx.x, lane = t & 63;
   if (t == 0) s_cnt = 0;
-  if (t < 2) s_p[t][256] = make_uint4(0u, 0u, 0u, 0u);
+  if (t < 2) { s_p[t][256] = make_uint4(0u, 0u, 0u, 0u); s_flag[t] = 0u; }
   s_c[0][t] = make_float2(0.f, 0.f); s_c[1][t] = make_float2(0.f, 0.f);    // the first row's (unconditional) neighbour reads
   // (band, sequence) assignment: a sequence's bands run on the XCD that built its pyramid (vo_xcd_assign); blocks of a band adjacent
   int bxy, bseq;
@@ -311,9 +312,11 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
   const __amdgpu_buffer_rsrc_t r_mask = __builtin_amdgcn_make_buffer_rsrc(mask, 0, -1, 0x00020000);
   if (eig) eig += (size_t)bseq * np;
   cand += (size_t)bseq * ST_CAND_STRIDE; nraw += bseq;
-  unsigned ring[D][3];
+  // the ring keeps the gradients (dx | dy << 16, |.| <= 1020), not the three products: 31 registers instead of 93 -- the kernel is
+  // bound by latency, its time goes with 1 / (waves per SIMD) (measured 170 us at 2, 118 at 3), and the ring decides the register count
+  uint32_t ring[D];
 #pragma unroll
-  for (int u = 0; u < D; u++) { ring[u][0] = 0; ring[u][1] = 0; ring[u][2] = 0; }
+  for (int u = 0; u < D; u++) ring[u] = 0;
   unsigned V0 = 0, V1 = 0, V2 = 0;
   float lmax = 0.f;                                                   // masked maximum of the outputs of this column (exact part of the global maximum)
   float rmax = 0.f;                                                   // running lower bound of the global maximum used for the candidate threshold
@@ -355,11 +358,15 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
                ((unsigned long long)__float_as_uint(pv) << 32) | (unsigned long long)(uint32_t)((size_t)py * W + xe);
     }
   };
-  // call where every thread sees the same s_cnt (right after a barrier): empties the list when the next row could overflow it
-  auto flush = [&](bool force) {
+  // Emptying the list.  The decision must be the same in every wave, but a count read after a barrier is not: a faster wave may
+  // already have appended this row's candidates (the earlier form read it there: waves could disagree when the list was nearly
+  // full).  So thread 0 publishes the decision for the NEXT row (s_flag, double-buffered by row parity; read on the other side of the
+  // row's barrier).  The count it saw is at most one row behind the count at the flush, and one more row is appended before the
+  // next chance: the list is emptied when it holds more than LCAP - 2 * 256 entries.
+  auto flush_now = [&]() {
+    __syncthreads();                                                   // every append of the previous row is in
     const unsigned int n = s_cnt;
-    if (n == 0 || (!force && n <= (unsigned int)(LCAP - 256))) return;
-    if (t == 0) s_gbase = atomicAdd(nraw, n);
+    if (t == 0 && n) s_gbase = atomicAdd(nraw, n);
     __syncthreads();
     const unsigned int gb = s_gbase;
     for (unsigned int i = t; i < n; i += 256) if (gb + i < ST_GLOBAL_CAP) cand[gb + i] = s_keys[i];
@@ -371,6 +378,44 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
   for (int i = 0; i < PF; i++) fetch(i, q[i]);
   auto mask_row = [&](int ke) { return min(max(y0 - 1 + ke, 0), H - 1); };   // image row of eigenvalue row index ke (clamped: halo rows of the image border)
   uint8_t mk_next = __builtin_amdgcn_raw_buffer_load_b8(r_mask, xo_c, mask_row(0) * W, 0);
+  uint8_t mk_post = 0;                                                // mask byte of the row post() handles
+  // post(k): everything of eigenvalue row k - 2 R that needs the OTHER threads' prefix sums (written before the last barrier): the
+  // pending 3 x 3 test of the row before, the eigenvalue, maxima, the column maxima for the next test.  It runs one iteration late,
+  // next to the Sobel / ring / scan work of row k + 1 (two independent dependency chains between two barriers).
+  auto post = [&](int k) {
+    if (do_nms) {
+      if (s_flag[k & 1]) flush_now();
+      test_pending((k - 1) & 1);                                      // row ye - 2 against the maxima written one row ago
+      if (t == 0) s_flag[(k + 1) & 1] = (s_cnt > (unsigned int)(LCAP - 512)) ? 1u : 0u;
+    }
+    const uint4* buf = s_p[k & 1];
+    const int ke = k - 2 * R, ye = y0 - 1 + ke;                       // eigenvalue row (-1 and H are halo rows of nothing)
+    const uint8_t mk = mk_post;
+    float e0;
+    {
+      // every thread forms a value (slot 256 holds zeros: no selects); the ones outside the eigenvalue columns drop it
+      const uint4 A = buf[ia], Bv = buf[ib_z], T = buf[it_z];          // T: total of the wave the window starts in
+      const int sa = (int)(A.x - Bv.x + T.x), sb = (int)(A.y - Bv.y + T.y), sc = (int)(A.z - Bv.z + T.z);
+      const float a = ((float)sa * s2) * 0.5f, b = (float)sb * s2, c = ((float)sc * s2) * 0.5f;
+      e0 = evalid ? (a + c) - st_sqrt_rn((a - c) * (a - c) + b * b) : 0.f;
+    }
+    const bool own_row = (ke >= 1) && (ke <= rows_out);               // ye is one of this workgroup's output rows
+    const bool mine = outt && own_row;
+    lmax = (mine && mk) ? fmaxf(lmax, e0) : lmax;
+    if (mine) {
+      const size_t o = (size_t)ye * W + xe;
+      if (eig) eig[o] = e0;
+      if (restore_mask && mk != 255) mask[o] = 255;
+    }
+    rmax = fmaxf(rmax, lmax);
+    // publish: max of the column over rows ye - 2 .. ye, and the running maximum
+    const float cm = fmaxf(e2, e0);
+    if (do_nms) s_c[k & 1][t] = make_float2(fmaxf(cm, e1), rmax);
+    // the centre row ye - 1 becomes the pending test (decided by the next post, when the neighbours' maxima are visible)
+    pv = e1; pcm = cm; py = ye - 1;
+    pok = outt && (ke >= 2) && (ke - 1 <= rows_out) && mk1 && (py >= 1) && (py < H - 1) && (xe >= 1) && (xe < W - 1);
+    e2 = e1; e1 = e0; mk1 = (outt && own_row) ? mk : (uint8_t)0;
+  };
   for (int kb = 0; kb < total; kb += D) {
 #pragma unroll
     for (int u = 0; u < D; u++) {
@@ -389,45 +434,27 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
         const int dx = (int)(__builtin_amdgcn_udot4(w2, 0x00010000u, __builtin_amdgcn_udot4(w1, 0x00020000u, __builtin_amdgcn_udot4(w0, 0x00010000u, 0u, false), false), false) -
                              __builtin_amdgcn_udot4(w2, 0x00000001u, __builtin_amdgcn_udot4(w1, 0x00000002u, __builtin_amdgcn_udot4(w0, 0x00000001u, 0u, false), false), false));
         const int dy = (int)(__builtin_amdgcn_udot4(w2, 0x00010201u, 0u, false) - __builtin_amdgcn_udot4(w0, 0x00010201u, 0u, false));
-        const unsigned pxx = (unsigned)(dx * dx), pxy = (unsigned)(dx * dy), pyy = (unsigned)(dy * dy);
-        V0 += pxx - ring[u][0]; V1 += pxy - ring[u][1]; V2 += pyy - ring[u][2];
-        ring[u][0] = pxx; ring[u][1] = pxy; ring[u][2] = pyy;
+        {
+          // V += (products of the entering row) - (products of the leaving row), as three 2-term dot products of 16-bit pairs:
+          //   (dx, dxo) . (dx, -dxo),  (dx, dxo) . (dy, -dyo),  (dy, dyo) . (dy, -dyo)
+          typedef short s16x2 __attribute__((ext_vector_type(2)));
+          const uint32_t nw = __builtin_amdgcn_perm((uint32_t)dy, (uint32_t)dx, 0x05040100u), od = ring[u];
+          ring[u] = nw;
+          const s16x2 px = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(od, nw, 0x05040100u));      // (dx, dxo)
+          const s16x2 py = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(od, nw, 0x07060302u));      // (dy, dyo)
+          const s16x2 sgn = {1, -1};
+          const s16x2 nx = px * sgn, ny = py * sgn;
+          V0 = (unsigned)__builtin_amdgcn_sdot2(px, nx, (int)V0, false);
+          V1 = (unsigned)__builtin_amdgcn_sdot2(px, ny, (int)V1, false);
+          V2 = (unsigned)__builtin_amdgcn_sdot2(py, ny, (int)V2, false);
+        }
         if (k >= 2 * R) {
           unsigned P0 = V0, P1 = V1, P2 = V2;
           st_scan64x3(P0, P1, P2);
-          uint4* buf = s_p[k & 1];
-          buf[t] = make_uint4(P0, P1, P2, 0u);
+          s_p[k & 1][t] = make_uint4(P0, P1, P2, 0u);
+          if (k > 2 * R) post(k - 1);                                  // reads the OTHER buffer, filled before the last barrier
+          mk_post = mk;
           __syncthreads();
-          if (do_nms) {
-            flush(false);
-            test_pending((k - 1) & 1);                               // row ye - 2 against the maxima written one row ago
-          }
-          const int ke = k - 2 * R, ye = y0 - 1 + ke;                // eigenvalue row of this iteration (-1 and H are halo rows of nothing)
-          float e0;
-          {
-            // every thread forms a value (clamped LDS indices: no divergent branch); the ones outside the eigenvalue columns drop it
-            // (ia, ib_z, it_z are fixed per thread; slot 256 holds zeros: no selects)
-            const uint4 A = buf[ia], Bv = buf[ib_z], T = buf[it_z];    // T: total of the wave the window starts in
-            const int sa = (int)(A.x - Bv.x + T.x), sb = (int)(A.y - Bv.y + T.y), sc = (int)(A.z - Bv.z + T.z);
-            const float a = ((float)sa * s2) * 0.5f, b = (float)sb * s2, c = ((float)sc * s2) * 0.5f;
-            e0 = evalid ? (a + c) - st_sqrt_rn((a - c) * (a - c) + b * b) : 0.f;
-          }
-          const bool own_row = (ke >= 1) && (ke <= rows_out);        // ye is one of this workgroup's output rows
-          const bool mine = outt && own_row;
-          lmax = (mine && mk) ? fmaxf(lmax, e0) : lmax;
-          if (mine) {
-            const size_t o = (size_t)ye * W + xe;
-            if (eig) eig[o] = e0;
-            if (restore_mask && mk != 255) mask[o] = 255;
-          }
-          rmax = fmaxf(rmax, lmax);
-          // publish: max of the column over rows ye - 2 .. ye, and the running maximum
-          const float cm = fmaxf(e2, e0);
-          if (do_nms) s_c[k & 1][t] = make_float2(fmaxf(cm, e1), rmax);
-          // the centre row ye - 1 becomes the pending test (decided next iteration, when the neighbours' maxima are visible)
-          pv = e1; pcm = cm; py = ye - 1;
-          pok = outt && (ke >= 2) && (ke - 1 <= rows_out) && mk1 && (py >= 1) && (py < H - 1) && (xe >= 1) && (xe < W - 1);
-          e2 = e1; e1 = e0; mk1 = (outt && own_row) ? mk : (uint8_t)0;
         }
       }
     }
@@ -439,12 +466,12 @@ __global__ void __launch_bounds__(256) k_st_eig_fused(const uint8_t* __restrict_
       for (int i = 0; i < PF; i++) { q[i][0] = tmp[i][0]; q[i][1] = tmp[i][1]; q[i][2] = tmp[i][2]; }
     }
   }
+  post(total - 1);
   __syncthreads();
   if (do_nms) {
-    flush(false);
+    if (s_flag[total & 1]) flush_now();
     test_pending((total - 1) & 1);
-    __syncthreads();
-    flush(true);
+    flush_now();
   }
   for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
   if ((t & 63) == 0) s_m[t >> 6] = lmax;
@@ -1005,8 +1032,12 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
   if (fused) {
     // rows per band: few bands keep the 30-row start-up small; with few sequences in flight more, shorter bands fill the GPU
     const int gx = vo_div_up(W, 256 - 32);
-    int rb = 94;
-    while (rb > 16 && gx * vo_div_up(H, rb) * B < 512) rb = (rb + 1) / 2;
+    // (4 workgroups fit a CU -- k_st_eig_fused is built for 4 waves per SIMD --: as many bands as keep the launch within those
+    //  1024 slots, at least 12 rows each; KITTI frames in a batch of 32: 5 bands of 76 rows x 6 column blocks = 960 workgroups)
+    int gyw = 1024 / (gx * B);
+    if (gyw > H / 12) gyw = H / 12;
+    if (gyw < 1) gyw = 1;
+    int rb = vo_div_up(H, gyw);
     if (s->force_rb > 0) rb = s->force_rb < H ? s->force_rb : H;
     const int gy = vo_div_up(H, rb);
     n_blockmax = gx * gy;
