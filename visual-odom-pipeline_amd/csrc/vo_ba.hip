@@ -48,7 +48,9 @@
 #define BA_POSE_VALS 28      // Hpp upper (21) + gp (6) + cost (1)
 #define BA_MAX_SLOTS 20
 #define BA_EVAL_VALS 4
-#define BA_PITCH_PAD 16      // panel row pitch = RP + 16 doubles: 16-lane row groups land on disjoint LDS banks
+#define BA_PITCH_PAD 8       // panel row pitch = RP + 8 doubles.  A pitch of RP + 16 keeps the 16-lane row groups of the MFMA operand reads on
+                             // disjoint LDS banks, but its 30.7 KB panel lets only 4 workgroups share a CU; measured (VO_BA_PAD): pads 0..12
+                             // 54 us per launch, pad 16 57 us -- the bank conflicts cost nothing here, the fifth workgroup is worth 5 %
 #define BA_CAM 21            // per-slot camera data staged in LDS: R(9) t(3) Jr(9)
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -526,23 +528,24 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   VO_STAMP(dbgb, 3);   // camera sums reduced and written
   // ---- Y^ panel of this workgroup in LDS: row 3 pl + c, columns 6 slot .. 6 slot + 5, column 6W = y ----
   const int pitch = P.pitch;
+  double* const rw0 = dyn + (size_t)(3 * pl) * pitch;         // rows 3 pl, 3 pl + 1, 3 pl + 2 of the panel
+  double* const rw1 = rw0 + pitch;
+  double* const rw2 = rw1 + pitch;
   if (slot < W) {
-    double* r0 = dyn + (size_t)(3 * pl) * pitch + 6 * slot;
 #pragma unroll
     for (int a = 0; a < 6; a++) {
       const double b0 = o.w * (o.Jp[0][a] * o.Jl[0][0] + o.Jp[1][a] * o.Jl[1][0]);
       const double b1 = o.w * (o.Jp[0][a] * o.Jl[0][1] + o.Jp[1][a] * o.Jl[1][1]);
       const double b2 = o.w * (o.Jp[0][a] * o.Jl[0][2] + o.Jp[1][a] * o.Jl[1][2]);
-      r0[a] = b0 * i00;                                   // Y[a][0] = B[a][0] Cinv[0][0]
-      r0[pitch + a] = b0 * i10 + b1 * i11;                // Y[a][1]
-      r0[2 * pitch + a] = b0 * i20 + b1 * i21 + b2 * i22; // Y[a][2]
+      rw0[6 * slot + a] = b0 * i00;                                   // Y[a][0] = B[a][0] Cinv[0][0]
+      rw1[6 * slot + a] = b0 * i10 + b1 * i11;                        // Y[a][1]
+      rw2[6 * slot + a] = b0 * i20 + b1 * i21 + b2 * i22;             // Y[a][2]
     }
   }
   if (slot == 0) {
-    double* r0 = dyn + (size_t)(3 * pl) * pitch;
     const bool in = j < N;
-    r0[6 * W] = in ? y0 : 0.0; r0[pitch + 6 * W] = in ? y1 : 0.0; r0[2 * pitch + 6 * W] = in ? y2 : 0.0;
-    for (int cidx = 6 * W + 1; cidx < P.RP; cidx++) { r0[cidx] = 0; r0[pitch + cidx] = 0; r0[2 * pitch + cidx] = 0; }
+    rw0[6 * W] = in ? y0 : 0.0; rw1[6 * W] = in ? y1 : 0.0; rw2[6 * W] = in ? y2 : 0.0;
+    for (int cidx = 6 * W + 1; cidx < P.RP; cidx++) { rw0[cidx] = 0; rw1[cidx] = 0; rw2[cidx] = 0; }
   }
   __syncthreads();
   // ---- Gram matrix of the panel: upper 16x16 tiles, one wave per tile, v_mfma_f64_16x16x4_f64 ----
@@ -1157,6 +1160,7 @@ static void ba_geometry(vo_ba_ws* b, int W, int N) {
   b->nblk = vo_div_up(N, b->PPB);
   b->RP = ((6 * W + 1 + 15) / 16) * 16; b->RT = b->RP / 16; b->n_tiles = b->RT * (b->RT + 1) / 2;
   b->pitch = b->RP + BA_PITCH_PAD;
+  if (const char* e = getenv("VO_BA_PAD")) b->pitch = b->RP + atoi(e);      // experiment knob
   const size_t panel = sizeof(double) * (size_t)3 * b->PPB * b->pitch;
   const size_t scratch = sizeof(double) * (size_t)(b->tpb / 64) * b->LPP * BA_POSE_VALS;
   b->build_lds = panel > scratch ? panel : scratch;
