@@ -56,8 +56,9 @@ def parse():
     ap.add_argument("--host-threads", type=int, default=3, help="enqueue/fetch the contexts from this many host threads")
     ap.add_argument("--fixed-ba-budget", action="store_true",
                     help="always enqueue --ba-iters LM iterations (default: what the last fetched frame needed, + 2 after a frame that hit its budget)")
-    ap.add_argument("--side-stream", choices=("on", "off"), default="on",
-                    help="Shi-Tomasi + DLT of a step on a side stream beside the BA (on: +1-2 %% with three contexts, +10-20 %% with one)")
+    ap.add_argument("--side-stream", choices=("on", "off", "pipeline"), default="on",
+                    help="Shi-Tomasi + DLT of a step on a side stream beside the BA (on: +1-2 %% with three contexts, +10-20 %% with one); "
+                         "pipeline: also the BA of frame t beside the front end of frame t + 1 (three streams)")
     ap.add_argument("--workload", choices=("A", "config5", "pipeline"), default="A",
                     help="A: BASELINE configs[2], the metric's configuration (default).  config5: ONE 1920x1080 sequence, 5000 "
                          "points, 20-frame BA whose landmarks are sharded over the ranks with an RCCL all-reduce per LM "
@@ -407,8 +408,14 @@ def measure_extras(device, frame_sets, a):
         return time.perf_counter() - t0
     g = Group(device, frame_sets, seed0=7000, batch=1, ba_iters=a.ba_iters)
     dt = run(g, 300)
+    side = {"frames_per_s": round(300 / dt, 1), "ms_per_frame": round(dt / 300 * 1e3, 4), "stream_layout": "side stream (re-detection + triangulation beside the BA)"}
+    # the layout meant for ONE sequence: three streams, the BA of frame t beside the pyramid + KLT of frame t + 1 (vo_set_side_stream 2)
+    g.c.set_side_stream("pipeline")
+    dt = run(g, 300)
     out["single_sequence"] = {"frames_per_s": round(300 / dt, 1), "ms_per_frame": round(dt / 300 * 1e3, 4), "sequences": 1, "contexts": 1,
-                              "workload": WORKLOAD}
+                              "workload": WORKLOAD, "stream_layout": "pipeline (three streams: BA of frame t beside the front end of frame t + 1)",
+                              "side_stream_layout": side}
+    g.c.set_side_stream(True)
     kl = {}
     for batch in (1, 32):
         gk = g if batch == 1 else Group(device, frame_sets, seed0=7100, batch=32, ba_iters=a.ba_iters)
@@ -562,7 +569,7 @@ def main():
         seqs = [Group(dist.local_rank, frame_sets, seed0=1000 * dist.rank + 100 * i, batch=per[i], ba_iters=a.ba_iters, pipeline=pl)
                 for i in range(a.ctxs)]
     t_setup = time.perf_counter() - t_gen
-    side = a.side_stream == "on"
+    side = {"on": 1, "off": 0, "pipeline": 2}[a.side_stream]
     for s in seqs:
         s.c.set_side_stream(side)
         s.c.set_graph_mode(bool(a.graph))
@@ -684,7 +691,7 @@ def main():
                           "ba_lm_iteration_budget": a.ba_iters, "ba_lm_iterations_run": ba_stats["iters"],
                           "ba_final_cost": round(ba_stats["cost"], 4), "ba_initial_cost": round(ba_stats["cost0"], 2),
                           "launch": "hipGraph replay" if a.graph else "plain", "ba_budget": "fixed" if a.fixed_ba_budget else "adaptive (last frame's maximum; + 2 after a truncated solve)",
-                          "ba_budget_truncated_solves": n_trunc, "side_stream": bool(side), "host_threads": max(a.host_threads, 1),
+                          "ba_budget_truncated_solves": n_trunc, "side_stream": a.side_stream, "host_threads": max(a.host_threads, 1),
                           "sequences_per_gpu": a.seqs, "batched_contexts_per_gpu": a.ctxs,
                           "frames_per_step": 1 if c5 else a.seqs * dist.world,
                           "parallelism": ("one sequence, BA landmarks sharded over %d GPU(s), RCCL all-reduce of the reduced camera "

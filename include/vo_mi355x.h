@@ -374,8 +374,11 @@ int32_t vo_frame_fetch(vo_ctx* ctx, int32_t n_pts, float* p, uint8_t* status, fl
                        double* depth1, double* reproj, double* poses, double* points, vo_ba_stats* stats,
                        float* corners, int32_t* n_corners);
 int32_t vo_set_graph_mode(vo_ctx* ctx, int32_t on);
-/* Re-detection + triangulation of vo_frame_step_resident on a side stream beside the bundle adjustment (default on; environment
- * VO_SIDE_STREAM sets the default): +10-20 % for one context, +1-2 % with three.  Fetch the steps in flight first. */
+/* Stream layout of vo_frame_step_resident.  0: one stream.  1 (default; environment VO_SIDE_STREAM sets the default): re-detection +
+ * triangulation on a side stream beside the bundle adjustment (+10-20 % for one context, +1-2 % with three).  2: pipelined, three
+ * streams -- pyramid + KLT | re-detection + triangulation | bundle adjustment -- so that the bundle adjustment of frame t also runs
+ * beside the front end of frame t + 1 when two steps are in flight (ONE sequence: 3 400 -> 4 250 frames/s; three batched contexts lose
+ * 2 %).  Results are identical in every layout.  Fetch the steps in flight first. */
 int32_t vo_set_side_stream(vo_ctx* ctx, int32_t on);
 
 /* ---- in-stream timing (hipEvent pairs recorded on the ctx stream around a region's launches) -----

@@ -56,17 +56,21 @@ def test_frame_step_matches_individual_calls(graph, block_size):
             assert np.array_equal(got["corners"], corners), k
 
 
-def test_two_steps_in_flight_match_one_at_a_time():
+@pytest.mark.parametrize("layout", [1, "pipeline"])
+def test_two_steps_in_flight_match_one_at_a_time(layout):
     """step t + 1 may be enqueued before step t is fetched (alternating pinned mirrors); results are those of the
-    one-at-a-time loop, fetched oldest first; a third step without a fetch is refused"""
+    one-at-a-time loop on ONE stream, fetched oldest first; a third step without a fetch is refused.  layout 1: re-detection and
+    triangulation on a side stream; "pipeline": three streams, the bundle adjustment of frame t runs beside the pyramid and the
+    KLT of frame t + 1 (vo_set_side_stream(ctx, 2))"""
     from vo_mi355x import VoContext, VoError, synthetic as syn
     w, h, n, n_new = 640, 240, 600, 200
     frames, _ = syn.make_sequence(5, w=w, h=h, seed=23, margin=64)
     pts = syn.grid_points(n, w, h, seed=5)
     scene = syn.make_ba_scene(n_pts=300, n_slots=6, seed=3, visibility=0.9)
-    order = [1, 2, 3, 4, 3, 2, 1, 0]
+    order = [1, 2, 3, 4, 3, 2, 1, 0] * 3
     keys = ("points2d", "status", "err", "X4", "depth1", "reproj", "poses", "landmarks", "corners")
     with VoContext(w, h, max_pts=1024) as c:
+        c.set_side_stream(False)
         _setup(c, frames, pts, scene, n_new)
         bap = c.ba_params(max_iters=6)
         ref = []
@@ -74,6 +78,7 @@ def test_two_steps_in_flight_match_one_at_a_time():
             c.frame_step_resident(f, n, ba=bap)
             ref.append(c.frame_fetch())
     with VoContext(w, h, max_pts=1024) as c:
+        c.set_side_stream(layout)
         _setup(c, frames, pts, scene, n_new)
         bap = c.ba_params(max_iters=6)
         got = []

@@ -1268,6 +1268,7 @@ extern "C" int32_t vo_ba_upload(vo_ctx* c, const double* K, const double* poses,
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, K && poses && points && obs, VO_E_INVALID, "null buffer");
   VO_HIP(c, hipSetDevice(c->device));
+  if (c->stream3) VO_HIP(c, hipStreamSynchronize(c->stream3));     // a pipelined frame step runs its bundle adjustment there
   int32_t r = ba_alloc(c, n_slots, n_pts);
   if (r != VO_OK) return r;
   vo_ba_ws* b = c->ba;
@@ -1337,6 +1338,8 @@ extern "C" int32_t vo_ba_solve_resident(vo_ctx* c, const vo_ba_params* prm) {
   if (r != VO_OK) return r;
   vo_ba_ws* b = c->ba;
   const ba_ptrs P = ba_make_ptrs(c);
+  // pipelined frame step: the copy of the PREVIOUS solution runs on another stream; it must have left d_pub before this one lands there
+  if (c->ba_wait_before_publish) VO_HIP(c, hipStreamWaitEvent(c->stream, c->ba_wait_before_publish, 0));
   ba_launch_finalize(c, P, d, prm->max_iters, b->d_state + (prm->max_iters & 1), 2);
   VO_HIP(c, hipGetLastError());
   return VO_OK;

@@ -298,6 +298,7 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);   // side branch of the frame step (an error path may have left it unjoined)
+  if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   (void)vo_comm_destroy(c);
   vo_trk_destroy(c);
   vo_pnp_destroy(c);
@@ -321,6 +322,8 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->stream3) (void)hipStreamDestroy(c->stream3);
+  for (int k = 0; k < 2; k++) { if (c->ev_ba[k]) (void)hipEventDestroy(c->ev_ba[k]); if (c->ev_pub[k]) (void)hipEventDestroy(c->ev_pub[k]); if (c->ev_copy1[k]) (void)hipEventDestroy(c->ev_copy1[k]); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return VO_OK;
@@ -357,6 +360,7 @@ extern "C" int32_t vo_ctx_create_batched(int32_t device, int32_t width, int32_t 
   CR(hipSetDevice(device));
   CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   CR(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+
   if (const char* e = getenv("VO_SIDE_STREAM")) c->side_stream = atoi(e) != 0;
   CR(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   CR(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -417,6 +421,8 @@ extern "C" int32_t vo_sync(vo_ctx* c) {
   if (!c) return VO_E_INVALID;
   VO_HIP(c, hipSetDevice(c->device));
   VO_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->stream2) VO_HIP(c, hipStreamSynchronize(c->stream2));     // branches of a frame step that has not been fetched
+  if (c->stream3) VO_HIP(c, hipStreamSynchronize(c->stream3));
   return VO_OK;
 }
 
@@ -483,6 +489,7 @@ extern "C" int32_t vo_seq_upload(vo_ctx* c, const uint8_t* frames, int32_t n_fra
   VO_HIP(c, hipSetDevice(c->device));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   if (c->stream2) VO_HIP(c, hipStreamSynchronize(c->stream2));
+  if (c->stream3) VO_HIP(c, hipStreamSynchronize(c->stream3));
   if (c->d_seq) { VO_HIP(c, hipFree(c->d_seq)); c->d_seq = nullptr; c->seq_n = 0; }
   const size_t bytes = (size_t)c->width * c->height * n_frames * c->batch;
   VO_HIP(c, hipMalloc((void**)&c->d_seq, bytes));

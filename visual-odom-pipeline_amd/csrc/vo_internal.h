@@ -44,6 +44,12 @@ struct vo_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;     // side stream of the fused frame step: Shi-Tomasi runs beside DLT + BA (fork / join by events)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t stream3 = nullptr;     // pipelined frame step (vo_set_side_stream(c, 2)): the bundle adjustment of frame t runs here beside the front end of frame t + 1
+  hipEvent_t ev_ba[2] = {nullptr, nullptr};     // the BA of the step using half k has published its solution (d_pub)
+  hipEvent_t ev_copy1[2] = {nullptr, nullptr};  // the KLT results of the step using half k have left the device (copy on stream A)
+  hipEvent_t ev_pub[2] = {nullptr, nullptr};    // ... and the copy of it (on stream2) has left the device: the next k_ba_finalize may overwrite d_pub
+  hipEvent_t ba_wait_before_publish = nullptr;  // set by the pipelined step around vo_ba_solve_resident
+  bool pub_copy_pending = false;                // a pipelined step has recorded ev_pub at least once
   // loader pre-filter (vo_set_prefilter): cv2.bilateralFilter taps applied while a frame enters the frame store
   int bil_maxk = 0;                  // 0 = off
   signed char bil_dx[49], bil_dy[49];

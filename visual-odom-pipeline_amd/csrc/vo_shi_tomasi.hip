@@ -1143,6 +1143,7 @@ extern "C" int32_t vo_shi_tomasi_read(vo_ctx* c, float* eig_out, uint8_t* mask_o
   VO_HIP(c, hipSetDevice(c->device));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   if (c->stream2) VO_HIP(c, hipStreamSynchronize(c->stream2));
+  if (c->stream3) VO_HIP(c, hipStreamSynchronize(c->stream3));
   const size_t np = (size_t)c->width * c->height * c->batch;
   if (eig_out) VO_HIP(c, hipMemcpy(eig_out, c->st->d_eig, np * sizeof(float), hipMemcpyDeviceToHost));
   if (mask_out) VO_HIP(c, hipMemcpy(mask_out, c->st->d_mask, np, hipMemcpyDeviceToHost));

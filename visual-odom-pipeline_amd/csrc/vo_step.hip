@@ -7,7 +7,28 @@
 // bundle-adjust -> re-detect), with the Python object bookkeeping left to the caller.
 #include "vo_internal.h"
 
+#include <stdlib.h>
 #include <string.h>
+
+#include <vector>
+#include <stdio.h>
+static std::vector<hipEvent_t> g_tr;      // VO_STEP_TRACE: (start, end) of the bundle adjustment of every pipelined step on stream C
+static std::vector<hipEvent_t> g_ta;      // ... and (start, end) of the front end (pyramid, KLT, copy) on stream A
+static std::vector<hipEvent_t> g_tb;      // ... (after the pyramid, after the KLT)
+extern "C" void vo_debug_step_trace_dump() {
+  for (size_t i = 400; i + 3 < g_tr.size() && i + 3 < g_ta.size() && i < 424; i += 2) {
+    float d = 0, gap = 0, a0 = 0, a1 = 0;
+    (void)hipEventElapsedTime(&d, g_tr[i], g_tr[i + 1]);
+    (void)hipEventElapsedTime(&gap, g_tr[i + 1], g_tr[i + 2]);
+    (void)hipEventElapsedTime(&a0, g_tr[i], g_ta[i + 2]);          // start of the NEXT step's front end relative to this BA's start
+    (void)hipEventElapsedTime(&a1, g_tr[i], g_ta[i + 3]);
+    float b0 = 0, b1 = 0;
+    (void)hipEventElapsedTime(&b0, g_tr[i], g_tb[i + 2]);
+    (void)hipEventElapsedTime(&b1, g_tr[i], g_tb[i + 3]);
+    fprintf(stderr, "step %zu: BA %.1f us, idle until the next BA starts %.1f us; next front end: start %.1f, pyramid done %.1f, KLT done %.1f, copy done %.1f us after this BA started\n",
+            i / 2, d * 1e3, gap * 1e3, a0 * 1e3, b0 * 1e3, b1 * 1e3, a1 * 1e3);
+  }
+}
 
 struct step_cfg {
   int n_pts, do_dlt, do_ba, do_st, mask_radius;
@@ -16,15 +37,69 @@ struct step_cfg {
   vo_ba_params ba;
 };
 
-// enqueue everything of one frame on the ctx stream (also used under stream capture)
-static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame_idx, int frame_idx, int half) {
+// enqueue everything of one frame on the ctx stream (also used under stream capture); *recorded: ev_step[half] has been recorded
+static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame_idx, int frame_idx, int half, bool* recorded) {
   int32_t r;
+  *recorded = false;
+  static const bool trace_a = getenv("VO_STEP_TRACE") != nullptr;
+  if (trace_a && c->side_stream == 2 && g_ta.size() < 4000) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); g_ta.push_back(e); }
   const size_t fr = (size_t)c->width * c->height;
   if (d_frame_idx) r = vo_build_pyramid(c, c->d_seq, fr * c->seq_n, d_frame_idx);
   else r = vo_build_pyramid(c, c->d_seq + (size_t)frame_idx * fr, fr * c->seq_n, nullptr);
   if (r != VO_OK) return r;
+  if (trace_a && c->side_stream == 2 && g_tb.size() < 6000) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); g_tb.push_back(e); }
   r = vo_klt_track_resident(c, s.n_pts, &s.klt);
   if (r != VO_OK) return r;
+  if (trace_a && c->side_stream == 2 && g_tb.size() < 6000) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); g_tb.push_back(e); }
+  uint8_t* const h_dst = c->h_slab + (size_t)half * c->slab_bytes;
+  if (c->side_stream == 2 && s.do_ba && !d_frame_idx) {
+    // ---- pipelined layout: three in-order streams.  A (c->stream): pyramid, KLT and the copy of the KLT results -- then it is free
+    // for the NEXT frame's front end; B (stream2): re-detection, triangulation and the copy of their results; C (stream3): the
+    // bundle adjustment and the copy of its solution.  B waits for C at the end, ev_step[half] is recorded on B.  What makes it
+    // safe with two steps in flight: the KLT results of step t leave the device on A before KLT(t + 1) can overwrite status / err;
+    // B's and C's outputs are copied on B / C before step t + 1's kernels on the same stream; step t + 2 (which overwrites the
+    // frame buffer and the point buffer B reads) is not enqueued before step t has been fetched. ----
+    const size_t part1 = c->off_X4;
+    // the fork comes BEFORE A's result copy: device-to-host copies of all streams pass through the copy engine in submission
+    // order, and the copies of the previous step (submitted earlier, waiting for ITS bundle adjustment) would hold this one -- and
+    // with it the start of this step's bundle adjustment -- until that BA has finished (measured: 185 us of a 250 us frame)
+    VO_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+    VO_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    VO_HIP(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+    if (c->batch == 1) VO_HIP(c, hipMemcpyAsync(h_dst, c->d_slab, part1, hipMemcpyDeviceToHost, c->stream));
+    else VO_HIP(c, hipMemcpy2DAsync(h_dst, c->slab_seq, c->d_slab, c->slab_seq, part1, c->batch, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipEventRecord(c->ev_copy1[half], c->stream));
+    if (trace_a && g_ta.size() < 4000) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); g_ta.push_back(e); }
+    hipStream_t main_stream = c->stream;
+    c->stream = c->stream3;
+    static const bool trace = getenv("VO_STEP_TRACE") != nullptr;      // debug: GPU-side timeline of stream C, printed by vo_debug_step_trace_dump
+    if (trace && g_tr.size() < 4000) { hipEvent_t e0; (void)hipEventCreate(&e0); (void)hipEventRecord(e0, c->stream3); g_tr.push_back(e0); }
+    // C carries nothing but the LM iterations and k_ba_finalize: the copy of the solution goes to B (behind ev_ba), so that the next
+    // frame's iterations follow this frame's directly; k_ba_finalize of the next step waits for that copy (ev_pub) -- long done by then
+    c->ba_wait_before_publish = c->pub_copy_pending ? c->ev_pub[half ^ 1] : nullptr;
+    r = vo_ba_solve_resident(c, &s.ba);
+    c->ba_wait_before_publish = nullptr;
+    hipError_t e = hipEventRecord(c->ev_ba[half], c->stream3);
+    if (trace && g_tr.size() < 4000) { hipEvent_t e1; (void)hipEventCreate(&e1); (void)hipEventRecord(e1, c->stream3); g_tr.push_back(e1); }
+    c->stream = c->stream2;
+    if (r == VO_OK && s.do_st) r = vo_shi_tomasi_resident(c, s.n_pts, s.mask_radius, &s.st);
+    if (r == VO_OK && s.do_dlt) r = vo_dlt_resident(c);
+    if (e == hipSuccess) e = (c->batch == 1) ? hipMemcpyAsync(h_dst + part1, c->d_slab + part1, c->slab_seq - part1, hipMemcpyDeviceToHost, c->stream2)
+                                             : hipMemcpy2DAsync(h_dst + part1, c->slab_seq, c->d_slab + part1, c->slab_seq, c->slab_seq - part1, c->batch,
+                                                                hipMemcpyDeviceToHost, c->stream2);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream2, c->ev_copy1[half], 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream2, c->ev_ba[half], 0);
+    if (r == VO_OK && e == hipSuccess) r = vo_ba_enqueue_pub_copy(c, half);      // on B (c->stream is stream2 here)
+    if (e == hipSuccess) e = hipEventRecord(c->ev_pub[half], c->stream2);
+    c->pub_copy_pending = true;
+    c->stream = main_stream;
+    if (e == hipSuccess) e = hipEventRecord(c->ev_step[half], c->stream2);
+    if (r != VO_OK) return r;
+    VO_HIP(c, e);
+    *recorded = true;
+    c->step_off_p[half] = vo_off_p(c);
+    return VO_OK;
+  }
   // Re-detection needs only the new frame and the tracked points, DLT + BA only the tracked points: the two branches
   // run side by side (the BA iterations are chains of narrow latency-bound launches, Shi-Tomasi is wide streaming
   // kernels).  Under graph capture everything stays on the one captured stream.
@@ -57,7 +132,7 @@ static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame
   if (s.do_ba) { r = vo_ba_solve_resident(c, &s.ba); if (r != VO_OK) { (void)join(); return r; } }
   if (fork) VO_HIP(c, join());
   else if (s.do_st) { r = vo_shi_tomasi_resident(c, s.n_pts, s.mask_radius, &s.st); if (r != VO_OK) return r; }
-  VO_HIP(c, hipMemcpyAsync(c->h_slab + (size_t)half * c->slab_bytes, c->d_slab, c->slab_bytes, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipMemcpyAsync(h_dst, c->d_slab, c->slab_bytes, hipMemcpyDeviceToHost, c->stream));
   if (s.do_ba) { r = vo_ba_enqueue_pub_copy(c, half); if (r != VO_OK) return r; }
   c->step_off_p[half] = vo_off_p(c);
   return VO_OK;
@@ -106,9 +181,10 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
   const int half = c->use_graph ? 0 : (int)(c->steps_enq & 1);
   const bool graph_ok = c->use_graph && c->prof.mask == 0 && c->n_pushed >= 2;
   if (!graph_ok) {
-    const int32_t r = step_enqueue(c, s, nullptr, frame_idx, half);
+    bool recorded = false;
+    const int32_t r = step_enqueue(c, s, nullptr, frame_idx, half, &recorded);
     if (r != VO_OK) return r;
-    VO_HIP(c, hipEventRecord(c->ev_step[half], c->stream));
+    if (!recorded) VO_HIP(c, hipEventRecord(c->ev_step[half], c->stream));
     c->steps_enq++;
     return VO_OK;
   }
@@ -121,7 +197,8 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
     hipGraph_t g = nullptr;
     const int cur0 = c->cur, pushed0 = c->n_pushed, parity0 = c->p_parity;
     VO_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    const int32_t r = step_enqueue(c, s, c->d_frame_idx, frame_idx, 0);
+    bool recorded = false;
+    const int32_t r = step_enqueue(c, s, c->d_frame_idx, frame_idx, 0, &recorded);
     const hipError_t e = hipStreamEndCapture(c->stream, &g);
     if (r != VO_OK || e != hipSuccess) {
       // nothing was launched: undo what the enqueue functions did to the host-side frame / point parities
@@ -169,6 +246,8 @@ extern "C" int32_t vo_frame_fetch(vo_ctx* c, int32_t n_pts, float* p, uint8_t* s
     VO_CHECK(c, c->steps_enq > 0, VO_E_STATE, "no step to fetch");
     half = c->use_graph ? 0 : (int)((c->steps_enq - 1) & 1);
     VO_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->stream2) VO_HIP(c, hipStreamSynchronize(c->stream2));
+    if (c->stream3) VO_HIP(c, hipStreamSynchronize(c->stream3));
   }
   const size_t off_p = c->step_off_p[half];
   const int mc = vo_st_last_max_corners(c) > 0 ? vo_st_last_max_corners(c) : 4096;
@@ -198,7 +277,25 @@ extern "C" int32_t vo_frame_fetch(vo_ctx* c, int32_t n_pts, float* p, uint8_t* s
 extern "C" int32_t vo_set_side_stream(vo_ctx* c, int32_t on) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->steps_enq == c->steps_fetched, VO_E_STATE, "fetch the steps in flight before switching the stream layout");
-  c->side_stream = on ? 1 : 0;
+  if (on == 2 && !c->stream3) {
+    // created on demand: streams share the hardware queues, and a third (idle) stream per context re-deals which of them share one --
+    // three batched contexts lost 10 % of their throughput to it
+    VO_HIP(c, hipSetDevice(c->device));
+    {
+      int lo = 0, hi = 0;
+      VO_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+      static const int prio = getenv("VO_BA_STREAM_PRIO") ? atoi(getenv("VO_BA_STREAM_PRIO")) : 0;   // experiment knob: 1 = highest
+      if (prio) VO_HIP(c, hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, hi));
+      else VO_HIP(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    }
+    VO_HIP(c, hipEventCreateWithFlags(&c->ev_ba[0], hipEventDisableTiming));
+    VO_HIP(c, hipEventCreateWithFlags(&c->ev_ba[1], hipEventDisableTiming));
+    VO_HIP(c, hipEventCreateWithFlags(&c->ev_pub[0], hipEventDisableTiming));
+    VO_HIP(c, hipEventCreateWithFlags(&c->ev_pub[1], hipEventDisableTiming));
+    VO_HIP(c, hipEventCreateWithFlags(&c->ev_copy1[0], hipEventDisableTiming));
+    VO_HIP(c, hipEventCreateWithFlags(&c->ev_copy1[1], hipEventDisableTiming));
+  }
+  c->side_stream = (on == 2) ? 2 : (on ? 1 : 0);      // 2: pipelined (BA of frame t beside the front end of frame t + 1)
   return VO_OK;
 }
 

@@ -268,8 +268,11 @@ class VoContext:
         self._ck(self._L.vo_set_graph_mode(self._h, 1 if on else 0))
 
     def set_side_stream(self, on=True):
-        """re-detection + triangulation of the fused step on a side stream beside the bundle adjustment (default) or in line"""
-        self._ck(self._L.vo_set_side_stream(self._h, 1 if on else 0))
+        """re-detection + triangulation of the fused step on a side stream beside the bundle adjustment (True / 1, default) or in
+        line (False / 0); 2 or "pipeline": three streams -- the bundle adjustment of frame t also runs beside the front end of
+        frame t + 1 (two steps in flight)"""
+        mode = 2 if on in (2, "pipeline") else (1 if on else 0)
+        self._ck(self._L.vo_set_side_stream(self._h, mode))
 
     def frame_step_resident(self, frame_idx, n_pts, do_dlt=True, do_ba=True, do_st=True, mask_radius=7,
                             klt=None, st=None, ba=None):
