@@ -364,8 +364,12 @@ extern "C" int32_t vo_ctx_create_batched(int32_t device, int32_t width, int32_t 
   if (const char* e = getenv("VO_SIDE_STREAM")) c->side_stream = atoi(e) != 0;
   CR(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   CR(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-  CR(hipEventCreateWithFlags(&c->ev_step[0], hipEventDisableTiming));
-  CR(hipEventCreateWithFlags(&c->ev_step[1], hipEventDisableTiming));
+  {
+    // VO_BLOCKING_SYNC=1: vo_frame_fetch sleeps in the driver instead of spinning on the step's event (for more host threads than cores)
+    const unsigned fl = hipEventDisableTiming | ((getenv("VO_BLOCKING_SYNC") && atoi(getenv("VO_BLOCKING_SYNC"))) ? hipEventBlockingSync : 0u);
+    CR(hipEventCreateWithFlags(&c->ev_step[0], fl));
+    CR(hipEventCreateWithFlags(&c->ev_step[1], fl));
+  }
   // pyramid geometry (buildOpticalFlowPyramid truncation rule)
   int w = width, h = height, top = 0;
   for (int l = 0; l <= max_level; l++) {
