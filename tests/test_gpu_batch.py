@@ -79,3 +79,21 @@ def test_batched_context_equals_single_contexts(B):
                 assert np.array_equal(got["poses"][b], r["poses"]) and np.array_equal(got["landmarks"][b], r["landmarks"])
                 assert got["ba_stats"][b]["cost"] == r["ba_stats"]["cost"]
                 assert np.array_equal(got["corners"][b], r["corners"])
+        # the same steps again in the pipelined stream layout with two steps in flight (strided result copies of a batch)
+        c.set_side_stream("pipeline")
+        c.points_upload(np.stack(pts))
+        c.push_frame_resident(0)
+        order = (1, 2, 3, 2)
+        got_all = []
+        c.frame_step_resident(order[0], n, ba=c.ba_params(max_iters=5))
+        for f in order[1:]:
+            c.frame_step_resident(f, n, ba=c.ba_params(max_iters=5))
+            got_all.append(c.frame_fetch())
+        got_all.append(c.frame_fetch())
+        for k, got in enumerate(got_all):
+            for b in range(B):
+                r = ref[b][5][k]
+                assert np.array_equal(got["points2d"][b], r["points2d"]) and np.array_equal(got["status"][b], r["status"]), (k, b)
+                assert np.array_equal(got["err"][b], r["err"]) and np.array_equal(got["X4"][b], r["X4"], equal_nan=True)
+                assert np.array_equal(got["poses"][b], r["poses"]) and np.array_equal(got["landmarks"][b], r["landmarks"])
+                assert np.array_equal(got["corners"][b], r["corners"]), (k, b)
