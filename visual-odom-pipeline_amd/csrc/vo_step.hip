@@ -281,13 +281,7 @@ extern "C" int32_t vo_set_side_stream(vo_ctx* c, int32_t on) {
     // created on demand: streams share the hardware queues, and a third (idle) stream per context re-deals which of them share one --
     // three batched contexts lost 10 % of their throughput to it
     VO_HIP(c, hipSetDevice(c->device));
-    {
-      int lo = 0, hi = 0;
-      VO_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-      static const int prio = getenv("VO_BA_STREAM_PRIO") ? atoi(getenv("VO_BA_STREAM_PRIO")) : 0;   // experiment knob: 1 = highest
-      if (prio) VO_HIP(c, hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, hi));
-      else VO_HIP(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
-    }
+    VO_HIP(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));     // (a highest-priority stream for the BA chain: no difference)
     VO_HIP(c, hipEventCreateWithFlags(&c->ev_ba[0], hipEventDisableTiming));
     VO_HIP(c, hipEventCreateWithFlags(&c->ev_ba[1], hipEventDisableTiming));
     VO_HIP(c, hipEventCreateWithFlags(&c->ev_pub[0], hipEventDisableTiming));
