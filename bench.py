@@ -234,9 +234,8 @@ class Group:
         if self.pipeline:
             rv, tv, inl, pst = self.c.pnp_fetch()                  # waits for the frame
             po, pt, bst = self.c.ba_fetch()
-            tr = self.c.tracks_read()
-            tr = tr if isinstance(tr, list) else [tr]
-            self.last = {"ba_stats": bst, "pnp_stats": pst, "n_tracks": [len(x["tag"]) for x in tr]}
+            nl, _ = self.c.tracks_counts()                         # the tables stay on the device; the loop needs the counters
+            self.last = {"ba_stats": bst, "pnp_stats": pst, "n_tracks": list(np.atleast_1d(nl))}
         else:
             self.last = self.c.frame_fetch()
         self.inflight -= 1

@@ -533,6 +533,15 @@ class VoContext:
                     t_total=tt[b, :n[b]].copy(), tag=tag[b, :n[b]].copy(), dead_tag=dead[b, :nd[b]].copy()) for b in range(B)]
         return out[0] if B == 1 else out
 
+    def tracks_counts(self):
+        """-> (n_live, n_dead) per sequence [(B,) int32 each; ints if batch == 1]: the synchronous read-back of the counters only
+        (vo_tracks_read with NULL tables) -- what a per-frame loop needs when the tables stay on the device"""
+        B = self.batch
+        n, nd = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        i = C.c_int32
+        self._ck(self._L.vo_tracks_read(self._h, ptr(n, i), None, None, None, None, None, ptr(nd, i), None))
+        return (int(n[0]), int(nd[0])) if B == 1 else (n, nd)
+
     def tracks_obs(self, t_now, window):
         """BA observation table of the live tracks -> (B, window, max_pts, 2) f64 [(window, max_pts, 2) if batch == 1]."""
         obs = np.zeros((self.batch, window, self.max_pts, 2))
