@@ -34,6 +34,7 @@
 #include "vo_internal.h"
 
 #include <math.h>
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
@@ -142,27 +143,28 @@ struct vo_ba_ws {
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void d_rodrigues(const double* r, double* R) {
-  const double th = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+// R (Rodrigues), t and the right Jacobian of SO(3) (R(r + dr) ~ R(r) Exp(Jr dr)) of one pose: 21 doubles, ONE sincos -- the trial
+// cameras are on k_ba_solve's critical path, computed by W lanes
+__device__ __forceinline__ void d_camera(const double* p, double* cam) {
+  const double x = p[0], y = p[1], z = p[2];
+  const double th2 = x * x + y * y + z * z;
+  const double th = sqrt(th2);
+  double sn, cs;
+  sincos(th, &sn, &cs);
+  double* R = cam;
   if (th < 2.220446049250313e-16) {
     R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
-    return;
+  } else {
+    const double kx = x / th, ky = y / th, kz = z / th, c1 = 1.0 - cs;
+    R[0] = cs + c1 * kx * kx;      R[1] = c1 * kx * ky - sn * kz; R[2] = c1 * kx * kz + sn * ky;
+    R[3] = c1 * ky * kx + sn * kz; R[4] = cs + c1 * ky * ky;      R[5] = c1 * ky * kz - sn * kx;
+    R[6] = c1 * kz * kx - sn * ky; R[7] = c1 * kz * ky + sn * kx; R[8] = cs + c1 * kz * kz;
   }
-  const double kx = r[0] / th, ky = r[1] / th, kz = r[2] / th;
-  const double c = cos(th), s = sin(th), c1 = 1.0 - c;
-  R[0] = c + c1 * kx * kx;      R[1] = c1 * kx * ky - s * kz; R[2] = c1 * kx * kz + s * ky;
-  R[3] = c1 * ky * kx + s * kz; R[4] = c + c1 * ky * ky;      R[5] = c1 * ky * kz - s * kx;
-  R[6] = c1 * kz * kx - s * ky; R[7] = c1 * kz * ky + s * kx; R[8] = c + c1 * kz * kz;
-}
-
-// right Jacobian of SO(3): R(r + dr) ~ R(r) Exp(Jr dr)
-__device__ __forceinline__ void d_right_jacobian(const double* r, double* J) {
-  const double th2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  cam[9] = p[3]; cam[10] = p[4]; cam[11] = p[5];
   double a, b;
   if (th2 < 1e-8) { a = 0.5 - th2 / 24.0; b = 1.0 / 6.0 - th2 / 120.0; }
-  else { const double th = sqrt(th2); a = (1.0 - cos(th)) / th2; b = (th - sin(th)) / (th2 * th); }
-  const double x = r[0], y = r[1], z = r[2];
-  // S = [r]x ; S^2 = r r^T - th2 I
+  else { a = (1.0 - cs) / th2; b = (th - sn) / (th2 * th); }
+  double* J = cam + 12;
   J[0] = 1.0 + b * (x * x - th2); J[1] = a * z + b * x * y;       J[2] = -a * y + b * x * z;
   J[3] = -a * z + b * y * x;      J[4] = 1.0 + b * (y * y - th2); J[5] = a * x + b * y * z;
   J[6] = a * y + b * z * x;       J[7] = -a * x + b * z * y;      J[8] = 1.0 + b * (z * z - th2);
@@ -172,9 +174,7 @@ __device__ __forceinline__ void stage_cameras(const double* poses, int W, double
   for (int i = tid; i < W; i += nthreads) {
     const double* p = poses + 6 * i;
     double* c = cam + BA_CAM * i;
-    d_rodrigues(p, c);
-    c[9] = p[3]; c[10] = p[4]; c[11] = p[5];
-    d_right_jacobian(p, c + 12);
+    d_camera(p, c);
   }
 }
 
@@ -870,50 +870,64 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
   //      broadcasts), then the lanes above the block subtract their 6-term update -> W steps instead of 6W ----
   if (tid < 64) {
     const int lane = tid;
-    double y0 = (lane < n) ? A[(size_t)lane * PT + n] : 0.0;
-    double y1 = (lane + 64 < n) ? A[(size_t)(lane + 64) * PT + n] : 0.0;
-    for (int kb = W - 1; kb >= 0; kb--) {
-      const int c0 = 6 * kb;
-      // every LDS operand of this block first (none depends on the running y): the inverse of the diagonal block (21 entries,
-      // wave-uniform addresses) and this lane's 2 x 6 column entries
-      double Li[6][6], ca[6], cb[6];
-      {
-        int q = 0;
+    // SMALL (n <= 64, W <= 10): every row lives in y0 -- no second row per lane, no choice of the source register per entry
+    auto backsub = [&](auto small_tag) {
+      constexpr bool SMALL = decltype(small_tag)::value;
+      const int la = min(lane, n - 1), lb = min(lane + 64, n - 1);            // clamped rows: the loads are unconditional, masked after
+      double y0 = (lane < n) ? A[(size_t)la * PT + n] : 0.0;
+      double y1 = (!SMALL && lane + 64 < n) ? A[(size_t)lb * PT + n] : 0.0;
+      // the LDS operands of a block do not depend on the running y.  This lane's column entries of the NEXT block are requested
+      // before this block's arithmetic (prefetching the 21 entries of the next diagonal-block inverse as well needs 160 live VGPRs
+      // in a 1024-lane workgroup: it spilled, 14.5 k -> 55 k cycles)
+      double ca[6], cb[6];
+      auto load_cols = [&](const int kb, double (&a)[6], double (&b)[6]) {
+        const int c0 = 6 * kb;
 #pragma unroll
-        for (int e = 0; e < 6; e++)
+        for (int c = 0; c < 6; c++) {
+          const double va = A[(size_t)la * PT + c0 + c];
+          a[c] = (lane < c0) ? va : 0.0;
+          if (!SMALL) { const double vb = A[(size_t)lb * PT + c0 + c]; b[c] = (lane + 64 < c0) ? vb : 0.0; } else b[c] = 0.0;
+        }
+      };
+      load_cols(W - 1, ca, cb);
+      for (int kb = W - 1; kb >= 0; kb--) {
+        const int c0 = 6 * kb;
+        double Li[21];
 #pragma unroll
-          for (int c = 0; c <= e; c++) Li[e][c] = s_linv[21 * kb + q++];
+        for (int q = 0; q < 21; q++) Li[q] = s_linv[21 * kb + q];
+        double nca[6], ncb[6];
+        load_cols(max(kb - 1, 0), nca, ncb);
+        double yb[6], d[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          const int k = c0 + c;
+          if (SMALL) yb[c] = readlane_f64(y0, k);
+          else { const double r0 = readlane_f64(y0, k & 63), r1 = readlane_f64(y1, k & 63); yb[c] = (k < 64) ? r0 : r1; }
+        }
+        // d = L_kk^-T yb: six independent dot products (Li: lower triangle, row-major packed: entry (e, c) at e (e + 1) / 2 + c)
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          double t = Li[(c * (c + 1)) / 2 + c] * yb[c];
+#pragma unroll
+          for (int e = c + 1; e < 6; e++) t += Li[(e * (e + 1)) / 2 + c] * yb[e];
+          d[c] = t;
+        }
+        // rows above the block: y_i -= sum_c L[c0 + c][i] d_c
+#pragma unroll
+        for (int c = 0; c < 6; c++) { y0 -= ca[c] * d[c]; if (!SMALL) y1 -= cb[c] * d[c]; }
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          const int k = c0 + c;
+          if (SMALL) y0 = (lane == k) ? d[c] : y0;
+          else { y0 = (lane == k) ? d[c] : y0; y1 = (lane + 64 == k) ? d[c] : y1; }
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) { ca[c] = nca[c]; cb[c] = ncb[c]; }
       }
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        ca[c] = (lane < c0) ? A[(size_t)lane * PT + c0 + c] : 0.0;
-        cb[c] = (lane + 64 < c0) ? A[(size_t)(lane + 64) * PT + c0 + c] : 0.0;
-      }
-      double yb[6], d[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        const int k = c0 + c;
-        yb[c] = (k < 64) ? readlane_f64(y0, k & 63) : readlane_f64(y1, k & 63);
-      }
-      // d = L_kk^-T yb: six independent dot products
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double t = Li[c][c] * yb[c];
-#pragma unroll
-        for (int e = c + 1; e < 6; e++) t += Li[e][c] * yb[e];
-        d[c] = t;
-      }
-      // rows above the block: y_i -= sum_c L[c0 + c][i] d_c
-#pragma unroll
-      for (int c = 0; c < 6; c++) { y0 -= ca[c] * d[c]; y1 -= cb[c] * d[c]; }
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        const int k = c0 + c;
-        if (lane == (k & 63)) { if (k < 64) y0 = d[c]; else y1 = d[c]; }
-      }
-    }
-    if (lane < n) s_dp[lane] = y0;
-    if (lane + 64 < n) s_dp[lane + 64] = y1;
+      if (lane < n) s_dp[lane] = y0;
+      if (!SMALL && lane + 64 < n) s_dp[lane + 64] = y1;
+    };
+    if (n <= 64) backsub(std::true_type{}); else backsub(std::false_type{});
   }
   __syncthreads();
   VO_STAMP(dbgs, 4);   // back substitution
@@ -928,9 +942,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
 #pragma unroll
     for (int a = 0; a < 6; a++) pt6[a] = pc[a] + (fail ? 0.0 : s_dp[6 * i + a]);
     double* cg = P.cams + ((size_t)(st.cur ^ 1) * W + i) * BA_CAM;
-    d_rodrigues(pt6, cg);
-    cg[9] = pt6[3]; cg[10] = pt6[4]; cg[11] = pt6[5];
-    d_right_jacobian(pt6, cg + 12);
+    d_camera(pt6, cg);
   }
   if (tid < 128) {
     // wave-parallel step statistics of the camera block (lanes = parameters)
