@@ -377,7 +377,7 @@ int32_t vo_set_graph_mode(vo_ctx* ctx, int32_t on);
 /* Stream layout of vo_frame_step_resident.  0: one stream.  1 (default; environment VO_SIDE_STREAM sets the default): re-detection +
  * triangulation on a side stream beside the bundle adjustment (+10-20 % for one context, +1-2 % with three).  2: pipelined, three
  * streams -- pyramid + KLT | re-detection + triangulation | bundle adjustment -- so that the bundle adjustment of frame t also runs
- * beside the front end of frame t + 1 when two steps are in flight (ONE sequence: 3 400 -> 4 250 frames/s; three batched contexts lose
+ * beside the front end of frame t + 1 when two steps are in flight (ONE sequence: 3 600 -> 4 500 frames/s; three batched contexts lose
  * 2 %).  Results are identical in every layout.  Fetch the steps in flight first. */
 int32_t vo_set_side_stream(vo_ctx* ctx, int32_t on);
 
