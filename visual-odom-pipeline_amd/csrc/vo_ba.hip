@@ -567,23 +567,31 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
     }
     const double* base = dyn + (size_t)(lane >> 4) * pitch + (lane & 15);
     d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0;
-    // krows = 3 PPB is a multiple of 8 (PPB = 8, 16 or 32): two k-steps per trip, their 12 LDS reads issued before the 6 MFMAs
-    for (int k0 = 0; k0 < krows; k0 += 8) {
-      double av[2][3], bv[2][3];
+    // krows = 3 PPB is a multiple of 8 (PPB = 8, 16 or 32): two k-steps per trip, their LDS reads issued before the MFMAs.  The
+    // chains of one loop run unconditionally (a conditional MFMA makes the compiler shuttle accumulators between register files);
+    // a wave that owns only one or two tiles in this trip (wave-uniform) takes the loop with that many chains instead of
+    // recomputing tile 0 in the spare ones (10 tiles on 4 waves: waves 2 and 3 issued 36 MFMAs for 24)
+    auto gram = [&](auto nch_tag) {
+      constexpr int NCH = decltype(nch_tag)::value;
+      for (int k0 = 0; k0 < krows; k0 += 8) {
+        double av[2][3], bv[2][3];
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
-        const double* rowp = base + (size_t)(k0 + 4 * q) * pitch;
+        for (int q = 0; q < 2; q++) {
+          const double* rowp = base + (size_t)(k0 + 4 * q) * pitch;
 #pragma unroll
-        for (int u = 0; u < 3; u++) { av[q][u] = rowp[16 * tas[u]]; bv[q][u] = rowp[16 * tbs[u]]; }
+          for (int u = 0; u < NCH; u++) { av[q][u] = rowp[16 * tas[u]]; bv[q][u] = rowp[16 * tbs[u]]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][0], bv[q][0], acc0, 0, 0, 0);
+          if (NCH > 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][1], bv[q][1], acc1, 0, 0, 0);
+          if (NCH > 2) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][2], bv[q][2], acc2, 0, 0, 0);
+        }
       }
-      // all three chains run unconditionally (a wave without a 2nd / 3rd tile recomputes tile 0 and drops it)
-#pragma unroll
-      for (int q = 0; q < 2; q++) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][0], bv[q][0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][1], bv[q][1], acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][2], bv[q][2], acc2, 0, 0, 0);
-      }
-    }
+    };
+    if (on[2]) gram(std::integral_constant<int, 3>{});
+    else if (on[1]) gram(std::integral_constant<int, 2>{});
+    else gram(std::integral_constant<int, 1>{});
 #pragma unroll
     for (int u = 0; u < 3; u++) {
       if (!on[u]) continue;
