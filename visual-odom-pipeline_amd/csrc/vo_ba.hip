@@ -185,9 +185,12 @@ struct ba_obs_lin {
 };
 
 // residual + Jacobian blocks of one observation.  returns false if unobserved.
+// Aout (optional, with WANT_JP = false): the 2 x 3 projection Jacobian d(u, v) / d(camera-frame point) -- with it the caller forms
+// Jp d for a given step d without the 2 x 6 block (k_ba_update)
 template <bool WANT_JP>
 __device__ __forceinline__ bool ba_linearize_obs(const double* __restrict__ K, const double* __restrict__ cam,
-                                                 const double X[3], double uo, double vo, double delta, ba_obs_lin& o) {
+                                                 const double X[3], double uo, double vo, double delta, ba_obs_lin& o,
+                                                 double (*Aout)[3] = nullptr) {
   if (uo != uo) return false;
   const double* R = cam; const double* t = cam + 9; const double* Jr = cam + 12;
   const double xc = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0];
@@ -206,6 +209,10 @@ __device__ __forceinline__ bool ba_linearize_obs(const double* __restrict__ K, c
   double A[2][3];
 #pragma unroll
   for (int c = 0; c < 3; c++) { A[0][c] = (K[c] - u * K[6 + c]) * ip2; A[1][c] = (K[3 + c] - v * K[6 + c]) * ip2; }
+  if (Aout) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) { Aout[0][c] = A[0][c]; Aout[1][c] = A[1][c]; }
+  }
 #pragma unroll
   for (int k = 0; k < 2; k++)
 #pragma unroll
@@ -1036,11 +1043,17 @@ __global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs Pall, ba_params_dev p
   if (j < N) {
     if (slot < W) {
       ba_obs_lin o;
-      if (ba_linearize_obs<true>(s_K, s_cam + BA_CAM * slot, X, uo, vo, prm.delta, o)) {
+      double Aj[2][3];
+      if (ba_linearize_obs<false>(s_K, s_cam + BA_CAM * slot, X, uo, vo, prm.delta, o, Aj)) {
+        // Jp d without forming Jp = [-Jl [X]x Jr | A]:  Jp_rot d_rot = -Jl (X x (Jr d_rot)),  Jp_trans d_trans = A d_trans
         const double* d = s_dp + 6 * slot;
-        double q0 = 0, q1 = 0;
-#pragma unroll
-        for (int a = 0; a < 6; a++) { q0 += o.Jp[0][a] * d[a]; q1 += o.Jp[1][a] * d[a]; }
+        const double* Jr = s_cam + BA_CAM * slot + 12;
+        const double u0 = Jr[0] * d[0] + Jr[1] * d[1] + Jr[2] * d[2];
+        const double u1 = Jr[3] * d[0] + Jr[4] * d[1] + Jr[5] * d[2];
+        const double u2 = Jr[6] * d[0] + Jr[7] * d[1] + Jr[8] * d[2];
+        const double t0 = X[1] * u2 - X[2] * u1, t1 = X[2] * u0 - X[0] * u2, t2 = X[0] * u1 - X[1] * u0;
+        const double q0 = (Aj[0][0] * d[3] + Aj[0][1] * d[4] + Aj[0][2] * d[5]) - (o.Jl[0][0] * t0 + o.Jl[0][1] * t1 + o.Jl[0][2] * t2);
+        const double q1 = (Aj[1][0] * d[3] + Aj[1][1] * d[4] + Aj[1][2] * d[5]) - (o.Jl[1][0] * t0 + o.Jl[1][1] * t1 + o.Jl[1][2] * t2);
         v0 = o.w * (o.Jl[0][0] * q0 + o.Jl[1][0] * q1);     // B^T d_pose = w Jl^T (Jp d_pose)
         v1 = o.w * (o.Jl[0][1] * q0 + o.Jl[1][1] * q1);
         v2 = o.w * (o.Jl[0][2] * q0 + o.Jl[1][2] * q1);
