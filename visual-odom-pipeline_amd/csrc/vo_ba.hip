@@ -455,6 +455,12 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
     }
   }
   VO_STAMP(dbgb, 1);   // cameras staged + observation linearised
+  // the Huber weight goes into one factor of every product once (12 multiplications instead of one per term: 39 fewer)
+  double wJp[2][6];
+#pragma unroll
+  for (int k = 0; k < 2; k++)
+#pragma unroll
+    for (int a = 0; a < 6; a++) wJp[k][a] = o.w * o.Jp[k][a];
   // ---- landmark sums over the group ----
   const double h00 = group_allreduce(o.w * (o.Jl[0][0] * o.Jl[0][0] + o.Jl[1][0] * o.Jl[1][0]), LPP);
   const double h10 = group_allreduce(o.w * (o.Jl[0][1] * o.Jl[0][0] + o.Jl[1][1] * o.Jl[1][0]), LPP);
@@ -500,8 +506,8 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
     constexpr int QA[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
     constexpr int QC[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
     auto term = [&](int q) -> double {
-      if (q < 21) return o.w * (o.Jp[0][QA[q]] * o.Jp[0][QC[q]] + o.Jp[1][QA[q]] * o.Jp[1][QC[q]]);
-      if (q < 27) return o.w * (o.Jp[0][q - 21] * o.e0 + o.Jp[1][q - 21] * o.e1);
+      if (q < 21) return wJp[0][QA[q]] * o.Jp[0][QC[q]] + wJp[1][QA[q]] * o.Jp[1][QC[q]];
+      if (q < 27) return wJp[0][q - 21] * o.e0 + wJp[1][q - 21] * o.e1;
       return 0.5 * o.rho;
     };
     double* dst = dyn + (size_t)(wave * LPP + (lane & (LPP - 1))) * BA_POSE_VALS;
@@ -541,9 +547,9 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   if (slot < W) {
 #pragma unroll
     for (int a = 0; a < 6; a++) {
-      const double b0 = o.w * (o.Jp[0][a] * o.Jl[0][0] + o.Jp[1][a] * o.Jl[1][0]);
-      const double b1 = o.w * (o.Jp[0][a] * o.Jl[0][1] + o.Jp[1][a] * o.Jl[1][1]);
-      const double b2 = o.w * (o.Jp[0][a] * o.Jl[0][2] + o.Jp[1][a] * o.Jl[1][2]);
+      const double b0 = wJp[0][a] * o.Jl[0][0] + wJp[1][a] * o.Jl[1][0];
+      const double b1 = wJp[0][a] * o.Jl[0][1] + wJp[1][a] * o.Jl[1][1];
+      const double b2 = wJp[0][a] * o.Jl[0][2] + wJp[1][a] * o.Jl[1][2];
       rw0[6 * slot + a] = b0 * i00;                                   // Y[a][0] = B[a][0] Cinv[0][0]
       rw1[6 * slot + a] = b0 * i10 + b1 * i11;                        // Y[a][1]
       rw2[6 * slot + a] = b0 * i20 + b1 * i21 + b2 * i22;             // Y[a][2]
