@@ -84,6 +84,7 @@ struct ba_ptrs {
   // per-problem strides (elements) of the batched buffers
   size_t s_obs, s_x, s_aux, s_posepart, s_gmax, s_tiles, s_dp, s_evalpart, s_tilesum, s_posesum, s_cams;
   int W, N, LPP, PPB, nblk, RP, RT, n_tiles, pitch;
+  int nset;                           // partial sets (= workgroups of k_ba_build): nblk, or fewer when a workgroup walks several landmark chunks
   int cam_off;                        // k_ba_build: offset (doubles) of the staged cameras inside the dynamic LDS
   int sharded, rank, n_ranks, batch;  // sharded: the batch entries (x the ranks) are landmark shards of one problem
 };
@@ -417,15 +418,7 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   const double* poses = (it == 0) ? P.x0 : ba_x(P, st.cur);
   const double* pts = poses + 6 * W;
   // this lane's landmark and observation: issued before the camera staging so that the two HBM round trips overlap
-  const int pl = tid / LPP, slot = tid - pl * LPP;       // landmark (local), window slot
-  const int j = blockIdx.x * P.PPB + pl;
-  double X[3] = {0, 0, 0};
-  double uo = __builtin_nan(""), vo = 0;
-  if (slot < W && j < N) {
-    X[0] = pts[3 * j]; X[1] = pts[3 * j + 1]; X[2] = pts[3 * j + 2];
-    const double* ob = P.obs + ((size_t)slot * N + j) * 2;
-    uo = ob[0]; vo = ob[1];
-  }
+  // cameras and K into LDS, once per workgroup
   if (it == 0) {
     stage_cameras(poses, W, s_cam, tid, TPB);           // nobody has prepared the cameras of x0 yet
   } else {
@@ -436,10 +429,28 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   if (it == 0 && blockIdx.x == 0 && tid < 6 * W) P.xa[tid] = poses[tid];
   __syncthreads();
   if (it == 0 && blockIdx.x == 0) for (int i = tid; i < W * BA_CAM; i += TPB) P.cams[i] = s_cam[i];   // cams[0] <-> x[0]
+  const int pl = tid / LPP, slot = tid - pl * LPP;       // landmark (local), window slot
+  // A workgroup walks the landmark chunks blockIdx.x, blockIdx.x + gridDim.x, ... (PPB landmarks each) and owns ONE partial set:
+  // the later chunks add their Gram tiles and camera sums to what the earlier ones stored (the workgroup's own 20 KB, still in L2).
+  // Half as many partial sets with two chunks per workgroup: the tile stores are HBM-write bound (61 MB per launch, 15 of the
+  // kernel's 58 us) and k_ba_reduce reads them all back.
+  int seed_x = (it == 0) ? 1 : 0;                  // (opaque, so that the chunk loop is not versioned on it)
+  asm volatile("" : "+v"(seed_x));
+#pragma unroll 1
+  for (int chunk = blockIdx.x; chunk < P.nblk; chunk += gridDim.x) {
+  const bool later = chunk != (int)blockIdx.x;
+  const int j = chunk * P.PPB + pl;
+  double X[3] = {0, 0, 0};
+  double uo = __builtin_nan(""), vo = 0;
+  if (slot < W && j < N) {
+    X[0] = pts[3 * j]; X[1] = pts[3 * j + 1]; X[2] = pts[3 * j + 2];
+    const double* ob = P.obs + ((size_t)slot * N + j) * 2;
+    uo = ob[0]; vo = ob[1];
+  }
 
   ba_obs_lin o;
   bool have = false;
-  if (it == 0 && slot == 0 && j < N) {
+  if (seed_x && slot == 0 && j < N) {
     double* dst = P.xa + 6 * W + 3 * j;
     dst[0] = X[0]; dst[1] = X[1]; dst[2] = X[2];
   }
@@ -494,7 +505,7 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   {
     double gm = (j < N) ? fmax(fabs(g0), fmax(fabs(g1), fabs(g2))) : 0.0;
     for (int ofs = 32; ofs > 0; ofs >>= 1) gm = fmax(gm, __shfl_xor(gm, ofs));
-    if (lane == 0) s_gmax[wave] = gm;
+    if (lane == 0) s_gmax[wave] = later ? fmax(s_gmax[wave], gm) : gm;
   }
   VO_STAMP(dbgb, 2);   // group sums + 3x3 factor
   // ---- camera sums: across the landmarks of the wave by shuffles, across waves through LDS ----
@@ -530,7 +541,8 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
     double s = 0;
 #pragma unroll
     for (int wv = 0; wv < (TPB / 64); wv++) s += dyn[(size_t)(wv * LPP + sl) * BA_POSE_VALS + k];
-    P.posepart[((size_t)blockIdx.x * W + sl) * BA_POSE_VALS + k] = s;
+    double* pp = P.posepart + ((size_t)blockIdx.x * W + sl) * BA_POSE_VALS + k;
+    *pp = later ? *pp + s : s;
   }
   if (tid == 0) {
     double gm = 0;
@@ -610,9 +622,12 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
       if (!on[u]) continue;
       const d4 acc = (u == 0) ? acc0 : (u == 1) ? acc1 : acc2;
       double* out = P.tiles + ((size_t)blockIdx.x * P.n_tiles + tile0 + u * (TPB / 64)) * 256 + lane * 4;
-      out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2]; out[3] = acc[3];
+      if (later) { out[0] += acc[0]; out[1] += acc[1]; out[2] += acc[2]; out[3] += acc[3]; }
+      else { out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2]; out[3] = acc[3]; }
     }
   }
+  __syncthreads();                       // the panel has been read: the next chunk's camera-sum scratch may overwrite it
+  }   // chunk
   VO_STAMP(dbgb, 5);   // Gram tiles (wave 0)
 }
 
@@ -638,7 +653,7 @@ __global__ void __launch_bounds__(256) k_ba_reduce(ba_ptrs Pall, int it) {
     // group g sums partials g, g + 4, g + 8, ... (8 loads in flight), groups are combined in fixed order below
     double s0 = 0, s1 = 0;
     int b = g;
-    for (; b + 60 < P.nblk; b += 64) {   // 16 loads in flight
+    for (; b + 60 < P.nset; b += 64) {   // 16 loads in flight
       double v[16];
 #pragma unroll
       for (int u = 0; u < 16; u++) v[u] = src[(size_t)(b + 4 * u) * stride];
@@ -648,14 +663,14 @@ __global__ void __launch_bounds__(256) k_ba_reduce(ba_ptrs Pall, int it) {
         else { s0 += v[u]; s1 += v[u + 1]; }
       }
     }
-    for (; b + 28 < P.nblk; b += 32) {
+    for (; b + 28 < P.nset; b += 32) {
       const double v0 = src[(size_t)b * stride], v1 = src[(size_t)(b + 4) * stride], v2 = src[(size_t)(b + 8) * stride];
       const double v3 = src[(size_t)(b + 12) * stride], v4 = src[(size_t)(b + 16) * stride], v5 = src[(size_t)(b + 20) * stride];
       const double v6 = src[(size_t)(b + 24) * stride], v7 = src[(size_t)(b + 28) * stride];
       if (is_max) { s0 = fmax(fmax(fmax(s0, v0), fmax(v1, v2)), fmax(fmax(v3, v4), fmax(fmax(v5, v6), v7))); }
       else { s0 += v0; s1 += v1; s0 += v2; s1 += v3; s0 += v4; s1 += v5; s0 += v6; s1 += v7; }
     }
-    for (; b < P.nblk; b += 4) { const double v = src[(size_t)b * stride]; if (is_max) s0 = fmax(s0, v); else s0 += v; }
+    for (; b < P.nset; b += 4) { const double v = src[(size_t)b * stride]; if (is_max) s0 = fmax(s0, v); else s0 += v; }
     acc = is_max ? s0 : (s0 + s1);
   }
   s_part[g][o] = acc;
@@ -1282,6 +1297,15 @@ static ba_ptrs ba_make_ptrs(const vo_ctx* c) {
   P.state = b->d_state; P.info = b->d_info; P.dbg = nullptr;
   P.W = b->W; P.N = b->N; P.LPP = b->LPP; P.PPB = b->PPB; P.nblk = b->nblk; P.cam_off = b->cam_off; P.RP = b->RP; P.RT = b->RT;
   P.n_tiles = b->n_tiles; P.pitch = b->pitch;
+  {
+    // landmark chunks per workgroup: as many as keep >= 1024 workgroups (4 per CU, what the kernel's registers allow) in the launch,
+    // at most 4 -- a batch of 32 problems x 125 chunks -> 32 workgroups per problem; ONE sequence keeps a workgroup per chunk
+    static const int cpw_env = getenv("VO_BA_CHUNKS") ? atoi(getenv("VO_BA_CHUNKS")) : 0;  // experiment knob (0 = the rule)
+    int cpw = cpw_env > 0 ? cpw_env : (int)(((long long)c->batch * b->nblk + 512) / 1024);
+    if (cpw < 1) cpw = 1;
+    if (cpw > 4 && cpw_env <= 0) cpw = 4;
+    P.nset = (cpw > 1 && b->tpb == 256) ? (b->nblk + cpw - 1) / cpw : b->nblk;
+  }
   // strides use the ALLOCATED capacity for N-dependent buffers? no: they are packed for the current problem size
   const size_t W = (size_t)b->W, N = (size_t)b->N;
   P.s_obs = 2 * W * N; P.s_x = 6 * W + 3 * N; P.s_aux = N * BA_AUX; P.s_posepart = (size_t)b->nblk * W * BA_POSE_VALS;
@@ -1325,7 +1349,7 @@ static int32_t ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& 
                               double* probe_S, double* hpp_out, double* probe_dl) {
   vo_ba_ws* b = c->ba;
   const int B = c->batch;
-  if (b->tpb == 256) hipLaunchKernelGGL(k_ba_build<256>, dim3(b->nblk, B), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
+  if (b->tpb == 256) hipLaunchKernelGGL(k_ba_build<256>, dim3(P.nset, B), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
   else if (b->tpb == 512) hipLaunchKernelGGL(k_ba_build<512>, dim3(b->nblk, B), dim3(512), b->build_lds, c->stream, P, prm, it, probe_lambda);
   else hipLaunchKernelGGL(k_ba_build<1024>, dim3(b->nblk, B), dim3(1024), b->build_lds, c->stream, P, prm, it, probe_lambda);
   hipLaunchKernelGGL(k_ba_reduce, dim3(vo_div_up(b->n_tiles * 256 + b->W * BA_POSE_VALS + 1, 64), B), dim3(256), 0, c->stream, P, it);
