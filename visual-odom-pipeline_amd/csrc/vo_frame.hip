@@ -114,52 +114,63 @@ __global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restric
   src += (size_t)bseq * src_seq_px;
   if (bx < nb_scharr) {
     // ---- Scharr: Ix = [3 10 3]^T (x) [-1 0 1], Iy = [-1 0 1]^T (x) [3 10 3], un-normalised.
-    //      4 pixels per thread: 3 aligned dwords per source row, one 16-byte store of 4 (4 Ix | 4 Iy << 16) ----
-    const int per_row = (w + 1023) / 1024;
-    const int y = bx / per_row;
-    const int x0 = ((bx - y * per_row) * 256 + threadIdx.x) * 4;
-    if (x0 >= w) return;
-    const size_t o = (size_t)(y + VO_PAD) * pitch + (x0 + VO_PAD);       // multiple of 4
-    // columns x0 - 1 .. x0 + 4 of rows y - 1 .. y + 1 as three pairs of 16-bit values per row (one byte gather each); the vertical
-    // parts run on packed pairs, the horizontal 3-tap on v_dot2: 35 vector instructions per 4 pixels (90 with per-byte extraction;
-    // every vector instruction of this mix costs the same issue slot, tools/issue_probe.hip)
+    //      A thread owns a strip of 4 pixels x SR rows: SR + 2 source rows of 3 aligned dwords each (12 row loads per 16 pixels
+    //      instead of 36), one 16-byte store of 4 (4 Ix | 4 Iy << 16) per row.  The threads run over (row strip, 4-pixel group)
+    //      pairs in one flat index, so every workgroup is full (a 1241-pixel row used to take two 1024-pixel workgroups, the second
+    //      one fifth full).  The kernel is bound by the latency of many tiny workgroups, not by its stores (without the derivative
+    //      stores the level-0 launch took 31 instead of 34 us): more work per thread is what helps ----
+    constexpr int SR = 4;
+    const int gpr = (w + 3) / 4;                                          // 4-pixel groups per row
+    const unsigned gid = (unsigned)bx * 256u + threadIdx.x;
+    const int ys = (int)(gid / (unsigned)gpr);                            // row strip
+    const int x0 = (int)(gid - (unsigned)ys * (unsigned)gpr) * 4;
+    const int y0 = ys * SR;
+    if (y0 >= h) return;
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     typedef short s16x2 __attribute__((ext_vector_type(2)));
-    u16x2 a[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(src + o + (size_t)(r - 1) * pitch);
+    // columns x0 - 1 .. x0 + 4 of a source row as three pairs of 16-bit values (one byte gather each)
+    auto load_row = [&](int yy, u16x2 (&a)[3]) {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(src + (size_t)(yy + VO_PAD) * pitch + (x0 + VO_PAD));
       const uint32_t L = q[-1], M = q[0], R = q[1];
-      a[r][0] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(M, L, 0x0c040c03u));   // (x0 - 1, x0)
-      a[r][1] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, M, 0x0c020c01u));  // (x0 + 1, x0 + 2)
-      a[r][2] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(R, M, 0x0c040c03u));   // (x0 + 3, x0 + 4)
-    }
-    // stored times 4 (|4 Scharr| <= 16 320 fits int16): k_klt_track's interpolation sum then carries its result in the upper
-    // 16 bits (vo_klt.hip deriv1); vo_pyramid_read hands out the plain values
-    s16x2 cs[3], dv[3];                                                   // 4 x [3 10 3]^T column sums, row differences
+      a[0] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(M, L, 0x0c040c03u));   // (x0 - 1, x0)
+      a[1] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, M, 0x0c020c01u));  // (x0 + 1, x0 + 2)
+      a[2] = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(R, M, 0x0c040c03u));   // (x0 + 3, x0 + 4)
+    };
+    u16x2 rows[SR + 2][3];
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-      cs[c] = __builtin_bit_cast(s16x2, (u16x2)((a[0][c] + a[2][c]) * (unsigned short)12 + a[1][c] * (unsigned short)40));
-      dv[c] = __builtin_bit_cast(s16x2, (u16x2)(a[2][c] - a[0][c]));
-    }
-    const uint32_t ix01 = __builtin_bit_cast(uint32_t, (s16x2)(cs[1] - cs[0]));        // Ix of pixels 0, 1: column k + 2 minus column k
-    const uint32_t ix23 = __builtin_bit_cast(uint32_t, (s16x2)(cs[2] - cs[1]));
-    const s16x2 w_lo = {12, 40}, w_hi = {40, 12}, w_0 = {12, 0}, w_1 = {0, 12};
-    const int iy0 = __builtin_amdgcn_sdot2(dv[1], w_0, __builtin_amdgcn_sdot2(dv[0], w_lo, 0, false), false);   // 12 d0 + 40 d1 + 12 d2
-    const int iy1 = __builtin_amdgcn_sdot2(dv[1], w_hi, __builtin_amdgcn_sdot2(dv[0], w_1, 0, false), false);   // 12 d1 + 40 d2 + 12 d3
-    const int iy2 = __builtin_amdgcn_sdot2(dv[2], w_0, __builtin_amdgcn_sdot2(dv[1], w_lo, 0, false), false);
-    const int iy3 = __builtin_amdgcn_sdot2(dv[2], w_hi, __builtin_amdgcn_sdot2(dv[1], w_1, 0, false), false);
-    uint32_t out[4];
-    out[0] = __builtin_amdgcn_perm((uint32_t)iy0, ix01, 0x05040100u);     // (Ix | Iy << 16)
-    out[1] = __builtin_amdgcn_perm((uint32_t)iy1, ix01, 0x05040302u);
-    out[2] = __builtin_amdgcn_perm((uint32_t)iy2, ix23, 0x05040100u);
-    out[3] = __builtin_amdgcn_perm((uint32_t)iy3, ix23, 0x05040302u);
-    if (x0 + 3 >= w) {                                                    // columns >= w belong to the zero (BORDER_CONSTANT) frame of the derivative image
+    for (int r = 0; r < SR + 2; r++) load_row(min(y0 - 1 + r, h), rows[r]);      // rows y0 - 1 .. y0 + SR (clamped into the padded image)
 #pragma unroll
-      for (int k = 1; k < 4; k++) if (x0 + k >= w) out[k] = 0u;
+    for (int r = 0; r < SR; r++) {
+      const int y = y0 + r;
+      if (y >= h) break;
+      // stored times 4 (|4 Scharr| <= 16 320 fits int16): k_klt_track's interpolation sum then carries its result in the upper
+      // 16 bits (vo_klt.hip deriv1); vo_pyramid_read hands out the plain values
+      s16x2 cs[3], dv[3];                                                 // 4 x [3 10 3]^T column sums, row differences
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        cs[c] = __builtin_bit_cast(s16x2, (u16x2)((rows[r][c] + rows[r + 2][c]) * (unsigned short)12 + rows[r + 1][c] * (unsigned short)40));
+        dv[c] = __builtin_bit_cast(s16x2, (u16x2)(rows[r + 2][c] - rows[r][c]));
+      }
+      const uint32_t ix01 = __builtin_bit_cast(uint32_t, (s16x2)(cs[1] - cs[0]));      // Ix of pixels 0, 1: column k + 2 minus column k
+      const uint32_t ix23 = __builtin_bit_cast(uint32_t, (s16x2)(cs[2] - cs[1]));
+      const s16x2 w_lo = {12, 40}, w_hi = {40, 12}, w_0 = {12, 0}, w_1 = {0, 12};
+      const int iy0 = __builtin_amdgcn_sdot2(dv[1], w_0, __builtin_amdgcn_sdot2(dv[0], w_lo, 0, false), false);   // 12 d0 + 40 d1 + 12 d2
+      const int iy1 = __builtin_amdgcn_sdot2(dv[1], w_hi, __builtin_amdgcn_sdot2(dv[0], w_1, 0, false), false);   // 12 d1 + 40 d2 + 12 d3
+      const int iy2 = __builtin_amdgcn_sdot2(dv[2], w_0, __builtin_amdgcn_sdot2(dv[1], w_lo, 0, false), false);
+      const int iy3 = __builtin_amdgcn_sdot2(dv[2], w_hi, __builtin_amdgcn_sdot2(dv[1], w_1, 0, false), false);
+      uint32_t out[4];
+      out[0] = __builtin_amdgcn_perm((uint32_t)iy0, ix01, 0x05040100u);     // (Ix | Iy << 16)
+      out[1] = __builtin_amdgcn_perm((uint32_t)iy1, ix01, 0x05040302u);
+      out[2] = __builtin_amdgcn_perm((uint32_t)iy2, ix23, 0x05040100u);
+      out[3] = __builtin_amdgcn_perm((uint32_t)iy3, ix23, 0x05040302u);
+      if (x0 + 3 >= w) {                                                    // columns >= w belong to the zero (BORDER_CONSTANT) frame of the derivative image
+#pragma unroll
+        for (int k = 1; k < 4; k++) if (x0 + k >= w) out[k] = 0u;
+      }
+      uint4 pk; pk.x = out[0]; pk.y = out[1]; pk.z = out[2]; pk.w = out[3];
+      const size_t o = (size_t)(y + VO_PAD) * pitch + (x0 + VO_PAD);       // multiple of 4
+      *reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(der) + (size_t)bseq * src_seq_px + o) = pk;
     }
-    uint4 pk; pk.x = out[0]; pk.y = out[1]; pk.z = out[2]; pk.w = out[3];
-    *reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(der) + (size_t)bseq * src_seq_px + o) = pk;
   } else {
     // ---- pyrDown: 5x5 [1 4 6 4 1]^2, (sum + 128) >> 8, output padded domain, 4 outputs per thread ----
     const int b = bx - nb_scharr;
@@ -457,7 +468,7 @@ int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, size_t raw_seq_str
   }
   for (int l = 0; l <= c->top; l++) {
     const vo_level& L = c->lv[l];
-    const int nb_scharr = vo_div_up(L.w, 1024) * L.h;
+    const int nb_scharr = vo_div_up(vo_div_up(L.w, 4) * vo_div_up(L.h, 4), 256);      // threads = (4-pixel groups per row) x (4-row strips)
     int nb_down = 0;
     uint8_t* dst = nullptr; int dw = 0, dh = 0, dpitch = 0; size_t dpx = 0;
     if (l < c->top) {
