@@ -175,10 +175,11 @@ __global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restric
     // ---- pyrDown: 5x5 [1 4 6 4 1]^2, (sum + 128) >> 8, output padded domain, 4 outputs per thread ----
     const int b = bx - nb_scharr;
     const int pw = dw + 2 * VO_PAD;
-    const int per_row = (pw + 1023) / 1024;
-    const int Y = b / per_row;
-    const int X0 = ((b - Y * per_row) * 256 + threadIdx.x) * 4;
-    if (X0 >= pw || Y >= dh + 2 * VO_PAD) return;
+    const int gpr = (pw + 3) / 4;                                         // dwords per padded destination row; flat (row, dword) index
+    const unsigned gid = (unsigned)b * 256u + threadIdx.x;
+    const int Y = (int)(gid / (unsigned)gpr);
+    const int X0 = (int)(gid - (unsigned)Y * (unsigned)gpr) * 4;
+    if (Y >= dh + 2 * VO_PAD) return;
     const int y = d_reflect101(Y - VO_PAD, dh);
     // source is padded by 32 with reflect-101, so 2x-2 .. 2x+2 never needs index reflection
     const uint8_t* prow = src + (size_t)(2 * y + VO_PAD) * pitch + VO_PAD;
@@ -474,7 +475,7 @@ int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, size_t raw_seq_str
     if (l < c->top) {
       const vo_level& D = c->lv[l + 1];
       dst = F.img[l + 1]; dw = D.w; dh = D.h; dpitch = D.pitch; dpx = c->lvl_px[l + 1];
-      nb_down = vo_div_up(D.w + 2 * VO_PAD, 1024) * D.ph;
+      nb_down = vo_div_up(vo_div_up(D.w + 2 * VO_PAD, 4) * D.ph, 256);
     }
     hipLaunchKernelGGL(k_scharr_pyrdown, dim3(nb_scharr + nb_down, B), dim3(256), 0, c->stream,
                        F.img[l], c->lvl_px[l], L.w, L.h, L.pitch, F.der[l], nb_scharr, dst, dpx, dw, dh, dpitch, remap);
