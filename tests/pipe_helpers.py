@@ -1,0 +1,182 @@
+"""Shared by the closed-loop pipeline tests: (i) the reference's Pipeline.step (pipeline.py:92-167) restated over the drop-in
+Extractor / BundleAdjuster / State classes one step at a time, (ii) a rendered two-plane scene with a camera that sways back
+and forth (so a sequence of any length stays in view) and a ground-truth bootstrap state for it, (iii) the object-by-object
+comparison of that loop's lists with a table state (the array model of oracle/pipe_oracle.py or the device tables)."""
+import copy
+
+import numpy as np
+
+
+# ---------------------------------------------------------------------------------------------------------
+# scene
+# ---------------------------------------------------------------------------------------------------------
+def sway_pose(t, amp=(0.9, 0.25, -0.5), roll=0.02, period=40.0):
+    """frame-0 camera -> frame-t camera: the camera side-steps, rises and approaches on a sinusoid and rolls with it"""
+    s = np.sin(2 * np.pi * t / period)
+    Hm = np.eye(4)
+    ang = roll * s
+    Hm[:2, :2] = [[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]]
+    Hm[:3, 3] = np.asarray(amp, float) * s
+    return Hm
+
+
+def scene(n_frames, w=416, h=240, f=400.0, seed=2024, z_bg=10.0, z_fg=6.5, pose_fn=sway_pose, margin=128):
+    """-> dict(frames [n, h, w] u8, K, poses [n, 4, 4], depth(t, xy) -> Z of the surface seen at pixel xy of frame t and its frame-0 pixel)"""
+    from vo_mi355x import synthetic as syn
+    K = np.array([[f, 0, (w - 1) / 2], [0, f, (h - 1) / 2], [0, 0, 1]])
+    c = K[:2, 2]
+    tex_bg = syn.make_texture(h + 2 * margin, w + 2 * margin, seed)
+    tex_fg = syn.make_texture(h + 2 * margin, w + 2 * margin, seed + 1)
+    rect = (0.29 * w, 0.25 * h, 0.72 * w, 0.77 * h)
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    frames = np.empty((n_frames, h, w), np.uint8)
+    poses = np.empty((n_frames, 4, 4))
+    motions = []
+
+    def plane_motion(Hm, Z):
+        s_ = Z / (Z + Hm[2, 3])
+        A = np.zeros((2, 3)); A[:, :2] = s_ * Hm[:2, :2]; A[:, 2] = c - s_ * Hm[:2, :2] @ c + f * Hm[:2, 3] / (Z + Hm[2, 3])
+        return A
+    for t in range(n_frames):
+        Hm = pose_fn(t)
+        poses[t] = Hm
+        A_bg, A_fg = plane_motion(Hm, z_bg), plane_motion(Hm, z_fg)
+        motions.append((A_bg, A_fg))
+        bg = syn.render_frame(tex_bg, A_bg, w, h, margin)
+        fg = syn.render_frame(tex_fg, A_fg, w, h, margin)
+        Ainv = np.linalg.inv(np.vstack([A_fg, [0, 0, 1]]))[:2]
+        x0 = Ainv[0, 0] * xs + Ainv[0, 1] * ys + Ainv[0, 2]; y0 = Ainv[1, 0] * xs + Ainv[1, 1] * ys + Ainv[1, 2]
+        inside = (x0 >= rect[0]) & (x0 < rect[2]) & (y0 >= rect[1]) & (y0 < rect[3])
+        frames[t] = np.where(inside, fg, bg)
+
+    def surface(t, xy):
+        """for pixels xy [n, 2] of frame t: (Z [n], frame-0 pixel [n, 2]) of the plane seen there"""
+        xy = np.asarray(xy, np.float64).reshape(-1, 2)
+        out_z, out_p0 = np.empty(len(xy)), np.empty((len(xy), 2))
+        for k, (A, Z) in enumerate(((motions[t][1], z_fg), (motions[t][0], z_bg))):
+            Ainv = np.linalg.inv(np.vstack([A, [0, 0, 1]]))[:2]
+            p0 = xy @ Ainv[:, :2].T + Ainv[:, 2]
+            if k == 0:
+                fgm = (p0[:, 0] >= rect[0]) & (p0[:, 0] < rect[2]) & (p0[:, 1] >= rect[1]) & (p0[:, 1] < rect[3])
+                out_z[fgm], out_p0[fgm] = Z, p0[fgm]
+            else:
+                out_z[~fgm], out_p0[~fgm] = Z, p0[~fgm]
+        return out_z, out_p0
+    return dict(frames=frames, K=K, poses=poses, surface=surface, f=f)
+
+
+def gt_bootstrap(ctx, sc, t0=0, t1=4, n_landmarks=0.6, min_kp_dist=7):
+    """A State like Pipeline._get_init_state's (pipeline.py:42-90) from ground truth instead of SIFT + five-point: Shi-Tomasi corners
+    of frame t1 (through `ctx`), the first `n_landmarks` share of them become landmarks at their true position (world = camera t0,
+    unit = the t0 -> t1 baseline, as the bootstrap fixes it), the rest candidates born at step 1.  -> (state, t_loader)"""
+    from vo_mi355x import Extractor, Landmark, State, Trajectory
+    ext = Extractor(min_kp_dist=min_kp_dist, ctx=ctx)
+    kps = ext.extract(sc["frames"][t1], 1, current_kp=[], detector='shi-tomasi', mask_radius=min_kp_dist, describe=False)
+    G0, G1 = sc["poses"][t0], sc["poses"][t1]
+    rel = G1 @ np.linalg.inv(G0)
+    unit = np.linalg.norm(rel[:3, 3])
+    H1 = rel.copy(); H1[:3, 3] /= unit
+    n_l = int(len(kps) * n_landmarks) if n_landmarks <= 1 else int(n_landmarks)
+    uv = np.array([k.uv.reshape(2) for k in kps[:n_l]], np.float64)
+    Z, p0 = sc["surface"](t1, uv)
+    K = sc["K"]
+    X0 = np.stack([(p0[:, 0] - K[0, 2]) / K[0, 0] * Z, (p0[:, 1] - K[1, 2]) / K[1, 1] * Z, Z], 1)      # frame-0 camera coordinates
+    Xw = (X0 @ G0[:3, :3].T + G0[:3, 3]) / unit                                                        # camera t0 = world, unit baseline
+    lms = [Landmark(1, Xw[i].reshape(3, 1).copy(), kps[i].des) for i in range(n_l)]
+    traj = Trajectory({})
+    traj.append(0, np.eye(4)); traj.append(1, H1)
+    return State(lms, kps[:n_l], kps[n_l:], traj), t1
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the reference's loop over the drop-in classes
+# ---------------------------------------------------------------------------------------------------------
+class ObjectLoop:
+    """Pipeline.__init__ / step (pipeline.py:13-40, 92-167) over vo_mi355x.Extractor / BundleAdjuster"""
+
+    def __init__(self, ctx, K, state, im_prev, t_step=1, ba_window=4, min_kp_dist=7, max_reproj=2.0, min_angle=0.5, ba_max_iters=50):
+        from vo_mi355x import BundleAdjuster, Extractor
+        self.K, self.state, self.t_step = K, state, t_step
+        self.ba_window, self.min_kp_dist, self.max_reproj, self.min_angle = ba_window, min_kp_dist, max_reproj, min_angle
+        self.extractor = Extractor(min_kp_dist=min_kp_dist, ctx=ctx)
+        self.adjuster = BundleAdjuster(verbosity=0, window_size=ba_window, method='trf', xtol=1e-3, ftol=1e-3, ctx=ctx, max_iters=ba_max_iters)
+        self.dead, self.dead_kp = [], []
+        self.extractor._im_prev = im_prev
+        self.info = {}
+
+    def step(self, im):
+        ex, st, K = self.extractor, self.state, self.K
+        self.t_step += 1
+        st._candidates_kp = ex.extend_tracks(im, st._candidates_kp, max_bidir_error=np.inf)
+        st._landmarks, st._landmarks_kp, ld, lkd = ex.extend_landmarks(im, st._landmarks, st._landmarks_kp, max_bidir_error=np.inf)
+        self.dead += copy.deepcopy(ld); self.dead_kp += copy.deepcopy(lkd)
+        ex._im_prev = im.copy()
+        inl, Hk = ex.camera_pose(K, st._landmarks, st._landmarks_kp, corr='3D-2D', max_err_reproj=self.max_reproj)
+        inl_set = set(inl)
+        lms, lkp = [], []
+        for i in range(len(st._landmarks)):
+            if i in inl_set:
+                lms.append(st._landmarks[i]); lkp.append(st._landmarks_kp[i])
+            else:
+                self.dead.append(copy.deepcopy(st._landmarks[i])); self.dead_kp.append(copy.deepcopy(st._landmarks_kp[i]))
+        st._landmarks, st._landmarks_kp = lms, lkp
+        st._trajectory.append(self.t_step, Hk)
+        l_new, lk_new, st._candidates_kp = ex.triangulate_tracks(K, st._candidates_kp, st._trajectory, t_curr=self.t_step, min_track_length=3,
+                                                                 min_bearing_angle=self.min_angle, max_err_reproj=self.max_reproj, refine=True)
+        st._landmarks_kp += lk_new; st._landmarks += l_new
+        n_before = len(st._landmarks)
+        self.state, self.dead, self.dead_kp = self.adjuster.adjust(st, self.dead, self.dead_kp, K, self.t_step)
+        st = self.state
+        new_c = ex.extract(im, self.t_step, st._landmarks_kp + st._candidates_kp, detector='shi-tomasi', mask_radius=self.min_kp_dist, describe=False)
+        st._candidates_kp += new_c
+        self.info = dict(n_inliers=len(inl), n_new=len(l_new), n_resurrected=len(st._landmarks) - n_before, n_detected=len(new_c),
+                         ba=self.adjuster.last_stats)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# comparison: object lists vs table state
+# ---------------------------------------------------------------------------------------------------------
+def _kp_fields(k, hist_depth):
+    h = np.array(k.uv_history, np.float64).reshape(-1, 2)
+    return (int(k.t_first), int(k.t_total), np.asarray(k.uv_first, np.float64).reshape(2), np.asarray(k.uv, np.float64).reshape(2), len(h),
+            h[max(0, len(h) - hist_depth):])
+
+
+def compare_lists(loop, table_entries, hist_depth=32, p_tol=0.0, what=""):
+    """table_entries: dict(cand=[entry], lm=[entry], dead=[entry]) with entry = (t_latest | None, p | None, t_first, t_total, uv_first, uv,
+    hist_len, hist tail) in list order (PipeModel.entry / the device read-back); loop: ObjectLoop.  Exact on integers and float32
+    pixel coordinates, `p_tol` (relative) on landmark positions."""
+    st = loop.state
+    # the tables drop dead entries that can never be resurrected again (window test failed and the Landmark object is not in the
+    # state's list: its t_latest is frozen, the test only fails harder) and count them; the same filter on the object side
+    live = {id(l) for l in st._landmarks}
+    dead = [(l, k) for l, k in zip(loop.dead, loop.dead_kp)
+            if (loop.t_step - (l.t_latest - (len(k.uv_history) - 1))) < loop.ba_window or id(l) in live]
+    if "n_dead_total" in table_entries:
+        assert table_entries["n_dead_total"] == len(loop.dead), (what, table_entries["n_dead_total"], len(loop.dead))
+    pairs = dict(cand=[(None, k) for k in st._candidates_kp], lm=list(zip(st._landmarks, st._landmarks_kp)), dead=dead)
+    for name in ("cand", "lm", "dead"):
+        ref, got = pairs[name], table_entries[name]
+        assert len(ref) == len(got), (what, name, len(ref), len(got))
+        for i, ((l, k), e) in enumerate(zip(ref, got)):
+            tl, p, tf, tt, uvf, uv, n, hist = e
+            rf = _kp_fields(k, hist_depth)
+            assert (tf, tt, n) == (rf[0], rf[1], rf[4]), (what, name, i, (tf, tt, n), rf[:2] + (rf[4],))
+            assert np.array_equal(np.float64(uvf), rf[2]) and np.array_equal(np.float64(uv), rf[3]), (what, name, i, uv, rf[3])
+            assert np.array_equal(np.float64(hist), rf[5]), (what, name, i)
+            if l is not None:
+                assert tl == int(l.t_latest), (what, name, i, tl, l.t_latest)
+                pr = np.asarray(l.p, np.float64).reshape(3)
+                if p_tol == 0.0:
+                    assert np.array_equal(p, pr), (what, name, i, p, pr)
+                else:
+                    assert np.linalg.norm(p - pr) <= p_tol * max(np.linalg.norm(pr), 1e-12), (what, name, i, p, pr)
+
+
+def sharing_signature(loop):
+    """how the loop's lists share objects: for every state landmark entry the index of the first dead entry holding the same Landmark /
+    the same Keypoint object (-1: none) -- the structure the table model must reproduce for later frames to agree"""
+    dl = {id(l): i for i, l in reversed(list(enumerate(loop.dead)))}
+    dk = {id(k): i for i, k in reversed(list(enumerate(loop.dead_kp)))}
+    st = loop.state
+    return [(dl.get(id(l), -1), dk.get(id(k), -1)) for l, k in zip(st._landmarks, st._landmarks_kp)]
