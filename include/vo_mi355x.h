@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VO_ABI_VERSION 2
+#define VO_ABI_VERSION 3
 
 enum {
   VO_OK = 0,
@@ -356,6 +356,94 @@ int32_t vo_tracks_read(vo_ctx* ctx, int32_t* n, float* uv, float* uv_first, int3
 int32_t vo_tracks_obs(vo_ctx* ctx, int32_t t_now, int32_t window, double* obs);
 /* the same table written into the RESIDENT BA problem (uploaded with N = max_pts landmarks): no host round trip (async) */
 int32_t vo_ba_obs_from_tracks(vo_ctx* ctx, int32_t t_now);
+
+/* ---- closed-loop Pipeline.step on the device (SURVEY.md 8f "next" row 3, the State half) ---------------------------
+ * The whole per-frame state the reference keeps in Python lists of objects -- State(landmarks, landmarks_kp, candidates_kp,
+ * trajectory) (src/state/state.py:4-10) and Pipeline._landmarks_dead / _landmarks_kp_dead (src/pipeline/pipeline.py:31) -- as
+ * device tables, and Pipeline.step (pipeline.py:92-167) as ONE enqueue per frame with every data dependence on the device:
+ *   TRACK        pyramid + KLT of all landmark and candidate keypoints, the keep rule and bookkeeping of
+ *                Extractor.extend_tracks / extend_landmarks (extractor.py:38-88), what dies goes to the dead lists (pipeline.py:98-103)
+ *   POSE         RANSAC-P3P pose from the landmarks' 3-D points and tracked pixels (extractor.py:174-191), non-inliers to the dead
+ *                lists (pipeline.py:124-137), pose appended to the trajectory (:140)
+ *   TRIANGULATE  Extractor.triangulate_tracks (extractor.py:193-277): candidates with t_total >= min_track_length leave the
+ *                candidate list, DLT between their first and newest observation, cheirality + reprojection filters
+ *                (triangulate.py:87-111), the per-group gate of extractor.py:231-240, promotion to landmarks
+ *   ADJUST       BundleAdjuster.adjust (bundle_adjuster.py:127-215): dead landmarks whose track lies inside the window are
+ *                appended to the state's lists again AS THE SAME OBJECTS (:142-150), observation table from the keypoint
+ *                histories (:153-158), x0 from the landmark positions and the window's poses (:165-176), LM solve, positions and
+ *                poses written back (:197-213)
+ *   DETECT       exclusion discs at every keypoint of the state + Shi-Tomasi, corners appended as candidates (pipeline.py:159-163)
+ * Object identity matters in the reference (adjust appends without copying, extend_landmarks deep-copies the keypoint but keeps the
+ * landmark object, Pipeline.step deep-copies what dies): the tables are OBJECT rows with stable indices -- K rows (Keypoint:
+ * t_first, t_total, uv_first, uv, history length, ring of the last 32 history entries by index) and L rows (Landmark: t_latest, p) --
+ * plus ordered lists of row indices (candidates [K]; landmarks [(L, K, keypoint-shared-with-a-dead-entry)]; dead [(L, K)]), so
+ * several list entries can refer to one object exactly as in the reference.  Dead entries that can never be resurrected again
+ * are dropped and counted.  oracle/pipe_oracle.py restates the algorithm; tests/test_gpu_pipe.py compares the tables with the
+ * reference's loop over Python objects frame by frame.
+ * Capacity: candidates + landmarks <= max_pts (they share the KLT point buffer), dead list <= max_pts, object rows 4 x max_pts.
+ * When a list is full, detections / promotions / resurrections are cut in list order and the record's `overflow` bits say so
+ * (the reference's lists are unbounded).
+ * Frames come from the resident sequence (vo_seq_upload) by index, or frame_idx = -1: the caller has pushed the frame
+ * (vo_frame_push).  Up to VO_PIPE_INFLIGHT steps may be enqueued before the oldest record is fetched; nothing else crosses
+ * the bus per frame. */
+typedef struct {
+  int32_t ba_window;          /* 4    pipeline.py:19  (<= 20) */
+  int32_t min_track_length;   /* 3    pipeline.py:147 */
+  int32_t mask_radius;        /* 7    pipeline.py:162 (min_kp_dist) */
+  int32_t max_new;            /* 1000 corners appended per frame (maxCorners, extractor.py:21) */
+  int32_t pnp_blind_batches;  /* 4    batches of 256 P3P hypotheses enqueued per frame (they exit early once the RANSAC bound is reached) */
+  int32_t ba_budget;          /* LM iterations enqueued per frame, <= ba.max_iters (they exit early once the LM has stopped) */
+  double  max_reproj_err;     /* 2.0  pipeline.py:23 (PnP consensus and triangulation filter) */
+  double  min_bearing_angle;  /* 0.5  pipeline.py:24 */
+  vo_klt_params klt;
+  vo_st_params  st;
+  vo_ba_params  ba;
+  vo_pnp_params pnp;
+} vo_pipe_params;
+
+/* what comes back per sequence and frame */
+typedef struct {
+  int32_t t;                  /* step index after this frame (Pipeline._t_step) */
+  int32_t status;             /* 0, or VO_PIPE_* bits: the sequence stopped at the frame that set them */
+  int32_t overflow;           /* capacity policy acted: 1 dead list, 2 promotion, 4 resurrection, 8 detection, 16 Shi-Tomasi candidate capacity */
+  int32_t n_landmarks, n_candidates;      /* len(state._landmarks), len(state._candidates_kp) after the frame */
+  int32_t n_dead, n_dead_total;           /* dead entries kept on the device / ever (= len(Pipeline._landmarks_dead)) */
+  int32_t n_tracked;                      /* keypoints that went into the KLT of this frame */
+  int32_t pnp_inliers, pnp_hypotheses, pnp_bound_reached;
+  int32_t n_ripe, n_new, n_resurrected, n_detected;
+  int32_t ba_landmarks, ba_observations, ba_iters, ba_accepted, ba_status, ba_done;   /* ba_done 0: the budget cut the solve */
+  int32_t pad;
+  double  ba_cost0, ba_cost;
+  double  H[12];              /* pose of this frame AFTER the adjust: rows of [R | t], world -> camera */
+} vo_pipe_record;
+
+enum { VO_PIPE_LOST = 1, VO_PIPE_CAPACITY = 2, VO_PIPE_GROUPS = 4 };   /* LOST: the 3D-2D pose found no consensus (the reference crashes there); CAPACITY: object rows exhausted; GROUPS: a ripe candidate was born more than 32 frames ago (its pose has left the trajectory ring) */
+enum { VO_PIPE_TRACK = 1, VO_PIPE_POSE = 2, VO_PIPE_TRIANGULATE = 4, VO_PIPE_ADJUST = 8, VO_PIPE_DETECT = 16, VO_PIPE_ALL = 31 };
+#define VO_PIPE_INFLIGHT 4
+#define VO_PIPE_HIST 32
+
+/* the device tables, for seeding and read-back (all with a leading [batch] dimension; N = max_pts, R = 4 x max_pts rows):
+ * K rows: K_TFIRST, K_TTOTAL, K_HISTLEN i32 [R]; K_UV, K_UVFIRST f32 [R][2]; K_HIST f32 [32][R][2] (entry idx in slot idx % 32)
+ * L rows: L_TLATEST i32 [R]; L_P f64 [R][3]
+ * lists:  CAND i32 [N]; LM_L, LM_K, LM_KSHARED i32 [N]; DEAD_L, DEAD_K i32 [N]
+ * COUNTS i32 [32]: [0] n_cand [1] n_lm [2] n_dead [3] n_dead_dropped [4] status [5] t
+ * POSES f64 [32][12]: trajectory ring, pose of step t in slot t % 32 */
+enum { VO_PIPE_K_TFIRST = 0, VO_PIPE_K_TTOTAL, VO_PIPE_K_HISTLEN, VO_PIPE_K_UV, VO_PIPE_K_UVFIRST, VO_PIPE_K_HIST, VO_PIPE_L_TLATEST,
+       VO_PIPE_L_P, VO_PIPE_CAND, VO_PIPE_LM_L, VO_PIPE_LM_K, VO_PIPE_LM_KSHARED, VO_PIPE_DEAD_L, VO_PIPE_DEAD_K, VO_PIPE_COUNTS,
+       VO_PIPE_POSES, VO_PIPE_N_TABLES };
+
+int32_t vo_pipe_default_params(vo_pipe_params* p);
+/* K [batch][9].  Allocates the tables (empty state, t = 0) and the BA / PnP / DLT workspaces for max_pts landmark slots. */
+int32_t vo_pipe_create(vo_ctx* ctx, const double* K, const vo_pipe_params* prm);
+int32_t vo_pipe_table_bytes(vo_ctx* ctx, int32_t which, uint64_t* bytes);
+int32_t vo_pipe_table_write(vo_ctx* ctx, int32_t which, const void* src);     /* synchronous; needs no steps in flight */
+int32_t vo_pipe_table_read(vo_ctx* ctx, int32_t which, void* dst);            /* synchronous */
+/* after the tables were written: free rows and the resident point set are rebuilt from the lists */
+int32_t vo_pipe_commit(vo_ctx* ctx);
+/* one frame; stages = VO_PIPE_ALL, or a subset for stage-wise parity tests (the step counter advances in TRACK)   (async) */
+int32_t vo_pipe_step(vo_ctx* ctx, int32_t frame_idx, int32_t stages);
+int32_t vo_pipe_fetch(vo_ctx* ctx, vo_pipe_record* rec /* [batch] */);        /* waits for the OLDEST step not fetched yet */
+int32_t vo_pipe_set_ba_budget(vo_ctx* ctx, int32_t budget);
 
 /* ---- fused per-frame step on resident data ---------------------------------------------------
  * One call enqueues the hot path of one frame in the order of Pipeline.step (src/pipeline/pipeline.py:92-167):

@@ -30,7 +30,7 @@ HIST = 32
 # per-sequence status bits (same values as VO_PIPE_* in include/vo_mi355x.h)
 ST_LOST = 1          # the 3D-2D pose found no consensus (the reference crashes in cv2.Rodrigues(None))
 ST_CAPACITY = 2      # a list or an object table is full
-ST_GROUPS = 4        # ripe candidates with different birth frames (cannot happen when every frame triangulates)
+ST_GROUPS = 4        # a ripe candidate's birth pose has left the 32-frame trajectory ring
 
 
 def _rot_to_vec(R):
@@ -239,33 +239,36 @@ class PipeModel:
         self.info["n_new"] = 0
         if not ripe:
             return
-        born = int(self.k_tf[ripe[0]])
-        if any(int(self.k_tf[k]) != born for k in ripe):
-            self.status |= ST_GROUPS
-            return
-        H0, H1 = self.poses[born], self.poses[self.t]
-        P0, P1 = np.float32(self.K @ H0[:3]), np.float32(self.K @ H1[:3])
-        X4, depth1, reproj = self.ctx.triangulate(P0, P1, self.k_first[ripe], self.k_uv[ripe], self.K, H0, H1)
-        X4 = X4.reshape(4, -1)
-        pts = (X4[:3] / X4[3]).T
-        rows = np.nonzero((np.asarray(depth1) > 0) & (np.asarray(reproj) < prm.max_reproj_err))[0]
-        if not len(rows):
-            return
-        # the reference's "bearing angle" of the group's first landmark (extractor.py:231-240)
-        ray = np.zeros(4); ray[:3] = np.float64(pts[rows[0]])
-        a = np.linalg.norm(H1 @ np.linalg.inv(H0))
-        b, c = np.linalg.norm(H0 @ ray), np.linalg.norm(H1 @ ray)
-        with np.errstate(invalid='ignore', divide='ignore'):
-            theta = np.degrees(np.arccos((b * b + c * c - a * a) / (2 * b * c)))
-        if not (theta > prm.min_bearing_angle):
-            return
-        room = self.cap - len(self.lm_L) - len(self.cand)          # capacity policy: the lists share the KLT point buffer
-        if len(rows) > room:
-            rows = rows[:max(room, 0)]
-            self.info["overflow"] = self.info.get("overflow", 0) | 2
-        for i in rows:
-            self.lm_L.append(self.new_L(self.t, np.float64(pts[i]))); self.lm_K.append(ripe[i]); self.lm_ksh.append(False)
-        self.info["n_new"] = len(rows)
+        H1 = self.poses[self.t]
+        # groups by birth frame, ascending (the reference walks a Python set of small ints: extractor.py:210-212)
+        for born in sorted(set(int(self.k_tf[k]) for k in ripe)):
+            grp = [k for k in ripe if int(self.k_tf[k]) == born]
+            if born not in self.poses or not (0 <= self.t - born < HIST):
+                self.status |= ST_GROUPS
+                return
+            H0 = self.poses[born]
+            P0, P1 = np.float32(self.K @ H0[:3]), np.float32(self.K @ H1[:3])
+            X4, depth1, reproj = self.ctx.triangulate(P0, P1, self.k_first[grp], self.k_uv[grp], self.K, H0, H1)
+            X4 = X4.reshape(4, -1)
+            pts = (X4[:3] / X4[3]).T
+            rows = np.nonzero((np.asarray(depth1) > 0) & (np.asarray(reproj) < prm.max_reproj_err))[0]
+            if not len(rows):
+                continue
+            # the reference's "bearing angle" of the group's first landmark (extractor.py:231-240)
+            ray = np.zeros(4); ray[:3] = np.float64(pts[rows[0]])
+            a = np.linalg.norm(H1 @ np.linalg.inv(H0))
+            b, c = np.linalg.norm(H0 @ ray), np.linalg.norm(H1 @ ray)
+            with np.errstate(invalid='ignore', divide='ignore'):
+                theta = np.degrees(np.arccos((b * b + c * c - a * a) / (2 * b * c)))
+            if not (theta > prm.min_bearing_angle):
+                continue
+            room = self.cap - len(self.lm_L) - len(self.cand)          # capacity policy: the lists share the KLT point buffer
+            if len(rows) > room:
+                rows = rows[:max(room, 0)]
+                self.info["overflow"] = self.info.get("overflow", 0) | 2
+            for i in rows:
+                self.lm_L.append(self.new_L(self.t, np.float64(pts[i]))); self.lm_K.append(grp[i]); self.lm_ksh.append(False)
+            self.info["n_new"] += len(rows)
 
     # ---- stage 4: sliding-window bundle adjustment (bundle_adjuster.py:127-215) -----------------------------
     def ba_problem(self):

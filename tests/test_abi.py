@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libvo_mi355x.so does not export %s" % n
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert _lib.load().vo_abi_version() == 2
+    assert _lib.load().vo_abi_version() == 3
 
 
 def test_struct_layouts_match_header():

@@ -1408,6 +1408,37 @@ extern "C" int32_t vo_ba_solve_resident(vo_ctx* c, const vo_ba_params* prm) {
   return VO_OK;
 }
 
+// ---- closed-loop pipeline hooks: the problem (x0, obs) is written by a device kernel every frame ----
+int32_t vo_ba_reserve(vo_ctx* c, const double* K_host, int W, int N) {
+  if (c->stream3) VO_HIP(c, hipStreamSynchronize(c->stream3));
+  int32_t r = ba_alloc(c, W, N);
+  if (r != VO_OK) return r;
+  vo_ba_ws* b = c->ba;
+  const size_t B = c->batch;
+  VO_HIP(c, hipMemcpyAsync(b->d_K, K_host, 9 * sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipMemsetAsync(b->d_x0, 0, sizeof(double) * ((size_t)6 * W + 3 * (size_t)N) * B, c->stream));
+  VO_HIP(c, hipMemsetAsync(b->d_obs, 0xFF, sizeof(double) * 2 * (size_t)W * N * B, c->stream));       // all NaN: nothing observed
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  b->uploaded = true;
+  return VO_OK;
+}
+int32_t vo_ba_get_view(vo_ctx* c, vo_ba_view* v) {
+  VO_CHECK(c, c->ba && c->ba->uploaded, VO_E_STATE, "vo_ba_reserve first");
+  vo_ba_ws* b = c->ba;
+  v->x0 = b->d_x0; v->obs = b->d_obs; v->pub = b->d_pub; v->pub_bytes = b->pub_bytes;
+  v->x_stride = (size_t)6 * b->W + 3 * (size_t)b->N; v->obs_stride = (size_t)2 * b->W * b->N; v->W = b->W; v->N = b->N;
+  return VO_OK;
+}
+int32_t vo_ba_enqueue_budget(vo_ctx* c, const vo_ba_params* prm, int it0, int n_it) {
+  VO_CHECK(c, c->ba && c->ba->uploaded, VO_E_STATE, "vo_ba_reserve first");
+  const ba_params_dev d = ba_dev_params(prm);
+  if (n_it > 0) { const int32_t r = ba_enqueue_iters(c, d, it0, n_it); if (r != VO_OK) return r; }
+  const ba_ptrs P = ba_make_ptrs(c);
+  ba_launch_finalize(c, P, d, it0 + n_it, c->ba->d_state + ((it0 + n_it) & 1), 2);
+  VO_HIP(c, hipGetLastError());
+  return VO_OK;
+}
+
 static void ba_fill_stats(const ba_state& s, int n_obs, vo_ba_stats* st) {
   st->cost0 = s.cost0; st->cost = s.cost; st->lambda = s.lambda; st->iters = s.iter; st->accepted = s.accepted;
   st->status = s.status; st->n_obs = n_obs;

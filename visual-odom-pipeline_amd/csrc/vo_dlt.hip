@@ -8,12 +8,6 @@
 // float32-rounded, float32-dehomogenised point exactly like extractor.py:271 / triangulate.py:15-29.
 #include "vo_internal.h"
 
-struct vo_dlt_cam {          // per sequence
-  float P0[12], P1[12];
-  double M0[12], M1[12];   // K @ H[:3,:] (f64) of both views
-  double H1z[4];           // third row of H1
-};
-
 // 1/sqrt(x) and 1/x from the hardware estimates + two Newton steps (relative error ~1e-16): the IEEE-exact sqrt / divide
 // expansions are ~30 dependent f64 instructions each and a Jacobi rotation needs three of each; the kernel is one long
 // dependent chain per point (500 waves on 1024 SIMDs), so their latency IS the run time.  Parity here is by tolerance
@@ -34,11 +28,15 @@ __device__ __forceinline__ double dlt_rcp(double x) {
 // grid (ceil(n / 64), batch)
 __global__ void __launch_bounds__(64) k_dlt(const vo_dlt_cam* __restrict__ cams, int n, int want_stats, size_t uv_seq,
                                             size_t slab_seq, const float* __restrict__ uv0, const float* __restrict__ uv1,
-                                            float* __restrict__ X4, double* __restrict__ depth1, double* __restrict__ reproj) {
+                                            float* __restrict__ X4, double* __restrict__ depth1, double* __restrict__ reproj,
+                                            const int32_t* __restrict__ counts, const int32_t* __restrict__ cam_sel, int cams_per_seq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int bseq = blockIdx.y;
-  const vo_dlt_cam& a = cams[bseq];
+  if (counts && i >= counts[bseq]) return;
+  // closed-loop pipeline: a sequence triangulates groups of tracks born at different frames in one launch, each group against its
+  // own first camera (extractor.py:210-220): cam_sel[i] picks the pair of point i
+  const vo_dlt_cam& a = cam_sel ? cams[(size_t)bseq * cams_per_seq + cam_sel[(size_t)bseq * n + i]] : cams[bseq];
   uv0 += (size_t)bseq * uv_seq; uv1 += (size_t)bseq * uv_seq;
   X4 = vo_seq(X4, slab_seq, bseq); depth1 = vo_seq(depth1, slab_seq, bseq); reproj = vo_seq(reproj, slab_seq, bseq);
   const float u0 = uv0[2 * i], v0 = uv0[2 * i + 1], u1 = uv1[2 * i], v1 = uv1[2 * i + 1];
@@ -146,7 +144,18 @@ static int32_t dlt_launch(vo_ctx* c, int n) {
   vo_prof_scope prof(c, VO_PROF_DLT);
   hipLaunchKernelGGL(k_dlt, dim3(vo_div_up(n, 64), c->batch), dim3(64), 0, c->stream, c->d_dlt_cam, n, c->dlt_stats,
                      (size_t)c->max_pts * 2, c->slab_seq, c->d_uv0, c->d_uv1, vo_slab<float>(c, c->off_X4),
-                     vo_slab<double>(c, c->off_depth), vo_slab<double>(c, c->off_reproj));
+                     vo_slab<double>(c, c->off_depth), vo_slab<double>(c, c->off_reproj), nullptr, nullptr, 1);
+  VO_HIP(c, hipGetLastError());
+  return VO_OK;
+}
+
+// closed-loop pipeline: cameras (cams_per_seq per sequence), their per-point selection and the pixel pairs were written by device
+// kernels; counts[b] pairs are valid; X4 keeps the row stride n_hi
+int32_t vo_dlt_enqueue_counts(vo_ctx* c, int n_hi, const int32_t* d_counts, const vo_dlt_cam* d_cams, const int32_t* d_cam_sel, int cams_per_seq) {
+  vo_prof_scope prof(c, VO_PROF_DLT);
+  hipLaunchKernelGGL(k_dlt, dim3(vo_div_up(n_hi, 64), c->batch), dim3(64), 0, c->stream, d_cams, n_hi, 1,
+                     (size_t)c->max_pts * 2, c->slab_seq, c->d_uv0, c->d_uv1, vo_slab<float>(c, c->off_X4),
+                     vo_slab<double>(c, c->off_depth), vo_slab<double>(c, c->off_reproj), d_counts, d_cam_sel, cams_per_seq);
   VO_HIP(c, hipGetLastError());
   return VO_OK;
 }

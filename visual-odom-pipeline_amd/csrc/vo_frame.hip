@@ -312,6 +312,7 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);   // side branch of the frame step (an error path may have left it unjoined)
   if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   (void)vo_comm_destroy(c);
+  vo_pipe_destroy(c);
   vo_trk_destroy(c);
   vo_pnp_destroy(c);
   vo_ess_destroy(c);

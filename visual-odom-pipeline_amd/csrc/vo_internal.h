@@ -34,7 +34,12 @@ struct vo_prof {
 struct vo_st_ws;   // Shi-Tomasi workspace (vo_shi_tomasi.hip)
 struct vo_ba_ws;   // bundle-adjustment workspace (vo_ba.hip)
 
-struct vo_dlt_cam;  // per-sequence DLT camera data (vo_dlt.hip)
+// per-sequence camera data of the two-view triangulation (vo_dlt.hip; written on the device by the closed-loop pipeline)
+struct vo_dlt_cam {
+  float P0[12], P1[12];    // K @ H[:3,:] rounded to float32, as the reference hands them to cv2.triangulatePoints (extractor.py:268-269)
+  double M0[12], M1[12];   // the same products in float64 (filter statistics)
+  double H1z[4];           // third row of H1
+};
 
 // A context carries `batch` independent sequences in lockstep: every device buffer has a leading sequence
 // dimension with a uniform stride and every kernel a grid dimension over sequences, so that one launch serves
@@ -82,6 +87,7 @@ struct vo_ctx {
   struct vo_match_ws* match = nullptr;   // descriptor matcher buffers (vo_match.hip)
   struct vo_ess_ws* ess = nullptr;   // essential-matrix RANSAC workspace (vo_essential.hip)
   struct vo_trk_ws* trk = nullptr;   // device-resident track table (vo_tracks.hip)
+  struct vo_pipe_ws* pipe = nullptr; // closed-loop Pipeline.step on the device (vo_pipeline.hip)
   const int32_t* d_pt_counts = nullptr;   // per-sequence number of live resident points, or null = uniform n (KLT / exclusion discs)
   vo_ba_ws* ba = nullptr;
   vo_prof prof;
@@ -187,6 +193,21 @@ int32_t vo_comm_allreduce_f64(vo_ctx* c, double* buf, size_t count);
 int32_t vo_comm_allgather_f64(vo_ctx* c, const double* send, double* recv, size_t count);
 
 void vo_trk_destroy(vo_ctx* c);
+void vo_pipe_destroy(vo_ctx* c);
+
+// ---- hooks of the closed-loop pipeline (vo_pipeline.hip) into the stage units: device-resident inputs, per-sequence counts ----
+// bundle adjustment: workspace for W slots x N landmark slots with K uploaded, problem written on the device into x0 / obs
+struct vo_ba_view { double* x0; double* obs; const uint8_t* pub; size_t pub_bytes; size_t x_stride; size_t obs_stride; int W, N; };
+int32_t vo_ba_reserve(vo_ctx* c, const double* K_host, int W, int N);
+int32_t vo_ba_get_view(vo_ctx* c, vo_ba_view* v);
+int32_t vo_ba_enqueue_budget(vo_ctx* c, const vo_ba_params* prm, int it0, int n_it);   // iterations it0 .. it0 + n_it - 1, then publish
+// 3D-2D pose: correspondences written on the device, counts[b] of them per sequence
+struct vo_pnp_view { float* X; float* uv; const uint8_t* mask; const double* out; const int32_t* ctrl; size_t ctrl_stride; int cap; };
+int32_t vo_pnp_reserve(vo_ctx* c, const double* K_host);
+int32_t vo_pnp_get_view(vo_ctx* c, vo_pnp_view* v);
+int32_t vo_pnp_enqueue_counts(vo_ctx* c, const vo_pnp_params* prm, int blind_batches, const int32_t* d_counts);
+// triangulation of up to n_hi pairs per sequence (c->d_uv0 / d_uv1), counts[b] valid; point i of sequence b uses cams[b][cam_sel[b][i]]
+int32_t vo_dlt_enqueue_counts(vo_ctx* c, int n_hi, const int32_t* d_counts, const vo_dlt_cam* d_cams, const int32_t* d_cam_sel, int cams_per_seq);
 void vo_pnp_destroy(vo_ctx* c);
 void vo_ess_destroy(vo_ctx* c);
 void vo_match_destroy(vo_ctx* c);

@@ -1,0 +1,938 @@
+// Closed-loop Pipeline.step on the device (SURVEY.md 8f "next" row 3, the State half): the per-frame state of the reference --
+// State(landmarks, landmarks_kp, candidates_kp, trajectory) and the dead lists (src/state/state.py:4-10, src/pipeline/pipeline.py:31) --
+// as device tables, and the glue of Pipeline.step (pipeline.py:92-167) between the stage kernels as five list kernels:
+//
+//   k_pipe_extend     after KLT     Extractor.extend_tracks / extend_landmarks (extractor.py:38-88) + pipeline.py:101-102
+//   k_pipe_prune      after PnP     pipeline.py:124-140 (inlier pruning, trajectory.append) + the split of triangulate_tracks (extractor.py:202-203)
+//   k_pipe_promote    after DLT     triangulate.py:87-111 filters, extractor.py:231-240 gate, pipeline.py:153-154; then the selection half of
+//                                   BundleAdjuster.adjust (bundle_adjuster.py:132-176): resurrection, observation table, x0
+//   k_pipe_writeback  after BA      bundle_adjuster.py:197-213; the resident point set (exclusion discs, next frame's KLT)
+//   k_pipe_spawn      after S-T     extractor.py:127-131 / pipeline.py:159-163; free rows rebuilt; the frame's record
+//
+// The reference relies on OBJECT IDENTITY: adjust appends recently dead landmarks to state._landmarks without copying
+// (bundle_adjuster.py:142-147), extend_landmarks deep-copies the keypoint of a survivor but keeps the landmark object
+// (extractor.py:80-86), Pipeline.step deep-copies what dies (one deepcopy call per list: entries sharing a landmark object share
+// the copy).  So the tables are OBJECT ROWS with stable indices (K = Keypoint, L = Landmark) and the lists hold row indices; several
+// entries may refer to one row.  oracle/pipe_oracle.py is the same algorithm in numpy, checked object by object against the
+// reference's loop over Python objects; this file follows it phase by phase.
+//
+// One workgroup (1024 threads) per sequence; a thread owns list entries tid, tid + 1024, ... (<= 4: max_pts <= 4096), reads them all
+// before anything is written, and ordered compaction / allocation are block-wide prefix scans, so results do not depend on timing.
+#include "vo_internal.h"
+
+#include <math.h>
+#include <string.h>
+
+#define PIPE_TPB 1024
+#define PIPE_CH 4                 // list entries per thread: max_pts <= PIPE_TPB * PIPE_CH
+#define PIPE_HIST VO_PIPE_HIST
+#define PIPE_NCNT 32
+
+// counters [B][PIPE_NCNT]
+enum { C_NCAND = 0, C_NLM = 1, C_NDEAD = 2, C_NINERT = 3, C_STATUS = 4, C_T = 5,
+       C_NFREEK = 6, C_NFREEL = 7, C_HEADK = 8, C_HEADL = 9, C_NRIPE = 10, C_NPTS = 11, C_NNEW = 12, C_NRES = 13, C_NDET = 14,
+       C_OVERFLOW = 15, C_NOBS = 16, C_NKLT = 17, C_BORN = 18, C_NPNP = 19 };
+
+struct pipe_ptrs {
+  int32_t *k_tf, *k_tt, *k_len; float2 *k_uv, *k_first, *k_hist;     // K rows [B][R]; hist [B][HIST][R]
+  int32_t* l_tl; double* l_p;                                         // L rows [B][R], [B][R][3]
+  int32_t *cand, *lm_L, *lm_K, *lm_ksh, *dead_L, *dead_K, *ripe;      // lists [B][N]
+  int32_t* cnt;                                                       // [B][PIPE_NCNT]
+  int32_t *freeK, *freeL, *scr;                                       // [B][R]
+  double* H;                                                          // [B][HIST][12]
+  double* Kc;                                                         // [B][9]
+  int32_t* dn;                                                        // [3][B] dense per-sequence counts the stage kernels index by sequence:
+                                                                      // resident points (KLT, exclusion discs) | PnP correspondences | DLT pairs
+  int N, R;
+};
+enum { DN_PTS = 0, DN_PNP = 1, DN_RIPE = 2 };
+
+struct vo_pipe_ws {
+  int N = 0, R = 0;
+  vo_pipe_params prm;
+  void* tab[VO_PIPE_N_TABLES] = {};
+  size_t tab_bytes[VO_PIPE_N_TABLES] = {};       // per sequence
+  int32_t *d_ripe = nullptr, *d_freeK = nullptr, *d_freeL = nullptr, *d_scr = nullptr, *d_dn = nullptr, *d_cam_sel = nullptr;
+  vo_dlt_cam* d_cams = nullptr;                  // [B][HIST]: one camera pair per birth frame of the ripe candidates
+  double* d_K = nullptr;
+  vo_pipe_record* d_rec = nullptr;               // [B]
+  vo_pipe_record* h_rec = nullptr;               // pinned [VO_PIPE_INFLIGHT][B]
+  hipEvent_t ev[VO_PIPE_INFLIGHT] = {};
+  long enq = 0, fetched = 0;
+};
+
+static pipe_ptrs pipe_make(const vo_pipe_ws* w) {
+  pipe_ptrs P;
+  P.k_tf = (int32_t*)w->tab[VO_PIPE_K_TFIRST]; P.k_tt = (int32_t*)w->tab[VO_PIPE_K_TTOTAL]; P.k_len = (int32_t*)w->tab[VO_PIPE_K_HISTLEN];
+  P.k_uv = (float2*)w->tab[VO_PIPE_K_UV]; P.k_first = (float2*)w->tab[VO_PIPE_K_UVFIRST]; P.k_hist = (float2*)w->tab[VO_PIPE_K_HIST];
+  P.l_tl = (int32_t*)w->tab[VO_PIPE_L_TLATEST]; P.l_p = (double*)w->tab[VO_PIPE_L_P];
+  P.cand = (int32_t*)w->tab[VO_PIPE_CAND]; P.lm_L = (int32_t*)w->tab[VO_PIPE_LM_L]; P.lm_K = (int32_t*)w->tab[VO_PIPE_LM_K];
+  P.lm_ksh = (int32_t*)w->tab[VO_PIPE_LM_KSHARED]; P.dead_L = (int32_t*)w->tab[VO_PIPE_DEAD_L]; P.dead_K = (int32_t*)w->tab[VO_PIPE_DEAD_K];
+  P.ripe = w->d_ripe; P.cnt = (int32_t*)w->tab[VO_PIPE_COUNTS]; P.freeK = w->d_freeK; P.freeL = w->d_freeL; P.scr = w->d_scr;
+  P.H = (double*)w->tab[VO_PIPE_POSES]; P.Kc = w->d_K; P.dn = w->d_dn; P.N = w->N; P.R = w->R;
+  return P;
+}
+
+// tables of sequence b
+__device__ __forceinline__ pipe_ptrs pipe_select(pipe_ptrs P, int b) {
+  const size_t r = (size_t)b * P.R, n = (size_t)b * P.N;
+  P.k_tf += r; P.k_tt += r; P.k_len += r; P.k_uv += r; P.k_first += r; P.k_hist += r * PIPE_HIST;
+  P.l_tl += r; P.l_p += 3 * r;
+  P.cand += n; P.lm_L += n; P.lm_K += n; P.lm_ksh += n; P.dead_L += n; P.dead_K += n; P.ripe += n;
+  P.cnt += (size_t)b * PIPE_NCNT; P.freeK += r; P.freeL += r; P.scr += r;
+  P.H += (size_t)b * PIPE_HIST * 12; P.Kc += 9 * (size_t)b;
+  return P;
+}
+
+// values other threads of the workgroup update with atomics are read / written through the same path (the L2), not the vector L1
+__device__ __forceinline__ int ld_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_i32(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// block-wide exclusive scan of a 0/1 flag over the 1024 threads in thread order; s_w: 16 ints of LDS
+__device__ __forceinline__ int pipe_scan(int flag, int* s_w, int& total) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long bal = __ballot(flag);
+  const int within = __popcll(bal & ((1ull << lane) - 1ull));
+  __syncthreads();                       // s_w may still be read from the previous call
+  if (lane == 0) s_w[wave] = __popcll(bal);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) { const int v = s_w[w]; if (w < wave) off += v; tot += v; }
+  total = tot;
+  return off + within;
+}
+
+// ranks of flagged entries in LIST order (entry j = c * 1024 + tid): rank[c] for c < PIPE_CH; returns the total
+__device__ __forceinline__ int pipe_rank(const bool* flag, int* rank, int* s_w) {
+  int base = 0;
+#pragma unroll
+  for (int c = 0; c < PIPE_CH; c++) {
+    int tot;
+    const int pos = pipe_scan(flag[c] ? 1 : 0, s_w, tot);
+    rank[c] = base + pos;
+    base += tot;
+  }
+  return base;
+}
+
+__device__ __forceinline__ float2* pipe_hist_slot(const pipe_ptrs& P, int idx) { return P.k_hist + (size_t)(idx & (PIPE_HIST - 1)) * P.R; }
+
+__device__ __forceinline__ void pipe_copy_K(const pipe_ptrs& P, int dst, int src) {
+  P.k_tf[dst] = P.k_tf[src]; P.k_tt[dst] = P.k_tt[src]; P.k_len[dst] = P.k_len[src];
+  P.k_uv[dst] = P.k_uv[src]; P.k_first[dst] = P.k_first[src];
+#pragma unroll 8
+  for (int h = 0; h < PIPE_HIST; h++) P.k_hist[(size_t)h * P.R + dst] = P.k_hist[(size_t)h * P.R + src];
+}
+
+// (free rows are handed out from the front of the ascending free lists: head counters C_HEADK / C_HEADL, rebuilt by k_pipe_spawn)
+__device__ __forceinline__ bool pipe_inside(float2 q, int W, int H) {
+  return q.x >= 0.f && q.x <= (float)W && q.y >= 0.f && q.y <= (float)H;       // ends included; NaN fails (extractor.py:53,75)
+}
+
+// vec -> R (so3.rodrigues_vec_to_mat / cv2.Rodrigues)
+__device__ inline void pipe_rodrigues(const double* r, double* R) {
+  const double th = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  if (th < 2.220446049250313e-16) { for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0; return; }
+  const double kx = r[0] / th, ky = r[1] / th, kz = r[2] / th, c = cos(th), s = sin(th), c1 = 1.0 - c;
+  R[0] = c + c1 * kx * kx;      R[1] = c1 * kx * ky - s * kz; R[2] = c1 * kx * kz + s * ky;
+  R[3] = c1 * ky * kx + s * kz; R[4] = c + c1 * ky * ky;      R[5] = c1 * ky * kz - s * kx;
+  R[6] = c1 * kz * kx - s * ky; R[7] = c1 * kz * ky + s * kx; R[8] = c + c1 * kz * kz;
+}
+
+// R -> vec (so3.rodrigues_mat_to_vec without the SVD projection: R is a rotation to rounding error)
+__device__ inline void pipe_log_so3(const double* R, double* r) {
+  const double v[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+  const double s = sqrt(0.25 * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]));
+  double c = (R[0] + R[4] + R[8] - 1.0) * 0.5;
+  c = fmin(1.0, fmax(-1.0, c));
+  const double th = acos(c);
+  if (s < 1e-5) {
+    if (c > 0) { r[0] = r[1] = r[2] = 0.0; return; }
+    double rx = sqrt(fmax((R[0] + 1) * 0.5, 0.0));
+    double ry = sqrt(fmax((R[4] + 1) * 0.5, 0.0)) * (R[1] < 0 ? -1.0 : 1.0);
+    double rz = sqrt(fmax((R[8] + 1) * 0.5, 0.0)) * (R[2] < 0 ? -1.0 : 1.0);
+    if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && ((R[5] > 0) != (ry * rz > 0))) rz = -rz;
+    const double n = sqrt(rx * rx + ry * ry + rz * rz);
+    const double k = n > 0 ? th / n : 0.0;
+    r[0] = rx * k; r[1] = ry * k; r[2] = rz * k;
+    return;
+  }
+  const double k = 0.5 * th / s;
+  r[0] = v[0] * k; r[1] = v[1] * k; r[2] = v[2] * k;
+}
+
+// ================================================================================================
+// k_pipe_extend: the keep rule and bookkeeping after the KLT of [landmark keypoints | candidates]
+// ================================================================================================
+__global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const float* __restrict__ pts, size_t slab_seq, int W, int H,
+                                                          float* __restrict__ pnp_X, float* __restrict__ pnp_uv, int pnp_cap) {
+  __shared__ int s_w[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const pipe_ptrs P = pipe_select(Pall, b);
+  if (P.cnt[C_STATUS]) return;
+  const float2* p1 = reinterpret_cast<const float2*>(vo_seq(pts, slab_seq, b));
+  pnp_X += (size_t)b * pnp_cap * 3; pnp_uv += (size_t)b * pnp_cap * 2;
+  const int nl = P.cnt[C_NLM], nc = P.cnt[C_NCAND], nd0 = P.cnt[C_NDEAD];
+  int headK = P.cnt[C_HEADK], headL = P.cnt[C_HEADL];
+  const int nfK = P.cnt[C_NFREEK], nfL = P.cnt[C_NFREEL];
+  int overflow = 0, inert = 0;
+  __syncthreads();                                   // every thread has read the counters before thread 0 rewrites them
+
+  // ---- everything this workgroup will touch is read first ----
+  int L[PIPE_CH], K[PIPE_CH], KC[PIPE_CH];
+  bool keep[PIPE_CH], die[PIPE_CH], ksh[PIPE_CH], keepc[PIPE_CH];
+  float2 q[PIPE_CH], qc[PIPE_CH];
+#pragma unroll
+  for (int c = 0; c < PIPE_CH; c++) {
+    const int j = c * PIPE_TPB + tid;
+    L[c] = 0; K[c] = 0; KC[c] = 0; keep[c] = die[c] = ksh[c] = keepc[c] = false;
+    q[c] = qc[c] = make_float2(0.f, 0.f);
+    if (j < nl) {
+      L[c] = P.lm_L[j]; K[c] = P.lm_K[j]; ksh[c] = P.lm_ksh[j] != 0; q[c] = p1[j];
+      keep[c] = pipe_inside(q[c], W, H); die[c] = !keep[c];
+    }
+    if (j < nc) { KC[c] = P.cand[j]; qc[c] = p1[nl + j]; keepc[c] = pipe_inside(qc[c], W, H); }
+  }
+  __syncthreads();
+
+  // ---- candidates (extend_tracks): survivors get uv, t_total + 1, a history entry; ordered compaction ----
+  {
+    int rank[PIPE_CH];
+    const int n_out = pipe_rank(keepc, rank, s_w);
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++)
+      if (keepc[c]) {
+        const int k = KC[c], len = P.k_len[k];
+        P.k_uv[k] = qc[c]; P.k_tt[k] += 1; pipe_hist_slot(P, len)[k] = qc[c]; P.k_len[k] = len + 1;
+        P.cand[rank[c]] = k;
+      }
+    if (tid == 0) P.cnt[C_NCAND] = n_out;
+  }
+
+  // ---- landmarks, phase A: survivors update their keypoint row and their landmark's t_latest (several entries may share an L row) ----
+#pragma unroll
+  for (int c = 0; c < PIPE_CH; c++)
+    if (keep[c]) {
+      const int k = K[c], len = P.k_len[k];
+      P.k_uv[k] = q[c]; P.k_tt[k] += 1; pipe_hist_slot(P, len)[k] = q[c]; P.k_len[k] = len + 1;
+      atomicAdd(&P.l_tl[L[c]], 1);
+    }
+  // ---- phase B: deepcopy(k) of a survivor (extractor.py:85) matters only when the dead list holds the same keypoint object ----
+  {
+    bool f[PIPE_CH]; int rank[PIPE_CH];
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) f[c] = keep[c] && ksh[c];
+    const int tot = pipe_rank(f, rank, s_w);
+    if (headK + tot > nfK) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_CAPACITY; return; }
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++)
+      if (f[c]) { const int nk = P.freeK[headK + rank[c]]; pipe_copy_K(P, nk, K[c]); K[c] = nk; }
+    headK += tot;
+  }
+  __syncthreads();                                   // all t_latest increments are done before anything copies an L row
+  // ---- phase C: what died is deep-copied into the dead lists (pipeline.py:101-102).  One deepcopy call per list: entries that share a
+  //      landmark object share its copy -> the entry with the smallest index copies the row for all of them ----
+  {
+    int drank[PIPE_CH];
+    const int n_die = pipe_rank(die, drank, s_w);
+    const int room = P.N - nd0;
+    bool ok[PIPE_CH], lead[PIPE_CH];
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) { ok[c] = die[c] && drank[c] < room; if (ok[c]) st_i32(&P.scr[L[c]], 0x7FFFFFFF); }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) if (ok[c]) atomicMin(&P.scr[L[c]], c * PIPE_TPB + tid);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) lead[c] = ok[c] && ld_i32(&P.scr[L[c]]) == c * PIPE_TPB + tid;
+    int lrank[PIPE_CH], krank[PIPE_CH];
+    const int n_lead = pipe_rank(lead, lrank, s_w);  // (its barriers also separate the reads of scr above from the writes below)
+    const int n_ok = pipe_rank(ok, krank, s_w);
+    if (headL + n_lead > nfL || headK + n_ok > nfK) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_CAPACITY; return; }
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++)
+      if (lead[c]) {
+        const int nlr = P.freeL[headL + lrank[c]];
+        P.l_tl[nlr] = ld_i32(&P.l_tl[L[c]]);
+        for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = P.l_p[3 * (size_t)L[c] + k];
+        st_i32(&P.scr[L[c]], nlr);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++)
+      if (ok[c]) {
+        const int nk = P.freeK[headK + krank[c]];
+        pipe_copy_K(P, nk, K[c]);
+        P.dead_L[nd0 + drank[c]] = ld_i32(&P.scr[L[c]]);
+        P.dead_K[nd0 + drank[c]] = nk;
+      }
+    headL += n_lead; headK += n_ok;
+    if (n_die > n_ok) { overflow |= 1; inert = n_die - n_ok; }
+    if (tid == 0) P.cnt[C_NDEAD] = nd0 + n_ok;
+  }
+  // ---- ordered compaction of the landmark list; the survivors are the 3D-2D correspondences of the pose stage (extractor.py:176-177) ----
+  {
+    int rank[PIPE_CH];
+    const int n_out = pipe_rank(keep, rank, s_w);
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++)
+      if (keep[c]) {
+        const int o = rank[c];
+        P.lm_L[o] = L[c]; P.lm_K[o] = K[c]; P.lm_ksh[o] = 0;
+        pnp_uv[2 * o] = q[c].x; pnp_uv[2 * o + 1] = q[c].y;
+        for (int k = 0; k < 3; k++) pnp_X[3 * o + k] = (float)P.l_p[3 * (size_t)L[c] + k];
+      }
+    if (tid == 0) {
+      P.cnt[C_NLM] = n_out; P.cnt[C_NPNP] = n_out; P.cnt[C_NKLT] = nl + nc;
+      Pall.dn[DN_PNP * gridDim.x + b] = n_out;
+      P.cnt[C_T] += 1; P.cnt[C_HEADK] = headK; P.cnt[C_HEADL] = headL;
+      P.cnt[C_NINERT] += inert; P.cnt[C_OVERFLOW] = overflow;
+    }
+  }
+}
+
+// ================================================================================================
+// k_pipe_prune: PnP result -> trajectory, non-inliers to the dead lists; ripe candidates -> DLT inputs
+// ================================================================================================
+__global__ void __launch_bounds__(PIPE_TPB) k_pipe_prune(pipe_ptrs Pall, int do_pose, int do_tri, const uint8_t* __restrict__ mask, const double* __restrict__ pnp_out,
+                                                         int pnp_cap, int min_len, float* __restrict__ uv0, float* __restrict__ uv1, size_t uv_seq,
+                                                         vo_dlt_cam* __restrict__ cams, int32_t* __restrict__ cam_sel) {
+  __shared__ int s_w[16];
+  __shared__ int s_present[PIPE_HIST];
+  __shared__ int s_bad;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const pipe_ptrs P = pipe_select(Pall, b);
+  if (P.cnt[C_STATUS]) return;
+  mask += (size_t)b * pnp_cap; pnp_out += 8 * (size_t)b;
+  uv0 += (size_t)b * uv_seq; uv1 += (size_t)b * uv_seq; cam_sel += (size_t)b * P.N;
+  const int nl = P.cnt[C_NLM], nc = P.cnt[C_NCAND], nd0 = P.cnt[C_NDEAD], t = P.cnt[C_T];
+  int headK = P.cnt[C_HEADK], headL = P.cnt[C_HEADL];
+  const int nfK = P.cnt[C_NFREEK], nfL = P.cnt[C_NFREEL];
+  int overflow = P.cnt[C_OVERFLOW];
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  if (do_pose) {
+    if (!(pnp_out[7] >= 4.0)) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_LOST; return; }      // cv2.solvePnPRansac found nothing: the reference crashes here
+    int L[PIPE_CH], K[PIPE_CH];
+    bool in[PIPE_CH], out[PIPE_CH];
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) {
+      const int j = c * PIPE_TPB + tid;
+      L[c] = K[c] = 0; in[c] = out[c] = false;
+      if (j < nl) { L[c] = P.lm_L[j]; K[c] = P.lm_K[j]; in[c] = mask[j] != 0; out[c] = !in[c]; }
+    }
+    __syncthreads();
+    // non-inliers: deepcopy per entry (pipeline.py:133-134), every one gets its own L and K copy
+    int drank[PIPE_CH], rank[PIPE_CH];
+    const int n_out = pipe_rank(out, drank, s_w);
+    const int room = P.N - nd0;
+    const int n_ok = n_out < room ? n_out : room;
+    if (headL + n_ok > nfL || headK + n_ok > nfK) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_CAPACITY; return; }
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++)
+      if (out[c] && drank[c] < room) {
+        const int nlr = P.freeL[headL + drank[c]], nk = P.freeK[headK + drank[c]];
+        P.l_tl[nlr] = P.l_tl[L[c]];
+        for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = P.l_p[3 * (size_t)L[c] + k];
+        pipe_copy_K(P, nk, K[c]);
+        P.dead_L[nd0 + drank[c]] = nlr; P.dead_K[nd0 + drank[c]] = nk;
+      }
+    headL += n_ok; headK += n_ok;
+    if (n_out > n_ok) overflow |= 1;
+    const int n_in = pipe_rank(in, rank, s_w);
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) if (in[c]) { P.lm_L[rank[c]] = L[c]; P.lm_K[rank[c]] = K[c]; P.lm_ksh[rank[c]] = 0; }
+    if (tid == 0) {
+      P.cnt[C_NLM] = n_in; P.cnt[C_NDEAD] = nd0 + n_ok; P.cnt[C_NINERT] += n_out - n_ok;
+      // trajectory.append(t, [R(rvec) | tvec]) (extractor.py:186-191, pipeline.py:140)
+      double R[9];
+      pipe_rodrigues(pnp_out, R);
+      double* Hd = P.H + 12 * (size_t)(t & (PIPE_HIST - 1));
+      for (int r = 0; r < 3; r++) { for (int k = 0; k < 3; k++) Hd[4 * r + k] = R[3 * r + k]; Hd[4 * r + 3] = pnp_out[3 + r]; }
+    }
+  }
+  __syncthreads();
+  if (do_tri) {
+    // triangulate_tracks (extractor.py:202-203): candidates that reached min_track_length leave the list whether or not they succeed.
+    // They are triangulated in groups by birth frame, each against the pose of its birth frame (:210-220); a group is named by its AGE
+    // a = t - t_first (the slot distance in the 32-frame trajectory ring)
+    int KC[PIPE_CH], age[PIPE_CH]; bool ripe[PIPE_CH], wait[PIPE_CH];
+    if (tid < PIPE_HIST) s_present[tid] = 0;
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) {
+      const int j = c * PIPE_TPB + tid;
+      KC[c] = 0; age[c] = 0; ripe[c] = wait[c] = false;
+      if (j < nc) { KC[c] = P.cand[j]; ripe[c] = P.k_tt[KC[c]] >= min_len; wait[c] = !ripe[c]; age[c] = t - P.k_tf[KC[c]]; }
+    }
+    __syncthreads();
+    int rr[PIPE_CH], wr[PIPE_CH];
+    const int n_ripe = pipe_rank(ripe, rr, s_w);
+    const int n_wait = pipe_rank(wait, wr, s_w);
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) {
+      if (ripe[c]) {
+        if (age[c] < 0 || age[c] >= PIPE_HIST || age[c] > t) s_bad = 1;       // the birth pose has left the trajectory ring
+        else s_present[age[c]] = 1;
+        const float2 a = P.k_first[KC[c]], q = P.k_uv[KC[c]];
+        uv0[2 * rr[c]] = a.x; uv0[2 * rr[c] + 1] = a.y; uv1[2 * rr[c]] = q.x; uv1[2 * rr[c] + 1] = q.y;
+        P.ripe[rr[c]] = KC[c]; cam_sel[rr[c]] = age[c] & (PIPE_HIST - 1);
+      }
+      if (wait[c]) P.cand[wr[c]] = KC[c];
+    }
+    __syncthreads();
+    if (tid < PIPE_HIST && s_present[tid] && !s_bad) {
+      // P = K @ H[:3] rounded to float32 for the DLT (extractor.py:268-269), float64 for the filter statistics
+      const double* H0 = P.H + 12 * (size_t)((t - tid) & (PIPE_HIST - 1)); const double* H1 = P.H + 12 * (size_t)(t & (PIPE_HIST - 1));
+      vo_dlt_cam& a = cams[(size_t)b * PIPE_HIST + tid];
+      for (int r = 0; r < 3; r++)
+        for (int col = 0; col < 4; col++) {
+          double s0 = 0, s1 = 0;
+          for (int k = 0; k < 3; k++) { s0 += P.Kc[3 * r + k] * H0[4 * k + col]; s1 += P.Kc[3 * r + k] * H1[4 * k + col]; }
+          a.M0[4 * r + col] = s0; a.M1[4 * r + col] = s1; a.P0[4 * r + col] = (float)s0; a.P1[4 * r + col] = (float)s1;
+        }
+      for (int k = 0; k < 4; k++) a.H1z[k] = H1[8 + k];
+    }
+    if (tid == 0) {
+      P.cnt[C_NCAND] = n_wait; P.cnt[C_NRIPE] = n_ripe;
+      Pall.dn[DN_RIPE * gridDim.x + b] = n_ripe;
+      if (n_ripe > 0 && s_bad) { P.cnt[C_STATUS] |= VO_PIPE_GROUPS; P.cnt[C_NRIPE] = 0; Pall.dn[DN_RIPE * gridDim.x + b] = 0; }
+    }
+  }
+  if (tid == 0) { P.cnt[C_HEADK] = headK; P.cnt[C_HEADL] = headL; P.cnt[C_OVERFLOW] = overflow; }
+}
+
+// ================================================================================================
+// k_pipe_promote: triangulation filters + gate + promotion; then the selection half of BundleAdjuster.adjust
+// ================================================================================================
+__global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int do_tri, int do_adjust, const float* __restrict__ X4, const double* __restrict__ depth1,
+                                                           const double* __restrict__ reproj, size_t slab_seq, int x4_stride, double max_err,
+                                                           double min_angle, const int32_t* __restrict__ cam_sel, int Wn, double* __restrict__ x0, double* __restrict__ obs,
+                                                           size_t x_stride, size_t obs_stride, int Nba) {
+  __shared__ int s_w[16];
+  __shared__ int s_first[PIPE_HIST], s_gate[PIPE_HIST];
+  __shared__ int s_nobs;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const pipe_ptrs P = pipe_select(Pall, b);
+  if (P.cnt[C_STATUS]) return;
+  X4 = vo_seq(X4, slab_seq, b); depth1 = vo_seq(depth1, slab_seq, b); reproj = vo_seq(reproj, slab_seq, b);
+  cam_sel += (size_t)b * P.N;
+  x0 += (size_t)b * x_stride; obs += (size_t)b * obs_stride;
+  const int t = P.cnt[C_T], nc = P.cnt[C_NCAND], n_ripe = do_tri ? P.cnt[C_NRIPE] : 0, nd0 = P.cnt[C_NDEAD];
+  int nl = P.cnt[C_NLM];
+  int headL = P.cnt[C_HEADL];
+  const int nfL = P.cnt[C_NFREEL];
+  int overflow = P.cnt[C_OVERFLOW];
+  if (tid == 0) s_nobs = 0;
+  __syncthreads();
+  int n_new = 0;
+  if (do_tri && n_ripe > 0) {
+    bool kept[PIPE_CH]; float pt[PIPE_CH][3]; int age[PIPE_CH];
+    if (tid < PIPE_HIST) { s_first[tid] = 0x7FFFFFFF; s_gate[tid] = 0; }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) {
+      const int j = c * PIPE_TPB + tid;
+      kept[c] = false; age[c] = 0;
+      if (j < n_ripe) {
+        const float w4 = X4[(size_t)3 * x4_stride + j];
+        for (int k = 0; k < 3; k++) pt[c][k] = X4[(size_t)k * x4_stride + j] / w4;          // numpy float32 divide (extractor.py:271)
+        kept[c] = depth1[j] > 0.0 && reproj[j] < max_err;                                    // triangulate.py:87-111
+        age[c] = cam_sel[j];
+        if (kept[c]) atomicMin(&s_first[age[c]], j);
+      }
+    }
+    __syncthreads();
+    if (tid < PIPE_HIST && s_first[tid] != 0x7FFFFFFF) {
+      // the reference's "bearing angle" of the group's FIRST landmark (extractor.py:231-240): a = Frobenius norm of the 4x4 relative
+      // transform, b = |H0 [p; 0]|, c = |H1 [p; 0]|, law of cosines in degrees; NaN rejects
+      const int j0 = s_first[tid];
+      const float w4 = X4[(size_t)3 * x4_stride + j0];
+      double p3[3];
+      for (int k = 0; k < 3; k++) p3[k] = (double)(X4[(size_t)k * x4_stride + j0] / w4);
+      const double* H0 = P.H + 12 * (size_t)((t - tid) & (PIPE_HIST - 1)); const double* H1 = P.H + 12 * (size_t)(t & (PIPE_HIST - 1));
+      double inv0[12];                                   // inv([R | t]) = [R^T | -R^T t]
+      for (int r = 0; r < 3; r++) {
+        for (int k = 0; k < 3; k++) inv0[4 * r + k] = H0[4 * k + r];
+        inv0[4 * r + 3] = -(H0[r] * H0[3] + H0[4 + r] * H0[7] + H0[8 + r] * H0[11]);
+      }
+      double a2 = 1.0;                                   // bottom row [0 0 0 1]
+      for (int r = 0; r < 3; r++)
+        for (int col = 0; col < 4; col++) {
+          double sacc = 0;
+          for (int k = 0; k < 3; k++) sacc += H1[4 * r + k] * inv0[4 * k + col];
+          if (col == 3) sacc += H1[4 * r + 3];
+          a2 += sacc * sacc;
+        }
+      double b2 = 0, c2 = 0;
+      for (int r = 0; r < 3; r++) {
+        const double v0 = H0[4 * r] * p3[0] + H0[4 * r + 1] * p3[1] + H0[4 * r + 2] * p3[2];
+        const double v1 = H1[4 * r] * p3[0] + H1[4 * r + 1] * p3[1] + H1[4 * r + 2] * p3[2];
+        b2 += v0 * v0; c2 += v1 * v1;
+      }
+      const double a = sqrt(a2), bb = sqrt(b2), cc = sqrt(c2);
+      const double theta = acos((bb * bb + cc * cc - a * a) / (2.0 * bb * cc)) * 57.29577951308232;
+      s_gate[tid] = (theta > min_angle) ? 1 : 0;         // false for NaN
+    }
+    __syncthreads();
+    // accepted groups are appended in ascending birth frame (= descending age; the reference walks a Python set of small ints),
+    // each in list order (extractor.py:238-240)
+    int room = P.N - nl - nc;
+    if (room < 0) room = 0;
+    for (int a = PIPE_HIST - 1; a >= 0; a--) {
+      if (!s_gate[a]) continue;                          // uniform: s_gate is shared
+      bool f[PIPE_CH]; int rank[PIPE_CH];
+#pragma unroll
+      for (int c = 0; c < PIPE_CH; c++) f[c] = kept[c] && age[c] == a;
+      const int n_grp = pipe_rank(f, rank, s_w);
+      int n_take = n_grp < room ? n_grp : room;
+      if (n_grp > n_take) overflow |= 2;
+      if (headL + n_take > nfL) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_CAPACITY; return; }
+#pragma unroll
+      for (int c = 0; c < PIPE_CH; c++)
+        if (f[c] && rank[c] < n_take) {
+          const int j = c * PIPE_TPB + tid, nlr = P.freeL[headL + rank[c]];
+          P.l_tl[nlr] = t;                                                                   // Landmark(t_curr, p, des) (extractor.py:274-275)
+          for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = (double)pt[c][k];
+          P.lm_L[nl + rank[c]] = nlr; P.lm_K[nl + rank[c]] = P.ripe[j]; P.lm_ksh[nl + rank[c]] = 0;
+        }
+      headL += n_take; nl += n_take; n_new += n_take; room -= n_take;
+    }
+  }
+  __syncthreads();
+  int n_res = 0, nd = nd0, n_inert = 0;
+  if (do_adjust) {
+    // ---- dead landmarks whose track lies inside the window are appended to the state's lists as the same objects (bundle_adjuster.py:132-150) ----
+    int DL[PIPE_CH], DK[PIPE_CH]; bool win[PIPE_CH], take[PIPE_CH], stay[PIPE_CH];
+    int wr[PIPE_CH];
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) {
+      const int j = c * PIPE_TPB + tid;
+      DL[c] = DK[c] = 0; win[c] = false;
+      if (j < nd0) { DL[c] = P.dead_L[j]; DK[c] = P.dead_K[j]; win[c] = (t - (P.l_tl[DL[c]] - (P.k_len[DK[c]] - 1))) < Wn; }
+    }
+    const int n_win = pipe_rank(win, wr, s_w);
+    int room = P.N - nl - nc;
+    if (room < 0) room = 0;
+    n_res = n_win < room ? n_win : room;
+    if (n_win > n_res) overflow |= 4;
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) {
+      take[c] = win[c] && wr[c] < n_res;
+      if (take[c]) { P.lm_L[nl + wr[c]] = DL[c]; P.lm_K[nl + wr[c]] = DK[c]; P.lm_ksh[nl + wr[c]] = 1; }
+      const int j = c * PIPE_TPB + tid;
+      if (j < nd0 && !take[c]) st_i32(&P.scr[DL[c]], 0);
+    }
+    nl += n_res;
+    __syncthreads();
+    // an entry that stays dead is kept while it may still be resurrected: the window test holds, or its L row is in the state's list
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) { const int j = c * PIPE_TPB + tid; if (j < nl) st_i32(&P.scr[P.lm_L[j]], 1); }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) { const int j = c * PIPE_TPB + tid; stay[c] = j < nd0 && !take[c] && (win[c] || ld_i32(&P.scr[DL[c]]) == 1); }
+    int tr[PIPE_CH], sr[PIPE_CH];
+    const int n_take = pipe_rank(take, tr, s_w);
+    const int n_stay = pipe_rank(stay, sr, s_w);
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) {
+      if (take[c]) { P.dead_L[tr[c]] = DL[c]; P.dead_K[tr[c]] = DK[c]; }
+      if (stay[c]) { P.dead_L[n_take + sr[c]] = DL[c]; P.dead_K[n_take + sr[c]] = DK[c]; }
+    }
+    nd = n_take + n_stay; n_inert = nd0 - nd;
+    __syncthreads();
+    // ---- the bundle-adjustment problem (bundle_adjuster.py:153-176): points, observations from the keypoint histories, window poses ----
+    double* pts0 = x0 + 6 * (size_t)Wn;
+    int nobs = 0;
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) {
+      const int j = c * PIPE_TPB + tid;
+      if (j >= Nba) continue;
+      if (j < nl) {
+        const int Lr = P.lm_L[j], Kr = P.lm_K[j], n = P.k_len[Kr], tl = P.l_tl[Lr];
+        for (int k = 0; k < 3; k++) pts0[3 * (size_t)j + k] = P.l_p[3 * (size_t)Lr + k];
+        for (int s = 0; s < Wn; s++) {
+          const int idx = (t - s) - tl + n - 1;                      // k.uv_history[(t_now - s) - l.t_latest + len - 1] (:56-59, :156)
+          double2 v = make_double2(__builtin_nan(""), __builtin_nan(""));
+          if (idx >= 0 && idx <= n - 1 && idx >= n - PIPE_HIST) { const float2 h = pipe_hist_slot(P, idx)[Kr]; v = make_double2((double)h.x, (double)h.y); nobs++; }
+          reinterpret_cast<double2*>(obs)[(size_t)s * Nba + j] = v;
+        }
+      } else {
+        for (int k = 0; k < 3; k++) pts0[3 * (size_t)j + k] = 0.0;
+        for (int s = 0; s < Wn; s++) reinterpret_cast<double2*>(obs)[(size_t)s * Nba + j] = make_double2(__builtin_nan(""), __builtin_nan(""));
+      }
+    }
+    if (nobs) atomicAdd(&s_nobs, nobs);
+    if (tid < Wn) {
+      double* po = x0 + 6 * tid;
+      const int tt = t - tid;
+      if (tt >= 0 && tid < PIPE_HIST) {                              // poses missing at the start of a sequence stay zero (:169-171)
+        const double* Hs = P.H + 12 * (size_t)(tt & (PIPE_HIST - 1));
+        const double R[9] = {Hs[0], Hs[1], Hs[2], Hs[4], Hs[5], Hs[6], Hs[8], Hs[9], Hs[10]};
+        pipe_log_so3(R, po);
+        po[3] = Hs[3]; po[4] = Hs[7]; po[5] = Hs[11];
+      } else {
+        for (int k = 0; k < 6; k++) po[k] = 0.0;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    P.cnt[C_NLM] = nl; P.cnt[C_NNEW] = n_new; P.cnt[C_HEADL] = headL; P.cnt[C_OVERFLOW] = overflow;
+    if (do_adjust) { P.cnt[C_NDEAD] = nd; P.cnt[C_NINERT] += n_inert; P.cnt[C_NRES] = n_res; P.cnt[C_NOBS] = s_nobs; }
+  }
+}
+
+// ================================================================================================
+// k_pipe_writeback: solution -> landmark rows and trajectory (bundle_adjuster.py:197-213); the resident point set
+// ================================================================================================
+struct pipe_ba_head { double lambda, nu, cost, cost0; int cur, iter, accepted, status, done, n_obs; };
+
+__global__ void __launch_bounds__(PIPE_TPB) k_pipe_writeback(pipe_ptrs Pall, int do_adjust, const uint8_t* __restrict__ pub, size_t pub_bytes, const double* __restrict__ x0,
+                                                             size_t x_stride, int Wn, float* __restrict__ pts, size_t slab_seq,
+                                                             vo_pipe_record* __restrict__ rec) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const pipe_ptrs P = pipe_select(Pall, b);
+  if (P.cnt[C_STATUS]) return;
+  const int nl = P.cnt[C_NLM], nc = P.cnt[C_NCAND], t = P.cnt[C_T];
+  float2* out = reinterpret_cast<float2*>(vo_seq(pts, slab_seq, b));
+  if (do_adjust) {
+    const pipe_ba_head* st = reinterpret_cast<const pipe_ba_head*>(pub + (size_t)b * pub_bytes);
+    // nothing observed: the adapter skips the solve and writes x0 back (bundle_adjuster.py would hand scipy an empty problem)
+    const double* x = (P.cnt[C_NOBS] > 0) ? reinterpret_cast<const double*>(pub + (size_t)b * pub_bytes + 64) : x0 + (size_t)b * x_stride;
+    const double* xp = x + 6 * (size_t)Wn;
+    // entries that share a landmark row: the reference assigns in list order, the LAST one wins (:197-201)
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) { const int j = c * PIPE_TPB + tid; if (j < nl) st_i32(&P.scr[P.lm_L[j]], -1); }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) { const int j = c * PIPE_TPB + tid; if (j < nl) atomicMax(&P.scr[P.lm_L[j]], j); }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < PIPE_CH; c++) {
+      const int j = c * PIPE_TPB + tid;
+      if (j < nl) { const int Lr = P.lm_L[j]; if (ld_i32(&P.scr[Lr]) == j) for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)Lr + k] = xp[3 * (size_t)j + k]; }
+    }
+    if (tid < Wn && t - tid >= 0 && tid < PIPE_HIST) {
+      double R[9];
+      pipe_rodrigues(x + 6 * tid, R);
+      double* Hd = P.H + 12 * (size_t)((t - tid) & (PIPE_HIST - 1));
+      for (int r = 0; r < 3; r++) { for (int k = 0; k < 3; k++) Hd[4 * r + k] = R[3 * r + k]; Hd[4 * r + 3] = x[6 * tid + 3 + r]; }
+    }
+    if (tid == 0) {
+      vo_pipe_record& r = rec[b];
+      const bool solved = P.cnt[C_NOBS] > 0;
+      r.ba_landmarks = nl; r.ba_observations = P.cnt[C_NOBS];
+      r.ba_iters = solved ? st->iter : 0; r.ba_accepted = solved ? st->accepted : 0; r.ba_status = solved ? st->status : 0;
+      r.ba_done = solved ? st->done : 1; r.ba_cost0 = solved ? st->cost0 : 0.0; r.ba_cost = solved ? st->cost : 0.0;
+    }
+  }
+  // resident point set = every keypoint of the state (landmark entries first): exclusion discs now, the next frame's KLT input
+#pragma unroll
+  for (int c = 0; c < PIPE_CH; c++) {
+    const int j = c * PIPE_TPB + tid;
+    if (j < nl) out[j] = P.k_uv[P.lm_K[j]];
+    if (j < nc) out[nl + j] = P.k_uv[P.cand[j]];
+  }
+  if (tid == 0) { P.cnt[C_NPTS] = nl + nc; Pall.dn[DN_PTS * gridDim.x + b] = nl + nc; }
+}
+
+// ================================================================================================
+// k_pipe_spawn: corners -> candidates; free rows; the frame's record
+// ================================================================================================
+__global__ void __launch_bounds__(PIPE_TPB) k_pipe_spawn(pipe_ptrs Pall, int do_detect, const uint32_t* __restrict__ st_scalars, const float* __restrict__ st_out,
+                                                         float* __restrict__ pts, size_t slab_seq, int max_new, const double* __restrict__ pnp_out,
+                                                         const int32_t* __restrict__ pnp_ctrl, size_t pnp_ctrl_stride, vo_pipe_record* __restrict__ rec) {
+  __shared__ int s_w[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const pipe_ptrs P = pipe_select(Pall, b);
+  vo_pipe_record& r = rec[b];
+  const int status = P.cnt[C_STATUS];
+  const int t = P.cnt[C_T], nl = P.cnt[C_NLM];
+  int nc = P.cnt[C_NCAND];
+  int overflow = P.cnt[C_OVERFLOW], n_det = 0;
+  __syncthreads();
+  if (!status && do_detect) {
+    const uint32_t* sc = vo_seq(st_scalars, slab_seq, b);
+    const float2* corners = reinterpret_cast<const float2*>(vo_seq(st_out, slab_seq, b));
+    float2* out = reinterpret_cast<float2*>(vo_seq(pts, slab_seq, b));
+    const uint32_t ndet = sc[2];
+    int m = (ndet == 0xFFFFFFFFu) ? 0 : (int)ndet;
+    if (ndet == 0xFFFFFFFFu) overflow |= 16;
+    if (m > max_new) m = max_new;
+    int room = P.N - nl - nc;
+    if (room < 0) room = 0;
+    if (m > room) { m = room; overflow |= 8; }
+    const int headK = P.cnt[C_HEADK], nfK = P.cnt[C_NFREEK];
+    if (headK + m > nfK) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_CAPACITY; m = 0; }
+    for (int i = tid; i < m; i += PIPE_TPB) {
+      // Keypoint(t_first = t, t_total = 1, uv_first = uv = corner, uv_history = [corner]) (extractor.py:127-130)
+      const int k = P.freeK[headK + i];
+      const float2 q = corners[i];
+      P.k_tf[k] = t; P.k_tt[k] = 1; P.k_len[k] = 1; P.k_uv[k] = q; P.k_first[k] = q; pipe_hist_slot(P, 0)[k] = q;
+      P.cand[nc + i] = k; out[nl + nc + i] = q;
+    }
+    n_det = m; nc += m;
+    __syncthreads();
+    if (tid == 0) { P.cnt[C_NCAND] = nc; P.cnt[C_NPTS] = nl + nc; Pall.dn[DN_PTS * gridDim.x + b] = nl + nc; P.cnt[C_HEADK] = headK + m; }
+  }
+  __syncthreads();
+  // ---- rows no list refers to go back to the free lists (ascending) ----
+  const int nd = P.cnt[C_NDEAD];
+  for (int pass = 0; pass < 2; pass++) {
+    for (int i = tid; i < P.R; i += PIPE_TPB) P.scr[i] = 0;
+    __syncthreads();
+    for (int j = tid; j < P.N; j += PIPE_TPB) {
+      if (pass == 0) { if (j < nc) P.scr[P.cand[j]] = 1; if (j < nl) P.scr[P.lm_K[j]] = 1; if (j < nd) P.scr[P.dead_K[j]] = 1; }
+      else { if (j < nl) P.scr[P.lm_L[j]] = 1; if (j < nd) P.scr[P.dead_L[j]] = 1; }
+    }
+    __syncthreads();
+    int32_t* fl = pass == 0 ? P.freeK : P.freeL;
+    int base = 0;
+    for (int i0 = 0; i0 < P.R; i0 += PIPE_TPB) {
+      const int i = i0 + tid;
+      const int fr = (i < P.R && P.scr[i] == 0) ? 1 : 0;
+      int tot;
+      const int pos = pipe_scan(fr, s_w, tot);
+      if (fr) fl[base + pos] = i;
+      base += tot;
+    }
+    __syncthreads();
+    if (tid == 0) { P.cnt[pass == 0 ? C_NFREEK : C_NFREEL] = base; P.cnt[pass == 0 ? C_HEADK : C_HEADL] = 0; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    r.t = t; r.status = P.cnt[C_STATUS]; r.overflow = overflow;
+    r.n_landmarks = nl; r.n_candidates = nc; r.n_dead = nd; r.n_dead_total = nd + P.cnt[C_NINERT];
+    r.n_tracked = P.cnt[C_NKLT];
+    const double n_in = pnp_out[8 * (size_t)b + 7];
+    r.pnp_inliers = (n_in == n_in) ? (int)n_in : 0; r.pnp_hypotheses = pnp_ctrl[(size_t)b * pnp_ctrl_stride + 1];
+    r.pnp_bound_reached = pnp_ctrl[(size_t)b * pnp_ctrl_stride + 2];
+    r.n_ripe = P.cnt[C_NRIPE]; r.n_new = P.cnt[C_NNEW]; r.n_resurrected = P.cnt[C_NRES]; r.n_detected = n_det; r.pad = 0;
+    const double* Hs = P.H + 12 * (size_t)(t & (PIPE_HIST - 1));
+    for (int k = 0; k < 12; k++) r.H[k] = Hs[k];
+    P.cnt[C_NDET] = n_det; P.cnt[C_OVERFLOW] = overflow;
+  }
+}
+
+// after the tables were written from the host: free rows + the resident point set
+__global__ void __launch_bounds__(PIPE_TPB) k_pipe_commit(pipe_ptrs Pall, float* __restrict__ pts, size_t slab_seq) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const pipe_ptrs P = pipe_select(Pall, b);
+  const int nl = P.cnt[C_NLM], nc = P.cnt[C_NCAND];
+  float2* out = reinterpret_cast<float2*>(vo_seq(pts, slab_seq, b));
+  for (int j = tid; j < P.N; j += PIPE_TPB) {
+    if (j < nl) out[j] = P.k_uv[P.lm_K[j]];
+    if (j < nc) out[nl + j] = P.k_uv[P.cand[j]];
+  }
+  if (tid == 0) { P.cnt[C_NPTS] = nl + nc; Pall.dn[DN_PTS * gridDim.x + b] = nl + nc; Pall.dn[DN_PNP * gridDim.x + b] = 0; Pall.dn[DN_RIPE * gridDim.x + b] = 0; }
+}
+
+// ================================================================================================
+// host
+// ================================================================================================
+void vo_pipe_destroy(vo_ctx* c) {
+  if (!c->pipe) return;
+  vo_pipe_ws* w = c->pipe;
+  for (void* p : w->tab) if (p) (void)hipFree(p);
+  void* bufs[] = {w->d_ripe, w->d_freeK, w->d_freeL, w->d_scr, w->d_dn, w->d_cam_sel, w->d_cams, w->d_K, w->d_rec};
+  for (void* p : bufs) if (p) (void)hipFree(p);
+  if (w->h_rec) (void)hipHostFree(w->h_rec);
+  for (hipEvent_t e : w->ev) if (e) (void)hipEventDestroy(e);
+  delete w;
+  c->pipe = nullptr;
+  c->d_pt_counts = nullptr;
+}
+
+extern "C" int32_t vo_pipe_default_params(vo_pipe_params* p) {
+  if (!p) return VO_E_INVALID;
+  memset(p, 0, sizeof(*p));
+  p->ba_window = 4; p->min_track_length = 3; p->mask_radius = 7; p->max_new = 1000; p->pnp_blind_batches = 4;
+  p->max_reproj_err = 2.0; p->min_bearing_angle = 0.5;
+  vo_klt_default_params(&p->klt); vo_st_default_params(&p->st); vo_ba_default_params(&p->ba); vo_pnp_default_params(&p->pnp);
+  p->st.min_distance = 7.0;
+  p->ba_budget = p->ba.max_iters;
+  return VO_OK;
+}
+
+extern "C" int32_t vo_pipe_create(vo_ctx* c, const double* K, const vo_pipe_params* prm) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, K, VO_E_INVALID, "null K");
+  vo_pipe_params def;
+  if (!prm) { vo_pipe_default_params(&def); prm = &def; }
+  VO_CHECK(c, prm->ba_window >= 1 && prm->ba_window <= 20, VO_E_INVALID, "ba_window must be 1..20");
+  VO_CHECK(c, c->max_pts <= PIPE_TPB * PIPE_CH, VO_E_CAPACITY, "the pipeline tables hold at most 4096 keypoints per sequence (max_pts)");
+  VO_CHECK(c, prm->min_track_length >= 1 && prm->max_new >= 0 && prm->pnp_blind_batches >= 1 && prm->pnp_blind_batches <= 64, VO_E_INVALID, "bad parameters");
+  VO_CHECK(c, prm->ba.max_iters >= 0 && prm->ba.max_iters <= 1000 && prm->ba_budget >= 0 && prm->ba_budget <= prm->ba.max_iters, VO_E_INVALID,
+           "ba_budget must be 0..ba.max_iters");
+  VO_HIP(c, hipSetDevice(c->device));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  vo_pipe_destroy(c);
+  vo_pipe_ws* w = new vo_pipe_ws();
+  c->pipe = w;
+  w->prm = *prm;
+  w->N = c->max_pts; w->R = 4 * c->max_pts;
+  const size_t B = c->batch, N = w->N, R = w->R;
+  const size_t sz[VO_PIPE_N_TABLES] = {4 * R, 4 * R, 4 * R, 8 * R, 8 * R, 8 * R * PIPE_HIST, 4 * R, 24 * R, 4 * N, 4 * N, 4 * N, 4 * N, 4 * N, 4 * N,
+                                       4 * PIPE_NCNT, 8 * 12 * PIPE_HIST};
+  for (int i = 0; i < VO_PIPE_N_TABLES; i++) {
+    w->tab_bytes[i] = sz[i];
+    VO_HIP(c, hipMalloc(&w->tab[i], sz[i] * B));
+    VO_HIP(c, hipMemsetAsync(w->tab[i], 0, sz[i] * B, c->stream));
+  }
+  VO_HIP(c, hipMalloc((void**)&w->d_ripe, 4 * N * B));
+  VO_HIP(c, hipMalloc((void**)&w->d_freeK, 4 * R * B));
+  VO_HIP(c, hipMalloc((void**)&w->d_freeL, 4 * R * B));
+  VO_HIP(c, hipMalloc((void**)&w->d_scr, 4 * R * B));
+  VO_HIP(c, hipMalloc((void**)&w->d_cam_sel, 4 * N * B));
+  VO_HIP(c, hipMemsetAsync(w->d_cam_sel, 0, 4 * N * B, c->stream));
+  VO_HIP(c, hipMalloc((void**)&w->d_cams, sizeof(vo_dlt_cam) * PIPE_HIST * B));
+  VO_HIP(c, hipMemsetAsync(w->d_cams, 0, sizeof(vo_dlt_cam) * PIPE_HIST * B, c->stream));
+  VO_HIP(c, hipMalloc((void**)&w->d_dn, 4 * 3 * B));
+  VO_HIP(c, hipMemsetAsync(w->d_dn, 0, 4 * 3 * B, c->stream));
+  VO_HIP(c, hipMalloc((void**)&w->d_K, 72 * B));
+  VO_HIP(c, hipMalloc((void**)&w->d_rec, sizeof(vo_pipe_record) * B));
+  VO_HIP(c, hipMemsetAsync(w->d_rec, 0, sizeof(vo_pipe_record) * B, c->stream));
+  VO_HIP(c, hipHostMalloc((void**)&w->h_rec, sizeof(vo_pipe_record) * B * VO_PIPE_INFLIGHT, hipHostMallocDefault));
+  const unsigned fl = hipEventDisableTiming | ((getenv("VO_BLOCKING_SYNC") && atoi(getenv("VO_BLOCKING_SYNC"))) ? hipEventBlockingSync : 0u);
+  for (int i = 0; i < VO_PIPE_INFLIGHT; i++) VO_HIP(c, hipEventCreateWithFlags(&w->ev[i], fl));
+  VO_HIP(c, hipMemcpyAsync(w->d_K, K, 72 * B, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  int32_t r = vo_ba_reserve(c, K, prm->ba_window, w->N);
+  if (r != VO_OK) return r;
+  r = vo_pnp_reserve(c, K);
+  if (r != VO_OK) return r;
+  r = vo_st_prepare(c, &w->prm.st);
+  if (r != VO_OK) return r;
+  c->n_resident = c->max_pts;
+  c->d_pt_counts = w->d_dn + DN_PTS * B;
+  return vo_pipe_commit(c);
+}
+
+extern "C" int32_t vo_pipe_table_bytes(vo_ctx* c, int32_t which, uint64_t* bytes) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->pipe && which >= 0 && which < VO_PIPE_N_TABLES && bytes, VO_E_INVALID, "vo_pipe_create first / bad table");
+  *bytes = (uint64_t)c->pipe->tab_bytes[which] * (uint64_t)c->batch;
+  return VO_OK;
+}
+
+extern "C" int32_t vo_pipe_table_write(vo_ctx* c, int32_t which, const void* src) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->pipe && which >= 0 && which < VO_PIPE_N_TABLES && src, VO_E_INVALID, "vo_pipe_create first / bad table");
+  VO_CHECK(c, c->pipe->enq == c->pipe->fetched, VO_E_STATE, "fetch the steps in flight first");
+  VO_HIP(c, hipSetDevice(c->device));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  VO_HIP(c, hipMemcpy(c->pipe->tab[which], src, c->pipe->tab_bytes[which] * c->batch, hipMemcpyHostToDevice));
+  return VO_OK;
+}
+
+extern "C" int32_t vo_pipe_table_read(vo_ctx* c, int32_t which, void* dst) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->pipe && which >= 0 && which < VO_PIPE_N_TABLES && dst, VO_E_INVALID, "vo_pipe_create first / bad table");
+  VO_HIP(c, hipSetDevice(c->device));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  VO_HIP(c, hipMemcpy(dst, c->pipe->tab[which], c->pipe->tab_bytes[which] * c->batch, hipMemcpyDeviceToHost));
+  return VO_OK;
+}
+
+static void pipe_launch_spawn(vo_ctx* c, int do_detect) {
+  vo_pipe_ws* w = c->pipe;
+  vo_pnp_view pv;
+  (void)vo_pnp_get_view(c, &pv);
+  hipLaunchKernelGGL(k_pipe_spawn, dim3(c->batch), dim3(PIPE_TPB), 0, c->stream, pipe_make(w), do_detect, vo_slab<const uint32_t>(c, c->off_st_scalars),
+                     vo_slab<const float>(c, c->off_st_out), vo_slab<float>(c, vo_off_p(c)), c->slab_seq, w->prm.max_new, pv.out, pv.ctrl,
+                     pv.ctrl_stride, w->d_rec);
+}
+
+extern "C" int32_t vo_pipe_commit(vo_ctx* c) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->pipe, VO_E_STATE, "vo_pipe_create first");
+  VO_HIP(c, hipSetDevice(c->device));
+  vo_pipe_ws* w = c->pipe;
+  hipLaunchKernelGGL(k_pipe_commit, dim3(c->batch), dim3(PIPE_TPB), 0, c->stream, pipe_make(w), vo_slab<float>(c, vo_off_p(c)), c->slab_seq);
+  pipe_launch_spawn(c, 0);                      // free lists (and a record of the seeded state)
+  VO_HIP(c, hipGetLastError());
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
+extern "C" int32_t vo_pipe_set_ba_budget(vo_ctx* c, int32_t budget) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->pipe, VO_E_STATE, "vo_pipe_create first");
+  VO_CHECK(c, budget >= 0 && budget <= c->pipe->prm.ba.max_iters, VO_E_INVALID, "budget must be 0..ba.max_iters");
+  c->pipe->prm.ba_budget = budget;
+  return VO_OK;
+}
+
+extern "C" int32_t vo_pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->pipe, VO_E_STATE, "vo_pipe_create first");
+  vo_pipe_ws* w = c->pipe;
+  VO_CHECK(c, w->enq - w->fetched < VO_PIPE_INFLIGHT, VO_E_STATE, "vo_pipe_fetch the oldest step first");
+  VO_HIP(c, hipSetDevice(c->device));
+  const vo_pipe_params& prm = w->prm;
+  const pipe_ptrs P = pipe_make(w);
+  const int B = c->batch;
+  int32_t r;
+  vo_pnp_view pv; vo_ba_view bv;
+  r = vo_pnp_get_view(c, &pv); if (r != VO_OK) return r;
+  r = vo_ba_get_view(c, &bv); if (r != VO_OK) return r;
+  if (stages & VO_PIPE_TRACK) {
+    if (frame_idx >= 0) {
+      VO_CHECK(c, c->d_seq && frame_idx < c->seq_n, VO_E_STATE, "no resident sequence / bad frame index");
+      const size_t fr = (size_t)c->width * c->height;
+      r = vo_build_pyramid(c, c->d_seq + (size_t)frame_idx * fr, fr * c->seq_n, nullptr);
+      if (r != VO_OK) return r;
+    }
+    VO_CHECK(c, c->n_pushed >= 2, VO_E_STATE, "tracking needs two frames in the frame store");
+    r = vo_klt_track_resident(c, w->N, &prm.klt);
+    if (r != VO_OK) return r;
+    hipLaunchKernelGGL(k_pipe_extend, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq, c->width, c->height,
+                       pv.X, pv.uv, pv.cap);
+  }
+  if (stages & VO_PIPE_POSE) {
+    r = vo_pnp_enqueue_counts(c, &prm.pnp, prm.pnp_blind_batches, w->d_dn + DN_PNP * B);
+    if (r != VO_OK) return r;
+  }
+  if (stages & (VO_PIPE_POSE | VO_PIPE_TRIANGULATE))
+    hipLaunchKernelGGL(k_pipe_prune, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, (stages & VO_PIPE_POSE) ? 1 : 0, (stages & VO_PIPE_TRIANGULATE) ? 1 : 0,
+                       pv.mask, pv.out, pv.cap, prm.min_track_length, c->d_uv0, c->d_uv1, (size_t)c->max_pts * 2, w->d_cams, w->d_cam_sel);
+  if (stages & VO_PIPE_TRIANGULATE) {
+    r = vo_dlt_enqueue_counts(c, w->N, w->d_dn + DN_RIPE * B, w->d_cams, w->d_cam_sel, PIPE_HIST);
+    if (r != VO_OK) return r;
+  }
+  if (stages & (VO_PIPE_TRIANGULATE | VO_PIPE_ADJUST))
+    hipLaunchKernelGGL(k_pipe_promote, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, (stages & VO_PIPE_TRIANGULATE) ? 1 : 0, (stages & VO_PIPE_ADJUST) ? 1 : 0,
+                       vo_slab<const float>(c, c->off_X4), vo_slab<const double>(c, c->off_depth), vo_slab<const double>(c, c->off_reproj), c->slab_seq,
+                       w->N, prm.max_reproj_err, prm.min_bearing_angle, w->d_cam_sel, bv.W, bv.x0, bv.obs, bv.x_stride, bv.obs_stride, bv.N);
+  if (stages & VO_PIPE_ADJUST) {
+    r = vo_ba_enqueue_budget(c, &prm.ba, 0, prm.ba_budget);
+    if (r != VO_OK) return r;
+  }
+  hipLaunchKernelGGL(k_pipe_writeback, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, (stages & VO_PIPE_ADJUST) ? 1 : 0, bv.pub, bv.pub_bytes, bv.x0, bv.x_stride,
+                     bv.W, vo_slab<float>(c, vo_off_p(c)), c->slab_seq, w->d_rec);
+  if (stages & VO_PIPE_DETECT) {
+    r = vo_shi_tomasi_resident(c, w->N, prm.mask_radius, &prm.st);
+    if (r != VO_OK) return r;
+  }
+  pipe_launch_spawn(c, (stages & VO_PIPE_DETECT) ? 1 : 0);
+  VO_HIP(c, hipGetLastError());
+  const int slot = (int)(w->enq % VO_PIPE_INFLIGHT);
+  VO_HIP(c, hipMemcpyAsync(w->h_rec + (size_t)slot * B, w->d_rec, sizeof(vo_pipe_record) * B, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipEventRecord(w->ev[slot], c->stream));
+  w->enq++;
+  return VO_OK;
+}
+
+extern "C" int32_t vo_pipe_fetch(vo_ctx* c, vo_pipe_record* rec) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->pipe && rec, VO_E_STATE, "vo_pipe_create first / null output");
+  vo_pipe_ws* w = c->pipe;
+  VO_CHECK(c, w->fetched < w->enq, VO_E_STATE, "no step in flight");
+  VO_HIP(c, hipSetDevice(c->device));
+  const int slot = (int)(w->fetched % VO_PIPE_INFLIGHT);
+  VO_HIP(c, hipEventSynchronize(w->ev[slot]));
+  memcpy(rec, w->h_rec + (size_t)slot * c->batch, sizeof(vo_pipe_record) * c->batch);
+  w->fetched++;
+  return VO_OK;
+}

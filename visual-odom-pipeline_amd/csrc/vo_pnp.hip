@@ -267,13 +267,15 @@ __device__ inline void pnp_inv3(const double* K, double* Ki) {
 // k_pnp_score : grid (PNP_BATCH, batch): WAVE per hypothesis -- the lanes stride over the points, shuffle sum
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_pnp_solve(const double* __restrict__ Kall, const float* __restrict__ Xall, const float* __restrict__ uvall,
-                                                  int cap, int n, unsigned seed, pnp_hyp* __restrict__ hyps, const pnp_ctrl* __restrict__ ctrl) {
+                                                  int cap, int n, unsigned seed, pnp_hyp* __restrict__ hyps, const pnp_ctrl* __restrict__ ctrl,
+                                                  const int32_t* __restrict__ counts) {
   const int b = blockIdx.y, slot = blockIdx.x * 64 + threadIdx.x;
+  if (counts) n = counts[b];
   const pnp_ctrl cs = ctrl[b];
   pnp_hyp* out = hyps + (size_t)b * PNP_BATCH + slot;
   const int h = cs.h_done + slot;
   out->h = h;
-  if (cs.done) { out->count = -1; return; }
+  if (cs.done || n < 4) { out->count = -1; return; }      // fewer than 4 correspondences: no sample exists
   const double* Kp = Kall + 9 * b;
   const float* X = Xall + (size_t)b * cap * 3;
   const float* uv = uvall + (size_t)b * cap * 2;
@@ -295,8 +297,9 @@ __global__ void __launch_bounds__(64) k_pnp_solve(const double* __restrict__ Kal
 }
 
 __global__ void __launch_bounds__(64) k_pnp_score(const double* __restrict__ Kall, const float* __restrict__ Xall, const float* __restrict__ uvall,
-                                                  int cap, int n, double thr2, pnp_hyp* __restrict__ hyps) {
+                                                  int cap, int n, double thr2, pnp_hyp* __restrict__ hyps, const int32_t* __restrict__ counts) {
   const int b = blockIdx.y, lane = threadIdx.x;
+  if (counts) n = counts[b];
   pnp_hyp* hp = hyps + (size_t)b * PNP_BATCH + blockIdx.x;
   if (hp->count < 0) { if (lane == 0) hp->count = 0; return; }
   const double* Kp = Kall + 9 * b;
@@ -328,11 +331,13 @@ __device__ inline int pnp_update_iters(double p, double ep, int model_points, in
 // k_pnp_select : grid (batch): running best (most inliers, ties to the smallest h) and the iteration bound
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PNP_BATCH) k_pnp_select(const pnp_hyp* __restrict__ hyps, pnp_ctrl* __restrict__ ctrl, int n, double conf,
-                                                          int max_iters) {
+                                                          int max_iters, const int32_t* __restrict__ counts) {
   __shared__ int s_cnt[PNP_BATCH];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (counts) n = counts[b];
   pnp_ctrl* c = ctrl + b;
   if (c->done) return;
+  if (n < 4) { if (tid == 0) c->done = 1; return; }
   const pnp_hyp* H = hyps + (size_t)b * PNP_BATCH;
   s_cnt[tid] = H[tid].count;
   __syncthreads();
@@ -404,11 +409,12 @@ __device__ inline void pnp_block_sum(double* v, int nv, double* s_red /* 4 * PNP
 
 __global__ void __launch_bounds__(256) k_pnp_refine(const double* __restrict__ Kall, const float* __restrict__ Xall, const float* __restrict__ uvall,
                                                     int cap, int n, double thr2, const pnp_ctrl* __restrict__ ctrl, uint8_t* __restrict__ mask_all,
-                                                    double* __restrict__ out_all) {
+                                                    double* __restrict__ out_all, const int32_t* __restrict__ counts) {
   __shared__ double s_red[4 * PNP_NRED], s_sum[PNP_NRED];
   __shared__ double s_R[9], s_t[3], s_Rn[9], s_tn[3], s_d[6];
   __shared__ int s_flag;
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (counts) n = counts[b];
   const double* K = Kall + 9 * b;
   const float* X = Xall + (size_t)b * cap * 3;
   const float* uv = uvall + (size_t)b * cap * 2;
@@ -578,31 +584,58 @@ static int32_t pnp_alloc(vo_ctx* c, int n) {
     VO_HIP(c, hipMalloc((void**)&w->d_ctrl, sizeof(pnp_ctrl) * B));
     VO_HIP(c, hipMalloc((void**)&w->d_mask, B * w->cap));
     VO_HIP(c, hipMalloc((void**)&w->d_out, sizeof(double) * 8 * B));
+    VO_HIP(c, hipMemsetAsync(w->d_out, 0, sizeof(double) * 8 * B, c->stream));
+    VO_HIP(c, hipMemsetAsync(w->d_ctrl, 0, sizeof(pnp_ctrl) * B, c->stream));
     VO_HIP(c, hipHostMalloc((void**)&w->h_ctrl, sizeof(pnp_ctrl) * B, hipHostMallocDefault));
     VO_HIP(c, hipHostMalloc((void**)&w->h_out, sizeof(double) * 8 * B, hipHostMallocDefault));
   }
   return VO_OK;
 }
 
-static void pnp_enqueue_batch(vo_ctx* c, const vo_pnp_params* prm) {
+static void pnp_enqueue_batch(vo_ctx* c, const vo_pnp_params* prm, const int32_t* counts = nullptr) {
   vo_pnp_ws* w = c->pnp;
   const unsigned B = (unsigned)c->batch;
   const double thr2 = prm->reproj_err * prm->reproj_err;
   hipLaunchKernelGGL(k_pnp_solve, dim3(PNP_BATCH / 64, B), dim3(64), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n, (unsigned)prm->seed,
-                     w->d_hyp, w->d_ctrl);
-  hipLaunchKernelGGL(k_pnp_score, dim3(PNP_BATCH, B), dim3(64), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n, thr2, w->d_hyp);
-  hipLaunchKernelGGL(k_pnp_select, dim3(B), dim3(PNP_BATCH), 0, c->stream, w->d_hyp, w->d_ctrl, w->n, prm->confidence, prm->max_iters);
+                     w->d_hyp, w->d_ctrl, counts);
+  hipLaunchKernelGGL(k_pnp_score, dim3(PNP_BATCH, B), dim3(64), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n, thr2, w->d_hyp, counts);
+  hipLaunchKernelGGL(k_pnp_select, dim3(B), dim3(PNP_BATCH), 0, c->stream, w->d_hyp, w->d_ctrl, w->n, prm->confidence, prm->max_iters, counts);
 }
 
-static int32_t pnp_enqueue_refine(vo_ctx* c, const vo_pnp_params* prm) {
+static int32_t pnp_enqueue_refine(vo_ctx* c, const vo_pnp_params* prm, const int32_t* counts = nullptr) {
   vo_pnp_ws* w = c->pnp;
   const size_t B = c->batch;
   hipLaunchKernelGGL(k_pnp_refine, dim3((unsigned)B), dim3(256), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n,
-                     prm->reproj_err * prm->reproj_err, w->d_ctrl, w->d_mask, w->d_out);
+                     prm->reproj_err * prm->reproj_err, w->d_ctrl, w->d_mask, w->d_out, counts);
   VO_HIP(c, hipGetLastError());
+  if (counts) return VO_OK;       // closed-loop pipeline: the results are consumed on the device
   VO_HIP(c, hipMemcpyAsync(w->h_out, w->d_out, sizeof(double) * 8 * B, hipMemcpyDeviceToHost, c->stream));
   VO_HIP(c, hipMemcpyAsync(w->h_ctrl, w->d_ctrl, sizeof(pnp_ctrl) * B, hipMemcpyDeviceToHost, c->stream));
   return VO_OK;
+}
+
+// ---- closed-loop pipeline hooks: the correspondences are written by a device kernel, counts[b] per sequence ----
+int32_t vo_pnp_reserve(vo_ctx* c, const double* K_host) {
+  int32_t r = pnp_alloc(c, c->max_pts);
+  if (r != VO_OK) return r;
+  VO_HIP(c, hipMemcpyAsync(c->pnp->d_K, K_host, sizeof(double) * 9 * c->batch, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  c->pnp->n = c->pnp->cap;
+  return VO_OK;
+}
+int32_t vo_pnp_get_view(vo_ctx* c, vo_pnp_view* v) {
+  VO_CHECK(c, c->pnp, VO_E_STATE, "vo_pnp_reserve first");
+  vo_pnp_ws* w = c->pnp;
+  v->X = w->d_X; v->uv = w->d_uv; v->mask = w->d_mask; v->out = w->d_out; v->ctrl = reinterpret_cast<const int32_t*>(w->d_ctrl);
+  v->ctrl_stride = sizeof(pnp_ctrl) / sizeof(int32_t); v->cap = w->cap;
+  return VO_OK;
+}
+int32_t vo_pnp_enqueue_counts(vo_ctx* c, const vo_pnp_params* prm, int blind_batches, const int32_t* d_counts) {
+  VO_CHECK(c, c->pnp, VO_E_STATE, "vo_pnp_reserve first");
+  vo_pnp_ws* w = c->pnp;
+  hipLaunchKernelGGL(k_pnp_init, dim3((unsigned)c->batch), dim3(1), 0, c->stream, w->d_ctrl, prm->max_iters);
+  for (int k = 0; k < blind_batches; k++) pnp_enqueue_batch(c, prm, d_counts);
+  return pnp_enqueue_refine(c, prm, d_counts);
 }
 
 // resident form: the correspondences stay in HBM (vo_pnp_upload), a solve is enqueued per frame without any host

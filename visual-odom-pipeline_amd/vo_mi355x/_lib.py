@@ -69,6 +69,19 @@ class BaStats(C.Structure):
                 ("accepted", C.c_int32), ("status", C.c_int32), ("n_obs", C.c_int32)]
 
 
+class PipeParams(C.Structure):
+    _fields_ = [("ba_window", C.c_int32), ("min_track_length", C.c_int32), ("mask_radius", C.c_int32), ("max_new", C.c_int32),
+                ("pnp_blind_batches", C.c_int32), ("ba_budget", C.c_int32), ("max_reproj_err", C.c_double),
+                ("min_bearing_angle", C.c_double), ("klt", KltParams), ("st", StParams), ("ba", BaParams), ("pnp", PnpParams)]
+
+
+class PipeRecord(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("t", "status", "overflow", "n_landmarks", "n_candidates", "n_dead", "n_dead_total", "n_tracked",
+                                         "pnp_inliers", "pnp_hypotheses", "pnp_bound_reached", "n_ripe", "n_new", "n_resurrected",
+                                         "n_detected", "ba_landmarks", "ba_observations", "ba_iters", "ba_accepted", "ba_status", "ba_done",
+                                         "_pad")] + [("ba_cost0", C.c_double), ("ba_cost", C.c_double), ("H", C.c_double * 12)]
+
+
 _u8p, _i16p, _i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.POINTER(C.c_int32)
 _f32p, _f64p = C.POINTER(C.c_float), C.POINTER(C.c_double)
 _ctx = C.c_void_p
@@ -141,6 +154,15 @@ SIGNATURES = {
     "vo_tracks_read": (C.c_int32, [_ctx, _i32p, _f32p, _f32p, _i32p, _i32p, _i32p, _i32p, _i32p]),
     "vo_tracks_obs": (C.c_int32, [_ctx, C.c_int32, C.c_int32, _f64p]),
     "vo_ba_obs_from_tracks": (C.c_int32, [_ctx, C.c_int32]),
+    "vo_pipe_default_params": (C.c_int32, [C.POINTER(PipeParams)]),
+    "vo_pipe_create": (C.c_int32, [_ctx, _f64p, C.POINTER(PipeParams)]),
+    "vo_pipe_table_bytes": (C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_uint64)]),
+    "vo_pipe_table_write": (C.c_int32, [_ctx, C.c_int32, C.c_void_p]),
+    "vo_pipe_table_read": (C.c_int32, [_ctx, C.c_int32, C.c_void_p]),
+    "vo_pipe_commit": (C.c_int32, [_ctx]),
+    "vo_pipe_step": (C.c_int32, [_ctx, C.c_int32, C.c_int32]),
+    "vo_pipe_fetch": (C.c_int32, [_ctx, C.POINTER(PipeRecord)]),
+    "vo_pipe_set_ba_budget": (C.c_int32, [_ctx, C.c_int32]),
     "vo_ba_probe": (C.c_int32, [_ctx, C.c_double, C.c_double, _f64p, _i32p, _f64p, _f64p, _f64p, _f64p, _f64p,
                                 _f64p, _f64p, _f64p, _f64p]),
 }
