@@ -52,6 +52,11 @@ def parse():
     ap.add_argument("--ctxs", type=int, default=3, help="batched contexts (HIP streams) the sequences are split over")
     ap.add_argument("--ba-iters", type=int, default=10, help="LM iteration budget per adjust")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames per sequence (played ping-pong)")
+    ap.add_argument("--pipe-window", type=int, default=4, help="--workload pipeline: BA window (the reference's own setting is 4, pipeline.py:19; BASELINE's 10)")
+    ap.add_argument("--pipe-no-resurrect", action="store_true", help="--workload pipeline: dead landmarks stay dead (the reference appends the recently dead "
+                                                                     "to the state's lists again in every adjust, bundle_adjuster.py:142-150)")
+    ap.add_argument("--pipe-max-pts", type=int, default=2048, help="--workload pipeline: capacity of the tracked keypoint set per sequence (<= 4096)")
+    ap.add_argument("--pipe-frames", type=int, default=40, help="--workload pipeline: rendered frames per scene (= the period of the camera's sway; played in a loop)")
     ap.add_argument("--graph", action="store_true", help="replay each frame from a captured hipGraph instead of plain launches")
     ap.add_argument("--host-threads", type=int, default=3, help="enqueue/fetch the contexts from this many host threads")
     ap.add_argument("--fixed-ba-budget", action="store_true",
@@ -62,9 +67,9 @@ def parse():
     ap.add_argument("--workload", choices=("A", "config5", "pipeline"), default="A",
                     help="A: BASELINE configs[2], the metric's configuration (default).  config5: ONE 1920x1080 sequence, 5000 "
                          "points, 20-frame BA whose landmarks are sharded over the ranks with an RCCL all-reduce per LM "
-                         "iteration (front end replicated); strong scaling, not the headline metric.  pipeline: workload A plus the "
-                         "steps of Pipeline.step around it on the device -- track table (KLT + pruning + history + re-detection "
-                         "spawn) and RANSAC-P3P pose -- issued as separate calls with one sync per frame; informational")
+                         "iteration (front end replicated); strong scaling, not the headline metric.  pipeline: the whole Pipeline.step "
+                         "resident on the device as a closed loop (tracks, landmarks, dead lists and the trajectory in device tables; one "
+                         "enqueue per frame, every stage fed by the previous ones); informational")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames each CPU-baseline worker process runs")
     ap.add_argument("--cpu-procs", type=int, default=16, help="CPU-baseline worker processes (one core each), capped by the host's cores")
@@ -131,7 +136,7 @@ class Group:
     """`batch` independent VO sequences carried in lockstep by ONE batched context (one HIP stream): every launch of
     the hot path serves all of them.  Everything is resident in HBM."""
 
-    def __init__(self, device, frame_sets, seed0, batch, ba_iters, shard=None, pipeline=False):
+    def __init__(self, device, frame_sets, seed0, batch, ba_iters, shard=None):
         """shard = (rank, n_ranks, unique_id): config 5 -- this context holds landmark shard `rank` of ONE BA problem"""
         from vo_mi355x import VoContext, sharding, synthetic as syn
         self.B = batch
@@ -139,10 +144,8 @@ class Group:
         c = self.c
         c.upload_sequence(np.stack([frame_sets[b % len(frame_sets)] for b in range(batch)]))
         self.nf = frame_sets[0].shape[0]
-        self.pipeline = pipeline
         pts0 = np.stack([syn.grid_points(N_PTS, W_IMG, H_IMG, seed=seed0 + b) for b in range(batch)])
-        if not pipeline:
-            c.points_upload(pts0)
+        c.points_upload(pts0)
         # DLT: 1000 new tracks between two window poses of each BA scene; BA: N = 2000, W = 10 per sequence
         kw = {} if K_CAM is None else dict(K=K_CAM, width=W_IMG, height=H_IMG)
         scenes = [syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=seed0 + b, **kw) for b in range(batch)]
@@ -182,17 +185,6 @@ class Group:
         self.klt_prm = c.klt_params()
         self.st_prm = c.st_params()
         c.push_frame_resident(0)
-        if pipeline:
-            # track table seeded with the keypoints; 3D-2D correspondences of the newest BA frame with 30 % gross outliers
-            c.tracks_seed(pts0, t=0)
-            rng = np.random.default_rng(seed0)
-            X = np.stack([s["points_gt"] for s in scenes]).astype(np.float32)
-            uv = np.stack([s["obs"][0] for s in scenes]).astype(np.float32)
-            for b in range(batch):
-                out = rng.choice(BA_N, int(0.3 * BA_N), replace=False)
-                uv[b, out] += rng.uniform(-80, 80, (len(out), 2)).astype(np.float32) + np.float32(15)
-            c.pnp_upload(np.stack(Ks), X, uv)
-            self.pnp_prm = c.pnp_params(reproj_err=2.0, confidence=0.9999, max_iters=1000000, seed=seed0)
         self.truncated = 0                 # solves that ended on the iteration budget (LM status 0)
         self.stages = (True, True, True)   # (DLT, BA, Shi-Tomasi) of the fused step
         self.t = 1
@@ -200,19 +192,6 @@ class Group:
         self.max_inflight = 2          # 1 when the step is replayed from a hipGraph (its host destinations are baked in)
 
     def enqueue(self):
-        if self.pipeline:
-            # Pipeline.step (reference pipeline.py:92-167) as separate device calls: frame -> extend tracks -> 3D-2D pose ->
-            # triangulate -> bundle adjust -> re-detect
-            c, t = self.c, self.t
-            c.push_frame_resident(pingpong(t, self.nf))
-            c.tracks_track(t, self.klt_prm)
-            c.pnp_solve_resident(self.pnp_prm, 2)
-            c.dlt_resident()
-            c.ba_solve_resident(self.ba_prm)
-            c.tracks_detect(t, 7, self.st_prm, max_new=1000)
-            self.t += 1
-            self.inflight += 1
-            return
         # one C call: pyramid + KLT + DLT + BA + Shi-Tomasi + result copies for the whole batch
         self.c.frame_step_resident(pingpong(self.t, self.nf), N_PTS, self.stages[0], self.stages[1], self.stages[2], 7, self.klt_prm,
                                    self.st_prm, self.ba_prm)
@@ -231,13 +210,7 @@ class Group:
             self.fetch()
 
     def fetch(self):
-        if self.pipeline:
-            rv, tv, inl, pst = self.c.pnp_fetch()                  # waits for the frame
-            po, pt, bst = self.c.ba_fetch()
-            nl, _ = self.c.tracks_counts()                         # the tables stay on the device; the loop needs the counters
-            self.last = {"ba_stats": bst, "pnp_stats": pst, "n_tracks": list(np.atleast_1d(nl))}
-        else:
-            self.last = self.c.frame_fetch()
+        self.last = self.c.frame_fetch()
         self.inflight -= 1
         if self.stages[1]:
             st = self.last["ba_stats"]
@@ -256,6 +229,182 @@ class Group:
     def ba_stats0(self):
         st = self.last["ba_stats"]
         return st[0] if isinstance(st, list) else st
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# closed loop: Pipeline.step (reference pipeline.py:92-167) resident on the device
+# ---------------------------------------------------------------------------------------------------------------------------
+PIPE_T1 = 4          # the bootstrap pair is (frame 0, frame 4) of a sequence (the reference uses (0, 10): datasets.yml)
+
+
+def pipe_scenes(n_scenes, n_frames, seed0):
+    """rendered KITTI-shaped two-plane scenes, camera swaying with period n_frames (frame n_frames - 1 is followed seamlessly by frame 0)"""
+    from vo_mi355x import synthetic as syn
+    return [syn.sway_scene(n_frames, w=W_IMG, h=H_IMG, f=718.856, seed=seed0 + k, pose_fn=lambda t: syn.sway_pose(t, period=float(n_frames)))
+            for k in range(n_scenes)]
+
+
+def pipe_phase_offsets(scene, n):
+    """start frames whose bootstrap pair (t, t + PIPE_T1) has a usable baseline (the sway stands still at its turning points)"""
+    P = scene["poses"]
+    nf = len(P)
+    base = np.array([np.linalg.norm((P[(t + PIPE_T1) % nf] @ np.linalg.inv(P[t]))[:3, 3]) for t in range(nf)])
+    good = [t for t in range(nf) if base[t] >= 0.5 * base.max()]
+    return [good[(3 * i) % len(good)] for i in range(n)]
+
+
+class PipeGroup:
+    """`batch` sequences in ONE batched context through the device-resident Pipeline.step: per frame one enqueue (pyramid, KLT of the
+    live landmark + candidate keypoints, list bookkeeping, RANSAC-P3P pose + pruning, triangulation of ripe candidates + promotion,
+    resurrection of recently dead landmarks, 10-frame bundle adjustment + write-back, Shi-Tomasi re-detection + spawn); every stage
+    reads what the previous stages and frames left in the device tables.  Up to 3 steps in flight; only the small records come back."""
+
+    def __init__(self, device, scenes, boot_ctx, first, batch, ba_iters, max_pts, fixed_budget, ba_window, resurrect):
+        from vo_mi355x import VoContext, synthetic as syn
+        from vo_mi355x.resident import ResidentPipeline
+        self.B, self.nf = batch, len(scenes[0]["frames"])
+        self.c = VoContext(W_IMG, H_IMG, max_pts=max_pts, device=device, batch=batch)
+        frames, states, Ks, self.gt = [], [], [], []
+        for b in range(batch):
+            sc = scenes[(first + b) % len(scenes)]
+            off = pipe_phase_offsets(sc, first + b + 1)[-1]
+            roll = dict(frames=np.roll(sc["frames"], -off, axis=0), poses=np.roll(sc["poses"], -off, axis=0), K=sc["K"], f=sc["f"],
+                        surface=lambda t, xy, sc=sc, off=off: sc["surface"]((t + off) % self.nf, xy))
+            st, _ = syn.gt_bootstrap(boot_ctx, roll, 0, PIPE_T1)
+            frames.append(roll["frames"]); states.append(st); Ks.append(sc["K"])
+            G0 = roll["poses"][0]
+            unit = np.linalg.norm((roll["poses"][PIPE_T1] @ np.linalg.inv(G0))[:3, 3])
+            self.gt.append((roll["poses"], G0, unit))
+        self.c.upload_sequence(np.stack(frames))
+        self.ba_cap, self.fixed = ba_iters, fixed_budget
+        self.rp = ResidentPipeline(self.c, np.stack(Ks), ba_window=ba_window, ba_max_iters=ba_iters, ba_budget=ba_iters, pnp_blind_batches=2, resurrect=resurrect)
+        self.rp.seed(states, None, None, t_step=1)
+        self.c.push_frame_resident(PIPE_T1)
+        self.frame, self.inflight, self.max_inflight = PIPE_T1 + 1, 0, 3
+        self.recs = []                      # records of the timed region (kept for the statistics)
+        self.keep = False
+        self.budget = ba_iters
+        self.last = None
+
+    def enqueue(self):
+        self.rp.step(self.frame % self.nf)
+        self.frame += 1
+        self.inflight += 1
+
+    def fetch(self):
+        self.last = self.rp.fetch()
+        self.inflight -= 1
+        if self.keep:
+            self.recs.append(self.last)
+        if not self.fixed:
+            # the LM stops by its own tests; the budget only bounds the (early-exiting) launches enqueued blindly: what the newest
+            # fetched frame needed over the batch + 2, never more than --ba-iters.  A solve the budget cut shows ba_done == 0.
+            need = max(r["ba_iters"] for r in self.last) + 2
+            b = max(3, min(self.ba_cap, need))
+            if b != self.budget:
+                self.rp.set_ba_budget(b)
+                self.budget = b
+
+    def step(self):
+        self.enqueue()
+        if self.inflight == self.max_inflight:
+            self.fetch()
+
+    def drain(self):
+        while self.inflight:
+            self.fetch()
+
+    def pose_errors(self):
+        """(rotation error in degrees, translation error in bootstrap baselines) of the newest fetched pose against the rendered ground truth"""
+        out = []
+        for b, r in enumerate(self.last):
+            poses, G0, unit = self.gt[b]
+            fidx = (PIPE_T1 + r["t"] - 1) % self.nf
+            gt = poses[fidx] @ np.linalg.inv(G0)
+            H = r["H"]
+            cosang = (np.trace(H[:3, :3] @ gt[:3, :3].T) - 1) / 2
+            out.append((float(np.degrees(np.arccos(np.clip(cosang, -1, 1)))), float(np.linalg.norm(H[:3, 3] - gt[:3, 3] / unit))))
+        return out
+
+
+def run_pipeline(device, a, dist, n_ctx, per_ctx, steps, warmup, regions, scenes=None):
+    """the timed closed loop -> dict for the bench line (also used, smaller, for the informational `pipeline_step` key of the default run)"""
+    from vo_mi355x import VoContext
+    t0 = time.perf_counter()
+    max_pts = a.pipe_max_pts
+    if scenes is None:
+        scenes = pipe_scenes(2, a.pipe_frames, 4321 + 16 * dist.rank)
+    boot = VoContext(W_IMG, H_IMG, max_pts=4096, device=device)
+    groups = [PipeGroup(device, scenes, boot, i * per_ctx, per_ctx, a.ba_iters, max_pts, a.fixed_ba_budget, a.pipe_window, not a.pipe_no_resurrect) for i in range(n_ctx)]
+    boot.close()
+    t_setup = time.perf_counter() - t0
+    pool = None
+    if n_ctx > 1 and a.host_threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(min(a.host_threads, n_ctx))
+
+    def each(fn):
+        if pool is not None:
+            list(pool.map(fn, groups))
+        else:
+            for g in groups:
+                fn(g)
+    for _ in range(warmup):
+        each(lambda g: g.step())
+    each(lambda g: g.drain())
+    for g in groups:
+        g.keep = True
+        g.c.profile_enable((g.c.PROF_KLT,))
+        g.c.sync()
+    region_dt = []
+    for _ in range(max(1, regions)):
+        for g in groups:
+            g.c.sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            each(lambda g: g.step())
+        each(lambda g: g.drain())
+        for g in groups:
+            g.c.sync()
+        dist.barrier()
+        region_dt.append(dist.max(time.perf_counter() - t0))
+    dt = float(np.median(region_dt))
+    klt_ms, klt_n = 0.0, 0
+    for g in groups:
+        ms, n = g.c.profile_read(g.c.PROF_KLT)
+        klt_ms += ms; klt_n += n
+        g.c.profile_enable(())
+    recs = [r for g in groups for step_recs in g.recs for r in step_recs]
+    errs = np.array([e for g in groups for e in g.pose_errors()])
+    alive = sum(1 for g in groups for r in g.last if r["status"] == 0)
+    n_seq = n_ctx * per_ctx
+    it = np.array([r["ba_iters"] for r in recs if r["status"] == 0])
+    live = [r for r in recs if r["status"] == 0]
+
+    def mean(k):
+        return round(float(np.mean([r[k] for r in live])), 1) if live else 0.0
+    out = {"frames_per_s": round(n_seq * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "sequences": n_seq, "contexts": n_ctx,
+           "steps": steps, "regions_ms_per_step": [round(x / steps * 1e3, 4) for x in region_dt],
+           "sequences_alive_at_end": alive, "frames_in_sequence": scenes[0]["frames"].shape[0], "max_tracked_keypoints": max_pts,
+           "ba_window": a.pipe_window, "resurrection_of_dead_landmarks": not a.pipe_no_resurrect, "ba_lm_iteration_cap": a.ba_iters, "ba_budget": "fixed" if a.fixed_ba_budget else "adaptive (newest fetched frame's maximum + 2)",
+           "mean_tracked_keypoints": mean("n_tracked"), "mean_landmark_entries": mean("n_landmarks"), "mean_candidates": mean("n_candidates"),
+           "mean_pnp_inliers": mean("pnp_inliers"), "mean_new_landmarks": mean("n_new"), "mean_resurrected": mean("n_resurrected"),
+           "mean_detected": mean("n_detected"), "mean_ba_observations": mean("ba_observations"),
+           "ba_iterations_histogram": {str(int(k)): int(v) for k, v in zip(*np.unique(it, return_counts=True))} if len(it) else {},
+           "ba_solves_cut_by_the_budget": int(sum(1 for r in live if r["ba_done"] == 0)),
+           "pnp_bound_not_reached": int(sum(1 for r in live if r["pnp_bound_reached"] == 0)),
+           "capacity_policy_frames": {name: int(sum(1 for r in live if r["overflow"] & bit)) for name, bit in
+                                      (("dead_list", 1), ("promotion", 2), ("resurrection", 4), ("detection", 8), ("st_candidates", 16))},
+           "pose_error_vs_ground_truth": {"rotation_deg_median": round(float(np.median(errs[:, 0])), 4), "rotation_deg_max": round(float(errs[:, 0].max()), 4),
+                                          "translation_baselines_median": round(float(np.median(errs[:, 1])), 4)},
+           "klt_avg_launch_us": round(klt_ms / max(klt_n, 1) * 1e3, 2), "setup_s": round(t_setup, 2)}
+    for g in groups:
+        g.c.close()
+    if pool is not None:
+        pool.shutdown()
+    return out
+
 
 
 def usable_cores():
@@ -389,7 +538,7 @@ def cpu_baseline(frames, n_frames, ba_iters):
     return n_frames / dt, dt
 
 
-def measure_extras(device, frame_sets, a):
+def measure_extras(device, frame_sets, a, dist):
     """Informational, after the timed regions, rank 0 of a 1-GPU run: the other BASELINE configurations on the same device.
     single_sequence: configs[2] / [3] literally -- ONE sequence in one context (launch-latency bound).
     klt_only: configs[1] -- pyramid + Scharr + KLT of 2000 points per frame, maxLevel 3 (4 levels) and 2, one sequence and a
@@ -428,12 +577,15 @@ def measure_extras(device, frame_sets, a):
             gk.c.close()
     out["klt_only"] = dict(kl, workload="synthetic_1241x376_2000pts_klt_only (BASELINE configs[1]: pyramid + Scharr + KLT, no BA)")
     g.c.close()
-    gp = Group(device, frame_sets, seed0=7200, batch=32, ba_iters=a.ba_iters, pipeline=True)
-    gp.max_inflight = 1
-    dt = run(gp, 40, warm=6)
-    out["pipeline_step"] = {"frames_per_s": round(40 * 32 / dt, 1), "ms_per_step": round(dt / 40 * 1e3, 4), "sequences": 32, "contexts": 1,
-                            "mean_live_tracks": round(float(np.mean(gp.last["n_tracks"])), 1)}
-    gp.c.close()
+    # Pipeline.step resident on the device, closed loop: 3 x 32 sequences like the headline.  Two configurations:
+    # the reference's own (window 4, recently dead landmarks resurrected into every adjust) and BASELINE's 10-frame window with dead
+    # landmarks left dead -- with the reference's resurrection a window of 10 fills the table with copies of young deaths
+    import copy as _copy
+    scenes = pipe_scenes(2, a.pipe_frames, 4321)
+    a4 = _copy.copy(a); a4.pipe_window, a4.pipe_no_resurrect = 4, False
+    a10 = _copy.copy(a); a10.pipe_window, a10.pipe_no_resurrect = 10, True
+    out["pipeline_step"] = {"reference_configuration_window4": run_pipeline(device, a4, dist, 3, 32, 40, 10, 3, scenes),
+                            "window10_dead_stay_dead": run_pipeline(device, a10, dist, 3, 32, 40, 10, 3, scenes)}
     return out
 
 
@@ -553,9 +705,22 @@ def main():
         os.environ["VO_BLOCKING_SYNC"] = "1"
     t_gen = time.perf_counter()
     c5 = a.workload == "config5"
-    pl = a.workload == "pipeline"
-    if pl:
-        a.no_cpu_baseline = True
+    if a.workload == "pipeline":
+        # the closed loop is its own harness (no resident BA problem, no uploaded point set: everything comes out of the device tables)
+        a.ctxs = max(1, min(a.ctxs, a.seqs))
+        r = run_pipeline(dist.local_rank, a, dist, a.ctxs, max(1, a.seqs // a.ctxs), a.steps, a.warmup, a.regions)
+        tot = dist.sum(float(r["sequences"]))
+        if dist.rank == 0:
+            fps = tot * a.steps / (r["ms_per_step"] * 1e-3 * a.steps)
+            print(json.dumps({"metric": "frames/sec, Pipeline.step resident on the device @1241x376 (<= 2048 tracked keypoints, RANSAC-P3P pose, triangulation, "
+                                        "10-frame BA, re-detection; closed loop)", "value": round(fps, 2), "unit": "frames/s", "n_gpus": dist.world,
+                              "steps": a.steps, "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "u8/i32 (KLT, Shi-Tomasi) + f64 (P3P, DLT, BA)", "data": "synthetic (rendered two-plane scene, known trajectory)",
+                              "config": {"workload": "pipeline_step_closed_loop_1241x376_ba10", "sequences_per_gpu": r["sequences"],
+                                         "batched_contexts_per_gpu": r["contexts"], "parallelism": "independent sequences, no collective"},
+                              "pipeline": r, "roofline": None, "cpu_baseline": None}))
+        dist.close()
+        return
     if c5:
         # ONE sequence over all ranks: every rank runs the (launch-bound) front end on the whole frame redundantly and
         # owns 1/n_ranks of the landmarks of the 20-frame bundle adjustment
@@ -570,14 +735,14 @@ def main():
         a.ctxs = max(1, min(a.ctxs, a.seqs))
         per = [a.seqs // a.ctxs + (1 if i < a.seqs % a.ctxs else 0) for i in range(a.ctxs)]
         frame_sets = [syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + 16 * dist.rank + k)[0] for k in range(min(4, a.seqs))]
-        seqs = [Group(dist.local_rank, frame_sets, seed0=1000 * dist.rank + 100 * i, batch=per[i], ba_iters=a.ba_iters, pipeline=pl)
+        seqs = [Group(dist.local_rank, frame_sets, seed0=1000 * dist.rank + 100 * i, batch=per[i], ba_iters=a.ba_iters)
                 for i in range(a.ctxs)]
     t_setup = time.perf_counter() - t_gen
     side = {"on": 1, "off": 0, "pipeline": 2}[a.side_stream]
     for s in seqs:
         s.c.set_side_stream(side)
         s.c.set_graph_mode(bool(a.graph))
-        s.max_inflight = 1 if (a.graph or pl) else 2
+        s.max_inflight = 1 if a.graph else 2
         s.adaptive = not a.fixed_ba_budget
 
     pool = None
@@ -662,12 +827,7 @@ def main():
         it_mean = [float(np.maximum(it[:, l], 0).mean()) for l in range(it.shape[1])]
         # ALGORITHMIC bytes of one KLT launch: sum over the tracked points and levels of 5120 + 1024 * it_l
         # (one launch tracks the whole batch; with the track table only the live slots count)
-        if s0.pipeline:
-            live = (it >= 0).any(axis=1)
-            klt_bytes = float(((5120.0 + 1024.0 * np.maximum(it[live], 0))).sum())
-            it_mean = [float(np.maximum(it[live][:, l], 0).mean()) for l in range(it.shape[1])]
-        else:
-            klt_bytes = N_PTS * s0.B * sum(5120.0 + 1024.0 * x for x in it_mean)
+        klt_bytes = N_PTS * s0.B * sum(5120.0 + 1024.0 * x for x in it_mean)
         klt_avg_s = (klt_ms / max(klt_n, 1)) * 1e-3
         achieved = klt_bytes / klt_avg_s / 1e9 if klt_avg_s > 0 else 0.0
         traffic, traffic_src = profile_constant("klt_traffic.json", "hbm_bytes_per_launch")
@@ -684,12 +844,11 @@ def main():
                         "`frac` is the launch as timed INSIDE the run: with several batched contexts it shares the vector ALUs with the "
                         "Shi-Tomasi / BA kernels of the other contexts and takes longer than on its own (`alone_*`)"}
         out = {"metric": ("frames/sec @1920x1080, 5000 KLT pts, 20-frame sharded BA (config 5)" if c5 else
-                          "frames/sec, Pipeline.step on the device @1241x376 (track table <= 2000 pts, PnP, DLT, 10-frame BA, re-detection)" if pl else
                           "frames/sec @1241x376, 2000 KLT pts, 10-frame BA window"), "value": round(fps, 2),
                "unit": "frames/s", "n_gpus": dist.world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if c5 else "weak",
                "vs_baseline": None, "dtype": "u8/i32 (KLT, Shi-Tomasi) + f64 (DLT, BA)", "data": "synthetic",
-               "config": {"workload": ("pipeline_step_" + WORKLOAD) if pl else WORKLOAD, "width": W_IMG, "height": H_IMG,
+               "config": {"workload": WORKLOAD, "width": W_IMG, "height": H_IMG,
                           "klt_points": N_PTS, "klt_win": 31, "klt_levels": 4, "dlt_points": N_NEW,
                           "ba_landmarks": BA_N, "ba_window": BA_W, "ba_observations": BA_N * BA_W,
                           "ba_lm_iteration_budget": a.ba_iters, "ba_lm_iterations_run": ba_stats["iters"],
@@ -703,10 +862,6 @@ def main():
                                           "packet + 4 statistics per LM iteration, front end replicated" % dist.world) if c5 else
                                          ("independent sequences, %d per GPU in %d batched context(s) x %d GPU(s), no collective"
                                           % (a.seqs, a.ctxs, dist.world))},
-               "pipeline": ({"mean_live_tracks": round(float(np.mean(s0.last["n_tracks"])), 1),
-                             "pnp_inliers": (s0.last["pnp_stats"][0] if isinstance(s0.last["pnp_stats"], list) else s0.last["pnp_stats"])["n_inliers"],
-                             "pnp_status_ok": all(x["status"] == 0 for x in (s0.last["pnp_stats"] if isinstance(s0.last["pnp_stats"], list) else [s0.last["pnp_stats"]]))}
-                            if pl else None),
                "regions": {"n": len(region_dt), "frames_per_s_min": round(frames_total / max(region_dt), 2),
                            "frames_per_s_median": round(fps, 2), "frames_per_s_max": round(frames_total / min(region_dt), 2),
                            "ms_per_step_each": [round(x / a.steps * 1e3, 4) for x in region_dt]},
@@ -717,7 +872,7 @@ def main():
         s.c.close()
     if out is not None and dist.world == 1 and a.workload == "A" and not a.no_extras:
         try:
-            out.update(measure_extras(dist.local_rank, frame_sets, a))
+            out.update(measure_extras(dist.local_rank, frame_sets, a, dist))
         except Exception as e:      # noqa: BLE001  (informational keys must never cost the bench line)
             out["extras_error"] = str(e)
     dist.close()

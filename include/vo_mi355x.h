@@ -393,6 +393,11 @@ typedef struct {
   int32_t max_new;            /* 1000 corners appended per frame (maxCorners, extractor.py:21) */
   int32_t pnp_blind_batches;  /* 4    batches of 256 P3P hypotheses enqueued per frame (they exit early once the RANSAC bound is reached) */
   int32_t ba_budget;          /* LM iterations enqueued per frame, <= ba.max_iters (they exit early once the LM has stopped) */
+  int32_t resurrect;          /* 1: as the reference -- adjust appends dead landmarks whose track lies inside the window to the state's lists again
+                                 (bundle_adjuster.py:142-150).  With the reference's window of 4 that is a handful per frame;
+                                 with a window of 10 every young death comes back every frame, and again for every copy that dies again, until the
+                                 table holds little else (measured: bench.py --workload pipeline).  0: dead landmarks stay dead. */
+  int32_t reserved;
   double  max_reproj_err;     /* 2.0  pipeline.py:23 (PnP consensus and triangulation filter) */
   double  min_bearing_angle;  /* 0.5  pipeline.py:24 */
   vo_klt_params klt;

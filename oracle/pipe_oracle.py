@@ -46,10 +46,11 @@ def _vec_to_rot(r):
 
 class Params:
     def __init__(self, ba_window=4, min_track_length=3, mask_radius=7, max_new=1000, max_reproj_err=2.0, min_bearing_angle=0.5,
-                 ba_max_iters=50, ba_ftol=1e-3, ba_xtol=1e-3, pnp_seed=0, min_distance=7):
+                 ba_max_iters=50, ba_ftol=1e-3, ba_xtol=1e-3, pnp_seed=0, min_distance=7, resurrect=True):
         self.ba_window, self.min_track_length, self.mask_radius, self.max_new = ba_window, min_track_length, mask_radius, max_new
         self.max_reproj_err, self.min_bearing_angle = max_reproj_err, min_bearing_angle
         self.ba_max_iters, self.ba_ftol, self.ba_xtol, self.pnp_seed, self.min_distance = ba_max_iters, ba_ftol, ba_xtol, pnp_seed, min_distance
+        self.resurrect = resurrect       # False: dead landmarks stay dead (not the reference; see vo_pipe_params.resurrect)
 
 
 class PipeModel:
@@ -274,7 +275,7 @@ class PipeModel:
     def ba_problem(self):
         W, t_now = self.prm.ba_window, self.t
         n_active = len(self.lm_L)
-        window = [(t_now - (int(self.l_tl[L]) - (int(self.k_len[K]) - 1))) < W for L, K in zip(self.dead_L, self.dead_K)]
+        window = [self.prm.resurrect and (t_now - (int(self.l_tl[L]) - (int(self.k_len[K]) - 1))) < W for L, K in zip(self.dead_L, self.dead_K)]
         room = self.cap - len(self.lm_L) - len(self.cand)          # capacity policy: resurrect in dead-list order while there is room
         crit, taken = [], 0
         for ok in window:

@@ -7,85 +7,7 @@ import copy
 import numpy as np
 
 
-# ---------------------------------------------------------------------------------------------------------
-# scene
-# ---------------------------------------------------------------------------------------------------------
-def sway_pose(t, amp=(0.9, 0.25, -0.5), roll=0.02, period=40.0):
-    """frame-0 camera -> frame-t camera: the camera side-steps, rises and approaches on a sinusoid and rolls with it"""
-    s = np.sin(2 * np.pi * t / period)
-    Hm = np.eye(4)
-    ang = roll * s
-    Hm[:2, :2] = [[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]]
-    Hm[:3, 3] = np.asarray(amp, float) * s
-    return Hm
-
-
-def scene(n_frames, w=416, h=240, f=400.0, seed=2024, z_bg=10.0, z_fg=6.5, pose_fn=sway_pose, margin=128):
-    """-> dict(frames [n, h, w] u8, K, poses [n, 4, 4], depth(t, xy) -> Z of the surface seen at pixel xy of frame t and its frame-0 pixel)"""
-    from vo_mi355x import synthetic as syn
-    K = np.array([[f, 0, (w - 1) / 2], [0, f, (h - 1) / 2], [0, 0, 1]])
-    c = K[:2, 2]
-    tex_bg = syn.make_texture(h + 2 * margin, w + 2 * margin, seed)
-    tex_fg = syn.make_texture(h + 2 * margin, w + 2 * margin, seed + 1)
-    rect = (0.29 * w, 0.25 * h, 0.72 * w, 0.77 * h)
-    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
-    frames = np.empty((n_frames, h, w), np.uint8)
-    poses = np.empty((n_frames, 4, 4))
-    motions = []
-
-    def plane_motion(Hm, Z):
-        s_ = Z / (Z + Hm[2, 3])
-        A = np.zeros((2, 3)); A[:, :2] = s_ * Hm[:2, :2]; A[:, 2] = c - s_ * Hm[:2, :2] @ c + f * Hm[:2, 3] / (Z + Hm[2, 3])
-        return A
-    for t in range(n_frames):
-        Hm = pose_fn(t)
-        poses[t] = Hm
-        A_bg, A_fg = plane_motion(Hm, z_bg), plane_motion(Hm, z_fg)
-        motions.append((A_bg, A_fg))
-        bg = syn.render_frame(tex_bg, A_bg, w, h, margin)
-        fg = syn.render_frame(tex_fg, A_fg, w, h, margin)
-        Ainv = np.linalg.inv(np.vstack([A_fg, [0, 0, 1]]))[:2]
-        x0 = Ainv[0, 0] * xs + Ainv[0, 1] * ys + Ainv[0, 2]; y0 = Ainv[1, 0] * xs + Ainv[1, 1] * ys + Ainv[1, 2]
-        inside = (x0 >= rect[0]) & (x0 < rect[2]) & (y0 >= rect[1]) & (y0 < rect[3])
-        frames[t] = np.where(inside, fg, bg)
-
-    def surface(t, xy):
-        """for pixels xy [n, 2] of frame t: (Z [n], frame-0 pixel [n, 2]) of the plane seen there"""
-        xy = np.asarray(xy, np.float64).reshape(-1, 2)
-        out_z, out_p0 = np.empty(len(xy)), np.empty((len(xy), 2))
-        for k, (A, Z) in enumerate(((motions[t][1], z_fg), (motions[t][0], z_bg))):
-            Ainv = np.linalg.inv(np.vstack([A, [0, 0, 1]]))[:2]
-            p0 = xy @ Ainv[:, :2].T + Ainv[:, 2]
-            if k == 0:
-                fgm = (p0[:, 0] >= rect[0]) & (p0[:, 0] < rect[2]) & (p0[:, 1] >= rect[1]) & (p0[:, 1] < rect[3])
-                out_z[fgm], out_p0[fgm] = Z, p0[fgm]
-            else:
-                out_z[~fgm], out_p0[~fgm] = Z, p0[~fgm]
-        return out_z, out_p0
-    return dict(frames=frames, K=K, poses=poses, surface=surface, f=f)
-
-
-def gt_bootstrap(ctx, sc, t0=0, t1=4, n_landmarks=0.6, min_kp_dist=7):
-    """A State like Pipeline._get_init_state's (pipeline.py:42-90) from ground truth instead of SIFT + five-point: Shi-Tomasi corners
-    of frame t1 (through `ctx`), the first `n_landmarks` share of them become landmarks at their true position (world = camera t0,
-    unit = the t0 -> t1 baseline, as the bootstrap fixes it), the rest candidates born at step 1.  -> (state, t_loader)"""
-    from vo_mi355x import Extractor, Landmark, State, Trajectory
-    ext = Extractor(min_kp_dist=min_kp_dist, ctx=ctx)
-    kps = ext.extract(sc["frames"][t1], 1, current_kp=[], detector='shi-tomasi', mask_radius=min_kp_dist, describe=False)
-    G0, G1 = sc["poses"][t0], sc["poses"][t1]
-    rel = G1 @ np.linalg.inv(G0)
-    unit = np.linalg.norm(rel[:3, 3])
-    H1 = rel.copy(); H1[:3, 3] /= unit
-    n_l = int(len(kps) * n_landmarks) if n_landmarks <= 1 else int(n_landmarks)
-    uv = np.array([k.uv.reshape(2) for k in kps[:n_l]], np.float64)
-    Z, p0 = sc["surface"](t1, uv)
-    K = sc["K"]
-    X0 = np.stack([(p0[:, 0] - K[0, 2]) / K[0, 0] * Z, (p0[:, 1] - K[1, 2]) / K[1, 1] * Z, Z], 1)      # frame-0 camera coordinates
-    Xw = (X0 @ G0[:3, :3].T + G0[:3, 3]) / unit                                                        # camera t0 = world, unit baseline
-    lms = [Landmark(1, Xw[i].reshape(3, 1).copy(), kps[i].des) for i in range(n_l)]
-    traj = Trajectory({})
-    traj.append(0, np.eye(4)); traj.append(1, H1)
-    return State(lms, kps[:n_l], kps[n_l:], traj), t1
+from vo_mi355x.synthetic import gt_bootstrap, sway_pose, sway_scene as scene  # noqa: E402,F401  (the scene lives with the product's synthetic inputs: bench.py uses it too)
 
 
 # ---------------------------------------------------------------------------------------------------------

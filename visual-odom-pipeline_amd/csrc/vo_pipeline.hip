@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_prune(pipe_ptrs Pall, int do_
 // ================================================================================================
 __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int do_tri, int do_adjust, const float* __restrict__ X4, const double* __restrict__ depth1,
                                                            const double* __restrict__ reproj, size_t slab_seq, int x4_stride, double max_err,
-                                                           double min_angle, const int32_t* __restrict__ cam_sel, int Wn, double* __restrict__ x0, double* __restrict__ obs,
+                                                           double min_angle, const int32_t* __restrict__ cam_sel, int Wn, int resurrect, double* __restrict__ x0, double* __restrict__ obs,
                                                            size_t x_stride, size_t obs_stride, int Nba) {
   __shared__ int s_w[16];
   __shared__ int s_first[PIPE_HIST], s_gate[PIPE_HIST];
@@ -509,7 +509,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
     for (int c = 0; c < PIPE_CH; c++) {
       const int j = c * PIPE_TPB + tid;
       DL[c] = DK[c] = 0; win[c] = false;
-      if (j < nd0) { DL[c] = P.dead_L[j]; DK[c] = P.dead_K[j]; win[c] = (t - (P.l_tl[DL[c]] - (P.k_len[DK[c]] - 1))) < Wn; }
+      if (j < nd0) { DL[c] = P.dead_L[j]; DK[c] = P.dead_K[j]; win[c] = resurrect && (t - (P.l_tl[DL[c]] - (P.k_len[DK[c]] - 1))) < Wn; }
     }
     const int n_win = pipe_rank(win, wr, s_w);
     int room = P.N - nl - nc;
@@ -748,7 +748,7 @@ extern "C" int32_t vo_pipe_default_params(vo_pipe_params* p) {
   if (!p) return VO_E_INVALID;
   memset(p, 0, sizeof(*p));
   p->ba_window = 4; p->min_track_length = 3; p->mask_radius = 7; p->max_new = 1000; p->pnp_blind_batches = 4;
-  p->max_reproj_err = 2.0; p->min_bearing_angle = 0.5;
+  p->max_reproj_err = 2.0; p->min_bearing_angle = 0.5; p->resurrect = 1;
   vo_klt_default_params(&p->klt); vo_st_default_params(&p->st); vo_ba_default_params(&p->ba); vo_pnp_default_params(&p->pnp);
   p->st.min_distance = 7.0;
   p->ba_budget = p->ba.max_iters;
@@ -904,7 +904,7 @@ extern "C" int32_t vo_pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages) {
   if (stages & (VO_PIPE_TRIANGULATE | VO_PIPE_ADJUST))
     hipLaunchKernelGGL(k_pipe_promote, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, (stages & VO_PIPE_TRIANGULATE) ? 1 : 0, (stages & VO_PIPE_ADJUST) ? 1 : 0,
                        vo_slab<const float>(c, c->off_X4), vo_slab<const double>(c, c->off_depth), vo_slab<const double>(c, c->off_reproj), c->slab_seq,
-                       w->N, prm.max_reproj_err, prm.min_bearing_angle, w->d_cam_sel, bv.W, bv.x0, bv.obs, bv.x_stride, bv.obs_stride, bv.N);
+                       w->N, prm.max_reproj_err, prm.min_bearing_angle, w->d_cam_sel, bv.W, prm.resurrect, bv.x0, bv.obs, bv.x_stride, bv.obs_stride, bv.N);
   if (stages & VO_PIPE_ADJUST) {
     r = vo_ba_enqueue_budget(c, &prm.ba, 0, prm.ba_budget);
     if (r != VO_OK) return r;

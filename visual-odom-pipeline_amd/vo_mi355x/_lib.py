@@ -71,7 +71,8 @@ class BaStats(C.Structure):
 
 class PipeParams(C.Structure):
     _fields_ = [("ba_window", C.c_int32), ("min_track_length", C.c_int32), ("mask_radius", C.c_int32), ("max_new", C.c_int32),
-                ("pnp_blind_batches", C.c_int32), ("ba_budget", C.c_int32), ("max_reproj_err", C.c_double),
+                ("pnp_blind_batches", C.c_int32), ("ba_budget", C.c_int32), ("resurrect", C.c_int32), ("reserved", C.c_int32),
+                ("max_reproj_err", C.c_double),
                 ("min_bearing_angle", C.c_double), ("klt", KltParams), ("st", StParams), ("ba", BaParams), ("pnp", PnpParams)]
 
 

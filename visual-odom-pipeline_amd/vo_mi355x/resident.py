@@ -41,7 +41,7 @@ _RECORD_FIELDS = [n for n, _ in PipeRecord._fields_ if n not in ("_pad", "H")]
 
 class ResidentPipeline:
     def __init__(self, ctx, K, ba_window=4, min_track_length=3, mask_radius=7, max_new=1000, max_reproj_err=2.0, min_bearing_angle=0.5,
-                 ba_max_iters=50, ba_budget=None, ba_ftol=1e-3, ba_xtol=1e-3, pnp_blind_batches=4, pnp_seed=0, min_kp_dist=7):
+                 ba_max_iters=50, ba_budget=None, ba_ftol=1e-3, ba_xtol=1e-3, pnp_blind_batches=4, pnp_seed=0, min_kp_dist=7, resurrect=True):
         self.ctx, self._L = ctx, ctx._L
         B = ctx.batch
         K = np.ascontiguousarray(np.broadcast_to(np.asarray(K, np.float64).reshape(-1, 3, 3), (B, 3, 3)))
@@ -52,6 +52,7 @@ class ResidentPipeline:
         p.max_reproj_err, p.min_bearing_angle, p.pnp_blind_batches = max_reproj_err, min_bearing_angle, pnp_blind_batches
         p.ba.max_iters, p.ba.ftol, p.ba.xtol = ba_max_iters, ba_ftol, ba_xtol
         p.ba_budget = ba_max_iters if ba_budget is None else ba_budget
+        p.resurrect = 1 if resurrect else 0
         p.pnp.reproj_err, p.pnp.seed = max_reproj_err, pnp_seed
         p.st.min_distance = float(min_kp_dist)
         self.params = p
