@@ -37,6 +37,9 @@ import numpy as np  # noqa: E402
 W_IMG, H_IMG, N_PTS, N_NEW, BA_N, BA_W = 1241, 376, 2000, 1000, 2000, 10       # --workload A (the metric's configuration)
 WORKLOAD = "kitti_shaped_1241x376_2000pts_ba10"
 K_CAM = None                                                                # None: synthetic.KITTI_K
+# (observation noise px, point noise m, pose noise m, visibility) of the BA problems a sequence cycles through, one per frame
+BA_VARIANTS = [(0.3, 0.3, 0.02, 1.0), (0.3, 0.6, 0.05, 1.0), (0.5, 0.3, 0.02, 0.9), (0.3, 1.0, 0.10, 1.0), (0.3, 0.3, 0.02, 0.8),
+               (0.8, 0.5, 0.05, 1.0), (0.3, 0.8, 0.02, 0.95), (0.4, 0.4, 0.08, 0.85)]
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
@@ -51,7 +54,7 @@ def parse():
     ap.add_argument("--seqs", type=int, default=96, help="independent sequences per GPU")
     ap.add_argument("--ctxs", type=int, default=3, help="batched contexts (HIP streams) the sequences are split over")
     ap.add_argument("--ba-iters", type=int, default=10, help="LM iteration budget per adjust")
-    ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames per sequence (played ping-pong)")
+    ap.add_argument("--frames", type=int, default=100, help="distinct synthetic frames per sequence: a closed loop of smooth motion, played round and round")
     ap.add_argument("--pipe-window", type=int, default=4, help="--workload pipeline: BA window (the reference's own setting is 4, pipeline.py:19; BASELINE's 10)")
     ap.add_argument("--pipe-no-resurrect", action="store_true", help="--workload pipeline: dead landmarks stay dead (the reference appends the recently dead "
                                                                      "to the state's lists again in every adjust, bundle_adjuster.py:142-150)")
@@ -159,9 +162,17 @@ class Group:
             u0.append(s["obs"][3, :N_NEW].astype(np.float32)); u1.append(s["obs"][0, :N_NEW].astype(np.float32))
             Ks.append(K); H0s.append(H0); H1s.append(H1)
         c.dlt_upload(np.stack(P0s), np.stack(P1s), np.stack(u0), np.stack(u1), np.stack(Ks), np.stack(H0s), np.stack(H1s))
+        self.n_ba = 1
         if shard is None:
-            c.ba_upload(np.stack(Ks), np.stack([s["poses0"] for s in scenes]), np.stack([s["points0"] for s in scenes]),
-                        np.stack([s["obs"] for s in scenes]))
+            # a BANK of BA_BANK distinct problems per sequence, one per frame in turn: a sliding window never shows the same problem twice,
+            # so the LM iteration count changes from frame to frame (4 ... 7 here) and the iteration budget has to cope with that
+            self.n_ba = len(BA_VARIANTS)
+            bank = [[scenes[b]] + [syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=seed0 + b + 7919 * k, obs_noise=v[0], pt_noise=v[1],
+                                                     pose_noise=v[2], visibility=v[3], **kw) for k, v in enumerate(BA_VARIANTS) if k > 0]
+                    for b in range(batch)]
+            c.ba_upload_bank(np.stack(Ks), np.stack([[bank[b][k]["poses0"] for b in range(batch)] for k in range(self.n_ba)]),
+                             np.stack([[bank[b][k]["points0"] for b in range(batch)] for k in range(self.n_ba)]),
+                             np.stack([[bank[b][k]["obs"] for b in range(batch)] for k in range(self.n_ba)]))
         else:
             rank, n_ranks, uid = shard
             s = scenes[0]
@@ -185,15 +196,26 @@ class Group:
         self.klt_prm = c.klt_params()
         self.st_prm = c.st_params()
         c.push_frame_resident(0)
-        self.truncated = 0                 # solves that ended on the iteration budget (LM status 0)
+        self.truncated = 0                 # solves the iteration budget cut (each is completed at once, see fetch)
+        self.at_cap = 0                    # solves the LM's own max_iters (--ba-iters) stopped
+        self.iter_hist = {}                # LM iterations per solve over the timed regions
+        self.groups_enq = self.groups_needed = self.n_steps = 0
+        self.recent = []                   # iterations the last fetched frames needed (maximum over the batch)
+        self.pending = []                  # (bank index, budget) of the steps in flight, oldest first
+        self.stationary = False            # True: every frame solves problem 0 of the bank (the round-2 benchmark; informational)
         self.stages = (True, True, True)   # (DLT, BA, Shi-Tomasi) of the fused step
         self.t = 1
         self.inflight = 0
         self.max_inflight = 2          # 1 when the step is replayed from a hipGraph (its host destinations are baked in)
 
     def enqueue(self):
-        # one C call: pyramid + KLT + DLT + BA + Shi-Tomasi + result copies for the whole batch
-        self.c.frame_step_resident(pingpong(self.t, self.nf), N_PTS, self.stages[0], self.stages[1], self.stages[2], 7, self.klt_prm,
+        # one C call: pyramid + KLT + DLT + BA + Shi-Tomasi + result copies for the whole batch; the frames are a closed loop
+        # (frame nf continues into frame 0), the BA problem of the step comes from the bank in turn
+        k = 0 if self.stationary else self.t % self.n_ba
+        if self.n_ba > 1 and self.stages[1]:
+            self.c.ba_select(k)
+        self.pending.append((k, self.ba_prm.max_iters))
+        self.c.frame_step_resident(self.t % self.nf, N_PTS, self.stages[0], self.stages[1], self.stages[2], 7, self.klt_prm,
                                    self.st_prm, self.ba_prm)
         self.t += 1
         self.inflight += 1
@@ -212,18 +234,37 @@ class Group:
     def fetch(self):
         self.last = self.c.frame_fetch()
         self.inflight -= 1
+        k, budget = self.pending.pop(0)
         if self.stages[1]:
             st = self.last["ba_stats"]
             st = st if isinstance(st, list) else [st]
-            hit = sum(1 for x in st if x["status"] == 0)          # LM status 0: stopped by the iteration budget, not by its own tests
-            self.truncated += hit
+            # LM status 0 = stopped by max_iters, which the fused step uses as its BLIND BUDGET (iterations enqueued without looking;
+            # they exit early once the LM's own ftol / xtol tests have stopped it).  A solve the budget cut short of --ba-iters is
+            # not a result: it is run again from its x0 with the full --ba-iters right here, inside the timed region (same
+            # iterations, deterministic reductions: the result of an uncut solve), and replaces the cut one
+            cut = [b for b, x in enumerate(st) if x["status"] == 0 and budget < self.ba_iters_cap]
+            if cut:
+                self.truncated += len(cut)
+                self.c.sync()                                      # (the pipelined stream layout runs the next step's BA on another stream)
+                if self.n_ba > 1:
+                    self.c.ba_select(k)
+                po, pt, st2 = self.c.ba_fetch_after(self.c.ba_solve_resident, self.c.ba_params(max_iters=self.ba_iters_cap, ftol=1e-3, xtol=1e-3))
+                st2 = st2 if isinstance(st2, list) else [st2]
+                for b in cut:
+                    st[b] = st2[b]
+                self.last["ba_stats"], self.last["ba_poses"], self.last["ba_points"] = (st if len(st) > 1 else st[0]), po, pt
+            self.at_cap += sum(1 for x in st if x["status"] == 0)
+            its = max(x["iters"] for x in st)
+            for x in st:
+                self.iter_hist[x["iters"]] = self.iter_hist.get(x["iters"], 0) + 1
+            self.groups_enq += budget; self.groups_needed += its; self.n_steps += 1
+            self.recent = (self.recent + [its])[-16:]
             if self.adaptive:
-                # the LM stops by its own ftol / xtol tests; the budget only bounds how many (early-exiting) launches are enqueued
-                # blindly.  Next frame: exactly what this frame needed (maximum over the batch) -- every blind group beyond it
-                # costs 2 % of the step -- and 2 more after a frame in which a solve hit the budget; never more than --ba-iters.
-                # `ba_budget_truncated_solves` of the bench line counts the solves that were cut: 0 means full work was done.
-                its = max(x["iters"] for x in st)
-                self.ba_prm.max_iters = max(3, min(self.ba_iters_cap, its + (2 if hit else 0)))
+                # next budget: one more than the most any of the last 16 fetched frames needed (maximum over the batch), never more than
+                # --ba-iters.  Every blind group beyond the need costs ~2 % of a step; a budget below the need costs a whole second solve.
+                self.ba_prm.max_iters = max(3, min(self.ba_iters_cap, max(self.recent) + 1))
+            else:
+                self.ba_prm.max_iters = self.ba_iters_cap
         return self.last
 
     def ba_stats0(self):
@@ -520,15 +561,18 @@ def cpu_baseline(frames, n_frames, ba_iters):
     from vo_mi355x import synthetic as syn
     p = syn.grid_points(N_PTS, W_IMG, H_IMG, seed=7)
     s = syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=0)
+    bank = [s] + [syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=7919 * k, obs_noise=v[0], pt_noise=v[1], pose_noise=v[2], visibility=v[3])
+                  for k, v in enumerate(BA_VARIANTS) if k > 0]                 # the same bank of problems the GPU sequences cycle through
     K = s["K"]
     P0 = (K @ np.hstack([syn.rodrigues(s["poses_gt"][3, :3]), s["poses_gt"][3, 3:, None]])).astype(np.float32)
     P1 = (K @ np.hstack([syn.rodrigues(s["poses_gt"][0, :3]), s["poses_gt"][0, 3:, None]])).astype(np.float32)
     t0 = time.perf_counter()
     for t in range(n_frames):
-        a, b = frames[pingpong(t, len(frames))], frames[pingpong(t + 1, len(frames))]
+        a, b = frames[t % len(frames)], frames[(t + 1) % len(frames)]
         p1, st, err = o.klt(a, b, p)                                   # builds both pyramids, like one cv2 call
         o.triangulate(P0, P1, s["obs"][3, :N_NEW], s["obs"][0, :N_NEW])
-        bo.solve(K, s["poses0"], s["points0"], s["obs"], max_iters=ba_iters, ftol=1e-3, xtol=1e-3)
+        q = bank[t % len(bank)]
+        bo.solve(K, q["poses0"], q["points0"], q["obs"], max_iters=ba_iters, ftol=1e-3, xtol=1e-3)
         mask = np.full((H_IMG, W_IMG), 255, np.uint8)
         for x, y in np.int32(p1):
             o.circle_mask(mask, (x, y), 7, 0)
@@ -680,7 +724,7 @@ def main():
         return
     if a.cpu_worker >= 0:          # CPU-baseline worker process: never touches the GPU library
         from vo_mi355x import synthetic as syn
-        frames = syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + a.cpu_worker)[0]
+        frames = syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + a.cpu_worker, periodic=True, n_render=a.cpu_frames + 2)[0]
         cpu_baseline(frames, 1, a.ba_iters)                    # page in the oracle, first-call costs
         v, secs = cpu_baseline(frames, a.cpu_frames, a.ba_iters)
         print(json.dumps({"frames": a.cpu_frames, "seconds": secs}))
@@ -729,12 +773,12 @@ def main():
         K_CAM = np.array([[1100.0, 0, 960.0], [0, 1100.0, 540.0], [0, 0, 1]])
         a.seqs, a.ctxs, a.host_threads, a.fixed_ba_budget, a.no_cpu_baseline = 1, 1, 1, True, True
         uid = dist.bcast_bytes(VoContext.comm_unique_id() if dist.rank == 0 else np.zeros(128, np.uint8))
-        frame_sets = [syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234, margin=96)[0]]
+        frame_sets = [syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234, margin=96, periodic=True)[0]]
         seqs = [Group(dist.local_rank, frame_sets, seed0=0, batch=1, ba_iters=a.ba_iters, shard=(dist.rank, dist.world, uid))]
     else:
         a.ctxs = max(1, min(a.ctxs, a.seqs))
         per = [a.seqs // a.ctxs + (1 if i < a.seqs % a.ctxs else 0) for i in range(a.ctxs)]
-        frame_sets = [syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + 16 * dist.rank + k)[0] for k in range(min(4, a.seqs))]
+        frame_sets = [syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + 16 * dist.rank + k, periodic=True)[0] for k in range(min(4, a.seqs))]
         seqs = [Group(dist.local_rank, frame_sets, seed0=1000 * dist.rank + 100 * i, batch=per[i], ba_iters=a.ba_iters)
                 for i in range(a.ctxs)]
     t_setup = time.perf_counter() - t_gen
@@ -781,7 +825,8 @@ def main():
     for s in seqs:
         s.c.profile_enable((s.c.PROF_KLT,))
         s.c.sync()
-        s.truncated = 0
+        s.truncated = s.at_cap = 0
+        s.iter_hist, s.groups_enq, s.groups_needed, s.n_steps = {}, 0, 0, 0
     region_dt = []
     for _ in range(max(1, a.regions)):
         for s in seqs:
@@ -803,6 +848,54 @@ def main():
         klt_n += n
         s.c.profile_enable(())
     n_trunc = int(dist.sum(float(sum(s.truncated for s in seqs))))
+    n_at_cap = int(dist.sum(float(sum(s.at_cap for s in seqs))))
+    iter_hist = {}
+    for s in seqs:
+        for k, v in s.iter_hist.items():
+            iter_hist[k] = iter_hist.get(k, 0) + v
+    groups_enq = sum(s.groups_enq for s in seqs) / max(1, sum(s.n_steps for s in seqs))
+    groups_need = sum(s.groups_needed for s in seqs) / max(1, sum(s.n_steps for s in seqs))
+    # the same K steps once more with the other budget policy (one region, informational): what the adaptive budget is worth
+    other_fps = stationary_fps = None
+    if not c5:
+        for s in seqs:
+            s.adaptive = not s.adaptive
+            s.ba_prm.max_iters = s.ba_iters_cap
+        for _ in range(5):
+            step()
+        drain()
+        for s in seqs:
+            s.c.sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        drain()
+        for s in seqs:
+            s.c.sync()
+        dist.barrier()
+        other_fps = dist.sum(float(a.seqs)) * a.steps / dist.max(time.perf_counter() - t0)
+        for s in seqs:
+            s.adaptive = not s.adaptive
+            s.stationary = True            # ... and with ONE problem per sequence solved every frame, as rounds 1-2 measured
+            s.recent = []
+        for _ in range(8):
+            step()
+        drain()
+        for s in seqs:
+            s.c.sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        drain()
+        for s in seqs:
+            s.c.sync()
+        dist.barrier()
+        stationary_fps = dist.sum(float(a.seqs)) * a.steps / dist.max(time.perf_counter() - t0)
+        for s in seqs:
+            s.stationary = False
+            s.recent = []
     frames_step = 1.0 if c5 else dist.sum(float(a.seqs))                             # config 5: ONE sequence on all ranks
     frames_total = frames_step * a.steps
     fps = frames_total / dt
@@ -853,8 +946,15 @@ def main():
                           "ba_landmarks": BA_N, "ba_window": BA_W, "ba_observations": BA_N * BA_W,
                           "ba_lm_iteration_budget": a.ba_iters, "ba_lm_iterations_run": ba_stats["iters"],
                           "ba_final_cost": round(ba_stats["cost"], 4), "ba_initial_cost": round(ba_stats["cost0"], 2),
-                          "launch": "hipGraph replay" if a.graph else "plain", "ba_budget": "fixed" if a.fixed_ba_budget else "adaptive (last frame's maximum; + 2 after a truncated solve)",
-                          "ba_budget_truncated_solves": n_trunc, "side_stream": a.side_stream, "host_threads": max(a.host_threads, 1),
+                          "launch": "hipGraph replay" if a.graph else "plain",
+                          "ba_problems_per_sequence": seqs[0].n_ba, "frames_per_sequence": a.frames,
+                          "ba_budget": "fixed (--ba-iters groups every frame)" if a.fixed_ba_budget else
+                                       "adaptive (1 + the most any of the last 16 fetched frames needed, over the batch)",
+                          "ba_lm_iterations_histogram": {str(k): iter_hist[k] for k in sorted(iter_hist)},
+                          "ba_iteration_groups_enqueued_per_step": round(groups_enq, 3), "ba_iteration_groups_needed_per_step": round(groups_need, 3),
+                          "ba_solves_cut_by_the_budget_and_rerun_in_the_timed_region": n_trunc, "ba_solves_stopped_by_lm_max_iters": n_at_cap,
+                          ("adaptive_budget_frames_per_s" if a.fixed_ba_budget else "fixed_budget_frames_per_s"): None if other_fps is None else round(other_fps, 1),
+                          "one_stationary_ba_problem_frames_per_s": None if stationary_fps is None else round(stationary_fps, 1), "side_stream": a.side_stream, "host_threads": max(a.host_threads, 1),
                           "host_wait": "blocking" if os.environ.get("VO_BLOCKING_SYNC", "0") not in ("", "0") else "spin",
                           "sequences_per_gpu": a.seqs, "batched_contexts_per_gpu": a.ctxs,
                           "frames_per_step": 1 if c5 else a.seqs * dist.world,

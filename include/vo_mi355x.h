@@ -242,6 +242,12 @@ int32_t vo_ba_adjust(vo_ctx* ctx, const double* K, const double* poses, const do
 int32_t vo_ba_upload(vo_ctx* ctx, const double* K, const double* poses, const double* points,
                      const double* obs, int32_t n_slots, int32_t n_pts);
 int32_t vo_ba_solve_resident(vo_ctx* ctx, const vo_ba_params* prm);          /* async */
+/* a BANK of n_problems resident problems of one shape, one selected per solve (host-side pointer switch, nothing enqueued): a sliding
+ * window never presents the same problem twice, so the bench's sequences cycle through distinct problems without an upload in the loop.
+ * poses [n_problems][batch][W][6], points [n_problems][batch][N][3], obs [n_problems][batch][W][N][2]; K [batch][9] */
+int32_t vo_ba_upload_bank(vo_ctx* ctx, const double* K, const double* poses, const double* points, const double* obs,
+                          int32_t n_slots, int32_t n_pts, int32_t n_problems);
+int32_t vo_ba_select_problem(vo_ctx* ctx, int32_t k);
 int32_t vo_ba_fetch(vo_ctx* ctx, double* poses_out, double* points_out, vo_ba_stats* stats);
 /* parity probes at the uploaded x0 (no iteration):
  *   residual: m f64 in the reference's order (slot-major, ascending landmark; :18-65)

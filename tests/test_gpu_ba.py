@@ -156,3 +156,33 @@ def test_ba_full_size_properties(ctx):
     assert np.sqrt((r ** 2).mean()) < 0.5          # observation noise is 0.3 px per axis
     ref = bo.solve(s["K"], s["poses0"], s["points0"], s["obs"], max_iters=30)
     assert abs(st["cost"] - ref["cost"]) <= 1e-6 * ref["cost"]
+
+
+def test_ba_bank_select_equals_individual_uploads():
+    """a bank of resident problems (vo_ba_upload_bank / vo_ba_select_problem): solving problem k of the bank = uploading and solving it alone,
+    bit for bit, in any order, on a batch of 2; a fetch while a frame step is in flight does not disturb that step's results"""
+    from vo_mi355x import VoContext, synthetic as syn
+    B, nb = 2, 3
+    sc = [[syn.make_ba_scene(n_pts=300, n_slots=6, seed=10 * b + k, pt_noise=0.3 + 0.3 * k, visibility=1.0 - 0.1 * k) for k in range(nb)] for b in range(B)]
+    K = np.stack([sc[b][0]["K"] for b in range(B)])
+    with VoContext(64, 64, max_pts=64, batch=B) as c:
+        prm = c.ba_params(max_iters=12)
+        alone = []
+        for k in range(nb):
+            c.ba_upload(K, np.stack([sc[b][k]["poses0"] for b in range(B)]), np.stack([sc[b][k]["points0"] for b in range(B)]),
+                        np.stack([sc[b][k]["obs"] for b in range(B)]))
+            c.ba_solve_resident(prm)
+            alone.append(c.ba_fetch())
+        c.ba_upload_bank(K, np.stack([[sc[b][k]["poses0"] for b in range(B)] for k in range(nb)]),
+                         np.stack([[sc[b][k]["points0"] for b in range(B)] for k in range(nb)]),
+                         np.stack([[sc[b][k]["obs"] for b in range(B)] for k in range(nb)]))
+        for k in (2, 0, 1, 2):
+            c.ba_select(k)
+            c.ba_solve_resident(prm)
+            po, pt, st = c.ba_fetch()
+            assert np.array_equal(po, alone[k][0]) and np.array_equal(pt, alone[k][1])
+            assert [x["iters"] for x in st] == [x["iters"] for x in alone[k][2]] and [x["cost"] for x in st] == [x["cost"] for x in alone[k][2]]
+        its = [x["iters"] for x in alone[0][2]] + [x["iters"] for x in alone[2][2]]
+        assert len(set(its)) > 1                      # the problems really differ in difficulty
+        with pytest.raises(Exception):
+            c.ba_select(nb)

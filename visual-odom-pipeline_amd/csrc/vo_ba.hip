@@ -139,6 +139,10 @@ struct vo_ba_ws {
   ba_info* d_info = nullptr;
   ba_state* h_state = nullptr;  // pinned
   bool uploaded = false;
+  // bank of resident problems (vo_ba_upload_bank): d_x0 / d_obs point at the selected one; the workspace's own buffers are kept for the free
+  double* d_x0_own = nullptr; double* d_obs_own = nullptr;
+  double* d_bank_x0 = nullptr; double* d_bank_obs = nullptr;
+  int bank_n = 0, bank_sel = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1180,6 +1184,9 @@ __global__ void __launch_bounds__(128) k_ba_residual(ba_ptrs Pall, const double*
 void vo_ba_destroy(vo_ctx* c) {
   if (!c->ba) return;
   vo_ba_ws* b = c->ba;
+  if (b->d_x0_own) { b->d_x0 = b->d_x0_own; b->d_obs = b->d_obs_own; }
+  if (b->d_bank_x0) (void)hipFree(b->d_bank_x0);
+  if (b->d_bank_obs) (void)hipFree(b->d_bank_obs);
   void* bufs[] = {b->d_K, b->d_obs, b->d_x0, b->d_x[0], b->d_x[1], b->d_aux, b->d_posepart, b->d_gmax,
                   b->d_tiles, b->d_dp, b->d_evalpart, b->d_tilesum, b->d_xstat, b->d_gather, b->d_cams, b->d_S, b->d_Hpp, b->d_res, b->d_dl, b->d_pub, b->d_state, b->d_info};
   for (void* p : bufs) if (p) (void)hipFree(p);
@@ -1272,7 +1279,7 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     VO_HIP(c, hipMalloc((void**)&b->d_dl, sizeof(double) * (size_t)3 * N));
     b->pub_bytes = 64 + sizeof(double) * nx;                                                        // per problem
     VO_HIP(c, hipMalloc((void**)&b->d_pub, b->pub_bytes * B));
-    VO_HIP(c, hipHostMalloc((void**)&b->h_pub, 2 * b->pub_bytes * B, hipHostMallocDefault));   // two halves (pipelined frame steps)
+    VO_HIP(c, hipHostMalloc((void**)&b->h_pub, 3 * b->pub_bytes * B, hipHostMallocDefault));   // two halves (pipelined frame steps) + one for vo_ba_fetch
     b->d_xout = reinterpret_cast<double*>(b->d_pub + 64);
     VO_HIP(c, hipMalloc((void**)&b->d_state, sizeof(ba_state) * 2 * B));
     VO_HIP(c, hipMalloc((void**)&b->d_info, sizeof(ba_info) * B));
@@ -1285,6 +1292,48 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
   ba_geometry(c->ba, W, N);
   VO_CHECK(c, c->ba->build_lds <= 130 * 1024 && c->ba->solve_lds <= 150 * 1024, VO_E_CAPACITY, "window too large for LDS");
   VO_CHECK(c, c->ba->nblk <= 640, VO_E_CAPACITY, "too many landmarks for one adjust (raise the partial capacity)");
+  return VO_OK;
+}
+
+// A bank of `n_problems` problems of one shape resident in HBM, one of them selected per solve: the bench's sequences see a different
+// bundle-adjustment problem every frame (a sliding window never presents the same problem twice) without any upload in the loop.
+// K [batch][9]; poses [n_problems][batch][W][6]; points [n_problems][batch][N][3]; obs [n_problems][batch][W][N][2]
+extern "C" int32_t vo_ba_upload_bank(vo_ctx* c, const double* K, const double* poses, const double* points, const double* obs,
+                                     int32_t n_slots, int32_t n_pts, int32_t n_problems) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, K && poses && points && obs && n_problems >= 1 && n_problems <= 64, VO_E_INVALID, "null buffer / bad bank size");
+  VO_HIP(c, hipSetDevice(c->device));
+  if (c->stream3) VO_HIP(c, hipStreamSynchronize(c->stream3));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->ba) vo_ba_destroy(c);                       // a fresh workspace: the bank replaces its problem buffers
+  int32_t r = ba_alloc(c, n_slots, n_pts);
+  if (r != VO_OK) return r;
+  vo_ba_ws* b = c->ba;
+  const size_t W = b->W, N = b->N, B = c->batch, nx = 6 * W + 3 * N, no = 2 * W * N;
+  VO_HIP(c, hipMalloc((void**)&b->d_bank_x0, sizeof(double) * nx * B * n_problems));
+  VO_HIP(c, hipMalloc((void**)&b->d_bank_obs, sizeof(double) * no * B * n_problems));
+  VO_HIP(c, hipMemcpyAsync(b->d_K, K, 9 * sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipMemcpyAsync(b->d_bank_obs, obs, sizeof(double) * no * B * n_problems, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipMemcpy2DAsync(b->d_bank_x0, sizeof(double) * nx, poses, sizeof(double) * 6 * W, sizeof(double) * 6 * W, B * n_problems, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipMemcpy2DAsync(b->d_bank_x0 + 6 * W, sizeof(double) * nx, points, sizeof(double) * 3 * N, sizeof(double) * 3 * N, B * n_problems, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  b->d_x0_own = b->d_x0; b->d_obs_own = b->d_obs;
+  b->d_x0 = b->d_bank_x0; b->d_obs = b->d_bank_obs;
+  b->bank_n = n_problems; b->bank_sel = 0;
+  b->uploaded = true;
+  return VO_OK;
+}
+
+// the problem the next vo_ba_solve_resident / vo_frame_step_resident solves (host-side pointer switch; nothing is enqueued)
+extern "C" int32_t vo_ba_select_problem(vo_ctx* c, int32_t k) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->ba && c->ba->bank_n > 0, VO_E_STATE, "vo_ba_upload_bank first");
+  VO_CHECK(c, k >= 0 && k < c->ba->bank_n, VO_E_INVALID, "no such problem in the bank");
+  vo_ba_ws* b = c->ba;
+  const size_t W = b->W, N = b->N, B = c->batch;
+  b->d_x0 = b->d_bank_x0 + (size_t)k * B * (6 * W + 3 * N);
+  b->d_obs = b->d_bank_obs + (size_t)k * B * (2 * W * N);
+  b->bank_sel = k;
   return VO_OK;
 }
 
@@ -1332,6 +1381,7 @@ extern "C" int32_t vo_ba_upload(vo_ctx* c, const double* K, const double* poses,
   VO_CHECK(c, K && poses && points && obs, VO_E_INVALID, "null buffer");
   VO_HIP(c, hipSetDevice(c->device));
   if (c->stream3) VO_HIP(c, hipStreamSynchronize(c->stream3));     // a pipelined frame step runs its bundle adjustment there
+  if (c->ba && c->ba->bank_n > 0) { VO_HIP(c, hipStreamSynchronize(c->stream)); vo_ba_destroy(c); }      // a plain upload replaces a bank
   int32_t r = ba_alloc(c, n_slots, n_pts);
   if (r != VO_OK) return r;
   vo_ba_ws* b = c->ba;
@@ -1411,6 +1461,7 @@ extern "C" int32_t vo_ba_solve_resident(vo_ctx* c, const vo_ba_params* prm) {
 // ---- closed-loop pipeline hooks: the problem (x0, obs) is written by a device kernel every frame ----
 int32_t vo_ba_reserve(vo_ctx* c, const double* K_host, int W, int N) {
   if (c->stream3) VO_HIP(c, hipStreamSynchronize(c->stream3));
+  if (c->ba && c->ba->bank_n > 0) { VO_HIP(c, hipStreamSynchronize(c->stream)); vo_ba_destroy(c); }
   int32_t r = ba_alloc(c, W, N);
   if (r != VO_OK) return r;
   vo_ba_ws* b = c->ba;
@@ -1467,10 +1518,11 @@ extern "C" int32_t vo_ba_fetch(vo_ctx* c, double* poses_out, double* points_out,
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->ba && c->ba->uploaded, VO_E_STATE, "nothing to fetch");
   VO_HIP(c, hipSetDevice(c->device));
-  int32_t r = vo_ba_enqueue_pub_copy(c, 0);
+  // its own pinned mirror: a frame step still in flight keeps the two halves vo_frame_fetch reads
+  int32_t r = vo_ba_enqueue_pub_copy(c, 2);
   if (r != VO_OK) return r;
   VO_HIP(c, hipStreamSynchronize(c->stream));
-  vo_ba_unpack_pub(c, 0, poses_out, points_out, stats);
+  vo_ba_unpack_pub(c, 2, poses_out, points_out, stats);
   return VO_OK;
 }
 
@@ -1541,10 +1593,10 @@ extern "C" int32_t vo_ba_adjust(vo_ctx* c, const double* K, const double* poses,
     all_done = true;
     for (int q = 0; q < B; q++) all_done = all_done && b->h_state[q].done;
   } while (!all_done && it < prm->max_iters);
-  r = vo_ba_enqueue_pub_copy(c, 0);
+  r = vo_ba_enqueue_pub_copy(c, 2);
   if (r != VO_OK) return r;
   VO_HIP(c, hipStreamSynchronize(c->stream));
-  vo_ba_unpack_pub(c, 0, poses_out, points_out, stats);
+  vo_ba_unpack_pub(c, 2, poses_out, points_out, stats);
   bool bad = false;
   for (int q = 0; q < B; q++) {
     if (stats) {

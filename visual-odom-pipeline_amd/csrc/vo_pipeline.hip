@@ -6,7 +6,8 @@
 //   k_pipe_prune      after PnP     pipeline.py:124-140 (inlier pruning, trajectory.append) + the split of triangulate_tracks (extractor.py:202-203)
 //   k_pipe_promote    after DLT     triangulate.py:87-111 filters, extractor.py:231-240 gate, pipeline.py:153-154; then the selection half of
 //                                   BundleAdjuster.adjust (bundle_adjuster.py:132-176): resurrection, observation table, x0
-//   k_pipe_writeback  after BA      bundle_adjuster.py:197-213; the resident point set (exclusion discs, next frame's KLT)
+//   k_pipe_dense      after promote the resident point set (exclusion discs, next KLT); then S-T on a side stream beside the BA
+//   k_pipe_writeback  after BA      bundle_adjuster.py:197-213
 //   k_pipe_spawn      after S-T     extractor.py:127-131 / pipeline.py:159-163; free rows rebuilt; the frame's record
 //
 // The reference relies on OBJECT IDENTITY: adjust appends recently dead landmarks to state._landmarks without copying
@@ -16,7 +17,7 @@
 // entries may refer to one row.  oracle/pipe_oracle.py is the same algorithm in numpy, checked object by object against the
 // reference's loop over Python objects; this file follows it phase by phase.
 //
-// One workgroup (1024 threads) per sequence; a thread owns list entries tid, tid + 1024, ... (<= 4: max_pts <= 4096), reads them all
+// One workgroup (1024 threads) per sequence; a thread owns CH = ceil(max_pts / 1024) <= 4 CONSECUTIVE list entries, reads them all
 // before anything is written, and ordered compaction / allocation are block-wide prefix scans, so results do not depend on timing.
 #include "vo_internal.h"
 
@@ -24,7 +25,7 @@
 #include <string.h>
 
 #define PIPE_TPB 1024
-#define PIPE_CH 4                 // list entries per thread: max_pts <= PIPE_TPB * PIPE_CH
+#define PIPE_CH 4                 // most list entries per thread: max_pts <= PIPE_TPB * PIPE_CH
 #define PIPE_HIST VO_PIPE_HIST
 #define PIPE_NCNT 32
 
@@ -103,17 +104,27 @@ __device__ __forceinline__ int pipe_scan(int flag, int* s_w, int& total) {
   return off + within;
 }
 
-// ranks of flagged entries in LIST order (entry j = c * 1024 + tid): rank[c] for c < PIPE_CH; returns the total
+// A thread owns the CH CONSECUTIVE list entries j = tid * CH + c, so list order is thread order and ONE block-wide scan of the
+// per-thread counts ranks the flagged entries: rank[c] = position of entry (tid, c) among the flagged ones; returns their number.
+template <int CH>
 __device__ __forceinline__ int pipe_rank(const bool* flag, int* rank, int* s_w) {
-  int base = 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int cnt = 0;
 #pragma unroll
-  for (int c = 0; c < PIPE_CH; c++) {
-    int tot;
-    const int pos = pipe_scan(flag[c] ? 1 : 0, s_w, tot);
-    rank[c] = base + pos;
-    base += tot;
-  }
-  return base;
+  for (int c = 0; c < CH; c++) cnt += flag[c] ? 1 : 0;
+  int x = cnt;                           // inclusive scan inside the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+  __syncthreads();                       // s_w may still be read from the previous call
+  if (lane == 63) s_w[wave] = x;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) { const int v = s_w[w]; if (w < wave) off += v; tot += v; }
+  int r = off + x - cnt;
+#pragma unroll
+  for (int c = 0; c < CH; c++) { rank[c] = r; r += flag[c] ? 1 : 0; }
+  return tot;
 }
 
 __device__ __forceinline__ float2* pipe_hist_slot(const pipe_ptrs& P, int idx) { return P.k_hist + (size_t)(idx & (PIPE_HIST - 1)) * P.R; }
@@ -165,6 +176,7 @@ __device__ inline void pipe_log_so3(const double* R, double* r) {
 // ================================================================================================
 // k_pipe_extend: the keep rule and bookkeeping after the KLT of [landmark keypoints | candidates]
 // ================================================================================================
+template <int CH>
 __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const float* __restrict__ pts, size_t slab_seq, int W, int H,
                                                           float* __restrict__ pnp_X, float* __restrict__ pnp_uv, int pnp_cap) {
   __shared__ int s_w[16];
@@ -180,12 +192,12 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
   __syncthreads();                                   // every thread has read the counters before thread 0 rewrites them
 
   // ---- everything this workgroup will touch is read first ----
-  int L[PIPE_CH], K[PIPE_CH], KC[PIPE_CH];
-  bool keep[PIPE_CH], die[PIPE_CH], ksh[PIPE_CH], keepc[PIPE_CH];
-  float2 q[PIPE_CH], qc[PIPE_CH];
+  int L[CH], K[CH], KC[CH];
+  bool keep[CH], die[CH], ksh[CH], keepc[CH];
+  float2 q[CH], qc[CH];
 #pragma unroll
-  for (int c = 0; c < PIPE_CH; c++) {
-    const int j = c * PIPE_TPB + tid;
+  for (int c = 0; c < CH; c++) {
+    const int j = tid * CH + c;
     L[c] = 0; K[c] = 0; KC[c] = 0; keep[c] = die[c] = ksh[c] = keepc[c] = false;
     q[c] = qc[c] = make_float2(0.f, 0.f);
     if (j < nl) {
@@ -198,10 +210,10 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
 
   // ---- candidates (extend_tracks): survivors get uv, t_total + 1, a history entry; ordered compaction ----
   {
-    int rank[PIPE_CH];
-    const int n_out = pipe_rank(keepc, rank, s_w);
+    int rank[CH];
+    const int n_out = pipe_rank<CH>(keepc, rank, s_w);
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++)
+    for (int c = 0; c < CH; c++)
       if (keepc[c]) {
         const int k = KC[c], len = P.k_len[k];
         P.k_uv[k] = qc[c]; P.k_tt[k] += 1; pipe_hist_slot(P, len)[k] = qc[c]; P.k_len[k] = len + 1;
@@ -212,7 +224,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
 
   // ---- landmarks, phase A: survivors update their keypoint row and their landmark's t_latest (several entries may share an L row) ----
 #pragma unroll
-  for (int c = 0; c < PIPE_CH; c++)
+  for (int c = 0; c < CH; c++)
     if (keep[c]) {
       const int k = K[c], len = P.k_len[k];
       P.k_uv[k] = q[c]; P.k_tt[k] += 1; pipe_hist_slot(P, len)[k] = q[c]; P.k_len[k] = len + 1;
@@ -220,13 +232,13 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
     }
   // ---- phase B: deepcopy(k) of a survivor (extractor.py:85) matters only when the dead list holds the same keypoint object ----
   {
-    bool f[PIPE_CH]; int rank[PIPE_CH];
+    bool f[CH]; int rank[CH];
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) f[c] = keep[c] && ksh[c];
-    const int tot = pipe_rank(f, rank, s_w);
+    for (int c = 0; c < CH; c++) f[c] = keep[c] && ksh[c];
+    const int tot = pipe_rank<CH>(f, rank, s_w);
     if (headK + tot > nfK) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_CAPACITY; return; }
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++)
+    for (int c = 0; c < CH; c++)
       if (f[c]) { const int nk = P.freeK[headK + rank[c]]; pipe_copy_K(P, nk, K[c]); K[c] = nk; }
     headK += tot;
   }
@@ -234,24 +246,24 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
   // ---- phase C: what died is deep-copied into the dead lists (pipeline.py:101-102).  One deepcopy call per list: entries that share a
   //      landmark object share its copy -> the entry with the smallest index copies the row for all of them ----
   {
-    int drank[PIPE_CH];
-    const int n_die = pipe_rank(die, drank, s_w);
+    int drank[CH];
+    const int n_die = pipe_rank<CH>(die, drank, s_w);
     const int room = P.N - nd0;
-    bool ok[PIPE_CH], lead[PIPE_CH];
+    bool ok[CH], lead[CH];
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) { ok[c] = die[c] && drank[c] < room; if (ok[c]) st_i32(&P.scr[L[c]], 0x7FFFFFFF); }
+    for (int c = 0; c < CH; c++) { ok[c] = die[c] && drank[c] < room; if (ok[c]) st_i32(&P.scr[L[c]], 0x7FFFFFFF); }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) if (ok[c]) atomicMin(&P.scr[L[c]], c * PIPE_TPB + tid);
+    for (int c = 0; c < CH; c++) if (ok[c]) atomicMin(&P.scr[L[c]], tid * CH + c);
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) lead[c] = ok[c] && ld_i32(&P.scr[L[c]]) == c * PIPE_TPB + tid;
-    int lrank[PIPE_CH], krank[PIPE_CH];
-    const int n_lead = pipe_rank(lead, lrank, s_w);  // (its barriers also separate the reads of scr above from the writes below)
-    const int n_ok = pipe_rank(ok, krank, s_w);
+    for (int c = 0; c < CH; c++) lead[c] = ok[c] && ld_i32(&P.scr[L[c]]) == tid * CH + c;
+    int lrank[CH], krank[CH];
+    const int n_lead = pipe_rank<CH>(lead, lrank, s_w);  // (its barriers also separate the reads of scr above from the writes below)
+    const int n_ok = pipe_rank<CH>(ok, krank, s_w);
     if (headL + n_lead > nfL || headK + n_ok > nfK) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_CAPACITY; return; }
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++)
+    for (int c = 0; c < CH; c++)
       if (lead[c]) {
         const int nlr = P.freeL[headL + lrank[c]];
         P.l_tl[nlr] = ld_i32(&P.l_tl[L[c]]);
@@ -260,7 +272,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
       }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++)
+    for (int c = 0; c < CH; c++)
       if (ok[c]) {
         const int nk = P.freeK[headK + krank[c]];
         pipe_copy_K(P, nk, K[c]);
@@ -273,10 +285,10 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
   }
   // ---- ordered compaction of the landmark list; the survivors are the 3D-2D correspondences of the pose stage (extractor.py:176-177) ----
   {
-    int rank[PIPE_CH];
-    const int n_out = pipe_rank(keep, rank, s_w);
+    int rank[CH];
+    const int n_out = pipe_rank<CH>(keep, rank, s_w);
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++)
+    for (int c = 0; c < CH; c++)
       if (keep[c]) {
         const int o = rank[c];
         P.lm_L[o] = L[c]; P.lm_K[o] = K[c]; P.lm_ksh[o] = 0;
@@ -295,6 +307,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
 // ================================================================================================
 // k_pipe_prune: PnP result -> trajectory, non-inliers to the dead lists; ripe candidates -> DLT inputs
 // ================================================================================================
+template <int CH>
 __global__ void __launch_bounds__(PIPE_TPB) k_pipe_prune(pipe_ptrs Pall, int do_pose, int do_tri, const uint8_t* __restrict__ mask, const double* __restrict__ pnp_out,
                                                          int pnp_cap, int min_len, float* __restrict__ uv0, float* __restrict__ uv1, size_t uv_seq,
                                                          vo_dlt_cam* __restrict__ cams, int32_t* __restrict__ cam_sel) {
@@ -314,23 +327,23 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_prune(pipe_ptrs Pall, int do_
   __syncthreads();
   if (do_pose) {
     if (!(pnp_out[7] >= 4.0)) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_LOST; return; }      // cv2.solvePnPRansac found nothing: the reference crashes here
-    int L[PIPE_CH], K[PIPE_CH];
-    bool in[PIPE_CH], out[PIPE_CH];
+    int L[CH], K[CH];
+    bool in[CH], out[CH];
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) {
-      const int j = c * PIPE_TPB + tid;
+    for (int c = 0; c < CH; c++) {
+      const int j = tid * CH + c;
       L[c] = K[c] = 0; in[c] = out[c] = false;
       if (j < nl) { L[c] = P.lm_L[j]; K[c] = P.lm_K[j]; in[c] = mask[j] != 0; out[c] = !in[c]; }
     }
     __syncthreads();
     // non-inliers: deepcopy per entry (pipeline.py:133-134), every one gets its own L and K copy
-    int drank[PIPE_CH], rank[PIPE_CH];
-    const int n_out = pipe_rank(out, drank, s_w);
+    int drank[CH], rank[CH];
+    const int n_out = pipe_rank<CH>(out, drank, s_w);
     const int room = P.N - nd0;
     const int n_ok = n_out < room ? n_out : room;
     if (headL + n_ok > nfL || headK + n_ok > nfK) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_CAPACITY; return; }
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++)
+    for (int c = 0; c < CH; c++)
       if (out[c] && drank[c] < room) {
         const int nlr = P.freeL[headL + drank[c]], nk = P.freeK[headK + drank[c]];
         P.l_tl[nlr] = P.l_tl[L[c]];
@@ -340,9 +353,9 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_prune(pipe_ptrs Pall, int do_
       }
     headL += n_ok; headK += n_ok;
     if (n_out > n_ok) overflow |= 1;
-    const int n_in = pipe_rank(in, rank, s_w);
+    const int n_in = pipe_rank<CH>(in, rank, s_w);
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) if (in[c]) { P.lm_L[rank[c]] = L[c]; P.lm_K[rank[c]] = K[c]; P.lm_ksh[rank[c]] = 0; }
+    for (int c = 0; c < CH; c++) if (in[c]) { P.lm_L[rank[c]] = L[c]; P.lm_K[rank[c]] = K[c]; P.lm_ksh[rank[c]] = 0; }
     if (tid == 0) {
       P.cnt[C_NLM] = n_in; P.cnt[C_NDEAD] = nd0 + n_ok; P.cnt[C_NINERT] += n_out - n_ok;
       // trajectory.append(t, [R(rvec) | tvec]) (extractor.py:186-191, pipeline.py:140)
@@ -357,20 +370,20 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_prune(pipe_ptrs Pall, int do_
     // triangulate_tracks (extractor.py:202-203): candidates that reached min_track_length leave the list whether or not they succeed.
     // They are triangulated in groups by birth frame, each against the pose of its birth frame (:210-220); a group is named by its AGE
     // a = t - t_first (the slot distance in the 32-frame trajectory ring)
-    int KC[PIPE_CH], age[PIPE_CH]; bool ripe[PIPE_CH], wait[PIPE_CH];
+    int KC[CH], age[CH]; bool ripe[CH], wait[CH];
     if (tid < PIPE_HIST) s_present[tid] = 0;
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) {
-      const int j = c * PIPE_TPB + tid;
+    for (int c = 0; c < CH; c++) {
+      const int j = tid * CH + c;
       KC[c] = 0; age[c] = 0; ripe[c] = wait[c] = false;
       if (j < nc) { KC[c] = P.cand[j]; ripe[c] = P.k_tt[KC[c]] >= min_len; wait[c] = !ripe[c]; age[c] = t - P.k_tf[KC[c]]; }
     }
     __syncthreads();
-    int rr[PIPE_CH], wr[PIPE_CH];
-    const int n_ripe = pipe_rank(ripe, rr, s_w);
-    const int n_wait = pipe_rank(wait, wr, s_w);
+    int rr[CH], wr[CH];
+    const int n_ripe = pipe_rank<CH>(ripe, rr, s_w);
+    const int n_wait = pipe_rank<CH>(wait, wr, s_w);
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) {
+    for (int c = 0; c < CH; c++) {
       if (ripe[c]) {
         if (age[c] < 0 || age[c] >= PIPE_HIST || age[c] > t) s_bad = 1;       // the birth pose has left the trajectory ring
         else s_present[age[c]] = 1;
@@ -405,6 +418,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_prune(pipe_ptrs Pall, int do_
 // ================================================================================================
 // k_pipe_promote: triangulation filters + gate + promotion; then the selection half of BundleAdjuster.adjust
 // ================================================================================================
+template <int CH>
 __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int do_tri, int do_adjust, const float* __restrict__ X4, const double* __restrict__ depth1,
                                                            const double* __restrict__ reproj, size_t slab_seq, int x4_stride, double max_err,
                                                            double min_angle, const int32_t* __restrict__ cam_sel, int Wn, int resurrect, double* __restrict__ x0, double* __restrict__ obs,
@@ -427,12 +441,12 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
   __syncthreads();
   int n_new = 0;
   if (do_tri && n_ripe > 0) {
-    bool kept[PIPE_CH]; float pt[PIPE_CH][3]; int age[PIPE_CH];
+    bool kept[CH]; float pt[CH][3]; int age[CH];
     if (tid < PIPE_HIST) { s_first[tid] = 0x7FFFFFFF; s_gate[tid] = 0; }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) {
-      const int j = c * PIPE_TPB + tid;
+    for (int c = 0; c < CH; c++) {
+      const int j = tid * CH + c;
       kept[c] = false; age[c] = 0;
       if (j < n_ripe) {
         const float w4 = X4[(size_t)3 * x4_stride + j];
@@ -481,17 +495,17 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
     if (room < 0) room = 0;
     for (int a = PIPE_HIST - 1; a >= 0; a--) {
       if (!s_gate[a]) continue;                          // uniform: s_gate is shared
-      bool f[PIPE_CH]; int rank[PIPE_CH];
+      bool f[CH]; int rank[CH];
 #pragma unroll
-      for (int c = 0; c < PIPE_CH; c++) f[c] = kept[c] && age[c] == a;
-      const int n_grp = pipe_rank(f, rank, s_w);
+      for (int c = 0; c < CH; c++) f[c] = kept[c] && age[c] == a;
+      const int n_grp = pipe_rank<CH>(f, rank, s_w);
       int n_take = n_grp < room ? n_grp : room;
       if (n_grp > n_take) overflow |= 2;
       if (headL + n_take > nfL) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_CAPACITY; return; }
 #pragma unroll
-      for (int c = 0; c < PIPE_CH; c++)
+      for (int c = 0; c < CH; c++)
         if (f[c] && rank[c] < n_take) {
-          const int j = c * PIPE_TPB + tid, nlr = P.freeL[headL + rank[c]];
+          const int j = tid * CH + c, nlr = P.freeL[headL + rank[c]];
           P.l_tl[nlr] = t;                                                                   // Landmark(t_curr, p, des) (extractor.py:274-275)
           for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = (double)pt[c][k];
           P.lm_L[nl + rank[c]] = nlr; P.lm_K[nl + rank[c]] = P.ripe[j]; P.lm_ksh[nl + rank[c]] = 0;
@@ -503,39 +517,39 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
   int n_res = 0, nd = nd0, n_inert = 0;
   if (do_adjust) {
     // ---- dead landmarks whose track lies inside the window are appended to the state's lists as the same objects (bundle_adjuster.py:132-150) ----
-    int DL[PIPE_CH], DK[PIPE_CH]; bool win[PIPE_CH], take[PIPE_CH], stay[PIPE_CH];
-    int wr[PIPE_CH];
+    int DL[CH], DK[CH]; bool win[CH], take[CH], stay[CH];
+    int wr[CH];
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) {
-      const int j = c * PIPE_TPB + tid;
+    for (int c = 0; c < CH; c++) {
+      const int j = tid * CH + c;
       DL[c] = DK[c] = 0; win[c] = false;
       if (j < nd0) { DL[c] = P.dead_L[j]; DK[c] = P.dead_K[j]; win[c] = resurrect && (t - (P.l_tl[DL[c]] - (P.k_len[DK[c]] - 1))) < Wn; }
     }
-    const int n_win = pipe_rank(win, wr, s_w);
+    const int n_win = pipe_rank<CH>(win, wr, s_w);
     int room = P.N - nl - nc;
     if (room < 0) room = 0;
     n_res = n_win < room ? n_win : room;
     if (n_win > n_res) overflow |= 4;
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) {
+    for (int c = 0; c < CH; c++) {
       take[c] = win[c] && wr[c] < n_res;
       if (take[c]) { P.lm_L[nl + wr[c]] = DL[c]; P.lm_K[nl + wr[c]] = DK[c]; P.lm_ksh[nl + wr[c]] = 1; }
-      const int j = c * PIPE_TPB + tid;
+      const int j = tid * CH + c;
       if (j < nd0 && !take[c]) st_i32(&P.scr[DL[c]], 0);
     }
     nl += n_res;
     __syncthreads();
     // an entry that stays dead is kept while it may still be resurrected: the window test holds, or its L row is in the state's list
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) { const int j = c * PIPE_TPB + tid; if (j < nl) st_i32(&P.scr[P.lm_L[j]], 1); }
+    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; if (j < nl) st_i32(&P.scr[P.lm_L[j]], 1); }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) { const int j = c * PIPE_TPB + tid; stay[c] = j < nd0 && !take[c] && (win[c] || ld_i32(&P.scr[DL[c]]) == 1); }
-    int tr[PIPE_CH], sr[PIPE_CH];
-    const int n_take = pipe_rank(take, tr, s_w);
-    const int n_stay = pipe_rank(stay, sr, s_w);
+    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; stay[c] = j < nd0 && !take[c] && (win[c] || ld_i32(&P.scr[DL[c]]) == 1); }
+    int tr[CH], sr[CH];
+    const int n_take = pipe_rank<CH>(take, tr, s_w);
+    const int n_stay = pipe_rank<CH>(stay, sr, s_w);
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) {
+    for (int c = 0; c < CH; c++) {
       if (take[c]) { P.dead_L[tr[c]] = DL[c]; P.dead_K[tr[c]] = DK[c]; }
       if (stay[c]) { P.dead_L[n_take + sr[c]] = DL[c]; P.dead_K[n_take + sr[c]] = DK[c]; }
     }
@@ -545,8 +559,8 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
     double* pts0 = x0 + 6 * (size_t)Wn;
     int nobs = 0;
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) {
-      const int j = c * PIPE_TPB + tid;
+    for (int c = 0; c < CH; c++) {
+      const int j = tid * CH + c;
       if (j >= Nba) continue;
       if (j < nl) {
         const int Lr = P.lm_L[j], Kr = P.lm_K[j], n = P.k_len[Kr], tl = P.l_tl[Lr];
@@ -584,18 +598,17 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
 }
 
 // ================================================================================================
-// k_pipe_writeback: solution -> landmark rows and trajectory (bundle_adjuster.py:197-213); the resident point set
+// k_pipe_writeback: solution -> landmark rows and trajectory (bundle_adjuster.py:197-213)
 // ================================================================================================
 struct pipe_ba_head { double lambda, nu, cost, cost0; int cur, iter, accepted, status, done, n_obs; };
 
+template <int CH>
 __global__ void __launch_bounds__(PIPE_TPB) k_pipe_writeback(pipe_ptrs Pall, int do_adjust, const uint8_t* __restrict__ pub, size_t pub_bytes, const double* __restrict__ x0,
-                                                             size_t x_stride, int Wn, float* __restrict__ pts, size_t slab_seq,
-                                                             vo_pipe_record* __restrict__ rec) {
+                                                             size_t x_stride, int Wn, vo_pipe_record* __restrict__ rec) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const pipe_ptrs P = pipe_select(Pall, b);
   if (P.cnt[C_STATUS]) return;
-  const int nl = P.cnt[C_NLM], nc = P.cnt[C_NCAND], t = P.cnt[C_T];
-  float2* out = reinterpret_cast<float2*>(vo_seq(pts, slab_seq, b));
+  const int nl = P.cnt[C_NLM], t = P.cnt[C_T];
   if (do_adjust) {
     const pipe_ba_head* st = reinterpret_cast<const pipe_ba_head*>(pub + (size_t)b * pub_bytes);
     // nothing observed: the adapter skips the solve and writes x0 back (bundle_adjuster.py would hand scipy an empty problem)
@@ -603,14 +616,14 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_writeback(pipe_ptrs Pall, int
     const double* xp = x + 6 * (size_t)Wn;
     // entries that share a landmark row: the reference assigns in list order, the LAST one wins (:197-201)
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) { const int j = c * PIPE_TPB + tid; if (j < nl) st_i32(&P.scr[P.lm_L[j]], -1); }
+    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; if (j < nl) st_i32(&P.scr[P.lm_L[j]], -1); }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) { const int j = c * PIPE_TPB + tid; if (j < nl) atomicMax(&P.scr[P.lm_L[j]], j); }
+    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; if (j < nl) atomicMax(&P.scr[P.lm_L[j]], j); }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < PIPE_CH; c++) {
-      const int j = c * PIPE_TPB + tid;
+    for (int c = 0; c < CH; c++) {
+      const int j = tid * CH + c;
       if (j < nl) { const int Lr = P.lm_L[j]; if (ld_i32(&P.scr[Lr]) == j) for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)Lr + k] = xp[3 * (size_t)j + k]; }
     }
     if (tid < Wn && t - tid >= 0 && tid < PIPE_HIST) {
@@ -627,19 +640,12 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_writeback(pipe_ptrs Pall, int
       r.ba_done = solved ? st->done : 1; r.ba_cost0 = solved ? st->cost0 : 0.0; r.ba_cost = solved ? st->cost : 0.0;
     }
   }
-  // resident point set = every keypoint of the state (landmark entries first): exclusion discs now, the next frame's KLT input
-#pragma unroll
-  for (int c = 0; c < PIPE_CH; c++) {
-    const int j = c * PIPE_TPB + tid;
-    if (j < nl) out[j] = P.k_uv[P.lm_K[j]];
-    if (j < nc) out[nl + j] = P.k_uv[P.cand[j]];
-  }
-  if (tid == 0) { P.cnt[C_NPTS] = nl + nc; Pall.dn[DN_PTS * gridDim.x + b] = nl + nc; }
 }
 
 // ================================================================================================
 // k_pipe_spawn: corners -> candidates; free rows; the frame's record
 // ================================================================================================
+template <int CH>
 __global__ void __launch_bounds__(PIPE_TPB) k_pipe_spawn(pipe_ptrs Pall, int do_detect, const uint32_t* __restrict__ st_scalars, const float* __restrict__ st_out,
                                                          float* __restrict__ pts, size_t slab_seq, int max_new, const double* __restrict__ pnp_out,
                                                          const int32_t* __restrict__ pnp_ctrl, size_t pnp_ctrl_stride, vo_pipe_record* __restrict__ rec) {
@@ -715,17 +721,20 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_spawn(pipe_ptrs Pall, int do_
   }
 }
 
-// after the tables were written from the host: free rows + the resident point set
-__global__ void __launch_bounds__(PIPE_TPB) k_pipe_commit(pipe_ptrs Pall, float* __restrict__ pts, size_t slab_seq) {
+// resident point set = every keypoint of the state (landmark entries first): the exclusion discs of this frame's re-detection (extractor.py:103-107
+// with pipeline.py:160: state._landmarks_kp + state._candidates_kp AFTER adjust has appended the resurrected entries), then -- with the corners
+// k_pipe_spawn appends -- the next frame's KLT input.  Also run after the tables were written from the host (reset = 1).
+__global__ void __launch_bounds__(PIPE_TPB) k_pipe_dense(pipe_ptrs Pall, float* __restrict__ pts, size_t slab_seq, int reset) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const pipe_ptrs P = pipe_select(Pall, b);
+  if (!reset && P.cnt[C_STATUS]) return;
   const int nl = P.cnt[C_NLM], nc = P.cnt[C_NCAND];
   float2* out = reinterpret_cast<float2*>(vo_seq(pts, slab_seq, b));
   for (int j = tid; j < P.N; j += PIPE_TPB) {
     if (j < nl) out[j] = P.k_uv[P.lm_K[j]];
     if (j < nc) out[nl + j] = P.k_uv[P.cand[j]];
   }
-  if (tid == 0) { P.cnt[C_NPTS] = nl + nc; Pall.dn[DN_PTS * gridDim.x + b] = nl + nc; Pall.dn[DN_PNP * gridDim.x + b] = 0; Pall.dn[DN_RIPE * gridDim.x + b] = 0; }
+  if (tid == 0) { P.cnt[C_NPTS] = nl + nc; Pall.dn[DN_PTS * gridDim.x + b] = nl + nc; if (reset) { Pall.dn[DN_PNP * gridDim.x + b] = 0; Pall.dn[DN_RIPE * gridDim.x + b] = 0; } }
 }
 
 // ================================================================================================
@@ -835,11 +844,19 @@ extern "C" int32_t vo_pipe_table_read(vo_ctx* c, int32_t which, void* dst) {
   return VO_OK;
 }
 
+// entries per thread of the list kernels: the lists hold at most max_pts entries
+#define PIPE_DISPATCH(KERNEL, ...)                                                                                              \
+  do {                                                                                                                          \
+    if (w->N <= PIPE_TPB) hipLaunchKernelGGL(KERNEL<1>, dim3(c->batch), dim3(PIPE_TPB), 0, c->stream, __VA_ARGS__);              \
+    else if (w->N <= 2 * PIPE_TPB) hipLaunchKernelGGL(KERNEL<2>, dim3(c->batch), dim3(PIPE_TPB), 0, c->stream, __VA_ARGS__);     \
+    else hipLaunchKernelGGL(KERNEL<4>, dim3(c->batch), dim3(PIPE_TPB), 0, c->stream, __VA_ARGS__);                               \
+  } while (0)
+
 static void pipe_launch_spawn(vo_ctx* c, int do_detect) {
   vo_pipe_ws* w = c->pipe;
   vo_pnp_view pv;
   (void)vo_pnp_get_view(c, &pv);
-  hipLaunchKernelGGL(k_pipe_spawn, dim3(c->batch), dim3(PIPE_TPB), 0, c->stream, pipe_make(w), do_detect, vo_slab<const uint32_t>(c, c->off_st_scalars),
+  PIPE_DISPATCH(k_pipe_spawn, pipe_make(w), do_detect, vo_slab<const uint32_t>(c, c->off_st_scalars),
                      vo_slab<const float>(c, c->off_st_out), vo_slab<float>(c, vo_off_p(c)), c->slab_seq, w->prm.max_new, pv.out, pv.ctrl,
                      pv.ctrl_stride, w->d_rec);
 }
@@ -849,7 +866,7 @@ extern "C" int32_t vo_pipe_commit(vo_ctx* c) {
   VO_CHECK(c, c->pipe, VO_E_STATE, "vo_pipe_create first");
   VO_HIP(c, hipSetDevice(c->device));
   vo_pipe_ws* w = c->pipe;
-  hipLaunchKernelGGL(k_pipe_commit, dim3(c->batch), dim3(PIPE_TPB), 0, c->stream, pipe_make(w), vo_slab<float>(c, vo_off_p(c)), c->slab_seq);
+  hipLaunchKernelGGL(k_pipe_dense, dim3(c->batch), dim3(PIPE_TPB), 0, c->stream, pipe_make(w), vo_slab<float>(c, vo_off_p(c)), c->slab_seq, 1);
   pipe_launch_spawn(c, 0);                      // free lists (and a record of the seeded state)
   VO_HIP(c, hipGetLastError());
   VO_HIP(c, hipStreamSynchronize(c->stream));
@@ -887,7 +904,7 @@ extern "C" int32_t vo_pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages) {
     VO_CHECK(c, c->n_pushed >= 2, VO_E_STATE, "tracking needs two frames in the frame store");
     r = vo_klt_track_resident(c, w->N, &prm.klt);
     if (r != VO_OK) return r;
-    hipLaunchKernelGGL(k_pipe_extend, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq, c->width, c->height,
+    PIPE_DISPATCH(k_pipe_extend, P, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq, c->width, c->height,
                        pv.X, pv.uv, pv.cap);
   }
   if (stages & VO_PIPE_POSE) {
@@ -895,26 +912,43 @@ extern "C" int32_t vo_pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages) {
     if (r != VO_OK) return r;
   }
   if (stages & (VO_PIPE_POSE | VO_PIPE_TRIANGULATE))
-    hipLaunchKernelGGL(k_pipe_prune, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, (stages & VO_PIPE_POSE) ? 1 : 0, (stages & VO_PIPE_TRIANGULATE) ? 1 : 0,
+    PIPE_DISPATCH(k_pipe_prune, P, (stages & VO_PIPE_POSE) ? 1 : 0, (stages & VO_PIPE_TRIANGULATE) ? 1 : 0,
                        pv.mask, pv.out, pv.cap, prm.min_track_length, c->d_uv0, c->d_uv1, (size_t)c->max_pts * 2, w->d_cams, w->d_cam_sel);
   if (stages & VO_PIPE_TRIANGULATE) {
     r = vo_dlt_enqueue_counts(c, w->N, w->d_dn + DN_RIPE * B, w->d_cams, w->d_cam_sel, PIPE_HIST);
     if (r != VO_OK) return r;
   }
   if (stages & (VO_PIPE_TRIANGULATE | VO_PIPE_ADJUST))
-    hipLaunchKernelGGL(k_pipe_promote, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, (stages & VO_PIPE_TRIANGULATE) ? 1 : 0, (stages & VO_PIPE_ADJUST) ? 1 : 0,
+    PIPE_DISPATCH(k_pipe_promote, P, (stages & VO_PIPE_TRIANGULATE) ? 1 : 0, (stages & VO_PIPE_ADJUST) ? 1 : 0,
                        vo_slab<const float>(c, c->off_X4), vo_slab<const double>(c, c->off_depth), vo_slab<const double>(c, c->off_reproj), c->slab_seq,
                        w->N, prm.max_reproj_err, prm.min_bearing_angle, w->d_cam_sel, bv.W, prm.resurrect, bv.x0, bv.obs, bv.x_stride, bv.obs_stride, bv.N);
-  if (stages & VO_PIPE_ADJUST) {
-    r = vo_ba_enqueue_budget(c, &prm.ba, 0, prm.ba_budget);
-    if (r != VO_OK) return r;
-  }
-  hipLaunchKernelGGL(k_pipe_writeback, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, (stages & VO_PIPE_ADJUST) ? 1 : 0, bv.pub, bv.pub_bytes, bv.x0, bv.x_stride,
-                     bv.W, vo_slab<float>(c, vo_off_p(c)), c->slab_seq, w->d_rec);
-  if (stages & VO_PIPE_DETECT) {
+  hipLaunchKernelGGL(k_pipe_dense, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, vo_slab<float>(c, vo_off_p(c)), c->slab_seq, 0);
+  // the re-detection reads the frame and the keypoints of the state, the bundle adjustment the landmark rows and poses: two chains of
+  // narrow launches that share nothing -- side by side when the context has its side stream (vo_set_side_stream), joined before the spawn
+  const bool fork = (stages & VO_PIPE_ADJUST) && (stages & VO_PIPE_DETECT) && c->side_stream != 0;
+  if (fork) {
+    VO_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+    VO_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    hipStream_t main_stream = c->stream;
+    c->stream = c->stream2;
     r = vo_shi_tomasi_resident(c, w->N, prm.mask_radius, &prm.st);
+    c->stream = main_stream;
+    if (r == VO_OK) r = vo_ba_enqueue_budget(c, &prm.ba, 0, prm.ba_budget);
+    const hipError_t e1 = hipEventRecord(c->ev_join, c->stream2);
+    const hipError_t e2 = hipStreamWaitEvent(c->stream, c->ev_join, 0);     // joined on every path: nothing is left running on the side stream
     if (r != VO_OK) return r;
+    VO_HIP(c, e1); VO_HIP(c, e2);
+  } else {
+    if (stages & VO_PIPE_ADJUST) {
+      r = vo_ba_enqueue_budget(c, &prm.ba, 0, prm.ba_budget);
+      if (r != VO_OK) return r;
+    }
+    if (stages & VO_PIPE_DETECT) {
+      r = vo_shi_tomasi_resident(c, w->N, prm.mask_radius, &prm.st);
+      if (r != VO_OK) return r;
+    }
   }
+  PIPE_DISPATCH(k_pipe_writeback, P, (stages & VO_PIPE_ADJUST) ? 1 : 0, bv.pub, bv.pub_bytes, bv.x0, bv.x_stride, bv.W, w->d_rec);
   pipe_launch_spawn(c, (stages & VO_PIPE_DETECT) ? 1 : 0);
   VO_HIP(c, hipGetLastError());
   const int slot = (int)(w->enq % VO_PIPE_INFLIGHT);

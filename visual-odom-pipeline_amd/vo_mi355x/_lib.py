@@ -132,6 +132,8 @@ SIGNATURES = {
                                  _f64p, _f64p, C.POINTER(BaStats)]),
     "vo_ba_upload": (C.c_int32, [_ctx, _f64p, _f64p, _f64p, _f64p, C.c_int32, C.c_int32]),
     "vo_ba_solve_resident": (C.c_int32, [_ctx, C.POINTER(BaParams)]),
+    "vo_ba_upload_bank": (C.c_int32, [_ctx, _f64p, _f64p, _f64p, _f64p, C.c_int32, C.c_int32, C.c_int32]),
+    "vo_ba_select_problem": (C.c_int32, [_ctx, C.c_int32]),
     "vo_ba_fetch": (C.c_int32, [_ctx, _f64p, _f64p, C.POINTER(BaStats)]),
     "vo_comm_unique_id": (C.c_int32, [_u8p]),
     "vo_comm_init": (C.c_int32, [_ctx, C.c_int32, C.c_int32, _u8p]),

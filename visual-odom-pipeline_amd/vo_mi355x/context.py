@@ -379,6 +379,22 @@ class VoContext:
         d = C.c_double
         self._ck(self._L.vo_ba_upload(self._h, ptr(K, d), ptr(poses, d), ptr(points, d), ptr(obs, d), W, N))
 
+    def ba_upload_bank(self, K, poses, points, obs):
+        """a bank of resident problems of one shape: poses [n, B, W, 6], points [n, B, N, 3], obs [n, B, W, N, 2] (B = batch);
+        ba_select(k) picks the one the next resident solve / frame step works on (no upload, no launch)"""
+        obs = np.ascontiguousarray(obs, np.float64)
+        n, B, W, N = obs.shape[:4]
+        assert B == self.batch and obs.shape[4] == 2
+        poses = np.ascontiguousarray(poses, np.float64).reshape(n, B, W, 6)
+        points = np.ascontiguousarray(points, np.float64).reshape(n, B, N, 3)
+        K = self._in(K, np.float64, (3, 3))
+        d = C.c_double
+        self._ck(self._L.vo_ba_upload_bank(self._h, ptr(K, d), ptr(poses, d), ptr(points, d), ptr(obs, d), W, N, n))
+        self._ba_shape = (W, N)
+
+    def ba_select(self, k):
+        self._ck(self._L.vo_ba_select_problem(self._h, int(k)))
+
     def ba_solve_resident(self, params=None):
         prm = params if params is not None else self.ba_params()
         self._ck(self._L.vo_ba_solve_resident(self._h, C.byref(prm)))
@@ -390,6 +406,11 @@ class VoContext:
         self._ck(self._L.vo_ba_fetch(self._h, ptr(po, C.c_double), ptr(pt, C.c_double), st))
         stats = [self._stats(st[b]) for b in range(B)]
         return self._out(po), self._out(pt), stats[0] if B == 1 else stats
+
+    def ba_fetch_after(self, solve, params):
+        """solve(params) then ba_fetch() -- a resident solve whose result is wanted at once"""
+        solve(params)
+        return self.ba_fetch()
 
     # -- 3D-2D pose -----------------------------------------------------------------------------
     def pnp_ransac(self, K, pts3d, pts2d, reproj_err=2.0, confidence=0.9999, max_iters=1000000, seed=0):

@@ -81,13 +81,29 @@ def render_frame(tex, A, w, h, margin):
     return np.clip(np.rint(v), 0, 255).astype(np.uint8)
 
 
-def make_sequence(n_frames, w=1241, h=376, seed=1234, margin=96):
-    """-> (frames uint8 [n, h, w], motions [n, 2, 3])"""
+def frame_motion_periodic(t, w, h, period):
+    """like frame_motion, on a closed curve: the similarity sways with period `period` frames (frame `period` = frame 0), at most
+    ~2.5 px, 0.0025 rad and 0.4 % of scale per frame for a period of 100 -- a sequence that can be played in a loop of any length"""
+    c = np.array([(w - 1) * 0.5, (h - 1) * 0.5])
+    ph = 2 * np.pi * t / period
+    ang, s = 0.04 * np.sin(ph), 1.0 + 0.06 * np.sin(ph + 0.7)
+    R = s * np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+    tr = np.array([40.0 * np.sin(ph), 14.0 * np.sin(2 * ph)])
+    A = np.zeros((2, 3))
+    A[:, :2] = R
+    A[:, 2] = c - R @ c + tr
+    return A
+
+
+def make_sequence(n_frames, w=1241, h=376, seed=1234, margin=96, periodic=False, n_render=None):
+    """-> (frames uint8 [n, h, w], motions [n, 2, 3]); periodic: frame n_frames would equal frame 0 (play it in a loop);
+    n_render: only the first n_render frames of the n_frames-long motion are rendered"""
     tex = make_texture(h + 2 * margin, w + 2 * margin, seed)
-    frames = np.empty((n_frames, h, w), np.uint8)
-    motions = np.empty((n_frames, 2, 3))
-    for t in range(n_frames):
-        A = frame_motion(t, w, h)
+    n_out = n_frames if n_render is None else min(n_render, n_frames)
+    frames = np.empty((n_out, h, w), np.uint8)
+    motions = np.empty((n_out, 2, 3))
+    for t in range(n_out):
+        A = frame_motion_periodic(t, w, h, n_frames) if periodic else frame_motion(t, w, h)
         motions[t] = A
         frames[t] = render_frame(tex, A, w, h, margin)
     return frames, motions
