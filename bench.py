@@ -475,7 +475,6 @@ def cpu_baseline_parallel(n_procs, n_frames, ba_iters):
     t0 = time.perf_counter()
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--cpu-frames", str(n_frames),
                                "--ba-iters", str(ba_iters)], stdout=subprocess.PIPE, env=env, text=True) for i in range(n_procs)]
-    side = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "10000"], stdout=subprocess.PIPE, env=env, text=True)
     done, slowest = 0, 0.0
     for pr in procs:
         out, _ = pr.communicate()
@@ -485,6 +484,9 @@ def cpu_baseline_parallel(n_procs, n_frames, ba_iters):
             slowest = max(slowest, r["seconds"])
     wall = time.perf_counter() - t0
     extra = {}
+    # the side job (the reference's solver recipe, live OpenCV timings) runs AFTER the workers: beside them it would take a core from the
+    # timed baseline (17 busy processes on 16 granted cores)
+    side = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "10000"], stdout=subprocess.PIPE, env=env, text=True)
     try:
         so, _ = side.communicate(timeout=600)
         if side.returncode == 0 and so.strip():
@@ -633,10 +635,14 @@ def measure_extras(device, frame_sets, a, dist):
     return out
 
 
-def _klt_source_digest():
+def _klt_source_digest(with_frame_store=False):
+    """digest of the tracker's source; with_frame_store: also of vo_frame.hip, whose 4x derivative format the tracker consumes"""
     import hashlib
-    with open(os.path.join(ROOT, "visual-odom-pipeline_amd", "csrc", "vo_klt.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    for name in ("vo_klt.hip",) + (("vo_frame.hip",) if with_frame_store else ()):
+        with open(os.path.join(ROOT, "visual-odom-pipeline_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def profile_constant(fname, key):
@@ -650,6 +656,8 @@ def profile_constant(fname, key):
         d = json.load(open(path))
     except Exception as e:          # noqa: BLE001
         return None, "profiles/%s unreadable: %s" % (fname, e)
+    if "klt_frame_source_sha256_16" in d and d["klt_frame_source_sha256_16"] != _klt_source_digest(True):
+        return None, "profiles/%s was measured on another version of vo_klt.hip / vo_frame.hip (stale): re-run tools/profile_round.sh" % fname
     if d.get("klt_source_sha256_16") != _klt_source_digest():
         return None, "profiles/%s was measured on another version of vo_klt.hip (stale): re-run tools/profile_round.sh" % fname
     return d.get(key), "profiles/%s (rocprofv3 --pmc, %s)" % (fname, d.get("measured", "this round"))
@@ -664,8 +672,13 @@ def valu_roofline(launch_s, n_waves):
     """the roof that actually binds k_klt_track: vector-instruction issue.  SQ_INSTS_VALU per launch comes from the committed
     rocprofv3 --pmc summary (profiles/klt_valu.json); launch time is measured live in this run."""
     insts, src = profile_constant("klt_valu.json", "sq_insts_valu_per_launch")
+    waves, _ = profile_constant("klt_valu.json", "sq_waves_per_launch")
     if insts is None or launch_s <= 0:
         return {"wave_insts_per_launch": None, "source": src}
+    if waves and n_waves != int(waves):
+        # measured for another launch shape (--seqs / --ctxs changed the batch): the count scales with the waves, every wave tracks one keypoint
+        insts = insts * n_waves / waves
+        src += "; scaled from %d to %d waves per launch" % (int(waves), n_waves)
     rate = insts / launch_s
     peak = VALU_ISSUE_PER_CLK_PER_SIMD * N_SIMDS * CLK_HZ
     return {"wave_insts_per_launch": int(insts), "wave_insts_per_wave": round(insts / max(n_waves, 1), 1),

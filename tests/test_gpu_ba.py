@@ -186,3 +186,27 @@ def test_ba_bank_select_equals_individual_uploads():
         assert len(set(its)) > 1                      # the problems really differ in difficulty
         with pytest.raises(Exception):
             c.ba_select(nb)
+
+
+def test_ba_chunked_partial_sets_match_one_chunk_per_workgroup(monkeypatch):
+    """The headline batch (32 x 125 landmark chunks) makes a workgroup of k_ba_build walk up to 4 chunks and ADD their partial sums into
+    one set; a single problem keeps one chunk per workgroup.  VO_BA_CHUNKS forces either form: same LM iteration / acceptance sequence,
+    cost and solution to 1e-12 (the summation order differs, so not bit for bit), also for the last, partly filled workgroup
+    (125 chunks = 31 x 4 + 1), and equal to the oracle."""
+    import ba_oracle as bo
+    from vo_mi355x import VoContext, synthetic as syn
+    s = syn.make_ba_scene(n_pts=2000, n_slots=10, seed=3, visibility=0.9)
+    ref = bo.solve(s["K"], s["poses0"], s["points0"], s["obs"], max_iters=12)
+    out = {}
+    with VoContext(64, 64, max_pts=64) as c:
+        for cpw in (1, 2, 4, 3):
+            monkeypatch.setenv("VO_BA_CHUNKS", str(cpw))
+            out[cpw] = c.ba_adjust(s["K"], s["poses0"], s["points0"], s["obs"], c.ba_params(max_iters=12))
+        monkeypatch.delenv("VO_BA_CHUNKS")
+        out[0] = c.ba_adjust(s["K"], s["poses0"], s["points0"], s["obs"], c.ba_params(max_iters=12))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])          # the rule: one chunk per workgroup for one problem
+    for cpw in (2, 3, 4):
+        po, pt, st = out[cpw]
+        assert st["iters"] == out[1][2]["iters"] == ref["iters"] and st["accepted"] == out[1][2]["accepted"]
+        assert abs(st["cost"] - out[1][2]["cost"]) <= 1e-12 * st["cost"] and abs(st["cost"] - ref["cost"]) <= 1e-7 * ref["cost"]
+        assert np.abs(po - out[1][0]).max() <= 1e-10 and np.abs(pt - out[1][1]).max() <= 1e-9

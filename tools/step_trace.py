@@ -13,4 +13,4 @@ for _ in range(300): g.step()
 g.drain(); g.c.sync()
 import ctypes
 L = ctypes.CDLL(_lib.LIB_PATH)
-L.vo_debug_step_trace_dump()
+L.vo_debug_step_trace_dump(400, 12)

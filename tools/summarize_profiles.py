@@ -20,6 +20,11 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = "gpurun_out"
 with open(os.path.join("visual-odom-pipeline_amd", "csrc", "vo_klt.hip"), "rb") as _f:
     KLT_DIGEST = hashlib.sha256(_f.read()).hexdigest()[:16]       # bench.py refuses these constants for any other kernel source
+_h = hashlib.sha256()
+for _n in ("vo_klt.hip", "vo_frame.hip"):                          # ... and for another frame store (the 4x derivative format the tracker consumes)
+    with open(os.path.join("visual-odom-pipeline_amd", "csrc", _n), "rb") as _f:
+        _h.update(_f.read())
+KLT_FRAME_DIGEST = _h.hexdigest()[:16]
 
 
 def find(pattern):
@@ -69,7 +74,7 @@ if means:
         fe = means["FETCH_SIZE"][k][0] if "FETCH_SIZE" in means else 0.0
         wr = means["WRITE_SIZE"][k][0] if "WRITE_SIZE" in means else 0.0
         json.dump({
-            "kernel": k, "klt_source_sha256_16": KLT_DIGEST, "measured": tag,
+            "kernel": k, "klt_source_sha256_16": KLT_DIGEST, "klt_frame_source_sha256_16": KLT_FRAME_DIGEST, "measured": tag,
             "config": "one k_klt_track launch of a batched context: 32 sequences x 2000 points (bench.py default: 96 sequences in 3 such contexts)",
             "fetch_size_kb_per_launch": 2 * fe,
             "write_size_kb_per_launch": wr,
@@ -111,7 +116,7 @@ if path:
     if klt:
         k = klt[0]
         m = {c: (acc[k][c][0] / acc[k][c][1] if acc[k][c][1] else 0.0) for c in names}
-        json.dump({"kernel": k, "klt_source_sha256_16": KLT_DIGEST, "measured": tag,
+        json.dump({"kernel": k, "klt_source_sha256_16": KLT_DIGEST, "klt_frame_source_sha256_16": KLT_FRAME_DIGEST, "measured": tag,
                    "sq_insts_valu_per_launch": m["SQ_INSTS_VALU"], "sq_waves_per_launch": m["SQ_WAVES"],
                    "sq_active_inst_valu": m["SQ_ACTIVE_INST_VALU"], "sq_wave_cycles": m["SQ_WAVE_CYCLES"],
                    "sq_busy_cycles": m["SQ_BUSY_CYCLES"], "grbm_gui_active": m["GRBM_GUI_ACTIVE"],

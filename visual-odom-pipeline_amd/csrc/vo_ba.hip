@@ -1349,7 +1349,11 @@ static ba_ptrs ba_make_ptrs(const vo_ctx* c) {
   {
     // landmark chunks per workgroup: as many as keep >= 1024 workgroups (4 per CU, what the kernel's registers allow) in the launch,
     // at most 4 -- a batch of 32 problems x 125 chunks -> 32 workgroups per problem; ONE sequence keeps a workgroup per chunk
-    static const int cpw_env = getenv("VO_BA_CHUNKS") ? atoi(getenv("VO_BA_CHUNKS")) : 0;  // experiment knob (0 = the rule)
+    // VO_BA_CHUNKS (read at every solve, so a test can switch it): chunks per workgroup, 0 / unset = the rule.  NB the partial sums of a
+    // workgroup's chunks are added in chunk order, so the last bits of a solution depend on this number -- and through the rule on the
+    // batch size: a batch of 32 problems is not bit-identical to the same problems solved one by one (tests/test_gpu_ba.py pins 1e-12)
+    const char* cpw_s = getenv("VO_BA_CHUNKS");
+    const int cpw_env = cpw_s ? atoi(cpw_s) : 0;
     int cpw = cpw_env > 0 ? cpw_env : (int)(((long long)c->batch * b->nblk + 512) / 1024);
     if (cpw < 1) cpw = 1;
     if (cpw > 4 && cpw_env <= 0) cpw = 4;
@@ -1380,6 +1384,7 @@ extern "C" int32_t vo_ba_upload(vo_ctx* c, const double* K, const double* poses,
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, K && poses && points && obs, VO_E_INVALID, "null buffer");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   if (c->stream3) VO_HIP(c, hipStreamSynchronize(c->stream3));     // a pipelined frame step runs its bundle adjustment there
   if (c->ba && c->ba->bank_n > 0) { VO_HIP(c, hipStreamSynchronize(c->stream)); vo_ba_destroy(c); }      // a plain upload replaces a bank
   int32_t r = ba_alloc(c, n_slots, n_pts);
@@ -1446,6 +1451,7 @@ extern "C" int32_t vo_ba_solve_resident(vo_ctx* c, const vo_ba_params* prm) {
   VO_CHECK(c, c->ba && c->ba->uploaded, VO_E_STATE, "vo_ba_upload first");
   VO_CHECK(c, prm->max_iters >= 0 && prm->max_iters <= 1000, VO_E_INVALID, "bad max_iters");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   const ba_params_dev d = ba_dev_params(prm);
   int32_t r = ba_enqueue_iters(c, d, 0, prm->max_iters);
   if (r != VO_OK) return r;
@@ -1518,6 +1524,7 @@ extern "C" int32_t vo_ba_fetch(vo_ctx* c, double* poses_out, double* points_out,
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->ba && c->ba->uploaded, VO_E_STATE, "nothing to fetch");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   // its own pinned mirror: a frame step still in flight keeps the two halves vo_frame_fetch reads
   int32_t r = vo_ba_enqueue_pub_copy(c, 2);
   if (r != VO_OK) return r;
@@ -1618,6 +1625,7 @@ extern "C" int32_t vo_ba_probe(vo_ctx* c, double lambda, double huber_delta, dou
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->ba && c->ba->uploaded, VO_E_STATE, "vo_ba_upload first");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   vo_ba_ws* b = c->ba;
   const int W = b->W, N = b->N, n = 6 * W;
   vo_ba_params prm;

@@ -185,6 +185,7 @@ extern "C" int32_t vo_triangulate_dlt(vo_ctx* c, const float* P0, const float* P
   VO_CHECK(c, P0 && P1 && uv0 && uv1 && X4, VO_E_INVALID, "null buffer");
   if (K) VO_CHECK(c, H0 && H1 && depth1 && reproj, VO_E_INVALID, "statistics need K, H0, H1, depth1, reproj");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   int32_t r = dlt_set_cams(c, P0, P1, K, H0, H1);
   if (r != VO_OK) return r;
   r = dlt_upload_uv(c, uv0, uv1, n);
@@ -204,6 +205,7 @@ extern "C" int32_t vo_dlt_upload(vo_ctx* c, const float* P0, const float* P1, co
   VO_CHECK(c, P0 && P1 && uv0 && uv1, VO_E_INVALID, "null buffer");
   if (K) VO_CHECK(c, H0 && H1, VO_E_INVALID, "statistics need K, H0, H1");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   int32_t r = dlt_set_cams(c, P0, P1, K, H0, H1);
   if (r != VO_OK) return r;
   r = dlt_upload_uv(c, uv0, uv1, n);
@@ -217,6 +219,7 @@ extern "C" int32_t vo_dlt_resident(vo_ctx* c) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->dlt_n > 0, VO_E_STATE, "vo_dlt_upload first");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   return dlt_launch(c, c->dlt_n);
 }
 
@@ -224,6 +227,7 @@ extern "C" int32_t vo_dlt_fetch(vo_ctx* c, float* X4, double* depth1, double* re
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->dlt_n > 0, VO_E_STATE, "nothing to fetch");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   int32_t r = dlt_download(c, c->dlt_n, X4, depth1, reproj);
   if (r != VO_OK) return r;
   VO_HIP(c, hipStreamSynchronize(c->stream));

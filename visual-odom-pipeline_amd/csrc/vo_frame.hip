@@ -491,6 +491,7 @@ extern "C" int32_t vo_frame_push(vo_ctx* c, const uint8_t* img, int32_t stride) 
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, img != nullptr && stride >= c->width, VO_E_INVALID, "bad image / stride");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   // the batch's images are contiguous: [batch][height] rows of `stride` bytes
   VO_HIP(c, hipMemcpy2DAsync(c->d_raw, c->width, img, stride, c->width, (size_t)c->height * c->batch, hipMemcpyHostToDevice, c->stream));
   int32_t r = vo_build_pyramid(c, c->d_raw, (size_t)c->width * c->height, nullptr);
@@ -519,6 +520,7 @@ extern "C" int32_t vo_frame_push_resident(vo_ctx* c, int32_t idx) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->d_seq != nullptr && idx >= 0 && idx < c->seq_n, VO_E_STATE, "no resident sequence / bad index");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   const size_t fr = (size_t)c->width * c->height;
   return vo_build_pyramid(c, c->d_seq + (size_t)idx * fr, fr * c->seq_n, nullptr);
 }

@@ -61,6 +61,7 @@ struct vo_ctx {
   float bil_sw[49];
   float* d_bil_cw = nullptr;         // [256] colour weights
   int side_stream = 1;               // env VO_SIDE_STREAM=0 keeps the frame step on one stream
+  bool in_step = false;              // inside vo_frame_step_resident: its stage calls must not wait for the side streams (vo_quiesce_side)
   int batch = 1;
   int width = 0, height = 0, max_pts = 0, max_level = 0, win = 0;
   int top = 0;                       // highest pyramid level index built
@@ -186,6 +187,11 @@ double* vo_ba_obs_device(vo_ctx* c, int* n_slots, int* n_pts);   // resident obs
 bool vo_st_ready(const vo_ctx* c);
 int vo_st_last_max_corners(const vo_ctx* c);
 int vo_st_launch_state(const vo_ctx* c);
+int vo_st_flags_save(const vo_ctx* c);
+void vo_st_flags_restore(vo_ctx* c, int saved);
+// the pipelined stream layout (vo_set_side_stream 2) leaves work on streams B and C after a step: every entry point outside the
+// step / fetch pair that touches the result slab, the frame store, the BA / Shi-Tomasi / DLT / PnP workspaces waits for them first
+int32_t vo_quiesce_side(vo_ctx* c);
 int32_t vo_st_prepare(vo_ctx* c, const vo_st_params* prm);
 
 // collectives on the ctx stream (vo_comm.hip); identity / device copy without a communicator

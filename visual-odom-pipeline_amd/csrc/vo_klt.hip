@@ -526,6 +526,7 @@ extern "C" int32_t vo_klt_track(vo_ctx* c, const float* p0, int32_t n, const vo_
   if (n == 0) return VO_OK;
   VO_CHECK(c, p0 && p1 && status && err, VO_E_INVALID, "null buffer");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   const size_t off_in = vo_off_p(c), off_out = vo_off_p_next(c);
   VO_HIP(c, slab_h2d(c, off_in, p0, sizeof(float) * 2 * n));
   int32_t r = klt_launch(c, n, prm, off_in, off_out, nullptr);
@@ -546,6 +547,7 @@ extern "C" int32_t vo_points_upload(vo_ctx* c, const float* p, int32_t n) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, p && n >= 0 && n <= c->max_pts, VO_E_CAPACITY, "bad point set");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   if (n > 0) VO_HIP(c, slab_h2d(c, vo_off_p(c), p, sizeof(float) * 2 * n));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   c->n_resident = n;
@@ -556,6 +558,7 @@ extern "C" int32_t vo_points_download(vo_ctx* c, float* p, uint8_t* status, floa
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, n >= 0 && n <= c->n_resident, VO_E_INVALID, "n exceeds the resident point set");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   if (n > 0) {
     if (p) VO_HIP(c, slab_d2h(c, p, vo_off_p(c), sizeof(float) * 2 * n));
     if (status) VO_HIP(c, slab_d2h(c, status, c->off_status, n));
@@ -576,6 +579,7 @@ extern "C" int32_t vo_klt_track_resident(vo_ctx* c, int32_t n, const vo_klt_para
   if (!prm) { vo_klt_default_params(&def); prm = &def; }
   VO_CHECK(c, n >= 0 && n <= c->n_resident, VO_E_INVALID, "n exceeds the resident point set");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   int32_t r = klt_launch(c, n, prm, vo_off_p(c), vo_off_p_next(c), c->d_pt_counts);   // track table: per-sequence counts
   if (r != VO_OK) return r;
   c->p_parity ^= 1;   // tracked positions become the resident set

@@ -865,6 +865,7 @@ extern "C" int32_t vo_pipe_commit(vo_ctx* c) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->pipe, VO_E_STATE, "vo_pipe_create first");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   vo_pipe_ws* w = c->pipe;
   hipLaunchKernelGGL(k_pipe_dense, dim3(c->batch), dim3(PIPE_TPB), 0, c->stream, pipe_make(w), vo_slab<float>(c, vo_off_p(c)), c->slab_seq, 1);
   pipe_launch_spawn(c, 0);                      // free lists (and a record of the seeded state)
@@ -887,6 +888,7 @@ extern "C" int32_t vo_pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages) {
   vo_pipe_ws* w = c->pipe;
   VO_CHECK(c, w->enq - w->fetched < VO_PIPE_INFLIGHT, VO_E_STATE, "vo_pipe_fetch the oldest step first");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   const vo_pipe_params& prm = w->prm;
   const pipe_ptrs P = pipe_make(w);
   const int B = c->batch;

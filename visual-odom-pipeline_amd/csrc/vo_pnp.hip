@@ -645,6 +645,7 @@ extern "C" int32_t vo_pnp_upload(vo_ctx* c, const double* K, const float* pts3d,
   VO_CHECK(c, K && pts3d && pts2d, VO_E_INVALID, "null buffer");
   VO_CHECK(c, n >= 4, VO_E_INVALID, "at least 4 correspondences");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   int32_t r = pnp_alloc(c, n);
   if (r != VO_OK) return r;
   vo_pnp_ws* w = c->pnp;
@@ -669,6 +670,7 @@ extern "C" int32_t vo_pnp_solve_resident(vo_ctx* c, const vo_pnp_params* prm, in
   VO_CHECK(c, c->pnp && c->pnp->n >= 4, VO_E_STATE, "vo_pnp_upload first");
   VO_CHECK(c, prm->max_iters >= 1 && prm->reproj_err > 0 && blind_batches >= 1 && blind_batches <= 64, VO_E_INVALID, "bad parameters");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   vo_pnp_ws* w = c->pnp;
   hipLaunchKernelGGL(k_pnp_init, dim3((unsigned)c->batch), dim3(1), 0, c->stream, w->d_ctrl, prm->max_iters);
   for (int k = 0; k < blind_batches; k++) pnp_enqueue_batch(c, prm);
@@ -679,6 +681,7 @@ extern "C" int32_t vo_pnp_fetch(vo_ctx* c, double* rvec, double* tvec, uint8_t* 
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->pnp && c->pnp->n >= 4, VO_E_STATE, "nothing to fetch");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   vo_pnp_ws* w = c->pnp;
   const size_t B = c->batch;
   if (inlier_mask) VO_HIP(c, hipMemcpy2DAsync(inlier_mask, w->n, w->d_mask, w->cap, w->n, B, hipMemcpyDeviceToHost, c->stream));

@@ -977,6 +977,10 @@ static void circle_rows(int radius, disc_rows* rows) {
 
 bool vo_st_ready(const vo_ctx* c) { return c->st != nullptr; }
 int vo_st_last_max_corners(const vo_ctx* c) { return c->st ? c->st->last_max_corners : 0; }
+// host-side flags a launch sets at ENQUEUE time (also under stream capture): a capture that fails must put them back, or the next
+// resident launch skips k_st_mask_init on a mask that still holds the previous frame's discs
+int vo_st_flags_save(const vo_ctx* c) { return c->st ? (c->st->mask_clean ? 1 : 0) | (c->st->eig_valid ? 2 : 0) : -1; }
+void vo_st_flags_restore(vo_ctx* c, int saved) { if (c->st && saved >= 0) { c->st->mask_clean = (saved & 1) != 0; c->st->eig_valid = (saved & 2) != 0; } }
 int vo_st_launch_state(const vo_ctx* c) { return c->st ? (c->st->mask_clean ? 1 : 0) | (c->st->keep_default ? 2 : 0) : 0; }   // decides which kernels a resident launch enqueues
 // all allocations a launch with these parameters needs (called outside any graph capture)
 int32_t vo_st_prepare(vo_ctx* c, const vo_st_params* prm) {
@@ -1102,6 +1106,7 @@ extern "C" int32_t vo_shi_tomasi(vo_ctx* c, const float* cur_pts, int32_t n_cur,
   VO_CHECK(c, out_pts && n_out, VO_E_INVALID, "null output");
   VO_CHECK(c, n_cur >= 0 && n_cur <= c->max_pts && (n_cur == 0 || cur_pts), VO_E_CAPACITY, "bad cur_pts");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   int32_t r = st_init(c);
   if (r != VO_OK) return r;
   vo_st_ws* s = c->st;
@@ -1121,6 +1126,7 @@ extern "C" int32_t vo_shi_tomasi_resident(vo_ctx* c, int32_t n_cur, int32_t mask
   if (!prm) { vo_st_default_params(&def); prm = &def; }
   VO_CHECK(c, n_cur >= 0 && n_cur <= c->n_resident, VO_E_INVALID, "n_cur exceeds the resident point set");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   int32_t r = st_init(c);
   if (r != VO_OK) return r;
   return st_launch(c, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq, n_cur, mask_radius, nullptr, prm, c->d_pt_counts,

@@ -10,13 +10,25 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 #include <stdio.h>
-static std::vector<hipEvent_t> g_tr;      // VO_STEP_TRACE: (start, end) of the bundle adjustment of every pipelined step on stream C
-static std::vector<hipEvent_t> g_ta;      // ... and (start, end) of the front end (pyramid, KLT, copy) on stream A
-static std::vector<hipEvent_t> g_tb;      // ... (after the pyramid, after the KLT)
-extern "C" void vo_debug_step_trace_dump() {
-  for (size_t i = 400; i + 3 < g_tr.size() && i + 3 < g_ta.size() && i < 424; i += 2) {
+// VO_STEP_TRACE=1 (debug): in-stream event stamps of the pipelined layout -- (start, end) of every bundle adjustment on stream C,
+// (start, end) and (after the pyramid, after the KLT) of the front end on stream A.  One trace per process, filled under a mutex
+// (several host threads step their own contexts); vo_debug_step_trace_dump(first, count) prints a window of it and frees the events.
+static std::mutex g_trace_mu;
+static std::vector<hipEvent_t> g_tr, g_ta, g_tb;
+static void trace_push(std::vector<hipEvent_t>& v, hipStream_t st, size_t cap) {
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  if (v.size() >= cap) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, st);
+  v.push_back(e);
+}
+extern "C" void vo_debug_step_trace_dump(int first_step, int n_steps) {
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  for (size_t i = 2 * (size_t)(first_step < 0 ? 0 : first_step); i + 3 < g_tr.size() && i + 3 < g_ta.size() && i + 3 < g_tb.size() && i < 2 * (size_t)(first_step + n_steps); i += 2) {
     float d = 0, gap = 0, a0 = 0, a1 = 0;
     (void)hipEventElapsedTime(&d, g_tr[i], g_tr[i + 1]);
     (void)hipEventElapsedTime(&gap, g_tr[i + 1], g_tr[i + 2]);
@@ -28,6 +40,14 @@ extern "C" void vo_debug_step_trace_dump() {
     fprintf(stderr, "step %zu: BA %.1f us, idle until the next BA starts %.1f us; next front end: start %.1f, pyramid done %.1f, KLT done %.1f, copy done %.1f us after this BA started\n",
             i / 2, d * 1e3, gap * 1e3, a0 * 1e3, b0 * 1e3, b1 * 1e3, a1 * 1e3);
   }
+  for (std::vector<hipEvent_t>* v : {&g_tr, &g_ta, &g_tb}) { for (hipEvent_t e : *v) (void)hipEventDestroy(e); v->clear(); }
+}
+
+int32_t vo_quiesce_side(vo_ctx* c) {
+  if (c->side_stream != 2 || c->in_step) return VO_OK;      // layouts 0 / 1 join their side stream inside the step
+  if (c->stream2) VO_HIP(c, hipStreamSynchronize(c->stream2));
+  if (c->stream3) VO_HIP(c, hipStreamSynchronize(c->stream3));
+  return VO_OK;
 }
 
 struct step_cfg {
@@ -42,15 +62,15 @@ static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame
   int32_t r;
   *recorded = false;
   static const bool trace_a = getenv("VO_STEP_TRACE") != nullptr;
-  if (trace_a && c->side_stream == 2 && g_ta.size() < 4000) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); g_ta.push_back(e); }
+  if (trace_a && c->side_stream == 2) trace_push(g_ta, c->stream, 4000);
   const size_t fr = (size_t)c->width * c->height;
   if (d_frame_idx) r = vo_build_pyramid(c, c->d_seq, fr * c->seq_n, d_frame_idx);
   else r = vo_build_pyramid(c, c->d_seq + (size_t)frame_idx * fr, fr * c->seq_n, nullptr);
   if (r != VO_OK) return r;
-  if (trace_a && c->side_stream == 2 && g_tb.size() < 6000) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); g_tb.push_back(e); }
+  if (trace_a && c->side_stream == 2) trace_push(g_tb, c->stream, 6000);
   r = vo_klt_track_resident(c, s.n_pts, &s.klt);
   if (r != VO_OK) return r;
-  if (trace_a && c->side_stream == 2 && g_tb.size() < 6000) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); g_tb.push_back(e); }
+  if (trace_a && c->side_stream == 2) trace_push(g_tb, c->stream, 6000);
   uint8_t* const h_dst = c->h_slab + (size_t)half * c->slab_bytes;
   if (c->side_stream == 2 && s.do_ba && !d_frame_idx) {
     // ---- pipelined layout: three in-order streams.  A (c->stream): pyramid, KLT and the copy of the KLT results -- then it is free
@@ -69,18 +89,18 @@ static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame
     if (c->batch == 1) VO_HIP(c, hipMemcpyAsync(h_dst, c->d_slab, part1, hipMemcpyDeviceToHost, c->stream));
     else VO_HIP(c, hipMemcpy2DAsync(h_dst, c->slab_seq, c->d_slab, c->slab_seq, part1, c->batch, hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipEventRecord(c->ev_copy1[half], c->stream));
-    if (trace_a && g_ta.size() < 4000) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); g_ta.push_back(e); }
+    if (trace_a) trace_push(g_ta, c->stream, 4000);
     hipStream_t main_stream = c->stream;
     c->stream = c->stream3;
     static const bool trace = getenv("VO_STEP_TRACE") != nullptr;      // debug: GPU-side timeline of stream C, printed by vo_debug_step_trace_dump
-    if (trace && g_tr.size() < 4000) { hipEvent_t e0; (void)hipEventCreate(&e0); (void)hipEventRecord(e0, c->stream3); g_tr.push_back(e0); }
+    if (trace) trace_push(g_tr, c->stream3, 4000);
     // C carries nothing but the LM iterations and k_ba_finalize: the copy of the solution goes to B (behind ev_ba), so that the next
     // frame's iterations follow this frame's directly; k_ba_finalize of the next step waits for that copy (ev_pub) -- long done by then
     c->ba_wait_before_publish = c->pub_copy_pending ? c->ev_pub[half ^ 1] : nullptr;
     r = vo_ba_solve_resident(c, &s.ba);
     c->ba_wait_before_publish = nullptr;
     hipError_t e = hipEventRecord(c->ev_ba[half], c->stream3);
-    if (trace && g_tr.size() < 4000) { hipEvent_t e1; (void)hipEventCreate(&e1); (void)hipEventRecord(e1, c->stream3); g_tr.push_back(e1); }
+    if (trace) trace_push(g_tr, c->stream3, 4000);
     c->stream = c->stream2;
     if (r == VO_OK && s.do_st) r = vo_shi_tomasi_resident(c, s.n_pts, s.mask_radius, &s.st);
     if (r == VO_OK && s.do_dlt) r = vo_dlt_resident(c);
@@ -182,7 +202,9 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
   const bool graph_ok = c->use_graph && c->prof.mask == 0 && c->n_pushed >= 2;
   if (!graph_ok) {
     bool recorded = false;
+    c->in_step = true;
     const int32_t r = step_enqueue(c, s, nullptr, frame_idx, half, &recorded);
+    c->in_step = false;
     if (r != VO_OK) return r;
     if (!recorded) VO_HIP(c, hipEventRecord(c->ev_step[half], c->stream));
     c->steps_enq++;
@@ -195,21 +217,23 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
     // (re)capture: the enqueue functions advance the host-side state exactly as a direct call would
     if (c->step_graph[parity]) { (void)hipGraphExecDestroy(c->step_graph[parity]); c->step_graph[parity] = nullptr; }
     hipGraph_t g = nullptr;
-    const int cur0 = c->cur, pushed0 = c->n_pushed, parity0 = c->p_parity;
+    const int cur0 = c->cur, pushed0 = c->n_pushed, parity0 = c->p_parity, st0 = vo_st_flags_save(c);
     VO_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     bool recorded = false;
+    c->in_step = true;
     const int32_t r = step_enqueue(c, s, c->d_frame_idx, frame_idx, 0, &recorded);
+    c->in_step = false;
     const hipError_t e = hipStreamEndCapture(c->stream, &g);
     if (r != VO_OK || e != hipSuccess) {
       // nothing was launched: undo what the enqueue functions did to the host-side frame / point parities
-      c->cur = cur0; c->n_pushed = pushed0; c->p_parity = parity0;
+      c->cur = cur0; c->n_pushed = pushed0; c->p_parity = parity0; vo_st_flags_restore(c, st0);
       if (g) (void)hipGraphDestroy(g);
       if (r != VO_OK) return r;
     }
     VO_HIP(c, e);
     const hipError_t ei = hipGraphInstantiate(&c->step_graph[parity], g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
-    if (ei != hipSuccess) { c->cur = cur0; c->n_pushed = pushed0; c->p_parity = parity0; c->step_graph[parity] = nullptr; }
+    if (ei != hipSuccess) { c->cur = cur0; c->n_pushed = pushed0; c->p_parity = parity0; vo_st_flags_restore(c, st0); c->step_graph[parity] = nullptr; }
     VO_HIP(c, ei);
     c->step_sig[parity] = sig;
   } else {

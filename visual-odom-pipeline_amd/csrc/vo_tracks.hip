@@ -206,6 +206,7 @@ extern "C" int32_t vo_tracks_seed(vo_ctx* c, const float* pts, int32_t n, int32_
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, n >= 0 && n <= c->max_pts && (n == 0 || pts), VO_E_CAPACITY, "bad point set");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   int32_t r = trk_init(c);
   if (r != VO_OK) return r;
   r = vo_points_upload(c, pts, n);
@@ -223,6 +224,7 @@ extern "C" int32_t vo_tracks_seed(vo_ctx* c, const float* pts, int32_t n, int32_
 // KLT prev -> cur of every live track (the frame store must hold both frames), then the reference's pruning and bookkeeping
 extern "C" int32_t vo_tracks_track(vo_ctx* c, int32_t t, const vo_klt_params* prm) {
   if (!c) return VO_E_INVALID;
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   VO_CHECK(c, c->trk && c->d_pt_counts, VO_E_STATE, "vo_tracks_seed first");
   vo_trk_ws* tw = c->trk;
   if (tw->n_hi > 0) {
@@ -239,6 +241,7 @@ extern "C" int32_t vo_tracks_track(vo_ctx* c, int32_t t, const vo_klt_params* pr
 // sequence are appended as new tracks born at frame t
 extern "C" int32_t vo_tracks_detect(vo_ctx* c, int32_t t, int32_t mask_radius, const vo_st_params* st, int32_t max_new) {
   if (!c) return VO_E_INVALID;
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   VO_CHECK(c, c->trk && c->d_pt_counts, VO_E_STATE, "vo_tracks_seed first");
   vo_trk_ws* tw = c->trk;
   vo_st_params def;
@@ -263,6 +266,7 @@ extern "C" int32_t vo_tracks_read(vo_ctx* c, int32_t* n, float* uv, float* uv_fi
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->trk, VO_E_STATE, "vo_tracks_seed first");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   vo_trk_ws* tw = c->trk;
   const size_t B = c->batch, cap = tw->cap;
   VO_HIP(c, hipStreamSynchronize(c->stream));
@@ -290,6 +294,7 @@ extern "C" int32_t vo_tracks_obs(vo_ctx* c, int32_t t_now, int32_t window, doubl
   VO_CHECK(c, c->trk, VO_E_STATE, "vo_tracks_seed first");
   VO_CHECK(c, obs && window >= 1 && window <= VO_TRK_HIST, VO_E_INVALID, "window must be 1..32");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   vo_trk_ws* tw = c->trk;
   const size_t total = (size_t)c->batch * window * tw->cap * 2;
   if (tw->obs_cap < total) {
@@ -315,6 +320,7 @@ extern "C" int32_t vo_ba_obs_from_tracks(vo_ctx* c, int32_t t_now) {
   VO_CHECK(c, d_obs, VO_E_STATE, "vo_ba_upload first");
   VO_CHECK(c, N == c->trk->cap && W <= VO_TRK_HIST, VO_E_INVALID, "the resident BA problem must have max_pts landmarks and <= 32 slots");
   VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   hipLaunchKernelGGL(k_trk_obs, dim3(vo_div_up(N, 256), W, c->batch), dim3(256), 0, c->stream, trk_make(c->trk), t_now, W, d_obs);
   VO_HIP(c, hipGetLastError());
   return VO_OK;
