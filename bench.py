@@ -58,6 +58,10 @@ def parse():
     ap.add_argument("--pipe-window", type=int, default=4, help="--workload pipeline: BA window (the reference's own setting is 4, pipeline.py:19; BASELINE's 10)")
     ap.add_argument("--pipe-no-resurrect", action="store_true", help="--workload pipeline: dead landmarks stay dead (the reference appends the recently dead "
                                                                      "to the state's lists again in every adjust, bundle_adjuster.py:142-150)")
+    ap.add_argument("--pipe-adaptive-budget", action="store_true",
+                    help="--workload pipeline: enqueue only (newest fetched frame's maximum + 2) LM iterations per frame instead of --ba-iters "
+                         "(+5 %%; a solve the budget cuts cannot be continued in a closed loop -- the next frame already depends on it -- so the default "
+                         "enqueues the LM's full --ba-iters, whose surplus groups exit early)")
     ap.add_argument("--pipe-max-pts", type=int, default=2048, help="--workload pipeline: capacity of the tracked keypoint set per sequence (<= 4096)")
     ap.add_argument("--pipe-frames", type=int, default=40, help="--workload pipeline: rendered frames per scene (= the period of the camera's sway; played in a loop)")
     ap.add_argument("--graph", action="store_true", help="replay each frame from a captured hipGraph instead of plain launches")
@@ -376,7 +380,7 @@ def run_pipeline(device, a, dist, n_ctx, per_ctx, steps, warmup, regions, scenes
     if scenes is None:
         scenes = pipe_scenes(2, a.pipe_frames, 4321 + 16 * dist.rank)
     boot = VoContext(W_IMG, H_IMG, max_pts=4096, device=device)
-    groups = [PipeGroup(device, scenes, boot, i * per_ctx, per_ctx, a.ba_iters, max_pts, a.fixed_ba_budget, a.pipe_window, not a.pipe_no_resurrect) for i in range(n_ctx)]
+    groups = [PipeGroup(device, scenes, boot, i * per_ctx, per_ctx, a.ba_iters, max_pts, not a.pipe_adaptive_budget, a.pipe_window, not a.pipe_no_resurrect) for i in range(n_ctx)]
     boot.close()
     t_setup = time.perf_counter() - t0
     pool = None
@@ -428,7 +432,7 @@ def run_pipeline(device, a, dist, n_ctx, per_ctx, steps, warmup, regions, scenes
     out = {"frames_per_s": round(n_seq * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "sequences": n_seq, "contexts": n_ctx,
            "steps": steps, "regions_ms_per_step": [round(x / steps * 1e3, 4) for x in region_dt],
            "sequences_alive_at_end": alive, "frames_in_sequence": scenes[0]["frames"].shape[0], "max_tracked_keypoints": max_pts,
-           "ba_window": a.pipe_window, "resurrection_of_dead_landmarks": not a.pipe_no_resurrect, "ba_lm_iteration_cap": a.ba_iters, "ba_budget": "fixed" if a.fixed_ba_budget else "adaptive (newest fetched frame's maximum + 2)",
+           "ba_window": a.pipe_window, "resurrection_of_dead_landmarks": not a.pipe_no_resurrect, "ba_lm_iteration_cap": a.ba_iters, "ba_budget": "adaptive (newest fetched frame's maximum + 2)" if a.pipe_adaptive_budget else "the LM's full --ba-iters every frame (surplus groups exit early)",
            "mean_tracked_keypoints": mean("n_tracked"), "mean_landmark_entries": mean("n_landmarks"), "mean_candidates": mean("n_candidates"),
            "mean_pnp_inliers": mean("pnp_inliers"), "mean_new_landmarks": mean("n_new"), "mean_resurrected": mean("n_resurrected"),
            "mean_detected": mean("n_detected"), "mean_ba_observations": mean("ba_observations"),
@@ -444,6 +448,76 @@ def run_pipeline(device, a, dist, n_ctx, per_ctx, steps, warmup, regions, scenes
         g.c.close()
     if pool is not None:
         pool.shutdown()
+    return out
+
+
+
+def dropin_step_ms(device, scene, ba_window=4, n_warm=4, n_time=8):
+    """What a user of the reference's own interface gets: Pipeline.step (pipeline.py:92-167) driven from Python over the drop-in
+    Extractor / BundleAdjuster classes -- lists of Keypoint / Landmark objects in and out of every call, synchronous, host buffers --
+    on ONE sequence of the closed-loop scene; beside it the same sequence through the device-resident tables (ResidentPipeline, one
+    enqueue per frame).  -> dict"""
+    import copy
+    from vo_mi355x import BundleAdjuster, Extractor, VoContext, synthetic as syn
+    from vo_mi355x.resident import ResidentPipeline
+    frames, K = scene["frames"], scene["K"]
+    out = {}
+    with VoContext(W_IMG, H_IMG, max_pts=4096, device=device) as c:
+        state, _ = syn.gt_bootstrap(c, scene, 0, PIPE_T1)
+        st = copy.deepcopy(state)
+        ex = Extractor(min_kp_dist=7, ctx=c)
+        ba = BundleAdjuster(verbosity=0, window_size=ba_window, method='trf', xtol=1e-3, ftol=1e-3, ctx=c, max_iters=10)
+        ex._im_prev = frames[PIPE_T1]
+        dead, dead_kp, t_step = [], [], 1
+        times = []
+        for s in range(n_warm + n_time):
+            im = frames[(PIPE_T1 + 1 + s) % len(frames)]
+            t0 = time.perf_counter()
+            t_step += 1
+            st._candidates_kp = ex.extend_tracks(im, st._candidates_kp, max_bidir_error=np.inf)
+            st._landmarks, st._landmarks_kp, ld, lkd = ex.extend_landmarks(im, st._landmarks, st._landmarks_kp, max_bidir_error=np.inf)
+            dead += copy.deepcopy(ld); dead_kp += copy.deepcopy(lkd)
+            ex._im_prev = im.copy()
+            inl, Hk = ex.camera_pose(K, st._landmarks, st._landmarks_kp, corr='3D-2D', max_err_reproj=2.0)
+            keep = set(inl)
+            lms, lkp = [], []
+            for i in range(len(st._landmarks)):
+                if i in keep:
+                    lms.append(st._landmarks[i]); lkp.append(st._landmarks_kp[i])
+                else:
+                    dead.append(copy.deepcopy(st._landmarks[i])); dead_kp.append(copy.deepcopy(st._landmarks_kp[i]))
+            st._landmarks, st._landmarks_kp = lms, lkp
+            st._trajectory.append(t_step, Hk)
+            l_new, lk_new, st._candidates_kp = ex.triangulate_tracks(K, st._candidates_kp, st._trajectory, t_curr=t_step, min_track_length=3,
+                                                                     min_bearing_angle=0.5, max_err_reproj=2.0, refine=True)
+            st._landmarks_kp += lk_new; st._landmarks += l_new
+            st, dead, dead_kp = ba.adjust(st, dead, dead_kp, K, t_step)
+            st._candidates_kp += ex.extract(im, t_step, st._landmarks_kp + st._candidates_kp, detector='shi-tomasi', mask_radius=7, describe=False)
+            times.append(time.perf_counter() - t0)
+        out["python_objects_ms_per_step"] = round(float(np.median(times[n_warm:])) * 1e3, 3)
+        out["python_objects_frames_per_s"] = round(1.0 / float(np.median(times[n_warm:])), 1)
+        out["landmarks"], out["candidates"] = len(st._landmarks), len(st._candidates_kp)
+        # the same sequence, state in device tables
+        c.upload_sequence(frames)
+        rp = ResidentPipeline(c, K, ba_window=ba_window, ba_max_iters=10, pnp_blind_batches=2)
+        rp.seed(state, [], [], 1)
+        c.push_frame_resident(PIPE_T1)
+        f = PIPE_T1 + 1
+        for _ in range(6):
+            rp.step(f % len(frames)); f += 1
+            rp.fetch()
+        n = 60
+        t0 = time.perf_counter()
+        for k in range(n):
+            rp.step(f % len(frames)); f += 1
+            if k >= 2:
+                rp.fetch()
+        rp.fetch(); rp.fetch()
+        dt = time.perf_counter() - t0
+        out["resident_tables_ms_per_step"] = round(dt / n * 1e3, 4)
+        out["resident_tables_frames_per_s"] = round(n / dt, 1)
+    out["what"] = ("ONE 1241x376 sequence, window %d: Pipeline.step over the drop-in classes (Python lists of objects, host buffers, synchronous) "
+                   "vs the same step resident in device tables (vo_pipe_step, 3 steps in flight)" % ba_window)
     return out
 
 
@@ -630,8 +704,15 @@ def measure_extras(device, frame_sets, a, dist):
     scenes = pipe_scenes(2, a.pipe_frames, 4321)
     a4 = _copy.copy(a); a4.pipe_window, a4.pipe_no_resurrect = 4, False
     a10 = _copy.copy(a); a10.pipe_window, a10.pipe_no_resurrect = 10, True
-    out["pipeline_step"] = {"reference_configuration_window4": run_pipeline(device, a4, dist, 3, 32, 40, 10, 3, scenes),
-                            "window10_dead_stay_dead": run_pipeline(device, a10, dist, 3, 32, 40, 10, 3, scenes)}
+    try:
+        out["pipeline_step"] = {"reference_configuration_window4": run_pipeline(device, a4, dist, 3, 32, 40, 10, 3, scenes),
+                                "window10_dead_stay_dead": run_pipeline(device, a10, dist, 3, 32, 40, 10, 3, scenes)}
+    except Exception as e:      # noqa: BLE001  (an informational key must not cost the others)
+        out["pipeline_step"] = {"error": str(e)}
+    try:
+        out["dropin_step"] = dropin_step_ms(device, scenes[0])
+    except Exception as e:      # noqa: BLE001
+        out["dropin_step"] = {"error": str(e)}
     return out
 
 
