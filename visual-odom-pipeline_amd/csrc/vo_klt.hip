@@ -437,6 +437,247 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
   }
 }
 
+// ================================================================================================
+// k_klt_track2: TWO keypoints per wave (experiment, VO_KLT_PAIR=1).  Of the ~150 vector instructions of an LK iteration ~62 are the same
+// for every lane (weights, solve, tests, the cross-lane sums' tails): one wave per keypoint pays them per keypoint.  Here the two halves of
+// a wave own one keypoint each -- lane = h * 32 + r * 16 + cp, a lane covers window rows 16 r + s (s = 0..15), columns 2 cp and 2 cp + 1 --
+// so the per-pixel work per keypoint is unchanged (twice the steps on half the lanes) and the lane-uniform work is issued once per PAIR.
+// The price: both halves stay in a level's loop for max(it_a, it_b) iterations (tools/klt_pairing_study.py: +8 % iterations for neighbours
+// in the point list, -11.5 % instructions per keypoint net), the window origin is per half, so it rides in the per-lane offset instead of a
+// scalar register, and the template needs 48 registers.  Same integer sums, same float expressions: bit-identical results.
+// ================================================================================================
+__device__ __forceinline__ uint32_t row_next2(uint32_t v, int lane) {       // the lane 16 further up INSIDE the half
+  return (uint32_t)__builtin_amdgcn_ds_bpermute(((lane & 32) | ((lane + 16) & 31)) << 2, (int)v);
+}
+// sum over the two 16-lane rows of a half, lane class (lane & 3) preserved; every lane of the half receives its class's total
+__device__ __forceinline__ int klt_half_sum(int z) {
+  z += klt_dpp<0x124>(z);                                       // row_ror:4
+  z += klt_dpp<0x128>(z);                                       // row_ror:8
+  const auto r = __builtin_amdgcn_permlane16_swap((unsigned)z, (unsigned)z, false, false);
+  return (int)r[0] + (int)r[1];                                 // rows 0 + 1 and rows 2 + 3: the halves
+}
+template <int K> __device__ __forceinline__ int klt_class(int z) {          // value of lane class K of the quad in all four lanes
+  return __builtin_amdgcn_update_dpp(0, z, K * 0x55 /* quad_perm [K, K, K, K] */, 0xf, 0xf, true);
+}
+
+template <int WAVES>
+__global__ void __launch_bounds__(64, WAVES) k_klt_track2(klt_args A, const float* __restrict__ p0, float* __restrict__ p1,
+                                                   uint8_t* __restrict__ status, float* __restrict__ err,
+                                                   int32_t* __restrict__ iters, const int32_t* __restrict__ counts) {
+  const int npair = (A.n + 1) >> 1;
+  int pr = blockIdx.x, bseq = blockIdx.y;
+  if (A.xcd_remap) {
+    const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned q = id >> 3;
+    bseq = (int)(id & 7u) + 8 * (int)(q / (unsigned)npair);
+    pr = (int)(q % (unsigned)npair);
+  }
+  if (pr >= npair) return;
+  const int lane = threadIdx.x, hsel = lane >> 5, l32 = lane & 31;
+  const int pt = 2 * pr + hsel;
+  if (iters) iters += (size_t)bseq * A.iters_seq;
+  const int nlive = counts ? min(counts[bseq], A.n) : A.n;
+  const bool exists = pt < A.n, dead = pt >= nlive;
+  if (iters && exists && l32 < A.iters_stride && (dead || l32 > A.top)) iters[pt * A.iters_stride + l32] = -1;
+  if (2 * pr >= nlive) return;                          // both slots dead (wave-uniform)
+  p0 = vo_seq(p0, A.slab_seq, bseq); p1 = vo_seq(p1, A.slab_seq, bseq);
+  status = vo_seq(status, A.slab_seq, bseq); err = vo_seq(err, A.slab_seq, bseq);
+  const int cp = lane & 15, r = (lane >> 4) & 1;
+  const int win = A.win;
+  const float half = (float)(win - 1) * 0.5f;
+  const float FLT_SCALE = 1.f / (float)(1 << 20);
+  const int ptc = dead ? 2 * pr : pt;                   // a dead half reads its partner's point (never written back)
+  const float p0x = p0[2 * ptc], p0y = p0[2 * ptc + 1];
+  float outx = 0.f, outy = 0.f;
+  int st = 1;
+  float errv = 0.f;
+  const uint32_t colmask = ((2 * cp < win) ? 0x0000FFFFu : 0u) | ((2 * cp + 1 < win) ? 0xFFFF0000u : 0u);
+  const uint32_t colones = colmask & 0x00010001u;
+  const uint32_t colsel = (0x07060302u & colmask) | (0x0c0c0c0cu & ~colmask);
+
+  for (int level = A.top; level >= 0; level--) {
+    klt_level_args L = A.lv[level];
+    L.imgI += (size_t)bseq * L.seq_px; L.derI += (size_t)bseq * L.seq_px; L.imgJ += (size_t)bseq * L.seq_px;
+    const float scale = __int_as_float((127 - level) << 23);
+    float prevx = p0x * scale, prevy = p0y * scale;
+    float nextx, nexty;
+    if (level == A.top) { nextx = prevx; nexty = prevy; }
+    else { nextx = outx * 2.f; nexty = outy * 2.f; }
+    outx = nextx; outy = nexty;
+    int n_it = -1;
+    prevx -= half; prevy -= half;
+    const float fpx = floorf(prevx), fpy = floorf(prevy);
+    const int ipx = (int)fpx, ipy = (int)fpy;
+    bool ok = !dead && !(ipx < -win || ipx >= L.w || ipy < -win || ipy >= L.h);
+    if (!ok && !dead && level == 0) { st = 0; errv = 0.f; }
+    const uint32_t lane_off = (uint32_t)(16 * r * L.pitch + 2 * cp);
+    uint32_t tI[16], tX[16], tY[16];
+    float A11 = 0.f, A12 = 0.f, A22 = 0.f, D = 0.f;
+    if (ok) {
+      uint32_t wt, wb;
+      lk_weights(prevx - fpx, prevy - fpy, wt, wb);
+      const uint32_t vo = lane_off + (uint32_t)(ipy + VO_PAD) * (uint32_t)L.pitch + (uint32_t)(ipx + VO_PAD);      // per lane: the half's origin
+      const __amdgpu_buffer_rsrc_t rI = klt_rsrc(L.imgI), rD = klt_rsrc(L.derI);
+      int a11 = 0, a12 = 0, a22 = 0;
+      uint32_t T0 = 0; u32x3 d0 = {0, 0, 0};           // row 0 of the lane (its row-group neighbour needs it as the bottom row of step 15)
+      uint32_t Tc = 0; u32x3 dc = {0, 0, 0};           // the row the next batch starts from
+      // four batches of 4 steps: 5 (4) rows of loads in flight, then their arithmetic (all 17 rows at once would need 68 registers; the
+      // template's 48 stay live for the whole level)
+#pragma unroll
+      for (int bt = 0; bt < 4; bt++) {
+        uint32_t T[5]; u32x3 Dv[5];
+        if (bt == 0) {
+          T[0] = __builtin_amdgcn_raw_buffer_load_b32(rI, (int)vo, 0, 0);
+          Dv[0] = __builtin_amdgcn_raw_buffer_load_b96(rD, (int)(vo * 4u), 0, 0);
+          T0 = T[0]; d0 = Dv[0];
+        } else { T[0] = Tc; Dv[0] = dc; }
+#pragma unroll
+        for (int k = 1; k < 5; k++) {
+          const int row = 4 * bt + k;
+          if (row < 16) {
+            const uint32_t o = (uint32_t)row * (uint32_t)L.pitch;         // wave-uniform row advance (scalar)
+            T[k] = __builtin_amdgcn_raw_buffer_load_b32(rI, (int)vo, (int)o, 0);
+            Dv[k] = __builtin_amdgcn_raw_buffer_load_b96(rD, (int)(vo * 4u), (int)(o * 4u), 0);
+          } else {
+            T[k] = row_next2(T0, lane);
+            Dv[k][0] = row_next2(d0[0], lane); Dv[k][1] = row_next2(d0[1], lane); Dv[k][2] = row_next2(d0[2], lane);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int s2 = 4 * bt + k;
+          tI[s2] = sample2(T[k], T[k + 1], wt, wb);
+          const uint32_t x0 = deriv1(pack_lo(Dv[k][0], Dv[k][1]), pack_lo(Dv[k + 1][0], Dv[k + 1][1]), wt, wb);
+          const uint32_t y0 = deriv1(pack_hi(Dv[k][0], Dv[k][1]), pack_hi(Dv[k + 1][0], Dv[k + 1][1]), wt, wb);
+          const uint32_t x1 = deriv1(pack_lo(Dv[k][1], Dv[k][2]), pack_lo(Dv[k + 1][1], Dv[k + 1][2]), wt, wb);
+          const uint32_t y1 = deriv1(pack_hi(Dv[k][1], Dv[k][2]), pack_hi(Dv[k + 1][1], Dv[k + 1][2]), wt, wb);
+          const uint32_t sel = (16 * r + s2 < win) ? colsel : 0x0c0c0c0cu;
+          const uint32_t xp = __builtin_amdgcn_perm(x1, x0, sel), yp = __builtin_amdgcn_perm(y1, y0, sel);
+          tX[s2] = xp; tY[s2] = yp;
+          a11 = s2 ? dot2(xp, xp, a11) : dot2k(xp, xp, 0);
+          a12 = s2 ? dot2(xp, yp, a12) : dot2k(xp, yp, 0);
+          a22 = s2 ? dot2(yp, yp, a22) : dot2k(yp, yp, 0);
+        }
+        Tc = T[4]; dc = Dv[4];
+      }
+      {
+        // per lane 32 products of two int16 derivatives (|Scharr| <= 4080): a quad's sum <= 4 * 32 * 4080^2 < 2^31, so the pair and quad
+        // stages run on the full values (reduce-scatter), only the quad sums are split into 16-bit halves for the two rows of the half
+        const bool odd = lane & 1, up = lane & 2;
+        const int x = (odd ? a12 : a11) + klt_dpp<0xB1>(odd ? a11 : a12);     // pairs: even lanes a11, odd lanes a12
+        const int y = a22 + klt_dpp<0xB1>(a22);                               // pairs of a22 in every lane
+        const int z = (up ? y : x) + klt_dpp<0x4E>(up ? x : y);               // quads: lane & 3 = 0: a11, 1: a12, 2 and 3: a22
+        const int w0 = klt_half_sum(((lane & 3) == 3) ? (z >> 16) : (z & 0xFFFF));   // lo a11, lo a12, lo a22, hi a22
+        const int w1 = klt_half_sum(z >> 16);                                        // hi a11, hi a12
+        A11 = klt_combine(klt_class<0>(w1), klt_class<0>(w0)) * FLT_SCALE;
+        A12 = klt_combine(klt_class<1>(w1), klt_class<1>(w0)) * FLT_SCALE;
+        A22 = klt_combine(klt_class<3>(w0), klt_class<2>(w0)) * FLT_SCALE;
+      }
+      D = A11 * A22 - A12 * A12;
+      const float num = A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12);
+      if (num < A.min_eig_num || D < 1.1920929e-07f) {
+        if (level == 0) st = 0;
+        ok = false;
+      }
+      D = 1.f / D;
+    }
+    nextx -= half; nexty -= half;
+    const __amdgpu_buffer_rsrc_t rJ = klt_rsrc(L.imgJ);
+    float pdx = 0.f, pdy = 0.f;
+    int j = 0;
+    bool act = ok && A.max_count > 0;
+    if (ok) n_it = 0;
+    while (__any(act)) {
+      if (act) {
+        const float fnx = floorf(nextx), fny = floorf(nexty);
+        const int inx = (int)fnx, iny = (int)fny;
+        if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) {
+          if (level == 0) st = 0;
+          act = false;
+        } else {
+          uint32_t jt, jb;
+          lk_weights(nextx - fnx, nexty - fny, jt, jb);
+          const uint32_t vj = lane_off + (uint32_t)(iny + VO_PAD) * (uint32_t)L.pitch + (uint32_t)(inx + VO_PAD);
+          uint32_t Tj[16];
+#pragma unroll
+          for (int s = 0; s < 16; s++) Tj[s] = __builtin_amdgcn_raw_buffer_load_b32(rJ, (int)vj, (int)((uint32_t)s * (uint32_t)L.pitch), 0);
+          const uint32_t Tj16 = row_next2(Tj[0], lane);
+          int b1 = 0, b2 = 0;
+#pragma unroll
+          for (int s = 0; s < 16; s++) {
+            const uint32_t B = (s < 15) ? Tj[(s + 1) & 15] : Tj16;
+            const uint32_t d = pk_sub(sample2(Tj[s], B, jt, jb), tI[s]);
+            b1 = s ? dot2(d, tX[s], b1) : dot2k(d, tX[0], 0);
+            b2 = s ? dot2(d, tY[s], b2) : dot2k(d, tY[0], 0);
+          }
+          // per lane 32 products |diff| <= 8160 times |derivative| <= 4080: < 2^29.99 -- a quad's sum would leave int32, so the values are
+          // split into 16-bit halves first and the four halves go through one reduce-scatter (lane & 3 = 0: lo b1, 1: lo b2, 2: hi b1, 3: hi b2)
+          const bool odd = lane & 1, up = lane & 2;
+          const int lo1 = b1 & 0xFFFF, hi1 = b1 >> 16, lo2 = b2 & 0xFFFF, hi2 = b2 >> 16;
+          const int x = (odd ? lo2 : lo1) + klt_dpp<0xB1>(odd ? lo1 : lo2);
+          const int y = (odd ? hi2 : hi1) + klt_dpp<0xB1>(odd ? hi1 : hi2);
+          int z = (up ? y : x) + klt_dpp<0x4E>(up ? x : y);
+          z = klt_half_sum(z);
+          const int l1 = klt_class<0>(z), l2 = klt_class<1>(z), h1 = klt_class<2>(z), h2 = klt_class<3>(z);
+          const float fb1 = klt_combine(h1, l1) * FLT_SCALE;
+          const float fb2 = klt_combine(h2, l2) * FLT_SCALE;
+          const float dx = (A12 * fb2 - A22 * fb1) * D;
+          const float dy = (A12 * fb1 - A11 * fb2) * D;
+          nextx += dx; nexty += dy;
+          outx = nextx + half; outy = nexty + half;
+          const float d2 = dx * dx + dy * dy;
+          bool conv;
+          if (d2 < A.eps_lo) conv = true;
+          else if (d2 > A.eps_hi) conv = false;
+          else conv = (double)dx * (double)dx + (double)dy * (double)dy <= A.eps2;
+          j++;
+          if (conv) act = false;
+          else if (j > 1 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
+            outx -= dx * 0.5f; outy -= dy * 0.5f;
+            act = false;
+          }
+          pdx = dx; pdy = dy;
+          if (j >= A.max_count) act = false;
+        }
+      }
+    }
+    if (ok) n_it = j;
+    if (iters && exists && !dead && l32 == 0) iters[pt * A.iters_stride + level] = n_it;
+    if (ok && st && level == 0) {
+      const float nx = outx - half, ny = outy - half;
+      const float fnx = floorf(nx), fny = floorf(ny);
+      const int inx = (int)fnx, iny = (int)fny;
+      if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) {
+        st = 0;
+      } else {
+        uint32_t jt, jb;
+        lk_weights(nx - fnx, ny - fny, jt, jb);
+        const uint32_t vj = lane_off + (uint32_t)(iny + VO_PAD) * (uint32_t)L.pitch + (uint32_t)(inx + VO_PAD);
+        uint32_t Tj[16];
+#pragma unroll
+        for (int s = 0; s < 16; s++) Tj[s] = __builtin_amdgcn_raw_buffer_load_b32(rJ, (int)vj, (int)((uint32_t)s * (uint32_t)L.pitch), 0);
+        const uint32_t Tj16 = row_next2(Tj[0], lane);
+        int e = 0;
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+          const uint32_t B = (s < 15) ? Tj[(s + 1) & 15] : Tj16;
+          const uint32_t d = pk_abs(pk_sub(sample2(Tj[s], B, jt, jb), tI[s]));
+          const uint32_t ones = (16 * r + s < win) ? colones : 0u;
+          e = s ? dot2(d, ones, e) : dot2k(d, ones, 0);
+        }
+        e += klt_dpp<0xB1>(e); e += klt_dpp<0x4E>(e);                    // quad total in every lane of the quad
+        e = klt_half_sum(e);
+        errv = (float)e * 1.f / (float)(32 * win * win);
+      }
+    }
+  }
+  if (exists && !dead && l32 == 0) {
+    p1[2 * pt] = outx; p1[2 * pt + 1] = outy;
+    status[pt] = (uint8_t)st;
+    err[pt] = st ? errv : 0.f;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -502,7 +743,17 @@ static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, size_t off
 #define VO_KLT_LAUNCH(WV) hipLaunchKernelGGL(k_klt_track<WV>, dim3(n, c->batch), dim3(64), 0, c->stream, A,                \
                        vo_slab<const float>(c, off_in), vo_slab<float>(c, off_out), vo_slab<uint8_t>(c, c->off_status),     \
                        vo_slab<float>(c, c->off_err), c->d_iters, c->d_dbg, counts)
-    if (waves <= 4) VO_KLT_LAUNCH(4); else if (waves == 5) VO_KLT_LAUNCH(5); else VO_KLT_LAUNCH(6);
+    // VO_KLT_PAIR=1 (experiment): two keypoints per wave (k_klt_track2); read per launch so that a test can compare both kernels
+    const char* pair_s = getenv("VO_KLT_PAIR");
+    const int pair = pair_s ? atoi(pair_s) : 0;
+    if (pair) {
+      const int npair = (n + 1) / 2;
+#define VO_KLT_LAUNCH2(WV) hipLaunchKernelGGL(k_klt_track2<WV>, dim3(npair, c->batch), dim3(64), 0, c->stream, A,            \
+                       vo_slab<const float>(c, off_in), vo_slab<float>(c, off_out), vo_slab<uint8_t>(c, c->off_status),     \
+                       vo_slab<float>(c, c->off_err), c->d_iters, counts)
+      if (pair == 3) VO_KLT_LAUNCH2(3); else if (pair == 5) VO_KLT_LAUNCH2(5); else VO_KLT_LAUNCH2(4);
+#undef VO_KLT_LAUNCH2
+    } else if (waves <= 4) VO_KLT_LAUNCH(4); else if (waves == 5) VO_KLT_LAUNCH(5); else VO_KLT_LAUNCH(6);
 #undef VO_KLT_LAUNCH
   }
   VO_HIP(c, hipGetLastError());
