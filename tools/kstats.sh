@@ -13,12 +13,13 @@ python3 - <<PY > $OUT/${TAG}_kstats.txt
 import csv, glob
 f = sorted(glob.glob("$OUT/${TAG}_ks/**/*kernel_stats.csv", recursive=True))[-1]
 tot = 0
-steps = 35 + 20 + 1   # warm-up + timed + the 20 untimed stage-breakdown steps + the first push
-for r in csv.DictReader(open(f)):
+rows = list(csv.DictReader(open(f)))
+steps = max(1, sum(int(r["Calls"]) for r in rows if "k_klt_track" in r["Name"]))     # one KLT launch per step (warm-up, timed and untimed steps alike)
+for r in rows:
     n = r["Name"].split("(")[0].replace("void ", "")[:24]
     t = float(r["TotalDurationNs"]) / 1e3
     tot += t
     print("%-24s calls %5s avg %8.1f us  per-step %7.1f us" % (n, r["Calls"], float(r["AverageNs"]) / 1e3, t / steps))
-print("sum per 32-frame step: %.1f us" % (tot / steps))
+print("sum per 32-frame step: %.1f us over %d steps (adaptive-budget, fixed-budget and stationary-BA regions mixed)" % (tot / steps, steps))
 PY
 cat $OUT/${TAG}_kstats.txt

@@ -16,7 +16,7 @@ import csv, glob, json
 f = sorted(glob.glob("$OUT/${TAG}_ks/**/*kernel_stats.csv", recursive=True))[-1]
 tot = 0
 rows = list(csv.DictReader(open(f)))
-steps = 50
+steps = max(1, sum(int(r["Calls"]) for r in rows if "k_klt_track" in r["Name"]))
 for r in rows:
     n = r["Name"].split("(")[0].replace("void ", "")[:26]
     t = float(r["TotalDurationNs"]) / 1e3
