@@ -27,64 +27,60 @@ class BundleAdjuster:
 
     def build_problem(self, state, landmarks_dead, landmarks_kp_dead, t_now):
         """The reference's selection rules (:132-176) -> dense problem (poses [W,6], points [N,3], obs [W,N,2]).
-        Like the reference this APPENDS the recently-dead landmarks to state._landmarks / state._landmarks_kp."""
+        Like the reference this APPENDS the recently-dead landmarks to state._landmarks / state._landmarks_kp (the lists the
+        solve works on ARE the state's lists, :142).  -> (poses, points, obs, number of live landmarks, dead pairs that stay out)"""
         W = self._window_size
-        n_landmarks_active = len(state._landmarks)
-        t_earliest = [l.t_latest - (len(k.uv_history) - 1) for l, k in zip(landmarks_dead, landmarks_kp_dead)]
-        refine_landmarks, refine_landmarks_kp = state._landmarks, state._landmarks_kp     # aliases (:142)
-        unrefined_landmarks, unrefined_landmarks_kp = [], []
-        for i, l in enumerate(landmarks_dead):
-            if (t_now - t_earliest[i]) < W:
-                refine_landmarks.append(l)
-                refine_landmarks_kp.append(landmarks_kp_dead[i])
+        lms, kps = state._landmarks, state._landmarks_kp          # aliases, deliberately
+        n_live = len(lms)
+        stay_out = []
+        for l, k in zip(landmarks_dead, landmarks_kp_dead):
+            born = l.t_latest - (len(k.uv_history) - 1)           # frame of the track's first history entry (:136-139)
+            if t_now - born < W:                                  # the whole track lies inside the window (:144-147)
+                lms.append(l)
+                kps.append(k)
             else:
-                unrefined_landmarks.append(l)
-                unrefined_landmarks_kp.append(landmarks_kp_dead[i])
-        N = len(refine_landmarks)
-        # observation of landmark j in window slot t <-> history index (t_now - t) - t_latest + L - 1 (:56-59, :150-158):
-        # valid slots are one contiguous run, read back to front -> one slice per landmark instead of W lookups
+                stay_out.append((l, k))
+        N = len(lms)
+        # observation of landmark j in window slot s <-> history index (t_now - s) - t_latest + L - 1 (:56-59, :150-158):
+        # the valid slots are one contiguous run read back to front -> one slice per landmark instead of W lookups
         obs = np.full((W, N, 2), np.nan)
-        for j, (l, k) in enumerate(zip(refine_landmarks, refine_landmarks_kp)):
+        for j, (l, k) in enumerate(zip(lms, kps)):
             L = len(k.uv_history)
-            base = t_now - l.t_latest + (L - 1)              # history index of slot 0
-            t_lo, t_hi = max(0, base - (L - 1)), min(W - 1, base)
-            if t_lo <= t_hi:
-                h = np.array(k.uv_history[base - t_hi:base - t_lo + 1], dtype=np.float64).reshape(-1, 2)
-                obs[t_lo:t_hi + 1, j] = h[::-1]
-        points = (np.array([l.p for l in refine_landmarks], dtype=np.float64).reshape(N, 3) if N else np.zeros((0, 3)))
-        poses = np.zeros((W, 6))        # poses missing at the start of a sequence stay identity (:169-171)
-        T = len(state._trajectory)
-        for i in range(W):
-            if T - 1 - i < 0:
-                break
-            H = state._trajectory[T - 1 - i]
-            poses[i, :3] = rodrigues_mat_to_vec(H[:3, :3])
-            poses[i, 3:] = H[:3, 3]
-        return poses, points, obs, n_landmarks_active, unrefined_landmarks, unrefined_landmarks_kp
+            newest = t_now - l.t_latest + (L - 1)                 # history index of slot 0
+            s_lo, s_hi = max(0, newest - (L - 1)), min(W - 1, newest)
+            if s_lo <= s_hi:
+                run = np.array(k.uv_history[newest - s_hi:newest - s_lo + 1], dtype=np.float64).reshape(-1, 2)
+                obs[s_lo:s_hi + 1, j] = run[::-1]
+        points = np.array([l.p for l in lms], dtype=np.float64).reshape(N, 3) if N else np.zeros((0, 3))
+        poses = np.zeros((W, 6))                                  # poses missing at the start of a sequence stay identity (:169-171)
+        n_traj = len(state._trajectory)
+        for s in range(min(W, n_traj)):
+            H = state._trajectory[n_traj - 1 - s]
+            poses[s, :3] = rodrigues_mat_to_vec(H[:3, :3])
+            poses[s, 3:] = H[:3, 3]
+        return poses, points, obs, n_live, [p[0] for p in stay_out], [p[1] for p in stay_out]
 
     def adjust(self, state, landmarks_dead, landmarks_kp_dead, K, t_now):
-        poses, points, obs, n_active, unref_l, unref_k = self.build_problem(state, landmarks_dead, landmarks_kp_dead, t_now)
-        refine_landmarks, refine_landmarks_kp = state._landmarks, state._landmarks_kp
-        N, W = len(refine_landmarks), self._window_size
+        poses, points, obs, n_live, out_l, out_k = self.build_problem(state, landmarks_dead, landmarks_kp_dead, t_now)
+        lms, kps = state._landmarks, state._landmarks_kp
+        N, W = len(lms), self._window_size
         if N > 0 and not np.isnan(obs[..., 0]).all():
             c = self._context()
             delta = 1.0 if self._loss == 'huber' else 1e30       # 'linear' loss == Huber with an unreachable knee
             prm = c.ba_params(max_iters=self._max_iters, ftol=self._ftol, xtol=self._xtol, huber_delta=delta)
-            poses_out, points_out, self.last_stats = c.ba_adjust(np.asarray(K, np.float64), poses, points, obs, prm)
-        else:
-            poses_out, points_out = poses, points
-        # write back exactly like the reference (:197-213)
-        p_new = np.ascontiguousarray(points_out, np.float64).reshape(N, 3, 1).copy()     # each landmark gets its own row
-        for i in range(N):
-            refine_landmarks[i].p = p_new[i]
-        landmarks_dead = [refine_landmarks[i] for i in range(n_active, N)] + unref_l
-        landmarks_kp_dead = [refine_landmarks_kp[i] for i in range(n_active, N)] + unref_k
-        for i in range(W):
-            t = t_now - i
-            if not (t in state._trajectory._poses):
+            poses, points, self.last_stats = c.ba_adjust(np.asarray(K, np.float64), poses, points, obs, prm)
+        # positions back into the landmark objects, every landmark its own (3, 1) array (:197-201)
+        fresh = np.ascontiguousarray(points, np.float64).reshape(N, 3, 1).copy()
+        for l, p in zip(lms, fresh):
+            l.p = p
+        # the resurrected ones lead the dead lists the caller gets back (:203-204)
+        dead_l, dead_k = lms[n_live:] + out_l, kps[n_live:] + out_k
+        # window poses back into the trajectory, newest first, as far as it reaches back (:206-213)
+        for s in range(W):
+            if (t_now - s) not in state._trajectory._poses:
                 break
-            H_i = np.eye(4)
-            H_i[:3, :3] = rodrigues_vec_to_mat(poses_out[i, :3])
-            H_i[:3, 3] = poses_out[i, 3:]
-            state._trajectory._poses[t] = H_i
-        return state, landmarks_dead, landmarks_kp_dead
+            H = np.eye(4)
+            H[:3, :3] = rodrigues_vec_to_mat(poses[s, :3])
+            H[:3, 3] = poses[s, 3:]
+            state._trajectory._poses[t_now - s] = H
+        return state, dead_l, dead_k
