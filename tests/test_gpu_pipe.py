@@ -27,11 +27,14 @@ def _sharing(e):
     return [(dl.get(int(l), -1) >= 0, dk.get(int(k), -1) >= 0) for l, k in zip(e["rows"]["lm_l"], e["rows"]["lm_k"])]
 
 
-@pytest.mark.parametrize("ba_window,n_steps", [(4, 12), (10, 10)])
-def test_resident_pipeline_equals_object_loop(ba_window, n_steps):
+@pytest.mark.parametrize("ba_window,n_steps,seed,period,amp", [(4, 12, 2024, 24.0, (0.9, 0.25, -0.5)), (10, 10, 2024, 24.0, (0.9, 0.25, -0.5)),
+                                                              (4, 30, 7, 16.0, (1.6, 0.4, -0.8)), (6, 16, 99, 20.0, (1.2, -0.3, 0.6))])
+def test_resident_pipeline_equals_object_loop(ba_window, n_steps, seed, period, amp):
+    """the last two: other scenes, faster motion (more tracks leave the image, more deaths and resurrections), a longer run (the history
+    ring wraps at 32 entries per keypoint only for tracks older than the run: 30 frames stay inside it)"""
     from vo_mi355x.resident import ResidentPipeline
     w, h, t1 = 256, 160, 3
-    sc = ph.scene(t1 + n_steps + 1, w=w, h=h, f=260.0, seed=2024, pose_fn=lambda t: ph.sway_pose(t, period=24.0))
+    sc = ph.scene(t1 + n_steps + 1, w=w, h=h, f=260.0, seed=seed, pose_fn=lambda t: ph.sway_pose(t, amp=amp, period=period))
     ctx_a, ctx_b = _ctx(w, h), _ctx(w, h)
     state, t_loader = ph.gt_bootstrap(ctx_a, sc, 0, t1)
     loop = ph.ObjectLoop(ctx_a, sc["K"], copy.deepcopy(state), sc["frames"][t_loader], ba_window=ba_window, ba_max_iters=16)
