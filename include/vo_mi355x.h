@@ -423,9 +423,10 @@ typedef struct {
   int32_t pnp_inliers, pnp_hypotheses, pnp_bound_reached;
   int32_t n_ripe, n_new, n_resurrected, n_detected;
   int32_t ba_landmarks, ba_observations, ba_iters, ba_accepted, ba_status, ba_done;   /* ba_done 0: the budget cut the solve */
-  int32_t pad;
+  int32_t t_final;            /* step whose pose has just left the BA window (t - ba_window + 1, or -1): H_final will not change any more */
   double  ba_cost0, ba_cost;
-  double  H[12];              /* pose of this frame AFTER the adjust: rows of [R | t], world -> camera */
+  double  H[12];              /* pose of this frame AFTER the adjust: rows of [R | t], world -> camera (later adjusts refine it while it is in the window) */
+  double  H_final[12];        /* pose of step t_final: collecting these gives the trajectory the reference ends up with (state._trajectory) */
 } vo_pipe_record;
 
 enum { VO_PIPE_LOST = 1, VO_PIPE_CAPACITY = 2, VO_PIPE_GROUPS = 4 };   /* LOST: the 3D-2D pose found no consensus (the reference crashes there); CAPACITY: object rows exhausted; GROUPS: a ripe candidate was born more than 32 frames ago (its pose has left the trajectory ring) */

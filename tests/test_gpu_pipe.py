@@ -43,6 +43,7 @@ def test_resident_pipeline_equals_object_loop(ba_window, n_steps, seed, period, 
     ctx_b.push_frame(sc["frames"][t_loader])
     ph.compare_lists(loop, rp.entries(), what="seed")
     seen = dict(res=0, new=0, shared=0, dup=0)
+    final = {}
     for s in range(n_steps):
         im = sc["frames"][t_loader + 1 + s]
         loop.step(im)
@@ -63,6 +64,9 @@ def test_resident_pipeline_equals_object_loop(ba_window, n_steps, seed, period, 
         for t in range(loop.t_step + 1):
             assert np.abs(e["poses"][t] - st._trajectory[t]).max() <= 1e-7, (what, t)
         assert np.abs(rec["H"] - st._trajectory[loop.t_step]).max() <= 1e-7
+        assert rec["t_final"] == max(-1, loop.t_step - (ba_window - 1))
+        if rec["t_final"] >= 0:
+            final[rec["t_final"]] = rec["H_final"]
         sl = ph.sharing_signature(loop)
         assert [(a >= 0, b >= 0) for a, b in sl] == _sharing(e), what
         seen["res"] += rec["n_resurrected"]; seen["new"] += rec["n_new"]
@@ -72,6 +76,8 @@ def test_resident_pipeline_equals_object_loop(ba_window, n_steps, seed, period, 
     assert seen["res"] > 0 and seen["new"] > 0 and seen["shared"] > 0, seen
     if ba_window > 4:
         assert seen["dup"] > 0, seen
+    # the poses collected as they left the window ARE the reference's final trajectory for those steps (no later adjust touches them)
+    assert final and all(np.abs(H - loop.state._trajectory[t]).max() <= 1e-7 for t, H in final.items())
     # tables -> objects: the reference's classes with the sharing restored
     st2, dead2, dead_kp2 = rp.objects()
     assert len(st2._landmarks) == len(loop.state._landmarks) and len({id(l) for l in st2._landmarks}) == len({id(l) for l in loop.state._landmarks})
@@ -111,8 +117,8 @@ def test_steps_in_flight_and_batch_equal_one_at_a_time():
         recs, ent = ref[i]
         for s in range(n):
             for k in recs[s]:
-                if k == "H":
-                    assert np.array_equal(got[s][b]["H"], recs[s]["H"]), (b, s)
+                if k in ("H", "H_final"):
+                    assert np.array_equal(got[s][b][k], recs[s][k]), (b, s, k)
                 else:
                     assert got[s][b][k] == recs[s][k], (b, s, k, got[s][b][k], recs[s][k])
         eb = rpb.entries(b, T)

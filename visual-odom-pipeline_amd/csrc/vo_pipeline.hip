@@ -648,7 +648,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_writeback(pipe_ptrs Pall, int
 template <int CH>
 __global__ void __launch_bounds__(PIPE_TPB) k_pipe_spawn(pipe_ptrs Pall, int do_detect, const uint32_t* __restrict__ st_scalars, const float* __restrict__ st_out,
                                                          float* __restrict__ pts, size_t slab_seq, int max_new, const double* __restrict__ pnp_out,
-                                                         const int32_t* __restrict__ pnp_ctrl, size_t pnp_ctrl_stride, vo_pipe_record* __restrict__ rec) {
+                                                         const int32_t* __restrict__ pnp_ctrl, size_t pnp_ctrl_stride, int Wn, vo_pipe_record* __restrict__ rec) {
   __shared__ int s_w[16];
   const int b = blockIdx.x, tid = threadIdx.x;
   const pipe_ptrs P = pipe_select(Pall, b);
@@ -714,9 +714,14 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_spawn(pipe_ptrs Pall, int do_
     const double n_in = pnp_out[8 * (size_t)b + 7];
     r.pnp_inliers = (n_in == n_in) ? (int)n_in : 0; r.pnp_hypotheses = pnp_ctrl[(size_t)b * pnp_ctrl_stride + 1];
     r.pnp_bound_reached = pnp_ctrl[(size_t)b * pnp_ctrl_stride + 2];
-    r.n_ripe = P.cnt[C_NRIPE]; r.n_new = P.cnt[C_NNEW]; r.n_resurrected = P.cnt[C_NRES]; r.n_detected = n_det; r.pad = 0;
+    r.n_ripe = P.cnt[C_NRIPE]; r.n_new = P.cnt[C_NNEW]; r.n_resurrected = P.cnt[C_NRES]; r.n_detected = n_det;
     const double* Hs = P.H + 12 * (size_t)(t & (PIPE_HIST - 1));
     for (int k = 0; k < 12; k++) r.H[k] = Hs[k];
+    // the oldest pose of the window: the next adjust no longer touches it
+    const int tf = t - (Wn - 1);
+    r.t_final = tf >= 0 ? tf : -1;
+    const double* Hf = P.H + 12 * (size_t)((tf >= 0 ? tf : t) & (PIPE_HIST - 1));
+    for (int k = 0; k < 12; k++) r.H_final[k] = Hf[k];
     P.cnt[C_NDET] = n_det; P.cnt[C_OVERFLOW] = overflow;
   }
 }
@@ -858,7 +863,7 @@ static void pipe_launch_spawn(vo_ctx* c, int do_detect) {
   (void)vo_pnp_get_view(c, &pv);
   PIPE_DISPATCH(k_pipe_spawn, pipe_make(w), do_detect, vo_slab<const uint32_t>(c, c->off_st_scalars),
                      vo_slab<const float>(c, c->off_st_out), vo_slab<float>(c, vo_off_p(c)), c->slab_seq, w->prm.max_new, pv.out, pv.ctrl,
-                     pv.ctrl_stride, w->d_rec);
+                pv.ctrl_stride, w->prm.ba_window, w->d_rec);
 }
 
 extern "C" int32_t vo_pipe_commit(vo_ctx* c) {

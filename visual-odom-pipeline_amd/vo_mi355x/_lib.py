@@ -80,7 +80,8 @@ class PipeRecord(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("t", "status", "overflow", "n_landmarks", "n_candidates", "n_dead", "n_dead_total", "n_tracked",
                                          "pnp_inliers", "pnp_hypotheses", "pnp_bound_reached", "n_ripe", "n_new", "n_resurrected",
                                          "n_detected", "ba_landmarks", "ba_observations", "ba_iters", "ba_accepted", "ba_status", "ba_done",
-                                         "_pad")] + [("ba_cost0", C.c_double), ("ba_cost", C.c_double), ("H", C.c_double * 12)]
+                                         "t_final")] + [("ba_cost0", C.c_double), ("ba_cost", C.c_double), ("H", C.c_double * 12),
+                                                        ("H_final", C.c_double * 12)]
 
 
 _u8p, _i16p, _i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.POINTER(C.c_int32)

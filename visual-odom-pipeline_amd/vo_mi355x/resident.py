@@ -36,7 +36,7 @@ _TABLES = {
     "lm_kshared": (11, np.int32, lambda N, R: (N,)), "dead_l": (12, np.int32, lambda N, R: (N,)), "dead_k": (13, np.int32, lambda N, R: (N,)),
     "counts": (14, np.int32, lambda N, R: (32,)), "poses": (15, np.float64, lambda N, R: (HIST, 12)),
 }
-_RECORD_FIELDS = [n for n, _ in PipeRecord._fields_ if n not in ("_pad", "H")]
+_RECORD_FIELDS = [n for n, _ in PipeRecord._fields_ if n not in ("H", "H_final")]
 
 
 class ResidentPipeline:
@@ -94,6 +94,8 @@ class ResidentPipeline:
             d = {n: getattr(r, n) for n in _RECORD_FIELDS}
             H = np.eye(4); H[:3] = np.array(r.H[:]).reshape(3, 4)
             d["H"] = H
+            Hf = np.eye(4); Hf[:3] = np.array(r.H_final[:]).reshape(3, 4)
+            d["H_final"] = Hf                      # pose of step d["t_final"]: out of the window now, final
             out.append(d)
         return out[0] if self.B == 1 else out
 
