@@ -210,7 +210,7 @@ class Group:
         self.stages = (True, True, True)   # (DLT, BA, Shi-Tomasi) of the fused step
         self.t = 1
         self.inflight = 0
-        self.max_inflight = 2          # 1 when the step is replayed from a hipGraph (its host destinations are baked in)
+        self.max_inflight = 2          # plain launches and hipGraph replay alike (a graph per pinned mirror half)
 
     def enqueue(self):
         # one C call: pyramid + KLT + DLT + BA + Shi-Tomasi + result copies for the whole batch; the frames are a closed loop
@@ -684,6 +684,20 @@ def measure_extras(device, frame_sets, a, dist):
                               "workload": WORKLOAD, "stream_layout": "pipeline (three streams: BA of frame t beside the front end of frame t + 1)",
                               "side_stream_layout": side}
     g.c.set_side_stream(True)
+    # the same sequence replayed from captured hipGraphs (one per frame parity, pinned mirror half and bank problem; fixed BA budget:
+    # the budget is baked into a capture), two steps in flight
+    try:
+        g.adaptive = False
+        g.ba_prm.max_iters = g.ba_iters_cap
+        g.c.set_graph_mode(True)
+        dt = run(g, 300, warm=40)
+        g.c.set_graph_mode(False)
+        dtp = run(g, 300)
+        out["single_sequence"]["graph_replay"] = {"frames_per_s": round(300 / dt, 1), "plain_launches_same_settings_frames_per_s": round(300 / dtp, 1),
+                                                  "settings": "side-stream layout off under capture (one stream), fixed BA budget %d" % g.ba_iters_cap}
+        g.adaptive = True
+    except Exception as e:      # noqa: BLE001
+        out["single_sequence"]["graph_replay"] = {"error": str(e)}
     kl = {}
     for batch in (1, 32):
         gk = g if batch == 1 else Group(device, frame_sets, seed0=7100, batch=32, ba_iters=a.ba_iters)
@@ -880,7 +894,7 @@ def main():
     for s in seqs:
         s.c.set_side_stream(side)
         s.c.set_graph_mode(bool(a.graph))
-        s.max_inflight = 1 if a.graph else 2
+        s.max_inflight = 2
         s.adaptive = not a.fixed_ba_budget
 
     pool = None

@@ -125,3 +125,47 @@ def test_resident_shi_tomasi_keeps_no_map_and_hands_the_mask_back_clean(seq3):
         eig, m, n = c.shi_tomasi_read()
         assert np.array_equal(got, ref) and np.array_equal(m, mask) and n == nc
         assert np.array_equal(eig, o.min_eig(frames[1]))
+
+
+def test_graph_replay_two_steps_in_flight_with_a_ba_bank():
+    """graph mode: one captured graph per (frame parity, pinned mirror half, selected bank problem), TWO steps in flight like the plain
+    path (round 2 kept one graph per parity and one step in flight -- that, not the replay, made graph mode slower); results bit for bit
+    those of plain launches one at a time"""
+    from vo_mi355x import VoContext, synthetic as syn
+    w, h, n, n_new, nb = 640, 240, 600, 200, 3
+    frames, _ = syn.make_sequence(5, w=w, h=h, seed=23, margin=64)
+    pts = syn.grid_points(n, w, h, seed=5)
+    scenes = [syn.make_ba_scene(n_pts=300, n_slots=6, seed=3 + k, visibility=0.9, pt_noise=0.3 + 0.2 * k) for k in range(nb)]
+    order = [1, 2, 3, 4, 3, 2, 1, 0] * 3
+    keys = ("points2d", "status", "err", "X4", "depth1", "reproj", "poses", "landmarks", "corners")
+
+    def setup(c):
+        _setup(c, frames, pts, scenes[0], n_new)
+        c.ba_upload_bank(scenes[0]["K"], np.stack([s["poses0"][None] for s in scenes]), np.stack([s["points0"][None] for s in scenes]),
+                         np.stack([s["obs"][None] for s in scenes]))
+    with VoContext(w, h, max_pts=1024) as c:
+        c.set_side_stream(False)
+        setup(c)
+        bap = c.ba_params(max_iters=8)
+        ref = []
+        for t, f in enumerate(order):
+            c.ba_select(t % nb)
+            c.frame_step_resident(f, n, ba=bap)
+            ref.append(c.frame_fetch())
+    with VoContext(w, h, max_pts=1024) as c:
+        c.set_graph_mode(True)
+        setup(c)
+        bap = c.ba_params(max_iters=8)
+        got = []
+        c.ba_select(0)
+        c.frame_step_resident(order[0], n, ba=bap)
+        for t, f in enumerate(order[1:], start=1):
+            c.ba_select(t % nb)
+            c.frame_step_resident(f, n, ba=bap)       # two in flight
+            got.append(c.frame_fetch())
+        got.append(c.frame_fetch())
+    assert len({tuple(np.round(r["ba_stats"]["cost"], 6) for r in ref[k::nb]) for k in range(nb)}) == nb     # the bank's problems differ
+    for k in range(len(order)):
+        for key in keys:
+            assert np.array_equal(got[k][key], ref[k][key], equal_nan=True), (k, key)
+        assert got[k]["ba_stats"] == ref[k]["ba_stats"]

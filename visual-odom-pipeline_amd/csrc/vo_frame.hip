@@ -325,7 +325,7 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
       if (c->fr[f].img[l]) (void)hipFree(c->fr[f].img[l]);
       if (c->fr[f].der[l]) (void)hipFree(c->fr[f].der[l]);
     }
-  for (int g = 0; g < 2; g++) if (c->step_graph[g]) (void)hipGraphExecDestroy(c->step_graph[g]);
+  for (auto& g : c->step_graphs) if (g.second) (void)hipGraphExecDestroy(g.second);
   void* bufs[] = {c->d_bil_cw, c->d_dbg, c->d_raw, c->d_seq, c->d_iters, c->d_uv0, c->d_uv1, c->d_slab, c->d_frame_idx, c->d_dlt_cam};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_slab) (void)hipHostFree(c->h_slab);

@@ -106,8 +106,9 @@ struct vo_ctx {
   size_t off_pa = 0, off_pb = 0, off_status = 0, off_err = 0, off_X4 = 0, off_depth = 0, off_reproj = 0,
          off_st_scalars = 0, off_st_out = 0;
   // per-frame step (vo_frame_step_resident) captured as hipGraphs, one per frame parity
-  hipGraphExec_t step_graph[2] = {nullptr, nullptr};
-  uint64_t step_sig[2] = {0, 0};         // hash of everything a captured step bakes in (parameters by value, device pointers, problem shapes)
+  // captured steps, keyed by the hash of everything a capture bakes in: parameters by value, device pointers (the selected problem of a
+  // BA bank among them), problem shapes, frame-store parity and the pinned mirror half the results go to
+  std::vector<std::pair<uint64_t, hipGraphExec_t>> step_graphs;
   int32_t* d_frame_idx = nullptr;        // frame index consumed by the captured k_pad_level0
   int32_t* h_frame_idx = nullptr;        // pinned ring of frame indices (H2D source must outlive the copy)
   int frame_ring = 0;

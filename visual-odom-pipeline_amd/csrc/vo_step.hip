@@ -196,9 +196,11 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
   if (s.do_st) { int32_t r = vo_st_prepare(c, &s.st); if (r != VO_OK) return r; }    // allocations happen outside any capture
 
   // up to two steps may be in flight: step t + 1 is enqueued while the host still reads step t's (pinned) results.
-  // A captured graph has its host destination baked in, so graph mode keeps one step in flight and one mirror half.
-  VO_CHECK(c, c->steps_enq - c->steps_fetched < (c->use_graph ? 1 : 2), VO_E_STATE, "vo_frame_fetch the previous step(s) first");
-  const int half = c->use_graph ? 0 : (int)(c->steps_enq & 1);
+  // A captured graph has its host destination baked in: one graph per (frame parity, mirror half), so graph mode keeps two steps
+  // in flight as well (round 2 kept ONE graph per parity and one step in flight -- that, not the replay itself, is what made graph
+  // mode 0.2 ms per frame slower: tools/graph_probe.hip)
+  VO_CHECK(c, c->steps_enq - c->steps_fetched < 2, VO_E_STATE, "vo_frame_fetch the previous step(s) first");
+  const int half = (int)(c->steps_enq & 1);
   const bool graph_ok = c->use_graph && c->prof.mask == 0 && c->n_pushed >= 2;
   if (!graph_ok) {
     bool recorded = false;
@@ -211,31 +213,36 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
     return VO_OK;
   }
 
-  const int parity = c->cur;                 // frame-store parity BEFORE this step
-  const uint64_t sig = step_signature(c, s);
-  if (!c->step_graph[parity] || sig != c->step_sig[parity]) {
-    // (re)capture: the enqueue functions advance the host-side state exactly as a direct call would
-    if (c->step_graph[parity]) { (void)hipGraphExecDestroy(c->step_graph[parity]); c->step_graph[parity] = nullptr; }
+  uint64_t sig = step_signature(c, s);
+  sig = (sig ^ (uint64_t)(2 * c->cur + half + 1)) * 1099511628211ull;       // frame-store parity BEFORE this step x the pinned mirror half
+  hipGraphExec_t exec = nullptr;
+  for (auto& g : c->step_graphs) if (g.first == sig) { exec = g.second; break; }
+  if (!exec) {
+    // capture: the enqueue functions advance the host-side state exactly as a direct call would
+    if (c->step_graphs.size() >= 64) {             // (a caller that keeps changing parameters: start over rather than grow without bound)
+      for (auto& g : c->step_graphs) (void)hipGraphExecDestroy(g.second);
+      c->step_graphs.clear();
+    }
     hipGraph_t g = nullptr;
     const int cur0 = c->cur, pushed0 = c->n_pushed, parity0 = c->p_parity, st0 = vo_st_flags_save(c);
     VO_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     bool recorded = false;
     c->in_step = true;
-    const int32_t r = step_enqueue(c, s, c->d_frame_idx, frame_idx, 0, &recorded);
+    const int32_t r = step_enqueue(c, s, c->d_frame_idx, frame_idx, half, &recorded);
     c->in_step = false;
     const hipError_t e = hipStreamEndCapture(c->stream, &g);
     if (r != VO_OK || e != hipSuccess) {
-      // nothing was launched: undo what the enqueue functions did to the host-side frame / point parities
+      // nothing was launched: undo what the enqueue functions did to the host-side frame / point parities and launch flags
       c->cur = cur0; c->n_pushed = pushed0; c->p_parity = parity0; vo_st_flags_restore(c, st0);
       if (g) (void)hipGraphDestroy(g);
       if (r != VO_OK) return r;
     }
     VO_HIP(c, e);
-    const hipError_t ei = hipGraphInstantiate(&c->step_graph[parity], g, nullptr, nullptr, 0);
+    const hipError_t ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
-    if (ei != hipSuccess) { c->cur = cur0; c->n_pushed = pushed0; c->p_parity = parity0; vo_st_flags_restore(c, st0); c->step_graph[parity] = nullptr; }
+    if (ei != hipSuccess) { c->cur = cur0; c->n_pushed = pushed0; c->p_parity = parity0; vo_st_flags_restore(c, st0); }
     VO_HIP(c, ei);
-    c->step_sig[parity] = sig;
+    c->step_graphs.emplace_back(sig, exec);
   } else {
     // replay: redo the host-side state changes the enqueue functions would have made
     c->cur ^= 1; c->n_pushed++;
@@ -244,9 +251,9 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
   c->frame_ring = (c->frame_ring + 1) & 63;
   c->h_frame_idx[c->frame_ring] = frame_idx;
   VO_HIP(c, hipMemcpyAsync(c->d_frame_idx, &c->h_frame_idx[c->frame_ring], sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-  VO_HIP(c, hipGraphLaunch(c->step_graph[parity], c->stream));
-  c->step_off_p[0] = vo_off_p(c);
-  VO_HIP(c, hipEventRecord(c->ev_step[0], c->stream));
+  VO_HIP(c, hipGraphLaunch(exec, c->stream));
+  c->step_off_p[half] = vo_off_p(c);
+  VO_HIP(c, hipEventRecord(c->ev_step[half], c->stream));
   c->steps_enq++;
   return VO_OK;
 }
@@ -263,12 +270,12 @@ extern "C" int32_t vo_frame_fetch(vo_ctx* c, int32_t n_pts, float* p, uint8_t* s
   // the OLDEST step not fetched yet; with nothing in flight: the last one again
   int half;
   if (c->steps_fetched < c->steps_enq) {
-    half = c->use_graph ? 0 : (int)(c->steps_fetched & 1);
+    half = (int)(c->steps_fetched & 1);
     VO_HIP(c, hipEventSynchronize(c->ev_step[half]));
     c->steps_fetched++;
   } else {
     VO_CHECK(c, c->steps_enq > 0, VO_E_STATE, "no step to fetch");
-    half = c->use_graph ? 0 : (int)((c->steps_enq - 1) & 1);
+    half = (int)((c->steps_enq - 1) & 1);
     VO_HIP(c, hipStreamSynchronize(c->stream));
     if (c->stream2) VO_HIP(c, hipStreamSynchronize(c->stream2));
     if (c->stream3) VO_HIP(c, hipStreamSynchronize(c->stream3));
