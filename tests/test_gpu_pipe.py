@@ -303,3 +303,47 @@ def test_adjust_golden_through_the_tables(golden_dir, name):
     assert np.abs(P - Pr).max() <= 1e-9 * np.abs(Pr).max()
     for i in range(W):
         assert np.abs(e["poses"][t_now - i] - s2._trajectory[t_now - i]).max() <= 1e-9
+
+
+def test_resident_pipeline_seeded_by_the_sift_bootstrap():
+    """the reference's own start: Pipeline._get_init_state (pipeline.py:42-90 -- SIFT on two frames, ratio matching, five-point pose,
+    triangulation) through the drop-in Extractor on the device, its State handed to the tables, then 8 frames resident on the device
+    against the reference's loop over Python objects from the same State"""
+    from test_gpu_e2e import K, _frames
+    from vo_mi355x import Extractor, State, Trajectory
+    from vo_mi355x.resident import ResidentPipeline
+    n_steps, t0, t1 = 8, 0, 4
+    frames = _frames(t1 + n_steps + 1)
+    h, w = frames[0][0].shape
+    ctx_a, ctx_b = _ctx(w, h, max_pts=4096), _ctx(w, h, max_pts=4096)
+    ex = Extractor(min_kp_dist=7, ctx=ctx_a)
+    kp0 = ex.extract(frames[t0][0], 0, detector='custom', describe=True)
+    kp1 = ex.extract(frames[t1][0], 1, detector='custom', describe=True)
+    matches = ex.match_lists(kp0, kp1)
+    kp0_m, kp1_m, i1_nm = [], [], list(range(len(kp1)))
+    for m in matches:
+        kp0_m.append(copy.deepcopy(kp0[m.queryIdx])); kp1_m.append(copy.deepcopy(kp1[m.trainIdx]))
+        if m.trainIdx in i1_nm:
+            i1_nm.remove(m.trainIdx)
+    inliers, H1 = ex.camera_pose(K, kp0_m, kp1_m, corr='2D-2D')
+    kp0_m = [kp0_m[i] for i in inliers]; kp1_m = [kp1_m[i] for i in inliers]
+    landmarks, kp0_m, kp1_m = ex.triangulate_nonlinear(K, np.eye(4), H1, kp0_m, kp1_m, 1, max_err_reproj=2.0)
+    assert len(landmarks) >= 150
+    state = State(landmarks, kp1_m, [kp1[i] for i in i1_nm], Trajectory({0: np.eye(4), 1: H1}))
+    loop = ph.ObjectLoop(ctx_a, K, copy.deepcopy(state), frames[t1][0], ba_window=4, ba_max_iters=16)
+    rp = ResidentPipeline(ctx_b, K, ba_window=4, ba_max_iters=16, pnp_blind_batches=8)
+    rp.seed(state, [], [], t_step=1)
+    ctx_b.push_frame(frames[t1][0])
+    for s in range(n_steps):
+        im = frames[t1 + 1 + s][0]
+        loop.step(im)
+        ctx_b.push_frame(im); rp.step(); rec = rp.fetch()
+        assert rec["status"] == 0 and rec["overflow"] == 0, rec
+        e = rp.entries()
+        ph.compare_lists(loop, e, what="step %d" % (s + 2), p_tol=1e-7)
+        assert np.abs(rec["H"] - loop.state._trajectory[loop.t_step]).max() <= 1e-7
+    # and the run is a sane odometry: the pose of the last frame against the rendered ground truth, in bootstrap baselines
+    gt = frames[t1 + n_steps][1]
+    unit = np.linalg.norm(frames[t1][1][:3, 3])
+    cosang = (np.trace(rec["H"][:3, :3] @ gt[:3, :3].T) - 1) / 2
+    assert np.degrees(np.arccos(np.clip(cosang, -1, 1))) <= 0.5 and np.linalg.norm(rec["H"][:3, 3] - gt[:3, 3] / unit) <= 0.75
