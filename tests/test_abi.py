@@ -61,7 +61,7 @@ def test_product_does_not_import_the_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
-                bad = re.findall(r"^\s*(?:import|from)\s+(?:vo_oracle|ba_oracle|cv2|oracle)\b|#include\s+\"[^\"]*oracle"
+                bad = re.findall(r"^\s*(?:import|from)\s+(?:\w*_oracle|cv2|oracle)\b|#include\s+\"[^\"]*oracle"
                                  r"|libvo_oracle|ref_stub/", txt, flags=re.M)
                 assert not bad, (f, bad)
 
