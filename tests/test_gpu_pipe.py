@@ -347,3 +347,31 @@ def test_resident_pipeline_seeded_by_the_sift_bootstrap():
     unit = np.linalg.norm(frames[t1][1][:3, 3])
     cosang = (np.trace(rec["H"][:3, :3] @ gt[:3, :3].T) - 1) / 2
     assert np.degrees(np.arccos(np.clip(cosang, -1, 1))) <= 0.5 and np.linalg.norm(rec["H"][:3, 3] - gt[:3, 3] / unit) <= 0.75
+
+
+def test_resident_pipeline_equals_object_loop_at_the_baseline_shape():
+    """1241 x 376, ~1000 bootstrap keypoints growing towards the 4096 slots, 10-frame window: frames of the device tables against the
+    reference's loop over Python objects until the table is full (four list entries per thread, four pyramid levels, the image size the
+    benchmark runs)"""
+    from vo_mi355x.resident import ResidentPipeline
+    w, h, t1, n_steps = 1241, 376, 4, 5
+    sc = ph.scene(t1 + n_steps + 1, w=w, h=h, f=718.856, seed=4321, pose_fn=lambda t: ph.sway_pose(t, period=40.0))
+    ctx_a, ctx_b = _ctx(w, h, max_pts=8192), _ctx(w, h, max_pts=4096)
+    state, t_loader = ph.gt_bootstrap(ctx_a, sc, 0, t1)
+    assert len(state._landmarks) + len(state._candidates_kp) >= 800
+    loop = ph.ObjectLoop(ctx_a, sc["K"], copy.deepcopy(state), sc["frames"][t_loader], ba_window=10, ba_max_iters=12)
+    rp = ResidentPipeline(ctx_b, sc["K"], ba_window=10, ba_max_iters=12, pnp_blind_batches=8)
+    rp.seed(state, [], [], t_step=1)
+    ctx_b.push_frame(sc["frames"][t_loader])
+    for s in range(n_steps):
+        im = sc["frames"][t_loader + 1 + s]
+        loop.step(im)
+        ctx_b.push_frame(im); rp.step(); rec = rp.fetch()
+        what = "step %d" % (s + 2)
+        assert rec["status"] == 0, (what, rec)
+        if rec["overflow"]:
+            break                                        # the 4096 slots are full: from here on the capacity policy (tested against the model) acts
+        ph.compare_lists(loop, rp.entries(), what=what, p_tol=1e-7)
+        assert np.abs(rec["H"] - loop.state._trajectory[loop.t_step]).max() <= 1e-7
+        assert rec["ba_observations"] > 1000 and rec["pnp_inliers"] == loop.info["n_inliers"]
+    assert s >= 2
