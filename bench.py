@@ -337,7 +337,8 @@ class PipeGroup:
         self.inflight += 1
 
     def fetch(self):
-        self.last = self.rp.fetch()
+        rec = self.rp.fetch()
+        self.last = rec if isinstance(rec, list) else [rec]           # (a dict when the context carries ONE sequence)
         self.inflight -= 1
         if self.keep:
             self.recs.append(self.last)

@@ -32,7 +32,7 @@
 // counters [B][PIPE_NCNT]
 enum { C_NCAND = 0, C_NLM = 1, C_NDEAD = 2, C_NINERT = 3, C_STATUS = 4, C_T = 5,
        C_NFREEK = 6, C_NFREEL = 7, C_HEADK = 8, C_HEADL = 9, C_NRIPE = 10, C_NPTS = 11, C_NNEW = 12, C_NRES = 13, C_NDET = 14,
-       C_OVERFLOW = 15, C_NOBS = 16, C_NKLT = 17, C_BORN = 18, C_NPNP = 19 };
+       C_OVERFLOW = 15, C_NOBS = 16, C_NKLT = 17, C_NPNP = 19 };
 
 struct pipe_ptrs {
   int32_t *k_tf, *k_tt, *k_len; float2 *k_uv, *k_first, *k_hist;     // K rows [B][R]; hist [B][HIST][R]
