@@ -395,22 +395,34 @@ __device__ inline void pnp_log_so3(const double* R, double* r) {
 
 #define PNP_NRED 28    // 21 (J^T J upper) + 6 (J^T e) + 1 (cost)
 
-// fixed-order block sum of v[0 .. nv) (256 threads): wave shuffles, then the 4 wave partials in order
-__device__ inline void pnp_block_sum(double* v, int nv, double* s_red /* 4 * PNP_NRED */, double* s_out /* PNP_NRED */) {
+#define PNP_REFINE_THREADS 1024     // 16 waves per sequence: 2 000 correspondences = 2 per thread and pass (256 threads: 88 -> measured below)
+#define PNP_REFINE_WAVES (PNP_REFINE_THREADS / 64)
+
+// fixed-order block sum of v[0 .. nv): wave shuffles, then the wave partials as a fixed pairwise tree
+__device__ inline void pnp_block_sum(double* v, int nv, double* s_red /* PNP_REFINE_WAVES * PNP_NRED */, double* s_out /* PNP_NRED */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int k = 0; k < nv; k++) {
     const double x = pnp_wave_sum(v[k]);
     if (lane == 0) s_red[wave * PNP_NRED + k] = x;
   }
   __syncthreads();
-  if (tid < nv) s_out[tid] = (s_red[tid] + s_red[PNP_NRED + tid]) + (s_red[2 * PNP_NRED + tid] + s_red[3 * PNP_NRED + tid]);
+  if (tid < nv) {
+    double p[PNP_REFINE_WAVES];
+#pragma unroll
+    for (int w = 0; w < PNP_REFINE_WAVES; w++) p[w] = s_red[w * PNP_NRED + tid];
+#pragma unroll
+    for (int st = 1; st < PNP_REFINE_WAVES; st <<= 1)
+#pragma unroll
+      for (int w = 0; w + st < PNP_REFINE_WAVES; w += 2 * st) p[w] += p[w + st];
+    s_out[tid] = p[0];
+  }
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) k_pnp_refine(const double* __restrict__ Kall, const float* __restrict__ Xall, const float* __restrict__ uvall,
+__global__ void __launch_bounds__(PNP_REFINE_THREADS) k_pnp_refine(const double* __restrict__ Kall, const float* __restrict__ Xall, const float* __restrict__ uvall,
                                                     int cap, int n, double thr2, const pnp_ctrl* __restrict__ ctrl, uint8_t* __restrict__ mask_all,
                                                     double* __restrict__ out_all, const int32_t* __restrict__ counts) {
-  __shared__ double s_red[4 * PNP_NRED], s_sum[PNP_NRED];
+  __shared__ double s_red[PNP_REFINE_WAVES * PNP_NRED], s_sum[PNP_NRED];
   __shared__ double s_R[9], s_t[3], s_Rn[9], s_tn[3], s_d[6];
   __shared__ int s_flag;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -422,7 +434,7 @@ __global__ void __launch_bounds__(256) k_pnp_refine(const double* __restrict__ K
   double* out = out_all + 8 * b;
   const pnp_hyp best = ctrl[b].best;
   if (best.count < 4) {
-    for (int i = tid; i < n; i += 256) mask[i] = 0;
+    for (int i = tid; i < n; i += PNP_REFINE_THREADS) mask[i] = 0;
     if (tid < 8) out[tid] = (tid == 7) ? 0.0 : __builtin_nan("");
     return;
   }
@@ -430,7 +442,7 @@ __global__ void __launch_bounds__(256) k_pnp_refine(const double* __restrict__ K
   if (tid < 3) s_t[tid] = best.t[tid];
   __syncthreads();
   int n_in = 0;
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += PNP_REFINE_THREADS) {
     const double Xi[3] = {(double)X[3 * i], (double)X[3 * i + 1], (double)X[3 * i + 2]};
     const uint8_t m = (pnp_err2(K, s_R, s_t, Xi, (double)uv[2 * i], (double)uv[2 * i + 1]) <= thr2) ? 1 : 0;
     mask[i] = m; n_in += m;
@@ -440,7 +452,7 @@ __global__ void __launch_bounds__(256) k_pnp_refine(const double* __restrict__ K
   for (int iter = 0; iter < 20; iter++) {
     double acc[PNP_NRED];
     for (int k = 0; k < PNP_NRED; k++) acc[k] = 0;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += PNP_REFINE_THREADS) {
       if (!mask[i]) continue;
       const double Xw[3] = {(double)X[3 * i], (double)X[3 * i + 1], (double)X[3 * i + 2]};
       const double rx = s_R[0] * Xw[0] + s_R[1] * Xw[1] + s_R[2] * Xw[2];
@@ -510,7 +522,7 @@ __global__ void __launch_bounds__(256) k_pnp_refine(const double* __restrict__ K
       }
       __syncthreads();
       double cpart[1] = {0.0};
-      for (int i = tid; i < n; i += 256) {
+      for (int i = tid; i < n; i += PNP_REFINE_THREADS) {
         if (!mask[i]) continue;
         const double Xi[3] = {(double)X[3 * i], (double)X[3 * i + 1], (double)X[3 * i + 2]};
         cpart[0] += pnp_err2(K, s_Rn, s_tn, Xi, (double)uv[2 * i], (double)uv[2 * i + 1]);
@@ -605,7 +617,7 @@ static void pnp_enqueue_batch(vo_ctx* c, const vo_pnp_params* prm, const int32_t
 static int32_t pnp_enqueue_refine(vo_ctx* c, const vo_pnp_params* prm, const int32_t* counts = nullptr) {
   vo_pnp_ws* w = c->pnp;
   const size_t B = c->batch;
-  hipLaunchKernelGGL(k_pnp_refine, dim3((unsigned)B), dim3(256), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n,
+  hipLaunchKernelGGL(k_pnp_refine, dim3((unsigned)B), dim3(PNP_REFINE_THREADS), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n,
                      prm->reproj_err * prm->reproj_err, w->d_ctrl, w->d_mask, w->d_out, counts);
   VO_HIP(c, hipGetLastError());
   if (counts) return VO_OK;       // closed-loop pipeline: the results are consumed on the device
