@@ -40,6 +40,12 @@ _RECORD_FIELDS = [n for n, _ in PipeRecord._fields_ if n not in ("H", "H_final")
 
 
 class ResidentPipeline:
+    """ba_max_iters: the LM's own iteration cap; ba_budget: LM iterations ENQUEUED per frame (default = ba_max_iters, which never cuts a
+    solve).  An enqueued iteration whose solve has already stopped exits at once but still costs its four launches (~16 us per frame for
+    one sequence, ~45 us for a batch of 32), so a caller that tracks one camera may pass the few iterations a warm-started window needs
+    (2-3 typical; e.g. ba_budget=6) and watch rec["ba_done"]: 0 flags a solve the budget cut (set_ba_budget raises it between frames).
+    resurrect=False leaves dead landmarks dead (not the reference; see include/vo_mi355x.h)."""
+
     def __init__(self, ctx, K, ba_window=4, min_track_length=3, mask_radius=7, max_new=1000, max_reproj_err=2.0, min_bearing_angle=0.5,
                  ba_max_iters=50, ba_budget=None, ba_ftol=1e-3, ba_xtol=1e-3, pnp_blind_batches=4, pnp_seed=0, min_kp_dist=7, resurrect=True):
         self.ctx, self._L = ctx, ctx._L
