@@ -375,3 +375,38 @@ def test_resident_pipeline_equals_object_loop_at_the_baseline_shape():
         assert np.abs(rec["H"] - loop.state._trajectory[loop.t_step]).max() <= 1e-7
         assert rec["ba_observations"] > 1000 and rec["pnp_inliers"] == loop.info["n_inliers"]
     assert s >= 2
+
+
+@pytest.mark.gpu
+def test_side_stream_layout_equals_one_stream_with_steps_in_flight():
+    """With a side stream the re-detection and the spawn of frame t and the pyramid + KLT of frame t + 1 run beside the bundle adjustment of
+    frame t (csrc/vo_pipeline.hip, pipe_step).  Full image size, two sequences, three steps in flight: records and tables are bit-identical
+    to the same run on ONE stream -- whatever overlaps, nothing reads what the other stream has not finished writing."""
+    from vo_mi355x.resident import ResidentPipeline
+    w, h, t1, n = 1241, 376, 4, 12
+    scs = [ph.scene(t1 + n + 1, w=w, h=h, f=718.856, seed=sd, pose_fn=lambda t: ph.sway_pose(t, period=40.0)) for sd in (99, 4321)]
+    boot = _ctx(w, h, max_pts=4096)
+    states = [ph.gt_bootstrap(boot, sc, 0, t1)[0] for sc in scs]
+    runs = []
+    for side in (True, False):
+        c = _ctx(w, h, max_pts=2048, batch=2)
+        c.set_side_stream(side)
+        c.upload_sequence(np.stack([sc["frames"] for sc in scs]))
+        rp = ResidentPipeline(c, np.stack([sc["K"] for sc in scs]), ba_window=4, ba_max_iters=10)
+        rp.seed([copy.deepcopy(s) for s in states], None, None, 1)
+        c.push_frame_resident(t1)
+        recs = []
+        for s0 in range(0, n, 3):
+            for s in range(s0, s0 + 3):
+                rp.step(t1 + 1 + s)
+            for s in range(s0, s0 + 3):
+                recs.append(rp.fetch())
+        runs.append((recs, rp.read_tables()))
+    (ra, Ta), (rb, Tb) = runs
+    for s in range(n):
+        for b in range(2):
+            assert ra[s][b]["status"] == 0 and ra[s][b]["ba_observations"] > 1000, (s, b, ra[s][b])
+            for k in ra[s][b]:
+                assert np.array_equal(np.asarray(ra[s][b][k]), np.asarray(rb[s][b][k])), (s, b, k, ra[s][b][k], rb[s][b][k])
+    for name in Ta:
+        assert np.array_equal(Ta[name], Tb[name], equal_nan=True) if Ta[name].dtype.kind == "f" else np.array_equal(Ta[name], Tb[name]), name

@@ -39,7 +39,7 @@ struct pipe_ptrs {
   int32_t* l_tl; double* l_p;                                         // L rows [B][R], [B][R][3]
   int32_t *cand, *lm_L, *lm_K, *lm_ksh, *dead_L, *dead_K, *ripe;      // lists [B][N]
   int32_t* cnt;                                                       // [B][PIPE_NCNT]
-  int32_t *freeK, *freeL, *scr;                                       // [B][R]
+  int32_t *freeK, *freeL, *scr, *scr2;                                // [B][R]; scr2: k_pipe_writeback's own (it may run beside k_pipe_spawn)
   double* H;                                                          // [B][HIST][12]
   double* Kc;                                                         // [B][9]
   int32_t* dn;                                                        // [3][B] dense per-sequence counts the stage kernels index by sequence:
@@ -53,12 +53,13 @@ struct vo_pipe_ws {
   vo_pipe_params prm;
   void* tab[VO_PIPE_N_TABLES] = {};
   size_t tab_bytes[VO_PIPE_N_TABLES] = {};       // per sequence
-  int32_t *d_ripe = nullptr, *d_freeK = nullptr, *d_freeL = nullptr, *d_scr = nullptr, *d_dn = nullptr, *d_cam_sel = nullptr;
+  int32_t *d_ripe = nullptr, *d_freeK = nullptr, *d_freeL = nullptr, *d_scr = nullptr, *d_scr2 = nullptr, *d_dn = nullptr, *d_cam_sel = nullptr;
   vo_dlt_cam* d_cams = nullptr;                  // [B][HIST]: one camera pair per birth frame of the ripe candidates
   double* d_K = nullptr;
   vo_pipe_record* d_rec = nullptr;               // [B]
   vo_pipe_record* h_rec = nullptr;               // pinned [VO_PIPE_INFLIGHT][B]
   hipEvent_t ev[VO_PIPE_INFLIGHT] = {};
+  hipEvent_t ev_track = nullptr;                 // the side stream's pyramid + KLT of a step are done
   long enq = 0, fetched = 0;
 };
 
@@ -69,7 +70,7 @@ static pipe_ptrs pipe_make(const vo_pipe_ws* w) {
   P.l_tl = (int32_t*)w->tab[VO_PIPE_L_TLATEST]; P.l_p = (double*)w->tab[VO_PIPE_L_P];
   P.cand = (int32_t*)w->tab[VO_PIPE_CAND]; P.lm_L = (int32_t*)w->tab[VO_PIPE_LM_L]; P.lm_K = (int32_t*)w->tab[VO_PIPE_LM_K];
   P.lm_ksh = (int32_t*)w->tab[VO_PIPE_LM_KSHARED]; P.dead_L = (int32_t*)w->tab[VO_PIPE_DEAD_L]; P.dead_K = (int32_t*)w->tab[VO_PIPE_DEAD_K];
-  P.ripe = w->d_ripe; P.cnt = (int32_t*)w->tab[VO_PIPE_COUNTS]; P.freeK = w->d_freeK; P.freeL = w->d_freeL; P.scr = w->d_scr;
+  P.ripe = w->d_ripe; P.cnt = (int32_t*)w->tab[VO_PIPE_COUNTS]; P.freeK = w->d_freeK; P.freeL = w->d_freeL; P.scr = w->d_scr; P.scr2 = w->d_scr2;
   P.H = (double*)w->tab[VO_PIPE_POSES]; P.Kc = w->d_K; P.dn = w->d_dn; P.N = w->N; P.R = w->R;
   return P;
 }
@@ -80,7 +81,7 @@ __device__ __forceinline__ pipe_ptrs pipe_select(pipe_ptrs P, int b) {
   P.k_tf += r; P.k_tt += r; P.k_len += r; P.k_uv += r; P.k_first += r; P.k_hist += r * PIPE_HIST;
   P.l_tl += r; P.l_p += 3 * r;
   P.cand += n; P.lm_L += n; P.lm_K += n; P.lm_ksh += n; P.dead_L += n; P.dead_K += n; P.ripe += n;
-  P.cnt += (size_t)b * PIPE_NCNT; P.freeK += r; P.freeL += r; P.scr += r;
+  P.cnt += (size_t)b * PIPE_NCNT; P.freeK += r; P.freeL += r; P.scr += r; P.scr2 += r;
   P.H += (size_t)b * PIPE_HIST * 12; P.Kc += 9 * (size_t)b;
   return P;
 }
@@ -607,24 +608,25 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_writeback(pipe_ptrs Pall, int
                                                              size_t x_stride, int Wn, vo_pipe_record* __restrict__ rec) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const pipe_ptrs P = pipe_select(Pall, b);
-  if (P.cnt[C_STATUS]) return;
+  // (C_STATUS, C_NLM, C_T, C_NOBS and the landmark list are final before the fork: k_pipe_spawn, which may run beside this kernel on the
+  //  side stream, touches the candidate list, fresh keypoint rows, the free lists and P.scr -- hence the separate scratch here)
   const int nl = P.cnt[C_NLM], t = P.cnt[C_T];
-  if (do_adjust) {
+  if (do_adjust && !P.cnt[C_STATUS]) {
     const pipe_ba_head* st = reinterpret_cast<const pipe_ba_head*>(pub + (size_t)b * pub_bytes);
     // nothing observed: the adapter skips the solve and writes x0 back (bundle_adjuster.py would hand scipy an empty problem)
     const double* x = (P.cnt[C_NOBS] > 0) ? reinterpret_cast<const double*>(pub + (size_t)b * pub_bytes + 64) : x0 + (size_t)b * x_stride;
     const double* xp = x + 6 * (size_t)Wn;
     // entries that share a landmark row: the reference assigns in list order, the LAST one wins (:197-201)
 #pragma unroll
-    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; if (j < nl) st_i32(&P.scr[P.lm_L[j]], -1); }
+    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; if (j < nl) st_i32(&P.scr2[P.lm_L[j]], -1); }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; if (j < nl) atomicMax(&P.scr[P.lm_L[j]], j); }
+    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; if (j < nl) atomicMax(&P.scr2[P.lm_L[j]], j); }
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < CH; c++) {
       const int j = tid * CH + c;
-      if (j < nl) { const int Lr = P.lm_L[j]; if (ld_i32(&P.scr[Lr]) == j) for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)Lr + k] = xp[3 * (size_t)j + k]; }
+      if (j < nl) { const int Lr = P.lm_L[j]; if (ld_i32(&P.scr2[Lr]) == j) for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)Lr + k] = xp[3 * (size_t)j + k]; }
     }
     if (tid < Wn && t - tid >= 0 && tid < PIPE_HIST) {
       double R[9];
@@ -640,6 +642,17 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_writeback(pipe_ptrs Pall, int
       r.ba_done = solved ? st->done : 1; r.ba_cost0 = solved ? st->cost0 : 0.0; r.ba_cost = solved ? st->cost : 0.0;
     }
   }
+  __syncthreads();                                   // the window's poses are in the ring
+  if (tid == 0) {
+    // the frame's pose as the adjustment leaves it, and the oldest pose of the window: the next adjust no longer touches that one
+    vo_pipe_record& r = rec[b];
+    const double* Hs = P.H + 12 * (size_t)(t & (PIPE_HIST - 1));
+    for (int k = 0; k < 12; k++) r.H[k] = Hs[k];
+    const int tf = t - (Wn - 1);
+    r.t_final = tf >= 0 ? tf : -1;
+    const double* Hf = P.H + 12 * (size_t)((tf >= 0 ? tf : t) & (PIPE_HIST - 1));
+    for (int k = 0; k < 12; k++) r.H_final[k] = Hf[k];
+  }
 }
 
 // ================================================================================================
@@ -648,7 +661,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_writeback(pipe_ptrs Pall, int
 template <int CH>
 __global__ void __launch_bounds__(PIPE_TPB) k_pipe_spawn(pipe_ptrs Pall, int do_detect, const uint32_t* __restrict__ st_scalars, const float* __restrict__ st_out,
                                                          float* __restrict__ pts, size_t slab_seq, int max_new, const double* __restrict__ pnp_out,
-                                                         const int32_t* __restrict__ pnp_ctrl, size_t pnp_ctrl_stride, int Wn, vo_pipe_record* __restrict__ rec) {
+                                                         const int32_t* __restrict__ pnp_ctrl, size_t pnp_ctrl_stride, vo_pipe_record* __restrict__ rec) {
   __shared__ int s_w[16];
   const int b = blockIdx.x, tid = threadIdx.x;
   const pipe_ptrs P = pipe_select(Pall, b);
@@ -715,14 +728,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_spawn(pipe_ptrs Pall, int do_
     r.pnp_inliers = (n_in == n_in) ? (int)n_in : 0; r.pnp_hypotheses = pnp_ctrl[(size_t)b * pnp_ctrl_stride + 1];
     r.pnp_bound_reached = pnp_ctrl[(size_t)b * pnp_ctrl_stride + 2];
     r.n_ripe = P.cnt[C_NRIPE]; r.n_new = P.cnt[C_NNEW]; r.n_resurrected = P.cnt[C_NRES]; r.n_detected = n_det;
-    const double* Hs = P.H + 12 * (size_t)(t & (PIPE_HIST - 1));
-    for (int k = 0; k < 12; k++) r.H[k] = Hs[k];
-    // the oldest pose of the window: the next adjust no longer touches it
-    const int tf = t - (Wn - 1);
-    r.t_final = tf >= 0 ? tf : -1;
-    const double* Hf = P.H + 12 * (size_t)((tf >= 0 ? tf : t) & (PIPE_HIST - 1));
-    for (int k = 0; k < 12; k++) r.H_final[k] = Hf[k];
-    P.cnt[C_NDET] = n_det; P.cnt[C_OVERFLOW] = overflow;
+    P.cnt[C_NDET] = n_det; P.cnt[C_OVERFLOW] = overflow;       // (H, H_final, t_final and the ba_* fields: k_pipe_writeback)
   }
 }
 
@@ -749,10 +755,11 @@ void vo_pipe_destroy(vo_ctx* c) {
   if (!c->pipe) return;
   vo_pipe_ws* w = c->pipe;
   for (void* p : w->tab) if (p) (void)hipFree(p);
-  void* bufs[] = {w->d_ripe, w->d_freeK, w->d_freeL, w->d_scr, w->d_dn, w->d_cam_sel, w->d_cams, w->d_K, w->d_rec};
+  void* bufs[] = {w->d_ripe, w->d_freeK, w->d_freeL, w->d_scr, w->d_scr2, w->d_dn, w->d_cam_sel, w->d_cams, w->d_K, w->d_rec};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (w->h_rec) (void)hipHostFree(w->h_rec);
   for (hipEvent_t e : w->ev) if (e) (void)hipEventDestroy(e);
+  if (w->ev_track) (void)hipEventDestroy(w->ev_track);
   delete w;
   c->pipe = nullptr;
   c->d_pt_counts = nullptr;
@@ -769,8 +776,17 @@ extern "C" int32_t vo_pipe_default_params(vo_pipe_params* p) {
   return VO_OK;
 }
 
+static int32_t pipe_create(vo_ctx* c, const double* K, const vo_pipe_params* prm, bool* replaced);
+
 extern "C" int32_t vo_pipe_create(vo_ctx* c, const double* K, const vo_pipe_params* prm) {
   if (!c) return VO_E_INVALID;
+  bool replaced = false;                          // rejected arguments leave an existing pipeline alone
+  const int32_t r = pipe_create(c, K, prm, &replaced);
+  if (r != VO_OK && replaced) vo_pipe_destroy(c); // never leave a half-built workspace behind (vo_last_error keeps the reason)
+  return r;
+}
+
+static int32_t pipe_create(vo_ctx* c, const double* K, const vo_pipe_params* prm, bool* replaced) {
   VO_CHECK(c, K, VO_E_INVALID, "null K");
   vo_pipe_params def;
   if (!prm) { vo_pipe_default_params(&def); prm = &def; }
@@ -782,6 +798,7 @@ extern "C" int32_t vo_pipe_create(vo_ctx* c, const double* K, const vo_pipe_para
   VO_HIP(c, hipSetDevice(c->device));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   vo_pipe_destroy(c);
+  *replaced = true;
   vo_pipe_ws* w = new vo_pipe_ws();
   c->pipe = w;
   w->prm = *prm;
@@ -798,6 +815,7 @@ extern "C" int32_t vo_pipe_create(vo_ctx* c, const double* K, const vo_pipe_para
   VO_HIP(c, hipMalloc((void**)&w->d_freeK, 4 * R * B));
   VO_HIP(c, hipMalloc((void**)&w->d_freeL, 4 * R * B));
   VO_HIP(c, hipMalloc((void**)&w->d_scr, 4 * R * B));
+  VO_HIP(c, hipMalloc((void**)&w->d_scr2, 4 * R * B));
   VO_HIP(c, hipMalloc((void**)&w->d_cam_sel, 4 * N * B));
   VO_HIP(c, hipMemsetAsync(w->d_cam_sel, 0, 4 * N * B, c->stream));
   VO_HIP(c, hipMalloc((void**)&w->d_cams, sizeof(vo_dlt_cam) * PIPE_HIST * B));
@@ -810,6 +828,7 @@ extern "C" int32_t vo_pipe_create(vo_ctx* c, const double* K, const vo_pipe_para
   VO_HIP(c, hipHostMalloc((void**)&w->h_rec, sizeof(vo_pipe_record) * B * VO_PIPE_INFLIGHT, hipHostMallocDefault));
   const unsigned fl = hipEventDisableTiming | ((getenv("VO_BLOCKING_SYNC") && atoi(getenv("VO_BLOCKING_SYNC"))) ? hipEventBlockingSync : 0u);
   for (int i = 0; i < VO_PIPE_INFLIGHT; i++) VO_HIP(c, hipEventCreateWithFlags(&w->ev[i], fl));
+  VO_HIP(c, hipEventCreateWithFlags(&w->ev_track, hipEventDisableTiming));
   VO_HIP(c, hipMemcpyAsync(w->d_K, K, 72 * B, hipMemcpyHostToDevice, c->stream));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   int32_t r = vo_ba_reserve(c, K, prm->ba_window, w->N);
@@ -863,7 +882,7 @@ static void pipe_launch_spawn(vo_ctx* c, int do_detect) {
   (void)vo_pnp_get_view(c, &pv);
   PIPE_DISPATCH(k_pipe_spawn, pipe_make(w), do_detect, vo_slab<const uint32_t>(c, c->off_st_scalars),
                      vo_slab<const float>(c, c->off_st_out), vo_slab<float>(c, vo_off_p(c)), c->slab_seq, w->prm.max_new, pv.out, pv.ctrl,
-                pv.ctrl_stride, w->prm.ba_window, w->d_rec);
+                pv.ctrl_stride, w->d_rec);
 }
 
 extern "C" int32_t vo_pipe_commit(vo_ctx* c) {
@@ -874,6 +893,9 @@ extern "C" int32_t vo_pipe_commit(vo_ctx* c) {
   vo_pipe_ws* w = c->pipe;
   hipLaunchKernelGGL(k_pipe_dense, dim3(c->batch), dim3(PIPE_TPB), 0, c->stream, pipe_make(w), vo_slab<float>(c, vo_off_p(c)), c->slab_seq, 1);
   pipe_launch_spawn(c, 0);                      // free lists (and a record of the seeded state)
+  { vo_ba_view bv; const int32_t rb = vo_ba_get_view(c, &bv); if (rb != VO_OK) return rb;
+    const pipe_ptrs P = pipe_make(w);
+    PIPE_DISPATCH(k_pipe_writeback, P, 0, bv.pub, bv.pub_bytes, bv.x0, bv.x_stride, bv.W, w->d_rec); }
   VO_HIP(c, hipGetLastError());
   VO_HIP(c, hipStreamSynchronize(c->stream));
   return VO_OK;
@@ -887,13 +909,24 @@ extern "C" int32_t vo_pipe_set_ba_budget(vo_ctx* c, int32_t budget) {
   return VO_OK;
 }
 
+static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages);
+
 extern "C" int32_t vo_pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->pipe, VO_E_STATE, "vo_pipe_create first");
-  vo_pipe_ws* w = c->pipe;
-  VO_CHECK(c, w->enq - w->fetched < VO_PIPE_INFLIGHT, VO_E_STATE, "vo_pipe_fetch the oldest step first");
+  VO_CHECK(c, c->pipe->enq - c->pipe->fetched < VO_PIPE_INFLIGHT, VO_E_STATE, "vo_pipe_fetch the oldest step first");
   VO_HIP(c, hipSetDevice(c->device));
   { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
+  hipStream_t const main_stream = c->stream;
+  c->in_step = true;                              // the stage calls below must not wait for the side streams on the host
+  const int32_t r = pipe_step(c, frame_idx, stages);
+  c->in_step = false;
+  c->stream = main_stream;                        // (an early return may have left the side stream selected)
+  return r;
+}
+
+static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages) {
+  vo_pipe_ws* w = c->pipe;
   const vo_pipe_params& prm = w->prm;
   const pipe_ptrs P = pipe_make(w);
   const int B = c->batch;
@@ -901,15 +934,33 @@ extern "C" int32_t vo_pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages) {
   vo_pnp_view pv; vo_ba_view bv;
   r = vo_pnp_get_view(c, &pv); if (r != VO_OK) return r;
   r = vo_ba_get_view(c, &bv); if (r != VO_OK) return r;
+  // Stream layout with a side stream (vo_set_side_stream != 0).  The loop-carried chain of the closed loop is
+  //   extend -> PnP -> prune -> DLT -> promote -> bundle adjustment -> write-back -> extend of the next frame (it copies landmark positions);
+  // everything else hangs off it and runs on the side stream, in that stream's order:
+  //   [after promote]  re-detection -> spawn (candidate list, free rows, the list half of the record)
+  //   [next step]      pyramid + KLT of the next frame (they need the spawned candidates, not the adjustment)
+  // so the adjustment of frame t runs beside the re-detection of frame t AND the tracking of frame t + 1 as soon as two steps are in
+  // flight.  The main stream waits for the side stream twice per step (before extend, before the record leaves), so after every call
+  // it is downstream of all side work.  A frame the caller pushed itself (frame_idx < 0) is tracked on the main stream as before.
+  const bool side = c->side_stream != 0 && c->stream2 != nullptr;
+  hipStream_t const main_stream = c->stream;
   if (stages & VO_PIPE_TRACK) {
+    if (frame_idx >= 0) VO_CHECK(c, c->d_seq && frame_idx < c->seq_n, VO_E_STATE, "no resident sequence / bad frame index");
+    VO_CHECK(c, c->n_pushed + (frame_idx >= 0 ? 1 : 0) >= 2, VO_E_STATE, "tracking needs two frames in the frame store");
+    const bool track_side = side && frame_idx >= 0;
+    if (track_side) c->stream = c->stream2;
+    r = VO_OK;
     if (frame_idx >= 0) {
-      VO_CHECK(c, c->d_seq && frame_idx < c->seq_n, VO_E_STATE, "no resident sequence / bad frame index");
       const size_t fr = (size_t)c->width * c->height;
       r = vo_build_pyramid(c, c->d_seq + (size_t)frame_idx * fr, fr * c->seq_n, nullptr);
-      if (r != VO_OK) return r;
     }
-    VO_CHECK(c, c->n_pushed >= 2, VO_E_STATE, "tracking needs two frames in the frame store");
-    r = vo_klt_track_resident(c, w->N, &prm.klt);
+    if (r == VO_OK) r = vo_klt_track_resident(c, w->N, &prm.klt);
+    c->stream = main_stream;
+    if (track_side) {                                  // joined on every path
+      const hipError_t e1 = hipEventRecord(w->ev_track, c->stream2);
+      const hipError_t e2 = hipStreamWaitEvent(c->stream, w->ev_track, 0);
+      if (r == VO_OK) { VO_HIP(c, e1); VO_HIP(c, e2); }
+    }
     if (r != VO_OK) return r;
     PIPE_DISPATCH(k_pipe_extend, P, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq, c->width, c->height,
                        pv.X, pv.uv, pv.cap);
@@ -930,17 +981,16 @@ extern "C" int32_t vo_pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages) {
                        vo_slab<const float>(c, c->off_X4), vo_slab<const double>(c, c->off_depth), vo_slab<const double>(c, c->off_reproj), c->slab_seq,
                        w->N, prm.max_reproj_err, prm.min_bearing_angle, w->d_cam_sel, bv.W, prm.resurrect, bv.x0, bv.obs, bv.x_stride, bv.obs_stride, bv.N);
   hipLaunchKernelGGL(k_pipe_dense, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, vo_slab<float>(c, vo_off_p(c)), c->slab_seq, 0);
-  // the re-detection reads the frame and the keypoints of the state, the bundle adjustment the landmark rows and poses: two chains of
-  // narrow launches that share nothing -- side by side when the context has its side stream (vo_set_side_stream), joined before the spawn
-  const bool fork = (stages & VO_PIPE_ADJUST) && (stages & VO_PIPE_DETECT) && c->side_stream != 0;
-  if (fork) {
+  if (side) {
+    // re-detection + spawn on the side stream behind promote / dense; adjustment + write-back on the main stream
     VO_HIP(c, hipEventRecord(c->ev_fork, c->stream));
     VO_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    hipStream_t main_stream = c->stream;
     c->stream = c->stream2;
-    r = vo_shi_tomasi_resident(c, w->N, prm.mask_radius, &prm.st);
+    r = (stages & VO_PIPE_DETECT) ? vo_shi_tomasi_resident(c, w->N, prm.mask_radius, &prm.st) : VO_OK;
+    if (r == VO_OK) pipe_launch_spawn(c, (stages & VO_PIPE_DETECT) ? 1 : 0);
     c->stream = main_stream;
-    if (r == VO_OK) r = vo_ba_enqueue_budget(c, &prm.ba, 0, prm.ba_budget);
+    if (r == VO_OK && (stages & VO_PIPE_ADJUST)) r = vo_ba_enqueue_budget(c, &prm.ba, 0, prm.ba_budget);
+    if (r == VO_OK) PIPE_DISPATCH(k_pipe_writeback, P, (stages & VO_PIPE_ADJUST) ? 1 : 0, bv.pub, bv.pub_bytes, bv.x0, bv.x_stride, bv.W, w->d_rec);
     const hipError_t e1 = hipEventRecord(c->ev_join, c->stream2);
     const hipError_t e2 = hipStreamWaitEvent(c->stream, c->ev_join, 0);     // joined on every path: nothing is left running on the side stream
     if (r != VO_OK) return r;
@@ -954,9 +1004,9 @@ extern "C" int32_t vo_pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages) {
       r = vo_shi_tomasi_resident(c, w->N, prm.mask_radius, &prm.st);
       if (r != VO_OK) return r;
     }
+    PIPE_DISPATCH(k_pipe_writeback, P, (stages & VO_PIPE_ADJUST) ? 1 : 0, bv.pub, bv.pub_bytes, bv.x0, bv.x_stride, bv.W, w->d_rec);
+    pipe_launch_spawn(c, (stages & VO_PIPE_DETECT) ? 1 : 0);
   }
-  PIPE_DISPATCH(k_pipe_writeback, P, (stages & VO_PIPE_ADJUST) ? 1 : 0, bv.pub, bv.pub_bytes, bv.x0, bv.x_stride, bv.W, w->d_rec);
-  pipe_launch_spawn(c, (stages & VO_PIPE_DETECT) ? 1 : 0);
   VO_HIP(c, hipGetLastError());
   const int slot = (int)(w->enq % VO_PIPE_INFLIGHT);
   VO_HIP(c, hipMemcpyAsync(w->h_rec + (size_t)slot * B, w->d_rec, sizeof(vo_pipe_record) * B, hipMemcpyDeviceToHost, c->stream));

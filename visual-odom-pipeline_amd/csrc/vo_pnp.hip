@@ -361,14 +361,30 @@ __device__ inline void pnp_rodrigues(const double* r, double* R) {
   const double th = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
   double a, bq;
   if (th < 1e-12) { a = 1.0; bq = 0.0; }
-  else { a = sin(th) / th; bq = (1.0 - cos(th)) / (th * th); }
+  else { double sn, cs; sincos(th, &sn, &cs); a = sn / th; bq = (1.0 - cs) / (th * th); }      // one range reduction for both
   const double K0[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+#pragma unroll
   for (int i = 0; i < 3; i++)
+#pragma unroll
     for (int j = 0; j < 3; j++) {
       double kk = 0;
+#pragma unroll
       for (int k = 0; k < 3; k++) kk += K0[3 * i + k] * K0[3 * k + j];
       R[3 * i + j] = (i == j ? 1.0 : 0.0) + a * K0[3 * i + j] + bq * kk;
     }
+}
+
+// trial pose of the Gauss-Newton step d scaled by `step`: Rn = exp(step d[0:3]) R, tn = t + step d[3:6]
+__device__ inline void pnp_trial_pose(const double* R, const double* t, const double* d, double step, double* Rn, double* tn) {
+  const double w[3] = {step * d[0], step * d[1], step * d[2]};
+  double E[9];
+  pnp_rodrigues(w, E);
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) Rn[3 * i + j] = E[3 * i] * R[j] + E[3 * i + 1] * R[3 + j] + E[3 * i + 2] * R[6 + j];
+#pragma unroll
+  for (int i = 0; i < 3; i++) tn[i] = t[i] + step * d[3 + i];
 }
 
 __device__ inline void pnp_log_so3(const double* R, double* r) {
@@ -395,7 +411,7 @@ __device__ inline void pnp_log_so3(const double* R, double* r) {
 
 #define PNP_NRED 28    // 21 (J^T J upper) + 6 (J^T e) + 1 (cost)
 
-#define PNP_REFINE_THREADS 1024     // 16 waves per sequence: 2 000 correspondences = 2 per thread and pass (256 threads: 88 -> measured below)
+#define PNP_REFINE_THREADS 512      // 8 waves per sequence (256 VGPRs each: the 28 partial sums + the Jacobian stay in registers; 1024 threads spilled 41)
 #define PNP_REFINE_WAVES (PNP_REFINE_THREADS / 64)
 
 // fixed-order block sum of v[0 .. nv): wave shuffles, then the wave partials as a fixed pairwise tree
@@ -432,14 +448,14 @@ __global__ void __launch_bounds__(PNP_REFINE_THREADS) k_pnp_refine(const double*
   const float* uv = uvall + (size_t)b * cap * 2;
   uint8_t* mask = mask_all + (size_t)b * cap;
   double* out = out_all + 8 * b;
-  const pnp_hyp best = ctrl[b].best;
-  if (best.count < 4) {
+  const pnp_hyp* best = &ctrl[b].best;     // (a by-value copy indexed by tid below would live in scratch memory)
+  if (best->count < 4) {
     for (int i = tid; i < n; i += PNP_REFINE_THREADS) mask[i] = 0;
     if (tid < 8) out[tid] = (tid == 7) ? 0.0 : __builtin_nan("");
     return;
   }
-  if (tid < 9) s_R[tid] = best.R[tid];
-  if (tid < 3) s_t[tid] = best.t[tid];
+  if (tid < 9) s_R[tid] = best->R[tid];
+  if (tid < 3) s_t[tid] = best->t[tid];
   __syncthreads();
   int n_in = 0;
   for (int i = tid; i < n; i += PNP_REFINE_THREADS) {
@@ -448,78 +464,121 @@ __global__ void __launch_bounds__(PNP_REFINE_THREADS) k_pnp_refine(const double*
     mask[i] = m; n_in += m;
   }
   __syncthreads();     // the mask is read back below by the same threads that wrote it (same indices): no hazard, keeps phases tidy
-  double cost = -1.0;
-  for (int iter = 0; iter < 20; iter++) {
-    double acc[PNP_NRED];
+  // normal equations J^T J (21), J^T e (6) and the cost (1) of the masked points at pose (R, t): per-thread partial sums
+  auto linearise = [&](const double* R, const double* t, double* acc) {
+#pragma unroll
     for (int k = 0; k < PNP_NRED; k++) acc[k] = 0;
     for (int i = tid; i < n; i += PNP_REFINE_THREADS) {
       if (!mask[i]) continue;
       const double Xw[3] = {(double)X[3 * i], (double)X[3 * i + 1], (double)X[3 * i + 2]};
-      const double rx = s_R[0] * Xw[0] + s_R[1] * Xw[1] + s_R[2] * Xw[2];
-      const double ry = s_R[3] * Xw[0] + s_R[4] * Xw[1] + s_R[5] * Xw[2];
-      const double rz = s_R[6] * Xw[0] + s_R[7] * Xw[1] + s_R[8] * Xw[2];
-      const double xc = rx + s_t[0], yc = ry + s_t[1], zc = rz + s_t[2];
+      const double rx = R[0] * Xw[0] + R[1] * Xw[1] + R[2] * Xw[2];
+      const double ry = R[3] * Xw[0] + R[4] * Xw[1] + R[5] * Xw[2];
+      const double rz = R[6] * Xw[0] + R[7] * Xw[1] + R[8] * Xw[2];
+      const double xc = rx + t[0], yc = ry + t[1], zc = rz + t[2];
       const double p0 = K[0] * xc + K[1] * yc + K[2] * zc, p1 = K[3] * xc + K[4] * yc + K[5] * zc, p2 = K[6] * xc + K[7] * yc + K[8] * zc;
       const double ip2 = pnp_rcp(p2);
       const double u = p0 * ip2, v = p1 * ip2;
       const double e0 = u - (double)uv[2 * i], e1 = v - (double)uv[2 * i + 1];
       double A[2][3];
+#pragma unroll
       for (int c = 0; c < 3; c++) { A[0][c] = (K[c] - u * K[6 + c]) * ip2; A[1][c] = (K[3 + c] - v * K[6 + c]) * ip2; }
       // left perturbation exp(w) R X: d(RX)/dw_k = e_k x (RX)
       const double G[3][3] = {{0.0, rz, -ry}, {-rz, 0.0, rx}, {ry, -rx, 0.0}};   // -[RX]x: column k = e_k x RX
       double J[2][6];
+#pragma unroll
       for (int r = 0; r < 2; r++) {
+#pragma unroll
         for (int k = 0; k < 3; k++) J[r][k] = A[r][0] * G[0][k] + A[r][1] * G[1][k] + A[r][2] * G[2][k];
+#pragma unroll
         for (int k = 0; k < 3; k++) J[r][3 + k] = A[r][k];
       }
       int q = 0;
+#pragma unroll
       for (int a = 0; a < 6; a++)
+#pragma unroll
         for (int c = a; c < 6; c++) acc[q++] += J[0][a] * J[0][c] + J[1][a] * J[1][c];
+#pragma unroll
       for (int a = 0; a < 6; a++) acc[21 + a] += J[0][a] * e0 + J[1][a] * e1;
-      acc[27] += e0 * e0 + e1 * e1;
+      acc[27] += e0 * e0 + e1 * e1;                    // (the same operations as pnp_err2: a trial pose's cost is this entry)
     }
+  };
+  // Gauss-Newton with step halving (oracle/pnp_oracle.py refine).  The FULL step is tried by linearising at the trial pose straight away:
+  // its cost entry decides the step, and when the step is taken (the normal case) the sums ARE the next iteration's normal equations --
+  // one pass, one block sum and one one-lane solve per iteration instead of two passes and two sums.  Shorter steps (rare) are tried with
+  // cost-only passes as before, followed by one linearisation at the accepted pose.  Same sums in the same order either way.
+  double cost = -1.0;
+  {
+    double acc[PNP_NRED];
+    linearise(s_R, s_t, acc);
     pnp_block_sum(acc, PNP_NRED, s_red, s_sum);
+    cost = s_sum[27];
+  }
+  for (int iter = 0; iter < 20; iter++) {
     if (tid == 0) {
-      cost = s_sum[27];
-      // Cholesky of the 6x6 normal matrix, solve H d = -g
-      double Hm[6][6], g[6];
-      int q = 0;
-      for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { Hm[a][c] = s_sum[q]; Hm[c][a] = s_sum[q]; q++; }
+      // Cholesky of the 6x6 normal matrix, solve H d = -g.  Every loop is unrolled over compile-time bounds (no early exit: a bad pivot
+      // only clears the flag), so the factor lives in registers -- indexed by run-time loop counters it sat in scratch memory
+      // (480 bytes per thread) and every access of this one-lane chain was a memory round trip
+      double Hm[6][6], g[6], d[6];
+      {
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int c = a; c < 6; c++) { Hm[a][c] = s_sum[q]; Hm[c][a] = s_sum[q]; q++; }
+      }
+#pragma unroll
       for (int a = 0; a < 6; a++) g[a] = -s_sum[21 + a];
       bool okc = true;
-      for (int j = 0; j < 6 && okc; j++) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
         double sdiag = Hm[j][j];
+#pragma unroll
         for (int k = 0; k < j; k++) sdiag -= Hm[j][k] * Hm[j][k];
-        if (!(sdiag > 0)) { okc = false; break; }
+        if (!(sdiag > 0)) { okc = false; sdiag = 1.0; }
         const double rs = pnp_rsqrt(sdiag);           // 1 / L_jj
         Hm[j][j] = rs;                                // the diagonal holds the INVERSE pivot
+#pragma unroll
         for (int i = j + 1; i < 6; i++) {
           double sv = Hm[i][j];
+#pragma unroll
           for (int k = 0; k < j; k++) sv -= Hm[i][k] * Hm[j][k];
           Hm[i][j] = sv * rs;
         }
       }
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        double sv = g[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) sv -= Hm[i][k] * d[k];
+        d[i] = sv * Hm[i][i];
+      }
+#pragma unroll
+      for (int i = 5; i >= 0; i--) {
+        double sv = d[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) sv -= Hm[k][i] * d[k];
+        d[i] = sv * Hm[i][i];
+      }
       if (okc) {
-        for (int i = 0; i < 6; i++) { double sv = g[i]; for (int k = 0; k < i; k++) sv -= Hm[i][k] * s_d[k]; s_d[i] = sv * Hm[i][i]; }
-        for (int i = 5; i >= 0; i--) { double sv = s_d[i]; for (int k = i + 1; k < 6; k++) sv -= Hm[k][i] * s_d[k]; s_d[i] = sv * Hm[i][i]; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) s_d[i] = d[i];
+        pnp_trial_pose(s_R, s_t, d, 1.0, s_Rn, s_tn);
       }
       s_flag = okc ? 1 : 0;
     }
     __syncthreads();
     if (!s_flag) break;
-    cost = s_sum[27];
-    // step halving: accept the first step length that lowers the cost
-    double step = 1.0;
-    bool accepted = false;
-    double cn = 0;
-    for (int hh = 0; hh < 6; hh++) {
-      if (tid == 0) {
-        double w[3] = {step * s_d[0], step * s_d[1], step * s_d[2]}, E[9];
-        pnp_rodrigues(w, E);
-        for (int i = 0; i < 3; i++)
-          for (int j = 0; j < 3; j++) s_Rn[3 * i + j] = E[3 * i] * s_R[j] + E[3 * i + 1] * s_R[3 + j] + E[3 * i + 2] * s_R[6 + j];
-        for (int i = 0; i < 3; i++) s_tn[i] = s_t[i] + step * s_d[3 + i];
-      }
+    // the full step
+    double acc[PNP_NRED];
+    linearise(s_Rn, s_tn, acc);
+    pnp_block_sum(acc, PNP_NRED, s_red, s_sum);       // (its barriers also order the reads of s_Rn / s_tn before the next trial pose)
+    double cn = s_sum[27];
+    bool accepted = cn < cost, halved = false;
+    double step = 0.5;
+    for (int hh = 1; hh < 6 && !accepted; hh++) {      // uniform: cn and cost come out of LDS
+      halved = true;
+      __syncthreads();
+      if (tid == 0) { double d[6]; for (int i = 0; i < 6; i++) d[i] = s_d[i]; pnp_trial_pose(s_R, s_t, d, step, s_Rn, s_tn); }
       __syncthreads();
       double cpart[1] = {0.0};
       for (int i = tid; i < n; i += PNP_REFINE_THREADS) {
@@ -529,9 +588,8 @@ __global__ void __launch_bounds__(PNP_REFINE_THREADS) k_pnp_refine(const double*
       }
       pnp_block_sum(cpart, 1, s_red, s_sum);
       cn = s_sum[0];
-      if (cn < cost) { accepted = true; break; }
+      accepted = cn < cost;
       step *= 0.5;
-      __syncthreads();
     }
     if (!accepted) break;
     const bool small = (cost - cn) <= 1e-12 * fmax(cost, 1e-300);
@@ -541,6 +599,10 @@ __global__ void __launch_bounds__(PNP_REFINE_THREADS) k_pnp_refine(const double*
     cost = cn;
     __syncthreads();
     if (small) break;
+    if (halved) {                                      // the sums in LDS belong to a rejected pose: linearise at the accepted one
+      linearise(s_R, s_t, acc);
+      pnp_block_sum(acc, PNP_NRED, s_red, s_sum);
+    }
   }
   if (tid == 0) {
     double rv[3];
