@@ -435,6 +435,9 @@ __device__ inline void pnp_block_sum(double* v, int nv, double* s_red /* PNP_REF
   __syncthreads();
 }
 
+// PPT > 0: a thread's points (i = tid + k * PNP_REFINE_THREADS, k < PPT) and their inlier bits stay in registers for all passes -- every
+// pass is then arithmetic only, not a round trip to the L2 for X, uv and the mask; PPT = 0: any n, the passes re-read memory
+template <int PPT>
 __global__ void __launch_bounds__(PNP_REFINE_THREADS) k_pnp_refine(const double* __restrict__ Kall, const float* __restrict__ Xall, const float* __restrict__ uvall,
                                                     int cap, int n, double thr2, const pnp_ctrl* __restrict__ ctrl, uint8_t* __restrict__ mask_all,
                                                     double* __restrict__ out_all, const int32_t* __restrict__ counts) {
@@ -457,20 +460,51 @@ __global__ void __launch_bounds__(PNP_REFINE_THREADS) k_pnp_refine(const double*
   if (tid < 9) s_R[tid] = best->R[tid];
   if (tid < 3) s_t[tid] = best->t[tid];
   __syncthreads();
-  int n_in = 0;
-  for (int i = tid; i < n; i += PNP_REFINE_THREADS) {
-    const double Xi[3] = {(double)X[3 * i], (double)X[3 * i + 1], (double)X[3 * i + 2]};
-    const uint8_t m = (pnp_err2(K, s_R, s_t, Xi, (double)uv[2 * i], (double)uv[2 * i + 1]) <= thr2) ? 1 : 0;
-    mask[i] = m; n_in += m;
+  constexpr int NP = PPT > 0 ? PPT : 1;
+  float px[NP][3], pu[NP][2];
+  unsigned mbits = 0;
+  if (PPT > 0) {
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      const int i = tid + k * PNP_REFINE_THREADS;
+      const bool in = i < n;                            // (n <= PPT * PNP_REFINE_THREADS: the launcher picks PPT)
+      const int ic = in ? i : 0;
+      px[k][0] = X[3 * ic]; px[k][1] = X[3 * ic + 1]; px[k][2] = X[3 * ic + 2]; pu[k][0] = uv[2 * ic]; pu[k][1] = uv[2 * ic + 1];
+      mbits |= in ? (1u << k) : 0u;
+    }
   }
-  __syncthreads();     // the mask is read back below by the same threads that wrote it (same indices): no hazard, keeps phases tidy
+  // f(X, u, v) for every point of this thread whose bit is set in `bits` (register copy) / whose mask byte is set (memory), in index order
+  auto for_points = [&](const bool use_mask, auto&& f) {
+    if (PPT > 0) {
+#pragma unroll
+      for (int k = 0; k < NP; k++) {
+        if (!((mbits >> k) & 1u)) continue;
+        const double Xw[3] = {(double)px[k][0], (double)px[k][1], (double)px[k][2]};
+        f(tid + k * PNP_REFINE_THREADS, k, Xw, (double)pu[k][0], (double)pu[k][1]);
+      }
+    } else {
+      for (int i = tid; i < n; i += PNP_REFINE_THREADS) {
+        if (use_mask && !mask[i]) continue;
+        const double Xw[3] = {(double)X[3 * i], (double)X[3 * i + 1], (double)X[3 * i + 2]};
+        f(i, 0, Xw, (double)uv[2 * i], (double)uv[2 * i + 1]);
+      }
+    }
+  };
+  int n_in = 0;
+  {
+    unsigned inl = 0;
+    for_points(false, [&](int i, int k, const double* Xw, double u, double v) {
+      const uint8_t m = (pnp_err2(K, s_R, s_t, Xw, u, v) <= thr2) ? 1 : 0;
+      mask[i] = m; n_in += m; inl |= (unsigned)m << k;
+    });
+    if (PPT > 0) mbits = inl;                           // from here on: the consensus set
+  }
+  __syncthreads();     // (PPT = 0: the mask is read back below by the same threads that wrote it, same indices: no hazard, keeps phases tidy)
   // normal equations J^T J (21), J^T e (6) and the cost (1) of the masked points at pose (R, t): per-thread partial sums
   auto linearise = [&](const double* R, const double* t, double* acc) {
 #pragma unroll
     for (int k = 0; k < PNP_NRED; k++) acc[k] = 0;
-    for (int i = tid; i < n; i += PNP_REFINE_THREADS) {
-      if (!mask[i]) continue;
-      const double Xw[3] = {(double)X[3 * i], (double)X[3 * i + 1], (double)X[3 * i + 2]};
+    for_points(true, [&](int, int, const double* Xw, double uo, double vo) {
       const double rx = R[0] * Xw[0] + R[1] * Xw[1] + R[2] * Xw[2];
       const double ry = R[3] * Xw[0] + R[4] * Xw[1] + R[5] * Xw[2];
       const double rz = R[6] * Xw[0] + R[7] * Xw[1] + R[8] * Xw[2];
@@ -478,7 +512,7 @@ __global__ void __launch_bounds__(PNP_REFINE_THREADS) k_pnp_refine(const double*
       const double p0 = K[0] * xc + K[1] * yc + K[2] * zc, p1 = K[3] * xc + K[4] * yc + K[5] * zc, p2 = K[6] * xc + K[7] * yc + K[8] * zc;
       const double ip2 = pnp_rcp(p2);
       const double u = p0 * ip2, v = p1 * ip2;
-      const double e0 = u - (double)uv[2 * i], e1 = v - (double)uv[2 * i + 1];
+      const double e0 = u - uo, e1 = v - vo;
       double A[2][3];
 #pragma unroll
       for (int c = 0; c < 3; c++) { A[0][c] = (K[c] - u * K[6 + c]) * ip2; A[1][c] = (K[3 + c] - v * K[6 + c]) * ip2; }
@@ -500,7 +534,7 @@ __global__ void __launch_bounds__(PNP_REFINE_THREADS) k_pnp_refine(const double*
 #pragma unroll
       for (int a = 0; a < 6; a++) acc[21 + a] += J[0][a] * e0 + J[1][a] * e1;
       acc[27] += e0 * e0 + e1 * e1;                    // (the same operations as pnp_err2: a trial pose's cost is this entry)
-    }
+    });
   };
   // Gauss-Newton with step halving (oracle/pnp_oracle.py refine).  The FULL step is tried by linearising at the trial pose straight away:
   // its cost entry decides the step, and when the step is taken (the normal case) the sums ARE the next iteration's normal equations --
@@ -581,11 +615,7 @@ __global__ void __launch_bounds__(PNP_REFINE_THREADS) k_pnp_refine(const double*
       if (tid == 0) { double d[6]; for (int i = 0; i < 6; i++) d[i] = s_d[i]; pnp_trial_pose(s_R, s_t, d, step, s_Rn, s_tn); }
       __syncthreads();
       double cpart[1] = {0.0};
-      for (int i = tid; i < n; i += PNP_REFINE_THREADS) {
-        if (!mask[i]) continue;
-        const double Xi[3] = {(double)X[3 * i], (double)X[3 * i + 1], (double)X[3 * i + 2]};
-        cpart[0] += pnp_err2(K, s_Rn, s_tn, Xi, (double)uv[2 * i], (double)uv[2 * i + 1]);
-      }
+      for_points(true, [&](int, int, const double* Xw, double uo, double vo) { cpart[0] += pnp_err2(K, s_Rn, s_tn, Xw, uo, vo); });
       pnp_block_sum(cpart, 1, s_red, s_sum);
       cn = s_sum[0];
       accepted = cn < cost;
@@ -679,8 +709,14 @@ static void pnp_enqueue_batch(vo_ctx* c, const vo_pnp_params* prm, const int32_t
 static int32_t pnp_enqueue_refine(vo_ctx* c, const vo_pnp_params* prm, const int32_t* counts = nullptr) {
   vo_pnp_ws* w = c->pnp;
   const size_t B = c->batch;
-  hipLaunchKernelGGL(k_pnp_refine, dim3((unsigned)B), dim3(PNP_REFINE_THREADS), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n,
-                     prm->reproj_err * prm->reproj_err, w->d_ctrl, w->d_mask, w->d_out, counts);
+  const int n_most = counts ? w->cap : w->n;          // (device-side counts never exceed the capacity)
+  auto launch = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(PNP_REFINE_THREADS), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n,
+                       prm->reproj_err * prm->reproj_err, w->d_ctrl, w->d_mask, w->d_out, counts);
+  };
+  if (n_most <= 4 * PNP_REFINE_THREADS) launch(k_pnp_refine<4>);
+  else if (n_most <= 8 * PNP_REFINE_THREADS) launch(k_pnp_refine<8>);
+  else launch(k_pnp_refine<0>);
   VO_HIP(c, hipGetLastError());
   if (counts) return VO_OK;       // closed-loop pipeline: the results are consumed on the device
   VO_HIP(c, hipMemcpyAsync(w->h_out, w->d_out, sizeof(double) * 8 * B, hipMemcpyDeviceToHost, c->stream));

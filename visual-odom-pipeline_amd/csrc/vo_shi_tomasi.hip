@@ -20,6 +20,8 @@
 //                     equivalent to OpenCV's sequential grid scan, output in rank order, first maxCorners.
 #include "vo_internal.h"
 
+#include <type_traits>
+
 #define ST_CAND_CAP 16384        // keys sorted in LDS (128 KB of the CU's 160 KB)
 #define ST_GLOBAL_CAP (1 << 18)  // NMS candidates kept per sequence in HBM; above ST_CAND_CAP the selection works on the
                                  // ST_CAND_CAP strongest (radix select) and is exact whenever it fills max_corners
@@ -795,7 +797,11 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
     if (tid < 3) s_flags[tid] = 0;
     __syncthreads();
     if (pass == 0) VO_STAMP(dbg, 1);   // sort done
-    if (use_dist) {
+    // The conflict lists live in registers, one 64-bit word per own candidate: the section is specialised by the number of candidates per
+    // thread the chunk really has (1, 2, 4, 8 or 16 -- a full-size frame has 1 500 ... 4 000 candidates), otherwise the 16-entry arrays of
+    // the largest case set the register pressure of every launch (90 spilled registers in a 1024-thread workgroup)
+    auto select_rounds = [&](auto kp_tag) {
+      constexpr int KPC = decltype(kp_tag)::value;
       // ---- grid of linked lists (acceleration structure only: any cell size >= min_distance gives the same result) ----
       for (int i = tid; i < n; i += 1024) {
         const uint32_t p = xy[i];
@@ -807,10 +813,10 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
       // ---- conflict lists: for each own candidate the (<= 4) higher-ranked candidates closer than min_distance,
       //      found by ONE walk over the 3x3 cells (9 independent head reads, then the short chains) and kept in
       //      registers, so that the selection rounds below touch one LDS byte per conflict ----
-      unsigned long long nb[ST_KP_MAX];
+      unsigned long long nb[KPC];
       uint32_t over = 0, undec = 0;   // bit q: list overflowed / still undecided
 #pragma unroll
-      for (int q = 0; q < ST_KP_MAX; q++) {
+      for (int q = 0; q < KPC; q++) {
         nb[q] = ~0ull;
         const int i = tid + q * 1024;
         if (i >= n_acc && i < n) {
@@ -846,7 +852,7 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
       for (int round = 0; round <= n; round++) {
         if (tid == 0) s_flags[(round + 1) % 3] = 0;   // re-arm the flag last read two rounds ago
 #pragma unroll
-        for (int q = 0; q < ST_KP_MAX; q++) {
+        for (int q = 0; q < KPC; q++) {
           if (!((undec >> q) & 1)) continue;
           const int i = tid + q * 1024;
           bool any_acc = false, any_und = false;
@@ -886,6 +892,13 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
         if (round == 0 && pass == 0) VO_STAMP(dbg, 5);
         if (!s_flags[round % 3]) { rounds_total += (uint32_t)round + 1; break; }
       }
+    };
+    if (use_dist) {
+      if (n <= 1024) select_rounds(std::integral_constant<int, 1>{});
+      else if (n <= 2048) select_rounds(std::integral_constant<int, 2>{});
+      else if (n <= 4096) select_rounds(std::integral_constant<int, 4>{});
+      else if (n <= 8192) select_rounds(std::integral_constant<int, 8>{});
+      else select_rounds(std::integral_constant<int, ST_KP_MAX>{});
     }
     if (pass == 0) VO_STAMP(dbg, 3);   // rounds done
     // ---- ordered compaction of the chunk's accepted candidates (rank order) behind the earlier ones, up to max_corners ----
