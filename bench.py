@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)     # launcher plumbing test: no GPU work
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--seqs", type=int, default=96, help="independent sequences per GPU")
-    ap.add_argument("--ctxs", type=int, default=3, help="batched contexts (HIP streams) the sequences are split over")
+    ap.add_argument("--ctxs", type=int, default=None, help="batched contexts (HIP streams) the sequences are split over; default 3 (1 for "
+                    "--workload pipeline, whose own stream layout overlaps the stages of one context: DESIGN.md section 6)")
     ap.add_argument("--ba-iters", type=int, default=10, help="LM iteration budget per adjust")
     ap.add_argument("--frames", type=int, default=100, help="distinct synthetic frames per sequence: a closed loop of smooth motion, played round and round")
     ap.add_argument("--pipe-window", type=int, default=4, help="--workload pipeline: BA window (the reference's own setting is 4, pipeline.py:19; BASELINE's 10)")
@@ -712,7 +713,7 @@ def measure_extras(device, frame_sets, a, dist):
             gk.c.close()
     out["klt_only"] = dict(kl, workload="synthetic_1241x376_2000pts_klt_only (BASELINE configs[1]: pyramid + Scharr + KLT, no BA)")
     g.c.close()
-    # Pipeline.step resident on the device, closed loop: 3 x 32 sequences like the headline.  Two configurations:
+    # Pipeline.step resident on the device, closed loop: 96 sequences like the headline.  Two configurations:
     # the reference's own (window 4, recently dead landmarks resurrected into every adjust) and BASELINE's 10-frame window with dead
     # landmarks left dead -- with the reference's resurrection a window of 10 fills the table with copies of young deaths
     import copy as _copy
@@ -720,8 +721,11 @@ def measure_extras(device, frame_sets, a, dist):
     a4 = _copy.copy(a); a4.pipe_window, a4.pipe_no_resurrect = 4, False
     a10 = _copy.copy(a); a10.pipe_window, a10.pipe_no_resurrect = 10, True
     try:
-        out["pipeline_step"] = {"reference_configuration_window4": run_pipeline(device, a4, dist, 3, 32, 40, 10, 3, scenes),
-                                "window10_dead_stay_dead": run_pipeline(device, a10, dist, 3, 32, 40, 10, 3, scenes)}
+        # ONE context of 96 sequences: since the tracking of frame t + 1 and the spawn of frame t run beside the adjustment of frame t inside a
+        # context (csrc/vo_pipeline.hip), one large batch beats three small ones (39.0 k against 33.1 k frames/s; 128 sequences: 40.9 k)
+        out["pipeline_step"] = {"reference_configuration_window4": run_pipeline(device, a4, dist, 1, 96, 40, 10, 3, scenes),
+                                "window10_dead_stay_dead": run_pipeline(device, a10, dist, 1, 96, 40, 10, 3, scenes),
+                                "one_sequence_window4": run_pipeline(device, a4, dist, 1, 1, 100, 10, 3, scenes)}
     except Exception as e:      # noqa: BLE001  (an informational key must not cost the others)
         out["pipeline_step"] = {"error": str(e)}
     try:
@@ -854,6 +858,8 @@ def main():
     # more stepping host threads on this node than cores it grants (8 ranks x 3 threads on a 16-core cgroup): wait for a step's event
     # in the driver instead of spinning on it (1 GPU: 34 650 vs 34 640 frames/s, two ranks on one GPU 31 580 vs 31 190 -- no loss)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if a.ctxs is None:
+        a.ctxs = 1 if a.workload == "pipeline" else 3
     if "VO_BLOCKING_SYNC" not in os.environ and local_world * max(a.host_threads, 1) > usable_cores():
         os.environ["VO_BLOCKING_SYNC"] = "1"
     t_gen = time.perf_counter()

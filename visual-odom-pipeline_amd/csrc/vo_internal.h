@@ -62,6 +62,8 @@ struct vo_ctx {
   float* d_bil_cw = nullptr;         // [256] colour weights
   int side_stream = 1;               // env VO_SIDE_STREAM=0 keeps the frame step on one stream
   bool in_step = false;              // inside vo_frame_step_resident: its stage calls must not wait for the side streams (vo_quiesce_side)
+  bool main_dirty = true;            // an entry point other than vo_pipe_step may have enqueued work on `stream` since the last pipe step (set by
+                                     // vo_quiesce_side, which every such entry point calls): the next pipe step orders its side streams behind it
   int batch = 1;
   int width = 0, height = 0, max_pts = 0, max_level = 0, win = 0;
   int top = 0;                       // highest pyramid level index built

@@ -44,6 +44,7 @@ extern "C" void vo_debug_step_trace_dump(int first_step, int n_steps) {
 }
 
 int32_t vo_quiesce_side(vo_ctx* c) {
+  if (!c->in_step) c->main_dirty = true;                    // (vo_pipe_step clears it: see there)
   if (c->side_stream != 2 || c->in_step) return VO_OK;      // layouts 0 / 1 join their side stream inside the step
   if (c->stream2) VO_HIP(c, hipStreamSynchronize(c->stream2));
   if (c->stream3) VO_HIP(c, hipStreamSynchronize(c->stream3));
@@ -200,6 +201,7 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
   // in flight as well (round 2 kept ONE graph per parity and one step in flight -- that, not the replay itself, is what made graph
   // mode 0.2 ms per frame slower: tools/graph_probe.hip)
   VO_CHECK(c, c->steps_enq - c->steps_fetched < 2, VO_E_STATE, "vo_frame_fetch the previous step(s) first");
+  c->main_dirty = true;
   const int half = (int)(c->steps_enq & 1);
   const bool graph_ok = c->use_graph && c->prof.mask == 0 && c->n_pushed >= 2;
   if (!graph_ok) {
