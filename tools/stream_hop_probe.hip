@@ -19,10 +19,17 @@ int main() {
   unsigned long long* sink; CK(hipMalloc(&sink, 8));
   hipEvent_t e0, e1, ab, ba;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  CK(hipEventCreateWithFlags(&ab, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ba, hipEventDisableTiming));
   const int N = 300;
+  struct { const char* name; unsigned flags; } kinds[] = {
+      {"hipEventDisableTiming", hipEventDisableTiming},
+      {"hipEventDisableTiming | hipEventReleaseToDevice", hipEventDisableTiming | hipEventReleaseToDevice},
+      {"hipEventDisableTiming | hipEventDisableSystemFence", hipEventDisableTiming | hipEventDisableSystemFence},
+      {"hipEventDefault (timing)", hipEventDefault}};
+  for (auto& kind : kinds) {
+  printf("events created with %s\n", kind.name);
+  CK(hipEventCreateWithFlags(&ab, kind.flags)); CK(hipEventCreateWithFlags(&ba, kind.flags));
   printf("%-10s %-8s %22s %22s %12s\n", "kernel us", "blocks", "one stream, us/pair", "two streams, us/pair", "per hop us");
-  for (double us : {5.0, 20.0, 60.0})
+  for (double us : {5.0, 20.0})
     for (int blocks : {1, 256}) {
       const unsigned long long ticks = (unsigned long long)(us * 100.0);
       auto one = [&]() { for (int i = 0; i < N; i++) { hipLaunchKernelGGL(k_spin, dim3(blocks), dim3(64), 0, A, ticks, sink); hipLaunchKernelGGL(k_spin, dim3(blocks), dim3(64), 0, A, ticks, sink); } };
@@ -41,5 +48,7 @@ int main() {
       CK(hipEventRecord(e0, A)); two(); CK(hipEventRecord(e1, A)); CK(hipStreamSynchronize(A)); CK(hipStreamSynchronize(B)); CK(hipEventElapsedTime(&ms2, e0, e1));
       printf("%-10.0f %-8d %22.2f %22.2f %12.2f\n", us, blocks, ms1 * 1e3 / N, ms2 * 1e3 / N, (ms2 - ms1) * 1e3 / N / 2);
     }
+  CK(hipEventDestroy(ab)); CK(hipEventDestroy(ba));
+  }
   return 0;
 }
