@@ -423,7 +423,7 @@ template <int CH>
 __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int do_tri, int do_adjust, const float* __restrict__ X4, const double* __restrict__ depth1,
                                                            const double* __restrict__ reproj, size_t slab_seq, int x4_stride, double max_err,
                                                            double min_angle, const int32_t* __restrict__ cam_sel, int Wn, int resurrect, double* __restrict__ x0, double* __restrict__ obs,
-                                                           size_t x_stride, size_t obs_stride, int Nba) {
+                                                           size_t x_stride, size_t obs_stride, int Nba, float* __restrict__ pts, size_t pts_seq) {
   __shared__ int s_w[16];
   __shared__ int s_first[PIPE_HIST], s_gate[PIPE_HIST];
   __shared__ int s_nobs;
@@ -595,6 +595,16 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
   if (tid == 0) {
     P.cnt[C_NLM] = nl; P.cnt[C_NNEW] = n_new; P.cnt[C_HEADL] = headL; P.cnt[C_OVERFLOW] = overflow;
     if (do_adjust) { P.cnt[C_NDEAD] = nd; P.cnt[C_NINERT] += n_inert; P.cnt[C_NRES] = n_res; P.cnt[C_NOBS] = s_nobs; }
+  }
+  // the resident point set of the final lists (what k_pipe_dense writes; folded in here: one launch less on the frame's critical chain)
+  __syncthreads();                                     // the list entries other threads appended above are visible
+  {
+    float2* out = reinterpret_cast<float2*>(vo_seq(pts, pts_seq, b));
+    for (int j = tid; j < P.N; j += PIPE_TPB) {
+      if (j < nl) out[j] = P.k_uv[P.lm_K[j]];
+      if (j < nc) out[nl + j] = P.k_uv[P.cand[j]];
+    }
+    if (tid == 0) { P.cnt[C_NPTS] = nl + nc; Pall.dn[DN_PTS * gridDim.x + b] = nl + nc; }
   }
 }
 
@@ -989,8 +999,10 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
   if (stages & (VO_PIPE_TRIANGULATE | VO_PIPE_ADJUST))
     PIPE_DISPATCH(k_pipe_promote, P, (stages & VO_PIPE_TRIANGULATE) ? 1 : 0, (stages & VO_PIPE_ADJUST) ? 1 : 0,
                        vo_slab<const float>(c, c->off_X4), vo_slab<const double>(c, c->off_depth), vo_slab<const double>(c, c->off_reproj), c->slab_seq,
-                       w->N, prm.max_reproj_err, prm.min_bearing_angle, w->d_cam_sel, bv.W, prm.resurrect, bv.x0, bv.obs, bv.x_stride, bv.obs_stride, bv.N);
-  hipLaunchKernelGGL(k_pipe_dense, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, vo_slab<float>(c, vo_off_p(c)), c->slab_seq, 0);
+                       w->N, prm.max_reproj_err, prm.min_bearing_angle, w->d_cam_sel, bv.W, prm.resurrect, bv.x0, bv.obs, bv.x_stride, bv.obs_stride, bv.N,
+                       vo_slab<float>(c, vo_off_p(c)), c->slab_seq);
+  else
+    hipLaunchKernelGGL(k_pipe_dense, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, vo_slab<float>(c, vo_off_p(c)), c->slab_seq, 0);
   if (side) {
     // re-detection + spawn on the side stream behind promote / dense; adjustment + write-back on the main stream
     VO_HIP(c, hipEventRecord(c->ev_fork, c->stream));

@@ -268,14 +268,16 @@ __device__ inline void pnp_inv3(const double* K, double* Ki) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_pnp_solve(const double* __restrict__ Kall, const float* __restrict__ Xall, const float* __restrict__ uvall,
                                                   int cap, int n, unsigned seed, pnp_hyp* __restrict__ hyps, const pnp_ctrl* __restrict__ ctrl,
-                                                  const int32_t* __restrict__ counts) {
+                                                  const int32_t* __restrict__ counts, int first) {
   const int b = blockIdx.y, slot = blockIdx.x * 64 + threadIdx.x;
   if (counts) n = counts[b];
-  const pnp_ctrl cs = ctrl[b];
+  // first = 1: the first batch of a search -- the control block is taken as freshly initialised (k_pnp_select of this batch writes it),
+  // which saves the closed loop the k_pnp_init launch in front of every frame's search
+  const int h_done = first ? 0 : ctrl[b].h_done, done = first ? 0 : ctrl[b].done;
   pnp_hyp* out = hyps + (size_t)b * PNP_BATCH + slot;
-  const int h = cs.h_done + slot;
+  const int h = h_done + slot;
   out->h = h;
-  if (cs.done || n < 4) { out->count = -1; return; }      // fewer than 4 correspondences: no sample exists
+  if (done || n < 4) { out->count = -1; return; }         // fewer than 4 correspondences: no sample exists
   const double* Kp = Kall + 9 * b;
   const float* X = Xall + (size_t)b * cap * 3;
   const float* uv = uvall + (size_t)b * cap * 2;
@@ -330,18 +332,26 @@ __device__ inline int pnp_update_iters(double p, double ep, int model_points, in
 // ------------------------------------------------------------------------------------------------
 // k_pnp_select : grid (batch): running best (most inliers, ties to the smallest h) and the iteration bound
 // ------------------------------------------------------------------------------------------------
+__device__ inline void pnp_ctrl_reset(pnp_ctrl* c, int max_iters) {
+  c->niters = max_iters; c->h_done = 0; c->done = 0; c->pad = 0;
+  c->best.count = 0; c->best.h = -1;
+  for (int i = 0; i < 9; i++) c->best.R[i] = 0;
+  for (int i = 0; i < 3; i++) c->best.t[i] = 0;
+}
+
 __global__ void __launch_bounds__(PNP_BATCH) k_pnp_select(const pnp_hyp* __restrict__ hyps, pnp_ctrl* __restrict__ ctrl, int n, double conf,
-                                                          int max_iters, const int32_t* __restrict__ counts) {
+                                                          int max_iters, const int32_t* __restrict__ counts, int first) {
   __shared__ int s_cnt[PNP_BATCH];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (counts) n = counts[b];
   pnp_ctrl* c = ctrl + b;
-  if (c->done) return;
-  if (n < 4) { if (tid == 0) c->done = 1; return; }
+  if (!first && c->done) return;
+  if (n < 4) { if (tid == 0) { if (first) pnp_ctrl_reset(c, max_iters); c->done = 1; } return; }
   const pnp_hyp* H = hyps + (size_t)b * PNP_BATCH;
   s_cnt[tid] = H[tid].count;
   __syncthreads();
   if (tid == 0) {
+    if (first) pnp_ctrl_reset(c, max_iters);               // (see k_pnp_solve)
     int bi = -1, bc = c->best.count;
     for (int i = 0; i < PNP_BATCH; i++) if (s_cnt[i] > bc) { bc = s_cnt[i]; bi = i; }    // batch order = ascending h
     if (bi >= 0) c->best = H[bi];
@@ -646,13 +656,7 @@ __global__ void __launch_bounds__(PNP_REFINE_THREADS) k_pnp_refine(const double*
   if (tid == 0) out[7] = s_sum[0];
 }
 
-__global__ void k_pnp_init(pnp_ctrl* ctrl, int max_iters) {
-  pnp_ctrl* c = ctrl + blockIdx.x;
-  c->niters = max_iters; c->h_done = 0; c->done = 0; c->pad = 0;
-  c->best.count = 0; c->best.h = -1;
-  for (int i = 0; i < 9; i++) c->best.R[i] = 0;
-  for (int i = 0; i < 3; i++) c->best.t[i] = 0;
-}
+__global__ void k_pnp_init(pnp_ctrl* ctrl, int max_iters) { pnp_ctrl_reset(ctrl + blockIdx.x, max_iters); }
 
 // ================================================================================================
 // host
@@ -696,14 +700,14 @@ static int32_t pnp_alloc(vo_ctx* c, int n) {
   return VO_OK;
 }
 
-static void pnp_enqueue_batch(vo_ctx* c, const vo_pnp_params* prm, const int32_t* counts = nullptr) {
+static void pnp_enqueue_batch(vo_ctx* c, const vo_pnp_params* prm, const int32_t* counts = nullptr, int first = 0) {
   vo_pnp_ws* w = c->pnp;
   const unsigned B = (unsigned)c->batch;
   const double thr2 = prm->reproj_err * prm->reproj_err;
   hipLaunchKernelGGL(k_pnp_solve, dim3(PNP_BATCH / 64, B), dim3(64), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n, (unsigned)prm->seed,
-                     w->d_hyp, w->d_ctrl, counts);
+                     w->d_hyp, w->d_ctrl, counts, first);
   hipLaunchKernelGGL(k_pnp_score, dim3(PNP_BATCH, B), dim3(64), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n, thr2, w->d_hyp, counts);
-  hipLaunchKernelGGL(k_pnp_select, dim3(B), dim3(PNP_BATCH), 0, c->stream, w->d_hyp, w->d_ctrl, w->n, prm->confidence, prm->max_iters, counts);
+  hipLaunchKernelGGL(k_pnp_select, dim3(B), dim3(PNP_BATCH), 0, c->stream, w->d_hyp, w->d_ctrl, w->n, prm->confidence, prm->max_iters, counts, first);
 }
 
 static int32_t pnp_enqueue_refine(vo_ctx* c, const vo_pnp_params* prm, const int32_t* counts = nullptr) {
@@ -742,9 +746,7 @@ int32_t vo_pnp_get_view(vo_ctx* c, vo_pnp_view* v) {
 }
 int32_t vo_pnp_enqueue_counts(vo_ctx* c, const vo_pnp_params* prm, int blind_batches, const int32_t* d_counts) {
   VO_CHECK(c, c->pnp, VO_E_STATE, "vo_pnp_reserve first");
-  vo_pnp_ws* w = c->pnp;
-  hipLaunchKernelGGL(k_pnp_init, dim3((unsigned)c->batch), dim3(1), 0, c->stream, w->d_ctrl, prm->max_iters);
-  for (int k = 0; k < blind_batches; k++) pnp_enqueue_batch(c, prm, d_counts);
+  for (int k = 0; k < blind_batches; k++) pnp_enqueue_batch(c, prm, d_counts, k == 0 ? 1 : 0);     // (blind_batches >= 1: vo_pipe_create)
   return pnp_enqueue_refine(c, prm, d_counts);
 }
 

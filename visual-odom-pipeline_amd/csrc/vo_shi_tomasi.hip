@@ -577,10 +577,37 @@ __device__ __forceinline__ unsigned long long st_uniform64(unsigned long long v)
 #define ST_MAX_CELLS 8192
 #define ST_KP_MAX (ST_CAND_CAP / 1024)
 
+// value of lane (l ^ J) for J = 1 ... 32 without the LDS pipe's address path: DPP quad permutes / row rotation, one swizzle, the two
+// permlane swaps
+template <int J>
+__device__ __forceinline__ uint32_t st_xor_lane(uint32_t x, int lane) {
+  if (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true);        // quad_perm [1, 0, 3, 2]
+  if (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true);        // quad_perm [2, 3, 0, 1]
+  if (J == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x101F);                         // bit mode: and 0x1f, or 0, xor 4
+  if (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true);       // row_ror:8
+  if (J == 16) { const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); return (lane & 16) ? r[0] : r[1]; }
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return (lane & 32) ? r[0] : r[1];
+}
+
+template <int KP, int J>
+__device__ __forceinline__ void st_wave_substep(unsigned long long (&kr)[KP], int ibase, int lane, int k) {
+#pragma unroll
+  for (int q = 0; q < KP; q++) {
+    const int i = ibase + q * 64;
+    const unsigned long long mine = kr[q];
+    const unsigned long long other = ((unsigned long long)st_xor_lane<J>((uint32_t)(mine >> 32), lane) << 32) | st_xor_lane<J>((uint32_t)mine, lane);
+    const bool take_max = (((i & k) == 0) == ((lane & J) == 0));
+    kr[q] = take_max ? (mine > other ? mine : other) : (mine < other ? mine : other);
+  }
+}
+
 // Bitonic sort (descending) of n2 = 1024 * KP keys held in REGISTERS: lane (wave w, lane l) owns keys
 // i = w * 64 KP + q * 64 + l, q < KP.  Compare-exchange distances j < 64 are cross-lane shuffles, 64 <= j < 64 KP
 // are pure register swaps, only j >= 64 KP (between waves) goes through LDS -- LDS latency (~100 cycles per
-// dependent access) is what bounds an all-LDS bitonic sort of this size.
+// dependent access) is what bounds an all-LDS bitonic sort of this size.  What bounds THIS one is vector issue: 2 048 keys x 66 steps x
+// ~12 instructions on 64-bit keys = 38 k cycles (42 k with ds_bpermute exchanges).  Packing a small sort onto 4 waves x 8 keys (3 cross-wave
+// steps instead of 10) was measured and is slower, 60 k: one wave per SIMD cannot hide the exchange latencies.
 template <int KP>
 __device__ __forceinline__ void st_sort_regs(unsigned long long (&kr)[KP], unsigned long long* keys, int tid) {
   const int wave = tid >> 6, lane = tid & 63;
@@ -618,14 +645,15 @@ __device__ __forceinline__ void st_sort_regs(unsigned long long (&kr)[KP], unsig
           }
         }
       } else {
-#pragma unroll
-        for (int q = 0; q < KP; q++) {
-          const int i = ibase + q * 64;
-          const unsigned long long mine = kr[q];
-          const unsigned long long other = __shfl_xor(mine, j);
-          const bool take_max = (((i & k) == 0) == ((lane & j) == 0));
-          kr[q] = take_max ? (mine > other ? mine : other) : (mine < other ? mine : other);
-        }
+        // partner in the same wave: steps j, j / 2, ... 1 in one go, the lane-xor exchanges as VALU / swizzle instructions with compile-time
+        // patterns (a run-time __shfl_xor of a 64-bit key is two ds_bpermute + their address arithmetic per key and step)
+        if (j >= 32) st_wave_substep<KP, 32>(kr, ibase, lane, k);
+        if (j >= 16) st_wave_substep<KP, 16>(kr, ibase, lane, k);
+        if (j >= 8) st_wave_substep<KP, 8>(kr, ibase, lane, k);
+        if (j >= 4) st_wave_substep<KP, 4>(kr, ibase, lane, k);
+        if (j >= 2) st_wave_substep<KP, 2>(kr, ibase, lane, k);
+        st_wave_substep<KP, 1>(kr, ibase, lane, k);
+        break;
       }
     }
   }
