@@ -128,6 +128,22 @@ __device__ __forceinline__ int pipe_rank(const bool* flag, int* rank, int* s_w) 
   return tot;
 }
 
+// block-wide exclusive scan of one count per thread, in thread order; returns the offset of this thread, total = sum over the workgroup
+__device__ __forceinline__ int pipe_scan_count(int cnt, int* s_w, int& total) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int x = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+  __syncthreads();                       // s_w may still be read from the previous call
+  if (lane == 63) s_w[wave] = x;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) { const int v = s_w[w]; if (w < wave) off += v; tot += v; }
+  total = tot;
+  return off + x - cnt;
+}
+
 __device__ __forceinline__ float2* pipe_hist_slot(const pipe_ptrs& P, int idx) { return P.k_hist + (size_t)(idx & (PIPE_HIST - 1)) * P.R; }
 
 __device__ __forceinline__ void pipe_copy_K(const pipe_ptrs& P, int dst, int src) {
@@ -706,29 +722,34 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_spawn(pipe_ptrs Pall, int do_
     if (tid == 0) { P.cnt[C_NCAND] = nc; P.cnt[C_NPTS] = nl + nc; Pall.dn[DN_PTS * gridDim.x + b] = nl + nc; P.cnt[C_HEADK] = headK + m; }
   }
   __syncthreads();
-  // ---- rows no list refers to go back to the free lists (ascending) ----
+  // ---- rows no list refers to go back to the free lists (ascending).  Both mark arrays live in LDS (one byte per row), a thread owns
+  //      RPT consecutive rows, so the two free lists cost two block scans and no global round trip besides reading the lists (the earlier
+  //      form marked in global scratch and scanned the R rows 1 024 at a time: 16 scans, 8 global phases) ----
   const int nd = P.cnt[C_NDEAD];
-  for (int pass = 0; pass < 2; pass++) {
-    for (int i = tid; i < P.R; i += PIPE_TPB) P.scr[i] = 0;
+  {
+    __shared__ uint32_t s_mark[2][PIPE_TPB * PIPE_CH];            // [K | L][R / 4]: R <= 4 * max_pts <= 16 384 bytes each
+    uint8_t* const mk = reinterpret_cast<uint8_t*>(s_mark[0]);
+    uint8_t* const ml = reinterpret_cast<uint8_t*>(s_mark[1]);
+    for (int i = tid; i < (P.R + 3) / 4; i += PIPE_TPB) { s_mark[0][i] = 0; s_mark[1][i] = 0; }
     __syncthreads();
     for (int j = tid; j < P.N; j += PIPE_TPB) {
-      if (pass == 0) { if (j < nc) P.scr[P.cand[j]] = 1; if (j < nl) P.scr[P.lm_K[j]] = 1; if (j < nd) P.scr[P.dead_K[j]] = 1; }
-      else { if (j < nl) P.scr[P.lm_L[j]] = 1; if (j < nd) P.scr[P.dead_L[j]] = 1; }
+      if (j < nc) mk[P.cand[j]] = 1;
+      if (j < nl) { mk[P.lm_K[j]] = 1; ml[P.lm_L[j]] = 1; }
+      if (j < nd) { mk[P.dead_K[j]] = 1; ml[P.dead_L[j]] = 1; }
     }
     __syncthreads();
-    int32_t* fl = pass == 0 ? P.freeK : P.freeL;
-    int base = 0;
-    for (int i0 = 0; i0 < P.R; i0 += PIPE_TPB) {
-      const int i = i0 + tid;
-      const int fr = (i < P.R && P.scr[i] == 0) ? 1 : 0;
-      int tot;
-      const int pos = pipe_scan(fr, s_w, tot);
-      if (fr) fl[base + pos] = i;
-      base += tot;
+    const int rpt = (P.R + PIPE_TPB - 1) / PIPE_TPB;             // rows per thread (<= 16)
+    const int r0 = min(tid * rpt, P.R), r1 = min(r0 + rpt, P.R);
+    for (int pass = 0; pass < 2; pass++) {
+      const uint8_t* m = pass == 0 ? mk : ml;
+      int32_t* fl = pass == 0 ? P.freeK : P.freeL;
+      int cnt = 0;
+      for (int i = r0; i < r1; i++) cnt += m[i] == 0 ? 1 : 0;
+      int total;
+      int pos = pipe_scan_count(cnt, s_w, total);
+      for (int i = r0; i < r1; i++) if (m[i] == 0) fl[pos++] = i;
+      if (tid == 0) { P.cnt[pass == 0 ? C_NFREEK : C_NFREEL] = total; P.cnt[pass == 0 ? C_HEADK : C_HEADL] = 0; }
     }
-    __syncthreads();
-    if (tid == 0) { P.cnt[pass == 0 ? C_NFREEK : C_NFREEL] = base; P.cnt[pass == 0 ? C_HEADK : C_HEADL] = 0; }
-    __syncthreads();
   }
   if (tid == 0) {
     r.t = t; r.status = P.cnt[C_STATUS]; r.overflow = overflow;
