@@ -193,22 +193,35 @@ __device__ inline void pipe_log_so3(const double* R, double* r) {
 // ================================================================================================
 // k_pipe_extend: the keep rule and bookkeeping after the KLT of [landmark keypoints | candidates]
 // ================================================================================================
+// The kernel is a chain of phases of ONE workgroup, so what it costs is the number of dependent trips to global memory, not the work: the
+// first form made ~24 of them (row fields fetched where they were needed, free rows fetched when their rank was known, the leader election
+// and the t_latest increments as global atomics, every row copy a chain of 32 load-store pairs in one thread: 31 us for one sequence,
+// 75 in a batch of 32).  Now: (1) counters, (2) the lists and the tracked points, (3) EVERY row field any phase will need plus a window
+// of both free lists into LDS, then all bookkeeping on registers and LDS words (one word per landmark row: survivor count, then the
+// election), (4) the row copies as one cooperative pass of the whole workgroup over a work list.
+// Dynamic LDS: int32 [R] per-landmark-row word | [N] free K rows | [N] free L rows | [N] copy sources  (28 bytes per slot of the table)
 template <int CH>
 __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const float* __restrict__ pts, size_t slab_seq, int W, int H,
                                                           float* __restrict__ pnp_X, float* __restrict__ pnp_uv, int pnp_cap) {
+  extern __shared__ int32_t s_dyn[];
   __shared__ int s_w[16];
   const int b = blockIdx.x, tid = threadIdx.x;
   const pipe_ptrs P = pipe_select(Pall, b);
   if (P.cnt[C_STATUS]) return;
+  int32_t* const s_row = s_dyn;
+  int32_t* const s_fk = s_row + P.R;
+  int32_t* const s_fl = s_fk + P.N;
+  int32_t* const s_src = s_fl + P.N;
   const float2* p1 = reinterpret_cast<const float2*>(vo_seq(pts, slab_seq, b));
   pnp_X += (size_t)b * pnp_cap * 3; pnp_uv += (size_t)b * pnp_cap * 2;
+  // ---- trip 1: counters ----
   const int nl = P.cnt[C_NLM], nc = P.cnt[C_NCAND], nd0 = P.cnt[C_NDEAD];
   int headK = P.cnt[C_HEADK], headL = P.cnt[C_HEADL];
   const int nfK = P.cnt[C_NFREEK], nfL = P.cnt[C_NFREEL];
   int overflow = 0, inert = 0;
   __syncthreads();                                   // every thread has read the counters before thread 0 rewrites them
 
-  // ---- everything this workgroup will touch is read first ----
+  // ---- trip 2: the lists and the tracked positions ----
   int L[CH], K[CH], KC[CH];
   bool keep[CH], die[CH], ksh[CH], keepc[CH];
   float2 q[CH], qc[CH];
@@ -223,6 +236,24 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
     }
     if (j < nc) { KC[c] = P.cand[j]; qc[c] = p1[nl + j]; keepc[c] = pipe_inside(qc[c], W, H); }
   }
+  // ---- trip 3: every row field the phases below need, and the heads of the free lists ----
+  int len[CH], tt[CH], tl[CH], lenc[CH], ttc[CH];
+  double lp[CH][3];
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    const int j = tid * CH + c;
+    len[c] = tt[c] = tl[c] = lenc[c] = ttc[c] = 0; lp[c][0] = lp[c][1] = lp[c][2] = 0.0;
+    if (j < nl) {
+      len[c] = P.k_len[K[c]]; tt[c] = P.k_tt[K[c]]; tl[c] = P.l_tl[L[c]];
+      for (int k = 0; k < 3; k++) lp[c][k] = P.l_p[3 * (size_t)L[c] + k];
+      s_row[L[c]] = 0;                               // (entries that share a row all write 0)
+    }
+    if (j < nc) { lenc[c] = P.k_len[KC[c]]; ttc[c] = P.k_tt[KC[c]]; }
+  }
+  for (int i = tid; i < P.N; i += PIPE_TPB) {        // no phase takes more than N rows of either kind
+    s_fk[i] = (headK + i < nfK) ? P.freeK[headK + i] : -1;
+    s_fl[i] = (headL + i < nfL) ? P.freeL[headL + i] : -1;
+  }
   __syncthreads();
 
   // ---- candidates (extend_tracks): survivors get uv, t_total + 1, a history entry; ordered compaction ----
@@ -232,35 +263,45 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
 #pragma unroll
     for (int c = 0; c < CH; c++)
       if (keepc[c]) {
-        const int k = KC[c], len = P.k_len[k];
-        P.k_uv[k] = qc[c]; P.k_tt[k] += 1; pipe_hist_slot(P, len)[k] = qc[c]; P.k_len[k] = len + 1;
+        const int k = KC[c];
+        P.k_uv[k] = qc[c]; P.k_tt[k] = ttc[c] + 1; pipe_hist_slot(P, lenc[c])[k] = qc[c]; P.k_len[k] = lenc[c] + 1;
         P.cand[rank[c]] = k;
       }
     if (tid == 0) P.cnt[C_NCAND] = n_out;
   }
 
-  // ---- landmarks, phase A: survivors update their keypoint row and their landmark's t_latest (several entries may share an L row) ----
+  // ---- landmarks: survivors update their keypoint row IN PLACE (extractor.py:80-83: the deepcopy comes after) and count into their
+  //      landmark row's word -- several entries may share a landmark object, which then advances by as many frames ----
 #pragma unroll
   for (int c = 0; c < CH; c++)
     if (keep[c]) {
-      const int k = K[c], len = P.k_len[k];
-      P.k_uv[k] = q[c]; P.k_tt[k] += 1; pipe_hist_slot(P, len)[k] = q[c]; P.k_len[k] = len + 1;
-      atomicAdd(&P.l_tl[L[c]], 1);
+      const int k = K[c];
+      P.k_uv[k] = q[c]; P.k_tt[k] = tt[c] + 1; pipe_hist_slot(P, len[c])[k] = q[c]; P.k_len[k] = len[c] + 1;
+      atomicAdd(&s_row[L[c]], 1);                    // LDS
     }
-  // ---- phase B: deepcopy(k) of a survivor (extractor.py:85) matters only when the dead list holds the same keypoint object ----
+  __syncthreads();
+  int tlf[CH];                                       // t_latest of the entry's landmark object after this frame
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    const int j = tid * CH + c;
+    tlf[c] = (j < nl) ? tl[c] + s_row[L[c]] : 0;
+    if (keep[c]) P.l_tl[L[c]] = tlf[c];              // (the same value from every entry that shares the row)
+  }
+  // ---- deepcopy(k) of a survivor (extractor.py:85) matters only when the dead list holds the same keypoint object: own row, copied
+  //      AFTER the in-place update (the cooperative pass below runs behind a barrier) ----
+  int n_copy = 0;
   {
     bool f[CH]; int rank[CH];
 #pragma unroll
     for (int c = 0; c < CH; c++) f[c] = keep[c] && ksh[c];
-    const int tot = pipe_rank<CH>(f, rank, s_w);
+    const int tot = pipe_rank<CH>(f, rank, s_w);      // (its barriers also order the reads of s_row above before the election below)
     if (headK + tot > nfK) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_CAPACITY; return; }
 #pragma unroll
     for (int c = 0; c < CH; c++)
-      if (f[c]) { const int nk = P.freeK[headK + rank[c]]; pipe_copy_K(P, nk, K[c]); K[c] = nk; }
-    headK += tot;
+      if (f[c]) { s_src[rank[c]] = K[c]; K[c] = s_fk[rank[c]]; }
+    n_copy = tot;
   }
-  __syncthreads();                                   // all t_latest increments are done before anything copies an L row
-  // ---- phase C: what died is deep-copied into the dead lists (pipeline.py:101-102).  One deepcopy call per list: entries that share a
+  // ---- what died is deep-copied into the dead lists (pipeline.py:101-102).  One deepcopy call per list: entries that share a
   //      landmark object share its copy -> the entry with the smallest index copies the row for all of them ----
   {
     int drank[CH];
@@ -268,37 +309,50 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
     const int room = P.N - nd0;
     bool ok[CH], lead[CH];
 #pragma unroll
-    for (int c = 0; c < CH; c++) { ok[c] = die[c] && drank[c] < room; if (ok[c]) st_i32(&P.scr[L[c]], 0x7FFFFFFF); }
+    for (int c = 0; c < CH; c++) { ok[c] = die[c] && drank[c] < room; if (ok[c]) s_row[L[c]] = 0x7FFFFFFF; }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < CH; c++) if (ok[c]) atomicMin(&P.scr[L[c]], tid * CH + c);
+    for (int c = 0; c < CH; c++) if (ok[c]) atomicMin(&s_row[L[c]], tid * CH + c);
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < CH; c++) lead[c] = ok[c] && ld_i32(&P.scr[L[c]]) == tid * CH + c;
+    for (int c = 0; c < CH; c++) lead[c] = ok[c] && s_row[L[c]] == tid * CH + c;
     int lrank[CH], krank[CH];
-    const int n_lead = pipe_rank<CH>(lead, lrank, s_w);  // (its barriers also separate the reads of scr above from the writes below)
+    const int n_lead = pipe_rank<CH>(lead, lrank, s_w);  // (its barriers also separate the reads of s_row above from the writes below)
     const int n_ok = pipe_rank<CH>(ok, krank, s_w);
-    if (headL + n_lead > nfL || headK + n_ok > nfK) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_CAPACITY; return; }
+    if (headL + n_lead > nfL || headK + n_copy + n_ok > nfK) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_CAPACITY; return; }
 #pragma unroll
     for (int c = 0; c < CH; c++)
       if (lead[c]) {
-        const int nlr = P.freeL[headL + lrank[c]];
-        P.l_tl[nlr] = ld_i32(&P.l_tl[L[c]]);
-        for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = P.l_p[3 * (size_t)L[c] + k];
-        st_i32(&P.scr[L[c]], nlr);
+        const int nlr = s_fl[lrank[c]];
+        P.l_tl[nlr] = tlf[c];
+        for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = lp[c][k];
+        s_row[L[c]] = nlr;
       }
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < CH; c++)
       if (ok[c]) {
-        const int nk = P.freeK[headK + krank[c]];
-        pipe_copy_K(P, nk, K[c]);
-        P.dead_L[nd0 + drank[c]] = ld_i32(&P.scr[L[c]]);
-        P.dead_K[nd0 + drank[c]] = nk;
+        const int slot = n_copy + krank[c];
+        s_src[slot] = K[c];
+        P.dead_L[nd0 + drank[c]] = s_row[L[c]];
+        P.dead_K[nd0 + drank[c]] = s_fk[slot];
       }
-    headL += n_lead; headK += n_ok;
+    headL += n_lead; headK += n_copy + n_ok;
+    n_copy += n_ok;
     if (n_die > n_ok) { overflow |= 1; inert = n_die - n_ok; }
     if (tid == 0) P.cnt[C_NDEAD] = nd0 + n_ok;
+  }
+  __syncthreads();                                   // the in-place row updates and the work list are complete
+  // ---- trip 4: the row copies src = s_src[i] -> dst = s_fk[i], 37 values each, spread over the workgroup ----
+  for (int e = tid; e < n_copy * 40; e += PIPE_TPB) {
+    const int i = e / 40, f = e - i * 40;
+    const int src = s_src[i], dst = s_fk[i];
+    if (f < PIPE_HIST) P.k_hist[(size_t)f * P.R + dst] = P.k_hist[(size_t)f * P.R + src];
+    else if (f == 32) P.k_tf[dst] = P.k_tf[src];
+    else if (f == 33) P.k_tt[dst] = P.k_tt[src];
+    else if (f == 34) P.k_len[dst] = P.k_len[src];
+    else if (f == 35) P.k_uv[dst] = P.k_uv[src];
+    else if (f == 36) P.k_first[dst] = P.k_first[src];
   }
   // ---- ordered compaction of the landmark list; the survivors are the 3D-2D correspondences of the pose stage (extractor.py:176-177) ----
   {
@@ -310,7 +364,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
         const int o = rank[c];
         P.lm_L[o] = L[c]; P.lm_K[o] = K[c]; P.lm_ksh[o] = 0;
         pnp_uv[2 * o] = q[c].x; pnp_uv[2 * o + 1] = q[c].y;
-        for (int k = 0; k < 3; k++) pnp_X[3 * o + k] = (float)P.l_p[3 * (size_t)L[c] + k];
+        for (int k = 0; k < 3; k++) pnp_X[3 * o + k] = (float)lp[c][k];
       }
     if (tid == 0) {
       P.cnt[C_NLM] = n_out; P.cnt[C_NPNP] = n_out; P.cnt[C_NKLT] = nl + nc;
@@ -860,6 +914,9 @@ static int32_t pipe_create(vo_ctx* c, const double* K, const vo_pipe_params* prm
   const unsigned fl = hipEventDisableTiming | ((getenv("VO_BLOCKING_SYNC") && atoi(getenv("VO_BLOCKING_SYNC"))) ? hipEventBlockingSync : 0u);
   for (int i = 0; i < VO_PIPE_INFLIGHT; i++) VO_HIP(c, hipEventCreateWithFlags(&w->ev[i], fl));
   VO_HIP(c, hipEventCreateWithFlags(&w->ev_track, hipEventDisableTiming));
+  // k_pipe_extend keeps 28 bytes of LDS per table slot (112 KB at 4 096 slots: above the default limit of a launch)
+  VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_extend<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 28 * PIPE_TPB * PIPE_CH));
+  VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_extend<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 28 * PIPE_TPB * 2));
   VO_HIP(c, hipMemcpyAsync(w->d_K, K, 72 * B, hipMemcpyHostToDevice, c->stream));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   int32_t r = vo_ba_reserve(c, K, prm->ba_window, w->N);
@@ -1003,8 +1060,16 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
       if (r == VO_OK) { VO_HIP(c, e1); VO_HIP(c, e2); }
     }
     if (r != VO_OK) return r;
-    PIPE_DISPATCH(k_pipe_extend, P, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq, c->width, c->height,
-                       pv.X, pv.uv, pv.cap);
+    {
+      const size_t lds = sizeof(int32_t) * ((size_t)w->R + 3 * (size_t)w->N);
+      auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(c->batch), dim3(PIPE_TPB), lds, c->stream, P, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq,
+                           c->width, c->height, pv.X, pv.uv, pv.cap);
+      };
+      if (w->N <= PIPE_TPB) launch(k_pipe_extend<1>);
+      else if (w->N <= 2 * PIPE_TPB) launch(k_pipe_extend<2>);
+      else launch(k_pipe_extend<4>);
+    }
   }
   if (stages & VO_PIPE_POSE) {
     r = vo_pnp_enqueue_counts(c, &prm.pnp, prm.pnp_blind_batches, w->d_dn + DN_PNP * B);
