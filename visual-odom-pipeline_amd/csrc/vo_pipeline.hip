@@ -378,35 +378,63 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
 // ================================================================================================
 // k_pipe_prune: PnP result -> trajectory, non-inliers to the dead lists; ripe candidates -> DLT inputs
 // ================================================================================================
+// (same construction as k_pipe_extend: lists, then every row field and the free-list heads in one trip, the keypoint-row copies as one
+//  cooperative pass.)  Dynamic LDS: int32 [N] free K rows | [N] free L rows | [N] copy sources
 template <int CH>
 __global__ void __launch_bounds__(PIPE_TPB) k_pipe_prune(pipe_ptrs Pall, int do_pose, int do_tri, const uint8_t* __restrict__ mask, const double* __restrict__ pnp_out,
                                                          int pnp_cap, int min_len, float* __restrict__ uv0, float* __restrict__ uv1, size_t uv_seq,
                                                          vo_dlt_cam* __restrict__ cams, int32_t* __restrict__ cam_sel) {
+  extern __shared__ int32_t s_dyn[];
   __shared__ int s_w[16];
   __shared__ int s_present[PIPE_HIST];
   __shared__ int s_bad;
   const int b = blockIdx.x, tid = threadIdx.x;
   const pipe_ptrs P = pipe_select(Pall, b);
   if (P.cnt[C_STATUS]) return;
+  int32_t* const s_fk = s_dyn;
+  int32_t* const s_fl = s_fk + P.N;
+  int32_t* const s_src = s_fl + P.N;
   mask += (size_t)b * pnp_cap; pnp_out += 8 * (size_t)b;
   uv0 += (size_t)b * uv_seq; uv1 += (size_t)b * uv_seq; cam_sel += (size_t)b * P.N;
+  // ---- trip 1: counters, the pose ----
   const int nl = P.cnt[C_NLM], nc = P.cnt[C_NCAND], nd0 = P.cnt[C_NDEAD], t = P.cnt[C_T];
   int headK = P.cnt[C_HEADK], headL = P.cnt[C_HEADL];
   const int nfK = P.cnt[C_NFREEK], nfL = P.cnt[C_NFREEL];
   int overflow = P.cnt[C_OVERFLOW];
+  const double n_inl = do_pose ? pnp_out[7] : 4.0;
   if (tid == 0) s_bad = 0;
+  if (tid < PIPE_HIST) s_present[tid] = 0;
   __syncthreads();
-  if (do_pose) {
-    if (!(pnp_out[7] >= 4.0)) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_LOST; return; }      // cv2.solvePnPRansac found nothing: the reference crashes here
-    int L[CH], K[CH];
-    bool in[CH], out[CH];
+  if (do_pose && !(n_inl >= 4.0)) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_LOST; return; }      // cv2.solvePnPRansac found nothing: the reference crashes here
+  // ---- trip 2: lists, inlier mask ----
+  int L[CH], K[CH], KC[CH];
+  bool in[CH], out[CH];
 #pragma unroll
-    for (int c = 0; c < CH; c++) {
-      const int j = tid * CH + c;
-      L[c] = K[c] = 0; in[c] = out[c] = false;
-      if (j < nl) { L[c] = P.lm_L[j]; K[c] = P.lm_K[j]; in[c] = mask[j] != 0; out[c] = !in[c]; }
+  for (int c = 0; c < CH; c++) {
+    const int j = tid * CH + c;
+    L[c] = K[c] = KC[c] = 0; in[c] = out[c] = false;
+    if (do_pose && j < nl) { L[c] = P.lm_L[j]; K[c] = P.lm_K[j]; in[c] = mask[j] != 0; out[c] = !in[c]; }
+    if (do_tri && j < nc) KC[c] = P.cand[j];
+  }
+  // ---- trip 3: row fields, free-list heads ----
+  int tlo[CH], ttc[CH], tfc[CH];
+  double lp[CH][3];
+  float2 fst[CH], cur[CH];
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    const int j = tid * CH + c;
+    tlo[c] = ttc[c] = tfc[c] = 0; lp[c][0] = lp[c][1] = lp[c][2] = 0.0; fst[c] = cur[c] = make_float2(0.f, 0.f);
+    if (out[c]) { tlo[c] = P.l_tl[L[c]]; for (int k = 0; k < 3; k++) lp[c][k] = P.l_p[3 * (size_t)L[c] + k]; }
+    if (do_tri && j < nc) { ttc[c] = P.k_tt[KC[c]]; tfc[c] = P.k_tf[KC[c]]; fst[c] = P.k_first[KC[c]]; cur[c] = P.k_uv[KC[c]]; }
+  }
+  if (do_pose)
+    for (int i = tid; i < P.N; i += PIPE_TPB) {
+      s_fk[i] = (headK + i < nfK) ? P.freeK[headK + i] : -1;
+      s_fl[i] = (headL + i < nfL) ? P.freeL[headL + i] : -1;
     }
-    __syncthreads();
+  __syncthreads();
+  int n_copy = 0;
+  if (do_pose) {
     // non-inliers: deepcopy per entry (pipeline.py:133-134), every one gets its own L and K copy
     int drank[CH], rank[CH];
     const int n_out = pipe_rank<CH>(out, drank, s_w);
@@ -416,15 +444,16 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_prune(pipe_ptrs Pall, int do_
 #pragma unroll
     for (int c = 0; c < CH; c++)
       if (out[c] && drank[c] < room) {
-        const int nlr = P.freeL[headL + drank[c]], nk = P.freeK[headK + drank[c]];
-        P.l_tl[nlr] = P.l_tl[L[c]];
-        for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = P.l_p[3 * (size_t)L[c] + k];
-        pipe_copy_K(P, nk, K[c]);
+        const int nlr = s_fl[drank[c]], nk = s_fk[drank[c]];
+        P.l_tl[nlr] = tlo[c];
+        for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = lp[c][k];
+        s_src[drank[c]] = K[c];
         P.dead_L[nd0 + drank[c]] = nlr; P.dead_K[nd0 + drank[c]] = nk;
       }
+    n_copy = n_ok;
     headL += n_ok; headK += n_ok;
     if (n_out > n_ok) overflow |= 1;
-    const int n_in = pipe_rank<CH>(in, rank, s_w);
+    const int n_in = pipe_rank<CH>(in, rank, s_w);     // (its barriers also publish the work list)
 #pragma unroll
     for (int c = 0; c < CH; c++) if (in[c]) { P.lm_L[rank[c]] = L[c]; P.lm_K[rank[c]] = K[c]; P.lm_ksh[rank[c]] = 0; }
     if (tid == 0) {
@@ -435,21 +464,30 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_prune(pipe_ptrs Pall, int do_
       double* Hd = P.H + 12 * (size_t)(t & (PIPE_HIST - 1));
       for (int r = 0; r < 3; r++) { for (int k = 0; k < 3; k++) Hd[4 * r + k] = R[3 * r + k]; Hd[4 * r + 3] = pnp_out[3 + r]; }
     }
+    // the keypoint-row copies src = s_src[i] -> dst = s_fk[i]
+    for (int e = tid; e < n_copy * 40; e += PIPE_TPB) {
+      const int i = e / 40, f = e - i * 40;
+      const int src = s_src[i], dst = s_fk[i];
+      if (f < PIPE_HIST) P.k_hist[(size_t)f * P.R + dst] = P.k_hist[(size_t)f * P.R + src];
+      else if (f == 32) P.k_tf[dst] = P.k_tf[src];
+      else if (f == 33) P.k_tt[dst] = P.k_tt[src];
+      else if (f == 34) P.k_len[dst] = P.k_len[src];
+      else if (f == 35) P.k_uv[dst] = P.k_uv[src];
+      else if (f == 36) P.k_first[dst] = P.k_first[src];
+    }
   }
-  __syncthreads();
+  __syncthreads();                                     // the new pose is in the ring
   if (do_tri) {
     // triangulate_tracks (extractor.py:202-203): candidates that reached min_track_length leave the list whether or not they succeed.
     // They are triangulated in groups by birth frame, each against the pose of its birth frame (:210-220); a group is named by its AGE
     // a = t - t_first (the slot distance in the 32-frame trajectory ring)
-    int KC[CH], age[CH]; bool ripe[CH], wait[CH];
-    if (tid < PIPE_HIST) s_present[tid] = 0;
+    int age[CH]; bool ripe[CH], wait[CH];
 #pragma unroll
     for (int c = 0; c < CH; c++) {
       const int j = tid * CH + c;
-      KC[c] = 0; age[c] = 0; ripe[c] = wait[c] = false;
-      if (j < nc) { KC[c] = P.cand[j]; ripe[c] = P.k_tt[KC[c]] >= min_len; wait[c] = !ripe[c]; age[c] = t - P.k_tf[KC[c]]; }
+      age[c] = 0; ripe[c] = wait[c] = false;
+      if (j < nc) { ripe[c] = ttc[c] >= min_len; wait[c] = !ripe[c]; age[c] = t - tfc[c]; }
     }
-    __syncthreads();
     int rr[CH], wr[CH];
     const int n_ripe = pipe_rank<CH>(ripe, rr, s_w);
     const int n_wait = pipe_rank<CH>(wait, wr, s_w);
@@ -458,8 +496,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_prune(pipe_ptrs Pall, int do_
       if (ripe[c]) {
         if (age[c] < 0 || age[c] >= PIPE_HIST || age[c] > t) s_bad = 1;       // the birth pose has left the trajectory ring
         else s_present[age[c]] = 1;
-        const float2 a = P.k_first[KC[c]], q = P.k_uv[KC[c]];
-        uv0[2 * rr[c]] = a.x; uv0[2 * rr[c] + 1] = a.y; uv1[2 * rr[c]] = q.x; uv1[2 * rr[c] + 1] = q.y;
+        uv0[2 * rr[c]] = fst[c].x; uv0[2 * rr[c] + 1] = fst[c].y; uv1[2 * rr[c]] = cur[c].x; uv1[2 * rr[c] + 1] = cur[c].y;
         P.ripe[rr[c]] = KC[c]; cam_sel[rr[c]] = age[c] & (PIPE_HIST - 1);
       }
       if (wait[c]) P.cand[wr[c]] = KC[c];
@@ -1076,8 +1113,16 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
     if (r != VO_OK) return r;
   }
   if (stages & (VO_PIPE_POSE | VO_PIPE_TRIANGULATE))
-    PIPE_DISPATCH(k_pipe_prune, P, (stages & VO_PIPE_POSE) ? 1 : 0, (stages & VO_PIPE_TRIANGULATE) ? 1 : 0,
-                       pv.mask, pv.out, pv.cap, prm.min_track_length, c->d_uv0, c->d_uv1, (size_t)c->max_pts * 2, w->d_cams, w->d_cam_sel);
+  {
+    const size_t lds = sizeof(int32_t) * 3 * (size_t)w->N;
+    auto launch = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(c->batch), dim3(PIPE_TPB), lds, c->stream, P, (stages & VO_PIPE_POSE) ? 1 : 0, (stages & VO_PIPE_TRIANGULATE) ? 1 : 0,
+                         pv.mask, pv.out, pv.cap, prm.min_track_length, c->d_uv0, c->d_uv1, (size_t)c->max_pts * 2, w->d_cams, w->d_cam_sel);
+    };
+    if (w->N <= PIPE_TPB) launch(k_pipe_prune<1>);
+    else if (w->N <= 2 * PIPE_TPB) launch(k_pipe_prune<2>);
+    else launch(k_pipe_prune<4>);
+  }
   if (stages & VO_PIPE_TRIANGULATE) {
     r = vo_dlt_enqueue_counts(c, w->N, w->d_dn + DN_RIPE * B, w->d_cams, w->d_cam_sel, PIPE_HIST);
     if (r != VO_OK) return r;
