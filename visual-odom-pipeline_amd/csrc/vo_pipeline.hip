@@ -526,53 +526,92 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_prune(pipe_ptrs Pall, int do_
 // ================================================================================================
 // k_pipe_promote: triangulation filters + gate + promotion; then the selection half of BundleAdjuster.adjust
 // ================================================================================================
+// (Constructed like k_pipe_extend: trip 1 counters; trip 2 every list and per-candidate input, the free-row window and the whole trajectory
+//  ring into LDS; trip 3 the row fields of the dead entries, of the EXISTING state entries -- thread j owns final entry j, and entries are
+//  only appended -- and of the candidates; trips 4 / 5 the rows of appended entries and the history entries of the observation table.
+//  The landmark list is kept in LDS while it grows, "this landmark row is in the state's list" is a byte per row in LDS.)
+// Dynamic LDS: int32 [N] landmark rows of the list | [N] keypoint rows of the list | [N] free L rows | bytes [R] row-in-list marks
 template <int CH>
 __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int do_tri, int do_adjust, const float* __restrict__ X4, const double* __restrict__ depth1,
                                                            const double* __restrict__ reproj, size_t slab_seq, int x4_stride, double max_err,
                                                            double min_angle, const int32_t* __restrict__ cam_sel, int Wn, int resurrect, double* __restrict__ x0, double* __restrict__ obs,
                                                            size_t x_stride, size_t obs_stride, int Nba, float* __restrict__ pts, size_t pts_seq) {
+  extern __shared__ int32_t s_dyn[];
   __shared__ int s_w[16];
   __shared__ int s_first[PIPE_HIST], s_gate[PIPE_HIST];
+  __shared__ double s_p3[PIPE_HIST][3];
+  __shared__ double s_H[PIPE_HIST * 12];
   __shared__ int s_nobs;
   const int b = blockIdx.x, tid = threadIdx.x;
   const pipe_ptrs P = pipe_select(Pall, b);
   if (P.cnt[C_STATUS]) return;
+  int32_t* const s_lmL = s_dyn;
+  int32_t* const s_lmK = s_lmL + P.N;
+  int32_t* const s_fl = s_lmK + P.N;
+  uint8_t* const s_mark = reinterpret_cast<uint8_t*>(s_fl + P.N);
   X4 = vo_seq(X4, slab_seq, b); depth1 = vo_seq(depth1, slab_seq, b); reproj = vo_seq(reproj, slab_seq, b);
   cam_sel += (size_t)b * P.N;
   x0 += (size_t)b * x_stride; obs += (size_t)b * obs_stride;
+  // ---- trip 1: counters ----
   const int t = P.cnt[C_T], nc = P.cnt[C_NCAND], n_ripe = do_tri ? P.cnt[C_NRIPE] : 0, nd0 = P.cnt[C_NDEAD];
-  int nl = P.cnt[C_NLM];
-  int headL = P.cnt[C_HEADL];
+  const int nl0 = P.cnt[C_NLM];
+  int nl = nl0;
+  const int headL0 = P.cnt[C_HEADL];
   const int nfL = P.cnt[C_NFREEL];
   int overflow = P.cnt[C_OVERFLOW];
   if (tid == 0) s_nobs = 0;
+  if (tid < PIPE_HIST) { s_first[tid] = 0x7FFFFFFF; s_gate[tid] = 0; }
   __syncthreads();
-  int n_new = 0;
+  // ---- trip 2: lists, candidates of the triangulation, free rows, trajectory ring ----
+  bool kept[CH]; float pt[CH][3]; int age[CH], rk[CH];
+  int DL[CH], DK[CH], eL[CH], eK[CH], cK[CH];
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    const int j = tid * CH + c;
+    kept[c] = false; age[c] = 0; rk[c] = 0; pt[c][0] = pt[c][1] = pt[c][2] = 0.f;
+    DL[c] = DK[c] = eL[c] = eK[c] = cK[c] = 0;
+    if (j < n_ripe) {
+      const float w4 = X4[(size_t)3 * x4_stride + j];
+      for (int k = 0; k < 3; k++) pt[c][k] = X4[(size_t)k * x4_stride + j] / w4;          // numpy float32 divide (extractor.py:271)
+      kept[c] = depth1[j] > 0.0 && reproj[j] < max_err;                                    // triangulate.py:87-111
+      age[c] = cam_sel[j]; rk[c] = P.ripe[j];
+    }
+    if (do_adjust && j < nd0) { DL[c] = P.dead_L[j]; DK[c] = P.dead_K[j]; }
+    if (j < nl0) { eL[c] = P.lm_L[j]; eK[c] = P.lm_K[j]; s_lmL[j] = eL[c]; s_lmK[j] = eK[c]; }
+    if (j < nc) cK[c] = P.cand[j];
+  }
+  for (int i = tid; i < P.N; i += PIPE_TPB) s_fl[i] = (headL0 + i < nfL) ? P.freeL[headL0 + i] : -1;
+  for (int i = tid; i < PIPE_HIST * 12; i += PIPE_TPB) s_H[i] = P.H[i];
+  // ---- trip 3: row fields ----
+  int dtl[CH], dlen[CH], elen[CH], etl[CH];
+  double ep[CH][3];
+  float2 euv[CH], cuv[CH];
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    const int j = tid * CH + c;
+    dtl[c] = dlen[c] = elen[c] = etl[c] = 0; ep[c][0] = ep[c][1] = ep[c][2] = 0.0; euv[c] = cuv[c] = make_float2(0.f, 0.f);
+    if (do_adjust && j < nd0) { dtl[c] = P.l_tl[DL[c]]; dlen[c] = P.k_len[DK[c]]; }
+    if (j < nl0) {
+      elen[c] = P.k_len[eK[c]]; etl[c] = P.l_tl[eL[c]]; euv[c] = P.k_uv[eK[c]];
+      for (int k = 0; k < 3; k++) ep[c][k] = P.l_p[3 * (size_t)eL[c] + k];
+    }
+    if (j < nc) cuv[c] = P.k_uv[cK[c]];
+  }
+  __syncthreads();
+  int n_new = 0, fl_off = 0;
   if (do_tri && n_ripe > 0) {
-    bool kept[CH]; float pt[CH][3]; int age[CH];
-    if (tid < PIPE_HIST) { s_first[tid] = 0x7FFFFFFF; s_gate[tid] = 0; }
+#pragma unroll
+    for (int c = 0; c < CH; c++) if (kept[c]) atomicMin(&s_first[age[c]], tid * CH + c);
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < CH; c++) {
-      const int j = tid * CH + c;
-      kept[c] = false; age[c] = 0;
-      if (j < n_ripe) {
-        const float w4 = X4[(size_t)3 * x4_stride + j];
-        for (int k = 0; k < 3; k++) pt[c][k] = X4[(size_t)k * x4_stride + j] / w4;          // numpy float32 divide (extractor.py:271)
-        kept[c] = depth1[j] > 0.0 && reproj[j] < max_err;                                    // triangulate.py:87-111
-        age[c] = cam_sel[j];
-        if (kept[c]) atomicMin(&s_first[age[c]], j);
-      }
-    }
+    for (int c = 0; c < CH; c++)
+      if (kept[c] && s_first[age[c]] == tid * CH + c) for (int k = 0; k < 3; k++) s_p3[age[c]][k] = (double)pt[c][k];
     __syncthreads();
     if (tid < PIPE_HIST && s_first[tid] != 0x7FFFFFFF) {
       // the reference's "bearing angle" of the group's FIRST landmark (extractor.py:231-240): a = Frobenius norm of the 4x4 relative
       // transform, b = |H0 [p; 0]|, c = |H1 [p; 0]|, law of cosines in degrees; NaN rejects
-      const int j0 = s_first[tid];
-      const float w4 = X4[(size_t)3 * x4_stride + j0];
-      double p3[3];
-      for (int k = 0; k < 3; k++) p3[k] = (double)(X4[(size_t)k * x4_stride + j0] / w4);
-      const double* H0 = P.H + 12 * (size_t)((t - tid) & (PIPE_HIST - 1)); const double* H1 = P.H + 12 * (size_t)(t & (PIPE_HIST - 1));
+      const double p3[3] = {s_p3[tid][0], s_p3[tid][1], s_p3[tid][2]};
+      const double* H0 = s_H + 12 * (size_t)((t - tid) & (PIPE_HIST - 1)); const double* H1 = s_H + 12 * (size_t)(t & (PIPE_HIST - 1));
       double inv0[12];                                   // inv([R | t]) = [R^T | -R^T t]
       for (int r = 0; r < 3; r++) {
         for (int k = 0; k < 3; k++) inv0[4 * r + k] = H0[4 * k + r];
@@ -609,29 +648,29 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
       const int n_grp = pipe_rank<CH>(f, rank, s_w);
       int n_take = n_grp < room ? n_grp : room;
       if (n_grp > n_take) overflow |= 2;
-      if (headL + n_take > nfL) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_CAPACITY; return; }
+      if (headL0 + fl_off + n_take > nfL) { if (tid == 0) P.cnt[C_STATUS] |= VO_PIPE_CAPACITY; return; }
 #pragma unroll
       for (int c = 0; c < CH; c++)
         if (f[c] && rank[c] < n_take) {
-          const int j = tid * CH + c, nlr = P.freeL[headL + rank[c]];
+          const int nlr = s_fl[fl_off + rank[c]], o = nl + rank[c];
           P.l_tl[nlr] = t;                                                                   // Landmark(t_curr, p, des) (extractor.py:274-275)
           for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = (double)pt[c][k];
-          P.lm_L[nl + rank[c]] = nlr; P.lm_K[nl + rank[c]] = P.ripe[j]; P.lm_ksh[nl + rank[c]] = 0;
+          s_lmL[o] = nlr; s_lmK[o] = rk[c];
+          P.lm_L[o] = nlr; P.lm_K[o] = rk[c]; P.lm_ksh[o] = 0;
         }
-      headL += n_take; nl += n_take; n_new += n_take; room -= n_take;
+      fl_off += n_take; nl += n_take; n_new += n_take; room -= n_take;
     }
   }
   __syncthreads();
   int n_res = 0, nd = nd0, n_inert = 0;
   if (do_adjust) {
     // ---- dead landmarks whose track lies inside the window are appended to the state's lists as the same objects (bundle_adjuster.py:132-150) ----
-    int DL[CH], DK[CH]; bool win[CH], take[CH], stay[CH];
+    bool win[CH], take[CH], stay[CH];
     int wr[CH];
 #pragma unroll
     for (int c = 0; c < CH; c++) {
       const int j = tid * CH + c;
-      DL[c] = DK[c] = 0; win[c] = false;
-      if (j < nd0) { DL[c] = P.dead_L[j]; DK[c] = P.dead_K[j]; win[c] = resurrect && (t - (P.l_tl[DL[c]] - (P.k_len[DK[c]] - 1))) < Wn; }
+      win[c] = resurrect && j < nd0 && (t - (dtl[c] - (dlen[c] - 1))) < Wn;
     }
     const int n_win = pipe_rank<CH>(win, wr, s_w);
     int room = P.N - nl - nc;
@@ -641,18 +680,22 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
 #pragma unroll
     for (int c = 0; c < CH; c++) {
       take[c] = win[c] && wr[c] < n_res;
-      if (take[c]) { P.lm_L[nl + wr[c]] = DL[c]; P.lm_K[nl + wr[c]] = DK[c]; P.lm_ksh[nl + wr[c]] = 1; }
+      if (take[c]) {
+        const int o = nl + wr[c];
+        s_lmL[o] = DL[c]; s_lmK[o] = DK[c];
+        P.lm_L[o] = DL[c]; P.lm_K[o] = DK[c]; P.lm_ksh[o] = 1;
+      }
       const int j = tid * CH + c;
-      if (j < nd0 && !take[c]) st_i32(&P.scr[DL[c]], 0);
+      if (j < nd0 && !take[c]) s_mark[DL[c]] = 0;
     }
     nl += n_res;
     __syncthreads();
     // an entry that stays dead is kept while it may still be resurrected: the window test holds, or its L row is in the state's list
 #pragma unroll
-    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; if (j < nl) st_i32(&P.scr[P.lm_L[j]], 1); }
+    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; if (j < nl) s_mark[s_lmL[j]] = 1; }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; stay[c] = j < nd0 && !take[c] && (win[c] || ld_i32(&P.scr[DL[c]]) == 1); }
+    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; stay[c] = j < nd0 && !take[c] && (win[c] || s_mark[DL[c]] == 1); }
     int tr[CH], sr[CH];
     const int n_take = pipe_rank<CH>(take, tr, s_w);
     const int n_stay = pipe_rank<CH>(stay, sr, s_w);
@@ -662,7 +705,24 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
       if (stay[c]) { P.dead_L[n_take + sr[c]] = DL[c]; P.dead_K[n_take + sr[c]] = DK[c]; }
     }
     nd = n_take + n_stay; n_inert = nd0 - nd;
-    __syncthreads();
+  }
+  __syncthreads();                                     // the list in LDS and the new landmark rows are complete
+  // ---- trip 4: rows of the entries appended above (the existing ones were fetched in trip 3) ----
+  int Lr[CH], Kr[CH], len[CH], tl[CH];
+  double p3d[CH][3];
+  float2 uvk[CH];
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    const int j = tid * CH + c;
+    Lr[c] = eL[c]; Kr[c] = eK[c]; len[c] = elen[c]; tl[c] = etl[c]; uvk[c] = euv[c];
+    for (int k = 0; k < 3; k++) p3d[c][k] = ep[c][k];
+    if (j >= nl0 && j < nl) {
+      Lr[c] = s_lmL[j]; Kr[c] = s_lmK[j];
+      len[c] = P.k_len[Kr[c]]; tl[c] = P.l_tl[Lr[c]]; uvk[c] = P.k_uv[Kr[c]];
+      for (int k = 0; k < 3; k++) p3d[c][k] = P.l_p[3 * (size_t)Lr[c] + k];
+    }
+  }
+  if (do_adjust) {
     // ---- the bundle-adjustment problem (bundle_adjuster.py:153-176): points, observations from the keypoint histories, window poses ----
     double* pts0 = x0 + 6 * (size_t)Wn;
     int nobs = 0;
@@ -671,12 +731,12 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
       const int j = tid * CH + c;
       if (j >= Nba) continue;
       if (j < nl) {
-        const int Lr = P.lm_L[j], Kr = P.lm_K[j], n = P.k_len[Kr], tl = P.l_tl[Lr];
-        for (int k = 0; k < 3; k++) pts0[3 * (size_t)j + k] = P.l_p[3 * (size_t)Lr + k];
+        const int n = len[c];
+        for (int k = 0; k < 3; k++) pts0[3 * (size_t)j + k] = p3d[c][k];
         for (int s = 0; s < Wn; s++) {
-          const int idx = (t - s) - tl + n - 1;                      // k.uv_history[(t_now - s) - l.t_latest + len - 1] (:56-59, :156)
+          const int idx = (t - s) - tl[c] + n - 1;                   // k.uv_history[(t_now - s) - l.t_latest + len - 1] (:56-59, :156)
           double2 v = make_double2(__builtin_nan(""), __builtin_nan(""));
-          if (idx >= 0 && idx <= n - 1 && idx >= n - PIPE_HIST) { const float2 h = pipe_hist_slot(P, idx)[Kr]; v = make_double2((double)h.x, (double)h.y); nobs++; }
+          if (idx >= 0 && idx <= n - 1 && idx >= n - PIPE_HIST) { const float2 h = pipe_hist_slot(P, idx)[Kr[c]]; v = make_double2((double)h.x, (double)h.y); nobs++; }
           reinterpret_cast<double2*>(obs)[(size_t)s * Nba + j] = v;
         }
       } else {
@@ -689,7 +749,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
       double* po = x0 + 6 * tid;
       const int tt = t - tid;
       if (tt >= 0 && tid < PIPE_HIST) {                              // poses missing at the start of a sequence stay zero (:169-171)
-        const double* Hs = P.H + 12 * (size_t)(tt & (PIPE_HIST - 1));
+        const double* Hs = s_H + 12 * (size_t)(tt & (PIPE_HIST - 1));
         const double R[9] = {Hs[0], Hs[1], Hs[2], Hs[4], Hs[5], Hs[6], Hs[8], Hs[9], Hs[10]};
         pipe_log_so3(R, po);
         po[3] = Hs[3]; po[4] = Hs[7]; po[5] = Hs[11];
@@ -697,21 +757,22 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
         for (int k = 0; k < 6; k++) po[k] = 0.0;
       }
     }
-    __syncthreads();
   }
-  if (tid == 0) {
-    P.cnt[C_NLM] = nl; P.cnt[C_NNEW] = n_new; P.cnt[C_HEADL] = headL; P.cnt[C_OVERFLOW] = overflow;
-    if (do_adjust) { P.cnt[C_NDEAD] = nd; P.cnt[C_NINERT] += n_inert; P.cnt[C_NRES] = n_res; P.cnt[C_NOBS] = s_nobs; }
-  }
-  // the resident point set of the final lists (what k_pipe_dense writes; folded in here: one launch less on the frame's critical chain)
-  __syncthreads();                                     // the list entries other threads appended above are visible
+  // ---- the resident point set of the final lists (what k_pipe_dense writes; folded in here: one launch less on the frame's critical chain) ----
   {
     float2* out = reinterpret_cast<float2*>(vo_seq(pts, pts_seq, b));
-    for (int j = tid; j < P.N; j += PIPE_TPB) {
-      if (j < nl) out[j] = P.k_uv[P.lm_K[j]];
-      if (j < nc) out[nl + j] = P.k_uv[P.cand[j]];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      const int j = tid * CH + c;
+      if (j < nl) out[j] = uvk[c];
+      if (j < nc) out[nl + j] = cuv[c];
     }
-    if (tid == 0) { P.cnt[C_NPTS] = nl + nc; Pall.dn[DN_PTS * gridDim.x + b] = nl + nc; }
+  }
+  __syncthreads();                                     // s_nobs
+  if (tid == 0) {
+    P.cnt[C_NLM] = nl; P.cnt[C_NNEW] = n_new; P.cnt[C_HEADL] = headL0 + fl_off; P.cnt[C_OVERFLOW] = overflow;
+    if (do_adjust) { P.cnt[C_NDEAD] = nd; P.cnt[C_NINERT] += n_inert; P.cnt[C_NRES] = n_res; P.cnt[C_NOBS] = s_nobs; }
+    P.cnt[C_NPTS] = nl + nc; Pall.dn[DN_PTS * gridDim.x + b] = nl + nc;
   }
 }
 
@@ -954,6 +1015,7 @@ static int32_t pipe_create(vo_ctx* c, const double* K, const vo_pipe_params* prm
   // k_pipe_extend keeps 28 bytes of LDS per table slot (112 KB at 4 096 slots: above the default limit of a launch)
   VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_extend<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 28 * PIPE_TPB * PIPE_CH));
   VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_extend<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 28 * PIPE_TPB * 2));
+  VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_promote<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * PIPE_TPB * PIPE_CH));
   VO_HIP(c, hipMemcpyAsync(w->d_K, K, 72 * B, hipMemcpyHostToDevice, c->stream));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   int32_t r = vo_ba_reserve(c, K, prm->ba_window, w->N);
@@ -1128,10 +1190,18 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
     if (r != VO_OK) return r;
   }
   if (stages & (VO_PIPE_TRIANGULATE | VO_PIPE_ADJUST))
-    PIPE_DISPATCH(k_pipe_promote, P, (stages & VO_PIPE_TRIANGULATE) ? 1 : 0, (stages & VO_PIPE_ADJUST) ? 1 : 0,
-                       vo_slab<const float>(c, c->off_X4), vo_slab<const double>(c, c->off_depth), vo_slab<const double>(c, c->off_reproj), c->slab_seq,
-                       w->N, prm.max_reproj_err, prm.min_bearing_angle, w->d_cam_sel, bv.W, prm.resurrect, bv.x0, bv.obs, bv.x_stride, bv.obs_stride, bv.N,
-                       vo_slab<float>(c, vo_off_p(c)), c->slab_seq);
+  {
+    const size_t lds = sizeof(int32_t) * 3 * (size_t)w->N + (size_t)w->R;
+    auto launch = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(c->batch), dim3(PIPE_TPB), lds, c->stream, P, (stages & VO_PIPE_TRIANGULATE) ? 1 : 0, (stages & VO_PIPE_ADJUST) ? 1 : 0,
+                         vo_slab<const float>(c, c->off_X4), vo_slab<const double>(c, c->off_depth), vo_slab<const double>(c, c->off_reproj), c->slab_seq,
+                         w->N, prm.max_reproj_err, prm.min_bearing_angle, w->d_cam_sel, bv.W, prm.resurrect, bv.x0, bv.obs, bv.x_stride, bv.obs_stride, bv.N,
+                         vo_slab<float>(c, vo_off_p(c)), c->slab_seq);
+    };
+    if (w->N <= PIPE_TPB) launch(k_pipe_promote<1>);
+    else if (w->N <= 2 * PIPE_TPB) launch(k_pipe_promote<2>);
+    else launch(k_pipe_promote<4>);
+  }
   else
     hipLaunchKernelGGL(k_pipe_dense, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, vo_slab<float>(c, vo_off_p(c)), c->slab_seq, 0);
   if (side) {
