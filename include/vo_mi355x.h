@@ -452,7 +452,11 @@ int32_t vo_pipe_table_write(vo_ctx* ctx, int32_t which, const void* src);     /*
 int32_t vo_pipe_table_read(vo_ctx* ctx, int32_t which, void* dst);            /* synchronous */
 /* after the tables were written: free rows and the resident point set are rebuilt from the lists */
 int32_t vo_pipe_commit(vo_ctx* ctx);
-/* one frame; stages = VO_PIPE_ALL, or a subset for stage-wise parity tests (the step counter advances in TRACK)   (async) */
+/* one frame; stages = VO_PIPE_ALL, or a subset for stage-wise parity tests (the step counter advances in TRACK)   (async).
+ * frame_idx >= 0: frame of the uploaded sequence (vo_seq_upload); < 0: the caller has pushed the frame (vo_frame_push*).
+ * Up to VO_PIPE_INFLIGHT steps may be enqueued before the oldest is fetched.  With a side stream (vo_set_side_stream != 0, the
+ * default) the re-detection and spawn of frame t and the pyramid + KLT of frame t + 1 (frame_idx >= 0) run beside the bundle
+ * adjustment of frame t; results are bit-identical to the one-stream order.  Many sequences: ONE context with a large batch. */
 int32_t vo_pipe_step(vo_ctx* ctx, int32_t frame_idx, int32_t stages);
 int32_t vo_pipe_fetch(vo_ctx* ctx, vo_pipe_record* rec /* [batch] */);        /* waits for the OLDEST step not fetched yet */
 int32_t vo_pipe_set_ba_budget(vo_ctx* ctx, int32_t budget);
