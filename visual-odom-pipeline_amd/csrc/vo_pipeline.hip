@@ -6,7 +6,8 @@
 //   k_pipe_prune      after PnP     pipeline.py:124-140 (inlier pruning, trajectory.append) + the split of triangulate_tracks (extractor.py:202-203)
 //   k_pipe_promote    after DLT     triangulate.py:87-111 filters, extractor.py:231-240 gate, pipeline.py:153-154; then the selection half of
 //                                   BundleAdjuster.adjust (bundle_adjuster.py:132-176): resurrection, observation table, x0
-//   k_pipe_dense      after promote the resident point set (exclusion discs, next KLT); then S-T on a side stream beside the BA
+//                     also: the resident point set (exclusion discs, next KLT); then S-T + spawn on a side stream beside the BA
+//   (k_pipe_dense     the resident point set alone: after a host write of the tables, or when promote is not among the stages)
 //   k_pipe_writeback  after BA      bundle_adjuster.py:197-213
 //   k_pipe_spawn      after S-T     extractor.py:127-131 / pipeline.py:159-163; free rows rebuilt; the frame's record
 //
@@ -19,6 +20,8 @@
 //
 // One workgroup (1024 threads) per sequence; a thread owns CH = ceil(max_pts / 1024) <= 4 CONSECUTIVE list entries, reads them all
 // before anything is written, and ordered compaction / allocation are block-wide prefix scans, so results do not depend on timing.
+// What such a kernel costs is its number of DEPENDENT trips to global memory: extend, prune and promote read the lists, then every row field
+// and the heads of the free lists in one trip each, and keep their bookkeeping (elections, counts, the growing list) in LDS.
 #include "vo_internal.h"
 
 #include <math.h>
@@ -39,7 +42,8 @@ struct pipe_ptrs {
   int32_t* l_tl; double* l_p;                                         // L rows [B][R], [B][R][3]
   int32_t *cand, *lm_L, *lm_K, *lm_ksh, *dead_L, *dead_K, *ripe;      // lists [B][N]
   int32_t* cnt;                                                       // [B][PIPE_NCNT]
-  int32_t *freeK, *freeL, *scr, *scr2;                                // [B][R]; scr2: k_pipe_writeback's own (it may run beside k_pipe_spawn)
+  int32_t *freeK, *freeL, *scr;                                       // [B][R]; scr: one word per landmark row for k_pipe_writeback's election (the other
+                                                                      // list kernels keep theirs in LDS)
   double* H;                                                          // [B][HIST][12]
   double* Kc;                                                         // [B][9]
   int32_t* dn;                                                        // [3][B] dense per-sequence counts the stage kernels index by sequence:
@@ -53,7 +57,7 @@ struct vo_pipe_ws {
   vo_pipe_params prm;
   void* tab[VO_PIPE_N_TABLES] = {};
   size_t tab_bytes[VO_PIPE_N_TABLES] = {};       // per sequence
-  int32_t *d_ripe = nullptr, *d_freeK = nullptr, *d_freeL = nullptr, *d_scr = nullptr, *d_scr2 = nullptr, *d_dn = nullptr, *d_cam_sel = nullptr;
+  int32_t *d_ripe = nullptr, *d_freeK = nullptr, *d_freeL = nullptr, *d_scr = nullptr, *d_dn = nullptr, *d_cam_sel = nullptr;
   vo_dlt_cam* d_cams = nullptr;                  // [B][HIST]: one camera pair per birth frame of the ripe candidates
   double* d_K = nullptr;
   vo_pipe_record* d_rec = nullptr;               // [B]
@@ -70,7 +74,7 @@ static pipe_ptrs pipe_make(const vo_pipe_ws* w) {
   P.l_tl = (int32_t*)w->tab[VO_PIPE_L_TLATEST]; P.l_p = (double*)w->tab[VO_PIPE_L_P];
   P.cand = (int32_t*)w->tab[VO_PIPE_CAND]; P.lm_L = (int32_t*)w->tab[VO_PIPE_LM_L]; P.lm_K = (int32_t*)w->tab[VO_PIPE_LM_K];
   P.lm_ksh = (int32_t*)w->tab[VO_PIPE_LM_KSHARED]; P.dead_L = (int32_t*)w->tab[VO_PIPE_DEAD_L]; P.dead_K = (int32_t*)w->tab[VO_PIPE_DEAD_K];
-  P.ripe = w->d_ripe; P.cnt = (int32_t*)w->tab[VO_PIPE_COUNTS]; P.freeK = w->d_freeK; P.freeL = w->d_freeL; P.scr = w->d_scr; P.scr2 = w->d_scr2;
+  P.ripe = w->d_ripe; P.cnt = (int32_t*)w->tab[VO_PIPE_COUNTS]; P.freeK = w->d_freeK; P.freeL = w->d_freeL; P.scr = w->d_scr;
   P.H = (double*)w->tab[VO_PIPE_POSES]; P.Kc = w->d_K; P.dn = w->d_dn; P.N = w->N; P.R = w->R;
   return P;
 }
@@ -81,7 +85,7 @@ __device__ __forceinline__ pipe_ptrs pipe_select(pipe_ptrs P, int b) {
   P.k_tf += r; P.k_tt += r; P.k_len += r; P.k_uv += r; P.k_first += r; P.k_hist += r * PIPE_HIST;
   P.l_tl += r; P.l_p += 3 * r;
   P.cand += n; P.lm_L += n; P.lm_K += n; P.lm_ksh += n; P.dead_L += n; P.dead_K += n; P.ripe += n;
-  P.cnt += (size_t)b * PIPE_NCNT; P.freeK += r; P.freeL += r; P.scr += r; P.scr2 += r;
+  P.cnt += (size_t)b * PIPE_NCNT; P.freeK += r; P.freeL += r; P.scr += r;
   P.H += (size_t)b * PIPE_HIST * 12; P.Kc += 9 * (size_t)b;
   return P;
 }
@@ -787,7 +791,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_writeback(pipe_ptrs Pall, int
   const int b = blockIdx.x, tid = threadIdx.x;
   const pipe_ptrs P = pipe_select(Pall, b);
   // (C_STATUS, C_NLM, C_T, C_NOBS and the landmark list are final before the fork: k_pipe_spawn, which may run beside this kernel on the
-  //  side stream, touches the candidate list, fresh keypoint rows, the free lists and P.scr -- hence the separate scratch here)
+  //  side stream, touches the candidate list, fresh keypoint rows and the free lists)
   const int nl = P.cnt[C_NLM], t = P.cnt[C_T];
   if (do_adjust && !P.cnt[C_STATUS]) {
     const pipe_ba_head* st = reinterpret_cast<const pipe_ba_head*>(pub + (size_t)b * pub_bytes);
@@ -796,15 +800,15 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_writeback(pipe_ptrs Pall, int
     const double* xp = x + 6 * (size_t)Wn;
     // entries that share a landmark row: the reference assigns in list order, the LAST one wins (:197-201)
 #pragma unroll
-    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; if (j < nl) st_i32(&P.scr2[P.lm_L[j]], -1); }
+    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; if (j < nl) st_i32(&P.scr[P.lm_L[j]], -1); }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; if (j < nl) atomicMax(&P.scr2[P.lm_L[j]], j); }
+    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; if (j < nl) atomicMax(&P.scr[P.lm_L[j]], j); }
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < CH; c++) {
       const int j = tid * CH + c;
-      if (j < nl) { const int Lr = P.lm_L[j]; if (ld_i32(&P.scr2[Lr]) == j) for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)Lr + k] = xp[3 * (size_t)j + k]; }
+      if (j < nl) { const int Lr = P.lm_L[j]; if (ld_i32(&P.scr[Lr]) == j) for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)Lr + k] = xp[3 * (size_t)j + k]; }
     }
     if (tid < Wn && t - tid >= 0 && tid < PIPE_HIST) {
       double R[9];
@@ -938,7 +942,7 @@ void vo_pipe_destroy(vo_ctx* c) {
   if (!c->pipe) return;
   vo_pipe_ws* w = c->pipe;
   for (void* p : w->tab) if (p) (void)hipFree(p);
-  void* bufs[] = {w->d_ripe, w->d_freeK, w->d_freeL, w->d_scr, w->d_scr2, w->d_dn, w->d_cam_sel, w->d_cams, w->d_K, w->d_rec};
+  void* bufs[] = {w->d_ripe, w->d_freeK, w->d_freeL, w->d_scr, w->d_dn, w->d_cam_sel, w->d_cams, w->d_K, w->d_rec};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (w->h_rec) (void)hipHostFree(w->h_rec);
   for (hipEvent_t e : w->ev) if (e) (void)hipEventDestroy(e);
@@ -998,7 +1002,6 @@ static int32_t pipe_create(vo_ctx* c, const double* K, const vo_pipe_params* prm
   VO_HIP(c, hipMalloc((void**)&w->d_freeK, 4 * R * B));
   VO_HIP(c, hipMalloc((void**)&w->d_freeL, 4 * R * B));
   VO_HIP(c, hipMalloc((void**)&w->d_scr, 4 * R * B));
-  VO_HIP(c, hipMalloc((void**)&w->d_scr2, 4 * R * B));
   VO_HIP(c, hipMalloc((void**)&w->d_cam_sel, 4 * N * B));
   VO_HIP(c, hipMemsetAsync(w->d_cam_sel, 0, 4 * N * B, c->stream));
   VO_HIP(c, hipMalloc((void**)&w->d_cams, sizeof(vo_dlt_cam) * PIPE_HIST * B));
