@@ -13,7 +13,7 @@
 //   obs   [W][N][2]   slot-major (slot 0 = newest frame), NaN = not observed
 //   x[2]  {poses [W][6], points [N][3]}  current / trial, selected by state.cur
 //
-// Work mapping: ONE LANE PER OBSERVATION.  A landmark owns a group of LPP = 16 (W <= 16) or 32 lanes, lane s of
+// Work mapping: ONE LANE PER OBSERVATION.  A landmark owns a group of LPP = 8 (W <= 8), 16 (W <= 16) or 32 lanes, lane s of
 // the group handles the observation in window slot s; landmark sums are DPP row-rotate all-reduces inside the
 // group, camera sums are cross-group shuffles + one LDS pass, so every observation is linearised exactly once
 // per kernel and nothing is re-read from HBM.
@@ -294,6 +294,24 @@ __device__ __forceinline__ double group_allreduce(double v, int lpp) {
   return v;
 }
 
+// the same over a group of 8 lanes (windows of <= 8 slots: twice the landmarks per wave): x[l] + x[7 - l] by row_half_mirror, then the two
+// quad exchanges -- lanes 0..3 and 4..7 of the group hold the same four pair sums (mirrored), so both quads finish with the total
+__device__ __forceinline__ double group8_allreduce(double v) {
+  v += dpp_f64<0x141>(v);   // row_half_mirror
+  v += dpp_f64<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += dpp_f64<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  return v;
+}
+template <int LPPC>
+__device__ __forceinline__ double group_allreduce_t(double v, int lpp) { return LPPC == 8 ? group8_allreduce(v) : group_allreduce(v, lpp); }
+
+//   rs8(x, y): lanes with bit 3 clear receive x[l] + x[l ^ 8], lanes with bit 3 set receive y[l ^ 8] + y[l]  (row_ror:8 = lane ^ 8 in a row)
+__device__ __forceinline__ double rs8_sum(double x, double y, int lane) {
+  const bool hi = (lane & 8) != 0;
+  const double keep = hi ? y : x, send = hi ? x : y;
+  return keep + dpp_f64<0x128>(send);
+}
+
 // sum over the 64 lanes of a wave, result in every lane
 __device__ __forceinline__ double wave_allreduce(double v) {
   v += dpp_f64<0x128>(v);
@@ -383,7 +401,9 @@ __device__ inline ba_state ba_init_state(const ba_params_dev& prm) {
 // ------------------------------------------------------------------------------------------------
 // k_ba_build
 // ------------------------------------------------------------------------------------------------
-template <int TPB>
+// LPPC = 8: a landmark owns 8 lanes (windows of <= 8 slots -- the reference's own window is 4: with 16 lanes three quarters of the lanes carried
+// zeros through every phase); LPPC = 0: 16 or 32 lanes, taken from the problem (P.LPP)
+template <int TPB, int LPPC = 0>
 __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev prm, int it, double probe_lambda) {
   const ba_ptrs P = ba_select(Pall, blockIdx.y);
   extern __shared__ double dyn[];   // phase A: camera-sum scratch [wave][LPP][28]; phase B: Y^ panel [3 PPB][pitch]
@@ -417,7 +437,7 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   if (st.done) return;
   unsigned long long* dbgb = (blockIdx.x == 0 && P.dbg) ? P.dbg + 16 : nullptr;
   VO_STAMP(dbgb, 0);
-  const int W = P.W, N = P.N, LPP = P.LPP;
+  const int W = P.W, N = P.N, LPP = LPPC ? LPPC : P.LPP;
   // iteration 0 reads the uploaded x0 and seeds x[0] with it (each workgroup its own landmarks)
   const double* poses = (it == 0) ? P.x0 : ba_x(P, st.cur);
   const double* pts = poses + 6 * W;
@@ -477,15 +497,15 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
 #pragma unroll
     for (int a = 0; a < 6; a++) wJp[k][a] = o.w * o.Jp[k][a];
   // ---- landmark sums over the group ----
-  const double h00 = group_allreduce(o.w * (o.Jl[0][0] * o.Jl[0][0] + o.Jl[1][0] * o.Jl[1][0]), LPP);
-  const double h10 = group_allreduce(o.w * (o.Jl[0][1] * o.Jl[0][0] + o.Jl[1][1] * o.Jl[1][0]), LPP);
-  const double h11 = group_allreduce(o.w * (o.Jl[0][1] * o.Jl[0][1] + o.Jl[1][1] * o.Jl[1][1]), LPP);
-  const double h20 = group_allreduce(o.w * (o.Jl[0][2] * o.Jl[0][0] + o.Jl[1][2] * o.Jl[1][0]), LPP);
-  const double h21 = group_allreduce(o.w * (o.Jl[0][2] * o.Jl[0][1] + o.Jl[1][2] * o.Jl[1][1]), LPP);
-  const double h22 = group_allreduce(o.w * (o.Jl[0][2] * o.Jl[0][2] + o.Jl[1][2] * o.Jl[1][2]), LPP);
-  const double g0 = group_allreduce(o.w * (o.Jl[0][0] * o.e0 + o.Jl[1][0] * o.e1), LPP);
-  const double g1 = group_allreduce(o.w * (o.Jl[0][1] * o.e0 + o.Jl[1][1] * o.e1), LPP);
-  const double g2 = group_allreduce(o.w * (o.Jl[0][2] * o.e0 + o.Jl[1][2] * o.e1), LPP);
+  const double h00 = group_allreduce_t<LPPC>(o.w * (o.Jl[0][0] * o.Jl[0][0] + o.Jl[1][0] * o.Jl[1][0]), LPP);
+  const double h10 = group_allreduce_t<LPPC>(o.w * (o.Jl[0][1] * o.Jl[0][0] + o.Jl[1][1] * o.Jl[1][0]), LPP);
+  const double h11 = group_allreduce_t<LPPC>(o.w * (o.Jl[0][1] * o.Jl[0][1] + o.Jl[1][1] * o.Jl[1][1]), LPP);
+  const double h20 = group_allreduce_t<LPPC>(o.w * (o.Jl[0][2] * o.Jl[0][0] + o.Jl[1][2] * o.Jl[1][0]), LPP);
+  const double h21 = group_allreduce_t<LPPC>(o.w * (o.Jl[0][2] * o.Jl[0][1] + o.Jl[1][2] * o.Jl[1][1]), LPP);
+  const double h22 = group_allreduce_t<LPPC>(o.w * (o.Jl[0][2] * o.Jl[0][2] + o.Jl[1][2] * o.Jl[1][2]), LPP);
+  const double g0 = group_allreduce_t<LPPC>(o.w * (o.Jl[0][0] * o.e0 + o.Jl[1][0] * o.e1), LPP);
+  const double g1 = group_allreduce_t<LPPC>(o.w * (o.Jl[0][1] * o.e0 + o.Jl[1][1] * o.e1), LPP);
+  const double g2 = group_allreduce_t<LPPC>(o.w * (o.Jl[0][2] * o.e0 + o.Jl[1][2] * o.e1), LPP);
   // ---- damped 3x3 block: Cholesky C C^T, Cinv = C^-1 (lower), y = Cinv g, z = Cinv^T y = M g ----
   const double lam = st.lambda;
   const double a00 = h00 + lam * fmax(h00, 1e-12), a11 = h11 + lam * fmax(h11, 1e-12), a22 = h22 + lam * fmax(h22, 1e-12);
@@ -526,6 +546,18 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
       return 0.5 * o.rho;
     };
     double* dst = dyn + (size_t)(wave * LPP + (lane & (LPP - 1))) * BA_POSE_VALS;
+    if (LPPC == 8) {
+      // eight landmarks per wave: four values at a time through two reduce-scatter stages (lane ^ 8, lane ^ 16) -- the lane whose bits
+      // 3 and 4 spell i then holds value 4 g + i summed over four of the wave's landmarks -- and one exchange with lane ^ 32 for the other
+      // four; the lower half-wave stores.  (Eight values at a time through three scatter stages is the same instruction count at 130
+      // instead of 125 registers: one workgroup per CU less.)
+#pragma unroll
+      for (int g = 0; g < BA_POSE_VALS / 4; g++) {
+        const double a01 = rs8_sum(term(4 * g), term(4 * g + 1), lane), a23 = rs8_sum(term(4 * g + 2), term(4 * g + 3), lane);
+        const double u = xor32_sum(rs16_sum(a01, a23));
+        if (lane < 32) dst[4 * g + ((lane >> 3) & 1) + 2 * (lane >> 4)] = u;
+      }
+    } else
 #pragma unroll
     for (int g = 0; g < BA_POSE_VALS / 4; g++) {
       const double v0 = term(4 * g), v1 = term(4 * g + 1), v2 = term(4 * g + 2), v3 = term(4 * g + 3);
@@ -1022,7 +1054,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
 // ------------------------------------------------------------------------------------------------
 // k_ba_update : back-substitute landmarks, form the trial x, evaluate the trial cost
 // ------------------------------------------------------------------------------------------------
-template <int TPB>
+template <int TPB, int LPPC = 0>
 __global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs Pall, ba_params_dev prm, int it, double* __restrict__ probe_dl) {
   const ba_ptrs P = ba_select(Pall, blockIdx.y);
   if (blockIdx.y != 0) probe_dl = nullptr;
@@ -1034,7 +1066,7 @@ __global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs Pall, ba_params_dev p
   __shared__ double s_red[(TPB / 64) * BA_EVAL_VALS];
   const ba_state st = P.state[it & 1];
   if (st.done) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, W = P.W, N = P.N, LPP = P.LPP;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, W = P.W, N = P.N, LPP = LPPC ? LPPC : P.LPP;
   const double* poses = ba_x(P, st.cur);
   const double* pts = poses + 6 * W;
   double* tposes = ba_x(P, st.cur ^ 1);
@@ -1085,7 +1117,7 @@ __global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs Pall, ba_params_dev p
       }
     }
   }
-  v0 = group_allreduce(v0, LPP); v1 = group_allreduce(v1, LPP); v2 = group_allreduce(v2, LPP);
+  v0 = group_allreduce_t<LPPC>(v0, LPP); v1 = group_allreduce_t<LPPC>(v1, LPP); v2 = group_allreduce_t<LPPC>(v2, LPP);
   double e0 = 0, e1 = 0, e2 = 0, e3 = 0;
   if (j < N) {
     const double* ax = P.aux + (size_t)j * BA_AUX;
@@ -1212,11 +1244,13 @@ extern "C" int32_t vo_ba_default_params(vo_ba_params* p) {
 
 static void ba_geometry(vo_ba_ws* b, int W, int N) {
   b->W = W; b->N = N;
-  b->LPP = (W <= 16) ? 16 : 32;
+  b->LPP = (W <= 8) ? 8 : (W <= 16) ? 16 : 32;
+  if (const char* e = getenv("VO_BA_LPP8")) { if (atoi(e) == 0 && b->LPP == 8) b->LPP = 16; }      // A/B knob
   // workgroup size: 256 lanes (more workgroups -> more CUs, less contention on the f64 pipes) unless that would
   // produce more than 160 partial sets, then 1024
   b->tpb = (vo_div_up(N, 256 / b->LPP) <= 160) ? 256 : 1024;
   if (const char* e = getenv("VO_BA_TPB")) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) b->tpb = t; }   // experiment knob
+  if (b->LPP == 8 && b->tpb != 256) { b->LPP = 16; b->tpb = (vo_div_up(N, 256 / b->LPP) <= 160) ? 256 : 1024; }          // (8-lane groups exist for 256-lane workgroups only)
   b->PPB = b->tpb / b->LPP;
   b->nblk = vo_div_up(N, b->PPB);
   b->RP = ((6 * W + 1 + 15) / 16) * 16; b->RT = b->RP / 16; b->n_tiles = b->RT * (b->RT + 1) / 2;
@@ -1286,6 +1320,7 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     VO_HIP(c, hipHostMalloc((void**)&b->h_state, sizeof(ba_state) * B, hipHostMallocDefault));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   }
@@ -1404,7 +1439,8 @@ static int32_t ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& 
                               double* probe_S, double* hpp_out, double* probe_dl) {
   vo_ba_ws* b = c->ba;
   const int B = c->batch;
-  if (b->tpb == 256) hipLaunchKernelGGL(k_ba_build<256>, dim3(P.nset, B), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
+  if (b->tpb == 256 && b->LPP == 8) hipLaunchKernelGGL((k_ba_build<256, 8>), dim3(P.nset, B), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
+  else if (b->tpb == 256) hipLaunchKernelGGL(k_ba_build<256>, dim3(P.nset, B), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
   else if (b->tpb == 512) hipLaunchKernelGGL(k_ba_build<512>, dim3(b->nblk, B), dim3(512), b->build_lds, c->stream, P, prm, it, probe_lambda);
   else hipLaunchKernelGGL(k_ba_build<1024>, dim3(b->nblk, B), dim3(1024), b->build_lds, c->stream, P, prm, it, probe_lambda);
   hipLaunchKernelGGL(k_ba_reduce, dim3(vo_div_up(b->n_tiles * 256 + b->W * BA_POSE_VALS + 1, 64), B), dim3(256), 0, c->stream, P, it);
@@ -1415,7 +1451,8 @@ static int32_t ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& 
     if (r != VO_OK) return r;
   }
   hipLaunchKernelGGL(k_ba_solve, dim3(B), dim3(BA_SOLVE_THREADS), b->solve_lds, c->stream, P, prm, it, probe_S, hpp_out);
-  if (b->tpb == 256) hipLaunchKernelGGL(k_ba_update<256>, dim3(b->nblk, B), dim3(256), 0, c->stream, P, prm, it, probe_dl);
+  if (b->tpb == 256 && b->LPP == 8) hipLaunchKernelGGL((k_ba_update<256, 8>), dim3(b->nblk, B), dim3(256), 0, c->stream, P, prm, it, probe_dl);
+  else if (b->tpb == 256) hipLaunchKernelGGL(k_ba_update<256>, dim3(b->nblk, B), dim3(256), 0, c->stream, P, prm, it, probe_dl);
   else if (b->tpb == 512) hipLaunchKernelGGL(k_ba_update<512>, dim3(b->nblk, B), dim3(512), 0, c->stream, P, prm, it, probe_dl);
   else hipLaunchKernelGGL(k_ba_update<1024>, dim3(b->nblk, B), dim3(1024), 0, c->stream, P, prm, it, probe_dl);
   if (P.sharded) {
