@@ -210,3 +210,28 @@ def test_ba_chunked_partial_sets_match_one_chunk_per_workgroup(monkeypatch):
         assert st["iters"] == out[1][2]["iters"] == ref["iters"] and st["accepted"] == out[1][2]["accepted"]
         assert abs(st["cost"] - out[1][2]["cost"]) <= 1e-12 * st["cost"] and abs(st["cost"] - ref["cost"]) <= 1e-7 * ref["cost"]
         assert np.abs(po - out[1][0]).max() <= 1e-10 and np.abs(pt - out[1][1]).max() <= 1e-9
+
+
+@pytest.mark.parametrize("W,n_pts", [(4, 2000), (8, 1000), (3, 333), (5, 700)])
+def test_ba_eight_lanes_per_landmark_matches_oracle_and_the_sixteen_lane_form(monkeypatch, W, n_pts):
+    """Windows of <= 8 slots run k_ba_build<256, 8> / k_ba_update<256, 8> (a landmark owns 8 lanes, 32 landmarks per 256-lane workgroup);
+    VO_BA_LPP8=0 forces the 16-lane form.  Same LM iteration / acceptance sequence, cost and solution to 1e-10 between the two (the summation
+    order differs), equal to the oracle; also with a workgroup walking several landmark chunks (VO_BA_CHUNKS) and N not a multiple of 32."""
+    import ba_oracle as bo
+    from vo_mi355x import VoContext, synthetic as syn
+    s = syn.make_ba_scene(n_pts=n_pts, n_slots=W, seed=10 + W, visibility=0.85)
+    ref = bo.solve(s["K"], s["poses0"], s["points0"], s["obs"], max_iters=12)
+    out = {}
+    for key, env in (("l8", {}), ("l16", {"VO_BA_LPP8": "0"}), ("l8c3", {"VO_BA_CHUNKS": "3"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with VoContext(64, 64, max_pts=64) as c:          # (the lane count is fixed when the workspace is built: a fresh context per form)
+            out[key] = c.ba_adjust(s["K"], s["poses0"], s["points0"], s["obs"], c.ba_params(max_iters=12))
+        for k in env:
+            monkeypatch.delenv(k)
+    for key in ("l8", "l16", "l8c3"):
+        po, pt, st = out[key]
+        assert st["iters"] == ref["iters"] and st["accepted"] == ref["accepted"], (key, st, ref["iters"], ref["accepted"])
+        assert abs(st["cost"] - ref["cost"]) <= 1e-7 * ref["cost"], (key, st["cost"], ref["cost"])
+        assert abs(st["cost"] - out["l16"][2]["cost"]) <= 1e-10 * st["cost"]
+        assert np.abs(po - out["l16"][0]).max() <= 1e-9 and np.abs(pt - out["l16"][1]).max() <= 1e-8
