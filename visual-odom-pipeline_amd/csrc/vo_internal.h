@@ -92,6 +92,7 @@ struct vo_ctx {
   struct vo_trk_ws* trk = nullptr;   // device-resident track table (vo_tracks.hip)
   struct vo_pipe_ws* pipe = nullptr; // closed-loop Pipeline.step on the device (vo_pipeline.hip)
   const int32_t* d_pt_counts = nullptr;   // per-sequence number of live resident points, or null = uniform n (KLT / exclusion discs)
+  const int32_t* d_st_limit = nullptr;    // closed-loop pipeline: per-sequence cap on the corners a resident re-detection needs (free slots + 1), or null
   vo_ba_ws* ba = nullptr;
   vo_prof prof;
   unsigned long long* d_dbg = nullptr;   // 4 x 8 phase stamps (vo_debug_cycles)

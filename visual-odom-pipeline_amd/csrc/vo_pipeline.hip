@@ -46,11 +46,11 @@ struct pipe_ptrs {
                                                                       // list kernels keep theirs in LDS)
   double* H;                                                          // [B][HIST][12]
   double* Kc;                                                         // [B][9]
-  int32_t* dn;                                                        // [3][B] dense per-sequence counts the stage kernels index by sequence:
+  int32_t* dn;                                                        // [4][B] dense per-sequence counts the stage kernels index by sequence:
                                                                       // resident points (KLT, exclusion discs) | PnP correspondences | DLT pairs
   int N, R;
 };
-enum { DN_PTS = 0, DN_PNP = 1, DN_RIPE = 2 };
+enum { DN_PTS = 0, DN_PNP = 1, DN_RIPE = 2, DN_ROOM = 3 };   // DN_ROOM: free slots of the table + 1 = the corners the frame's re-detection can use
 
 struct vo_pipe_ws {
   int N = 0, R = 0;
@@ -776,7 +776,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
   if (tid == 0) {
     P.cnt[C_NLM] = nl; P.cnt[C_NNEW] = n_new; P.cnt[C_HEADL] = headL0 + fl_off; P.cnt[C_OVERFLOW] = overflow;
     if (do_adjust) { P.cnt[C_NDEAD] = nd; P.cnt[C_NINERT] += n_inert; P.cnt[C_NRES] = n_res; P.cnt[C_NOBS] = s_nobs; }
-    P.cnt[C_NPTS] = nl + nc; Pall.dn[DN_PTS * gridDim.x + b] = nl + nc;
+    P.cnt[C_NPTS] = nl + nc; Pall.dn[DN_PTS * gridDim.x + b] = nl + nc; Pall.dn[DN_ROOM * gridDim.x + b] = max(P.N - nl - nc, 0) + 1;
   }
 }
 
@@ -932,7 +932,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_dense(pipe_ptrs Pall, float* 
     if (j < nl) out[j] = P.k_uv[P.lm_K[j]];
     if (j < nc) out[nl + j] = P.k_uv[P.cand[j]];
   }
-  if (tid == 0) { P.cnt[C_NPTS] = nl + nc; Pall.dn[DN_PTS * gridDim.x + b] = nl + nc; if (reset) { Pall.dn[DN_PNP * gridDim.x + b] = 0; Pall.dn[DN_RIPE * gridDim.x + b] = 0; } }
+  if (tid == 0) { P.cnt[C_NPTS] = nl + nc; Pall.dn[DN_PTS * gridDim.x + b] = nl + nc; Pall.dn[DN_ROOM * gridDim.x + b] = max(P.N - nl - nc, 0) + 1; if (reset) { Pall.dn[DN_PNP * gridDim.x + b] = 0; Pall.dn[DN_RIPE * gridDim.x + b] = 0; } }
 }
 
 // ================================================================================================
@@ -950,6 +950,7 @@ void vo_pipe_destroy(vo_ctx* c) {
   delete w;
   c->pipe = nullptr;
   c->d_pt_counts = nullptr;
+  c->d_st_limit = nullptr;
 }
 
 extern "C" int32_t vo_pipe_default_params(vo_pipe_params* p) {
@@ -1006,8 +1007,8 @@ static int32_t pipe_create(vo_ctx* c, const double* K, const vo_pipe_params* prm
   VO_HIP(c, hipMemsetAsync(w->d_cam_sel, 0, 4 * N * B, c->stream));
   VO_HIP(c, hipMalloc((void**)&w->d_cams, sizeof(vo_dlt_cam) * PIPE_HIST * B));
   VO_HIP(c, hipMemsetAsync(w->d_cams, 0, sizeof(vo_dlt_cam) * PIPE_HIST * B, c->stream));
-  VO_HIP(c, hipMalloc((void**)&w->d_dn, 4 * 3 * B));
-  VO_HIP(c, hipMemsetAsync(w->d_dn, 0, 4 * 3 * B, c->stream));
+  VO_HIP(c, hipMalloc((void**)&w->d_dn, 4 * 4 * B));
+  VO_HIP(c, hipMemsetAsync(w->d_dn, 0, 4 * 4 * B, c->stream));
   VO_HIP(c, hipMalloc((void**)&w->d_K, 72 * B));
   VO_HIP(c, hipMalloc((void**)&w->d_rec, sizeof(vo_pipe_record) * B));
   VO_HIP(c, hipMemsetAsync(w->d_rec, 0, sizeof(vo_pipe_record) * B, c->stream));
@@ -1029,6 +1030,7 @@ static int32_t pipe_create(vo_ctx* c, const double* K, const vo_pipe_params* prm
   if (r != VO_OK) return r;
   c->n_resident = c->max_pts;
   c->d_pt_counts = w->d_dn + DN_PTS * B;
+  c->d_st_limit = w->d_dn + DN_ROOM * B;
   return vo_pipe_commit(c);
 }
 

@@ -690,7 +690,7 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
                                                     double md2, int use_dist, int max_corners, float* __restrict__ out,
                                                     size_t slab_seq, unsigned long long* __restrict__ dbg,
                                                     const float* __restrict__ blockmax, int n_blockmax, double quality,
-                                                    uint32_t* __restrict__ nraw) {
+                                                    uint32_t* __restrict__ nraw, const int32_t* __restrict__ limit_dev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cand += (size_t)blockIdx.x * ST_CAND_STRIDE;          // one workgroup per sequence
   scalars = vo_seq(scalars, slab_seq, blockIdx.x); out = vo_seq(out, slab_seq, blockIdx.x);
@@ -747,7 +747,16 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
   uint32_t* hist = reinterpret_cast<uint32_t*>(s_scan);
   __shared__ unsigned long long s_prefix;
   __shared__ uint32_t s_need, s_fill;
-  const int limit = (max_corners > 0) ? min(max_corners, ST_OUT_CAP) : ST_OUT_CAP;
+  int limit = (max_corners > 0) ? min(max_corners, ST_OUT_CAP) : ST_OUT_CAP;
+  // limit_dev (closed loop): the caller can use at most that many corners of this sequence (the free slots of its table + 1, typically a few
+  // dozen).  The scan is in rank order, so the first `limit` accepted corners depend only on the strongest candidates: the list is consumed
+  // in SHORT rank-ordered chunks (the radix select below) instead of sorting all of it -- the same corners, exactly.
+  int kcap = ST_CAND_CAP;
+  if (limit_dev) {
+    const int ld = (int)st_uniform((uint32_t)max(limit_dev[blockIdx.x], 0));
+    limit = min(limit, ld);
+    kcap = min(ST_CAND_CAP, max(512, 16 * limit));
+  }
   unsigned long long* const src = cand;                   // raw list (entries <= thr_key do not count)
   unsigned long long* const top = cand + ST_GLOBAL_CAP;   // chunk staging (behind the raw list)
   unsigned long long upper = ~0ull;                       // keys >= upper have been consumed by earlier chunks
@@ -756,7 +765,7 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
   uint32_t rounds_total = 0;
 #pragma unroll 1
   for (int pass = 0;; pass++) {
-    const int K = ST_CAND_CAP - n_acc;
+    const int K = min(ST_CAND_CAP - n_acc, kcap);
     const unsigned long long* chunk = src;
     int n_new = (int)remaining, n_load = (int)n_raw;
     unsigned long long next_upper = 0;
@@ -774,13 +783,27 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
           if (k > thr_key && k < upper && (byte == 7 || (k >> (sh + 8)) == (prefix >> (sh + 8)))) atomicAdd(&hist[(uint32_t)(k >> sh) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-          uint32_t nd = need;
-          int d = 255;
-          for (; d > 0; d--) { const uint32_t cnt = hist[d]; if (nd <= cnt) break; nd -= cnt; }
-          s_prefix = prefix | ((unsigned long long)d << sh);
-          s_need = nd;
-          s_fill = 0;
+        // the bin that holds the need-th largest key, counting from bin 255 down (bin 0 takes what is left): one wave, four bins per lane,
+        // a suffix sum over the lanes, then at most three steps inside the lane that holds it (one thread walking 255 dependent LDS reads
+        // cost 25 k cycles per pass: fine while this path was rare, not for the closed loop's short chunks)
+        if (tid < 64) {
+          const int l = tid;
+          const uint32_t h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+          const uint32_t s4 = hist[4 * l] + h1 + h2 + h3;
+          uint32_t x = s4;                                   // -> bins 4 l ... 255
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_down((int)x, o); if (l + o < 64) x += y; }
+          const uint32_t above = x - s4;
+          const bool hit = above < need && need <= x;
+          const bool none = __ballot(hit) == 0ull;           // fewer keys than asked for: everything down to bin 0
+          if (hit || (none && l == 0)) {
+            uint32_t nd = need - above;
+            int d = 4 * l + 3;
+            if (nd > h3) { nd -= h3; d--; if (nd > h2) { nd -= h2; d--; if (nd > h1) { nd -= h1; d--; } } }
+            s_prefix = prefix | ((unsigned long long)d << sh);
+            s_need = nd;
+            s_fill = 0;
+          }
         }
         __syncthreads();
         prefix = st_uniform64(s_prefix); need = st_uniform(s_need);
@@ -1043,7 +1066,7 @@ extern "C" int32_t vo_st_default_params(vo_st_params* p) {
 // keep: store the eigenvalue map and leave the exclusion mask in place (vo_shi_tomasi_read); otherwise the fused kernel writes
 // no map and hands the mask back clean, which saves the k_st_mask_init launch of the next call
 static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cur, int mask_radius, const uint8_t* d_user_mask,
-                         const vo_st_params* prm, const int32_t* counts, bool keep) {
+                         const vo_st_params* prm, const int32_t* counts, bool keep, const int32_t* limit_dev = nullptr) {
   VO_CHECK(c, c->n_pushed >= 1, VO_E_STATE, "no frame pushed");
   VO_CHECK(c, prm->block_size >= 1 && prm->block_size <= 31 && (prm->block_size & 1), VO_E_INVALID,
            "block_size must be odd, <= 31");
@@ -1115,7 +1138,7 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
   const double md2 = prm->min_distance * prm->min_distance;
   hipLaunchKernelGGL(k_st_select, dim3(B), dim3(1024), ST_SEL_LDS, c->stream, s->d_cand,
                      s->d_scalars, W, H, cell, gw, gh, md2, use_dist, prm->max_corners, s->d_out, c->slab_seq, c->d_dbg,
-                     s->d_blockmax, n_blockmax, prm->quality_level, s->d_nraw);
+                     s->d_blockmax, n_blockmax, prm->quality_level, s->d_nraw, limit_dev);
   VO_HIP(c, hipGetLastError());
   s->last_max_corners = prm->max_corners;
   return VO_OK;
@@ -1170,8 +1193,10 @@ extern "C" int32_t vo_shi_tomasi_resident(vo_ctx* c, int32_t n_cur, int32_t mask
   { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   int32_t r = st_init(c);
   if (r != VO_OK) return r;
+  const char* dl = getenv("VO_ST_DEV_LIMIT");                                                              // A/B knob, read per call (tests compare both)
+  const bool dev_limit = !(dl && atoi(dl) == 0);
   return st_launch(c, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq, n_cur, mask_radius, nullptr, prm, c->d_pt_counts,
-                   c->st->keep_default);
+                   c->st->keep_default, dev_limit ? c->d_st_limit : nullptr);
 }
 
 extern "C" int32_t vo_shi_tomasi_fetch(vo_ctx* c, float* out_pts, int32_t* n_out) {
