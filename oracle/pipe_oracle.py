@@ -44,6 +44,44 @@ def _vec_to_rot(r):
     return rodrigues_vec_to_mat(r)
 
 
+def cpython_set_order(keys):
+    """Iteration order of `set(keys)` for small non-negative ints in CPython 3 (Objects/setobject.c), which is the order the
+    reference walks the birth-frame groups in (`for t_first in set([k.t_first ...])`, extractor.py:210-211): an open-addressing table
+    of 8 slots (x4 whenever fill * 5 >= mask * 3: 32 at the 5th key, 128 at the 19th), slot = hash & mask with hash(i) = i, on a collision
+    up to 9 linear probes while they stay inside the table, then i = (5 i + 1 + perturb) & mask with perturb >>= 5; a resize re-inserts
+    the keys in slot order; iteration walks the slots.  The device does the same walk in k_pipe_promote (vo_pipeline.hip)."""
+    def insert(table, mask, key):
+        perturb, i = key, key & mask
+        while True:
+            if table[i] is None or table[i] == key:
+                table[i] = key
+                return
+            if i + 9 <= mask:
+                for j in range(i + 1, i + 10):
+                    if table[j] is None or table[j] == key:
+                        table[j] = key
+                        return
+            perturb >>= 5
+            i = (i * 5 + 1 + perturb) & mask
+    mask, table, fill = 7, [None] * 8, 0
+    for key in keys:
+        key = int(key)
+        assert key >= 0
+        if key in table:
+            continue
+        insert(table, mask, key)
+        fill += 1
+        if fill * 5 >= mask * 3:
+            old = [k for k in table if k is not None]
+            size = 8
+            while size <= fill * 4:
+                size <<= 1
+            mask, table = size - 1, [None] * size
+            for k in old:
+                insert(table, mask, k)
+    return [k for k in table if k is not None]
+
+
 class Params:
     def __init__(self, ba_window=4, min_track_length=3, mask_radius=7, max_new=1000, max_reproj_err=2.0, min_bearing_angle=0.5,
                  ba_max_iters=50, ba_ftol=1e-3, ba_xtol=1e-3, pnp_seed=0, min_distance=7, resurrect=True):
@@ -241,8 +279,8 @@ class PipeModel:
         if not ripe:
             return
         H1 = self.poses[self.t]
-        # groups by birth frame, ascending (the reference walks a Python set of small ints: extractor.py:210-212)
-        for born in sorted(set(int(self.k_tf[k]) for k in ripe)):
+        # groups by birth frame in the order CPython iterates the set the reference builds from the ripe list (extractor.py:210-212)
+        for born in cpython_set_order(int(self.k_tf[k]) for k in ripe):
             grp = [k for k in ripe if int(self.k_tf[k]) == born]
             if born not in self.poses or not (0 <= self.t - born < HIST):
                 self.status |= ST_GROUPS

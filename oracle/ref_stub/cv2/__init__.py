@@ -14,7 +14,7 @@ What it provides:
   * the few constants / factory names Extractor.__init__ touches
     (/root/reference/src/extractor/extractor.py:16-36)
   * calcOpticalFlowPyrLK / goodFeaturesToTrack / circle / triangulatePoints /
-    KeyPoint_convert, which forward to a pluggable backend (`set_backend`) --
+    KeyPoint_convert / solvePnPRansac, which forward to a pluggable backend (`set_backend`) --
     the tests plug in the CPU oracle (oracle/vo_oracle.py) so that the
     reference's *glue* code (list bookkeeping, filters, grouping) can be run
     unmodified on top of our restatement of the OpenCV arithmetic.
@@ -188,3 +188,23 @@ def cornerMinEigenVal(src, blockSize, ksize=3, borderType=4):
 
 def bilateralFilter(src, d, sigmaColor, sigmaSpace, borderType=4):
     return _need_backend("bilateralFilter").bilateral(src, int(d), float(sigmaColor), float(sigmaSpace))
+
+
+def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec=None, tvec=None, useExtrinsicGuess=False,
+                   iterationsCount=100, reprojectionError=8.0, confidence=0.99, inliers=None, flags=0):
+    """(retval, rvec (3,1), tvec (3,1), inliers (n,1) int32) -- the shapes the reference reads at extractor.py:182-191.
+    The backend's `pnp_ransac(K, X, uv, thr, conf, max_iters)` is oracle/pnp_oracle.py (RANSAC draws are not OpenCV's:
+    statistical parity); no consensus -> (False, None, None, None) like OpenCV."""
+    if distCoeffs is not None or useExtrinsicGuess:
+        raise NotImplementedError("cv2 stub: solvePnPRansac without distortion / extrinsic guess only")
+    X = np.asarray(objectPoints, np.float32).reshape(-1, 3)
+    uv = np.asarray(imagePoints, np.float32).reshape(-1, 2)
+    r, t, inl = _need_backend("solvePnPRansac").pnp_ransac(np.asarray(cameraMatrix, np.float64), X, uv, float(reprojectionError),
+                                                           float(confidence), int(iterationsCount))
+    if r is None:
+        return False, None, None, None
+    return True, np.asarray(r, np.float64).reshape(3, 1), np.asarray(t, np.float64).reshape(3, 1), np.asarray(inl, np.int32).reshape(-1, 1)
+
+
+def waitKey(delay=0):
+    return -1

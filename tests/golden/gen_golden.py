@@ -20,6 +20,13 @@ small .npz files next to this script:
   glue_s{seed}.npz           G3: Extractor glue (extend_tracks / extend_landmarks / extract / triangulate_tracks,
         /root/reference/src/extractor/extractor.py:38-132,193-253) run unmodified over the CPU oracle
   rodrigues.npz              G4: Rodrigues round trips of the stub (self-consistency)
+  pipe_{name}.npz            G5: the reference's OWN Pipeline.step (/root/reference/src/pipeline/pipeline.py:92-167), unmodified,
+        frame by frame: every list (candidates, landmarks + keypoints, both dead lists) with who-shares-which-object, the
+        trajectory.  `Pipeline` is created with __new__ and seeded from a ground-truth bootstrap (its __init__ needs SIFT and a
+        dataset on disk); `visu` is a no-op stand-in module; cv2 = the stub over the CPU oracle (+ solvePnPRansac ->
+        oracle/pnp_oracle.py); scipy's least_squares inside bundle_adjuster.py is replaced by the LM of oracle/ba_oracle.py (the
+        solver is the stated deviation of this build, DESIGN.md section 2 -- with scipy's TRF the landmark positions differ and
+        the lists diverge after the first PnP; `pipe_scipy_*.npz` holds that run too, for a statistical comparison).
 
 Usage:  python tests/golden/gen_golden.py
 """
@@ -405,7 +412,203 @@ def run_glue_case(seed=0):
           "new", len(new), "triangulated", len(out["tt_l_tag"]), "rest", len(rest))
 
 
+# ---------------------------------------------------------------------------------------------------------
+# G5: the reference's own Pipeline.step
+# ---------------------------------------------------------------------------------------------------------
+class _PipeBackend:
+    """cv2-stub backend: the C oracle for the OpenCV arithmetic + oracle/pnp_oracle.py behind solvePnPRansac"""
+
+    def __init__(self):
+        self.last_pnp = None
+
+    def __getattr__(self, name):
+        return getattr(vo_oracle, name)
+
+    def pnp_ransac(self, K, X, uv, thr, conf, max_iters):
+        import pnp_oracle
+        r, t, inl = pnp_oracle.pnp_ransac(K, X, uv, thr=thr, conf=conf, max_iters=max_iters, seed=0)
+        self.last_pnp = dict(n=len(X), n_inliers=len(inl))
+        return r, t, inl
+
+
+def _import_reference_pipeline():
+    """/root/reference/src/pipeline/pipeline.py imported UNMODIFIED; its `from visu import Visualizer` (matplotlib windows, APIs this
+    image's matplotlib no longer has: SURVEY App. C-11) is satisfied by a stand-in module with a no-op Visualizer"""
+    import types
+    if "visu" not in sys.modules:
+        visu = types.ModuleType("visu")
+
+        class Visualizer:
+            def __init__(self, *a, **k):
+                pass
+
+            def update(self, *a, **k):
+                pass
+
+            def render(self, *a, **k):
+                pass
+        visu.Visualizer = Visualizer
+        sys.modules["visu"] = visu
+    import pipeline.pipeline as ref_pipe_mod
+    return ref_pipe_mod
+
+
+def lm_as_least_squares(stats, max_iters=50):
+    """stand-in for scipy.optimize.least_squares INSIDE the reference's bundle_adjuster module: unpack the reference's own x0 /
+    args (bundle_adjuster.py:165-194) into the dense problem, run the LM of oracle/ba_oracle.py with the parameters the drop-in
+    BundleAdjuster passes, hand back .x in the reference's packing"""
+    import types
+    import ba_oracle as bo
+
+    def solve(fun, x0, args=(), ftol=1e-8, xtol=1e-8, loss='linear', **kw):
+        lkp, lms, observed, K, t_now = args
+        N = len(lms)
+        W = (len(x0) - 3 * N) // 6
+        obs = np.full((W, N, 2), np.nan)
+        for i, lst in enumerate(observed):
+            for j in lst:
+                hist = lkp[j].uv_history
+                obs[i, j] = np.asarray(hist[(t_now - i) - lms[j].t_latest + len(hist) - 1], np.float64).reshape(2)
+        points, poses = np.array(x0[:3 * N]).reshape(N, 3), np.array(x0[3 * N:]).reshape(W, 6)
+        if N == 0 or np.isnan(obs[..., 0]).all():
+            stats.append(None)
+            return types.SimpleNamespace(x=np.array(x0), cost=0.0, fun=np.zeros(0), nfev=0, status=0)
+        r = bo.solve(K, poses, points, obs, max_iters=max_iters, ftol=ftol, xtol=xtol, delta=1.0 if loss == 'huber' else 1e30)
+        stats.append(dict(cost0=r["cost0"], cost=r["cost"], iters=r["iters"], n=N, n_obs=int(bo.valid_mask(obs).sum())))
+        return types.SimpleNamespace(x=np.concatenate([r["points"].reshape(-1), r["poses"].reshape(-1)]), cost=r["cost"],
+                                     fun=np.zeros(0), nfev=r["iters"], status=r["status"])
+    return solve
+
+
+def pipe_scene(n_frames, w=256, h=160, seed=2024, period=24.0, amp=(0.9, 0.25, -0.5)):
+    return syn.sway_scene(n_frames, w=w, h=h, f=260.0, seed=seed, pose_fn=lambda t: syn.sway_pose(t, amp=amp, period=period))
+
+
+def pipe_seed(ext, sc, t_step, frame_of_step, births=None, n_landmarks=0.6):
+    """ground-truth seed at step `t_step` with the reference's classes: Shi-Tomasi corners of the current frame (through the reference's
+    own Extractor.extract); the first share become landmarks at their true position (world = camera of step 0, unit = the step 0 -> 1
+    baseline, as the bootstrap fixes it), the rest candidates.  births: None = all born now (Pipeline._get_init_state's shape), or a
+    list of birth steps dealt round-robin to the candidates, whose uv_first is then the true projection into that step's frame."""
+    G = [sc["poses"][frame_of_step(s)] for s in range(t_step + 1)]
+    unit = np.linalg.norm((G[1] @ np.linalg.inv(G[0]))[:3, 3])
+    traj = Trajectory({})
+    for s in range(t_step + 1):
+        H = G[s] @ np.linalg.inv(G[0])
+        H[:3, 3] /= unit
+        traj.append(s, H)
+    f_now = frame_of_step(t_step)
+    kps = ext.extract(sc["frames"][f_now], t_step, current_kp=[], detector='shi-tomasi', mask_radius=7, describe=False)
+    uv = np.array([k.uv.reshape(2) for k in kps], np.float64)
+    Z, p0 = sc["surface"](f_now, uv)
+    K = sc["K"]
+    X0 = np.stack([(p0[:, 0] - K[0, 2]) / K[0, 0] * Z, (p0[:, 1] - K[1, 2]) / K[1, 1] * Z, Z], 1)     # frame-0 camera coordinates
+    n_l = int(len(kps) * n_landmarks)
+    Xw = (X0 @ G[0][:3, :3].T + G[0][:3, 3]) / unit
+    lms = [Landmark(t_step, Xw[i].reshape(3, 1).copy(), kps[i].des) for i in range(n_l)]
+    cands = kps[n_l:]
+    if births:
+        for i, k in enumerate(cands):
+            b = births[i % len(births)]
+            if b == t_step:
+                continue
+            Gb = sc["poses"][frame_of_step(b)]
+            xb = Gb[:3, :3] @ X0[n_l + i] + Gb[:3, 3]
+            q = np.float32([K[0, 0] * xb[0] / xb[2] + K[0, 2], K[1, 1] * xb[1] / xb[2] + K[1, 2]]).reshape(2, 1)
+            k.t_first, k.uv_first = b, q            # (uv, t_total, the one-entry history stay: the reference reads nothing else)
+    return State(lms, kps[:n_l], cands, traj)
+
+
+def canonical_ids(*lists):
+    """object identity as data: every object numbered by first appearance over the given lists, in order"""
+    ids, out = {}, []
+    for lst in lists:
+        out.append(np.array([ids.setdefault(id(o), len(ids)) for o in lst], np.int64))
+    return out
+
+
+def dump_pipe_frame(out, prefix, pl):
+    st = pl._state
+    put(out, prefix + "cand", dump_kps(st._candidates_kp))
+    put(out, prefix + "lm", dump_lms(st._landmarks)); put(out, prefix + "lmk", dump_kps(st._landmarks_kp))
+    put(out, prefix + "dead", dump_lms(pl._landmarks_dead)); put(out, prefix + "deadk", dump_kps(pl._landmarks_kp_dead))
+    out[prefix + "lm_Lid"], out[prefix + "dead_Lid"] = canonical_ids(st._landmarks, pl._landmarks_dead)
+    out[prefix + "lm_Kid"], out[prefix + "cand_Kid"], out[prefix + "dead_Kid"] = canonical_ids(st._landmarks_kp, st._candidates_kp, pl._landmarks_kp_dead)
+    T = len(st._trajectory)
+    out[prefix + "traj"] = np.array([st._trajectory[t] for t in range(T)])
+
+
+def run_pipe_case(name, n_steps, ba_window=4, t_step0=1, t0=0, t1=3, births=None, w=256, h=160, scipy_solver=False):
+    """the reference's Pipeline object stepped `n_steps` frames; everything a step leaves behind dumped after every step"""
+    import hashlib
+    from extractor import Extractor
+    ref_pipe_mod = _import_reference_pipeline()
+    backend = _PipeBackend()
+    cv2.set_backend(backend)
+    frame_of_step = (lambda s: t0 if s == 0 else t1 + s - 1)
+    sc = pipe_scene(frame_of_step(t_step0 + n_steps) + 1, w=w, h=h)
+
+    class FakeLoader:                                  # what Pipeline.step asks of its loader (pipeline.py:95)
+        _name = "synthetic"
+
+        def getFrame(self, t):
+            return sc["frames"][t], None
+
+        def getCamera(self):
+            return sc["K"]
+
+    pl = ref_pipe_mod.Pipeline.__new__(ref_pipe_mod.Pipeline)      # __init__ needs a dataset on disk, SIFT and the visualiser (pipeline.py:30-40)
+    pl._loader, pl._K = FakeLoader(), sc["K"]
+    pl._ba, pl._ba_window_size, pl._ba_frequency, pl._min_kp_dist = True, ba_window, 1, 7                # pipeline.py:18-25
+    pl._max_bidir_error, pl._max_reprojection_error, pl._min_landmark_angle, pl._kp_method = np.inf, 2.0, 0.5, 'shi-tomasi'
+    pl._extractor = Extractor(min_kp_dist=pl._min_kp_dist)                                                # pipeline.py:27-29
+    pl._bundle_adjuster = BundleAdjuster(verbosity=0, window_size=ba_window, method='trf', xtol=1e-3, ftol=1e-3)
+    pl._visu = sys.modules["visu"].Visualizer()
+    pl._t_step = t_step0
+    pl._landmarks_dead, pl._landmarks_kp_dead = [], []
+    pl._state = pipe_seed(pl._extractor, sc, t_step0, frame_of_step, births)
+    pl._t_loader = frame_of_step(t_step0)
+    pl._extractor._im_prev = sc["frames"][pl._t_loader]                                                   # pipeline.py:36
+    out = dict(w=w, h=h, K=sc["K"], ba_window=ba_window, t_step0=t_step0, n_steps=n_steps, t0=t0, t1=t1,
+               frames_sha256=np.frombuffer(hashlib.sha256(sc["frames"].tobytes()).digest(), np.uint8),
+               frame_of_step=np.array([frame_of_step(s) for s in range(t_step0 + n_steps + 1)]), scipy_solver=int(scipy_solver))
+    dump_pipe_frame(out, "s0_", pl)
+    stats = []
+    real_ls = ref_ba_mod.least_squares
+    if not scipy_solver:
+        ref_ba_mod.least_squares = lm_as_least_squares(stats)
+    info = []
+    try:
+        for s in range(1, n_steps + 1):
+            n_l0 = len(pl._state._landmarks)
+            pl.step()
+            dump_pipe_frame(out, "s%d_" % s, pl)
+            ba = stats[-1] if stats and stats[-1] else {}
+            info.append([backend.last_pnp["n"], backend.last_pnp["n_inliers"], len(pl._state._landmarks), len(pl._state._candidates_kp),
+                         len(pl._landmarks_dead), ba.get("iters", -1), ba.get("n", -1), ba.get("n_obs", -1)])
+            out["s%d_ba_cost" % s] = np.array([ba.get("cost0", np.nan), ba.get("cost", np.nan)])
+            print("  step %2d (t = %2d): pnp %d/%d  landmarks %d  candidates %d  dead %d  ba %s" % (
+                s, pl._t_step, backend.last_pnp["n_inliers"], backend.last_pnp["n"], len(pl._state._landmarks), len(pl._state._candidates_kp),
+                len(pl._landmarks_dead), ba))
+    finally:
+        ref_ba_mod.least_squares = real_ls
+    out["info"] = np.array(info, np.int64)      # per step: pnp n, inliers, landmarks, candidates, dead, ba iters, ba landmarks, ba observations
+    path = os.path.join(HERE, "pipe_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def run_pipe_cases():
+    run_pipe_case("w4", 12, ba_window=4)                                             # the reference's own window (pipeline.py:19)
+    run_pipe_case("w10", 10, ba_window=10)                                           # BASELINE's window
+    # four birth groups ripen in one frame; CPython walks the set {2, 9, 16, 8} as 16, 9, 2, 8 (extractor.py:210-211)
+    run_pipe_case("groups", 5, ba_window=4, t_step0=16, t0=0, t1=1, births=[2, 9, 16, 8])
+    run_pipe_case("scipy_w4", 12, ba_window=4, scipy_solver=True)                    # scipy's TRF kept: statistical comparison only
+
+
 if __name__ == "__main__":
+    if "--pipe-only" in sys.argv:
+        run_pipe_cases()
+        sys.exit(0)
     if "--ba-extra" in sys.argv:       # the round-2 additions only (the other files are reproduced bit for bit by a full run)
         for seed, N, W in ((0, 64, 4), (1, 64, 4), (2, 256, 10), (0, 256, 10), (0, 2000, 10)):
             run_ba_polish(seed, N, W)
@@ -423,3 +626,4 @@ if __name__ == "__main__":
     for seed, N, W in ((0, 64, 4), (1, 64, 4), (2, 256, 10), (0, 256, 10), (0, 2000, 10)):
         run_ba_polish(seed, N, W)
     run_ba_case(0, 2000, 10, full=False)
+    run_pipe_cases()

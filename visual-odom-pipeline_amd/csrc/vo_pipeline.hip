@@ -527,6 +527,62 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_prune(pipe_ptrs Pall, int do_
   if (tid == 0) { P.cnt[C_HEADK] = headK; P.cnt[C_HEADL] = headL; P.cnt[C_OVERFLOW] = overflow; }
 }
 
+// The order in which the reference walks the birth-frame groups of the ripe candidates: `for t_first in set([k.t_first for k in ...])`
+// (extractor.py:210-211) iterates a CPython set of small non-negative ints, i.e. the slots of its open-addressing table (Objects/setobject.c):
+// 8 slots, x4 whenever fill * 5 >= mask * 3 (32 at the 5th key, 128 at the 19th; a resize re-inserts in slot order), slot = key & mask
+// (hash(i) = i), on a collision up to 9 linear probes while they stay inside the table, then i = (5 i + 1 + perturb) & mask with
+// perturb >>= 5.  {2, 9, 16, 8} is walked 16, 9, 2, 8.  Keys are inserted in order of first appearance in the ripe list (s_any[age] = that
+// index, 0x7FFFFFFF = no such group); oracle/pipe_oracle.py:cpython_set_order is the same walk, checked against the interpreter.
+// -> s_order[0 .. *s_n) = the ages in walk order.  Called by the whole workgroup (barriers inside); one group (every frame of a steady run)
+// takes the short way.
+__device__ inline void pipe_set_insert(int* s_tab, int mask, int key) {
+  int perturb = key, i = key & mask;
+  for (;;) {
+    if (s_tab[i] < 0) { s_tab[i] = key; return; }
+    if (i + 9 <= mask)
+      for (int j = i + 1; j <= i + 9; j++) if (s_tab[j] < 0) { s_tab[j] = key; return; }
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & mask;
+  }
+}
+
+__device__ __forceinline__ void pipe_set_order(const int* s_any, int* s_order, int* s_tab, int* s_tmp, int* s_n, int t) {
+  const int tid = threadIdx.x;
+  if (tid < 128) s_tab[tid] = -1;
+  int rank = -1;
+  if (tid < PIPE_HIST && s_any[tid] != 0x7FFFFFFF) {     // rank of this age by first appearance = its insertion index
+    rank = 0;
+    for (int a = 0; a < PIPE_HIST; a++) rank += (s_any[a] < s_any[tid]) ? 1 : 0;
+  }
+  __syncthreads();
+  if (rank >= 0) s_order[rank] = tid;
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int a = 0; a < PIPE_HIST; a++) n += (s_any[a] != 0x7FFFFFFF) ? 1 : 0;
+    if (n > 1) {
+      int mask = 7, fill = 0;
+      for (int k = 0; k < n; k++) {
+        pipe_set_insert(s_tab, mask, t - s_order[k]);    // key = birth frame
+        fill++;
+        if (fill * 5 >= mask * 3) {                      // grow: the keys leave in slot order and are inserted again
+          int m = 0;
+          for (int i = 0; i <= mask; i++) if (s_tab[i] >= 0) { s_tmp[m++] = s_tab[i]; s_tab[i] = -1; }
+          int size = 8;
+          while (size <= fill * 4) size <<= 1;
+          mask = size - 1;
+          for (int i = 0; i < m; i++) pipe_set_insert(s_tab, mask, s_tmp[i]);
+        }
+      }
+      int m = 0;
+      for (int i = 0; i <= mask; i++) if (s_tab[i] >= 0) s_tmp[m++] = t - s_tab[i];
+      for (int i = 0; i < m; i++) s_order[i] = s_tmp[i];
+    }
+    *s_n = n;
+  }
+  __syncthreads();
+}
+
 // ================================================================================================
 // k_pipe_promote: triangulation filters + gate + promotion; then the selection half of BundleAdjuster.adjust
 // ================================================================================================
@@ -543,6 +599,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
   extern __shared__ int32_t s_dyn[];
   __shared__ int s_w[16];
   __shared__ int s_first[PIPE_HIST], s_gate[PIPE_HIST];
+  __shared__ int s_any[PIPE_HIST], s_order[PIPE_HIST], s_tab[128], s_tmp[PIPE_HIST], s_norder;   // the walk order of the birth groups (pipe_set_order)
   __shared__ double s_p3[PIPE_HIST][3];
   __shared__ double s_H[PIPE_HIST * 12];
   __shared__ int s_nobs;
@@ -564,7 +621,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
   const int nfL = P.cnt[C_NFREEL];
   int overflow = P.cnt[C_OVERFLOW];
   if (tid == 0) s_nobs = 0;
-  if (tid < PIPE_HIST) { s_first[tid] = 0x7FFFFFFF; s_gate[tid] = 0; }
+  if (tid < PIPE_HIST) { s_first[tid] = 0x7FFFFFFF; s_gate[tid] = 0; s_any[tid] = 0x7FFFFFFF; }
   __syncthreads();
   // ---- trip 2: lists, candidates of the triangulation, free rows, trajectory ring ----
   bool kept[CH]; float pt[CH][3]; int age[CH], rk[CH];
@@ -605,8 +662,13 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
   int n_new = 0, fl_off = 0;
   if (do_tri && n_ripe > 0) {
 #pragma unroll
-    for (int c = 0; c < CH; c++) if (kept[c]) atomicMin(&s_first[age[c]], tid * CH + c);
+    for (int c = 0; c < CH; c++) {
+      const int j = tid * CH + c;
+      if (kept[c]) atomicMin(&s_first[age[c]], j);
+      if (j < n_ripe) atomicMin(&s_any[age[c]], j);      // first appearance of the birth frame in the ripe list, kept or not
+    }
     __syncthreads();
+    pipe_set_order(s_any, s_order, s_tab, s_tmp, &s_norder, t);
 #pragma unroll
     for (int c = 0; c < CH; c++)
       if (kept[c] && s_first[age[c]] == tid * CH + c) for (int k = 0; k < 3; k++) s_p3[age[c]][k] = (double)pt[c][k];
@@ -640,12 +702,14 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
       s_gate[tid] = (theta > min_angle) ? 1 : 0;         // false for NaN
     }
     __syncthreads();
-    // accepted groups are appended in ascending birth frame (= descending age; the reference walks a Python set of small ints),
-    // each in list order (extractor.py:238-240)
+    // accepted groups are appended in the order the reference walks them -- `for t_first in set(...)` (extractor.py:210-211): CPython's
+    // iteration order of a set of small ints, not ascending (pipe_set_order) --, each in list order (extractor.py:238-240)
     int room = P.N - nl - nc;
     if (room < 0) room = 0;
-    for (int a = PIPE_HIST - 1; a >= 0; a--) {
-      if (!s_gate[a]) continue;                          // uniform: s_gate is shared
+    const int n_order = s_norder;
+    for (int g = 0; g < n_order; g++) {
+      const int a = s_order[g];
+      if (!s_gate[a]) continue;                          // uniform: s_gate and s_order are shared
       bool f[CH]; int rank[CH];
 #pragma unroll
       for (int c = 0; c < CH; c++) f[c] = kept[c] && age[c] == a;

@@ -5,12 +5,13 @@ import numpy as np
 
 def rodrigues_vec_to_mat(r):
     r = np.asarray(r, dtype=np.float64).reshape(3)
-    theta = float(np.sqrt(r @ r))
+    theta = float(np.sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]))
     if theta < np.finfo(np.float64).eps:
         return np.eye(3)
     k = r / theta
     Kx = np.array([[0.0, -k[2], k[1]], [k[2], 0.0, -k[0]], [-k[1], k[0], 0.0]])
-    return np.cos(theta) * np.eye(3) + (1.0 - np.cos(theta)) * np.outer(k, k) + np.sin(theta) * Kx
+    c, s = np.cos(theta), np.sin(theta)
+    return c * np.eye(3) + (1.0 - c) * np.outer(k, k) + s * Kx
 
 
 def rodrigues_mat_to_vec(R):
@@ -19,7 +20,7 @@ def rodrigues_mat_to_vec(R):
     R = U @ Vt
     v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
     s = np.sqrt(0.25 * (v @ v))
-    c = min(1.0, max(-1.0, (np.trace(R) - 1.0) * 0.5))
+    c = min(1.0, max(-1.0, (R[0, 0] + R[1, 1] + R[2, 2] - 1.0) * 0.5))
     theta = np.arccos(c)
     if s < 1e-5:
         if c > 0:
