@@ -18,8 +18,8 @@ import pipe_helpers as ph
 
 pytestmark = pytest.mark.gpu
 
-P_TOL = 2e-5       # relative, landmark positions (units of the bootstrap baseline; a landmark sits ~40 units away)
-POSE_TOL = 2e-6    # absolute, entries of [R | t]
+P_TOL = 1e-4       # relative, landmark positions (units of the bootstrap baseline; a landmark sits ~40 units away)
+POSE_TOL = 2e-5    # absolute, entries of [R | t]   (measured over the three goldens: gpurun_out/g5_deviation_*.json -> profiles/r04_g5_deviation.txt)
 
 
 def _ctx(w, h, max_pts=2048):

@@ -91,8 +91,9 @@ struct vo_ctx {
   struct vo_ess_ws* ess = nullptr;   // essential-matrix RANSAC workspace (vo_essential.hip)
   struct vo_trk_ws* trk = nullptr;   // device-resident track table (vo_tracks.hip)
   struct vo_pipe_ws* pipe = nullptr; // closed-loop Pipeline.step on the device (vo_pipeline.hip)
-  const int32_t* d_pt_counts = nullptr;   // per-sequence number of live resident points, or null = uniform n (KLT / exclusion discs)
-  const int32_t* d_st_limit = nullptr;    // closed-loop pipeline: per-sequence cap on the corners a resident re-detection needs (free slots + 1), or null
+  const int32_t* d_pt_counts = nullptr;   // vo_tracks_* only (set by vo_tracks_seed, cleared by vo_trk_destroy): per-sequence number of live tracks the
+                                          // PUBLIC resident entry points (vo_klt_track_resident, vo_shi_tomasi_resident) then use; null = uniform n.
+                                          // The closed-loop pipeline passes its own counters explicitly (vo_*_resident_counts) and never touches this.
   vo_ba_ws* ba = nullptr;
   vo_prof prof;
   unsigned long long* d_dbg = nullptr;   // 4 x 8 phase stamps (vo_debug_cycles)
@@ -197,6 +198,11 @@ void vo_st_flags_restore(vo_ctx* c, int saved);
 // step / fetch pair that touches the result slab, the frame store, the BA / Shi-Tomasi / DLT / PnP workspaces waits for them first
 int32_t vo_quiesce_side(vo_ctx* c);
 int32_t vo_st_prepare(vo_ctx* c, const vo_st_params* prm);
+// the resident entry points with the per-sequence counters named by the caller (device arrays [batch], null = uniform): d_counts = live
+// points of each sequence (KLT input / exclusion discs), d_limit = cap on the corners each sequence's re-detection needs
+int32_t vo_klt_track_resident_counts(vo_ctx* c, int32_t n, const vo_klt_params* prm, const int32_t* d_counts);
+int32_t vo_shi_tomasi_resident_counts(vo_ctx* c, int32_t n_cur, int32_t mask_radius, const vo_st_params* prm, const int32_t* d_counts,
+                                      const int32_t* d_limit);
 
 // collectives on the ctx stream (vo_comm.hip); identity / device copy without a communicator
 int32_t vo_comm_allreduce_f64(vo_ctx* c, double* buf, size_t count);

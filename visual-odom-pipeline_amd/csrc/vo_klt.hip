@@ -826,12 +826,16 @@ extern "C" int32_t vo_points_download(vo_ctx* c, float* p, uint8_t* status, floa
 
 extern "C" int32_t vo_klt_track_resident(vo_ctx* c, int32_t n, const vo_klt_params* prm) {
   if (!c) return VO_E_INVALID;
+  return vo_klt_track_resident_counts(c, n, prm, c->d_pt_counts);      // (non-null only while a vo_tracks_* table is seeded)
+}
+
+int32_t vo_klt_track_resident_counts(vo_ctx* c, int32_t n, const vo_klt_params* prm, const int32_t* d_counts) {
   vo_klt_params def;
   if (!prm) { vo_klt_default_params(&def); prm = &def; }
   VO_CHECK(c, n >= 0 && n <= c->n_resident, VO_E_INVALID, "n exceeds the resident point set");
   VO_HIP(c, hipSetDevice(c->device));
   { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
-  int32_t r = klt_launch(c, n, prm, vo_off_p(c), vo_off_p_next(c), c->d_pt_counts);   // track table: per-sequence counts
+  int32_t r = klt_launch(c, n, prm, vo_off_p(c), vo_off_p_next(c), d_counts);
   if (r != VO_OK) return r;
   c->p_parity ^= 1;   // tracked positions become the resident set
   return VO_OK;

@@ -1013,8 +1013,6 @@ void vo_pipe_destroy(vo_ctx* c) {
   if (w->ev_track) (void)hipEventDestroy(w->ev_track);
   delete w;
   c->pipe = nullptr;
-  c->d_pt_counts = nullptr;
-  c->d_st_limit = nullptr;
 }
 
 extern "C" int32_t vo_pipe_default_params(vo_pipe_params* p) {
@@ -1093,8 +1091,8 @@ static int32_t pipe_create(vo_ctx* c, const double* K, const vo_pipe_params* prm
   r = vo_st_prepare(c, &w->prm.st);
   if (r != VO_OK) return r;
   c->n_resident = c->max_pts;
-  c->d_pt_counts = w->d_dn + DN_PTS * B;
-  c->d_st_limit = w->d_dn + DN_ROOM * B;
+  // (the per-sequence counters -- live points DN_PTS, free slots + 1 DN_ROOM -- are handed to the KLT / re-detection launches by pipe_step
+  //  itself: the context's other resident entry points never see them)
   return vo_pipe_commit(c);
 }
 
@@ -1220,7 +1218,7 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
       const size_t fr = (size_t)c->width * c->height;
       r = vo_build_pyramid(c, c->d_seq + (size_t)frame_idx * fr, fr * c->seq_n, nullptr);
     }
-    if (r == VO_OK) r = vo_klt_track_resident(c, w->N, &prm.klt);
+    if (r == VO_OK) r = vo_klt_track_resident_counts(c, w->N, &prm.klt, w->d_dn + DN_PTS * B);
     c->stream = main_stream;
     if (track_side) {                                  // joined on every path
       const hipError_t e1 = hipEventRecord(w->ev_track, c->stream2);
@@ -1278,7 +1276,7 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
     VO_HIP(c, hipEventRecord(c->ev_fork, c->stream));
     VO_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     c->stream = c->stream2;
-    r = (stages & VO_PIPE_DETECT) ? vo_shi_tomasi_resident(c, w->N, prm.mask_radius, &prm.st) : VO_OK;
+    r = (stages & VO_PIPE_DETECT) ? vo_shi_tomasi_resident_counts(c, w->N, prm.mask_radius, &prm.st, w->d_dn + DN_PTS * B, w->d_dn + DN_ROOM * B) : VO_OK;
     if (r == VO_OK) pipe_launch_spawn(c, (stages & VO_PIPE_DETECT) ? 1 : 0);
     c->stream = main_stream;
     if (r == VO_OK && (stages & VO_PIPE_ADJUST)) r = vo_ba_enqueue_budget(c, &prm.ba, 0, prm.ba_budget);
@@ -1293,7 +1291,7 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
       if (r != VO_OK) return r;
     }
     if (stages & VO_PIPE_DETECT) {
-      r = vo_shi_tomasi_resident(c, w->N, prm.mask_radius, &prm.st);
+      r = vo_shi_tomasi_resident_counts(c, w->N, prm.mask_radius, &prm.st, w->d_dn + DN_PTS * B, w->d_dn + DN_ROOM * B);
       if (r != VO_OK) return r;
     }
     PIPE_DISPATCH(k_pipe_writeback, P, (stages & VO_PIPE_ADJUST) ? 1 : 0, bv.pub, bv.pub_bytes, bv.x0, bv.x_stride, bv.W, w->d_rec);

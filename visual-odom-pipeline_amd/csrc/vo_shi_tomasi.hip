@@ -1186,6 +1186,11 @@ extern "C" int32_t vo_shi_tomasi(vo_ctx* c, const float* cur_pts, int32_t n_cur,
 
 extern "C" int32_t vo_shi_tomasi_resident(vo_ctx* c, int32_t n_cur, int32_t mask_radius, const vo_st_params* prm) {
   if (!c) return VO_E_INVALID;
+  return vo_shi_tomasi_resident_counts(c, n_cur, mask_radius, prm, c->d_pt_counts, nullptr);   // (counts: non-null only while a vo_tracks_* table is seeded)
+}
+
+int32_t vo_shi_tomasi_resident_counts(vo_ctx* c, int32_t n_cur, int32_t mask_radius, const vo_st_params* prm, const int32_t* d_counts,
+                                      const int32_t* d_limit) {
   vo_st_params def;
   if (!prm) { vo_st_default_params(&def); prm = &def; }
   VO_CHECK(c, n_cur >= 0 && n_cur <= c->n_resident, VO_E_INVALID, "n_cur exceeds the resident point set");
@@ -1195,8 +1200,8 @@ extern "C" int32_t vo_shi_tomasi_resident(vo_ctx* c, int32_t n_cur, int32_t mask
   if (r != VO_OK) return r;
   const char* dl = getenv("VO_ST_DEV_LIMIT");                                                              // A/B knob, read per call (tests compare both)
   const bool dev_limit = !(dl && atoi(dl) == 0);
-  return st_launch(c, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq, n_cur, mask_radius, nullptr, prm, c->d_pt_counts,
-                   c->st->keep_default, dev_limit ? c->d_st_limit : nullptr);
+  return st_launch(c, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq, n_cur, mask_radius, nullptr, prm, d_counts,
+                   c->st->keep_default, dev_limit ? d_limit : nullptr);
 }
 
 extern "C" int32_t vo_shi_tomasi_fetch(vo_ctx* c, float* out_pts, int32_t* n_out) {
