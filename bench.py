@@ -464,10 +464,12 @@ def dropin_step_ms(device, scene, ba_window=4, n_warm=4, n_time=8):
     from vo_mi355x.resident import ResidentPipeline
     frames, K = scene["frames"], scene["K"]
     out = {}
-    with VoContext(W_IMG, H_IMG, max_pts=4096, device=device) as c:
-        state, _ = syn.gt_bootstrap(c, scene, 0, PIPE_T1)
+
+    def reference_loop(c, state, lazy, literal, n_warm, n_time):
+        """pipeline.py:92-167 line for line over the drop-in classes; literal: `if i in inliers` on the list camera_pose returned (as the reference
+        writes it; a plain list of ~3 000 indices makes that O(n^2), so the plain classes are timed with a set there, as in round 3)"""
         st = copy.deepcopy(state)
-        ex = Extractor(min_kp_dist=7, ctx=c)
+        ex = Extractor(min_kp_dist=7, ctx=c, lazy=lazy)
         ba = BundleAdjuster(verbosity=0, window_size=ba_window, method='trf', xtol=1e-3, ftol=1e-3, ctx=c, max_iters=10)
         ex._im_prev = frames[PIPE_T1]
         dead, dead_kp, t_step = [], [], 1
@@ -481,7 +483,7 @@ def dropin_step_ms(device, scene, ba_window=4, n_warm=4, n_time=8):
             dead += copy.deepcopy(ld); dead_kp += copy.deepcopy(lkd)
             ex._im_prev = im.copy()
             inl, Hk = ex.camera_pose(K, st._landmarks, st._landmarks_kp, corr='3D-2D', max_err_reproj=2.0)
-            keep = set(inl)
+            keep = inl if literal else set(inl)
             lms, lkp = [], []
             for i in range(len(st._landmarks)):
                 if i in keep:
@@ -496,9 +498,31 @@ def dropin_step_ms(device, scene, ba_window=4, n_warm=4, n_time=8):
             st, dead, dead_kp = ba.adjust(st, dead, dead_kp, K, t_step)
             st._candidates_kp += ex.extract(im, t_step, st._landmarks_kp + st._candidates_kp, detector='shi-tomasi', mask_radius=7, describe=False)
             times.append(time.perf_counter() - t0)
+        return times, st, ex
+
+    with VoContext(W_IMG, H_IMG, max_pts=4096, device=device) as c:
+        state, _ = syn.gt_bootstrap(c, scene, 0, PIPE_T1)
+        times, st, ex = reference_loop(c, state, False, False, n_warm, n_time)
         out["python_objects_ms_per_step"] = round(float(np.median(times[n_warm:])) * 1e3, 3)
         out["python_objects_frames_per_s"] = round(1.0 / float(np.median(times[n_warm:])), 1)
         out["landmarks"], out["candidates"] = len(st._landmarks), len(st._candidates_kp)
+        # the same caller, `if i in inliers` written as the reference writes it, over the lazy boundary (vo_mi355x/lazy.py: the lists are views of the
+        # device tables; frame 1 takes the plain path and seeds them)
+        try:
+            times, st2, ex2 = reference_loop(c, state, True, True, n_warm, 4 * n_time)
+            sess = ex2._lazy
+            med = float(np.median(times[n_warm:]))
+            out["lazy_views_ms_per_step"] = round(med * 1e3, 3)
+            out["lazy_views_frames_per_s"] = round(1.0 / med, 1)
+            out["lazy_views"] = {"session_alive": bool(sess is not None and sess.alive), "fast_calls": sess.stats["fast"] if sess else 0,
+                                 "row_gathers": sess.stats["gathers"] if sess else 0, "frames": len(times),
+                                 "first_frame_plain_path_and_seed_ms": round(times[0] * 1e3, 2),
+                                 "landmarks": len(st2._landmarks), "candidates": len(st2._candidates_kp),
+                                 "why_not": None if sess is not None else getattr(ex2, "_lazy_error", "the frame did not come through the reference's call order")}
+            if sess is not None and sess.alive:
+                sess.desync("bench done")
+        except Exception as e:
+            out["lazy_views"] = {"error": repr(e)}
         # the same sequence, state in device tables
         c.upload_sequence(frames)
         rp = ResidentPipeline(c, K, ba_window=ba_window, ba_max_iters=10, pnp_blind_batches=2)
@@ -518,8 +542,10 @@ def dropin_step_ms(device, scene, ba_window=4, n_warm=4, n_time=8):
         dt = time.perf_counter() - t0
         out["resident_tables_ms_per_step"] = round(dt / n * 1e3, 4)
         out["resident_tables_frames_per_s"] = round(n / dt, 1)
-    out["what"] = ("ONE 1241x376 sequence, window %d: Pipeline.step over the drop-in classes (Python lists of objects, host buffers, synchronous) "
-                   "vs the same step resident in device tables (vo_pipe_step, 3 steps in flight)" % ba_window)
+    out["what"] = ("ONE 1241x376 sequence, window %d: Pipeline.step over the drop-in classes -- python_objects: every call gathers / scatters Python "
+                   "objects (host buffers, synchronous); lazy_views: the lists are views of the device tables (vo_mi355x/lazy.py), one vo_pipe_step stage "
+                   "per call, the reference's own caller loop (`if i in inliers` for every landmark, two appends) included -- vs the same step resident "
+                   "in device tables without any Python objects (vo_pipe_step, 3 steps in flight)" % ba_window)
     return out
 
 

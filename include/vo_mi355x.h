@@ -430,7 +430,14 @@ typedef struct {
 } vo_pipe_record;
 
 enum { VO_PIPE_LOST = 1, VO_PIPE_CAPACITY = 2, VO_PIPE_GROUPS = 4 };   /* LOST: the 3D-2D pose found no consensus (the reference crashes there); CAPACITY: object rows exhausted; GROUPS: a ripe candidate was born more than 32 frames ago (its pose has left the trajectory ring) */
-enum { VO_PIPE_TRACK = 1, VO_PIPE_POSE = 2, VO_PIPE_TRIANGULATE = 4, VO_PIPE_ADJUST = 8, VO_PIPE_DETECT = 16, VO_PIPE_ALL = 31 };
+enum { VO_PIPE_TRACK = 1, VO_PIPE_POSE = 2, VO_PIPE_TRIANGULATE = 4, VO_PIPE_ADJUST = 8, VO_PIPE_DETECT = 16, VO_PIPE_ALL = 31,
+       /* the two halves of TRACK's bookkeeping as the reference calls them (extractor.py:38-59 then :61-88): VO_PIPE_TRACK | VO_PIPE_TRACK_CANDIDATES
+          = pyramid + KLT of every keypoint + extend_tracks; then VO_PIPE_TRACK_LANDMARKS alone = extend_landmarks on the same tracked set (the
+          step counter advances here).  Neither bit: both halves (the closed loop).  Used by the object boundary, vo_mi355x/lazy.py */
+       VO_PIPE_TRACK_CANDIDATES = 32, VO_PIPE_TRACK_LANDMARKS = 64,
+       /* a stage-wise caller: rows that left the lists in this call are NOT handed out again yet (the free lists are rebuilt by the first later call
+          without this bit, normally the frame's DETECT) -- so their contents can still be read back after the call (vo_pipe_rows_read) */
+       VO_PIPE_KEEP_FREE_LISTS = 128 };
 #define VO_PIPE_INFLIGHT 4
 #define VO_PIPE_HIST 32
 
@@ -460,6 +467,16 @@ int32_t vo_pipe_commit(vo_ctx* ctx);
 int32_t vo_pipe_step(vo_ctx* ctx, int32_t frame_idx, int32_t stages);
 int32_t vo_pipe_fetch(vo_ctx* ctx, vo_pipe_record* rec /* [batch] */);        /* waits for the OLDEST step not fetched yet */
 int32_t vo_pipe_set_ba_budget(vo_ctx* ctx, int32_t budget);
+/* Read-backs for the object boundary (vo_mi355x/lazy.py: the reference's Extractor / BundleAdjuster interface, src/extractor/extractor.py:38-277 and
+ * src/bundle_adjuster/bundle_adjuster.py:127-215, as views of these tables).  All synchronous, no step may be in flight.
+ * lists_read: tables VO_PIPE_CAND .. VO_PIPE_POSES in ONE copy, as they lie on the device -- each [batch][...], each padded to a multiple of 256 bytes.
+ * rows_read: object rows by index, kind 0 = K rows -> {i32 t_first, t_total, hist_len, 0; f32 uv[2], uv_first[2]; f32 hist[32][2]} (288 bytes, ring
+ * slot order), kind 1 = L rows -> {i32 t_latest, 0; f64 p[3]} (32 bytes); rows [batch][n], n <= max_pts.
+ * inliers_read: the consensus mask of the last POSE stage over the landmark list as it was before the pruning, [batch][n]. */
+int32_t vo_pipe_lists_bytes(vo_ctx* ctx, uint64_t* bytes);
+int32_t vo_pipe_lists_read(vo_ctx* ctx, void* dst);
+int32_t vo_pipe_rows_read(vo_ctx* ctx, int32_t kind, const int32_t* rows, int32_t n, void* out);
+int32_t vo_pipe_inliers_read(vo_ctx* ctx, uint8_t* mask, int32_t n);
 
 /* ---- fused per-frame step on resident data ---------------------------------------------------
  * One call enqueues the hot path of one frame in the order of Pipeline.step (src/pipeline/pipeline.py:92-167):

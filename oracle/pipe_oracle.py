@@ -201,25 +201,36 @@ class PipeModel:
         return self.k_uv[ids].reshape(-1, 2).copy() if ids else np.zeros((0, 2), np.float32)
 
     def track(self, img):
-        self.t += 1
+        self.extend(self.track_points(img))
+
+    def track_points(self, img):
+        """pyramid + KLT of every keypoint of the state (landmark entries first): the tracked positions both halves of `extend` read"""
         self.ctx.push_frame(img)
         p0 = self.dense_points()
-        p1 = self.ctx.klt_track(p0)[0] if len(p0) else p0
-        self.extend(p1)
+        self._p1 = self.ctx.klt_track(p0)[0] if len(p0) else p0
+        self._p1_nl = len(self.lm_L)
+        return self._p1
 
     def _inside(self, p):
         return (p[:, 0] >= 0) & (p[:, 0] <= self.w) & (p[:, 1] >= 0) & (p[:, 1] <= self.h)     # NaN fails, ends included
 
-    def extend(self, p1):
+    def extend(self, p1, which=3):
+        """which: bit 0 the candidates (extend_tracks), bit 1 the landmarks (extend_landmarks; the step counter advances here) -- the two
+        halves of k_pipe_extend, which the object boundary runs one after the other on the same tracked point set"""
         nl = len(self.lm_L)
         keep = self._inside(p1)
-        # candidates (extend_tracks)
-        out = []
-        for i, k in enumerate(self.cand):
-            if keep[nl + i]:
-                self.k_uv[k] = p1[nl + i]; self.k_tt[k] += 1; self._append_hist(k, p1[nl + i])
-                out.append(k)
-        self.cand = out
+        if which & 1:
+            # candidates (extend_tracks)
+            out = []
+            for i, k in enumerate(self.cand):
+                if keep[nl + i]:
+                    self.k_uv[k] = p1[nl + i]; self.k_tt[k] += 1; self._append_hist(k, p1[nl + i])
+                    out.append(k)
+            self.cand = out
+        if not (which & 2):
+            return
+        self.t += 1
+        self.keep_mask = keep[:nl].copy()
         # landmarks (extend_landmarks): phase A -- survivors update their keypoint and their landmark's t_latest
         for j in range(nl):
             if keep[j]:
@@ -260,6 +271,7 @@ class PipeModel:
             return
         mask = np.zeros(len(X), bool)
         mask[np.asarray(inl, np.int64).reshape(-1)] = True
+        self.inlier_mask = mask.copy()
         for j in range(len(X)):
             if not mask[j]:       # deepcopy per entry (pipeline.py:133-134): no shared copies
                 self._push_dead(lambda: self.copy_L(self.lm_L[j]), lambda: self.copy_K(self.lm_K[j]))

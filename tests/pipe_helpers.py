@@ -16,11 +16,15 @@ from vo_mi355x.synthetic import gt_bootstrap, sway_pose, sway_scene as scene  # 
 class ObjectLoop:
     """Pipeline.__init__ / step (pipeline.py:13-40, 92-167) over vo_mi355x.Extractor / BundleAdjuster"""
 
-    def __init__(self, ctx, K, state, im_prev, t_step=1, ba_window=4, min_kp_dist=7, max_reproj=2.0, min_angle=0.5, ba_max_iters=50):
+    def __init__(self, ctx, K, state, im_prev, t_step=1, ba_window=4, min_kp_dist=7, max_reproj=2.0, min_angle=0.5, ba_max_iters=50, literal=False,
+                 **extractor_kw):
+        """literal: `if i in inliers` on the list camera_pose returned, as pipeline.py:130 writes it (default: a set, which a plain list of
+        3 000 inlier indices needs to stay out of O(n^2)); extractor_kw: lazy=..., lazy_backend=... (tests of vo_mi355x/lazy.py)"""
         from vo_mi355x import BundleAdjuster, Extractor
-        self.K, self.state, self.t_step = K, state, t_step
+        self.K, self.state, self.t_step, self.literal = K, state, t_step, literal
         self.ba_window, self.min_kp_dist, self.max_reproj, self.min_angle = ba_window, min_kp_dist, max_reproj, min_angle
-        self.extractor = Extractor(min_kp_dist=min_kp_dist, ctx=ctx)
+        extractor_kw.setdefault("lazy", False)
+        self.extractor = Extractor(min_kp_dist=min_kp_dist, ctx=ctx, **extractor_kw)
         self.adjuster = BundleAdjuster(verbosity=0, window_size=ba_window, method='trf', xtol=1e-3, ftol=1e-3, ctx=ctx, max_iters=ba_max_iters)
         self.dead, self.dead_kp = [], []
         self.extractor._im_prev = im_prev
@@ -34,7 +38,7 @@ class ObjectLoop:
         self.dead += copy.deepcopy(ld); self.dead_kp += copy.deepcopy(lkd)
         ex._im_prev = im.copy()
         inl, Hk = ex.camera_pose(K, st._landmarks, st._landmarks_kp, corr='3D-2D', max_err_reproj=self.max_reproj)
-        inl_set = set(inl)
+        inl_set = inl if self.literal else set(inl)
         lms, lkp = [], []
         for i in range(len(st._landmarks)):
             if i in inl_set:

@@ -55,8 +55,12 @@ enum { DN_PTS = 0, DN_PNP = 1, DN_RIPE = 2, DN_ROOM = 3 };   // DN_ROOM: free sl
 struct vo_pipe_ws {
   int N = 0, R = 0;
   vo_pipe_params prm;
-  void* tab[VO_PIPE_N_TABLES] = {};
-  size_t tab_bytes[VO_PIPE_N_TABLES] = {};       // per sequence
+  void* tab[VO_PIPE_N_TABLES] = {};              // all inside ONE allocation (tab_slab), in table order: the lists, the counters and the
+  size_t tab_bytes[VO_PIPE_N_TABLES] = {};       // trajectory ring (tables VO_PIPE_CAND ...) are contiguous -> vo_pipe_lists_read is one copy.  (per sequence)
+  uint8_t* tab_slab = nullptr;
+  size_t lists_bytes = 0;                        // from tab[VO_PIPE_CAND] to the end of the slab
+  uint8_t* d_gather = nullptr;                   // vo_pipe_rows_read: packed rows [N][288 B]
+  int32_t* d_gather_rows = nullptr;
   int32_t *d_ripe = nullptr, *d_freeK = nullptr, *d_freeL = nullptr, *d_scr = nullptr, *d_dn = nullptr, *d_cam_sel = nullptr;
   vo_dlt_cam* d_cams = nullptr;                  // [B][HIST]: one camera pair per birth frame of the ripe candidates
   double* d_K = nullptr;
@@ -205,8 +209,12 @@ __device__ inline void pipe_log_so3(const double* R, double* r) {
 // election), (4) the row copies as one cooperative pass of the whole workgroup over a work list.
 // Dynamic LDS: int32 [R] per-landmark-row word | [N] free K rows | [N] free L rows | [N] copy sources  (28 bytes per slot of the table)
 template <int CH>
+// which: bit 0 the candidates (extend_tracks), bit 1 the landmarks (extend_landmarks) -- both in the closed loop; the object boundary
+// (vo_mi355x/lazy.py) runs them as the reference calls them, one after the other on the SAME tracked point set (the step counter advances
+// with the landmarks)
 __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const float* __restrict__ pts, size_t slab_seq, int W, int H,
-                                                          float* __restrict__ pnp_X, float* __restrict__ pnp_uv, int pnp_cap) {
+                                                          float* __restrict__ pnp_X, float* __restrict__ pnp_uv, int pnp_cap, int which,
+                                                          uint8_t* __restrict__ keep_out) {
   extern __shared__ int32_t s_dyn[];
   __shared__ int s_w[16];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -234,11 +242,12 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
     const int j = tid * CH + c;
     L[c] = 0; K[c] = 0; KC[c] = 0; keep[c] = die[c] = ksh[c] = keepc[c] = false;
     q[c] = qc[c] = make_float2(0.f, 0.f);
-    if (j < nl) {
+    if ((which & 2) && j < nl) {
       L[c] = P.lm_L[j]; K[c] = P.lm_K[j]; ksh[c] = P.lm_ksh[j] != 0; q[c] = p1[j];
       keep[c] = pipe_inside(q[c], W, H); die[c] = !keep[c];
+      keep_out[(size_t)b * pnp_cap + j] = keep[c] ? 1 : 0;      // which landmark entries survived (vo_pipe_inliers_read until the POSE stage overwrites it)
     }
-    if (j < nc) { KC[c] = P.cand[j]; qc[c] = p1[nl + j]; keepc[c] = pipe_inside(qc[c], W, H); }
+    if ((which & 1) && j < nc) { KC[c] = P.cand[j]; qc[c] = p1[nl + j]; keepc[c] = pipe_inside(qc[c], W, H); }
   }
   // ---- trip 3: every row field the phases below need, and the heads of the free lists ----
   int len[CH], tt[CH], tl[CH], lenc[CH], ttc[CH];
@@ -247,12 +256,12 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
   for (int c = 0; c < CH; c++) {
     const int j = tid * CH + c;
     len[c] = tt[c] = tl[c] = lenc[c] = ttc[c] = 0; lp[c][0] = lp[c][1] = lp[c][2] = 0.0;
-    if (j < nl) {
+    if ((which & 2) && j < nl) {
       len[c] = P.k_len[K[c]]; tt[c] = P.k_tt[K[c]]; tl[c] = P.l_tl[L[c]];
       for (int k = 0; k < 3; k++) lp[c][k] = P.l_p[3 * (size_t)L[c] + k];
       s_row[L[c]] = 0;                               // (entries that share a row all write 0)
     }
-    if (j < nc) { lenc[c] = P.k_len[KC[c]]; ttc[c] = P.k_tt[KC[c]]; }
+    if ((which & 1) && j < nc) { lenc[c] = P.k_len[KC[c]]; ttc[c] = P.k_tt[KC[c]]; }
   }
   for (int i = tid; i < P.N; i += PIPE_TPB) {        // no phase takes more than N rows of either kind
     s_fk[i] = (headK + i < nfK) ? P.freeK[headK + i] : -1;
@@ -261,7 +270,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
   __syncthreads();
 
   // ---- candidates (extend_tracks): survivors get uv, t_total + 1, a history entry; ordered compaction ----
-  {
+  if (which & 1) {
     int rank[CH];
     const int n_out = pipe_rank<CH>(keepc, rank, s_w);
 #pragma unroll
@@ -271,8 +280,9 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
         P.k_uv[k] = qc[c]; P.k_tt[k] = ttc[c] + 1; pipe_hist_slot(P, lenc[c])[k] = qc[c]; P.k_len[k] = lenc[c] + 1;
         P.cand[rank[c]] = k;
       }
-    if (tid == 0) P.cnt[C_NCAND] = n_out;
+    if (tid == 0) { P.cnt[C_NCAND] = n_out; P.cnt[C_NKLT] = nl + nc; }
   }
+  if (!(which & 2)) return;                          // (uniform)
 
   // ---- landmarks: survivors update their keypoint row IN PLACE (extractor.py:80-83: the deepcopy comes after) and count into their
   //      landmark row's word -- several entries may share a landmark object, which then advances by as many frames ----
@@ -371,7 +381,8 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
         for (int k = 0; k < 3; k++) pnp_X[3 * o + k] = (float)lp[c][k];
       }
     if (tid == 0) {
-      P.cnt[C_NLM] = n_out; P.cnt[C_NPNP] = n_out; P.cnt[C_NKLT] = nl + nc;
+      P.cnt[C_NLM] = n_out; P.cnt[C_NPNP] = n_out;
+      if (which & 1) P.cnt[C_NKLT] = nl + nc;          // (landmarks alone: the candidates' half has recorded it before it compacted its list)
       Pall.dn[DN_PNP * gridDim.x + b] = n_out;
       P.cnt[C_T] += 1; P.cnt[C_HEADK] = headK; P.cnt[C_HEADL] = headL;
       P.cnt[C_NINERT] += inert; P.cnt[C_OVERFLOW] = overflow;
@@ -907,7 +918,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_writeback(pipe_ptrs Pall, int
 template <int CH>
 __global__ void __launch_bounds__(PIPE_TPB) k_pipe_spawn(pipe_ptrs Pall, int do_detect, const uint32_t* __restrict__ st_scalars, const float* __restrict__ st_out,
                                                          float* __restrict__ pts, size_t slab_seq, int max_new, const double* __restrict__ pnp_out,
-                                                         const int32_t* __restrict__ pnp_ctrl, size_t pnp_ctrl_stride, vo_pipe_record* __restrict__ rec) {
+                                                         const int32_t* __restrict__ pnp_ctrl, size_t pnp_ctrl_stride, vo_pipe_record* __restrict__ rec, int rebuild) {
   __shared__ int s_w[16];
   const int b = blockIdx.x, tid = threadIdx.x;
   const pipe_ptrs P = pipe_select(Pall, b);
@@ -946,7 +957,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_spawn(pipe_ptrs Pall, int do_
   //      RPT consecutive rows, so the two free lists cost two block scans and no global round trip besides reading the lists (the earlier
   //      form marked in global scratch and scanned the R rows 1 024 at a time: 16 scans, 8 global phases) ----
   const int nd = P.cnt[C_NDEAD];
-  {
+  if (rebuild) {       // (uniform.  Stage-wise callers may keep the free lists until the frame's last stage: VO_PIPE_KEEP_FREE_LISTS)
     __shared__ uint32_t s_mark[2][PIPE_TPB * PIPE_CH];            // [K | L][R / 4]: R <= 4 * max_pts <= 16 384 bytes each
     uint8_t* const mk = reinterpret_cast<uint8_t*>(s_mark[0]);
     uint8_t* const ml = reinterpret_cast<uint8_t*>(s_mark[1]);
@@ -1005,8 +1016,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_dense(pipe_ptrs Pall, float* 
 void vo_pipe_destroy(vo_ctx* c) {
   if (!c->pipe) return;
   vo_pipe_ws* w = c->pipe;
-  for (void* p : w->tab) if (p) (void)hipFree(p);
-  void* bufs[] = {w->d_ripe, w->d_freeK, w->d_freeL, w->d_scr, w->d_dn, w->d_cam_sel, w->d_cams, w->d_K, w->d_rec};
+  void* bufs[] = {w->tab_slab, w->d_gather, w->d_gather_rows, w->d_ripe, w->d_freeK, w->d_freeL, w->d_scr, w->d_dn, w->d_cam_sel, w->d_cams, w->d_K, w->d_rec};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (w->h_rec) (void)hipHostFree(w->h_rec);
   for (hipEvent_t e : w->ev) if (e) (void)hipEventDestroy(e);
@@ -1056,11 +1066,16 @@ static int32_t pipe_create(vo_ctx* c, const double* K, const vo_pipe_params* prm
   const size_t B = c->batch, N = w->N, R = w->R;
   const size_t sz[VO_PIPE_N_TABLES] = {4 * R, 4 * R, 4 * R, 8 * R, 8 * R, 8 * R * PIPE_HIST, 4 * R, 24 * R, 4 * N, 4 * N, 4 * N, 4 * N, 4 * N, 4 * N,
                                        4 * PIPE_NCNT, 8 * 12 * PIPE_HIST};
-  for (int i = 0; i < VO_PIPE_N_TABLES; i++) {
-    w->tab_bytes[i] = sz[i];
-    VO_HIP(c, hipMalloc(&w->tab[i], sz[i] * B));
-    VO_HIP(c, hipMemsetAsync(w->tab[i], 0, sz[i] * B, c->stream));
+  {
+    size_t off[VO_PIPE_N_TABLES + 1] = {};
+    for (int i = 0; i < VO_PIPE_N_TABLES; i++) { w->tab_bytes[i] = sz[i]; off[i + 1] = off[i] + ((sz[i] * B + 255) & ~(size_t)255); }
+    VO_HIP(c, hipMalloc((void**)&w->tab_slab, off[VO_PIPE_N_TABLES]));
+    VO_HIP(c, hipMemsetAsync(w->tab_slab, 0, off[VO_PIPE_N_TABLES], c->stream));
+    for (int i = 0; i < VO_PIPE_N_TABLES; i++) w->tab[i] = w->tab_slab + off[i];
+    w->lists_bytes = off[VO_PIPE_N_TABLES] - off[VO_PIPE_CAND];
   }
+  VO_HIP(c, hipMalloc((void**)&w->d_gather, 288 * N * B));
+  VO_HIP(c, hipMalloc((void**)&w->d_gather_rows, 4 * N * B));
   VO_HIP(c, hipMalloc((void**)&w->d_ripe, 4 * N * B));
   VO_HIP(c, hipMalloc((void**)&w->d_freeK, 4 * R * B));
   VO_HIP(c, hipMalloc((void**)&w->d_freeL, 4 * R * B));
@@ -1122,6 +1137,89 @@ extern "C" int32_t vo_pipe_table_read(vo_ctx* c, int32_t which, void* dst) {
   return VO_OK;
 }
 
+// The object boundary (vo_mi355x/lazy.py: the reference's Extractor / BundleAdjuster interface over these tables) reads, after a stage,
+// the LISTS -- tables VO_PIPE_CAND .. VO_PIPE_POSES as they lie in the slab, each [batch][...] and padded to 256 bytes: `bytes` from
+// vo_pipe_lists_bytes, offsets = the running sum of the padded table sizes -- in ONE copy, and single object rows by index.
+extern "C" int32_t vo_pipe_lists_bytes(vo_ctx* c, uint64_t* bytes) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->pipe && bytes, VO_E_INVALID, "vo_pipe_create first / null output");
+  *bytes = c->pipe->lists_bytes;
+  return VO_OK;
+}
+
+extern "C" int32_t vo_pipe_lists_read(vo_ctx* c, void* dst) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->pipe && dst, VO_E_INVALID, "vo_pipe_create first / null output");
+  VO_CHECK(c, c->pipe->enq == c->pipe->fetched, VO_E_STATE, "fetch the steps in flight first");
+  VO_HIP(c, hipSetDevice(c->device));
+  VO_HIP(c, hipMemcpyAsync(dst, c->pipe->tab[VO_PIPE_CAND], c->pipe->lists_bytes, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
+// packed object rows: K row = {i32 t_first, t_total, hist_len, 0; f32 uv[2], uv_first[2]; f32 hist[32][2]} (288 bytes, ring slot order),
+// L row = {i32 t_latest, 0; f64 p[3]} (32 bytes)
+__global__ void k_pipe_gather(pipe_ptrs Pall, int kind, const int32_t* __restrict__ rows, int n, int cap, uint8_t* __restrict__ out) {
+  const int b = blockIdx.y;
+  const pipe_ptrs P = pipe_select(Pall, b);
+  rows += (size_t)b * cap;
+  if (kind == 0) {
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5), f = threadIdx.x & 31;     // 32 lanes per row
+    if (i >= n) return;
+    const int r = rows[i];
+    uint8_t* o = out + ((size_t)b * cap + i) * 288;
+    if (r < 0 || r >= P.R) { if (f == 0) reinterpret_cast<int32_t*>(o)[0] = 0x7FFFFFFF; return; }
+    reinterpret_cast<float2*>(o + 32)[f] = P.k_hist[(size_t)f * P.R + r];
+    if (f == 0) { int32_t* h = reinterpret_cast<int32_t*>(o); h[0] = P.k_tf[r]; h[1] = P.k_tt[r]; h[2] = P.k_len[r]; h[3] = 0; }
+    if (f == 1) reinterpret_cast<float2*>(o + 16)[0] = P.k_uv[r];
+    if (f == 2) reinterpret_cast<float2*>(o + 24)[0] = P.k_first[r];
+  } else {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = rows[i];
+    uint8_t* o = out + ((size_t)b * cap + i) * 32;
+    if (r < 0 || r >= P.R) { reinterpret_cast<int32_t*>(o)[0] = 0x7FFFFFFF; return; }
+    reinterpret_cast<int32_t*>(o)[0] = P.l_tl[r]; reinterpret_cast<int32_t*>(o)[1] = 0;
+    for (int k = 0; k < 3; k++) reinterpret_cast<double*>(o + 8)[k] = P.l_p[3 * (size_t)r + k];
+  }
+}
+
+// rows [batch][n] (row indices of one kind: 0 = K rows, 1 = L rows), n <= max_pts -> out [batch][n][288 | 32 bytes]; synchronous
+extern "C" int32_t vo_pipe_rows_read(vo_ctx* c, int32_t kind, const int32_t* rows, int32_t n, void* out) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->pipe && rows && out && (kind == 0 || kind == 1), VO_E_INVALID, "vo_pipe_create first / bad arguments");
+  vo_pipe_ws* w = c->pipe;
+  VO_CHECK(c, n >= 0 && n <= w->N, VO_E_CAPACITY, "at most max_pts rows per call");
+  VO_CHECK(c, w->enq == w->fetched, VO_E_STATE, "fetch the steps in flight first");
+  if (n == 0) return VO_OK;
+  VO_HIP(c, hipSetDevice(c->device));
+  const size_t rec = kind == 0 ? 288 : 32;
+  VO_HIP(c, hipMemcpy2DAsync(w->d_gather_rows, 4 * (size_t)w->N, rows, 4 * (size_t)n, 4 * (size_t)n, c->batch, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_pipe_gather, dim3(kind == 0 ? vo_div_up(n, 8) : vo_div_up(n, 256), c->batch), dim3(256), 0, c->stream, pipe_make(w), kind,
+                     w->d_gather_rows, n, w->N, w->d_gather);
+  VO_HIP(c, hipGetLastError());
+  VO_HIP(c, hipMemcpy2DAsync(out, rec * n, w->d_gather, rec * w->N, rec * n, c->batch, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
+// the consensus set of the last POSE stage: mask [batch][n] over the landmark list as it was BEFORE the pruning (n = the record's pnp
+// input count, <= max_pts); synchronous
+extern "C" int32_t vo_pipe_inliers_read(vo_ctx* c, uint8_t* mask, int32_t n) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->pipe && mask, VO_E_INVALID, "vo_pipe_create first / null output");
+  vo_pipe_ws* w = c->pipe;
+  VO_CHECK(c, n >= 0 && n <= w->N, VO_E_CAPACITY, "at most max_pts entries");
+  VO_CHECK(c, w->enq == w->fetched, VO_E_STATE, "fetch the steps in flight first");
+  if (n == 0) return VO_OK;
+  VO_HIP(c, hipSetDevice(c->device));
+  vo_pnp_view pv;
+  { const int32_t r = vo_pnp_get_view(c, &pv); if (r != VO_OK) return r; }
+  VO_HIP(c, hipMemcpy2DAsync(mask, n, pv.mask, pv.cap, n, c->batch, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
 // entries per thread of the list kernels: the lists hold at most max_pts entries
 #define PIPE_DISPATCH(KERNEL, ...)                                                                                              \
   do {                                                                                                                          \
@@ -1130,13 +1228,13 @@ extern "C" int32_t vo_pipe_table_read(vo_ctx* c, int32_t which, void* dst) {
     else hipLaunchKernelGGL(KERNEL<4>, dim3(c->batch), dim3(PIPE_TPB), 0, c->stream, __VA_ARGS__);                               \
   } while (0)
 
-static void pipe_launch_spawn(vo_ctx* c, int do_detect) {
+static void pipe_launch_spawn(vo_ctx* c, int do_detect, int rebuild = 1) {
   vo_pipe_ws* w = c->pipe;
   vo_pnp_view pv;
   (void)vo_pnp_get_view(c, &pv);
   PIPE_DISPATCH(k_pipe_spawn, pipe_make(w), do_detect, vo_slab<const uint32_t>(c, c->off_st_scalars),
                      vo_slab<const float>(c, c->off_st_out), vo_slab<float>(c, vo_off_p(c)), c->slab_seq, w->prm.max_new, pv.out, pv.ctrl,
-                pv.ctrl_stride, w->d_rec);
+                pv.ctrl_stride, w->d_rec, rebuild);
 }
 
 extern "C" int32_t vo_pipe_commit(vo_ctx* c) {
@@ -1200,6 +1298,7 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
   // it is downstream of all side work.  A frame the caller pushed itself (frame_idx < 0) is tracked on the main stream as before.
   const bool side = c->side_stream != 0 && c->stream2 != nullptr;
   hipStream_t const main_stream = c->stream;
+  const int halves = (stages & (VO_PIPE_TRACK_CANDIDATES | VO_PIPE_TRACK_LANDMARKS)) ? (((stages & VO_PIPE_TRACK_CANDIDATES) ? 1 : 0) | ((stages & VO_PIPE_TRACK_LANDMARKS) ? 2 : 0)) : 3;
   if (stages & VO_PIPE_TRACK) {
     if (frame_idx >= 0) VO_CHECK(c, c->d_seq && frame_idx < c->seq_n, VO_E_STATE, "no resident sequence / bad frame index");
     VO_CHECK(c, c->n_pushed + (frame_idx >= 0 ? 1 : 0) >= 2, VO_E_STATE, "tracking needs two frames in the frame store");
@@ -1226,16 +1325,17 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
       if (r == VO_OK) { VO_HIP(c, e1); VO_HIP(c, e2); }
     }
     if (r != VO_OK) return r;
-    {
-      const size_t lds = sizeof(int32_t) * ((size_t)w->R + 3 * (size_t)w->N);
-      auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(c->batch), dim3(PIPE_TPB), lds, c->stream, P, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq,
-                           c->width, c->height, pv.X, pv.uv, pv.cap);
-      };
-      if (w->N <= PIPE_TPB) launch(k_pipe_extend<1>);
-      else if (w->N <= 2 * PIPE_TPB) launch(k_pipe_extend<2>);
-      else launch(k_pipe_extend<4>);
-    }
+  }
+  // the keep rule / bookkeeping on the tracked point set: with TRACK, or alone (VO_PIPE_TRACK_LANDMARKS after a TRACK | VO_PIPE_TRACK_CANDIDATES call)
+  if ((stages & VO_PIPE_TRACK) || (stages & (VO_PIPE_TRACK_CANDIDATES | VO_PIPE_TRACK_LANDMARKS))) {
+    const size_t lds = sizeof(int32_t) * ((size_t)w->R + 3 * (size_t)w->N);
+    auto launch = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(c->batch), dim3(PIPE_TPB), lds, c->stream, P, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq,
+                         c->width, c->height, pv.X, pv.uv, pv.cap, halves, const_cast<uint8_t*>(pv.mask));
+    };
+    if (w->N <= PIPE_TPB) launch(k_pipe_extend<1>);
+    else if (w->N <= 2 * PIPE_TPB) launch(k_pipe_extend<2>);
+    else launch(k_pipe_extend<4>);
   }
   if (stages & VO_PIPE_POSE) {
     r = vo_pnp_enqueue_counts(c, &prm.pnp, prm.pnp_blind_batches, w->d_dn + DN_PNP * B);
@@ -1269,7 +1369,7 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
     else if (w->N <= 2 * PIPE_TPB) launch(k_pipe_promote<2>);
     else launch(k_pipe_promote<4>);
   }
-  else
+  else if (halves & 2)   // (after the candidates' half alone the buffer still holds the tracked positions the landmarks' half will read)
     hipLaunchKernelGGL(k_pipe_dense, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, vo_slab<float>(c, vo_off_p(c)), c->slab_seq, 0);
   if (side) {
     // re-detection + spawn on the side stream behind promote / dense; adjustment + write-back on the main stream
@@ -1277,7 +1377,7 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
     VO_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     c->stream = c->stream2;
     r = (stages & VO_PIPE_DETECT) ? vo_shi_tomasi_resident_counts(c, w->N, prm.mask_radius, &prm.st, w->d_dn + DN_PTS * B, w->d_dn + DN_ROOM * B) : VO_OK;
-    if (r == VO_OK) pipe_launch_spawn(c, (stages & VO_PIPE_DETECT) ? 1 : 0);
+    if (r == VO_OK) pipe_launch_spawn(c, (stages & VO_PIPE_DETECT) ? 1 : 0, (stages & VO_PIPE_KEEP_FREE_LISTS) ? 0 : 1);
     c->stream = main_stream;
     if (r == VO_OK && (stages & VO_PIPE_ADJUST)) r = vo_ba_enqueue_budget(c, &prm.ba, 0, prm.ba_budget);
     if (r == VO_OK) PIPE_DISPATCH(k_pipe_writeback, P, (stages & VO_PIPE_ADJUST) ? 1 : 0, bv.pub, bv.pub_bytes, bv.x0, bv.x_stride, bv.W, w->d_rec);
@@ -1295,7 +1395,7 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
       if (r != VO_OK) return r;
     }
     PIPE_DISPATCH(k_pipe_writeback, P, (stages & VO_PIPE_ADJUST) ? 1 : 0, bv.pub, bv.pub_bytes, bv.x0, bv.x_stride, bv.W, w->d_rec);
-    pipe_launch_spawn(c, (stages & VO_PIPE_DETECT) ? 1 : 0);
+    pipe_launch_spawn(c, (stages & VO_PIPE_DETECT) ? 1 : 0, (stages & VO_PIPE_KEEP_FREE_LISTS) ? 0 : 1);
   }
   VO_HIP(c, hipGetLastError());
   const int slot = (int)(w->enq % VO_PIPE_INFLIGHT);

@@ -167,6 +167,10 @@ SIGNATURES = {
     "vo_pipe_step": (C.c_int32, [_ctx, C.c_int32, C.c_int32]),
     "vo_pipe_fetch": (C.c_int32, [_ctx, C.POINTER(PipeRecord)]),
     "vo_pipe_set_ba_budget": (C.c_int32, [_ctx, C.c_int32]),
+    "vo_pipe_lists_bytes": (C.c_int32, [_ctx, C.POINTER(C.c_uint64)]),
+    "vo_pipe_lists_read": (C.c_int32, [_ctx, C.c_void_p]),
+    "vo_pipe_rows_read": (C.c_int32, [_ctx, C.c_int32, _i32p, C.c_int32, C.c_void_p]),
+    "vo_pipe_inliers_read": (C.c_int32, [_ctx, _u8p, C.c_int32]),
     "vo_ba_probe": (C.c_int32, [_ctx, C.c_double, C.c_double, _f64p, _i32p, _f64p, _f64p, _f64p, _f64p, _f64p,
                                 _f64p, _f64p, _f64p, _f64p]),
 }

@@ -61,6 +61,20 @@ class BundleAdjuster:
         return poses, points, obs, n_live, [p[0] for p in stay_out], [p[1] for p in stay_out]
 
     def adjust(self, state, landmarks_dead, landmarks_kp_dead, K, t_now):
+        from . import lazy as _lz
+        sess = _lz.session_of(state, landmarks_kp_dead)
+        if sess is not None:          # the lists are views of the device tables (lazy.py): resurrection, solve and write-back happen there
+            r = sess.adjust(state, landmarks_dead, landmarks_kp_dead, K, t_now, self._window_size, self._ftol, self._xtol, self._max_iters) \
+                if self._loss == 'huber' else sess._fail("adjust: loss")
+            if r is not NotImplemented:
+                state, dead_l, dead_k, self.last_stats = r
+                return state, dead_l, dead_k
+        state, dead_l, dead_k = self._adjust_plain(state, landmarks_dead, landmarks_kp_dead, K, t_now)
+        # a frame that came through the reference's call order ends here: from now on the state can live in device tables
+        seeded = _lz.seed_after_adjust(self, state, dead_l, dead_k, K, t_now)
+        return (state,) + seeded if seeded is not None else (state, dead_l, dead_k)
+
+    def _adjust_plain(self, state, landmarks_dead, landmarks_kp_dead, K, t_now):
         poses, points, obs, n_live, out_l, out_k = self.build_problem(state, landmarks_dead, landmarks_kp_dead, t_now)
         lms, kps = state._landmarks, state._landmarks_kp
         N, W = len(lms), self._window_size

@@ -26,8 +26,18 @@ class DMatch:
 
 
 class Extractor:
-    def __init__(self, cfg=None, min_kp_dist=10, ctx=None, device=0, max_pts=8192):
+    def __init__(self, cfg=None, min_kp_dist=10, ctx=None, device=0, max_pts=4096, lazy=None, lazy_backend=None):
+        """lazy (default: on unless VO_LAZY=0): once a frame has come through the reference's call order (pipeline.py:98-156) the state moves
+        into device tables and the lists this class hands out are views of them (vo_mi355x/lazy.py); lazy_backend: test hook
+        (ctx, K, params, width, height) -> backend, default the GPU one.  max_pts: keypoints per call AND the capacity of those tables (<= 4096)."""
+        from . import lazy as _lz
         self._cfg = cfg
+        self._lazy_on = _lz.enabled() if lazy is None else bool(lazy)
+        self._lazy_backend = lazy_backend
+        self._lazy = None               # the live session, if any
+        self._trace = []                # the plain-path calls of the current frame, in order (is this the reference's Pipeline.step?)
+        self._seen = {}                 # parameters those calls came with (a session is created with them)
+        _lz._EXTRACTORS.add(self)
         # parameters hard-coded by the reference (extractor.py:16-24)
         self._lk_params = dict(winSize=(31, 31), maxLevel=3, criteria=(3, 30, 0.03))
         self._shitomasi_params = dict(maxCorners=1000, qualityLevel=0.03, minDistance=min_kp_dist, blockSize=31)
@@ -86,6 +96,35 @@ class Extractor:
             good = np.abs(p0 - p0r).max(-1) < max_bidir_error
         return p1, good
 
+    # -- the lazy boundary (lazy.py) ---------------------------------------------------------------
+    def _session(self):
+        s = self._lazy
+        if s is not None and not s.alive:
+            s = self._lazy = None
+        return s
+
+    def _plain(self, name, img=None, **seen):
+        """a call is about to take the plain path: a live session ends here (its proxies become plain objects first), and the call is noted"""
+        s = self._session()
+        if s is not None:
+            s.desync("%s took the plain path" % name)
+            self._lazy = None
+        if name == "extend_tracks":
+            self._trace = []
+        self._trace.append((name, None if img is None else id(img)))
+        self._seen.update(seen)
+
+    def _frame_is_reference_order(self):
+        """extend_tracks, extend_landmarks, camera_pose('3D-2D'), triangulate_tracks -- each once, in this order, on one image"""
+        names = [n for n, _ in self._trace]
+        imgs = {i for n, i in self._trace[:2]}
+        return names == ["extend_tracks", "extend_landmarks", "camera_pose", "triangulate_tracks"] and len(imgs) == 1
+
+    def _fast_pushed(self, s):
+        """the session pushed a frame into the context's store: keep this class's record of the store's contents"""
+        if self._dev_cur is not s.cur_img:
+            self._dev_prev, self._dev_cur = self._dev_cur, s.cur_img
+
     # -- KLT ------------------------------------------------------------------------------------
     def _survivors(self, im_curr, p1, good):
         """keep mask of the reference's rule (0 <= x <= W and 0 <= y <= H, ends included, and the 'bidirectional' flag)
@@ -98,6 +137,13 @@ class Extractor:
         return keep, uv, uv.copy()
 
     def extend_tracks(self, im_curr, kp, max_bidir_error=30):
+        s = self._session()
+        if s is not None:
+            r = s.extend_tracks(self._im_prev, im_curr, kp, max_bidir_error)
+            if r is not NotImplemented:
+                self._fast_pushed(s)
+                return r
+        self._plain("extend_tracks", im_curr, max_bidir_error=max_bidir_error)
         new_tracks = []
         if len(kp):
             p0 = self._uv_block(kp)
@@ -112,6 +158,13 @@ class Extractor:
         return new_tracks
 
     def extend_landmarks(self, im_curr, landmarks, landmarks_kp, max_bidir_error=30):
+        s = self._session()
+        if s is not None:
+            r = s.extend_landmarks(self._im_prev, im_curr, landmarks, landmarks_kp, max_bidir_error)
+            if r is not NotImplemented:
+                self._fast_pushed(s)
+                return r
+        self._plain("extend_landmarks", im_curr)
         landmarks_new, kp_new, landmarks_dead, kp_dead = [], [], [], []
         if not len(landmarks_kp):
             return landmarks_new, kp_new, landmarks_dead, kp_dead
@@ -137,11 +190,18 @@ class Extractor:
     # -- re-detection ---------------------------------------------------------------------------
     def extract(self, img, t, current_kp=[], detector='custom', mask_radius=5, describe=False):
         if detector == 'custom':
+            self._plain("extract_sift")
             return self._extract_sift(img, t, current_kp, describe)
         if detector != 'shi-tomasi':
             raise ValueError("detector must be 'shi-tomasi' or 'custom'")
         if describe:
             raise NotImplementedError("describe=True needs detector='custom' (SIFT): a Shi-Tomasi corner has no SIFT scale")
+        s = self._session()
+        if s is not None:
+            r = s.extract(img, t, current_kp, mask_radius)
+            if r is not NotImplemented:
+                return r
+        self._plain("extract", mask_radius=mask_radius)
         self._context(img)
         self._ensure_cur(img)
         c = self._ctx
@@ -228,6 +288,12 @@ class Extractor:
         """Candidates that reached `min_track_length` leave the candidate list (triangulated or not); they are triangulated
         per birth frame between their first and their newest observation and a group is kept iff its gate passes
         (reference extractor.py:193-242).  -> (new landmarks, their keypoints, remaining candidates)"""
+        s = self._session()
+        if s is not None and refine:
+            r = s.triangulate_tracks(K, candidates_kp, trajectory, t_curr, min_track_length, min_bearing_angle, max_err_reproj)
+            if r is not NotImplemented:
+                return r
+        self._plain("triangulate_tracks", min_track_length=min_track_length, min_bearing_angle=min_bearing_angle, tri_max_err=max_err_reproj)
         ripe = [k for k in candidates_kp if k.t_total >= min_track_length]
         waiting = [k for k in candidates_kp if k.t_total < min_track_length]
         out_l, out_k = [], []
@@ -301,6 +367,13 @@ class Extractor:
         corr='2D-2D' (reference extractor.py:162-172, the bootstrap): cv2.findEssentialMat(prob=0.9999, RANSAC,
         threshold=1.0) + cv2.recoverPose on its inliers; H maps view-1 -> view-2 coordinates, |t| = 1.
         RANSAC draws differ from OpenCV's (statistical parity, see include/vo_mi355x.h)."""
+        if corr == '3D-2D':
+            s = self._session()
+            if s is not None:
+                r = s.camera_pose(K, list_1, list_2, max_err_reproj)
+                if r is not NotImplemented:
+                    return r
+        self._plain("camera_pose" if corr == '3D-2D' else "camera_pose_2d2d", pose_max_err=max_err_reproj)
         if self._ctx is None:
             raise RuntimeError("camera_pose needs the device context: track a frame first (or pass ctx=)")
         if corr == '2D-2D':

@@ -1,0 +1,570 @@
+"""The reference's object interface as VIEWS of the device tables (SURVEY.md section 7 "keep SoA arrays and only materialise objects lazily").
+
+`Pipeline.step` (src/pipeline/pipeline.py:92-167) talks to `Extractor` / `BundleAdjuster` in lists of `Keypoint` / `Landmark` objects
+(src/extractor/extractor.py:38-277, src/bundle_adjuster/bundle_adjuster.py:127-215).  The plain drop-in classes gather every field of every
+object into arrays on the way in and scatter the results back on the way out: ~30 ms per 1241 x 376 frame, ~1 ms of it on the GPU.  Here the
+state lives in the tables of csrc/vo_pipeline.hip and the caller holds
+
+  * `LazyKeypoint` / `LazyLandmark`: one PROXY OBJECT per table row (same object for the same row, so `is` / sharing behave as in the
+    reference); a field is read from the device only when somebody asks for it (bulk gather, cached until the next stage);
+  * `LazyList`: a real `list` of proxies (C-speed `len`, indexing, `+`, `+=`, iteration); `copy.deepcopy` of the lists
+    `extend_landmarks` returns hands out the copies the device made (pipeline.py:101-102);
+  * `InlierList`: the list `camera_pose` returns, with O(1) `in` (pipeline.py:130 asks `i in inliers` for every landmark).
+
+Each method of the reference's call sequence maps to one stage of `vo_pipe_step`:
+
+    extend_tracks        TRACK | TRACK_CANDIDATES   pyramid + KLT of every keypoint, the candidates' keep rule / bookkeeping
+    extend_landmarks     TRACK_LANDMARKS            the landmarks' half on the same tracked set; deaths -> dead lists
+    camera_pose('3D-2D') POSE                       P3P-RANSAC + refinement, pruning, trajectory.append on the device
+    triangulate_tracks   TRIANGULATE                DLT per birth group, filters, gate, promotion
+    BundleAdjuster.adjust ADJUST                    resurrection, observation table, LM solve, write-back
+    extract('shi-tomasi') DETECT                    exclusion discs + Shi-Tomasi, corners appended as candidates
+
+A call takes the fast path only if its arguments ARE the session's current lists (checked by identity, C-speed list comparison) and its
+parameters are the ones the session was created with; anything else -- another call order, foreign objects in a list, an attribute written
+from outside, a list that no longer fits the tables -- DESYNCHRONISES the session: every proxy is filled with its values and becomes a
+plain object, and the call (and all later ones) run the plain drop-in path, until the next `BundleAdjuster.adjust` at the end of a frame
+that came through the reference's call order seeds a new session from the caller's objects.  So results are those of the plain classes
+whatever the caller does; only the speed differs.
+
+`DeviceBackend` is the only part that touches the GPU (vo_mi355x.resident.ResidentPipeline + the read-backs vo_pipe_lists_read /
+vo_pipe_rows_read / vo_pipe_inliers_read); tests drive the same `Session` over the table model of oracle/pipe_oracle.py.
+"""
+import copy
+import os
+import sys
+import weakref
+
+import numpy as np
+
+from .state import Keypoint, Landmark
+
+HIST = 32
+_K_FIELDS = ("t_first", "t_total", "uv_first", "uv", "des", "uv_history")
+_L_FIELDS = ("t_latest", "p", "des")
+_EXTRACTORS = weakref.WeakSet()           # drop-in Extractors alive in this process (BundleAdjuster.adjust looks for its partner here)
+
+
+def enabled():
+    return os.environ.get("VO_LAZY", "1") != "0"
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# proxies
+# ------------------------------------------------------------------------------------------------------------------------------------
+class _Proxy:
+    """attached: `_sess` / `_row` set and no field in the instance dict -> __getattr__ fetches; detached (`_row` = -1): a plain object"""
+
+    def __getattr__(self, name):
+        # only reached when normal lookup fails, i.e. for a field of an ATTACHED proxy
+        if name in self._FIELDS:
+            d = self.__dict__
+            row = d.get("_row", -1)
+            if row == -2:
+                raise RuntimeError("stale %s proxy: the object left the pipeline's lists and nobody held it then" % type(self).__name__)
+            if row >= 0:
+                return d["_sess"]._field(self, name)
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        d = self.__dict__
+        if name in self._FIELDS and d.get("_row", -1) >= 0:
+            d["_sess"].desync("an attribute of a %s was written from outside" % type(self).__name__)
+        d[name] = value
+
+    __eq__ = object.__eq__
+    __hash__ = object.__hash__
+
+    def __deepcopy__(self, memo):
+        d = self.__dict__
+        q = d.get("_copy")
+        if q:                                      # the copy the device made when this entry was pruned (pipeline.py:133-134); one per list entry
+            hint = q.pop(0)                        # that held this object, handed out in list order like the reference's per-entry deepcopy calls
+            if not q:
+                del d["_copy"]
+            return hint
+        if d.get("_row", -1) >= 0:
+            d["_sess"]._fill([self])               # values now; the copy is an independent plain object
+            vals = {f: getattr(self, f) for f in self._FIELDS}
+            for f in self._FIELDS:
+                d.pop(f, None)                     # (this proxy stays attached)
+        else:
+            vals = {f: d[f] for f in self._FIELDS if f in d}
+        new = type(self).__new__(type(self))
+        memo[id(self)] = new
+        nd = new.__dict__
+        nd["_row"] = -1
+        for f, v in vals.items():
+            nd[f] = copy.deepcopy(v, memo)
+        return new
+
+    def __repr__(self):
+        return "<%s row %d>" % (type(self).__name__, self.__dict__.get("_row", -1))
+
+
+class LazyKeypoint(_Proxy, Keypoint):
+    _FIELDS = frozenset(_K_FIELDS)
+    _KIND = "K"
+
+
+class LazyLandmark(_Proxy, Landmark):
+    _FIELDS = frozenset(_L_FIELDS)
+    _KIND = "L"
+
+
+class LazyList(list):
+    """a list of proxies; `_copies`: what deepcopy hands out (the device's copies of entries that died)"""
+    _copies = None
+
+    def __deepcopy__(self, memo):
+        if self._copies is not None:
+            out = LazyList(self._copies)
+            for a, b in zip(self, self._copies):
+                memo[id(a)] = b
+            return out
+        return LazyList(copy.deepcopy(x, memo) for x in self)
+
+
+class InlierList(list):
+    """`inliers.reshape((-1,)).tolist()` of extractor.py:191 with a set behind `in`"""
+
+    def __init__(self, it=()):
+        super().__init__(it)
+        self._set = frozenset(self)
+
+    def __contains__(self, i):
+        return i in self._set
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# the GPU side
+# ------------------------------------------------------------------------------------------------------------------------------------
+class DeviceBackend:
+    def __init__(self, ctx, K, prm):
+        from .resident import ResidentPipeline
+        self.ctx = ctx
+        self.rp = ResidentPipeline(ctx, K, ba_window=prm["ba_window"], min_track_length=prm["min_track_length"], mask_radius=prm["mask_radius"],
+                                   max_new=prm["max_new"], max_reproj_err=prm["max_reproj_err"], min_bearing_angle=prm["min_bearing_angle"],
+                                   ba_max_iters=prm["ba_max_iters"], ba_ftol=prm["ba_ftol"], ba_xtol=prm["ba_xtol"], min_kp_dist=prm["min_kp_dist"],
+                                   pnp_blind_batches=prm.get("pnp_blind_batches", 4))
+        self.N = self.rp.N
+
+    def seed(self, state, dead, dead_kp, t_step):
+        self.rp.seed(state, dead, dead_kp, t_step)
+
+    def push_frame(self, img):
+        self.ctx.push_frame(img)
+
+    def stage(self, stages):
+        from .resident import DETECT, KEEP_FREE_LISTS
+        self.rp.step(-1, stages | (0 if stages & DETECT else KEEP_FREE_LISTS))     # rows are recycled once per frame, behind the DETECT stage
+        return self.rp.fetch()
+
+    def lists(self):
+        T = self.rp.read_lists()
+        c = T["counts"][0]
+        n_c, n_l, n_d = int(c[0]), int(c[1]), int(c[2])
+        return dict(cand=T["cand"][0, :n_c].copy(), lm_l=T["lm_l"][0, :n_l].copy(), lm_k=T["lm_k"][0, :n_l].copy(), dead_l=T["dead_l"][0, :n_d].copy(),
+                    dead_k=T["dead_k"][0, :n_d].copy(), poses=T["poses"][0].copy(), t=int(c[5]), status=int(c[4]))
+
+    def mask(self, n):
+        return self.rp.read_inliers(n)
+
+    def rows(self, kind, rows):
+        return self.rp.read_rows(kind, rows)
+
+    def close(self):
+        pass
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# the session
+# ------------------------------------------------------------------------------------------------------------------------------------
+_REFCOUNT_IDLE = 2        # sys.getrefcount of a proxy nobody holds any more (the local name + getrefcount's argument)
+
+
+class Session:
+    def __init__(self, backend, K, prm, width, height):
+        self.be, self.K, self.prm, self.w, self.h = backend, np.asarray(K, np.float64), dict(prm), width, height
+        self.alive = True
+        self.reason = None
+        self.Kp, self.Lp = {}, {}                         # row -> proxy
+        R = 4 * backend.N
+        self._hasK, self._hasL = np.zeros(R, bool), np.zeros(R, bool)
+        self.cand, self.lm_L, self.lm_K, self.dead_L, self.dead_K = [], [], [], [], []      # lists of proxies = the device lists
+        self.rows = {}                                    # the same as row arrays
+        self.t = 0
+        self.last_H = None
+        self.cur_img = None                               # what the device frame store holds as its current frame
+        self.track_img = None                             # frame whose KLT has run and whose landmark half is still to come
+        self._cache = {}                                  # kind -> (row -> index, structured array) of the last bulk gather
+        self.stats = dict(fast=0, stages=0, gathers=0)
+
+    # ---- proxies / mirrors -----------------------------------------------------------------------------------------------------------
+    def _proxies(self, kind, rows):
+        table, cls = (self.Kp, LazyKeypoint) if kind == "K" else (self.Lp, LazyLandmark)
+        has = self._hasK if kind == "K" else self._hasL
+        new = rows[~has[rows]] if len(rows) else rows
+        for r in np.unique(new).tolist():
+            p = cls.__new__(cls)
+            d = p.__dict__
+            d["_sess"], d["_row"] = self, r
+            table[r] = p
+        if len(new):
+            has[new] = True
+        get = table.__getitem__
+        return list(map(get, rows.tolist()))
+
+    def _refresh(self, what, retire=False):
+        """lists after a stage -> mirrors (`what`: which lists the stage may have changed).  retire: the stage was the frame's last one -- the
+        device recycles the rows no list refers to (VO_PIPE_KEEP_FREE_LISTS on every other stage), so their proxies are settled now"""
+        L = self.be.lists()
+        self.rows = L
+        self.t = L["t"]
+        self._cache = {}
+        if "cand" in what:
+            self.cand = self._proxies("K", L["cand"])
+        if "lm" in what:
+            self.lm_L, self.lm_K = self._proxies("L", L["lm_l"]), self._proxies("K", L["lm_k"])
+        if "dead" in what:
+            self.dead_L, self.dead_K = self._proxies("L", L["dead_l"]), self._proxies("K", L["dead_k"])
+        if retire:
+            R = len(self._hasK)
+            liveK, liveL = np.zeros(R, bool), np.zeros(R, bool)
+            liveK[L["cand"]] = True; liveK[L["lm_k"]] = True; liveK[L["dead_k"]] = True
+            liveL[L["lm_l"]] = True; liveL[L["dead_l"]] = True
+            self._retire("K", np.nonzero(self._hasK & ~liveK)[0])
+            self._retire("L", np.nonzero(self._hasL & ~liveL)[0])
+        return L
+
+    def _retire(self, kind, rows):
+        """proxies whose row has left every list: somebody outside still holds one -> it gets its values now (the row is still intact) and
+        lives on as a plain object, like the reference's; otherwise it is simply forgotten"""
+        if not len(rows):
+            return
+        table, has = (self.Kp, self._hasK) if kind == "K" else (self.Lp, self._hasL)
+        held = []
+        for r in rows.tolist():
+            p = table.pop(r)
+            if sys.getrefcount(p) > _REFCOUNT_IDLE:
+                held.append(p)
+            else:
+                p.__dict__["_row"] = -2
+        has[rows] = False
+        if held:
+            self._fill(held, detach=True)
+
+    # ---- values ----------------------------------------------------------------------------------------------------------------------
+    def _gather(self, kind, rows):
+        self.stats["gathers"] += 1
+        return self.be.rows(kind, np.asarray(rows, np.int32))
+
+    def _values(self, kind, rec):
+        if kind == "L":
+            return dict(t_latest=int(rec["t_latest"]), p=np.array(rec["p"], np.float64).reshape(3, 1), des=np.zeros((1, 1)))
+        n = int(rec["hist_len"])
+        hist = [None] * n
+        ring = rec["hist"]
+        for i in range(max(0, n - HIST), n):
+            hist[i] = np.array(ring[i % HIST], np.float32).reshape(2, 1)
+        for i in range(0, max(0, n - HIST)):
+            hist[i] = np.full((2, 1), np.nan, np.float32)          # older than the ring: the window never reaches them (<= 20 frames)
+        return dict(t_first=int(rec["t_first"]), t_total=int(rec["t_total"]), uv_first=np.array(rec["uv_first"], np.float32).reshape(2, 1),
+                    uv=np.array(rec["uv"], np.float32).reshape(2, 1), des=np.zeros((1, 1)), uv_history=hist)
+
+    def _fill(self, proxies, detach=False):
+        """write the current values into the proxies' instance dicts (detach: they become plain objects for good)"""
+        for kind in ("K", "L"):
+            ps = [p for p in proxies if p._KIND == kind and p.__dict__.get("_row", -1) >= 0]
+            if not ps:
+                continue
+            recs = self._gather(kind, [p.__dict__["_row"] for p in ps])
+            for p, rec in zip(ps, recs):
+                d = p.__dict__
+                d.update(self._values(kind, rec))
+                if detach:
+                    d["_row"] = -1
+                    d.pop("_sess", None)
+
+    def _field(self, proxy, name):
+        """one field of an attached proxy: the first miss after a stage gathers every row of that kind that has a proxy"""
+        kind = proxy._KIND
+        c = self._cache.get(kind)
+        if c is None:
+            rows = np.nonzero(self._hasK if kind == "K" else self._hasL)[0]
+            recs = self._gather(kind, rows)
+            c = self._cache[kind] = ({int(r): i for i, r in enumerate(rows.tolist())}, recs, {})
+        index, recs, vals = c
+        row = proxy.__dict__["_row"]
+        v = vals.get(row)
+        if v is None:
+            v = vals[row] = self._values(kind, recs[index[row]])
+        return v[name]
+
+    # ---- leaving the fast path -------------------------------------------------------------------------------------------------------
+    def desync(self, reason):
+        """every proxy becomes a plain object holding its current values; the session is over"""
+        if not self.alive:
+            return
+        self.alive, self.reason = False, reason
+        self._fill(list(self.Kp.values()) + list(self.Lp.values()), detach=True)
+        self.Kp, self.Lp = {}, {}
+        self.be.close()
+
+    def _fail(self, reason):
+        self.desync(reason)
+        return NotImplemented
+
+    def _check_record(self, rec, in_place=False):
+        """in_place: the stage has rewritten rows the caller's objects stand for (tracked positions, adjusted landmarks), so the plain path
+        cannot take over from here -- its capacity was checked BEFORE the stage ran (`_room`), a failure now is a defect"""
+        if rec["status"] & 1:
+            self.desync("the pose stage found no consensus")
+            raise RuntimeError("solvePnPRansac found no pose")          # what the plain class raises (the reference crashes in cv2.Rodrigues(None))
+        if rec["status"] or rec["overflow"]:
+            if in_place:
+                self.desync("capacity after an in-place stage")
+                raise RuntimeError("vo_mi355x.lazy: the device tables overflowed in a stage whose capacity had been checked (status %d, overflow %d)"
+                                   % (rec["status"], rec["overflow"]))
+            return False
+        return True
+
+    def _room(self, extra_dead=0, extra_lm=0):
+        """capacity the next stage may need: the dead list takes what can die, the state's lists what can be resurrected"""
+        N = self.be.N
+        return len(self.dead_L) + extra_dead <= N and len(self.lm_L) + len(self.cand) + extra_lm <= N
+
+    @staticmethod
+    def _same_image(a, b):
+        return a is b or (a is not None and b is not None and a.shape == b.shape and np.array_equal(a, b))
+
+    # ---- seeding ---------------------------------------------------------------------------------------------------------------------
+    def seed(self, state, dead, dead_kp, t_step, cur_img):
+        """objects -> tables; the caller's lists are rewritten IN PLACE with the proxies; -> the two dead lists as lists of proxies"""
+        self.be.seed(state, dead, dead_kp, t_step)
+        self.cur_img = cur_img
+        L = self._refresh(("cand", "lm", "dead"), retire=True)
+        if not (len(L["lm_l"]) == len(state._landmarks) and len(L["cand"]) == len(state._candidates_kp) and len(L["dead_l"]) == len(dead)):
+            raise RuntimeError("seed: the tables do not hold the lists they were seeded with")
+        state._landmarks[:] = self.lm_L
+        state._landmarks_kp[:] = self.lm_K
+        state._candidates_kp[:] = self.cand
+        T = len(state._trajectory)
+        self.last_H = state._trajectory[T - 1] if T else None
+        return list(self.dead_L), list(self.dead_K)
+
+    # ---- the reference's calls -------------------------------------------------------------------------------------------------------
+    def extend_tracks(self, im_prev, im_curr, kp, max_bidir_error):
+        if not (np.isinf(max_bidir_error) and kp == self.cand and self._same_image(im_prev, self.cur_img)
+                and im_curr.shape == (self.h, self.w) and self.track_img is None):
+            return self._fail("extend_tracks: not the session's candidate list / frame pair")
+        from .resident import TRACK, TRACK_CANDIDATES
+        img = np.ascontiguousarray(im_curr, np.uint8)
+        self.be.push_frame(img)
+        self.cur_img = self.track_img = img.copy()
+        rec = self.be.stage(TRACK | TRACK_CANDIDATES)
+        self._check_record(rec, in_place=True)
+        self._refresh(("cand",))
+        self.stats["fast"] += 1
+        return LazyList(self.cand)
+
+    def extend_landmarks(self, im_prev, im_curr, landmarks, landmarks_kp, max_bidir_error):
+        from .resident import TRACK, TRACK_LANDMARKS
+        if not (np.isinf(max_bidir_error) and landmarks == self.lm_L and landmarks_kp == self.lm_K and self._room(extra_dead=len(self.lm_L))):
+            return self._fail("extend_landmarks: not the session's landmark lists (or the dead list could overflow)")
+        if self.track_img is not None:
+            if not self._same_image(im_curr, self.track_img):
+                return self._fail("extend_landmarks: another frame than extend_tracks")
+            stages = TRACK_LANDMARKS
+        else:                                              # the caller tracks its landmarks without having tracked candidates this frame
+            if not (self._same_image(im_prev, self.cur_img) and im_curr.shape == (self.h, self.w)):
+                return self._fail("extend_landmarks: not the session's frame pair")
+            img = np.ascontiguousarray(im_curr, np.uint8)
+            self.be.push_frame(img)
+            self.cur_img = img.copy()
+            stages = TRACK | TRACK_LANDMARKS
+        self.track_img = None
+        old_L, old_K, n_dead0 = self.lm_L, self.lm_K, len(self.dead_L)
+        rec = self.be.stage(stages)
+        self._check_record(rec, in_place=True)
+        keep = self.be.mask(len(old_L))
+        self._refresh(("lm", "dead"))
+        died = np.nonzero(~keep)[0].tolist()
+        if len(self.lm_L) != int(keep.sum()) or len(self.dead_L) != n_dead0 + len(died):
+            self.desync("extend_landmarks: the device lists do not match the keep mask")
+            raise RuntimeError("vo_mi355x.lazy: extend_landmarks: the device lists do not match the keep mask")
+        ld, lkd = LazyList(old_L[i] for i in died), LazyList(old_K[i] for i in died)
+        ld._copies, lkd._copies = self.dead_L[n_dead0:], self.dead_K[n_dead0:]
+        self.stats["fast"] += 1
+        return LazyList(self.lm_L), LazyList(self.lm_K), ld, lkd
+
+    def camera_pose(self, K, list_1, list_2, max_err_reproj):
+        from .resident import POSE
+        if not (list_1 == self.lm_L and list_2 == self.lm_K and max_err_reproj == self.prm["max_reproj_err"] and np.array_equal(np.asarray(K, np.float64), self.K)
+                and self.track_img is None and self._room(extra_dead=len(self.lm_L))):
+            return self._fail("camera_pose: not the session's landmark lists / parameters")
+        old_L, old_K, n_dead0 = self.lm_L, self.lm_K, len(self.dead_L)
+        rec = self.be.stage(POSE)
+        if not self._check_record(rec):
+            return self._fail("camera_pose: capacity")
+        mask = self.be.mask(len(old_L))
+        self._refresh(("lm", "dead"))
+        out = np.nonzero(~mask)[0].tolist()
+        if len(self.lm_L) != int(mask.sum()) or len(self.dead_L) != n_dead0 + len(out):
+            return self._fail("camera_pose: the device lists do not match the consensus mask")
+        for j, i in enumerate(out):                        # deepcopy(state._landmarks[i]) / (..._kp[i]) of pipeline.py:133-134 = the device's copies
+            old_L[i].__dict__.setdefault("_copy", []).append(self.dead_L[n_dead0 + j])
+            old_K[i].__dict__.setdefault("_copy", []).append(self.dead_K[n_dead0 + j])
+        self.last_H = np.array(rec["H"], np.float64)
+        self.stats["fast"] += 1
+        return InlierList(np.nonzero(mask)[0].tolist()), self.last_H
+
+    def triangulate_tracks(self, K, candidates_kp, trajectory, t_curr, min_track_length, min_bearing_angle, max_err_reproj):
+        from .resident import TRIANGULATE
+        p = self.prm
+        T = len(trajectory)
+        if not (candidates_kp == self.cand and t_curr == self.t and T == t_curr + 1 and trajectory[T - 1] is self.last_H
+                and (min_track_length, min_bearing_angle, max_err_reproj) == (p["min_track_length"], p["min_bearing_angle"], p["max_reproj_err"])
+                and np.array_equal(np.asarray(K, np.float64), self.K) and self.track_img is None):
+            return self._fail("triangulate_tracks: not the session's candidate list / trajectory / parameters")
+        n_l0 = len(self.lm_L)
+        rec = self.be.stage(TRIANGULATE)
+        if not self._check_record(rec):
+            return self._fail("triangulate_tracks: capacity")
+        self._refresh(("cand", "lm"))
+        if len(self.lm_L) != n_l0 + rec["n_new"]:
+            return self._fail("triangulate_tracks: list length")
+        self.stats["fast"] += 1
+        return LazyList(self.lm_L[n_l0:]), LazyList(self.lm_K[n_l0:]), LazyList(self.cand)
+
+    def adjust(self, state, landmarks_dead, landmarks_kp_dead, K, t_now, window, ftol, xtol, max_iters):
+        from .resident import ADJUST
+        p = self.prm
+        # the caller's dead list = the device's dead list + the entries the device has dropped as inert (they can never return: flagged then)
+        live, foreign = [], False
+        for i, k in enumerate(landmarks_kp_dead):
+            d = getattr(k, "__dict__", {})
+            if d.get("_row", -1) >= 0 and d.get("_sess") is self:
+                live.append(i)
+            elif not d.get("_inert"):
+                foreign = True
+        ok = (not foreign and self._room(extra_lm=len(self.dead_L)) and state._landmarks == self.lm_L and state._landmarks_kp == self.lm_K and state._candidates_kp == self.cand and t_now == self.t
+              and (window, ftol, xtol, max_iters) == (p["ba_window"], p["ba_ftol"], p["ba_xtol"], p["ba_max_iters"])
+              and len(landmarks_dead) == len(landmarks_kp_dead) and [landmarks_dead[i] for i in live] == self.dead_L
+              and [landmarks_kp_dead[i] for i in live] == self.dead_K and np.array_equal(np.asarray(K, np.float64), self.K) and self.track_img is None)
+        T = len(state._trajectory)
+        ok = ok and T == t_now + 1 and state._trajectory[T - 1] is self.last_H
+        if not ok:
+            return self._fail("adjust: not the session's lists / trajectory / parameters")
+        n_l0 = len(self.lm_L)
+        old_dead_K = self.dead_K
+        rec = self.be.stage(ADJUST)
+        self._check_record(rec, in_place=True)
+        L = self._refresh(("lm", "dead"))
+        n_res = rec["n_resurrected"]
+        if len(self.lm_L) != n_l0 + n_res:
+            self.desync("adjust: list length")
+            raise RuntimeError("vo_mi355x.lazy: adjust: the device lists do not match the record")
+        stay = set(map(id, self.dead_K))
+        for k in old_dead_K:                               # entries the device dropped for good (window test failed, landmark not in the state's list)
+            if id(k) not in stay:
+                k.__dict__["_inert"] = True
+        # recently dead landmarks are appended to the state's lists as the same objects (bundle_adjuster.py:142-147) ...
+        state._landmarks.extend(self.lm_L[n_l0:])
+        state._landmarks_kp.extend(self.lm_K[n_l0:])
+        # ... and lead the dead lists the caller gets back, the others keep their order (:203-204), the ones the device dropped included
+        taken = set(map(id, self.dead_K[:n_res]))
+        front = [i for i in live if id(landmarks_kp_dead[i]) in taken]
+        if len(front) != n_res:
+            self.desync("adjust: resurrected entries not found in the caller's dead list")
+            raise RuntimeError("vo_mi355x.lazy: adjust: resurrected entries not found in the caller's dead list")
+        fs = set(front)
+        rest = [i for i in range(len(landmarks_dead)) if i not in fs]
+        dead_l = [landmarks_dead[i] for i in front] + [landmarks_dead[i] for i in rest]
+        dead_k = [landmarks_kp_dead[i] for i in front] + [landmarks_kp_dead[i] for i in rest]
+        # window poses back into the trajectory (:206-213)
+        poses = L["poses"]
+        for s in range(window):
+            t = t_now - s
+            if t not in state._trajectory._poses:
+                break
+            H = np.eye(4)
+            H[:3] = poses[t % HIST].reshape(3, 4)
+            state._trajectory._poses[t] = H
+        self.last_H = state._trajectory._poses[t_now]
+        self.stats["fast"] += 1
+        stats = dict(cost0=rec["ba_cost0"], cost=rec["ba_cost"], iters=rec["ba_iters"], accepted=rec["ba_accepted"], status=rec["ba_status"],
+                     n_obs=rec["ba_observations"]) if rec["ba_observations"] > 0 else None
+        return state, dead_l, dead_k, stats
+
+    def extract(self, img, t, current_kp, mask_radius):
+        from .resident import DETECT
+        if not (t == self.t and mask_radius == self.prm["mask_radius"] and self._same_image(img, self.cur_img) and current_kp == self.lm_K + self.cand
+                and self.track_img is None):
+            return self._fail("extract: not the session's keypoints / frame / parameters")
+        n_c0 = len(self.cand)
+        rec = self.be.stage(DETECT)
+        if not self._check_record(rec):
+            return self._fail("extract: capacity")
+        new = self.be.lists()["cand"][n_c0:]             # (before the mirrors move: a failure here leaves the caller's objects untouched)
+        if len(new) != rec["n_detected"]:
+            return self._fail("extract: list length")
+        self._refresh(("cand",), retire=True)
+        self.stats["fast"] += 1
+        return LazyList(self.cand[n_c0:])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# how BundleAdjuster.adjust finds / starts a session
+# ------------------------------------------------------------------------------------------------------------------------------------
+def session_of(state, landmarks_kp_dead=()):
+    """the live session whose proxies the caller's lists hold, or None"""
+    for lst in (state._landmarks_kp, state._candidates_kp, landmarks_kp_dead):
+        if len(lst):
+            s = getattr(lst[0], "__dict__", {}).get("_sess")
+            if s is not None and s.alive:
+                return s
+    return None
+
+
+def seed_after_adjust(adjuster, state, dead_l, dead_k, K, t_now):
+    """Called at the end of a plain `adjust`.  If the frame came through the reference's call order on ONE drop-in Extractor that owns a device
+    context holding the frame, the caller's objects move into device tables: the state's lists are rewritten in place with proxies and the
+    two dead lists come back as lists of proxies (None: nothing changed)."""
+    if not enabled() or adjuster._loss != 'huber':
+        return None
+    cands = [e for e in _EXTRACTORS if e._lazy_on and e._frame_is_reference_order() and e._dev_cur is not None]
+    if len(cands) != 1:
+        return None
+    ext = cands[0]
+    ext._trace = []
+    ctx = ext._ctx
+    if ctx is None or (ext._lazy_backend is None and not hasattr(ctx, "_h")):
+        return None
+    N = getattr(ctx, "max_pts", 0)
+    T = len(state._trajectory)
+    n_l, n_c, n_d = len(state._landmarks), len(state._candidates_kp), len(dead_l)
+    if not (0 < N <= 4096 and getattr(ctx, "batch", 1) == 1 and n_l + n_c + n_d <= N and n_l == len(state._landmarks_kp) and T == t_now + 1
+            and all(t in state._trajectory._poses for t in range(max(0, t_now - HIST + 1), t_now + 1))):
+        return None
+    seen = ext._seen
+    if not np.isinf(seen.get("max_bidir_error", 0.0)):
+        return None
+    prm = dict(ba_window=adjuster._window_size, ba_ftol=adjuster._ftol, ba_xtol=adjuster._xtol, ba_max_iters=adjuster._max_iters,
+               min_track_length=seen.get("min_track_length", 3), min_bearing_angle=seen.get("min_bearing_angle", 0.5),
+               max_reproj_err=seen.get("pose_max_err", 2.0), mask_radius=seen.get("mask_radius", int(ext._shitomasi_params["minDistance"])),
+               max_new=ext._shitomasi_params["maxCorners"], min_kp_dist=ext._shitomasi_params["minDistance"])
+    if seen.get("tri_max_err", prm["max_reproj_err"]) != prm["max_reproj_err"]:
+        return None                     # one reprojection threshold on the device (pipeline.py:23 uses one for both)
+    h, w = ext._dev_cur.shape
+    try:
+        be = ext._lazy_backend(ctx, K, prm, w, h) if ext._lazy_backend is not None else DeviceBackend(ctx, K, prm)
+        sess = Session(be, K, prm, w, h)
+        out = sess.seed(state, dead_l, dead_k, t_now, ext._dev_cur)
+    except Exception as e:              # a state the tables cannot hold (capacity, histories ...): stay on the plain path
+        if os.environ.get("VO_LAZY_STRICT"):
+            raise
+        ext._lazy_error = repr(e)
+        return None
+    ext._lazy = sess
+    return out

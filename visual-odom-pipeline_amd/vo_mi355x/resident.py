@@ -26,6 +26,7 @@ from .state import Keypoint, Landmark, State, Trajectory
 
 HIST = 32
 TRACK, POSE, TRIANGULATE, ADJUST, DETECT, ALL = 1, 2, 4, 8, 16, 31
+TRACK_CANDIDATES, TRACK_LANDMARKS, KEEP_FREE_LISTS = 32, 64, 128      # the halves of TRACK's bookkeeping as the reference calls them (include/vo_mi355x.h)
 LOST, CAPACITY, GROUPS = 1, 2, 4
 # table ids (include/vo_mi355x.h) -> (dtype, per-sequence shape as a function of N = max_pts, R = 4 N)
 _TABLES = {
@@ -104,6 +105,45 @@ class ResidentPipeline:
             d["H_final"] = Hf                      # pose of step d["t_final"]: out of the window now, final
             out.append(d)
         return out[0] if self.B == 1 else out
+
+    # ---- read-backs of the object boundary (lazy.py): the lists in one copy, object rows by index, the consensus mask -------------
+    _LISTS = ("cand", "lm_l", "lm_k", "lm_kshared", "dead_l", "dead_k", "counts", "poses")
+    K_ROW = np.dtype([("t_first", "<i4"), ("t_total", "<i4"), ("hist_len", "<i4"), ("pad", "<i4"), ("uv", "<f4", 2), ("uv_first", "<f4", 2),
+                      ("hist", "<f4", (HIST, 2))])
+    L_ROW = np.dtype([("t_latest", "<i4"), ("pad", "<i4"), ("p", "<f8", 3)])
+
+    def read_lists(self):
+        """-> dict(cand, lm_l, lm_k, lm_kshared, dead_l, dead_k [B, N] i32, counts [B, 32] i32, poses [B, 32, 12] f64): ONE device-to-host copy"""
+        if not hasattr(self, "_lists_buf"):
+            nb = C.c_uint64()
+            self.ctx._ck(self._L.vo_pipe_lists_bytes(self.ctx._h, C.byref(nb)))
+            self._lists_buf = np.empty(nb.value, np.uint8)
+            off, self._lists_off = 0, {}
+            for n in self._LISTS:
+                _, dt, shp = _TABLES[n]
+                size = int(np.prod((self.B,) + shp(self.N, self.R))) * np.dtype(dt).itemsize
+                self._lists_off[n] = (off, size, dt, (self.B,) + shp(self.N, self.R))
+                off += (size + 255) & ~255
+            assert off == nb.value, (off, nb.value)
+        self.ctx._ck(self._L.vo_pipe_lists_read(self.ctx._h, self._lists_buf.ctypes.data_as(C.c_void_p)))
+        return {n: self._lists_buf[o:o + sz].view(dt).reshape(shape) for n, (o, sz, dt, shape) in self._lists_off.items()}
+
+    def read_rows(self, kind, rows):
+        """object rows by index (batch 1): kind 'K' -> structured array K_ROW (history in ring-slot order), 'L' -> L_ROW"""
+        rows = np.ascontiguousarray(rows, np.int32).reshape(-1)
+        dt = self.K_ROW if kind == "K" else self.L_ROW
+        out = np.empty(len(rows), dt)
+        for i in range(0, len(rows), self.N):
+            part = rows[i:i + self.N]
+            self.ctx._ck(self._L.vo_pipe_rows_read(self.ctx._h, 0 if kind == "K" else 1, part.ctypes.data_as(C.POINTER(C.c_int32)), len(part),
+                                                   out[i:i + len(part)].ctypes.data_as(C.c_void_p)))
+        return out
+
+    def read_inliers(self, n):
+        """consensus mask of the last POSE stage over the first n entries of the landmark list as it was before the pruning (batch 1)"""
+        m = np.zeros(max(n, 1), np.uint8)
+        self.ctx._ck(self._L.vo_pipe_inliers_read(self.ctx._h, m.ctypes.data_as(C.POINTER(C.c_uint8)), int(n)))
+        return m[:n].astype(bool)
 
     def set_ba_budget(self, budget):
         self.ctx._ck(self._L.vo_pipe_set_ba_budget(self.ctx._h, int(budget)))
