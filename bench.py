@@ -500,7 +500,7 @@ def dropin_step_ms(device, scene, ba_window=4, n_warm=4, n_time=8):
             times.append(time.perf_counter() - t0)
         return times, st, ex
 
-    with VoContext(W_IMG, H_IMG, max_pts=4096, device=device) as c:
+    with VoContext(W_IMG, H_IMG, max_pts=8192, device=device) as c:       # (the scene's steady state is ~4 400 keypoints)
         state, _ = syn.gt_bootstrap(c, scene, 0, PIPE_T1)
         times, st, ex = reference_loop(c, state, False, False, n_warm, n_time)
         out["python_objects_ms_per_step"] = round(float(np.median(times[n_warm:])) * 1e3, 3)
@@ -526,7 +526,7 @@ def dropin_step_ms(device, scene, ba_window=4, n_warm=4, n_time=8):
         # the same sequence, state in device tables
         c.upload_sequence(frames)
         rp = ResidentPipeline(c, K, ba_window=ba_window, ba_max_iters=10, pnp_blind_batches=2)
-        rp.seed(state, [], [], 1)
+        rp.seed(copy.deepcopy(state), [], [], 1)
         c.push_frame_resident(PIPE_T1)
         f = PIPE_T1 + 1
         for _ in range(6):

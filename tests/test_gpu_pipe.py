@@ -446,3 +446,43 @@ def test_device_side_corner_limit_gives_the_same_corners(monkeypatch):
                 assert np.array_equal(np.asarray(ra[s][b][k]), np.asarray(rb[s][b][k])), (s, b, k, ra[s][b][k], rb[s][b][k])
     for name in Ta:
         assert np.array_equal(Ta[name], Tb[name], equal_nan=True) if Ta[name].dtype.kind == "f" else np.array_equal(Ta[name], Tb[name]), name
+
+
+def test_tables_beyond_4096_slots_at_1080p_window20():
+    """BASELINE config 5's shape in the closed loop: 1920 x 1080, a 20-frame window, tables of 8 192 slots (the list kernels' 8-entries-per-thread
+    form: the per-landmark-row words move from LDS to the sequence's global scratch) -- against the table model frame by frame while the state
+    grows past 4 096 keypoints (1 000 new corners per frame), nothing cut by the capacity policy"""
+    import pipe_oracle as po
+    from vo_mi355x.resident import ResidentPipeline
+    w, h, t1, n = 1920, 1080, 3, 9
+    cap = 8192
+    sc = ph.scene(t1 + n + 1, w=w, h=h, f=1100.0, seed=11, pose_fn=lambda t: ph.sway_pose(t, period=40.0))
+    ctx_a, ctx_b = _ctx(w, h, max_pts=cap), _ctx(w, h, max_pts=cap)
+    state, _ = ph.gt_bootstrap(ctx_a, sc, 0, t1)
+    model = po.PipeModel(ctx_a, sc["K"], w, h, cap=cap, params=po.Params(ba_window=20, ba_max_iters=12))
+    model.seed(copy.deepcopy(state), [], [], 1)
+    ctx_a.push_frame(sc["frames"][t1])
+    rp = ResidentPipeline(ctx_b, sc["K"], ba_window=20, ba_max_iters=12, pnp_blind_batches=8)
+    rp.seed(state, [], [], 1)
+    ctx_b.push_frame(sc["frames"][t1])
+    biggest = 0
+    for s in range(n):
+        im = sc["frames"][t1 + 1 + s]
+        model.step(im)
+        ctx_b.push_frame(im); rp.step(); rec = rp.fetch()
+        what = "step %d" % (s + 2)
+        assert rec["status"] == 0 and model.status == 0 and rec["overflow"] == 0 and not model.info.get("overflow", 0), (what, rec, model.info)
+        e = rp.entries()
+        assert (len(e["cand"]), len(e["lm"]), len(e["dead"]), e["n_dead_total"]) == (len(model.cand), len(model.lm_L), len(model.dead_L),
+                                                                                    len(model.dead_L) + model.n_dead_inert), what
+        assert (rec["n_new"], rec["n_resurrected"], rec["n_detected"]) == (model.info["n_new"], model.info["n_resurrected"], model.info["n_detected"]), (what, rec)
+        for name, pairs in (("lm", zip(model.lm_L, model.lm_K)), ("dead", zip(model.dead_L, model.dead_K)), ("cand", ((None, k) for k in model.cand))):
+            for i, ((l, k), x) in enumerate(zip(pairs, e[name])):
+                y = model.entry(l, k)
+                assert x[2:4] == y[2:4] and x[6] == y[6] and np.array_equal(x[5], y[5]) and np.array_equal(x[4], y[4]) and np.array_equal(x[7], y[7]), (what, name, i)
+                if l is not None:
+                    assert x[0] == y[0] and np.linalg.norm(x[1] - y[1]) <= 1e-7 * np.linalg.norm(y[1]), (what, name, i)
+        for t in range(model.t + 1):
+            assert np.abs(e["poses"][t] - model.poses[t]).max() <= 1e-7, (what, t)
+        biggest = max(biggest, len(model.cand) + len(model.lm_L))
+    assert biggest > 4096, biggest

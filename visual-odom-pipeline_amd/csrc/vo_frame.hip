@@ -14,6 +14,7 @@
 #include "vo_internal.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 #include <new>
 
@@ -330,6 +331,8 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_slab) (void)hipHostFree(c->h_slab);
   if (c->h_frame_idx) (void)hipHostFree(c->h_frame_idx);
+  if (c->h_raw) (void)hipHostFree(c->h_raw);
+  if (c->ev_raw) (void)hipEventDestroy(c->ev_raw);
   for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
   for (int k = 0; k < 2; k++) if (c->ev_step[k]) (void)hipEventDestroy(c->ev_step[k]);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -492,12 +495,21 @@ extern "C" int32_t vo_frame_push(vo_ctx* c, const uint8_t* img, int32_t stride) 
   VO_CHECK(c, img != nullptr && stride >= c->width, VO_E_INVALID, "bad image / stride");
   VO_HIP(c, hipSetDevice(c->device));
   { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
-  // the batch's images are contiguous: [batch][height] rows of `stride` bytes
-  VO_HIP(c, hipMemcpy2DAsync(c->d_raw, c->width, img, stride, c->width, (size_t)c->height * c->batch, hipMemcpyHostToDevice, c->stream));
-  int32_t r = vo_build_pyramid(c, c->d_raw, (size_t)c->width * c->height, nullptr);
-  if (r != VO_OK) return r;
-  VO_HIP(c, hipStreamSynchronize(c->stream));   // the host buffer may be reused by the caller
-  return VO_OK;
+  // the batch's images are contiguous: [batch][height] rows of `stride` bytes.  They go through a pinned staging buffer: a 2-D copy out of
+  // pageable memory cost 2.5 ms per 1241 x 376 frame on this runtime (row by row), the memcpy + one linear copy 0.1 ms -- and the call no
+  // longer waits for the pyramid (the caller's buffer is free as soon as the memcpy is done)
+  const size_t rows = (size_t)c->height * c->batch, bytes = rows * c->width;
+  if (!c->h_raw) {
+    VO_HIP(c, hipHostMalloc((void**)&c->h_raw, bytes, hipHostMallocDefault));
+    VO_HIP(c, hipEventCreateWithFlags(&c->ev_raw, hipEventDisableTiming));
+  } else {
+    VO_HIP(c, hipEventSynchronize(c->ev_raw));    // the previous frame has left the staging buffer
+  }
+  if (stride == c->width) memcpy(c->h_raw, img, bytes);
+  else for (size_t y = 0; y < rows; y++) memcpy(c->h_raw + y * c->width, img + y * (size_t)stride, c->width);
+  VO_HIP(c, hipMemcpyAsync(c->d_raw, c->h_raw, bytes, hipMemcpyHostToDevice, c->stream));
+  VO_HIP(c, hipEventRecord(c->ev_raw, c->stream));
+  return vo_build_pyramid(c, c->d_raw, (size_t)c->width * c->height, nullptr);
 }
 
 // frames: [batch][n_frames][height][width] uint8

@@ -73,6 +73,8 @@ struct vo_ctx {
   int cur = 0;                       // index of the current frame in fr[]
   int n_pushed = 0;
   uint8_t* d_raw = nullptr;          // staging of one raw frame per sequence
+  uint8_t* h_raw = nullptr;          // pinned host staging of vo_frame_push (allocated on first use)
+  hipEvent_t ev_raw = nullptr;       // the upload out of h_raw is done
   uint8_t* d_seq = nullptr;          // preloaded sequences [batch][seq_n][h][w] (vo_seq_upload)
   int seq_n = 0;
   // tracked point sets live in the result slab (off_pa / off_pb, ping-pong selected by p_parity)

@@ -28,7 +28,7 @@
 #include <string.h>
 
 #define PIPE_TPB 1024
-#define PIPE_CH 4                 // most list entries per thread: max_pts <= PIPE_TPB * PIPE_CH
+#define PIPE_CH 8                 // most list entries per thread: max_pts <= PIPE_TPB * PIPE_CH = 8 192
 #define PIPE_HIST VO_PIPE_HIST
 #define PIPE_NCNT 32
 
@@ -220,8 +220,13 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
   const int b = blockIdx.x, tid = threadIdx.x;
   const pipe_ptrs P = pipe_select(Pall, b);
   if (P.cnt[C_STATUS]) return;
-  int32_t* const s_row = s_dyn;
-  int32_t* const s_fk = s_row + P.R;
+  // one word per landmark ROW (survivor count, then the election): in LDS up to 4 096 slots; above that (CH = 8: 16 384 + rows would not fit
+  // beside the three windows) in the global scratch words of the sequence, through the L2 like every value the workgroup's atomics touch
+  constexpr bool ROWS_GLOBAL = CH > 4;
+  int32_t* const s_row = ROWS_GLOBAL ? P.scr : s_dyn;
+  int32_t* const s_fk = ROWS_GLOBAL ? s_dyn : s_dyn + P.R;
+  auto row_st = [&](int r, int v) { if (ROWS_GLOBAL) st_i32(&s_row[r], v); else s_row[r] = v; };
+  auto row_ld = [&](int r) { return ROWS_GLOBAL ? ld_i32(&s_row[r]) : s_row[r]; };
   int32_t* const s_fl = s_fk + P.N;
   int32_t* const s_src = s_fl + P.N;
   const float2* p1 = reinterpret_cast<const float2*>(vo_seq(pts, slab_seq, b));
@@ -259,7 +264,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
     if ((which & 2) && j < nl) {
       len[c] = P.k_len[K[c]]; tt[c] = P.k_tt[K[c]]; tl[c] = P.l_tl[L[c]];
       for (int k = 0; k < 3; k++) lp[c][k] = P.l_p[3 * (size_t)L[c] + k];
-      s_row[L[c]] = 0;                               // (entries that share a row all write 0)
+      row_st(L[c], 0);                               // (entries that share a row all write 0)
     }
     if ((which & 1) && j < nc) { lenc[c] = P.k_len[KC[c]]; ttc[c] = P.k_tt[KC[c]]; }
   }
@@ -291,14 +296,14 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
     if (keep[c]) {
       const int k = K[c];
       P.k_uv[k] = q[c]; P.k_tt[k] = tt[c] + 1; pipe_hist_slot(P, len[c])[k] = q[c]; P.k_len[k] = len[c] + 1;
-      atomicAdd(&s_row[L[c]], 1);                    // LDS
+      atomicAdd(&s_row[L[c]], 1);                    // LDS (global scratch above 4 096 slots)
     }
   __syncthreads();
   int tlf[CH];                                       // t_latest of the entry's landmark object after this frame
 #pragma unroll
   for (int c = 0; c < CH; c++) {
     const int j = tid * CH + c;
-    tlf[c] = (j < nl) ? tl[c] + s_row[L[c]] : 0;
+    tlf[c] = (j < nl) ? tl[c] + row_ld(L[c]) : 0;
     if (keep[c]) P.l_tl[L[c]] = tlf[c];              // (the same value from every entry that shares the row)
   }
   // ---- deepcopy(k) of a survivor (extractor.py:85) matters only when the dead list holds the same keypoint object: own row, copied
@@ -323,13 +328,13 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
     const int room = P.N - nd0;
     bool ok[CH], lead[CH];
 #pragma unroll
-    for (int c = 0; c < CH; c++) { ok[c] = die[c] && drank[c] < room; if (ok[c]) s_row[L[c]] = 0x7FFFFFFF; }
+    for (int c = 0; c < CH; c++) { ok[c] = die[c] && drank[c] < room; if (ok[c]) row_st(L[c], 0x7FFFFFFF); }
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < CH; c++) if (ok[c]) atomicMin(&s_row[L[c]], tid * CH + c);
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < CH; c++) lead[c] = ok[c] && s_row[L[c]] == tid * CH + c;
+    for (int c = 0; c < CH; c++) lead[c] = ok[c] && row_ld(L[c]) == tid * CH + c;
     int lrank[CH], krank[CH];
     const int n_lead = pipe_rank<CH>(lead, lrank, s_w);  // (its barriers also separate the reads of s_row above from the writes below)
     const int n_ok = pipe_rank<CH>(ok, krank, s_w);
@@ -340,7 +345,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
         const int nlr = s_fl[lrank[c]];
         P.l_tl[nlr] = tlf[c];
         for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = lp[c][k];
-        s_row[L[c]] = nlr;
+        row_st(L[c], nlr);
       }
     __syncthreads();
 #pragma unroll
@@ -348,7 +353,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
       if (ok[c]) {
         const int slot = n_copy + krank[c];
         s_src[slot] = K[c];
-        P.dead_L[nd0 + drank[c]] = s_row[L[c]];
+        P.dead_L[nd0 + drank[c]] = row_ld(L[c]);
         P.dead_K[nd0 + drank[c]] = s_fk[slot];
       }
     headL += n_lead; headK += n_copy + n_ok;
@@ -958,10 +963,11 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_spawn(pipe_ptrs Pall, int do_
   //      form marked in global scratch and scanned the R rows 1 024 at a time: 16 scans, 8 global phases) ----
   const int nd = P.cnt[C_NDEAD];
   if (rebuild) {       // (uniform.  Stage-wise callers may keep the free lists until the frame's last stage: VO_PIPE_KEEP_FREE_LISTS)
-    __shared__ uint32_t s_mark[2][PIPE_TPB * PIPE_CH];            // [K | L][R / 4]: R <= 4 * max_pts <= 16 384 bytes each
-    uint8_t* const mk = reinterpret_cast<uint8_t*>(s_mark[0]);
-    uint8_t* const ml = reinterpret_cast<uint8_t*>(s_mark[1]);
-    for (int i = tid; i < (P.R + 3) / 4; i += PIPE_TPB) { s_mark[0][i] = 0; s_mark[1][i] = 0; }
+    extern __shared__ uint32_t s_mark_dyn[];                      // [K | L][R / 4] words: one byte per row (2 x 32 KB at 8 192 slots)
+    const int mw = (P.R + 3) / 4;
+    uint8_t* const mk = reinterpret_cast<uint8_t*>(s_mark_dyn);
+    uint8_t* const ml = reinterpret_cast<uint8_t*>(s_mark_dyn + mw);
+    for (int i = tid; i < 2 * mw; i += PIPE_TPB) s_mark_dyn[i] = 0;
     __syncthreads();
     for (int j = tid; j < P.N; j += PIPE_TPB) {
       if (j < nc) mk[P.cand[j]] = 1;
@@ -969,7 +975,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_spawn(pipe_ptrs Pall, int do_
       if (j < nd) { mk[P.dead_K[j]] = 1; ml[P.dead_L[j]] = 1; }
     }
     __syncthreads();
-    const int rpt = (P.R + PIPE_TPB - 1) / PIPE_TPB;             // rows per thread (<= 16)
+    const int rpt = (P.R + PIPE_TPB - 1) / PIPE_TPB;             // rows per thread (<= 32)
     const int r0 = min(tid * rpt, P.R), r1 = min(r0 + rpt, P.R);
     for (int pass = 0; pass < 2; pass++) {
       const uint8_t* m = pass == 0 ? mk : ml;
@@ -1051,7 +1057,7 @@ static int32_t pipe_create(vo_ctx* c, const double* K, const vo_pipe_params* prm
   vo_pipe_params def;
   if (!prm) { vo_pipe_default_params(&def); prm = &def; }
   VO_CHECK(c, prm->ba_window >= 1 && prm->ba_window <= 20, VO_E_INVALID, "ba_window must be 1..20");
-  VO_CHECK(c, c->max_pts <= PIPE_TPB * PIPE_CH, VO_E_CAPACITY, "the pipeline tables hold at most 4096 keypoints per sequence (max_pts)");
+  VO_CHECK(c, c->max_pts <= PIPE_TPB * PIPE_CH, VO_E_CAPACITY, "the pipeline tables hold at most 8192 keypoints per sequence (max_pts)");
   VO_CHECK(c, prm->min_track_length >= 1 && prm->max_new >= 0 && prm->pnp_blind_batches >= 1 && prm->pnp_blind_batches <= 64, VO_E_INVALID, "bad parameters");
   VO_CHECK(c, prm->ba.max_iters >= 0 && prm->ba.max_iters <= 1000 && prm->ba_budget >= 0 && prm->ba_budget <= prm->ba.max_iters, VO_E_INVALID,
            "ba_budget must be 0..ba.max_iters");
@@ -1094,9 +1100,14 @@ static int32_t pipe_create(vo_ctx* c, const double* K, const vo_pipe_params* prm
   for (int i = 0; i < VO_PIPE_INFLIGHT; i++) VO_HIP(c, hipEventCreateWithFlags(&w->ev[i], fl));
   VO_HIP(c, hipEventCreateWithFlags(&w->ev_track, hipEventDisableTiming));
   // k_pipe_extend keeps 28 bytes of LDS per table slot (112 KB at 4 096 slots: above the default limit of a launch)
-  VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_extend<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 28 * PIPE_TPB * PIPE_CH));
+  VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_extend<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 28 * PIPE_TPB * 4));
   VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_extend<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 28 * PIPE_TPB * 2));
-  VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_promote<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * PIPE_TPB * PIPE_CH));
+  VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_promote<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * PIPE_TPB * 4));
+  // 8 192 slots: extend 96 KB (the three windows; the row words are global), prune 96 KB, promote 128 KB, spawn 64 KB of the CU's 160 KB
+  VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_extend<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 12 * PIPE_TPB * 8));
+  VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_prune<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 12 * PIPE_TPB * 8));
+  VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_promote<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * PIPE_TPB * 8));
+  VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_spawn<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PIPE_TPB * 8));
   VO_HIP(c, hipMemcpyAsync(w->d_K, K, 72 * B, hipMemcpyHostToDevice, c->stream));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   int32_t r = vo_ba_reserve(c, K, prm->ba_window, w->N);
@@ -1221,18 +1232,20 @@ extern "C" int32_t vo_pipe_inliers_read(vo_ctx* c, uint8_t* mask, int32_t n) {
 }
 
 // entries per thread of the list kernels: the lists hold at most max_pts entries
-#define PIPE_DISPATCH(KERNEL, ...)                                                                                              \
-  do {                                                                                                                          \
-    if (w->N <= PIPE_TPB) hipLaunchKernelGGL(KERNEL<1>, dim3(c->batch), dim3(PIPE_TPB), 0, c->stream, __VA_ARGS__);              \
-    else if (w->N <= 2 * PIPE_TPB) hipLaunchKernelGGL(KERNEL<2>, dim3(c->batch), dim3(PIPE_TPB), 0, c->stream, __VA_ARGS__);     \
-    else hipLaunchKernelGGL(KERNEL<4>, dim3(c->batch), dim3(PIPE_TPB), 0, c->stream, __VA_ARGS__);                               \
+#define PIPE_DISPATCH_LDS(KERNEL, LDS, ...)                                                                                          \
+  do {                                                                                                                               \
+    if (w->N <= PIPE_TPB) hipLaunchKernelGGL(KERNEL<1>, dim3(c->batch), dim3(PIPE_TPB), LDS, c->stream, __VA_ARGS__);                 \
+    else if (w->N <= 2 * PIPE_TPB) hipLaunchKernelGGL(KERNEL<2>, dim3(c->batch), dim3(PIPE_TPB), LDS, c->stream, __VA_ARGS__);        \
+    else if (w->N <= 4 * PIPE_TPB) hipLaunchKernelGGL(KERNEL<4>, dim3(c->batch), dim3(PIPE_TPB), LDS, c->stream, __VA_ARGS__);        \
+    else hipLaunchKernelGGL(KERNEL<8>, dim3(c->batch), dim3(PIPE_TPB), LDS, c->stream, __VA_ARGS__);                                  \
   } while (0)
+#define PIPE_DISPATCH(KERNEL, ...) PIPE_DISPATCH_LDS(KERNEL, 0, __VA_ARGS__)
 
 static void pipe_launch_spawn(vo_ctx* c, int do_detect, int rebuild = 1) {
   vo_pipe_ws* w = c->pipe;
   vo_pnp_view pv;
   (void)vo_pnp_get_view(c, &pv);
-  PIPE_DISPATCH(k_pipe_spawn, pipe_make(w), do_detect, vo_slab<const uint32_t>(c, c->off_st_scalars),
+  PIPE_DISPATCH_LDS(k_pipe_spawn, 2 * sizeof(uint32_t) * (size_t)((w->R + 3) / 4), pipe_make(w), do_detect, vo_slab<const uint32_t>(c, c->off_st_scalars),
                      vo_slab<const float>(c, c->off_st_out), vo_slab<float>(c, vo_off_p(c)), c->slab_seq, w->prm.max_new, pv.out, pv.ctrl,
                 pv.ctrl_stride, w->d_rec, rebuild);
 }
@@ -1328,14 +1341,15 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
   }
   // the keep rule / bookkeeping on the tracked point set: with TRACK, or alone (VO_PIPE_TRACK_LANDMARKS after a TRACK | VO_PIPE_TRACK_CANDIDATES call)
   if ((stages & VO_PIPE_TRACK) || (stages & (VO_PIPE_TRACK_CANDIDATES | VO_PIPE_TRACK_LANDMARKS))) {
-    const size_t lds = sizeof(int32_t) * ((size_t)w->R + 3 * (size_t)w->N);
+    const size_t lds = sizeof(int32_t) * ((w->N > 4 * PIPE_TPB ? 0 : (size_t)w->R) + 3 * (size_t)w->N);     // (above 4 096 slots the row words are global)
     auto launch = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, dim3(c->batch), dim3(PIPE_TPB), lds, c->stream, P, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq,
                          c->width, c->height, pv.X, pv.uv, pv.cap, halves, const_cast<uint8_t*>(pv.mask));
     };
     if (w->N <= PIPE_TPB) launch(k_pipe_extend<1>);
     else if (w->N <= 2 * PIPE_TPB) launch(k_pipe_extend<2>);
-    else launch(k_pipe_extend<4>);
+    else if (w->N <= 4 * PIPE_TPB) launch(k_pipe_extend<4>);
+    else launch(k_pipe_extend<8>);
   }
   if (stages & VO_PIPE_POSE) {
     r = vo_pnp_enqueue_counts(c, &prm.pnp, prm.pnp_blind_batches, w->d_dn + DN_PNP * B);
@@ -1350,7 +1364,8 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
     };
     if (w->N <= PIPE_TPB) launch(k_pipe_prune<1>);
     else if (w->N <= 2 * PIPE_TPB) launch(k_pipe_prune<2>);
-    else launch(k_pipe_prune<4>);
+    else if (w->N <= 4 * PIPE_TPB) launch(k_pipe_prune<4>);
+    else launch(k_pipe_prune<8>);
   }
   if (stages & VO_PIPE_TRIANGULATE) {
     r = vo_dlt_enqueue_counts(c, w->N, w->d_dn + DN_RIPE * B, w->d_cams, w->d_cam_sel, PIPE_HIST);
@@ -1367,7 +1382,8 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
     };
     if (w->N <= PIPE_TPB) launch(k_pipe_promote<1>);
     else if (w->N <= 2 * PIPE_TPB) launch(k_pipe_promote<2>);
-    else launch(k_pipe_promote<4>);
+    else if (w->N <= 4 * PIPE_TPB) launch(k_pipe_promote<4>);
+    else launch(k_pipe_promote<8>);
   }
   else if (halves & 2)   // (after the candidates' half alone the buffer still holds the tracked positions the landmarks' half will read)
     hipLaunchKernelGGL(k_pipe_dense, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, vo_slab<float>(c, vo_off_p(c)), c->slab_seq, 0);

@@ -26,10 +26,10 @@ class DMatch:
 
 
 class Extractor:
-    def __init__(self, cfg=None, min_kp_dist=10, ctx=None, device=0, max_pts=4096, lazy=None, lazy_backend=None):
+    def __init__(self, cfg=None, min_kp_dist=10, ctx=None, device=0, max_pts=8192, lazy=None, lazy_backend=None):
         """lazy (default: on unless VO_LAZY=0): once a frame has come through the reference's call order (pipeline.py:98-156) the state moves
         into device tables and the lists this class hands out are views of them (vo_mi355x/lazy.py); lazy_backend: test hook
-        (ctx, K, params, width, height) -> backend, default the GPU one.  max_pts: keypoints per call AND the capacity of those tables (<= 4096)."""
+        (ctx, K, params, width, height) -> backend, default the GPU one.  max_pts: keypoints per call AND the capacity of those tables (<= 8192)."""
         from . import lazy as _lz
         self._cfg = cfg
         self._lazy_on = _lz.enabled() if lazy is None else bool(lazy)

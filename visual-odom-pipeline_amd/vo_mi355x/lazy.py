@@ -34,6 +34,7 @@ import copy
 import os
 import sys
 import weakref
+from itertools import compress as _compress
 
 import numpy as np
 
@@ -56,14 +57,20 @@ class _Proxy:
     """attached: `_sess` / `_row` set and no field in the instance dict -> __getattr__ fetches; detached (`_row` = -1): a plain object"""
 
     def __getattr__(self, name):
-        # only reached when normal lookup fails, i.e. for a field of an ATTACHED proxy
+        # only reached when normal lookup fails: a field of an ATTACHED proxy (read from the tables), or of a detached one that still holds the
+        # raw table row it left with (`_rec`: its fields are built the first time somebody asks)
         if name in self._FIELDS:
             d = self.__dict__
             row = d.get("_row", -1)
-            if row == -2:
-                raise RuntimeError("stale %s proxy: the object left the pipeline's lists and nobody held it then" % type(self).__name__)
             if row >= 0:
                 return d["_sess"]._field(self, name)
+            rec = d.get("_rec")
+            if rec is not None:
+                v = _field_of(self._KIND, rec, name)
+                d[name] = v
+                return v
+            if row == -2:
+                raise RuntimeError("stale %s proxy: the object left the pipeline's lists and nobody held it then" % type(self).__name__)
         raise AttributeError(name)
 
     def __setattr__(self, name, value):
@@ -83,23 +90,47 @@ class _Proxy:
             if not q:
                 del d["_copy"]
             return hint
-        if d.get("_row", -1) >= 0:
-            d["_sess"]._fill([self])               # values now; the copy is an independent plain object
-            vals = {f: getattr(self, f) for f in self._FIELDS}
-            for f in self._FIELDS:
-                d.pop(f, None)                     # (this proxy stays attached)
-        else:
-            vals = {f: d[f] for f in self._FIELDS if f in d}
         new = type(self).__new__(type(self))
         memo[id(self)] = new
         nd = new.__dict__
         nd["_row"] = -1
-        for f, v in vals.items():
-            nd[f] = copy.deepcopy(v, memo)
+        if d.get("_row", -1) >= 0:                 # attached: the copy is an independent plain object with the values of now
+            nd["_rec"] = d["_sess"]._gather(self._KIND, [d["_row"]])[0].copy()
+        else:
+            if "_rec" in d:
+                nd["_rec"] = d["_rec"].copy()
+            for f in self._FIELDS:
+                if f in d:
+                    nd[f] = copy.deepcopy(d[f], memo)
         return new
 
     def __repr__(self):
         return "<%s row %d>" % (type(self).__name__, self.__dict__.get("_row", -1))
+
+
+def _field_of(kind, rec, name):
+    """one field of a packed table row (resident.ResidentPipeline.K_ROW / L_ROW) as the reference's objects hold it"""
+    if kind == "L":
+        if name == "t_latest":
+            return int(rec["t_latest"])
+        if name == "p":
+            return np.array(rec["p"], np.float64).reshape(3, 1)
+        return np.zeros((1, 1))
+    if name == "t_first":
+        return int(rec["t_first"])
+    if name == "t_total":
+        return int(rec["t_total"])
+    if name == "uv_first":
+        return np.array(rec["uv_first"], np.float32).reshape(2, 1)
+    if name == "uv":
+        return np.array(rec["uv"], np.float32).reshape(2, 1)
+    if name == "uv_history":
+        n = int(rec["hist_len"])
+        ring = np.array(rec["hist"], np.float32)
+        lo = max(0, n - HIST)
+        # entries older than the ring (32) are gone: the window never reaches them (<= 20 frames); NaN stands in
+        return [np.full((2, 1), np.nan, np.float32)] * lo + [ring[i % HIST].reshape(2, 1).copy() for i in range(lo, n)]
+    return np.zeros((1, 1))
 
 
 class LazyKeypoint(_Proxy, Keypoint):
@@ -157,8 +188,17 @@ class DeviceBackend:
 
     def stage(self, stages):
         from .resident import DETECT, KEEP_FREE_LISTS
+        from .resident import POSE
         self.rp.step(-1, stages | (0 if stages & DETECT else KEEP_FREE_LISTS))     # rows are recycled once per frame, behind the DETECT stage
-        return self.rp.fetch()
+        r = self.rp.fetch_raw()[0]
+        rec = dict(status=r.status, overflow=r.overflow, t=r.t, n_new=r.n_new, n_resurrected=r.n_resurrected, n_detected=r.n_detected,
+                   ba_cost0=r.ba_cost0, ba_cost=r.ba_cost, ba_iters=r.ba_iters, ba_accepted=r.ba_accepted, ba_status=r.ba_status,
+                   ba_observations=r.ba_observations)
+        if stages & POSE:
+            H = np.eye(4)
+            H[:3] = np.frombuffer(r.H, np.float64).reshape(3, 4)
+            rec["H"] = H
+        return rec
 
     def lists(self):
         T = self.rp.read_lists()
@@ -215,19 +255,43 @@ class Session:
         get = table.__getitem__
         return list(map(get, rows.tolist()))
 
-    def _refresh(self, what, retire=False):
+    def _mirror(self, kind, old_list, old_rows, new_rows, mask=None):
+        """the list of proxies for `new_rows`, made from the previous mirror where the stage only compacted (mask) / appended / replaced a few
+        rows: C-speed list operations instead of one dict look-up per entry"""
+        if old_rows is None:
+            return self._proxies(kind, new_rows)
+        if mask is not None:
+            base, base_rows = list(_compress(old_list, mask.tolist())), old_rows[mask]
+        else:
+            base, base_rows = old_list, old_rows
+        n = len(base)
+        if len(new_rows) < n:
+            return self._proxies(kind, new_rows)
+        diff = np.nonzero(new_rows[:n] != base_rows)[0]
+        if len(diff) > 64 + n // 8:
+            return self._proxies(kind, new_rows)
+        if len(diff):
+            base = list(base)
+            for i, p in zip(diff.tolist(), self._proxies(kind, new_rows[diff])):
+                base[i] = p
+        return base + self._proxies(kind, new_rows[n:]) if len(new_rows) > n else list(base)
+
+    def _refresh(self, what, retire=False, lm_mask=None):
         """lists after a stage -> mirrors (`what`: which lists the stage may have changed).  retire: the stage was the frame's last one -- the
         device recycles the rows no list refers to (VO_PIPE_KEEP_FREE_LISTS on every other stage), so their proxies are settled now"""
         L = self.be.lists()
+        old = self.rows
         self.rows = L
         self.t = L["t"]
         self._cache = {}
         if "cand" in what:
-            self.cand = self._proxies("K", L["cand"])
+            self.cand = self._mirror("K", self.cand, old.get("cand"), L["cand"])
         if "lm" in what:
-            self.lm_L, self.lm_K = self._proxies("L", L["lm_l"]), self._proxies("K", L["lm_k"])
+            self.lm_L = self._mirror("L", self.lm_L, old.get("lm_l"), L["lm_l"], lm_mask)
+            self.lm_K = self._mirror("K", self.lm_K, old.get("lm_k"), L["lm_k"], lm_mask)
         if "dead" in what:
-            self.dead_L, self.dead_K = self._proxies("L", L["dead_l"]), self._proxies("K", L["dead_k"])
+            self.dead_L = self._mirror("L", self.dead_L, old.get("dead_l"), L["dead_l"])
+            self.dead_K = self._mirror("K", self.dead_K, old.get("dead_k"), L["dead_k"])
         if retire:
             R = len(self._hasK)
             liveK, liveL = np.zeros(R, bool), np.zeros(R, bool)
@@ -259,21 +323,8 @@ class Session:
         self.stats["gathers"] += 1
         return self.be.rows(kind, np.asarray(rows, np.int32))
 
-    def _values(self, kind, rec):
-        if kind == "L":
-            return dict(t_latest=int(rec["t_latest"]), p=np.array(rec["p"], np.float64).reshape(3, 1), des=np.zeros((1, 1)))
-        n = int(rec["hist_len"])
-        hist = [None] * n
-        ring = rec["hist"]
-        for i in range(max(0, n - HIST), n):
-            hist[i] = np.array(ring[i % HIST], np.float32).reshape(2, 1)
-        for i in range(0, max(0, n - HIST)):
-            hist[i] = np.full((2, 1), np.nan, np.float32)          # older than the ring: the window never reaches them (<= 20 frames)
-        return dict(t_first=int(rec["t_first"]), t_total=int(rec["t_total"]), uv_first=np.array(rec["uv_first"], np.float32).reshape(2, 1),
-                    uv=np.array(rec["uv"], np.float32).reshape(2, 1), des=np.zeros((1, 1)), uv_history=hist)
-
-    def _fill(self, proxies, detach=False):
-        """write the current values into the proxies' instance dicts (detach: they become plain objects for good)"""
+    def _fill(self, proxies, detach=True):
+        """the proxies take the table rows they stand for with them (`_rec`) and become plain objects; their fields are built on first use"""
         for kind in ("K", "L"):
             ps = [p for p in proxies if p._KIND == kind and p.__dict__.get("_row", -1) >= 0]
             if not ps:
@@ -281,10 +332,9 @@ class Session:
             recs = self._gather(kind, [p.__dict__["_row"] for p in ps])
             for p, rec in zip(ps, recs):
                 d = p.__dict__
-                d.update(self._values(kind, rec))
-                if detach:
-                    d["_row"] = -1
-                    d.pop("_sess", None)
+                d["_rec"] = rec.copy()
+                d["_row"] = -1
+                d.pop("_sess", None)
 
     def _field(self, proxy, name):
         """one field of an attached proxy: the first miss after a stage gathers every row of that kind that has a proxy"""
@@ -295,11 +345,11 @@ class Session:
             recs = self._gather(kind, rows)
             c = self._cache[kind] = ({int(r): i for i, r in enumerate(rows.tolist())}, recs, {})
         index, recs, vals = c
-        row = proxy.__dict__["_row"]
-        v = vals.get(row)
+        key = (proxy.__dict__["_row"], name)
+        v = vals.get(key)
         if v is None:
-            v = vals[row] = self._values(kind, recs[index[row]])
-        return v[name]
+            v = vals[key] = _field_of(kind, recs[index[key[0]]], name)
+        return v
 
     # ---- leaving the fast path -------------------------------------------------------------------------------------------------------
     def desync(self, reason):
@@ -388,7 +438,7 @@ class Session:
         rec = self.be.stage(stages)
         self._check_record(rec, in_place=True)
         keep = self.be.mask(len(old_L))
-        self._refresh(("lm", "dead"))
+        self._refresh(("lm", "dead"), lm_mask=keep)
         died = np.nonzero(~keep)[0].tolist()
         if len(self.lm_L) != int(keep.sum()) or len(self.dead_L) != n_dead0 + len(died):
             self.desync("extend_landmarks: the device lists do not match the keep mask")
@@ -408,7 +458,7 @@ class Session:
         if not self._check_record(rec):
             return self._fail("camera_pose: capacity")
         mask = self.be.mask(len(old_L))
-        self._refresh(("lm", "dead"))
+        self._refresh(("lm", "dead"), lm_mask=mask)
         out = np.nonzero(~mask)[0].tolist()
         if len(self.lm_L) != int(mask.sum()) or len(self.dead_L) != n_dead0 + len(out):
             return self._fail("camera_pose: the device lists do not match the consensus mask")
@@ -544,7 +594,7 @@ def seed_after_adjust(adjuster, state, dead_l, dead_k, K, t_now):
     N = getattr(ctx, "max_pts", 0)
     T = len(state._trajectory)
     n_l, n_c, n_d = len(state._landmarks), len(state._candidates_kp), len(dead_l)
-    if not (0 < N <= 4096 and getattr(ctx, "batch", 1) == 1 and n_l + n_c + n_d <= N and n_l == len(state._landmarks_kp) and T == t_now + 1
+    if not (0 < N <= 8192 and getattr(ctx, "batch", 1) == 1 and n_l + n_c + n_d <= N and n_l == len(state._landmarks_kp) and T == t_now + 1
             and all(t in state._trajectory._poses for t in range(max(0, t_now - HIST + 1), t_now + 1))):
         return None
     seen = ext._seen

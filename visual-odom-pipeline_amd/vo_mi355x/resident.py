@@ -106,6 +106,13 @@ class ResidentPipeline:
             out.append(d)
         return out[0] if self.B == 1 else out
 
+    def fetch_raw(self):
+        """the OLDEST step's records as the ctypes array (no dicts, no arrays: the per-stage caller of lazy.py reads four or five fields)"""
+        rec = (PipeRecord * self.B)()
+        self.ctx._ck(self._L.vo_pipe_fetch(self.ctx._h, rec))
+        self._inflight -= 1
+        return rec
+
     # ---- read-backs of the object boundary (lazy.py): the lists in one copy, object rows by index, the consensus mask -------------
     _LISTS = ("cand", "lm_l", "lm_k", "lm_kshared", "dead_l", "dead_k", "counts", "poses")
     K_ROW = np.dtype([("t_first", "<i4"), ("t_total", "<i4"), ("hist_len", "<i4"), ("pad", "<i4"), ("uv", "<f4", 2), ("uv_first", "<f4", 2),
