@@ -451,7 +451,7 @@ def test_device_side_corner_limit_gives_the_same_corners(monkeypatch):
 def test_tables_beyond_4096_slots_at_1080p_window20():
     """BASELINE config 5's shape in the closed loop: 1920 x 1080, a 20-frame window, tables of 8 192 slots (the list kernels' 8-entries-per-thread
     form: the per-landmark-row words move from LDS to the sequence's global scratch) -- against the table model frame by frame while the state
-    grows past 4 096 keypoints (1 000 new corners per frame), nothing cut by the capacity policy"""
+    grows past 4 096 keypoints (1 000 new corners per frame)"""
     import pipe_oracle as po
     from vo_mi355x.resident import ResidentPipeline
     w, h, t1, n = 1920, 1080, 3, 9
@@ -465,17 +465,22 @@ def test_tables_beyond_4096_slots_at_1080p_window20():
     rp = ResidentPipeline(ctx_b, sc["K"], ba_window=20, ba_max_iters=12, pnp_blind_batches=8)
     rp.seed(state, [], [], 1)
     ctx_b.push_frame(sc["frames"][t1])
-    biggest = 0
+    biggest, clean = 0, True
     for s in range(n):
         im = sc["frames"][t1 + 1 + s]
         model.step(im)
         ctx_b.push_frame(im); rp.step(); rec = rp.fetch()
         what = "step %d" % (s + 2)
-        assert rec["status"] == 0 and model.status == 0 and rec["overflow"] == 0 and not model.info.get("overflow", 0), (what, rec, model.info)
+        # (at a 20-frame window the reference's resurrection brings every young death back every frame: after a few frames even 8 192 slots are
+        #  full and the capacity policy acts -- identically in the model)
+        assert rec["status"] == 0 and model.status == 0 and rec["overflow"] == model.info.get("overflow", 0), (what, rec, model.info)
+        clean = clean and rec["overflow"] == 0
         e = rp.entries()
         assert (len(e["cand"]), len(e["lm"]), len(e["dead"]), e["n_dead_total"]) == (len(model.cand), len(model.lm_L), len(model.dead_L),
                                                                                     len(model.dead_L) + model.n_dead_inert), what
         assert (rec["n_new"], rec["n_resurrected"], rec["n_detected"]) == (model.info["n_new"], model.info["n_resurrected"], model.info["n_detected"]), (what, rec)
+        if clean:
+            biggest = max(biggest, len(model.cand) + len(model.lm_L))
         for name, pairs in (("lm", zip(model.lm_L, model.lm_K)), ("dead", zip(model.dead_L, model.dead_K)), ("cand", ((None, k) for k in model.cand))):
             for i, ((l, k), x) in enumerate(zip(pairs, e[name])):
                 y = model.entry(l, k)
@@ -484,5 +489,4 @@ def test_tables_beyond_4096_slots_at_1080p_window20():
                     assert x[0] == y[0] and np.linalg.norm(x[1] - y[1]) <= 1e-7 * np.linalg.norm(y[1]), (what, name, i)
         for t in range(model.t + 1):
             assert np.abs(e["poses"][t] - model.poses[t]).max() <= 1e-7, (what, t)
-        biggest = max(biggest, len(model.cand) + len(model.lm_L))
-    assert biggest > 4096, biggest
+    assert biggest > 4096, biggest          # reached with nothing cut
