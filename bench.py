@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--regions", type=int, default=5, help="the K-step timed region is repeated this many times; the median is reported")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational single-sequence / KLT-only / pipeline measurements")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)     # launcher plumbing test: no GPU work
+    ap.add_argument("--cpu-pipe-worker", type=int, default=-1, help=argparse.SUPPRESS)   # CPU-baseline worker of the closed loop (table model over the oracle)
+    ap.add_argument("--cpu-pipe-frames", type=int, default=6, help="frames each CPU worker of the closed-loop baseline steps (after 2 untimed ones)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--seqs", type=int, default=96, help="independent sequences per GPU")
     ap.add_argument("--ctxs", type=int, default=None, help="batched contexts (HIP streams) the sequences are split over; default 3 (1 for "
@@ -63,7 +65,7 @@ def parse():
                     help="--workload pipeline: enqueue only (newest fetched frame's maximum + 2) LM iterations per frame instead of --ba-iters "
                          "(+5 %%; a solve the budget cuts cannot be continued in a closed loop -- the next frame already depends on it -- so the default "
                          "enqueues the LM's full --ba-iters, whose surplus groups exit early)")
-    ap.add_argument("--pipe-max-pts", type=int, default=2048, help="--workload pipeline: capacity of the tracked keypoint set per sequence (<= 4096)")
+    ap.add_argument("--pipe-max-pts", type=int, default=2048, help="--workload pipeline: capacity of the tracked keypoint set per sequence (<= 8192)")
     ap.add_argument("--pipe-frames", type=int, default=40, help="--workload pipeline: rendered frames per scene (= the period of the camera's sway; played in a loop)")
     ap.add_argument("--graph", action="store_true", help="replay each frame from a captured hipGraph instead of plain launches")
     ap.add_argument("--host-threads", type=int, default=3, help="enqueue/fetch the contexts from this many host threads")
@@ -422,6 +424,22 @@ def run_pipeline(device, a, dist, n_ctx, per_ctx, steps, warmup, regions, scenes
         ms, n = g.c.profile_read(g.c.PROF_KLT)
         klt_ms += ms; klt_n += n
         g.c.profile_enable(())
+    # roofline of the closed loop's own KLT launch: algorithmic bytes = sum over the LIVE keypoints of the launch and the levels of
+    # 5120 + 1024 * iterations, from the iteration counts the last launch of context 0 left behind, / the launch's duration from hipEvents
+    g0 = groups[0]
+    n_live = [r["n_tracked"] for r in g0.last]
+    _, _, _, it = g0.c.points_download(max_pts, return_iters=True)
+    it = np.maximum(it.reshape(g0.B, max_pts, -1), 0)
+    live_bytes = sum(float((5120.0 + 1024.0 * it[b, :n_live[b]]).sum()) for b in range(g0.B))
+    it_mean = (sum(it[b, :n_live[b]].sum(0) for b in range(g0.B)) / max(1, sum(n_live))).tolist()
+    klt_avg_s = (klt_ms / max(klt_n, 1)) * 1e-3
+    achieved = live_bytes / klt_avg_s / 1e9 if klt_avg_s > 0 else 0.0
+    roof = {"bound": "hbm", "kernel": "k_klt_track", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": None, "avg_launch_us": round(klt_avg_s * 1e6, 3), "algorithmic_bytes_per_launch": int(live_bytes),
+            "live_keypoints_per_launch": int(sum(n_live)), "klt_mean_iters_per_level": [round(x, 3) for x in it_mean],
+            "valu": valu_roofline(klt_avg_s, int(sum(n_live))),
+            "note": "the closed loop's KLT launch tracks what the device tables hold (landmark keypoints + candidates of every sequence of the context); it runs "
+                    "on the side stream beside the bundle adjustment of the previous frame, so its duration includes what that overlap costs"}
     recs = [r for g in groups for step_recs in g.recs for r in step_recs]
     errs = np.array([e for g in groups for e in g.pose_errors()])
     alive = sum(1 for g in groups for r in g.last if r["status"] == 0)
@@ -431,7 +449,10 @@ def run_pipeline(device, a, dist, n_ctx, per_ctx, steps, warmup, regions, scenes
 
     def mean(k):
         return round(float(np.mean([r[k] for r in live])), 1) if live else 0.0
-    out = {"frames_per_s": round(n_seq * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "sequences": n_seq, "contexts": n_ctx,
+    # frames that count: only those of sequences still alive (a sequence whose status is set makes every list kernel return at once)
+    frames_ok = len(live) / max(1, len(region_dt))
+    out = {"frames_per_s": round(frames_ok / dt, 1), "frames_per_s_if_stopped_sequences_counted": round(n_seq * steps / dt, 1),
+           "ms_per_step": round(dt / steps * 1e3, 4), "sequences": n_seq, "contexts": n_ctx,
            "steps": steps, "regions_ms_per_step": [round(x / steps * 1e3, 4) for x in region_dt],
            "sequences_alive_at_end": alive, "frames_in_sequence": scenes[0]["frames"].shape[0], "max_tracked_keypoints": max_pts,
            "ba_window": a.pipe_window, "resurrection_of_dead_landmarks": not a.pipe_no_resurrect, "ba_lm_iteration_cap": a.ba_iters, "ba_budget": "adaptive (newest fetched frame's maximum + 2)" if a.pipe_adaptive_budget else "the LM's full --ba-iters every frame (surplus groups exit early)",
@@ -445,7 +466,7 @@ def run_pipeline(device, a, dist, n_ctx, per_ctx, steps, warmup, regions, scenes
                                       (("dead_list", 1), ("promotion", 2), ("resurrection", 4), ("detection", 8), ("st_candidates", 16))},
            "pose_error_vs_ground_truth": {"rotation_deg_median": round(float(np.median(errs[:, 0])), 4), "rotation_deg_max": round(float(errs[:, 0].max()), 4),
                                           "translation_baselines_median": round(float(np.median(errs[:, 1])), 4)},
-           "klt_avg_launch_us": round(klt_ms / max(klt_n, 1) * 1e3, 2), "setup_s": round(t_setup, 2)}
+           "klt_avg_launch_us": round(klt_ms / max(klt_n, 1) * 1e3, 2), "roofline": roof, "setup_s": round(t_setup, 2)}
     for g in groups:
         g.c.close()
     if pool is not None:
@@ -600,6 +621,63 @@ def cpu_baseline_parallel(n_procs, n_frames, ba_iters):
     return done / slowest, wall, n_procs, extra
 
 
+def cpu_pipeline_worker(a):
+    """one sequence of the closed loop on ONE host core: the table model of oracle/pipe_oracle.py (the algorithm csrc/vo_pipeline.hip implements, pinned
+    to the reference's own Pipeline.step by tests/golden/pipe_*.npz) over the CPU oracle (C: pyramid, KLT, Shi-Tomasi, DLT; numpy: P3P-RANSAC, BA)"""
+    for sub in ("oracle",):
+        sys.path.insert(0, os.path.join(ROOT, sub))
+    import pipe_oracle as po
+    from oracle_context_impl import OracleContext
+    from vo_mi355x import synthetic as syn
+    sc = pipe_scenes(1, a.pipe_frames, 4321 + a.cpu_pipe_worker)[0]
+    ctx = OracleContext(W_IMG, H_IMG)
+    off = pipe_phase_offsets(sc, a.cpu_pipe_worker + 1)[-1]
+    nf = len(sc["frames"])
+    roll = dict(frames=np.roll(sc["frames"], -off, axis=0), poses=np.roll(sc["poses"], -off, axis=0), K=sc["K"], f=sc["f"],
+                surface=lambda t, xy: sc["surface"]((t + off) % nf, xy))
+    state, _ = syn.gt_bootstrap(ctx, roll, 0, PIPE_T1)
+    m = po.PipeModel(ctx, sc["K"], W_IMG, H_IMG, cap=a.pipe_max_pts,
+                     params=po.Params(ba_window=a.pipe_window, ba_max_iters=a.ba_iters, resurrect=not a.pipe_no_resurrect))
+    m.seed(state, [], [], 1)
+    ctx.push_frame(roll["frames"][PIPE_T1])
+    f = PIPE_T1 + 1
+    for _ in range(2):
+        m.step(roll["frames"][f % nf]); f += 1
+    t0 = time.perf_counter()
+    for _ in range(a.cpu_pipe_frames):
+        m.step(roll["frames"][f % nf]); f += 1
+    secs = time.perf_counter() - t0
+    print(json.dumps({"frames": a.cpu_pipe_frames, "seconds": secs, "status": m.status, "landmarks": len(m.lm_L), "candidates": len(m.cand)}))
+
+
+def cpu_pipeline_baseline(a, n_procs):
+    """-> the `cpu_baseline` object of the closed loop: n_procs single-threaded worker processes (this file re-run with --cpu-pipe-worker), one
+    sequence each, started before this process touches the GPU"""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    argv = ["--cpu-pipe-frames", str(a.cpu_pipe_frames), "--ba-iters", str(a.ba_iters), "--pipe-frames", str(a.pipe_frames), "--pipe-window", str(a.pipe_window),
+            "--pipe-max-pts", str(a.pipe_max_pts)] + (["--pipe-no-resurrect"] if a.pipe_no_resurrect else [])
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-pipe-worker", str(i)] + argv, stdout=subprocess.PIPE, env=env, text=True)
+             for i in range(n_procs)]
+    done, slowest, lm = 0, 0.0, []
+    for pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode == 0 and out.strip():
+            r = json.loads(out.strip().splitlines()[-1])
+            if r["status"] == 0:
+                done += r["frames"]; slowest = max(slowest, r["seconds"]); lm.append(r["landmarks"] + r["candidates"])
+    wall = time.perf_counter() - t0
+    v = done / slowest if done else 0.0
+    return {"value": round(v, 3), "unit": "frames/s", "cores": n_procs, "cores_available": usable_cores(), "cores_visible": os.cpu_count() or 0, "kind": "port",
+            "per_core": round(v / max(n_procs, 1), 3),
+            "sample": "%d worker processes (1 core each, one sequence each) x %d frames of the closed loop (after 2 untimed) through the table model of "
+                      "oracle/pipe_oracle.py over the CPU oracle (C: pyramid + KLT + Shi-Tomasi + DLT, numpy: P3P-RANSAC + BA), window %d, %d-slot tables, "
+                      "~%d keypoints per sequence; %.1f s wall" % (n_procs, a.cpu_pipe_frames, a.pipe_window, a.pipe_max_pts, int(np.mean(lm)) if lm else 0, wall)}
+
+
 def reference_recipe_ba_seconds():
     """ONE bundle adjustment of the workload's shape (2000 landmarks x 10 poses, every landmark seen in every frame) solved with
     the REFERENCE'S SOLVER RECIPE -- scipy least_squares(method='trf', 2-point finite differences with jac_sparsity, loss='huber',
@@ -686,7 +764,7 @@ def cpu_baseline(frames, n_frames, ba_iters):
     return n_frames / dt, dt
 
 
-def measure_extras(device, frame_sets, a, dist):
+def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
     """Informational, after the timed regions, rank 0 of a 1-GPU run: the other BASELINE configurations on the same device.
     single_sequence: configs[2] / [3] literally -- ONE sequence in one context (launch-latency bound).
     klt_only: configs[1] -- pyramid + Scharr + KLT of 2000 points per frame, maxLevel 3 (4 levels) and 2, one sequence and a
@@ -749,9 +827,15 @@ def measure_extras(device, frame_sets, a, dist):
     try:
         # ONE context of 96 sequences: since the tracking of frame t + 1 and the spawn of frame t run beside the adjustment of frame t inside a
         # context (csrc/vo_pipeline.hip), one large batch beats three small ones (39.0 k against 33.1 k frames/s; 128 sequences: 40.9 k)
+        # the same with tables the scene does not fill (8 192 slots; the scene's steady state is ~4 400 keypoints): the loop measured is then the
+        # reference's unbounded lists, not the capacity policy's (capacity_policy_frames.detection = 0 after the fill-up)
+        a4big = _copy.copy(a4); a4big.pipe_max_pts = 8192
         out["pipeline_step"] = {"reference_configuration_window4": run_pipeline(device, a4, dist, 1, 96, 40, 10, 3, scenes),
                                 "window10_dead_stay_dead": run_pipeline(device, a10, dist, 1, 96, 40, 10, 3, scenes),
-                                "one_sequence_window4": run_pipeline(device, a4, dist, 1, 1, 100, 10, 3, scenes)}
+                                "one_sequence_window4": run_pipeline(device, a4, dist, 1, 1, 100, 10, 3, scenes),
+                                "window4_tables_not_full_8192_slots": run_pipeline(device, a4big, dist, 1, 32, 40, 60, 3, scenes)}
+        if cpu_pipe is not None:
+            out["pipeline_step"]["reference_configuration_window4"]["cpu_baseline"] = cpu_pipe
     except Exception as e:      # noqa: BLE001  (an informational key must not cost the others)
         out["pipeline_step"] = {"error": str(e)}
     try:
@@ -861,6 +945,9 @@ def main():
         frames = syn.make_sequence(2, W_IMG, H_IMG, seed=1234)[0]
         print(json.dumps({"reference_recipe_ba": reference_recipe_ba_seconds(), "opencv": opencv_baseline(frames)}))
         return
+    if a.cpu_pipe_worker >= 0:     # CPU-baseline worker of the closed loop: never touches the GPU library
+        cpu_pipeline_worker(a)
+        return
     if a.cpu_worker >= 0:          # CPU-baseline worker process: never touches the GPU library
         from vo_mi355x import synthetic as syn
         frames = syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + a.cpu_worker, periodic=True, n_render=a.cpu_frames + 2)[0]
@@ -880,6 +967,15 @@ def main():
                "sample": "%d worker processes (1 core each, independent sequences) x %d frames of the same workload on the CPU "
                          "oracle (C: pyramid+KLT+Shi-Tomasi+DLT, numpy: BA), %.1f s wall; %.2f frames/s per core; host shows %d cores, "
                          "its cgroup grants %d" % (cores, a.cpu_frames, secs, v / max(cores, 1), os.cpu_count() or 0, usable_cores())}
+    cpu_pipe = None
+    if dist.rank == 0 and dist.world == 1 and not a.no_cpu_baseline and (a.workload == "pipeline" or (a.workload == "A" and not a.no_extras)):
+        # (child processes: before anything initialises the GPU here.  In the default run it is the figure beside the informational
+        #  `pipeline_step.reference_configuration_window4` entry: the reference's own window, 2 048-slot tables)
+        ap = a
+        if a.workload == "A":
+            import copy as _c
+            ap = _c.copy(a); ap.pipe_window, ap.pipe_no_resurrect = 4, False
+        cpu_pipe = cpu_pipeline_baseline(ap, max(1, min(a.cpu_procs, usable_cores())))
     from vo_mi355x import VoContext, synthetic as syn
     # more stepping host threads on this node than cores it grants (8 ranks x 3 threads on a 16-core cgroup): wait for a step's event
     # in the driver instead of spinning on it (1 GPU: 34 650 vs 34 640 frames/s, two ranks on one GPU 31 580 vs 31 190 -- no loss)
@@ -897,13 +993,13 @@ def main():
         tot = dist.sum(float(r["sequences"]))
         if dist.rank == 0:
             fps = tot * a.steps / (r["ms_per_step"] * 1e-3 * a.steps)
-            print(json.dumps({"metric": "frames/sec, Pipeline.step resident on the device @1241x376 (<= 2048 tracked keypoints, RANSAC-P3P pose, triangulation, "
-                                        "10-frame BA, re-detection; closed loop)", "value": round(fps, 2), "unit": "frames/s", "n_gpus": dist.world,
+            print(json.dumps({"metric": "frames/sec, Pipeline.step resident on the device @1241x376 (<= %d tracked keypoints, RANSAC-P3P pose, triangulation, "
+                                        "%d-frame BA, re-detection; closed loop)" % (a.pipe_max_pts, a.pipe_window), "value": round(fps, 2), "unit": "frames/s", "n_gpus": dist.world,
                               "steps": a.steps, "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                               "vs_baseline": None, "dtype": "u8/i32 (KLT, Shi-Tomasi) + f64 (P3P, DLT, BA)", "data": "synthetic (rendered two-plane scene, known trajectory)",
-                              "config": {"workload": "pipeline_step_closed_loop_1241x376_ba10", "sequences_per_gpu": r["sequences"],
+                              "config": {"workload": "pipeline_step_closed_loop_1241x376_ba%d" % a.pipe_window, "sequences_per_gpu": r["sequences"],
                                          "batched_contexts_per_gpu": r["contexts"], "parallelism": "independent sequences, no collective"},
-                              "pipeline": r, "roofline": None, "cpu_baseline": None}))
+                              "pipeline": r, "roofline": r.pop("roofline", None), "cpu_baseline": cpu_pipe}))
         dist.close()
         return
     if c5:
@@ -1113,7 +1209,7 @@ def main():
         s.c.close()
     if out is not None and dist.world == 1 and a.workload == "A" and not a.no_extras:
         try:
-            out.update(measure_extras(dist.local_rank, frame_sets, a, dist))
+            out.update(measure_extras(dist.local_rank, frame_sets, a, dist, cpu_pipe))
         except Exception as e:      # noqa: BLE001  (informational keys must never cost the bench line)
             out["extras_error"] = str(e)
     dist.close()

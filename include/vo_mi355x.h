@@ -484,7 +484,7 @@ int32_t vo_pipe_inliers_read(vo_ctx* ctx, uint8_t* mask, int32_t n);
  * uploaded pairs] -> [BA of the uploaded problem] -> [Shi-Tomasi re-detection around the tracked points] ->
  * result copies.  With vo_set_graph_mode(ctx, 1) the launch sequence is captured once per buffer parity and replayed
  * as a hipGraph (bit-identical results; off by default: on ROCm 7.2 the replay costs more than ~45 plain launches).
- * Up to TWO steps may be in flight (one in graph mode): step t + 1 can be enqueued before step t is fetched, the
+ * Up to TWO steps may be in flight (in graph mode too: a capture is keyed by the mirror half it bakes in): step t + 1 can be enqueued before step t is fetched, the
  * results of consecutive steps land in alternating pinned mirrors, so the GPU queue never drains while the host
  * unpacks.  vo_frame_fetch waits for the OLDEST step not fetched yet (an event, not the whole stream) and unpacks it;
  * with nothing in flight it returns the last step's results again. */
