@@ -119,11 +119,13 @@ __global__ void __launch_bounds__(256) k_st_sobel_hsum(const uint8_t* __restrict
 // grid (blocks, batch); pts of sequence b at + b * pts_seq bytes
 __global__ void __launch_bounds__(256) k_st_discs(const float* __restrict__ pts, size_t pts_seq, int n, int radius, disc_rows rows,
                                                   uint8_t* __restrict__ mask, int W, int H, const int32_t* __restrict__ counts) {
+  // (16 lanes per disc row -- lane = column, so that a store instruction covers four 15-byte row segments instead of one byte in each of 64 rows --
+  //  was measured in round 4: 54.8 us instead of 38.4 per 32 x 2 048 discs; sixteen times the waves cost more than the scattered stores)
   const int nrows = 2 * radius + 1;
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= n * nrows) return;
   pts = vo_seq(pts, pts_seq, blockIdx.y);
   mask += (size_t)blockIdx.y * W * H;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * nrows) return;
   const int k = gid / nrows, dy = gid - k * nrows - radius;
   if (counts && k >= counts[blockIdx.y]) return;
   const int cx = (int)pts[2 * k], cy = (int)pts[2 * k + 1];   // np.int32(): truncation toward zero
@@ -571,10 +573,12 @@ __device__ __forceinline__ unsigned long long st_uniform64(unsigned long long v)
   return ((unsigned long long)st_uniform((uint32_t)(v >> 32)) << 32) | st_uniform((uint32_t)v);
 }
 
-// LDS map of k_st_select (144 KB): exchange buffer of the sort: keys u64 [n2 <= 16384] at 0.
-// selection phase (keys dead): xy u32 [n] at 0 | cell heads u32 [<= 8192] at 64 KB | next u16 [n] at 96 KB | state u8 [n] at 128 KB
-#define ST_SEL_LDS (144 * 1024)
+// LDS map of k_st_select for `cap` entries: exchange buffer of the sort: keys u64 [n2 <= cap] at 0.
+// selection phase (keys dead): xy u32 [cap] at 0 | cell heads u32 [8192] | next u16 [cap] | state u8 [cap]   (144 KB at cap = 16 384, 60 KB at 4 096)
 #define ST_MAX_CELLS 8192
+static inline size_t st_sel_lds(int cap) { const size_t a = 8 * (size_t)cap, b = 7 * (size_t)cap + 4 * ST_MAX_CELLS; return a > b ? a : b; }
+#define ST_SEL_LDS st_sel_lds(ST_CAND_CAP)
+#define ST_CAP_CLOSED_LOOP 4096
 #define ST_KP_MAX (ST_CAND_CAP / 1024)
 
 // value of lane (l ^ J) for J = 1 ... 32 without the LDS pipe's address path: DPP quad permutes / row rotation, one swizzle, the two
@@ -608,14 +612,15 @@ __device__ __forceinline__ void st_wave_substep(unsigned long long (&kr)[KP], in
 // dependent access) is what bounds an all-LDS bitonic sort of this size.  What bounds THIS one is vector issue: 2 048 keys x 66 steps x
 // ~12 instructions on 64-bit keys = 38 k cycles (42 k with ds_bpermute exchanges).  Packing a small sort onto 4 waves x 8 keys (3 cross-wave
 // steps instead of 10) was measured and is slower, 60 k: one wave per SIMD cannot hide the exchange latencies.
+// n2: the network's size for this call, a power of two in [64, 1024 KP] that covers the real keys (the slots behind them hold 0 and sort among
+// themselves): a 256-key chunk of the closed loop takes 36 compare-exchange steps, 3 of them across waves, instead of 55 / 10
 template <int KP>
-__device__ __forceinline__ void st_sort_regs(unsigned long long (&kr)[KP], unsigned long long* keys, int tid) {
+__device__ __forceinline__ void st_sort_regs(unsigned long long (&kr)[KP], unsigned long long* keys, int tid, int n2) {
   const int wave = tid >> 6, lane = tid & 63;
   constexpr int SEG = KP * 64;
-  constexpr int N2 = KP * 1024;
   const int ibase = wave * SEG + lane;
 #pragma unroll 1
-  for (int k = 2; k <= N2; k <<= 1) {
+  for (int k = 2; k <= n2; k <<= 1) {
 #pragma unroll 1
     for (int j = k >> 1; j > 0; j >>= 1) {
       if (j >= SEG) {
@@ -671,7 +676,9 @@ __device__ __forceinline__ void st_sort_dispatch(const unsigned long long* __res
     const unsigned long long k = (i < n_load) ? cand[i] : 0ull;
     kr[q] = (k > floor_key) ? k : 0ull;
   }
-  st_sort_regs<KP>(kr, keys, tid);
+  int n2 = 64;
+  while (n2 < n_load) n2 <<= 1;                    // (uniform; n_load <= 1024 KP)
+  st_sort_regs<KP>(kr, keys, tid, n2);
   __syncthreads();   // the exchange buffer aliases xy
   // keys -> packed (x, y) in rank order
 #pragma unroll
@@ -690,18 +697,21 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
                                                     double md2, int use_dist, int max_corners, float* __restrict__ out,
                                                     size_t slab_seq, unsigned long long* __restrict__ dbg,
                                                     const float* __restrict__ blockmax, int n_blockmax, double quality,
-                                                    uint32_t* __restrict__ nraw, const int32_t* __restrict__ limit_dev) {
+                                                    uint32_t* __restrict__ nraw, const int32_t* __restrict__ limit_dev, int cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cand += (size_t)blockIdx.x * ST_CAND_STRIDE;          // one workgroup per sequence
   scalars = vo_seq(scalars, slab_seq, blockIdx.x); out = vo_seq(out, slab_seq, blockIdx.x);
   if (blockIdx.x != 0) dbg = nullptr;
   __shared__ int s_flags[3];
   __shared__ int s_scan[1024];
+  // cap: entries the LDS structures of this launch hold (st_sel_lds(cap) bytes): ST_CAND_CAP = 16 384 (144 KB: a CU to itself) for a
+  // caller that may want every corner, 4 096 (60 KB) for the closed loop, whose device-side corner limit keeps the chunks short -- with 144 KB
+  // the workgroup had to wait until a whole CU's LDS was free of the bundle adjustment's workgroups running beside it
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
   uint32_t* xy = reinterpret_cast<uint32_t*>(smem);
-  uint32_t* heads = reinterpret_cast<uint32_t*>(smem + 64 * 1024);
-  uint16_t* nxt = reinterpret_cast<uint16_t*>(smem + 96 * 1024);
-  uint8_t* state = smem + 128 * 1024;   // plain LDS bytes (a volatile pointer here degrades to FLAT sc0 sc1 accesses)
+  uint32_t* heads = reinterpret_cast<uint32_t*>(smem + 4 * (size_t)cap);
+  uint16_t* nxt = reinterpret_cast<uint16_t*>(smem + 4 * (size_t)cap + 4 * ST_MAX_CELLS);
+  uint8_t* state = smem + 6 * (size_t)cap + 4 * ST_MAX_CELLS;   // plain LDS bytes (a volatile pointer here degrades to FLAT sc0 sc1 accesses)
   const int tid = threadIdx.x;
   VO_STAMP(dbg, 0);
   // ---- global masked maximum (minMaxLoc) from the per-workgroup maxima, the quality threshold, and the candidates that pass it:
@@ -746,16 +756,16 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
   //      strongest of them do not fill max_corners (flat or noisy images with a large min_distance). ----
   uint32_t* hist = reinterpret_cast<uint32_t*>(s_scan);
   __shared__ unsigned long long s_prefix;
-  __shared__ uint32_t s_need, s_fill;
+  __shared__ uint32_t s_need, s_fill, s_take;
   int limit = (max_corners > 0) ? min(max_corners, ST_OUT_CAP) : ST_OUT_CAP;
   // limit_dev (closed loop): the caller can use at most that many corners of this sequence (the free slots of its table + 1, typically a few
   // dozen).  The scan is in rank order, so the first `limit` accepted corners depend only on the strongest candidates: the list is consumed
   // in SHORT rank-ordered chunks (the radix select below) instead of sorting all of it -- the same corners, exactly.
-  int kcap = ST_CAND_CAP;
+  int kcap = cap;
   if (limit_dev) {
     const int ld = (int)st_uniform((uint32_t)max(limit_dev[blockIdx.x], 0));
     limit = min(limit, ld);
-    kcap = min(ST_CAND_CAP, max(512, 16 * limit));
+    kcap = min(cap, max(256, 8 * limit));
   }
   unsigned long long* const src = cand;                   // raw list (entries <= thr_key do not count)
   unsigned long long* const top = cand + ST_GLOBAL_CAP;   // chunk staging (behind the raw list)
@@ -765,15 +775,21 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
   uint32_t rounds_total = 0;
 #pragma unroll 1
   for (int pass = 0;; pass++) {
-    const int K = min(ST_CAND_CAP - n_acc, kcap);
+    const int K = min(cap - n_acc, kcap);
     const unsigned long long* chunk = src;
     int n_new = (int)remaining, n_load = (int)n_raw;
     unsigned long long next_upper = 0;
     if (remaining > (uint32_t)K) {
       // the K strongest keys below `upper`: keys are unique (value bits | pixel index), so the K-th largest is found exactly by
       // an 8-pass radix select (256-bin LDS histogram of the next byte among the keys that share the prefix)
+      // It stops as soon as the WHOLE bin of the K-th key still fits the sort's size class (K <= taken <= k_room): the chunk is then the keys
+      // down to that bin's lower bound -- a rank-ordered prefix of the list like any other, a few more keys than asked for -- after two or three
+      // passes instead of eight (eigenvalues between 3 % and 100 % of the maximum spread over ~640 bins of the top 16 bits).
+      int k_room = 1024;
+      while (k_room < K) k_room <<= 1;
+      k_room = min(k_room, cap - n_acc);
       unsigned long long prefix = 0;
-      uint32_t need = (uint32_t)K;
+      uint32_t need = (uint32_t)K, taken = (uint32_t)K;
       for (int byte = 7; byte >= 0; byte--) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
@@ -803,17 +819,21 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
             s_prefix = prefix | ((unsigned long long)d << sh);
             s_need = nd;
             s_fill = 0;
+            // keys above this bin (K - need from the earlier passes + the bins above it in this one) + the whole bin
+            s_take = ((uint32_t)K - need) + (need - nd) + hist[d];
           }
         }
         __syncthreads();
         prefix = st_uniform64(s_prefix); need = st_uniform(s_need);
+        const uint32_t whole = st_uniform(s_take);
+        if (whole <= (uint32_t)k_room) { taken = whole; break; }     // (uniform)
       }
       for (uint32_t i = tid; i < n_raw; i += 1024) {
         const unsigned long long k = src[i];
-        if (k >= prefix && k < upper) { const uint32_t pos = atomicAdd(&s_fill, 1u); if (pos < ST_CAND_CAP) top[pos] = k; }   // prefix > thr_key
+        if (k >= prefix && k > thr_key && k < upper) { const uint32_t pos = atomicAdd(&s_fill, 1u); if (pos < (uint32_t)cap) top[pos] = k; }   // (a whole bin may reach below the threshold)
       }
       __syncthreads();
-      chunk = top; n_new = K; n_load = K; next_upper = prefix;
+      chunk = top; n_new = (int)taken; n_load = (int)taken; next_upper = prefix;
     } else if (pass > 0) {
       if (tid == 0) s_fill = 0;
       __syncthreads();
@@ -823,7 +843,7 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
       }
       __syncthreads();
       chunk = top; n_load = n_new;
-    } else if (n_raw > ST_CAND_CAP) {
+    } else if (n_raw > (uint32_t)cap) {
       // first and only chunk, but the raw list is longer than the sort holds: compact the valid keys (<= ST_CAND_CAP of them)
       if (tid == 0) s_fill = 0;
       __syncthreads();
@@ -957,17 +977,17 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
     const int b0 = n_acc + min(tid * per, n_new), b1 = min(b0 + per, n);
     int cnt = 0;
     for (int i = b0; i < b1; i++) cnt += (state[i] == 1);
+    int incl = cnt;                  // inclusive scan inside the wave, the 16 wave totals through LDS: two barriers instead of twenty
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if ((tid & 63) >= o) incl += y; }
     __syncthreads();                 // hist (the radix select) aliases s_scan
-    s_scan[tid] = cnt;
+    if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      const int v = (tid >= o) ? s_scan[tid - o] : 0;
-      __syncthreads();
-      s_scan[tid] += v;
-      __syncthreads();
-    }
-    int pos = n_acc + s_scan[tid] - cnt;
-    const int total = n_acc + (int)st_uniform((uint32_t)s_scan[1023]);
+    int woff = 0, wtot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const int v = s_scan[w]; if (w < (tid >> 6)) woff += v; wtot += v; }
+    int pos = n_acc + woff + incl - cnt;
+    const int total = n_acc + (int)st_uniform((uint32_t)wtot);
     for (int i = b0; i < b1; i++)
       if (state[i] == 1) {
         if (pos < limit) {
@@ -1136,9 +1156,10 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
   while (((W + cell - 1) / cell) * ((H + cell - 1) / cell) > ST_MAX_CELLS) cell++;
   const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
   const double md2 = prm->min_distance * prm->min_distance;
-  hipLaunchKernelGGL(k_st_select, dim3(B), dim3(1024), ST_SEL_LDS, c->stream, s->d_cand,
+  const int sel_cap = limit_dev ? ST_CAP_CLOSED_LOOP : ST_CAND_CAP;
+  hipLaunchKernelGGL(k_st_select, dim3(B), dim3(1024), st_sel_lds(sel_cap), c->stream, s->d_cand,
                      s->d_scalars, W, H, cell, gw, gh, md2, use_dist, prm->max_corners, s->d_out, c->slab_seq, c->d_dbg,
-                     s->d_blockmax, n_blockmax, prm->quality_level, s->d_nraw, limit_dev);
+                     s->d_blockmax, n_blockmax, prm->quality_level, s->d_nraw, limit_dev, sel_cap);
   VO_HIP(c, hipGetLastError());
   s->last_max_corners = prm->max_corners;
   return VO_OK;
