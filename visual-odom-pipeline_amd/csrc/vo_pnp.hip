@@ -424,9 +424,50 @@ __device__ inline void pnp_log_so3(const double* R, double* r) {
 #define PNP_REFINE_THREADS 512      // 8 waves per sequence (256 VGPRs each: the 28 partial sums + the Jacobian stay in registers; 1024 threads spilled 41)
 #define PNP_REFINE_WAVES (PNP_REFINE_THREADS / 64)
 
-// fixed-order block sum of v[0 .. nv): wave shuffles, then the wave partials as a fixed pairwise tree
+// Reduce-scatter steps of the 28 wave sums: x and y are summed over lane pairs at once, one half of the lanes keeps x's sum, the other y's
+// (three instructions for two values; the all-reduce of pnp_wave_sum spends eighteen per value -- 504 per block sum, now ~130)
+__device__ __forceinline__ double pnp_rs32(double x, double y) {       // lanes 0..31: x[l] + x[l + 32]; lanes 32..63: y[l - 32] + y[l]
+  const auto l2 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto h2 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
+}
+__device__ __forceinline__ double pnp_rs16(double x, double y) {       // rows 0, 2: x[row] + x[row + 1]; rows 1, 3: y[row - 1] + y[row]
+  const auto l2 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto h2 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
+}
+__device__ __forceinline__ double pnp_rs8(double x, double y, int lane) {   // bit 3 clear: x[l] + x[l ^ 8]; set: y[l ^ 8] + y[l]
+  const bool hi = (lane & 8) != 0;
+  const double keep = hi ? y : x, send = hi ? x : y;
+  return keep + pnp_dpp<0x128>(send);                                       // row_ror:8 = lane ^ 8 inside a row of 16
+}
+
+// fixed-order block sum of v[0 .. nv): wave sums (nv = PNP_NRED: as a reduce-scatter -- after the three scatter stages the lane whose bits
+// 5, 4, 3 spell (b5, b4, b3) holds value 8 i + 4 b3 + 2 b4 + b5 in slot i, summed over eight lanes; one all-reduce over the remaining eight
+// lanes finishes four values at a time), then the wave partials as a fixed pairwise tree
 __device__ inline void pnp_block_sum(double* v, int nv, double* s_red /* PNP_REFINE_WAVES * PNP_NRED */, double* s_out /* PNP_NRED */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (nv == PNP_NRED) {
+    double a[14], c[8], e[4];
+#pragma unroll
+    for (int i = 0; i < 14; i++) a[i] = pnp_rs32(v[2 * i], v[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 7; i++) c[i] = pnp_rs16(a[2 * i], a[2 * i + 1]);
+    c[7] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      double x = pnp_rs8(c[2 * i], c[2 * i + 1], lane);
+      x += pnp_dpp<0x141>(x);        // row_half_mirror: x[l] + x[7 - l] inside every group of 8
+      x += pnp_dpp<0xB1>(x);         // quad_perm [1, 0, 3, 2]
+      x += pnp_dpp<0x4E>(x);         // quad_perm [2, 3, 0, 1]
+      e[i] = x;
+    }
+    if ((lane & 7) == 0) {
+      const int sub = ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (8 * i + sub < PNP_NRED) s_red[wave * PNP_NRED + 8 * i + sub] = e[i];
+    }
+  } else
   for (int k = 0; k < nv; k++) {
     const double x = pnp_wave_sum(v[k]);
     if (lane == 0) s_red[wave * PNP_NRED + k] = x;
