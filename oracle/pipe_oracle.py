@@ -338,6 +338,7 @@ class PipeModel:
             if ok:          # appended to the state's lists as the SAME objects (:142-147)
                 self.lm_L.append(L); self.lm_K.append(K); self.lm_ksh.append(True)
         live_L = set(self.lm_L)
+        live_L |= {L for ok, win, L in zip(crit, window, self.dead_L) if win and not ok}      # (capacity policy: in the window, no room this time)
         front = [(L, K) for ok, L, K in zip(crit, self.dead_L, self.dead_K) if ok]
         # an entry that stays dead is kept while it may still be resurrected: the window test holds (no room this time) or its
         # Landmark object is in the state's list (its t_latest still advances); otherwise it is inert and only counted

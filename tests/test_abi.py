@@ -76,3 +76,24 @@ def test_synthetic_generators():
     assert s["obs"].shape == (5, 50, 2) and not np.isnan(s["obs"]).any()
     s = syn.make_ba_scene(50, 5, visibility=0.5)
     assert np.isnan(s["obs"]).any()
+
+
+def test_ctypes_mirrors_have_the_c_structs_sizes(tmp_path):
+    """the structures of include/vo_mi355x.h, compiled by the host compiler, against their ctypes mirrors in vo_mi355x/_lib.py (a field added
+    on one side only would make every later field read garbage)"""
+    import shutil
+    import subprocess
+    from vo_mi355x import _lib
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no host C compiler")
+    pairs = [("vo_pipe_record", _lib.PipeRecord), ("vo_pipe_params", _lib.PipeParams), ("vo_klt_params", _lib.KltParams), ("vo_st_params", _lib.StParams),
+             ("vo_ba_params", _lib.BaParams), ("vo_ba_stats", _lib.BaStats), ("vo_pnp_params", _lib.PnpParams), ("vo_pnp_stats", _lib.PnpStats)]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "vo_mi355x.h"\nint main(void) { printf("%s\\n", %s); return 0; }\n' % (
+        " ".join(["%zu"] * len(pairs)), ", ".join("sizeof(%s)" % n for n, _ in pairs)))
+    exe = tmp_path / "sizes"
+    subprocess.check_call([cc, "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    for (name, mirror), size in zip(pairs, got):
+        assert ctypes.sizeof(mirror) == size, (name, ctypes.sizeof(mirror), size)

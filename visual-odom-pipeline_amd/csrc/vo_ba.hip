@@ -56,11 +56,6 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-struct ba_state {
-  double lambda, nu, cost, cost0;
-  int cur, iter, accepted, status, done, n_obs;
-};
-
 struct ba_info {            // written by k_ba_solve for the iteration
   double cost_cur, pred_pose, step2_pose, x2_pose, ginf;
   int chol_fail, pad;
@@ -1162,7 +1157,7 @@ __global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs Pall, ba_params_dev p
 __global__ void __launch_bounds__(256) k_ba_finalize(ba_ptrs Pall, ba_params_dev prm, int n_it, unsigned char* __restrict__ pub,
                                                      size_t pub_stride, ba_state* __restrict__ st_out, int st_stride) {
   const ba_ptrs P = ba_select(Pall, blockIdx.x);
-  double* x_out = reinterpret_cast<double*>(pub + (size_t)blockIdx.x * pub_stride + 64);
+  double* x_out = reinterpret_cast<double*>(pub + (size_t)blockIdx.x * pub_stride + VO_BA_PUB_HEADER);
   st_out += (size_t)blockIdx.x * st_stride;
   __shared__ ba_state s_st;
   __shared__ double s_esum[4];
@@ -1177,7 +1172,7 @@ __global__ void __launch_bounds__(256) k_ba_finalize(ba_ptrs Pall, ba_params_dev
     if (blockIdx.y == 0) {
       *st_out = st;
       P.state[n_it & 1] = st;
-      *reinterpret_cast<ba_state*>(reinterpret_cast<unsigned char*>(x_out) - 64) = st;   // pub header of this problem
+      *reinterpret_cast<ba_state*>(reinterpret_cast<unsigned char*>(x_out) - VO_BA_PUB_HEADER) = st;   // pub header of this problem
     }
   }
   __syncthreads();
@@ -1311,10 +1306,10 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     VO_HIP(c, hipMalloc((void**)&b->d_Hpp, sizeof(double) * (size_t)W * BA_POSE_VALS));
     VO_HIP(c, hipMalloc((void**)&b->d_res, sizeof(double) * (size_t)W * N * B));
     VO_HIP(c, hipMalloc((void**)&b->d_dl, sizeof(double) * (size_t)3 * N));
-    b->pub_bytes = 64 + sizeof(double) * nx;                                                        // per problem
+    b->pub_bytes = VO_BA_PUB_HEADER + sizeof(double) * nx;                                                        // per problem
     VO_HIP(c, hipMalloc((void**)&b->d_pub, b->pub_bytes * B));
     VO_HIP(c, hipHostMalloc((void**)&b->h_pub, 3 * b->pub_bytes * B, hipHostMallocDefault));   // two halves (pipelined frame steps) + one for vo_ba_fetch
-    b->d_xout = reinterpret_cast<double*>(b->d_pub + 64);
+    b->d_xout = reinterpret_cast<double*>(b->d_pub + VO_BA_PUB_HEADER);
     VO_HIP(c, hipMalloc((void**)&b->d_state, sizeof(ba_state) * 2 * B));
     VO_HIP(c, hipMalloc((void**)&b->d_info, sizeof(ba_info) * B));
     VO_HIP(c, hipHostMalloc((void**)&b->h_state, sizeof(ba_state) * B, hipHostMallocDefault));
@@ -1550,7 +1545,7 @@ void vo_ba_unpack_pub(vo_ctx* c, int half, double* poses_out, double* points_out
   vo_ba_ws* b = c->ba;
   for (int q = 0; q < c->batch; q++) {
     const uint8_t* pub = b->h_pub + (size_t)half * b->pub_bytes * c->batch + (size_t)q * b->pub_bytes;
-    const double* x = reinterpret_cast<const double*>(pub + 64);
+    const double* x = reinterpret_cast<const double*>(pub + VO_BA_PUB_HEADER);
     if (poses_out) memcpy(poses_out + (size_t)q * 6 * b->W, x, sizeof(double) * 6 * b->W);
     if (points_out) memcpy(points_out + (size_t)q * 3 * b->N, x + 6 * b->W, sizeof(double) * 3 * b->N);
     if (stats) ba_fill_stats(*reinterpret_cast<const ba_state*>(pub), -1, stats + q);
@@ -1594,7 +1589,7 @@ extern "C" int32_t vo_ba_gather_points(vo_ctx* c, double* points_all) {
   }
   double* send = b->d_gather; double* recv = b->d_gather + cnt;
   // points part of the published x of every problem -> packed send buffer
-  VO_HIP(c, hipMemcpy2DAsync(send, sizeof(double) * 3 * b->N, b->d_pub + 64 + sizeof(double) * 6 * b->W, b->pub_bytes,
+  VO_HIP(c, hipMemcpy2DAsync(send, sizeof(double) * 3 * b->N, b->d_pub + VO_BA_PUB_HEADER + sizeof(double) * 6 * b->W, b->pub_bytes,
                              sizeof(double) * 3 * b->N, B, hipMemcpyDeviceToDevice, c->stream));
   const int32_t r = vo_comm_allgather_f64(c, send, recv, cnt);
   if (r != VO_OK) return r;

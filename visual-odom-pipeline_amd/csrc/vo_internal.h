@@ -215,6 +215,14 @@ void vo_pipe_destroy(vo_ctx* c);
 
 // ---- hooks of the closed-loop pipeline (vo_pipeline.hip) into the stage units: device-resident inputs, per-sequence counts ----
 // bundle adjustment: workspace for W slots x N landmark slots with K uploaded, problem written on the device into x0 / obs
+// LM state of one bundle-adjustment problem; also the header of the publish buffer [ba_state, padded to VO_BA_PUB_HEADER bytes | x] that
+// k_ba_finalize writes and vo_ba_fetch / k_pipe_writeback read
+struct ba_state {
+  double lambda, nu, cost, cost0;
+  int cur, iter, accepted, status, done, n_obs;
+};
+#define VO_BA_PUB_HEADER 64
+static_assert(sizeof(ba_state) <= VO_BA_PUB_HEADER, "the publish buffer's header holds one ba_state");
 struct vo_ba_view { double* x0; double* obs; const uint8_t* pub; size_t pub_bytes; size_t x_stride; size_t obs_stride; int W, N; };
 int32_t vo_ba_reserve(vo_ctx* c, const double* K_host, int W, int N);
 int32_t vo_ba_get_view(vo_ctx* c, vo_ba_view* v);

@@ -776,7 +776,13 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
     __syncthreads();
     // an entry that stays dead is kept while it may still be resurrected: the window test holds, or its L row is in the state's list
 #pragma unroll
-    for (int c = 0; c < CH; c++) { const int j = tid * CH + c; if (j < nl) s_mark[s_lmL[j]] = 1; }
+    for (int c = 0; c < CH; c++) {
+      const int j = tid * CH + c;
+      if (j < nl) s_mark[s_lmL[j]] = 1;
+      // (capacity policy only: an entry inside the window that found no room stays a candidate for resurrection, and so does every entry
+      //  that shares its landmark row -- once it returns, the row's t_latest advances again for them too)
+      if (j < nd0 && win[c] && !take[c]) s_mark[DL[c]] = 1;
+    }
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < CH; c++) { const int j = tid * CH + c; stay[c] = j < nd0 && !take[c] && (win[c] || s_mark[DL[c]] == 1); }
@@ -863,7 +869,6 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
 // ================================================================================================
 // k_pipe_writeback: solution -> landmark rows and trajectory (bundle_adjuster.py:197-213)
 // ================================================================================================
-struct pipe_ba_head { double lambda, nu, cost, cost0; int cur, iter, accepted, status, done, n_obs; };
 
 template <int CH>
 __global__ void __launch_bounds__(PIPE_TPB) k_pipe_writeback(pipe_ptrs Pall, int do_adjust, const uint8_t* __restrict__ pub, size_t pub_bytes, const double* __restrict__ x0,
@@ -874,9 +879,9 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_writeback(pipe_ptrs Pall, int
   //  side stream, touches the candidate list, fresh keypoint rows and the free lists)
   const int nl = P.cnt[C_NLM], t = P.cnt[C_T];
   if (do_adjust && !P.cnt[C_STATUS]) {
-    const pipe_ba_head* st = reinterpret_cast<const pipe_ba_head*>(pub + (size_t)b * pub_bytes);
+    const ba_state* st = reinterpret_cast<const ba_state*>(pub + (size_t)b * pub_bytes);      // (vo_internal.h: shared with vo_ba.hip)
     // nothing observed: the adapter skips the solve and writes x0 back (bundle_adjuster.py would hand scipy an empty problem)
-    const double* x = (P.cnt[C_NOBS] > 0) ? reinterpret_cast<const double*>(pub + (size_t)b * pub_bytes + 64) : x0 + (size_t)b * x_stride;
+    const double* x = (P.cnt[C_NOBS] > 0) ? reinterpret_cast<const double*>(pub + (size_t)b * pub_bytes + VO_BA_PUB_HEADER) : x0 + (size_t)b * x_stride;
     const double* xp = x + 6 * (size_t)Wn;
     // entries that share a landmark row: the reference assigns in list order, the LAST one wins (:197-201)
 #pragma unroll
