@@ -82,6 +82,8 @@ struct ba_ptrs {
   int nset;                           // partial sets (= workgroups of k_ba_build): nblk, or fewer when a workgroup walks several landmark chunks
   int cam_off;                        // k_ba_build: offset (doubles) of the staged cameras inside the dynamic LDS
   int sharded, rank, n_ranks, batch;  // sharded: the batch entries (x the ranks) are landmark shards of one problem
+  const int32_t* n_live; int s_nlive; // optional (closed loop): landmark slots [0, *n_live) of the problem are in use, the workgroups of the rest only zero
+                                      // their partial sums (the tables of vo_pipeline.hip are sized for max_pts landmarks, a scene fills a part of them)
 };
 
 __device__ __forceinline__ double* ba_x(const ba_ptrs& P, int k) { return k ? P.xb : P.xa; }
@@ -94,6 +96,7 @@ __device__ __forceinline__ ba_ptrs ba_select(ba_ptrs P, int b) {
   P.dp += sb * P.s_dp; P.evalpart += sb * P.s_evalpart; P.tilesum += sb * P.s_tilesum; P.posesum += sb * P.s_posesum; P.cams += sb * P.s_cams;
   P.xstat += sb * BA_EVAL_VALS;
   P.state += 2 * sb; P.info += sb;
+  if (P.n_live) P.n_live += sb * P.s_nlive;
   if (b != 0) P.dbg = nullptr;
   return P;
 }
@@ -138,6 +141,7 @@ struct vo_ba_ws {
   double* d_x0_own = nullptr; double* d_obs_own = nullptr;
   double* d_bank_x0 = nullptr; double* d_bank_obs = nullptr;
   int bank_n = 0, bank_sel = 0;
+  const int32_t* d_nlive = nullptr; int nlive_stride = 0;     // vo_ba_set_live
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -455,9 +459,18 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   // kernel's 58 us) and k_ba_reduce reads them all back.
   int seed_x = (it == 0) ? 1 : 0;                  // (opaque, so that the chunk loop is not versioned on it)
   asm volatile("" : "+v"(seed_x));
+  const int n_live = P.n_live ? *P.n_live : N;
 #pragma unroll 1
   for (int chunk = blockIdx.x; chunk < P.nblk; chunk += gridDim.x) {
   const bool later = chunk != (int)blockIdx.x;
+  if (chunk * P.PPB >= n_live) {                   // (uniform) no landmark of this chunk -- nor of the later ones -- is in use
+    if (!later) {
+      for (int t = tid; t < W * BA_POSE_VALS; t += TPB) P.posepart[(size_t)blockIdx.x * W * BA_POSE_VALS + t] = 0.0;
+      for (int t = tid; t < P.n_tiles * 256; t += TPB) P.tiles[(size_t)blockIdx.x * P.n_tiles * 256 + t] = 0.0;
+      if (tid == 0) P.gmax[blockIdx.x] = 0.0;
+    }
+    break;
+  }
   const int j = chunk * P.PPB + pl;
   double X[3] = {0, 0, 0};
   double uo = __builtin_nan(""), vo = 0;
@@ -1062,6 +1075,10 @@ __global__ void __launch_bounds__(TPB) k_ba_update(ba_ptrs Pall, ba_params_dev p
   const ba_state st = P.state[it & 1];
   if (st.done) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, W = P.W, N = P.N, LPP = LPPC ? LPPC : P.LPP;
+  if (P.n_live && blockIdx.x > 0 && (int)blockIdx.x * P.PPB >= *P.n_live) {     // an unused part of the table (workgroup 0 carries the trial poses)
+    if (tid < BA_EVAL_VALS) P.evalpart[blockIdx.x * BA_EVAL_VALS + tid] = 0.0;
+    return;
+  }
   const double* poses = ba_x(P, st.cur);
   const double* pts = poses + 6 * W;
   double* tposes = ba_x(P, st.cur ^ 1);
@@ -1243,7 +1260,10 @@ static void ba_geometry(vo_ba_ws* b, int W, int N) {
   if (const char* e = getenv("VO_BA_LPP8")) { if (atoi(e) == 0 && b->LPP == 8) b->LPP = 16; }      // A/B knob
   // workgroup size: 256 lanes (more workgroups -> more CUs, less contention on the f64 pipes) unless that would
   // produce more than 160 partial sets, then 1024
-  b->tpb = (vo_div_up(N, 256 / b->LPP) <= 160) ? 256 : 1024;
+  // (8-lane groups -- windows of <= 8 slots -- keep 256 lanes whatever N: with 1 024-lane workgroups they fell back to 16 lanes per landmark,
+  //  three quarters of them idle at the reference's window of 4; the chunk walk of k_ba_build bounds the partial sets instead.  Measured on the
+  //  closed loop's 8 192-slot tables: k_ba_build 78 us -> see DESIGN section 4)
+  b->tpb = (b->LPP == 8 || vo_div_up(N, 256 / b->LPP) <= 160) ? 256 : 1024;
   if (const char* e = getenv("VO_BA_TPB")) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) b->tpb = t; }   // experiment knob
   if (b->LPP == 8 && b->tpb != 256) { b->LPP = 16; b->tpb = (vo_div_up(N, 256 / b->LPP) <= 160) ? 256 : 1024; }          // (8-lane groups exist for 256-lane workgroups only)
   b->PPB = b->tpb / b->LPP;
@@ -1350,6 +1370,7 @@ extern "C" int32_t vo_ba_upload_bank(vo_ctx* c, const double* K, const double* p
   b->d_x0_own = b->d_x0; b->d_obs_own = b->d_obs;
   b->d_x0 = b->d_bank_x0; b->d_obs = b->d_bank_obs;
   b->bank_n = n_problems; b->bank_sel = 0;
+  b->d_nlive = nullptr; b->nlive_stride = 0;      // a dense uploaded problem: every slot counts
   b->uploaded = true;
   return VO_OK;
 }
@@ -1396,7 +1417,14 @@ static ba_ptrs ba_make_ptrs(const vo_ctx* c) {
   P.s_evalpart = (size_t)b->nblk * BA_EVAL_VALS; P.s_tilesum = b->red_stride; P.s_posesum = b->red_stride;
   P.s_cams = 2 * W * BA_CAM;
   P.sharded = c->ba_sharded; P.rank = c->comm_rank; P.n_ranks = c->comm_ranks; P.batch = c->batch;
+  P.n_live = b->d_nlive; P.s_nlive = b->nlive_stride;
   return P;
+}
+
+// closed loop: counts[b * stride] landmark slots of problem b are in use (device memory, read by every launch; null: all N)
+void vo_ba_set_live(vo_ctx* c, const int32_t* d_counts, int stride) {
+  if (!c->ba) return;
+  c->ba->d_nlive = d_counts; c->ba->nlive_stride = stride;
 }
 static ba_ptrs ba_make_ptrs_dbg(vo_ctx* c) { ba_ptrs P = ba_make_ptrs(c); P.dbg = c->d_dbg; return P; }
 
@@ -1426,6 +1454,7 @@ extern "C" int32_t vo_ba_upload(vo_ctx* c, const double* K, const double* poses,
   VO_HIP(c, hipMemcpy2DAsync(b->d_x0, sizeof(double) * nx, poses, sizeof(double) * 6 * W, sizeof(double) * 6 * W, B, hipMemcpyHostToDevice, c->stream));
   VO_HIP(c, hipMemcpy2DAsync(b->d_x0 + 6 * W, sizeof(double) * nx, points, sizeof(double) * 3 * N, sizeof(double) * 3 * N, B, hipMemcpyHostToDevice, c->stream));
   VO_HIP(c, hipStreamSynchronize(c->stream));
+  b->d_nlive = nullptr; b->nlive_stride = 0;      // a dense uploaded problem: every slot counts
   b->uploaded = true;
   return VO_OK;
 }

@@ -226,6 +226,7 @@ static_assert(sizeof(ba_state) <= VO_BA_PUB_HEADER, "the publish buffer's header
 struct vo_ba_view { double* x0; double* obs; const uint8_t* pub; size_t pub_bytes; size_t x_stride; size_t obs_stride; int W, N; };
 int32_t vo_ba_reserve(vo_ctx* c, const double* K_host, int W, int N);
 int32_t vo_ba_get_view(vo_ctx* c, vo_ba_view* v);
+void vo_ba_set_live(vo_ctx* c, const int32_t* d_counts, int stride);   // landmark slots in use per problem (device counters), or null
 int32_t vo_ba_enqueue_budget(vo_ctx* c, const vo_ba_params* prm, int it0, int n_it);   // iterations it0 .. it0 + n_it - 1, then publish
 // 3D-2D pose: correspondences written on the device, counts[b] of them per sequence
 struct vo_pnp_view { float* X; float* uv; const uint8_t* mask; const double* out; const int32_t* ctrl; size_t ctrl_stride; int cap; };

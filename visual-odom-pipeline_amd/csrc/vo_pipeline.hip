@@ -1034,6 +1034,7 @@ void vo_pipe_destroy(vo_ctx* c) {
   if (w->ev_track) (void)hipEventDestroy(w->ev_track);
   delete w;
   c->pipe = nullptr;
+  vo_ba_set_live(c, nullptr, 0);       // (the counters the bundle adjustment looked at are gone)
 }
 
 extern "C" int32_t vo_pipe_default_params(vo_pipe_params* p) {
@@ -1117,6 +1118,8 @@ static int32_t pipe_create(vo_ctx* c, const double* K, const vo_pipe_params* prm
   VO_HIP(c, hipStreamSynchronize(c->stream));
   int32_t r = vo_ba_reserve(c, K, prm->ba_window, w->N);
   if (r != VO_OK) return r;
+  // (the adjustment walks the landmark slots in use, not the table: pipe_step names the counters before every enqueue -- an uploaded
+  //  problem, vo_ba_upload*, forgets them)
   r = vo_pnp_reserve(c, K);
   if (r != VO_OK) return r;
   r = vo_st_prepare(c, &w->prm.st);
@@ -1400,7 +1403,7 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
     r = (stages & VO_PIPE_DETECT) ? vo_shi_tomasi_resident_counts(c, w->N, prm.mask_radius, &prm.st, w->d_dn + DN_PTS * B, w->d_dn + DN_ROOM * B) : VO_OK;
     if (r == VO_OK) pipe_launch_spawn(c, (stages & VO_PIPE_DETECT) ? 1 : 0, (stages & VO_PIPE_KEEP_FREE_LISTS) ? 0 : 1);
     c->stream = main_stream;
-    if (r == VO_OK && (stages & VO_PIPE_ADJUST)) r = vo_ba_enqueue_budget(c, &prm.ba, 0, prm.ba_budget);
+    if (r == VO_OK && (stages & VO_PIPE_ADJUST)) { vo_ba_set_live(c, (const int32_t*)w->tab[VO_PIPE_COUNTS] + C_NLM, PIPE_NCNT); r = vo_ba_enqueue_budget(c, &prm.ba, 0, prm.ba_budget); }
     if (r == VO_OK) PIPE_DISPATCH(k_pipe_writeback, P, (stages & VO_PIPE_ADJUST) ? 1 : 0, bv.pub, bv.pub_bytes, bv.x0, bv.x_stride, bv.W, w->d_rec);
     const hipError_t e1 = hipEventRecord(c->ev_join, c->stream2);
     const hipError_t e2 = hipStreamWaitEvent(c->stream, c->ev_join, 0);     // joined on every path: nothing is left running on the side stream
@@ -1408,6 +1411,7 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
     VO_HIP(c, e1); VO_HIP(c, e2);
   } else {
     if (stages & VO_PIPE_ADJUST) {
+      vo_ba_set_live(c, (const int32_t*)w->tab[VO_PIPE_COUNTS] + C_NLM, PIPE_NCNT);
       r = vo_ba_enqueue_budget(c, &prm.ba, 0, prm.ba_budget);
       if (r != VO_OK) return r;
     }
