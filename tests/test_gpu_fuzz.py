@@ -202,7 +202,9 @@ def test_sharded_ba_fuzz(V, N, W, seed, vis):
     assert sum(x["n_obs"] for x in st2) == st0["n_obs"]
     assert (st2[0]["iters"], st2[0]["accepted"], st2[0]["status"]) == (st0["iters"], st0["accepted"], st0["status"])
     assert abs(st2[0]["cost"] - st0["cost"]) <= 1e-9 * st0["cost"] + 1e-14
-    assert np.abs(np.asarray(po2)[0] - po).max() <= 1e-7 and np.abs(pts - pt).max() <= 1e-7
+    # (points relative to the scene's extent -- coordinates reach 60: a two-frame window leaves depths weakly determined, and the shards' partial
+    #  sums are added in another order; found at VO_FUZZ_EXAMPLES=1500: V=6, N=696, W=2, seed=471 differs by 4.4e-7 at equal iterations and cost)
+    assert np.abs(np.asarray(po2)[0] - po).max() <= 1e-7 and np.abs(pts - pt).max() <= 1e-7 * max(1.0, np.abs(pt).max())
 
 
 @settings(**dict(FUZZ, max_examples=max(6, FUZZ["max_examples"] // 6)))

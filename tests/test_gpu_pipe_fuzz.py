@@ -78,7 +78,7 @@ def _same(model, rp, what, p_tol=1e-9):
     assert classes(list(r["lm_k"]) + list(r["dead_k"])) == classes(model.lm_K + model.dead_K), what          # keypoint rows
 
 
-@pytest.mark.parametrize("cap", [64, 1024, 1100, 2500])
+@pytest.mark.parametrize("cap", [64, 1024, 1100, 2500, 5000, 8192])      # 1 / 2 / 4 / 8 entries per thread (above 4 096: row words in global scratch)
 def test_random_states_stage_by_stage(cap):
     import pipe_oracle as po
     from vo_mi355x import VoContext
@@ -86,7 +86,7 @@ def test_random_states_stage_by_stage(cap):
     rng = np.random.default_rng(1000 + cap)
     sc = ph.scene(3, w=W_IMG, h=H_IMG, f=260.0, seed=5, pose_fn=lambda t: ph.sway_pose(t, period=24.0))
     ca, cb = VoContext(W_IMG, H_IMG, max_pts=cap), VoContext(W_IMG, H_IMG, max_pts=cap)
-    for trial in range(14 if cap <= 64 else 6 if cap < 2000 else 3):
+    for trial in range(14 if cap <= 64 else 6 if cap < 2000 else 3 if cap < 4096 else 2):
         full = trial % 3 == 2
         n_l = int(rng.integers(0, cap // 2)) if not full else cap // 2
         n_c = int(rng.integers(0, cap // 3)) if not full else cap - n_l          # the lists fill the table exactly
