@@ -692,12 +692,13 @@ __device__ __forceinline__ void st_sort_dispatch(const unsigned long long* __res
   }
 }
 
+template <int cap>       // entries the LDS structures hold: a template parameter so that the LDS offsets stay instruction immediates
 __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restrict__ cand,
                                                     uint32_t* __restrict__ scalars, int W, int H, int cell, int gw, int gh,
                                                     double md2, int use_dist, int max_corners, float* __restrict__ out,
                                                     size_t slab_seq, unsigned long long* __restrict__ dbg,
                                                     const float* __restrict__ blockmax, int n_blockmax, double quality,
-                                                    uint32_t* __restrict__ nraw, const int32_t* __restrict__ limit_dev, int cap) {
+                                                    uint32_t* __restrict__ nraw, const int32_t* __restrict__ limit_dev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cand += (size_t)blockIdx.x * ST_CAND_STRIDE;          // one workgroup per sequence
   scalars = vo_seq(scalars, slab_seq, blockIdx.x); out = vo_seq(out, slab_seq, blockIdx.x);
@@ -1037,7 +1038,9 @@ static int32_t st_init(vo_ctx* c) {
   VO_HIP(c, hipMalloc((void**)&s->d_blockmax, sizeof(float) * (size_t)s->n_blockmax * B));
   s->d_out = vo_slab<float>(c, c->off_st_out);
   VO_HIP(c, hipMalloc((void**)&s->d_pts, sizeof(float) * 2 * (size_t)c->max_pts * B));
-  VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_st_select), hipFuncAttributeMaxDynamicSharedMemorySize,
+  VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_st_select<ST_CAP_CLOSED_LOOP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)st_sel_lds(ST_CAP_CLOSED_LOOP)));
+  VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_st_select<ST_CAND_CAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)ST_SEL_LDS));
   return VO_OK;
 }
@@ -1156,10 +1159,14 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
   while (((W + cell - 1) / cell) * ((H + cell - 1) / cell) > ST_MAX_CELLS) cell++;
   const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
   const double md2 = prm->min_distance * prm->min_distance;
-  const int sel_cap = limit_dev ? ST_CAP_CLOSED_LOOP : ST_CAND_CAP;
-  hipLaunchKernelGGL(k_st_select, dim3(B), dim3(1024), st_sel_lds(sel_cap), c->stream, s->d_cand,
-                     s->d_scalars, W, H, cell, gw, gh, md2, use_dist, prm->max_corners, s->d_out, c->slab_seq, c->d_dbg,
-                     s->d_blockmax, n_blockmax, prm->quality_level, s->d_nraw, limit_dev, sel_cap);
+  if (limit_dev)
+    hipLaunchKernelGGL(k_st_select<ST_CAP_CLOSED_LOOP>, dim3(B), dim3(1024), st_sel_lds(ST_CAP_CLOSED_LOOP), c->stream, s->d_cand,
+                       s->d_scalars, W, H, cell, gw, gh, md2, use_dist, prm->max_corners, s->d_out, c->slab_seq, c->d_dbg,
+                       s->d_blockmax, n_blockmax, prm->quality_level, s->d_nraw, limit_dev);
+  else
+    hipLaunchKernelGGL(k_st_select<ST_CAND_CAP>, dim3(B), dim3(1024), st_sel_lds(ST_CAND_CAP), c->stream, s->d_cand,
+                       s->d_scalars, W, H, cell, gw, gh, md2, use_dist, prm->max_corners, s->d_out, c->slab_seq, c->d_dbg,
+                       s->d_blockmax, n_blockmax, prm->quality_level, s->d_nraw, limit_dev);
   VO_HIP(c, hipGetLastError());
   s->last_max_corners = prm->max_corners;
   return VO_OK;
