@@ -239,34 +239,54 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
   __syncthreads();                                   // every thread has read the counters before thread 0 rewrites them
 
   // ---- trip 2: the lists and the tracked positions ----
-  int L[CH], K[CH], KC[CH];
-  bool keep[CH], die[CH], ksh[CH], keepc[CH];
-  float2 q[CH], qc[CH];
+  // LATE (CH >= 4): the landmark positions -- 6 CH registers that only the copies of dead landmarks and the PnP input at the very end need -- are
+  // fetched there instead.  SPLIT (CH = 8): the candidates' half also fetches its own fields and finishes before the landmarks' row fields are
+  // requested (one dependent trip more, half the registers at the peak).  With everything prefetched the CH = 8 kernel kept 380 bytes per
+  // lane in scratch (a lane of a 1 024-lane workgroup has 128 registers) and took 123 us in a batch of 32.
+  constexpr bool LATE = CH >= 4, SPLIT = CH >= 8;
+  constexpr int CE = LATE ? 1 : CH, CS = SPLIT ? 1 : CH;
+  int L[CH], K[CH], KC[CS];
+  bool keep[CH], die[CH], ksh[CH], keepc[CS];
+  float2 q[CH], qc[CS];
 #pragma unroll
   for (int c = 0; c < CH; c++) {
     const int j = tid * CH + c;
-    L[c] = 0; K[c] = 0; KC[c] = 0; keep[c] = die[c] = ksh[c] = keepc[c] = false;
-    q[c] = qc[c] = make_float2(0.f, 0.f);
+    L[c] = 0; K[c] = 0; keep[c] = die[c] = ksh[c] = false;
+    q[c] = make_float2(0.f, 0.f);
     if ((which & 2) && j < nl) {
       L[c] = P.lm_L[j]; K[c] = P.lm_K[j]; ksh[c] = P.lm_ksh[j] != 0; q[c] = p1[j];
       keep[c] = pipe_inside(q[c], W, H); die[c] = !keep[c];
       keep_out[(size_t)b * pnp_cap + j] = keep[c] ? 1 : 0;      // which landmark entries survived (vo_pipe_inliers_read until the POSE stage overwrites it)
     }
-    if ((which & 1) && j < nc) { KC[c] = P.cand[j]; qc[c] = p1[nl + j]; keepc[c] = pipe_inside(qc[c], W, H); }
+    if (!SPLIT) {
+      KC[c] = 0; keepc[c] = false; qc[c] = make_float2(0.f, 0.f);
+      if ((which & 1) && j < nc) { KC[c] = P.cand[j]; qc[c] = p1[nl + j]; keepc[c] = pipe_inside(qc[c], W, H); }
+    }
   }
   // ---- trip 3: every row field the phases below need, and the heads of the free lists ----
-  int len[CH], tt[CH], tl[CH], lenc[CH], ttc[CH];
-  double lp[CH][3];
+  int len[CH], tt[CH], tl[CH], lenc[CS], ttc[CS];
+  double lp[CE][3];
+  auto lm_fields = [&]() {
 #pragma unroll
-  for (int c = 0; c < CH; c++) {
-    const int j = tid * CH + c;
-    len[c] = tt[c] = tl[c] = lenc[c] = ttc[c] = 0; lp[c][0] = lp[c][1] = lp[c][2] = 0.0;
-    if ((which & 2) && j < nl) {
-      len[c] = P.k_len[K[c]]; tt[c] = P.k_tt[K[c]]; tl[c] = P.l_tl[L[c]];
-      for (int k = 0; k < 3; k++) lp[c][k] = P.l_p[3 * (size_t)L[c] + k];
-      row_st(L[c], 0);                               // (entries that share a row all write 0)
+    for (int c = 0; c < CH; c++) {
+      const int j = tid * CH + c;
+      len[c] = tt[c] = tl[c] = 0;
+      if (!LATE) lp[c][0] = lp[c][1] = lp[c][2] = 0.0;
+      if ((which & 2) && j < nl) {
+        len[c] = P.k_len[K[c]]; tt[c] = P.k_tt[K[c]]; tl[c] = P.l_tl[L[c]];
+        if (!LATE) for (int k = 0; k < 3; k++) lp[c][k] = P.l_p[3 * (size_t)L[c] + k];
+        row_st(L[c], 0);                             // (entries that share a row all write 0)
+      }
     }
-    if ((which & 1) && j < nc) { lenc[c] = P.k_len[KC[c]]; ttc[c] = P.k_tt[KC[c]]; }
+  };
+  if (!SPLIT) {
+    lm_fields();
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      const int j = tid * CH + c;
+      lenc[c] = ttc[c] = 0;
+      if ((which & 1) && j < nc) { lenc[c] = P.k_len[KC[c]]; ttc[c] = P.k_tt[KC[c]]; }
+    }
   }
   for (int i = tid; i < P.N; i += PIPE_TPB) {        // no phase takes more than N rows of either kind
     s_fk[i] = (headK + i < nfK) ? P.freeK[headK + i] : -1;
@@ -275,19 +295,43 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
   __syncthreads();
 
   // ---- candidates (extend_tracks): survivors get uv, t_total + 1, a history entry; ordered compaction ----
-  if (which & 1) {
+  auto cand_half = [&](const int (&kc)[CH], const float2 (&pc)[CH], const bool (&kp)[CH], const int (&ln)[CH], const int (&ttk)[CH]) {
     int rank[CH];
-    const int n_out = pipe_rank<CH>(keepc, rank, s_w);
+    const int n_out = pipe_rank<CH>(kp, rank, s_w);
 #pragma unroll
     for (int c = 0; c < CH; c++)
-      if (keepc[c]) {
-        const int k = KC[c];
-        P.k_uv[k] = qc[c]; P.k_tt[k] = ttc[c] + 1; pipe_hist_slot(P, lenc[c])[k] = qc[c]; P.k_len[k] = lenc[c] + 1;
+      if (kp[c]) {
+        const int k = kc[c];
+        P.k_uv[k] = pc[c]; P.k_tt[k] = ttk[c] + 1; pipe_hist_slot(P, ln[c])[k] = pc[c]; P.k_len[k] = ln[c] + 1;
         P.cand[rank[c]] = k;
       }
     if (tid == 0) { P.cnt[C_NCAND] = n_out; P.cnt[C_NKLT] = nl + nc; }
+  };
+  if (which & 1) {
+    if constexpr (SPLIT) {
+      int kc[CH], ln[CH], ttk[CH]; float2 pc[CH]; bool kp[CH];
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const int j = tid * CH + c;
+        kc[c] = 0; kp[c] = false; pc[c] = make_float2(0.f, 0.f);
+        if (j < nc) { kc[c] = P.cand[j]; pc[c] = p1[nl + j]; kp[c] = pipe_inside(pc[c], W, H); }
+      }
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const int j = tid * CH + c;
+        ln[c] = ttk[c] = 0;
+        if (j < nc) { ln[c] = P.k_len[kc[c]]; ttk[c] = P.k_tt[kc[c]]; }
+      }
+      cand_half(kc, pc, kp, ln, ttk);
+    } else {
+      cand_half(KC, qc, keepc, lenc, ttc);
+    }
   }
   if (!(which & 2)) return;                          // (uniform)
+  if constexpr (SPLIT) {
+    lm_fields();
+    __syncthreads();                                 // the row words are cleared before the survivors count into them
+  }
 
   // ---- landmarks: survivors update their keypoint row IN PLACE (extractor.py:80-83: the deepcopy comes after) and count into their
   //      landmark row's word -- several entries may share a landmark object, which then advances by as many frames ----
@@ -344,7 +388,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
       if (lead[c]) {
         const int nlr = s_fl[lrank[c]];
         P.l_tl[nlr] = tlf[c];
-        for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = lp[c][k];
+        for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = LATE ? P.l_p[3 * (size_t)L[c] + k] : lp[LATE ? 0 : c][k];
         row_st(L[c], nlr);
       }
     __syncthreads();
@@ -383,7 +427,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_extend(pipe_ptrs Pall, const 
         const int o = rank[c];
         P.lm_L[o] = L[c]; P.lm_K[o] = K[c]; P.lm_ksh[o] = 0;
         pnp_uv[2 * o] = q[c].x; pnp_uv[2 * o + 1] = q[c].y;
-        for (int k = 0; k < 3; k++) pnp_X[3 * o + k] = (float)lp[c][k];
+        for (int k = 0; k < 3; k++) pnp_X[3 * o + k] = (float)(LATE ? P.l_p[3 * (size_t)L[c] + k] : lp[LATE ? 0 : c][k]);
       }
     if (tid == 0) {
       P.cnt[C_NLM] = n_out; P.cnt[C_NPNP] = n_out;
@@ -437,14 +481,17 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_prune(pipe_ptrs Pall, int do_
     if (do_tri && j < nc) KC[c] = P.cand[j];
   }
   // ---- trip 3: row fields, free-list heads ----
+  constexpr bool LATE = CH >= 8;                       // (as in k_pipe_extend: 224 bytes of scratch per lane at CH = 8 with the positions prefetched)
+  constexpr int CE = LATE ? 1 : CH;
   int tlo[CH], ttc[CH], tfc[CH];
-  double lp[CH][3];
+  double lp[CE][3];
   float2 fst[CH], cur[CH];
 #pragma unroll
   for (int c = 0; c < CH; c++) {
     const int j = tid * CH + c;
-    tlo[c] = ttc[c] = tfc[c] = 0; lp[c][0] = lp[c][1] = lp[c][2] = 0.0; fst[c] = cur[c] = make_float2(0.f, 0.f);
-    if (out[c]) { tlo[c] = P.l_tl[L[c]]; for (int k = 0; k < 3; k++) lp[c][k] = P.l_p[3 * (size_t)L[c] + k]; }
+    tlo[c] = ttc[c] = tfc[c] = 0; fst[c] = cur[c] = make_float2(0.f, 0.f);
+    if (!LATE) lp[c][0] = lp[c][1] = lp[c][2] = 0.0;
+    if (out[c]) { tlo[c] = P.l_tl[L[c]]; if (!LATE) for (int k = 0; k < 3; k++) lp[c][k] = P.l_p[3 * (size_t)L[c] + k]; }
     if (do_tri && j < nc) { ttc[c] = P.k_tt[KC[c]]; tfc[c] = P.k_tf[KC[c]]; fst[c] = P.k_first[KC[c]]; cur[c] = P.k_uv[KC[c]]; }
   }
   if (do_pose)
@@ -466,7 +513,7 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_prune(pipe_ptrs Pall, int do_
       if (out[c] && drank[c] < room) {
         const int nlr = s_fl[drank[c]], nk = s_fk[drank[c]];
         P.l_tl[nlr] = tlo[c];
-        for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = lp[c][k];
+        for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = LATE ? P.l_p[3 * (size_t)L[c] + k] : lp[LATE ? 0 : c][k];
         s_src[drank[c]] = K[c];
         P.dead_L[nd0 + drank[c]] = nlr; P.dead_K[nd0 + drank[c]] = nk;
       }
@@ -599,6 +646,57 @@ __device__ __forceinline__ void pipe_set_order(const int* s_any, int* s_order, i
   __syncthreads();
 }
 
+// One entry j of the final lists -> the bundle-adjustment problem (bundle_adjuster.py:153-176: point, observations from the keypoint history;
+// unused slots: zeros / NaN) and the resident point set [landmark keypoints | candidates] of the next frame's tracker.  -> observations written
+__device__ __forceinline__ int pipe_emit_entry(const pipe_ptrs& P, int j, int nl, int nc, int t, int do_adjust, int Wn, int Nba, double* __restrict__ x0,
+                                               double* __restrict__ obs, float2* __restrict__ out, int Kr, int len, int tl, const double (&p3d)[3],
+                                               float2 uvk, float2 cuvj) {
+  int nobs = 0;
+  if (do_adjust && j < Nba) {
+    double* const pts0 = x0 + 6 * (size_t)Wn;
+    if (j < nl) {
+      for (int k = 0; k < 3; k++) pts0[3 * (size_t)j + k] = p3d[k];
+      for (int s = 0; s < Wn; s++) {
+        const int idx = (t - s) - tl + len - 1;                      // k.uv_history[(t_now - s) - l.t_latest + len - 1] (:56-59, :156)
+        double2 v = make_double2(__builtin_nan(""), __builtin_nan(""));
+        if (idx >= 0 && idx <= len - 1 && idx >= len - PIPE_HIST) { const float2 h = pipe_hist_slot(P, idx)[Kr]; v = make_double2((double)h.x, (double)h.y); nobs++; }
+        reinterpret_cast<double2*>(obs)[(size_t)s * Nba + j] = v;
+      }
+    } else {
+      for (int k = 0; k < 3; k++) pts0[3 * (size_t)j + k] = 0.0;
+      for (int s = 0; s < Wn; s++) reinterpret_cast<double2*>(obs)[(size_t)s * Nba + j] = make_double2(__builtin_nan(""), __builtin_nan(""));
+    }
+  }
+  if (j < nl) out[j] = uvk;
+  if (j < nc) out[nl + j] = cuvj;
+  return nobs;
+}
+
+// k_pipe_problem: the last phase of k_pipe_promote for tables above 2 048 slots, one lane per list entry over N / 256 workgroups per sequence
+// (behind k_pipe_promote on the same stream: the lists and counters are final)
+__global__ void __launch_bounds__(256) k_pipe_problem(pipe_ptrs Pall, int do_adjust, int Wn, double* __restrict__ x0, double* __restrict__ obs, size_t x_stride,
+                                                      size_t obs_stride, int Nba, float* __restrict__ pts, size_t pts_seq) {
+  const int b = blockIdx.y;
+  const pipe_ptrs P = pipe_select(Pall, b);
+  if (P.cnt[C_STATUS]) return;
+  const int nl = P.cnt[C_NLM], nc = P.cnt[C_NCAND], t = P.cnt[C_T];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  x0 += (size_t)b * x_stride; obs += (size_t)b * obs_stride;
+  int Kr = 0, len = 0, tl = 0;
+  double p3d[3] = {0.0, 0.0, 0.0};
+  float2 uvk = make_float2(0.f, 0.f), cv = make_float2(0.f, 0.f);
+  if (j < nl) {
+    const int Lr = P.lm_L[j];
+    Kr = P.lm_K[j];
+    len = P.k_len[Kr]; tl = P.l_tl[Lr]; uvk = P.k_uv[Kr];
+    for (int k = 0; k < 3; k++) p3d[k] = P.l_p[3 * (size_t)Lr + k];
+  }
+  if (j < nc) cv = P.k_uv[P.cand[j]];
+  int nobs = (j < P.N) ? pipe_emit_entry(P, j, nl, nc, t, do_adjust, Wn, Nba, x0, obs, reinterpret_cast<float2*>(vo_seq(pts, pts_seq, b)), Kr, len, tl, p3d, uvk, cv) : 0;
+  for (int o = 32; o > 0; o >>= 1) nobs += __shfl_xor(nobs, o);
+  if (do_adjust && nobs && (threadIdx.x & 63) == 0) atomicAdd(&P.cnt[C_NOBS], nobs);
+}
+
 // ================================================================================================
 // k_pipe_promote: triangulation filters + gate + promotion; then the selection half of BundleAdjuster.adjust
 // ================================================================================================
@@ -640,41 +738,65 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
   if (tid < PIPE_HIST) { s_first[tid] = 0x7FFFFFFF; s_gate[tid] = 0; s_any[tid] = 0x7FFFFFFF; }
   __syncthreads();
   // ---- trip 2: lists, candidates of the triangulation, free rows, trajectory ring ----
-  bool kept[CH]; float pt[CH][3]; int age[CH], rk[CH];
-  int DL[CH], DK[CH], eL[CH], eK[CH], cK[CH];
+  // LATE (CH >= 4, tables above 2 048 slots): what a thread holds per entry -- CH of everything -- no longer fits the 128 registers a lane
+  // of a 1 024-lane workgroup gets (CH = 8: 708 bytes of scratch per lane, the kernel 177 us in a batch of 32).  There the fields that
+  // are only needed at the end (position, pixel, history length, t_latest of the existing entries; the triangulated point of a ripe
+  // candidate) are fetched where they are used, one dependent trip later, in blocks of four entries.
+  constexpr bool LATE = CH >= 4;
+  constexpr int CE = LATE ? 1 : CH;                   // entries whose prefetched fields are kept (LATE: none; the arrays shrink to one dummy)
+  bool kept[CH]; float pt[CE][3]; int age[CH], rk[CH];
+  int DL[CH], DK[CH], eL[CE], eK[CE], cK[CH];
 #pragma unroll
   for (int c = 0; c < CH; c++) {
     const int j = tid * CH + c;
-    kept[c] = false; age[c] = 0; rk[c] = 0; pt[c][0] = pt[c][1] = pt[c][2] = 0.f;
-    DL[c] = DK[c] = eL[c] = eK[c] = cK[c] = 0;
+    kept[c] = false; age[c] = 0; rk[c] = 0;
+    if (!LATE) { pt[c][0] = pt[c][1] = pt[c][2] = 0.f; eL[c] = eK[c] = 0; }
+    DL[c] = DK[c] = cK[c] = 0;
     if (j < n_ripe) {
-      const float w4 = X4[(size_t)3 * x4_stride + j];
-      for (int k = 0; k < 3; k++) pt[c][k] = X4[(size_t)k * x4_stride + j] / w4;          // numpy float32 divide (extractor.py:271)
+      if (!LATE) {
+        const float w4 = X4[(size_t)3 * x4_stride + j];
+        for (int k = 0; k < 3; k++) pt[c][k] = X4[(size_t)k * x4_stride + j] / w4;        // numpy float32 divide (extractor.py:271)
+      }
       kept[c] = depth1[j] > 0.0 && reproj[j] < max_err;                                    // triangulate.py:87-111
       age[c] = cam_sel[j]; rk[c] = P.ripe[j];
     }
     if (do_adjust && j < nd0) { DL[c] = P.dead_L[j]; DK[c] = P.dead_K[j]; }
-    if (j < nl0) { eL[c] = P.lm_L[j]; eK[c] = P.lm_K[j]; s_lmL[j] = eL[c]; s_lmK[j] = eK[c]; }
+    if (j < nl0) {
+      const int l = P.lm_L[j], k = P.lm_K[j];
+      s_lmL[j] = l; s_lmK[j] = k;
+      if (!LATE) { eL[c] = l; eK[c] = k; }
+    }
     if (j < nc) cK[c] = P.cand[j];
   }
   for (int i = tid; i < P.N; i += PIPE_TPB) s_fl[i] = (headL0 + i < nfL) ? P.freeL[headL0 + i] : -1;
   for (int i = tid; i < PIPE_HIST * 12; i += PIPE_TPB) s_H[i] = P.H[i];
   // ---- trip 3: row fields ----
-  int dtl[CH], dlen[CH], elen[CH], etl[CH];
-  double ep[CH][3];
-  float2 euv[CH], cuv[CH];
+  int dtl[CH], dlen[CH], elen[CE], etl[CE];
+  double ep[CE][3];
+  float2 euv[CE], cuv[CE];
 #pragma unroll
   for (int c = 0; c < CH; c++) {
     const int j = tid * CH + c;
-    dtl[c] = dlen[c] = elen[c] = etl[c] = 0; ep[c][0] = ep[c][1] = ep[c][2] = 0.0; euv[c] = cuv[c] = make_float2(0.f, 0.f);
+    dtl[c] = dlen[c] = 0;
     if (do_adjust && j < nd0) { dtl[c] = P.l_tl[DL[c]]; dlen[c] = P.k_len[DK[c]]; }
-    if (j < nl0) {
-      elen[c] = P.k_len[eK[c]]; etl[c] = P.l_tl[eL[c]]; euv[c] = P.k_uv[eK[c]];
-      for (int k = 0; k < 3; k++) ep[c][k] = P.l_p[3 * (size_t)eL[c] + k];
+    if (!LATE) {
+      elen[c] = etl[c] = 0; ep[c][0] = ep[c][1] = ep[c][2] = 0.0; euv[c] = cuv[c] = make_float2(0.f, 0.f);
+      if (j < nl0) {
+        elen[c] = P.k_len[eK[c]]; etl[c] = P.l_tl[eL[c]]; euv[c] = P.k_uv[eK[c]];
+        for (int k = 0; k < 3; k++) ep[c][k] = P.l_p[3 * (size_t)eL[c] + k];
+      }
+      if (j < nc) cuv[c] = P.k_uv[cK[c]];
     }
-    if (j < nc) cuv[c] = P.k_uv[cK[c]];
   }
   __syncthreads();
+  // which dead entries lie inside the window (bundle_adjuster.py:132-150): decided here, so that t_latest / history length of the dead
+  // entries are not carried through the triangulation
+  bool win[CH];
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    const int j = tid * CH + c;
+    win[c] = do_adjust && resurrect && j < nd0 && (t - (dtl[c] - (dlen[c] - 1))) < Wn;
+  }
   int n_new = 0, fl_off = 0;
   if (do_tri && n_ripe > 0) {
 #pragma unroll
@@ -687,7 +809,15 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
     pipe_set_order(s_any, s_order, s_tab, s_tmp, &s_norder, t);
 #pragma unroll
     for (int c = 0; c < CH; c++)
-      if (kept[c] && s_first[age[c]] == tid * CH + c) for (int k = 0; k < 3; k++) s_p3[age[c]][k] = (double)pt[c][k];
+      if (kept[c] && s_first[age[c]] == tid * CH + c) {
+        if (LATE) {
+          const int j = tid * CH + c;
+          const float w4 = X4[(size_t)3 * x4_stride + j];
+          for (int k = 0; k < 3; k++) s_p3[age[c]][k] = (double)(X4[(size_t)k * x4_stride + j] / w4);
+        } else {
+          for (int k = 0; k < 3; k++) s_p3[age[c]][k] = (double)pt[c][k];
+        }
+      }
     __syncthreads();
     if (tid < PIPE_HIST && s_first[tid] != 0x7FFFFFFF) {
       // the reference's "bearing angle" of the group's FIRST landmark (extractor.py:231-240): a = Frobenius norm of the 4x4 relative
@@ -738,7 +868,15 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
         if (f[c] && rank[c] < n_take) {
           const int nlr = s_fl[fl_off + rank[c]], o = nl + rank[c];
           P.l_tl[nlr] = t;                                                                   // Landmark(t_curr, p, des) (extractor.py:274-275)
-          for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = (double)pt[c][k];
+          float p3f[3];
+          if (LATE) {
+            const int j = tid * CH + c;
+            const float w4 = X4[(size_t)3 * x4_stride + j];
+            for (int k = 0; k < 3; k++) p3f[k] = X4[(size_t)k * x4_stride + j] / w4;       // numpy float32 divide (extractor.py:271)
+          } else {
+            for (int k = 0; k < 3; k++) p3f[k] = pt[c][k];
+          }
+          for (int k = 0; k < 3; k++) P.l_p[3 * (size_t)nlr + k] = (double)p3f[k];
           s_lmL[o] = nlr; s_lmK[o] = rk[c];
           P.lm_L[o] = nlr; P.lm_K[o] = rk[c]; P.lm_ksh[o] = 0;
         }
@@ -749,13 +887,8 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
   int n_res = 0, nd = nd0, n_inert = 0;
   if (do_adjust) {
     // ---- dead landmarks whose track lies inside the window are appended to the state's lists as the same objects (bundle_adjuster.py:132-150) ----
-    bool win[CH], take[CH], stay[CH];
+    bool take[CH], stay[CH];
     int wr[CH];
-#pragma unroll
-    for (int c = 0; c < CH; c++) {
-      const int j = tid * CH + c;
-      win[c] = resurrect && j < nd0 && (t - (dtl[c] - (dlen[c] - 1))) < Wn;
-    }
     const int n_win = pipe_rank<CH>(win, wr, s_w);
     int room = P.N - nl - nc;
     if (room < 0) room = 0;
@@ -797,43 +930,28 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
     nd = n_take + n_stay; n_inert = nd0 - nd;
   }
   __syncthreads();                                     // the list in LDS and the new landmark rows are complete
-  // ---- trip 4: rows of the entries appended above (the existing ones were fetched in trip 3) ----
-  int Lr[CH], Kr[CH], len[CH], tl[CH];
-  double p3d[CH][3];
-  float2 uvk[CH];
-#pragma unroll
-  for (int c = 0; c < CH; c++) {
-    const int j = tid * CH + c;
-    Lr[c] = eL[c]; Kr[c] = eK[c]; len[c] = elen[c]; tl[c] = etl[c]; uvk[c] = euv[c];
-    for (int k = 0; k < 3; k++) p3d[c][k] = ep[c][k];
-    if (j >= nl0 && j < nl) {
-      Lr[c] = s_lmL[j]; Kr[c] = s_lmK[j];
-      len[c] = P.k_len[Kr[c]]; tl[c] = P.l_tl[Lr[c]]; uvk[c] = P.k_uv[Kr[c]];
-      for (int k = 0; k < 3; k++) p3d[c][k] = P.l_p[3 * (size_t)Lr[c] + k];
-    }
-  }
-  if (do_adjust) {
-    // ---- the bundle-adjustment problem (bundle_adjuster.py:153-176): points, observations from the keypoint histories, window poses ----
-    double* pts0 = x0 + 6 * (size_t)Wn;
-    int nobs = 0;
+  // ---- trip 4: rows of the entries appended above (the existing ones were fetched in trip 3), the bundle-adjustment problem and the
+  //      resident point set of the final lists (pipe_emit_entry; folded in here: one launch less on the frame's critical chain).
+  //      LATE: that bulk work -- 8 entries per lane through ONE compute unit's memory pipes, ~60 us of this kernel at 8 192 slots --
+  //      is left to k_pipe_problem, a launch of N / 256 workgroups per sequence right behind this one ----
+  int nobs = 0;
+  if constexpr (!LATE) {
 #pragma unroll
     for (int c = 0; c < CH; c++) {
       const int j = tid * CH + c;
-      if (j >= Nba) continue;
-      if (j < nl) {
-        const int n = len[c];
-        for (int k = 0; k < 3; k++) pts0[3 * (size_t)j + k] = p3d[c][k];
-        for (int s = 0; s < Wn; s++) {
-          const int idx = (t - s) - tl[c] + n - 1;                   // k.uv_history[(t_now - s) - l.t_latest + len - 1] (:56-59, :156)
-          double2 v = make_double2(__builtin_nan(""), __builtin_nan(""));
-          if (idx >= 0 && idx <= n - 1 && idx >= n - PIPE_HIST) { const float2 h = pipe_hist_slot(P, idx)[Kr[c]]; v = make_double2((double)h.x, (double)h.y); nobs++; }
-          reinterpret_cast<double2*>(obs)[(size_t)s * Nba + j] = v;
-        }
-      } else {
-        for (int k = 0; k < 3; k++) pts0[3 * (size_t)j + k] = 0.0;
-        for (int s = 0; s < Wn; s++) reinterpret_cast<double2*>(obs)[(size_t)s * Nba + j] = make_double2(__builtin_nan(""), __builtin_nan(""));
+      int Kr = eK[c], len = elen[c], tl = etl[c];
+      double p3d[3] = {ep[c][0], ep[c][1], ep[c][2]};
+      float2 uvk = euv[c];
+      if (j >= nl0 && j < nl) {
+        const int Lr = s_lmL[j];
+        Kr = s_lmK[j];
+        len = P.k_len[Kr]; tl = P.l_tl[Lr]; uvk = P.k_uv[Kr];
+        for (int k = 0; k < 3; k++) p3d[k] = P.l_p[3 * (size_t)Lr + k];
       }
+      nobs += pipe_emit_entry(P, j, nl, nc, t, do_adjust, Wn, Nba, x0, obs, reinterpret_cast<float2*>(vo_seq(pts, pts_seq, b)), Kr, len, tl, p3d, uvk, cuv[c]);
     }
+  }
+  if (do_adjust) {
     if (nobs) atomicAdd(&s_nobs, nobs);
     if (tid < Wn) {
       double* po = x0 + 6 * tid;
@@ -846,16 +964,6 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_promote(pipe_ptrs Pall, int d
       } else {
         for (int k = 0; k < 6; k++) po[k] = 0.0;
       }
-    }
-  }
-  // ---- the resident point set of the final lists (what k_pipe_dense writes; folded in here: one launch less on the frame's critical chain) ----
-  {
-    float2* out = reinterpret_cast<float2*>(vo_seq(pts, pts_seq, b));
-#pragma unroll
-    for (int c = 0; c < CH; c++) {
-      const int j = tid * CH + c;
-      if (j < nl) out[j] = uvk[c];
-      if (j < nc) out[nl + j] = cuv[c];
     }
   }
   __syncthreads();                                     // s_nobs
@@ -1392,6 +1500,9 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
     else if (w->N <= 2 * PIPE_TPB) launch(k_pipe_promote<2>);
     else if (w->N <= 4 * PIPE_TPB) launch(k_pipe_promote<4>);
     else launch(k_pipe_promote<8>);
+    if (w->N > 2 * PIPE_TPB)     // (the CH >= 4 kernels leave the problem / point-set phase to a wide launch)
+      hipLaunchKernelGGL(k_pipe_problem, dim3(vo_div_up(w->N, 256), c->batch), dim3(256), 0, c->stream, P, (stages & VO_PIPE_ADJUST) ? 1 : 0, bv.W, bv.x0, bv.obs,
+                         bv.x_stride, bv.obs_stride, bv.N, vo_slab<float>(c, vo_off_p(c)), c->slab_seq);
   }
   else if (halves & 2)   // (after the candidates' half alone the buffer still holds the tracked positions the landmarks' half will read)
     hipLaunchKernelGGL(k_pipe_dense, dim3(B), dim3(PIPE_TPB), 0, c->stream, P, vo_slab<float>(c, vo_off_p(c)), c->slab_seq, 0);
