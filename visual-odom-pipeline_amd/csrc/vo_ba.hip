@@ -460,6 +460,19 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   int seed_x = (it == 0) ? 1 : 0;                  // (opaque, so that the chunk loop is not versioned on it)
   asm volatile("" : "+v"(seed_x));
   const int n_live = P.n_live ? *P.n_live : N;
+  // this lane's landmark and observation of a chunk; the NEXT chunk's are requested before the Gram phase of this one (they were the first
+  // thing a chunk waited for: a full trip to HBM / L2 at the head of every chunk of the walk)
+  double Xn[3] = {0, 0, 0}, uon = __builtin_nan(""), von = 0;
+  auto fetch_obs = [&](const int ch) {
+    const int jn = ch * P.PPB + pl;
+    Xn[0] = Xn[1] = Xn[2] = 0; uon = __builtin_nan(""); von = 0;
+    if (ch < P.nblk && ch * P.PPB < n_live && slot < W && jn < N) {
+      Xn[0] = pts[3 * jn]; Xn[1] = pts[3 * jn + 1]; Xn[2] = pts[3 * jn + 2];
+      const double* ob = P.obs + ((size_t)slot * N + jn) * 2;
+      uon = ob[0]; von = ob[1];
+    }
+  };
+  fetch_obs(blockIdx.x);
 #pragma unroll 1
   for (int chunk = blockIdx.x; chunk < P.nblk; chunk += gridDim.x) {
   const bool later = chunk != (int)blockIdx.x;
@@ -472,13 +485,8 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
     break;
   }
   const int j = chunk * P.PPB + pl;
-  double X[3] = {0, 0, 0};
-  double uo = __builtin_nan(""), vo = 0;
-  if (slot < W && j < N) {
-    X[0] = pts[3 * j]; X[1] = pts[3 * j + 1]; X[2] = pts[3 * j + 2];
-    const double* ob = P.obs + ((size_t)slot * N + j) * 2;
-    uo = ob[0]; vo = ob[1];
-  }
+  const double X[3] = {Xn[0], Xn[1], Xn[2]};
+  const double uo = uon, vo = von;
 
   ba_obs_lin o;
   bool have = false;
@@ -617,6 +625,7 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
     for (int cidx = 6 * W + 1; cidx < P.RP; cidx++) { rw0[cidx] = 0; rw1[cidx] = 0; rw2[cidx] = 0; }
   }
   __syncthreads();
+  fetch_obs(chunk + (int)gridDim.x);
   // ---- Gram matrix of the panel: upper 16x16 tiles, one wave per tile, v_mfma_f64_16x16x4_f64 ----
   //   A[i][k] = panel[k0 + k][16 ta + i]  (lane: i = l & 15, k = l >> 4),  B[k][j] = panel[k0 + k][16 tb + j]
   //   D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
