@@ -82,6 +82,7 @@ struct ba_ptrs {
   int nset;                           // partial sets (= workgroups of k_ba_build): nblk, or fewer when a workgroup walks several landmark chunks
   int cam_off;                        // k_ba_build: offset (doubles) of the staged cameras inside the dynamic LDS
   int sharded, rank, n_ranks, batch;  // sharded: the batch entries (x the ranks) are landmark shards of one problem
+  int fold;                           // the solve sums the partial sets itself, no k_ba_reduce launch (small windows, unsharded: ba_make_ptrs)
   const int32_t* n_live; int s_nlive; // optional (closed loop): landmark slots [0, *n_live) of the problem are in use, the workgroups of the rest only zero
                                       // their partial sums (the tables of vo_pipeline.hip are sized for max_pts landmarks, a scene fills a part of them)
 };
@@ -806,7 +807,22 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
   unsigned long long* dbgs = P.dbg ? P.dbg + 8 : nullptr;
   VO_STAMP(dbgs, 0);
   // ---- reduced camera sums; -E (lower triangle) and +r (row n) from the reduced Gram tiles ----
-  for (int q = tid; q < W * BA_POSE_VALS; q += BA_SOLVE_THREADS) s_hpp[q] = P.posesum[q];
+  // FOLD (P.fold: small windows, one problem per GPU or a batch): the partial sets of k_ba_build are summed right here, every thread the
+  // one or two values it is about to use -- a window of 4 needs 325 Gram entries + 112 camera sums from 32 sets, one trip of 32 loads in
+  // flight --, and the k_ba_reduce launch between build and solve is gone: one kernel boundary less in every LM iteration, and one
+  // early-exit launch less in every group a finished problem still sees.  Fixed order (two interleaved chains over the sets), so a solve
+  // stays bitwise reproducible; the sum differs in the last bits from k_ba_reduce's four-group order.
+  const bool fold = P.fold != 0;
+  auto set_sum = [&](const double* __restrict__ src, const size_t stride) -> double {
+    double s0 = 0, s1 = 0;
+    int bset = 0;
+#pragma unroll 8
+    for (; bset + 1 < P.nset; bset += 2) { s0 += src[(size_t)bset * stride]; s1 += src[(size_t)(bset + 1) * stride]; }
+    if (bset < P.nset) s0 += src[(size_t)bset * stride];
+    return s0 + s1;
+  };
+  const size_t n_tile_el = (size_t)P.n_tiles * 256, n_pose_el = (size_t)W * BA_POSE_VALS;
+  for (int q = tid; q < W * BA_POSE_VALS; q += BA_SOLVE_THREADS) s_hpp[q] = fold ? set_sum(P.posepart + q, n_pose_el) : P.posesum[q];
   for (int e = tid; e < n1 * n1; e += BA_SOLVE_THREADS) {
     const int col = e / n1, row = e - col * n1;       // consecutive threads -> consecutive rows
     if (row < col) continue;
@@ -814,8 +830,14 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
     // element (a = col, b = row), a <= b, lives in upper tile (ta, tb)
     const int ta = col >> 4, tb = row >> 4, ii = col & 15, jj = row & 15;
     const int tile = ta * P.RT - (ta * (ta - 1)) / 2 + (tb - ta);
-    const double v = P.tilesum[(size_t)tile * 256 + ((ii & 3) * 16 + jj) * 4 + (ii >> 2)];
+    const size_t idx = (size_t)tile * 256 + ((ii & 3) * 16 + jj) * 4 + (ii >> 2);
+    const double v = fold ? set_sum(P.tiles + idx, n_tile_el) : P.tilesum[idx];
     A[(size_t)col * PT + row] = (row == n) ? v : -v;
+  }
+  if (fold && tid == BA_SOLVE_THREADS - 1) {           // max |g_l| over the sets (what k_ba_reduce leaves behind the camera sums)
+    double gm = 0;
+    for (int bset = 0; bset < P.nset; bset++) gm = fmax(gm, P.gmax[bset]);
+    s_dp[n + 16] = gm;                                 // (scratch behind dp: entries n .. n + 15 carry the step statistics below)
   }
   __syncthreads();
   VO_STAMP(dbgs, 1);   // partials reduced
@@ -1060,7 +1082,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
     inf.cost_cur = w0[3] + w1[3]; inf.pred_pose = w0[0] + w1[0]; inf.step2_pose = w0[1] + w1[1]; inf.x2_pose = w0[2] + w1[2];
     double gl_max = 0;                       // max |g_l| over all landmarks
     if (P.sharded) { for (int r = 0; r < P.n_ranks; r++) gl_max = fmax(gl_max, P.posesum[W * BA_POSE_VALS + 1 + r]); }
-    else gl_max = P.posesum[W * BA_POSE_VALS];
+    else gl_max = fold ? s_dp[n + 16] : P.posesum[W * BA_POSE_VALS];
     inf.ginf = fmax(fmax(w0[4], w1[4]), gl_max);
     inf.chol_fail = fail; inf.pad = 0;
     *P.info = inf;
@@ -1427,6 +1449,16 @@ static ba_ptrs ba_make_ptrs(const vo_ctx* c) {
   P.s_cams = 2 * W * BA_CAM;
   P.sharded = c->ba_sharded; P.rank = c->comm_rank; P.n_ranks = c->comm_ranks; P.batch = c->batch;
   P.n_live = b->d_nlive; P.s_nlive = b->nlive_stride;
+  {
+    // the solve sums the partial sets itself when that is ONE trip per thread (lower triangle of [S rhs] + camera sums <= 1 024 values: windows
+    // of <= 6 slots; <= 64 sets) and no exchange between shards needs the reduced packet; VO_BA_FOLD = 0 / 1 overrides (A/B knob).  Measured
+    // (closed loop, window 4): 32 sequences 33 500 -> 34 600, 96 sequences 41 700 -> 44 100 frames/s; at window 10 (2 171 values from 32 sets,
+    // three trips) the headline LOSES 4 % and one sequence with 125 sets halves -- hence the rule
+    const int n1 = 6 * b->W + 1;
+    const char* e = getenv("VO_BA_FOLD");
+    const bool small = (n1 * (n1 + 1)) / 2 + b->W * BA_POSE_VALS <= BA_SOLVE_THREADS && P.nset <= 64;   // (a thread keeps <= 64 loads in flight)
+    P.fold = (!c->ba_sharded && (e ? atoi(e) != 0 : small)) ? 1 : 0;
+  }
   return P;
 }
 
@@ -1476,7 +1508,7 @@ static int32_t ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& 
   else if (b->tpb == 256) hipLaunchKernelGGL(k_ba_build<256>, dim3(P.nset, B), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
   else if (b->tpb == 512) hipLaunchKernelGGL(k_ba_build<512>, dim3(b->nblk, B), dim3(512), b->build_lds, c->stream, P, prm, it, probe_lambda);
   else hipLaunchKernelGGL(k_ba_build<1024>, dim3(b->nblk, B), dim3(1024), b->build_lds, c->stream, P, prm, it, probe_lambda);
-  hipLaunchKernelGGL(k_ba_reduce, dim3(vo_div_up(b->n_tiles * 256 + b->W * BA_POSE_VALS + 1, 64), B), dim3(256), 0, c->stream, P, it);
+  if (!P.fold) hipLaunchKernelGGL(k_ba_reduce, dim3(vo_div_up(b->n_tiles * 256 + b->W * BA_POSE_VALS + 1, 64), B), dim3(256), 0, c->stream, P, it);
   if (P.sharded) {
     // exchange 1: every shard's reduced packet -> the sum over all shards of all ranks, in every entry
     hipLaunchKernelGGL(k_ba_xsum, dim3(vo_div_up((int)b->red_stride, 256)), dim3(256), 0, c->stream, P, it);
