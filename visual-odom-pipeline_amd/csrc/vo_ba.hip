@@ -1451,12 +1451,13 @@ static ba_ptrs ba_make_ptrs(const vo_ctx* c) {
   P.n_live = b->d_nlive; P.s_nlive = b->nlive_stride;
   {
     // the solve sums the partial sets itself when that is ONE trip per thread (lower triangle of [S rhs] + camera sums <= 1 024 values: windows
-    // of <= 6 slots; <= 64 sets) and no exchange between shards needs the reduced packet; VO_BA_FOLD = 0 / 1 overrides (A/B knob).  Measured
-    // (closed loop, window 4): 32 sequences 33 500 -> 34 600, 96 sequences 41 700 -> 44 100 frames/s; at window 10 (2 171 values from 32 sets,
-    // three trips) the headline LOSES 4 % and one sequence with 125 sets halves -- hence the rule
+    // of <= 6 slots; <= 32 sets) and no exchange between shards needs the reduced packet; VO_BA_FOLD = 0 / 1 overrides (A/B knob).  Measured
+    // interleaved on one box (closed loop, window 4): 32 sequences (32 sets) 33 800 -> 35 000 frames/s, 96 sequences (16 sets) 42 200 ->
+    // 42 500; ONE sequence (64 sets) 3 134 -> 3 077: worse, and at window 10 (2 171 values from 32 sets, three trips) the headline loses 4 %
+    // and one sequence with 125 sets halves -- hence the rule
     const int n1 = 6 * b->W + 1;
     const char* e = getenv("VO_BA_FOLD");
-    const bool small = (n1 * (n1 + 1)) / 2 + b->W * BA_POSE_VALS <= BA_SOLVE_THREADS && P.nset <= 64;   // (a thread keeps <= 64 loads in flight)
+    const bool small = (n1 * (n1 + 1)) / 2 + b->W * BA_POSE_VALS <= BA_SOLVE_THREADS && P.nset <= 32;
     P.fold = (!c->ba_sharded && (e ? atoi(e) != 0 : small)) ? 1 : 0;
   }
   return P;
