@@ -296,7 +296,7 @@ int32_t vo_pnp_default_params(vo_pnp_params* p);
 int32_t vo_pnp_ransac(vo_ctx* ctx, const double* K, const float* pts3d, const float* pts2d, int32_t n,
                       const vo_pnp_params* prm, double* rvec, double* tvec, uint8_t* inlier_mask, vo_pnp_stats* stats);
 /* resident form: correspondences uploaded once, a solve enqueued per frame with no host synchronisation (`blind_batches`
- * batches of 256 hypotheses, early-exiting once the iteration bound is reached: 2 cover down to ~37 % inliers), results
+ * batches of 32, then 256 hypotheses each, early-exiting once the iteration bound is reached: 2 cover down to ~42 % inliers), results
  * fetched later; a sequence whose bound was not reached reports status VO_E_CAPACITY (pose = best so far). */
 int32_t vo_pnp_upload(vo_ctx* ctx, const double* K, const float* pts3d, const float* pts2d, int32_t n);
 int32_t vo_pnp_solve_resident(vo_ctx* ctx, const vo_pnp_params* prm, int32_t blind_batches);        /* async */
@@ -397,7 +397,7 @@ typedef struct {
   int32_t min_track_length;   /* 3    pipeline.py:147 */
   int32_t mask_radius;        /* 7    pipeline.py:162 (min_kp_dist) */
   int32_t max_new;            /* 1000 corners appended per frame (maxCorners, extractor.py:21) */
-  int32_t pnp_blind_batches;  /* 4    batches of 256 P3P hypotheses enqueued per frame (they exit early once the RANSAC bound is reached) */
+  int32_t pnp_blind_batches;  /* 4    batches of P3P hypotheses (32, then 256 each) enqueued per frame (they exit early once the RANSAC bound is reached) */
   int32_t ba_budget;          /* LM iterations enqueued per frame, <= ba.max_iters (they exit early once the LM has stopped) */
   int32_t resurrect;          /* 1: as the reference -- adjust appends dead landmarks whose track lies inside the window to the state's lists again
                                  (bundle_adjuster.py:142-150).  With the reference's window of 4 that is a handful per frame;

@@ -14,8 +14,9 @@ This file DEFINES the algorithm the GPU implements (csrc/vo_pnp.hip) so that the
 hypothesis:
   * hypothesis h: 4 distinct indices from a counter-based generator (splitmix64 of (seed, h, draw)); Grunert's P3P on the
     first three (quartic in the depth ratio, Ferrari + Newton polish), the fourth picks among the <= 4 solutions;
-  * hypotheses are scored in batches of `batch`; best = most inliers, ties to the smallest h; after every batch the
-    iteration bound is updated like OpenCV's RANSACUpdateNumIters with model_points = 4;
+  * hypotheses are scored in batches -- `first_batch` (32), then `batch` (256) each --; best = most inliers, ties to the smallest h; after
+    every batch the iteration bound is updated like OpenCV's RANSACUpdateNumIters with model_points = 4 (OpenCV updates it after every
+    hypothesis: the small first batch is the closer restatement where the bound falls to a handful, as in the closed loop);
   * Gauss-Newton (step halving) on (rvec, t) over the consensus set of the best hypothesis.
 """
 import math
@@ -247,7 +248,7 @@ def refine(K, rvec, t, X, uv, iters=20):
     return log_so3(R), tt, c
 
 
-def pnp_ransac(K, X, uv, thr=2.0, conf=0.9999, max_iters=1000000, seed=0, batch=256, return_info=False):
+def pnp_ransac(K, X, uv, thr=2.0, conf=0.9999, max_iters=1000000, seed=0, batch=256, return_info=False, first_batch=32):
     K = np.asarray(K, float); Kinv = np.linalg.inv(K)
     X = np.asarray(X, np.float32).astype(float).reshape(-1, 3); uv = np.asarray(uv, np.float32).astype(float).reshape(-1, 2)
     n = len(X)
@@ -255,7 +256,8 @@ def pnp_ransac(K, X, uv, thr=2.0, conf=0.9999, max_iters=1000000, seed=0, batch=
     best = dict(count=0, h=-1, R=None, t=None)
     niters, h0 = max_iters, 0
     while h0 < niters and n >= 4:
-        for h in range(h0, h0 + batch):
+        nb = first_batch if h0 == 0 else batch
+        for h in range(h0, h0 + nb):
             hyp = hypothesis(K, Kinv, X, uv, sample4(seed, h, n))
             if hyp is None:
                 continue
@@ -263,7 +265,7 @@ def pnp_ransac(K, X, uv, thr=2.0, conf=0.9999, max_iters=1000000, seed=0, batch=
             cnt = int((e2 <= thr2).sum())
             if cnt > best["count"]:
                 best = dict(count=cnt, h=h, R=hyp[0], t=hyp[1])
-        h0 += batch
+        h0 += nb
         if best["count"] > 0:
             niters = min(niters, update_num_iters(conf, (n - best["count"]) / n, 4, max_iters))
     if best["count"] < 4:

@@ -20,6 +20,12 @@
 #include <string.h>
 
 #define PNP_BATCH 256
+#ifndef PNP_FIRST_BATCH
+#define PNP_FIRST_BATCH 32   // hypotheses of the FIRST batch of a search (oracle/pnp_oracle.py: first_batch).  OpenCV re-evaluates its iteration
+                             // bound after every hypothesis -- at the closed loop's ~98 % inliers and 0.9999 confidence it stops after 4 --, so a
+                             // small first batch is closer to the reference AND cheaper: scoring 256 hypotheses x 2 000 points was 35 of the 59 us
+                             // a frame's first batch took in a batch of 32 sequences, all but the first handful for nothing
+#endif
 
 struct pnp_hyp { double R[9]; double t[3]; int count; int h; };
 struct pnp_ctrl { int niters; int h_done; int done; int pad; pnp_hyp best; };
@@ -268,8 +274,9 @@ __device__ inline void pnp_inv3(const double* K, double* Ki) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_pnp_solve(const double* __restrict__ Kall, const float* __restrict__ Xall, const float* __restrict__ uvall,
                                                   int cap, int n, unsigned seed, pnp_hyp* __restrict__ hyps, const pnp_ctrl* __restrict__ ctrl,
-                                                  const int32_t* __restrict__ counts, int first) {
+                                                  const int32_t* __restrict__ counts, int first, int nb) {
   const int b = blockIdx.y, slot = blockIdx.x * 64 + threadIdx.x;
+  if (slot >= nb) return;                                   // nb: hypotheses of this batch
   if (counts) n = counts[b];
   // first = 1: the first batch of a search -- the control block is taken as freshly initialised (k_pnp_select of this batch writes it),
   // which saves the closed loop the k_pnp_init launch in front of every frame's search
@@ -340,7 +347,7 @@ __device__ inline void pnp_ctrl_reset(pnp_ctrl* c, int max_iters) {
 }
 
 __global__ void __launch_bounds__(PNP_BATCH) k_pnp_select(const pnp_hyp* __restrict__ hyps, pnp_ctrl* __restrict__ ctrl, int n, double conf,
-                                                          int max_iters, const int32_t* __restrict__ counts, int first) {
+                                                          int max_iters, const int32_t* __restrict__ counts, int first, int nb) {
   __shared__ int s_cnt[PNP_BATCH];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (counts) n = counts[b];
@@ -348,14 +355,14 @@ __global__ void __launch_bounds__(PNP_BATCH) k_pnp_select(const pnp_hyp* __restr
   if (!first && c->done) return;
   if (n < 4) { if (tid == 0) { if (first) pnp_ctrl_reset(c, max_iters); c->done = 1; } return; }
   const pnp_hyp* H = hyps + (size_t)b * PNP_BATCH;
-  s_cnt[tid] = H[tid].count;
+  s_cnt[tid] = tid < nb ? H[tid].count : -1;
   __syncthreads();
   if (tid == 0) {
     if (first) pnp_ctrl_reset(c, max_iters);               // (see k_pnp_solve)
     int bi = -1, bc = c->best.count;
-    for (int i = 0; i < PNP_BATCH; i++) if (s_cnt[i] > bc) { bc = s_cnt[i]; bi = i; }    // batch order = ascending h
+    for (int i = 0; i < nb; i++) if (s_cnt[i] > bc) { bc = s_cnt[i]; bi = i; }    // batch order = ascending h
     if (bi >= 0) c->best = H[bi];
-    c->h_done += PNP_BATCH;
+    c->h_done += nb;
     if (c->best.count > 0) {
       const int ni = pnp_update_iters(conf, (double)(n - c->best.count) / (double)n, 4, max_iters);
       if (ni < c->niters) c->niters = ni;
@@ -741,14 +748,16 @@ static int32_t pnp_alloc(vo_ctx* c, int n) {
   return VO_OK;
 }
 
-static void pnp_enqueue_batch(vo_ctx* c, const vo_pnp_params* prm, const int32_t* counts = nullptr, int first = 0) {
+// k: index of the batch within its search (0: the small first batch); first: the control block is reset by this batch's own kernels
+static void pnp_enqueue_batch(vo_ctx* c, const vo_pnp_params* prm, int k, const int32_t* counts = nullptr, int first = 0) {
   vo_pnp_ws* w = c->pnp;
   const unsigned B = (unsigned)c->batch;
   const double thr2 = prm->reproj_err * prm->reproj_err;
-  hipLaunchKernelGGL(k_pnp_solve, dim3(PNP_BATCH / 64, B), dim3(64), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n, (unsigned)prm->seed,
-                     w->d_hyp, w->d_ctrl, counts, first);
-  hipLaunchKernelGGL(k_pnp_score, dim3(PNP_BATCH, B), dim3(64), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n, thr2, w->d_hyp, counts);
-  hipLaunchKernelGGL(k_pnp_select, dim3(B), dim3(PNP_BATCH), 0, c->stream, w->d_hyp, w->d_ctrl, w->n, prm->confidence, prm->max_iters, counts, first);
+  const int nb = k == 0 ? PNP_FIRST_BATCH : PNP_BATCH;
+  hipLaunchKernelGGL(k_pnp_solve, dim3((nb + 63) / 64, B), dim3(64), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n, (unsigned)prm->seed,
+                     w->d_hyp, w->d_ctrl, counts, first, nb);
+  hipLaunchKernelGGL(k_pnp_score, dim3(nb, B), dim3(64), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n, thr2, w->d_hyp, counts);
+  hipLaunchKernelGGL(k_pnp_select, dim3(B), dim3(PNP_BATCH), 0, c->stream, w->d_hyp, w->d_ctrl, w->n, prm->confidence, prm->max_iters, counts, first, nb);
 }
 
 static int32_t pnp_enqueue_refine(vo_ctx* c, const vo_pnp_params* prm, const int32_t* counts = nullptr) {
@@ -787,7 +796,7 @@ int32_t vo_pnp_get_view(vo_ctx* c, vo_pnp_view* v) {
 }
 int32_t vo_pnp_enqueue_counts(vo_ctx* c, const vo_pnp_params* prm, int blind_batches, const int32_t* d_counts) {
   VO_CHECK(c, c->pnp, VO_E_STATE, "vo_pnp_reserve first");
-  for (int k = 0; k < blind_batches; k++) pnp_enqueue_batch(c, prm, d_counts, k == 0 ? 1 : 0);     // (blind_batches >= 1: vo_pipe_create)
+  for (int k = 0; k < blind_batches; k++) pnp_enqueue_batch(c, prm, k, d_counts, k == 0 ? 1 : 0);     // (blind_batches >= 1: vo_pipe_create)
   return pnp_enqueue_refine(c, prm, d_counts);
 }
 
@@ -812,8 +821,8 @@ extern "C" int32_t vo_pnp_upload(vo_ctx* c, const double* K, const float* pts3d,
   return VO_OK;
 }
 
-// Enqueues `blind_batches` batches of 256 hypotheses (a batch exits at once for sequences that have reached their
-// iteration bound) and the refinement.  Two batches cover the bound down to ~37 % inliers (0.9999 confidence); a
+// Enqueues `blind_batches` batches of hypotheses -- 32, then 256 each -- (a batch exits at once for sequences that have reached their
+// iteration bound) and the refinement.  Two batches cover the bound down to ~42 % inliers (0.9999 confidence); a
 // sequence that would need more keeps the best pose found so far -- vo_pnp_fetch reports hypotheses < the bound through
 // status VO_E_CAPACITY so that the caller can fall back to the synchronous vo_pnp_ransac.
 extern "C" int32_t vo_pnp_solve_resident(vo_ctx* c, const vo_pnp_params* prm, int32_t blind_batches) {
@@ -826,7 +835,7 @@ extern "C" int32_t vo_pnp_solve_resident(vo_ctx* c, const vo_pnp_params* prm, in
   { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   vo_pnp_ws* w = c->pnp;
   hipLaunchKernelGGL(k_pnp_init, dim3((unsigned)c->batch), dim3(1), 0, c->stream, w->d_ctrl, prm->max_iters);
-  for (int k = 0; k < blind_batches; k++) pnp_enqueue_batch(c, prm);
+  for (int k = 0; k < blind_batches; k++) pnp_enqueue_batch(c, prm, k);
   return pnp_enqueue_refine(c, prm);
 }
 
@@ -866,10 +875,10 @@ extern "C" int32_t vo_pnp_ransac(vo_ctx* c, const double* K, const float* pts3d,
   vo_pnp_ws* w = c->pnp;
   const size_t B = c->batch;
   hipLaunchKernelGGL(k_pnp_init, dim3((unsigned)B), dim3(1), 0, c->stream, w->d_ctrl, prm->max_iters);
-  // batches of 256 hypotheses per sequence until every sequence has reached its iteration bound (typically one or
+  // batches of 32, then 256 hypotheses per sequence until every sequence has reached its iteration bound (typically one or
   // two batches: the bound is 33 iterations at 70 % inliers, 145 at 50 %)
-  for (int guard = 0; guard < (prm->max_iters + PNP_BATCH - 1) / PNP_BATCH; guard++) {
-    pnp_enqueue_batch(c, prm);
+  for (int guard = 0; guard < (prm->max_iters + PNP_BATCH - 1) / PNP_BATCH + 1; guard++) {
+    pnp_enqueue_batch(c, prm, guard);
     VO_HIP(c, hipMemcpyAsync(w->h_ctrl, w->d_ctrl, sizeof(pnp_ctrl) * B, hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipStreamSynchronize(c->stream));
     bool all = true;
