@@ -305,12 +305,18 @@ __global__ void __launch_bounds__(64) k_pnp_solve(const double* __restrict__ Kal
   for (int i = 0; i < 3; i++) out->t[i] = ok ? t[i] : 0.0;
 }
 
-__global__ void __launch_bounds__(64) k_pnp_score(const double* __restrict__ Kall, const float* __restrict__ Xall, const float* __restrict__ uvall,
+// (four waves per hypothesis: with one, a wave walked 2 000 points in 32 dependent trips -- 16 us for the 32 hypotheses of a first batch,
+//  where the launch is 1 024 waves on 1 024 SIMDs and nothing hides the latency)
+#define PNP_SCORE_THREADS 256
+__global__ void __launch_bounds__(PNP_SCORE_THREADS) k_pnp_score(const double* __restrict__ Kall, const float* __restrict__ Xall, const float* __restrict__ uvall,
                                                   int cap, int n, double thr2, pnp_hyp* __restrict__ hyps, const int32_t* __restrict__ counts) {
+  __shared__ int s_part[PNP_SCORE_THREADS / 64];
   const int b = blockIdx.y, lane = threadIdx.x;
   if (counts) n = counts[b];
   pnp_hyp* hp = hyps + (size_t)b * PNP_BATCH + blockIdx.x;
-  if (hp->count < 0) { if (lane == 0) hp->count = 0; return; }
+  const int c0 = hp->count;
+  __syncthreads();                                                      // every wave has read the flag before thread 0 overwrites it
+  if (c0 < 0) { if (lane == 0) hp->count = 0; return; }                 // no pose for this sample (uniform over the workgroup)
   const double* Kp = Kall + 9 * b;
   const float* X = Xall + (size_t)b * cap * 3;
   const float* uv = uvall + (size_t)b * cap * 2;
@@ -318,12 +324,14 @@ __global__ void __launch_bounds__(64) k_pnp_score(const double* __restrict__ Kal
   for (int i = 0; i < 9; i++) { K[i] = Kp[i]; R[i] = hp->R[i]; }
   for (int i = 0; i < 3; i++) t[i] = hp->t[i];
   int cnt = 0;
-  for (int i = lane; i < n; i += 64) {
+  for (int i = lane; i < n; i += PNP_SCORE_THREADS) {
     const double Xi[3] = {(double)X[3 * i], (double)X[3 * i + 1], (double)X[3 * i + 2]};
     cnt += (pnp_err2(K, R, t, Xi, (double)uv[2 * i], (double)uv[2 * i + 1]) <= thr2) ? 1 : 0;
   }
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-  if (lane == 0) hp->count = cnt;
+  if ((lane & 63) == 0) s_part[lane >> 6] = cnt;
+  __syncthreads();
+  if (lane == 0) { int tot = 0; for (int w = 0; w < PNP_SCORE_THREADS / 64; w++) tot += s_part[w]; hp->count = tot; }
 }
 
 // OpenCV RANSACUpdateNumIters (calib3d/ptsetreg.cpp)
@@ -756,7 +764,7 @@ static void pnp_enqueue_batch(vo_ctx* c, const vo_pnp_params* prm, int k, const 
   const int nb = k == 0 ? PNP_FIRST_BATCH : PNP_BATCH;
   hipLaunchKernelGGL(k_pnp_solve, dim3((nb + 63) / 64, B), dim3(64), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n, (unsigned)prm->seed,
                      w->d_hyp, w->d_ctrl, counts, first, nb);
-  hipLaunchKernelGGL(k_pnp_score, dim3(nb, B), dim3(64), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n, thr2, w->d_hyp, counts);
+  hipLaunchKernelGGL(k_pnp_score, dim3(nb, B), dim3(PNP_SCORE_THREADS), 0, c->stream, w->d_K, w->d_X, w->d_uv, w->cap, w->n, thr2, w->d_hyp, counts);
   hipLaunchKernelGGL(k_pnp_select, dim3(B), dim3(PNP_BATCH), 0, c->stream, w->d_hyp, w->d_ctrl, w->n, prm->confidence, prm->max_iters, counts, first, nb);
 }
 
