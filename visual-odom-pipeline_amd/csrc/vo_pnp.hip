@@ -11,8 +11,8 @@
 // Grunert P3P on three, the fourth disambiguates; batches of 256 hypotheses; ties to the smallest h) and is compared
 // with it hypothesis by hypothesis.
 //
-// GPU mapping: a LANE per hypothesis for the minimal solve, then a WAVE per hypothesis for the consensus count (lanes
-// stride over the points).  256 hypotheses x batch sequences per launch; a one-workgroup-per-sequence kernel keeps the running best and the
+// GPU mapping: a LANE per hypothesis for the minimal solve, then FOUR WAVES per hypothesis for the consensus count (lanes
+// stride over the points).  32 (first batch of a search) or 256 hypotheses x batch sequences per launch; a one-workgroup-per-sequence kernel keeps the running best and the
 // iteration bound on the device, another one refines.
 #include "vo_internal.h"
 
@@ -270,7 +270,7 @@ __device__ inline void pnp_inv3(const double* K, double* Ki) {
 // k_pnp_solve : grid (PNP_BATCH / 64, batch): LANE per hypothesis -- the minimal solve (sample, Grunert quartic, triad,
 //               disambiguation; ~3 k f64 operations with cbrt / acos / cos) runs once per hypothesis instead of once per
 //               lane of a wave
-// k_pnp_score : grid (PNP_BATCH, batch): WAVE per hypothesis -- the lanes stride over the points, shuffle sum
+// k_pnp_score : grid (hypotheses of the batch, batch): FOUR WAVES per hypothesis -- the lanes stride over the points, shuffle + LDS sum
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_pnp_solve(const double* __restrict__ Kall, const float* __restrict__ Xall, const float* __restrict__ uvall,
                                                   int cap, int n, unsigned seed, pnp_hyp* __restrict__ hyps, const pnp_ctrl* __restrict__ ctrl,
