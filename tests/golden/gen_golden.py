@@ -600,6 +600,9 @@ def run_pipe_case(name, n_steps, ba_window=4, t_step0=1, t0=0, t1=3, births=None
 def run_pipe_cases():
     run_pipe_case("w4", 12, ba_window=4)                                             # the reference's own window (pipeline.py:19)
     run_pipe_case("w10", 10, ba_window=10)                                           # BASELINE's window
+    # configs[4]'s window, seeded at step 22 so that all 20 slots have a pose (the w4 / w10 runs start at step 1: their windows are longer
+    # than the trajectory at first, bundle_adjuster.py:169-171)
+    run_pipe_case("w20", 8, ba_window=20, t_step0=22, t0=0, t1=1)
     # four birth groups ripen in one frame; CPython walks the set {2, 9, 16, 8} as 16, 9, 2, 8 (extractor.py:210-211)
     run_pipe_case("groups", 5, ba_window=4, t_step0=16, t0=0, t1=1, births=[2, 9, 16, 8])
     run_pipe_case("scipy_w4", 12, ba_window=4, scipy_solver=True)                    # scipy's TRF kept: statistical comparison only

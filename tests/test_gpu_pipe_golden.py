@@ -34,7 +34,7 @@ def _deviation(ref, got):
     return dp, dH
 
 
-@pytest.mark.parametrize("name,n_steps", [("w4", 12), ("w10", 10), ("groups", 5)])
+@pytest.mark.parametrize("name,n_steps", [("w4", 12), ("w10", 10), ("w20", 8), ("groups", 5)])
 def test_device_tables_equal_the_references_own_pipeline_step(name, n_steps):
     from vo_mi355x.resident import ResidentPipeline
     g = pg.load(name)

@@ -28,7 +28,7 @@ def _loop(g, lazy=True, cap=2048):
     return loop, sc, fos, t0
 
 
-@pytest.mark.parametrize("name,n_steps", [("w4", 12), ("w10", 10), ("groups", 5)])
+@pytest.mark.parametrize("name,n_steps", [("w4", 12), ("w10", 10), ("w20", 8), ("groups", 5)])
 def test_lazy_lists_equal_the_references_own_pipeline_step(name, n_steps):
     g = pg.load(name)
     loop, sc, fos, t0 = _loop(g)

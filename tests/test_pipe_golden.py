@@ -16,7 +16,7 @@ import pipe_golden as pg
 import pipe_helpers as ph
 from test_adapters import _oracle_ctx
 
-CASES = [("w4", 12), ("w10", 10), ("groups", 5)]
+CASES = [("w4", 12), ("w10", 10), ("w20", 8), ("groups", 5)]
 
 
 def replay(g, make_ctx, which, n_steps, p_tol=0.0, pose_tol=0.0, cap=4096):
