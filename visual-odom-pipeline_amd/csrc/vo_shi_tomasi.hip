@@ -785,7 +785,7 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
     kcap = min(cap, max(256, 8 * limit));
   }
   unsigned long long* const src = cand;                   // raw list (entries <= thr_key do not count)
-  unsigned long long* const top = cand + ST_GLOBAL_CAP;   // chunk staging (behind the raw list)
+  unsigned long long* const top_buf = cand + ST_GLOBAL_CAP;   // chunk staging (behind the raw list)
   unsigned long long upper = ~0ull;                       // keys >= upper have been consumed by earlier chunks
   uint32_t remaining = ncand;
   int n_acc = 0;                                          // corners accepted so far: out[0 .. n_acc) in rank order
@@ -802,18 +802,25 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
       // It stops as soon as the WHOLE bin of the K-th key still fits the sort's size class (K <= taken <= k_room): the chunk is then the keys
       // down to that bin's lower bound -- a rank-ordered prefix of the list like any other, a few more keys than asked for -- after two or three
       // passes instead of eight (eigenvalues between 3 % and 100 % of the maximum spread over ~640 bins of the top 16 bits).
-      int k_room = 1024;
-      while (k_room < K) k_room <<= 1;
+      int k_room = 512;                                   // (the sort network's size classes: 2 K at least, so that a whole bin has room)
+      while (k_room < 2 * K) k_room <<= 1;
       k_room = min(k_room, cap - n_acc);
-      unsigned long long prefix = 0;
+      // Every valid key lies in (thr_key, max_key]: the bits above the highest bit in which those two differ are common to all of them and
+      // carry no information (with the byte-aligned digits of the first form the whole first pass -- sign and seven exponent bits -- put every
+      // key of the list into one or two bins, 1 600 LDS atomics on the same address, and the second pass did the work).  The digits start at
+      // that bit: the first histogram spreads the keys over the whole value range [quality x max, max].
+      const unsigned long long max_key = ((unsigned long long)__float_as_uint(maxv) << 32) | 0xFFFFFFFFull;
+      const int top = 63 - __builtin_clzll((thr_key ^ max_key) | 0xFFull);      // >= 7; (a list with one distinct value: the low byte)
+      unsigned long long prefix = (top >= 63) ? 0ull : (max_key >> (top + 1)) << (top + 1);
       uint32_t need = (uint32_t)K, taken = (uint32_t)K;
-      for (int byte = 7; byte >= 0; byte--) {
+      for (int hi = top; hi >= 0; hi -= 8) {                // digit = bits hi ... max(hi - 7, 0)
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        const int sh = 8 * byte;
+        const int sh = max(hi - 7, 0), nbits = hi - sh + 1;
+        const uint32_t dmask = (1u << nbits) - 1u;
         for (uint32_t i = tid; i < n_raw; i += 1024) {
           const unsigned long long k = src[i];
-          if (k > thr_key && k < upper && (byte == 7 || (k >> (sh + 8)) == (prefix >> (sh + 8)))) atomicAdd(&hist[(uint32_t)(k >> sh) & 255u], 1u);
+          if (k > thr_key && k < upper && (hi >= 63 || (k >> (hi + 1)) == (prefix >> (hi + 1)))) atomicAdd(&hist[(uint32_t)(k >> sh) & dmask], 1u);
         }
         __syncthreads();
         // the bin that holds the need-th largest key, counting from bin 255 down (bin 0 takes what is left): one wave, four bins per lane,
@@ -845,31 +852,40 @@ __global__ void __launch_bounds__(1024) k_st_select(unsigned long long* __restri
         const uint32_t whole = st_uniform(s_take);
         if (whole <= (uint32_t)k_room) { taken = whole; break; }     // (uniform)
       }
-      for (uint32_t i = tid; i < n_raw; i += 1024) {
-        const unsigned long long k = src[i];
-        if (k >= prefix && k > thr_key && k < upper) { const uint32_t pos = atomicAdd(&s_fill, 1u); if (pos < (uint32_t)cap) top[pos] = k; }   // (a whole bin may reach below the threshold)
+      for (uint32_t i0 = 0; i0 < n_raw; i0 += 1024) {        // (uniform trip count: the ballot below needs every lane)
+        const uint32_t i = i0 + tid;
+        const unsigned long long k = (i < n_raw) ? src[i] : 0ull;
+        const bool in = k >= prefix && k > thr_key && k < upper;      // (a whole bin may reach below the threshold)
+        const unsigned long long bal = __ballot(in);
+        if (bal) {                                                    // one LDS atomic per wave instead of one per key on the same counter
+          uint32_t base = 0;
+          if ((tid & 63) == 0) base = atomicAdd(&s_fill, (uint32_t)__popcll(bal));
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          const uint32_t pos = base + (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
+          if (in && pos < (uint32_t)cap) top_buf[pos] = k;
+        }
       }
       __syncthreads();
-      chunk = top; n_new = (int)taken; n_load = (int)taken; next_upper = prefix;
+      chunk = top_buf; n_new = (int)taken; n_load = (int)taken; next_upper = prefix;
     } else if (pass > 0) {
       if (tid == 0) s_fill = 0;
       __syncthreads();
       for (uint32_t i = tid; i < n_raw; i += 1024) {
         const unsigned long long k = src[i];
-        if (k > thr_key && k < upper) top[atomicAdd(&s_fill, 1u)] = k;
+        if (k > thr_key && k < upper) top_buf[atomicAdd(&s_fill, 1u)] = k;
       }
       __syncthreads();
-      chunk = top; n_load = n_new;
+      chunk = top_buf; n_load = n_new;
     } else if (n_raw > (uint32_t)cap) {
       // first and only chunk, but the raw list is longer than the sort holds: compact the valid keys (<= ST_CAND_CAP of them)
       if (tid == 0) s_fill = 0;
       __syncthreads();
       for (uint32_t i = tid; i < n_raw; i += 1024) {
         const unsigned long long k = src[i];
-        if (k > thr_key) top[atomicAdd(&s_fill, 1u)] = k;
+        if (k > thr_key) top_buf[atomicAdd(&s_fill, 1u)] = k;
       }
       __syncthreads();
-      chunk = top; n_load = n_new;
+      chunk = top_buf; n_load = n_new;
     }
     const int n = n_acc + n_new;
     // ---- sort the chunk by (value desc, index desc) = OpenCV's greaterThanPtr order; result: xy[n_acc ..] in rank order ----
