@@ -53,9 +53,10 @@ def parse():
     ap.add_argument("--cpu-pipe-worker", type=int, default=-1, help=argparse.SUPPRESS)   # CPU-baseline worker of the closed loop (table model over the oracle)
     ap.add_argument("--cpu-pipe-frames", type=int, default=6, help="frames each CPU worker of the closed-loop baseline steps (after 2 untimed ones)")
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--seqs", type=int, default=96, help="independent sequences per GPU")
-    ap.add_argument("--ctxs", type=int, default=None, help="batched contexts (HIP streams) the sequences are split over; default 3 (1 for "
-                    "--workload pipeline, whose own stream layout overlaps the stages of one context: DESIGN.md section 6)")
+    ap.add_argument("--seqs", type=int, default=256, help="independent sequences per GPU (round 4: 256 in ONE batched context; rounds 1-3 ran "
+                    "96 in three contexts: --seqs 96 --ctxs 3 --side-stream on, also measured by the default run as `layout_3_contexts_of_32`)")
+    ap.add_argument("--ctxs", type=int, default=None, help="batched contexts the sequences are split over; default 1 (the stream layout of a "
+                    "context overlaps its own stages: DESIGN.md section 6)")
     ap.add_argument("--ba-iters", type=int, default=10, help="LM iteration budget per adjust")
     ap.add_argument("--frames", type=int, default=100, help="distinct synthetic frames per sequence: a closed loop of smooth motion, played round and round")
     ap.add_argument("--pipe-window", type=int, default=4, help="--workload pipeline: BA window (the reference's own setting is 4, pipeline.py:19; BASELINE's 10)")
@@ -71,9 +72,10 @@ def parse():
     ap.add_argument("--host-threads", type=int, default=3, help="enqueue/fetch the contexts from this many host threads")
     ap.add_argument("--fixed-ba-budget", action="store_true",
                     help="always enqueue --ba-iters LM iterations (default: what the last fetched frame needed, + 2 after a frame that hit its budget)")
-    ap.add_argument("--side-stream", choices=("on", "off", "pipeline"), default="on",
+    ap.add_argument("--side-stream", choices=("on", "off", "pipeline"), default=None,
                     help="Shi-Tomasi + DLT of a step on a side stream beside the BA (on: +1-2 %% with three contexts, +10-20 %% with one); "
-                         "pipeline: also the BA of frame t beside the front end of frame t + 1 (three streams)")
+                         "pipeline: also the BA of frame t beside the front end of frame t + 1 (three streams).  Default: pipeline with one "
+                         "context, on with several")
     ap.add_argument("--workload", choices=("A", "config5", "pipeline"), default="A",
                     help="A: BASELINE configs[2], the metric's configuration (default).  config5: ONE 1920x1080 sequence, 5000 "
                          "points, 20-frame BA whose landmarks are sharded over the ranks with an RCCL all-reduce per LM "
@@ -804,6 +806,22 @@ def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
         g.adaptive = True
     except Exception as e:      # noqa: BLE001
         out["single_sequence"]["graph_replay"] = {"error": str(e)}
+    # the default layout of rounds 1-3 on this build and box -- 96 sequences in three batched contexts of 32, side stream on, three host threads --
+    # as a child process running exactly that command (measured inside this process, beside the other informational contexts, it came out 20 % low)
+    try:
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--seqs", "96", "--ctxs", "3", "--side-stream", "on", "--host-threads", "3", "--steps", "60",
+               "--warmup", "10", "--regions", "3", "--no-extras", "--no-cpu-baseline", "--ba-iters", str(a.ba_iters), "--frames", str(a.frames)]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                                "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}      # (a 1-rank torchrun launch)
+        pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env)
+        d3 = json.loads([l for l in pr.stdout.decode().splitlines() if l.startswith("{")][-1])
+        out["layout_3_contexts_of_32"] = {"frames_per_s": d3["value"], "ms_per_step": d3["ms_per_step"], "sequences": 96, "contexts": 3,
+                                          "klt_roofline_frac": d3["roofline"]["frac"],
+                                          "what": "the default configuration of rounds 1-3 (BENCH_r01 .. r03) on this build and box: `python bench.py "
+                                                  "--seqs 96 --ctxs 3 --side-stream on --host-threads 3 --no-extras --no-cpu-baseline` run as a child process"}
+    except Exception as e:      # noqa: BLE001
+        out["layout_3_contexts_of_32"] = {"error": str(e)}
     kl = {}
     for batch in (1, 32):
         gk = g if batch == 1 else Group(device, frame_sets, seed0=7100, batch=32, ba_iters=a.ba_iters)
@@ -981,7 +999,9 @@ def main():
     # in the driver instead of spinning on it (1 GPU: 34 650 vs 34 640 frames/s, two ranks on one GPU 31 580 vs 31 190 -- no loss)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     if a.ctxs is None:
-        a.ctxs = 1 if a.workload == "pipeline" else 3
+        a.ctxs = 1
+    if a.side_stream is None:
+        a.side_stream = "pipeline" if (a.workload == "A" and a.ctxs == 1) else "on"
     if "VO_BLOCKING_SYNC" not in os.environ and local_world * max(a.host_threads, 1) > usable_cores():
         os.environ["VO_BLOCKING_SYNC"] = "1"
     t_gen = time.perf_counter()
@@ -1161,6 +1181,11 @@ def main():
         klt_avg_s = (klt_ms / max(klt_n, 1)) * 1e-3
         achieved = klt_bytes / klt_avg_s / 1e9 if klt_avg_s > 0 else 0.0
         traffic, traffic_src = profile_constant("klt_traffic.json", "hbm_bytes_per_launch")
+        # (the counters were averaged over launches of `sq_waves_per_launch` keypoints -- the default command's; another --seqs scales the figure)
+        pw, _ = profile_constant("klt_valu.json", "sq_waves_per_launch")
+        if traffic is not None and pw and int(pw) != s0.B * N_PTS:
+            traffic = int(traffic * (s0.B * N_PTS) / float(pw))
+            traffic_src += "; scaled from %d to %d keypoints per launch" % (int(pw), s0.B * N_PTS)
         valu = valu_roofline(klt_avg_s, s0.B * N_PTS)
         roof = {"bound": "hbm", "kernel": "k_klt_track", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "valu": valu,

@@ -75,7 +75,7 @@ if means:
         wr = means["WRITE_SIZE"][k][0] if "WRITE_SIZE" in means else 0.0
         json.dump({
             "kernel": k, "klt_source_sha256_16": KLT_DIGEST, "klt_frame_source_sha256_16": KLT_FRAME_DIGEST, "measured": tag,
-            "config": "one k_klt_track launch of a batched context: 32 sequences x 2000 points (bench.py default: 96 sequences in 3 such contexts)",
+            "config": "one k_klt_track launch of the profiled command (bench.py default: ONE batched context of 256 sequences x 2000 points; see `klt_valu.json` sq_waves_per_launch = sequences x points of the launch the counters were averaged over)",
             "fetch_size_kb_per_launch": 2 * fe,
             "write_size_kb_per_launch": wr,
             "hbm_bytes_per_launch": int((2 * fe + wr) * 1024),
@@ -121,7 +121,7 @@ if path:
                    "sq_active_inst_valu": m["SQ_ACTIVE_INST_VALU"], "sq_wave_cycles": m["SQ_WAVE_CYCLES"],
                    "sq_busy_cycles": m["SQ_BUSY_CYCLES"], "grbm_gui_active": m["GRBM_GUI_ACTIVE"],
                    "note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over "
-                           "`bench.py --steps 4 --warmup 2` (tools/profile_round.sh), mean over the k_klt_track launches (32 sequences x "
-                           "2000 points each); SQ_INSTS_VALU counts wave-instructions"},
+                           "`bench.py --steps 4 --warmup 2` (tools/profile_round.sh), mean over the k_klt_track launches (sq_waves_per_launch = "
+                           "sequences x points of one launch); SQ_INSTS_VALU counts wave-instructions"},
                   open(os.path.join(out, "klt_valu.json"), "w"), indent=1)
 print("summaries written for", tag)
