@@ -849,6 +849,8 @@ def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
         # reference's unbounded lists, not the capacity policy's (capacity_policy_frames.detection = 0 after the fill-up)
         a4big = _copy.copy(a4); a4big.pipe_max_pts = 8192
         out["pipeline_step"] = {"reference_configuration_window4": run_pipeline(device, a4, dist, 1, 96, 40, 10, 3, scenes),
+                                # (96 sequences: the batch rounds 2-3 reported; 256: the batch of the headline since the end of round 4)
+                                "reference_configuration_window4_256_sequences": run_pipeline(device, a4, dist, 1, 256, 40, 10, 3, scenes),
                                 "window10_dead_stay_dead": run_pipeline(device, a10, dist, 1, 96, 40, 10, 3, scenes),
                                 "one_sequence_window4": run_pipeline(device, a4, dist, 1, 1, 100, 10, 3, scenes),
                                 "window4_tables_not_full_8192_slots": run_pipeline(device, a4big, dist, 1, 32, 40, 60, 3, scenes)}
