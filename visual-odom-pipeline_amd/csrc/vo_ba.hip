@@ -83,6 +83,8 @@ struct ba_ptrs {
   int cam_off;                        // k_ba_build: offset (doubles) of the staged cameras inside the dynamic LDS
   int sharded, rank, n_ranks, batch;  // sharded: the batch entries (x the ranks) are landmark shards of one problem
   int fold;                           // the solve sums the partial sets itself, no k_ba_reduce launch (small windows, unsharded: ba_make_ptrs)
+  int n_eval;                         // entries of evalpart (= workgroups of k_ba_update)
+  int* gdyn;                          // wave-private kernels: [2][batch] partial sets / statistics entries of a problem in iteration it & 1 (null: nset, n_eval)
   const int32_t* n_live; int s_nlive; // optional (closed loop): landmark slots [0, *n_live) of the problem are in use, the workgroups of the rest only zero
                                       // their partial sums (the tables of vo_pipeline.hip are sized for max_pts landmarks, a scene fills a part of them)
 };
@@ -143,6 +145,11 @@ struct vo_ba_ws {
   double* d_bank_x0 = nullptr; double* d_bank_obs = nullptr;
   int bank_n = 0, bank_sel = 0;
   const int32_t* d_nlive = nullptr; int nlive_stride = 0;     // vo_ba_set_live
+  // wave-private kernels (vo_ba_wave.h): windows of <= 10 slots
+  int v2 = 0, v2_rt = 0, v2_spl = 0;
+  size_t v2_lds = 0;
+  int v2_g0 = 1, v2_gcap = 1;       // workgroups per problem of a launch; the most a running problem is given once others have finished
+  int* d_gdyn = nullptr;            // [2][batch]
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -398,6 +405,8 @@ __device__ inline ba_state ba_init_state(const ba_params_dev& prm) {
   return s;
 }
 
+#include "vo_ba_wave.h"
+
 // ------------------------------------------------------------------------------------------------
 // k_ba_build
 // ------------------------------------------------------------------------------------------------
@@ -423,7 +432,7 @@ __global__ void __launch_bounds__(TPB) k_ba_build(ba_ptrs Pall, ba_params_dev pr
   // ---- state for this iteration (every workgroup derives it from the same inputs).  Handing the decision to the workgroup of
   //      k_ba_update that arrives last (an arrival counter per problem) was measured: k_ba_build 60 -> 54 us, but 125 agent-scope
   //      atomics on one address serialise (k_ba_update 15 -> 43 us), and an agent-scope release fence writes the L2 back (245 us) ----
-  if (it > 0) ba_reduce_evalpart<TPB>(P.sharded ? P.xstat : P.evalpart, P.sharded ? 1 : P.nblk, s_esum);
+  if (it > 0) ba_reduce_evalpart<TPB>(P.sharded ? P.xstat : P.evalpart, P.sharded ? 1 : P.n_eval, s_esum);
   if (tid == 0) {
     ba_state st;
     if (it == 0) st = ba_init_state(prm);
@@ -694,6 +703,7 @@ __global__ void __launch_bounds__(256) k_ba_reduce(ba_ptrs Pall, int it) {
   __shared__ double s_part[4][64];
   const ba_state st = P.state[it & 1];
   if (st.done) return;
+  const int nset = Pall.gdyn ? Pall.gdyn[(it & 1) * Pall.batch + blockIdx.y] : P.nset;
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;       // output within the workgroup, partial group
   const int e = blockIdx.x * 64 + o;
   const int n_tile_el = P.n_tiles * 256, n_pose_el = P.W * BA_POSE_VALS;
@@ -707,7 +717,7 @@ __global__ void __launch_bounds__(256) k_ba_reduce(ba_ptrs Pall, int it) {
     // group g sums partials g, g + 4, g + 8, ... (8 loads in flight), groups are combined in fixed order below
     double s0 = 0, s1 = 0;
     int b = g;
-    for (; b + 60 < P.nset; b += 64) {   // 16 loads in flight
+    for (; b + 60 < nset; b += 64) {   // 16 loads in flight
       double v[16];
 #pragma unroll
       for (int u = 0; u < 16; u++) v[u] = src[(size_t)(b + 4 * u) * stride];
@@ -717,14 +727,14 @@ __global__ void __launch_bounds__(256) k_ba_reduce(ba_ptrs Pall, int it) {
         else { s0 += v[u]; s1 += v[u + 1]; }
       }
     }
-    for (; b + 28 < P.nset; b += 32) {
+    for (; b + 28 < nset; b += 32) {
       const double v0 = src[(size_t)b * stride], v1 = src[(size_t)(b + 4) * stride], v2 = src[(size_t)(b + 8) * stride];
       const double v3 = src[(size_t)(b + 12) * stride], v4 = src[(size_t)(b + 16) * stride], v5 = src[(size_t)(b + 20) * stride];
       const double v6 = src[(size_t)(b + 24) * stride], v7 = src[(size_t)(b + 28) * stride];
       if (is_max) { s0 = fmax(fmax(fmax(s0, v0), fmax(v1, v2)), fmax(fmax(v3, v4), fmax(fmax(v5, v6), v7))); }
       else { s0 += v0; s1 += v1; s0 += v2; s1 += v3; s0 += v4; s1 += v5; s0 += v6; s1 += v7; }
     }
-    for (; b < P.nset; b += 4) { const double v = src[(size_t)b * stride]; if (is_max) s0 = fmax(s0, v); else s0 += v; }
+    for (; b < nset; b += 4) { const double v = src[(size_t)b * stride]; if (is_max) s0 = fmax(s0, v); else s0 += v; }
     acc = is_max ? s0 : (s0 + s1);
   }
   s_part[g][o] = acc;
@@ -766,7 +776,7 @@ __global__ void __launch_bounds__(256) k_ba_xstat(ba_ptrs Pall, int it) {
   if (threadIdx.x < 4) s_tot[threadIdx.x] = 0;
   for (int b = 0; b < Pall.batch; b++) {
     __syncthreads();
-    ba_reduce_evalpart<256>(Pall.evalpart + (size_t)b * Pall.s_evalpart, Pall.nblk, s_sum);
+    ba_reduce_evalpart<256>(Pall.evalpart + (size_t)b * Pall.s_evalpart, Pall.n_eval, s_sum);
     if (threadIdx.x < 4) s_tot[threadIdx.x] += s_sum[threadIdx.x];
   }
   __syncthreads();
@@ -813,12 +823,13 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
   // early-exit launch less in every group a finished problem still sees.  Fixed order (two interleaved chains over the sets), so a solve
   // stays bitwise reproducible; the sum differs in the last bits from k_ba_reduce's four-group order.
   const bool fold = P.fold != 0;
+  const int nset = Pall.gdyn ? Pall.gdyn[(it & 1) * Pall.batch + blockIdx.x] : P.nset;
   auto set_sum = [&](const double* __restrict__ src, const size_t stride) -> double {
     double s0 = 0, s1 = 0;
     int bset = 0;
 #pragma unroll 8
-    for (; bset + 1 < P.nset; bset += 2) { s0 += src[(size_t)bset * stride]; s1 += src[(size_t)(bset + 1) * stride]; }
-    if (bset < P.nset) s0 += src[(size_t)bset * stride];
+    for (; bset + 1 < nset; bset += 2) { s0 += src[(size_t)bset * stride]; s1 += src[(size_t)(bset + 1) * stride]; }
+    if (bset < nset) s0 += src[(size_t)bset * stride];
     return s0 + s1;
   };
   const size_t n_tile_el = (size_t)P.n_tiles * 256, n_pose_el = (size_t)W * BA_POSE_VALS;
@@ -836,7 +847,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(ba_ptrs Pall, ba_
   }
   if (fold && tid == BA_SOLVE_THREADS - 1) {           // max |g_l| over the sets (what k_ba_reduce leaves behind the camera sums)
     double gm = 0;
-    for (int bset = 0; bset < P.nset; bset++) gm = fmax(gm, P.gmax[bset]);
+    for (int bset = 0; bset < nset; bset++) gm = fmax(gm, P.gmax[bset]);
     s_dp[n + 16] = gm;                                 // (scratch behind dp: entries n .. n + 15 carry the step statistics below)
   }
   __syncthreads();
@@ -1209,7 +1220,8 @@ __global__ void __launch_bounds__(256) k_ba_finalize(ba_ptrs Pall, ba_params_dev
   st_out += (size_t)blockIdx.x * st_stride;
   __shared__ ba_state s_st;
   __shared__ double s_esum[4];
-  if (n_it > 0) ba_reduce_evalpart<256>(P.sharded ? P.xstat : P.evalpart, P.sharded ? 1 : P.nblk, s_esum);
+  if (n_it > 0) ba_reduce_evalpart<256>(P.sharded ? P.xstat : P.evalpart,
+                                        P.sharded ? 1 : (Pall.gdyn ? Pall.gdyn[((n_it - 1) & 1) * Pall.batch + blockIdx.x] : P.n_eval), s_esum);
   // gridDim.y workgroups per problem share the copy of x (one 256-thread workgroup took 10 us for 6 000 doubles, at the end of
   // the critical path of a step); each derives the final state itself (deterministic), the first one publishes it
   if (threadIdx.x == 0) {
@@ -1263,7 +1275,7 @@ void vo_ba_destroy(vo_ctx* c) {
   if (b->d_bank_x0) (void)hipFree(b->d_bank_x0);
   if (b->d_bank_obs) (void)hipFree(b->d_bank_obs);
   void* bufs[] = {b->d_K, b->d_obs, b->d_x0, b->d_x[0], b->d_x[1], b->d_aux, b->d_posepart, b->d_gmax,
-                  b->d_tiles, b->d_dp, b->d_evalpart, b->d_tilesum, b->d_xstat, b->d_gather, b->d_cams, b->d_S, b->d_Hpp, b->d_res, b->d_dl, b->d_pub, b->d_state, b->d_info};
+                  b->d_tiles, b->d_dp, b->d_evalpart, b->d_tilesum, b->d_xstat, b->d_gather, b->d_cams, b->d_S, b->d_Hpp, b->d_res, b->d_dl, b->d_pub, b->d_state, b->d_info, b->d_gdyn};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (b->h_gather) (void)hipHostFree(b->h_gather);
   if (b->h_state) (void)hipHostFree(b->h_state);
@@ -1307,6 +1319,11 @@ static void ba_geometry(vo_ba_ws* b, int W, int N) {
   b->build_lds = panel > scratch ? panel : scratch;
   b->cam_off = (int)(b->build_lds / sizeof(double));
   b->build_lds += sizeof(double) * (size_t)BA_CAM * W;
+  // wave-private kernels: RT column blocks (6 W + 1 <= 16 RT <= 64), a lane serves SPL = ceil(W / 8) slots.  VO_BA_V2=0: the older kernels (A/B knob)
+  b->v2 = (W <= 10) ? 1 : 0;
+  if (const char* e = getenv("VO_BA_V2")) b->v2 = (W <= 10 && atoi(e) != 0) ? 1 : 0;
+  b->v2_rt = b->RT; b->v2_spl = (W + 7) / 8;
+  b->v2_lds = sizeof(double) * ((size_t)4 * (3 * 8) * (16 * b->v2_rt + 16) + (size_t)BA2_CAM * W);
   const int n1 = 6 * W + 1, PT = n1 | 1;
   b->solve_lds = sizeof(double) * ((size_t)n1 * PT + (size_t)W * BA_POSE_VALS + n1 + n1 + 24 + (size_t)21 * W) + sizeof(unsigned short) * ((size_t)n1 * (n1 + 1) / 2 + 8);
 }
@@ -1363,6 +1380,8 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     b->d_xout = reinterpret_cast<double*>(b->d_pub + VO_BA_PUB_HEADER);
     VO_HIP(c, hipMalloc((void**)&b->d_state, sizeof(ba_state) * 2 * B));
     VO_HIP(c, hipMalloc((void**)&b->d_info, sizeof(ba_info) * B));
+    VO_HIP(c, hipMalloc((void**)&b->d_gdyn, sizeof(int) * 2 * B));
+    VO_HIP(c, hipMemsetAsync(b->d_gdyn, 0, sizeof(int) * 2 * B, c->stream));
     VO_HIP(c, hipHostMalloc((void**)&b->h_state, sizeof(ba_state) * B, hipHostMallocDefault));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -1441,6 +1460,24 @@ static ba_ptrs ba_make_ptrs(const vo_ctx* c) {
     if (cpw > 4 && cpw_env <= 0) cpw = 4;
     P.nset = (cpw > 1 && b->tpb == 256) ? (b->nblk + cpw - 1) / cpw : b->nblk;
   }
+  P.n_eval = b->nblk;
+  if (b->v2) {
+    // G workgroups (4 waves each) per problem: enough for BA2_TARGET_WAVES waves in the launch, at most one chunk (8 landmarks) per wave.
+    // VO_BA_G overrides (experiment knob).  The partial sums depend on G like the older kernels' on the chunks per workgroup.
+    const int nchunk = vo_div_up(b->N, 8), gmax = vo_div_up(nchunk, 4);
+    int G = vo_div_up(BA2_TARGET_WAVES, 4 * c->batch);
+    if (const char* e = getenv("VO_BA_G")) { if (atoi(e) > 0) G = atoi(e); }
+    if (G > gmax) G = gmax;
+    if (G < 1) G = 1;
+    P.nset = G; P.n_eval = G;
+    // once problems of the batch have finished, a running one is given up to 16 workgroups (ba2_select_work)
+    int cap = 16;
+    if (const char* e = getenv("VO_BA_GCAP")) { if (atoi(e) > 0) cap = atoi(e); }
+    if (cap > gmax) cap = gmax;
+    if (cap < G) cap = G;
+    b->v2_g0 = G; b->v2_gcap = cap;
+  }
+  P.gdyn = b->v2 ? b->d_gdyn : nullptr;
   // strides use the ALLOCATED capacity for N-dependent buffers? no: they are packed for the current problem size
   const size_t W = (size_t)b->W, N = (size_t)b->N;
   P.s_obs = 2 * W * N; P.s_x = 6 * W + 3 * N; P.s_aux = N * BA_AUX; P.s_posepart = (size_t)b->nblk * W * BA_POSE_VALS;
@@ -1457,7 +1494,8 @@ static ba_ptrs ba_make_ptrs(const vo_ctx* c) {
     // and one sequence with 125 sets halves -- hence the rule
     const int n1 = 6 * b->W + 1;
     const char* e = getenv("VO_BA_FOLD");
-    const bool small = (n1 * (n1 + 1)) / 2 + b->W * BA_POSE_VALS <= BA_SOLVE_THREADS && P.nset <= 32;
+    const bool small = ((n1 * (n1 + 1)) / 2 + b->W * BA_POSE_VALS <= BA_SOLVE_THREADS && P.nset <= 32) || (b->v2 && P.nset <= 4);
+    // (wave-private kernels: the rule looks at the sets of a full launch; a tail launch hands a running problem up to v2_gcap of them)
     P.fold = (!c->ba_sharded && (e ? atoi(e) != 0 : small)) ? 1 : 0;
   }
   return P;
@@ -1505,7 +1543,15 @@ static int32_t ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& 
                               double* probe_S, double* hpp_out, double* probe_dl) {
   vo_ba_ws* b = c->ba;
   const int B = c->batch;
-  if (b->tpb == 256 && b->LPP == 8) hipLaunchKernelGGL((k_ba_build<256, 8>), dim3(P.nset, B), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
+  if (b->v2) {
+    const dim3 g(b->v2_g0 * B);
+    const int g0 = b->v2_g0, gc = b->v2_gcap;
+    if (b->v2_spl == 2) hipLaunchKernelGGL((k_ba_build_w<4, 2, 8>), g, dim3(256), b->v2_lds, c->stream, P, prm, it, probe_lambda, g0, gc);
+    else if (b->v2_rt == 4) hipLaunchKernelGGL((k_ba_build_w<4, 1, 8>), g, dim3(256), b->v2_lds, c->stream, P, prm, it, probe_lambda, g0, gc);
+    else if (b->v2_rt == 3) hipLaunchKernelGGL((k_ba_build_w<3, 1, 8>), g, dim3(256), b->v2_lds, c->stream, P, prm, it, probe_lambda, g0, gc);
+    else if (b->v2_rt == 2) hipLaunchKernelGGL((k_ba_build_w<2, 1, 8>), g, dim3(256), b->v2_lds, c->stream, P, prm, it, probe_lambda, g0, gc);
+    else hipLaunchKernelGGL((k_ba_build_w<1, 1, 8>), g, dim3(256), b->v2_lds, c->stream, P, prm, it, probe_lambda, g0, gc);
+  } else if (b->tpb == 256 && b->LPP == 8) hipLaunchKernelGGL((k_ba_build<256, 8>), dim3(P.nset, B), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
   else if (b->tpb == 256) hipLaunchKernelGGL(k_ba_build<256>, dim3(P.nset, B), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
   else if (b->tpb == 512) hipLaunchKernelGGL(k_ba_build<512>, dim3(b->nblk, B), dim3(512), b->build_lds, c->stream, P, prm, it, probe_lambda);
   else hipLaunchKernelGGL(k_ba_build<1024>, dim3(b->nblk, B), dim3(1024), b->build_lds, c->stream, P, prm, it, probe_lambda);
@@ -1517,7 +1563,10 @@ static int32_t ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& 
     if (r != VO_OK) return r;
   }
   hipLaunchKernelGGL(k_ba_solve, dim3(B), dim3(BA_SOLVE_THREADS), b->solve_lds, c->stream, P, prm, it, probe_S, hpp_out);
-  if (b->tpb == 256 && b->LPP == 8) hipLaunchKernelGGL((k_ba_update<256, 8>), dim3(b->nblk, B), dim3(256), 0, c->stream, P, prm, it, probe_dl);
+  if (b->v2) {
+    if (b->v2_spl == 2) hipLaunchKernelGGL((k_ba_update_w<2, 8>), dim3(b->v2_g0 * B), dim3(256), 0, c->stream, P, prm, it, probe_dl, b->v2_g0, b->v2_gcap);
+    else hipLaunchKernelGGL((k_ba_update_w<1, 8>), dim3(b->v2_g0 * B), dim3(256), 0, c->stream, P, prm, it, probe_dl, b->v2_g0, b->v2_gcap);
+  } else if (b->tpb == 256 && b->LPP == 8) hipLaunchKernelGGL((k_ba_update<256, 8>), dim3(b->nblk, B), dim3(256), 0, c->stream, P, prm, it, probe_dl);
   else if (b->tpb == 256) hipLaunchKernelGGL(k_ba_update<256>, dim3(b->nblk, B), dim3(256), 0, c->stream, P, prm, it, probe_dl);
   else if (b->tpb == 512) hipLaunchKernelGGL(k_ba_update<512>, dim3(b->nblk, B), dim3(512), 0, c->stream, P, prm, it, probe_dl);
   else hipLaunchKernelGGL(k_ba_update<1024>, dim3(b->nblk, B), dim3(1024), 0, c->stream, P, prm, it, probe_dl);
