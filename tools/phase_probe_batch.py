@@ -13,7 +13,7 @@ with VoContext(64, 64, max_pts=64, batch=B) as c:
         pr = c.ba_probe(1e-4)      # one iteration of all B problems, stamps from problem 0
     print("B =", B)
     print("ba_solve cycles [total, reduce, assemble, chol, backsub, publish]", c.debug_cycles(1)[:6])
-    print("ba_build cycles [total, lin, sums+3x3, camsums, panel, mfma, (w: total, stage, pass1, pass2, gram, rest of walk, epilogue)]", c.debug_cycles(2)[:7])
+    print("ba_build cycles [total, lin, sums+3x3, camsums, panel, mfma, (w: total, to 3rd chunk, pass1, pass2, gram, rest of walk, epilogue)]", c.debug_cycles(2)[:7])
     c.ba_solve_resident(c.ba_params(max_iters=10))
     po, pt, st = c.ba_fetch()
     st = st if isinstance(st, list) else [st]

@@ -36,20 +36,52 @@ __device__ __forceinline__ double rcp_nr(double x) {
   return y;
 }
 
+// ---- lane maps ----
+// LPP = 8: landmark = lane / 8 (8 per wave), slot group q = lane % 8.
+// LPP = 5 (windows of 9 and 10 slots: a lane serves slots q and q + 5, every lane busy twice -- with 8 lanes per landmark the second slot
+//          of six lanes in eight is empty): a 16-lane row holds three landmarks (lanes 0-4, 5-9, 10-14), lane 15 of every row is idle;
+//          12 landmarks per wave.  The sums of a landmark form in its LAST lane (q = 4, the "leader"); what the other lanes need comes
+//          back through ds_bpermute.
+template <int LPP> struct ba2_map;
+template <> struct ba2_map<8> {
+  static constexpr int LPC = 8, LEAD = 0;
+  int pl, q; bool idle;
+  __device__ __forceinline__ ba2_map(int lane) : pl(lane >> 3), q(lane & 7), idle(false) {}
+};
+template <> struct ba2_map<5> {
+  static constexpr int LPC = 12, LEAD = 4;
+  int pl, q; bool idle;
+  __device__ __forceinline__ ba2_map(int lane) {
+    const int c = lane & 15, g = (c * 13) >> 6;      // c / 5 for c < 16
+    pl = 3 * (lane >> 4) + (g < 3 ? g : 2); q = c - 5 * g; idle = c == 15;
+    if (idle) q = 0;
+  }
+};
+
+// sum over the lanes of a landmark: everywhere (LPP = 8) / in the leader lane (LPP = 5: row_shr 1, 2, 4 -- the leader's five-term window
+// ends inside its own group; the other lanes hold partial or foreign sums nobody reads)
 template <int LPP>
-__device__ __forceinline__ double ba2_group_allreduce(double v) {
+__device__ __forceinline__ double ba2_group_sum(double v) {
   if (LPP == 8) return group8_allreduce(v);
-  v += dpp_f64<0xB1>(v);    // quad_perm [1, 0, 3, 2]
-  v += dpp_f64<0x4E>(v);    // quad_perm [2, 3, 0, 1]
-  return v;
+  double s = v + dpp_f64<0x111>(v);     // row_shr:1   v[l] + v[l-1]
+  s += dpp_f64<0x112>(s);               // row_shr:2   ... + v[l-2] + v[l-3]
+  return s + dpp_f64<0x114>(v);         // row_shr:4   ... + v[l-4]
+}
+// the leader's value in every lane of its group (LPP = 5); src4 = 4 * (lane index of the group's leader)
+template <int LPP>
+__device__ __forceinline__ double ba2_from_leader(double v, int src4) {
+  if (LPP == 8) return v;
+  const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(v));
+  return __hiloint2double(hi, lo);
 }
 
-// the landmark bits of the lane index that the per-chunk swap stages (bits 4 and 5) leave: bit 3 (LPP = 8), bits 3 and 2 (LPP = 4)
+// the landmark positions of the lane index that the per-chunk swap stages (lane bits 4 and 5) leave: bit 3 (LPP = 8); the three groups of a
+// row (LPP = 5: row_shl 5 and 10, valid in lanes 0..4 of a row)
 template <int LPP>
 __device__ __forceinline__ double ba2_finish_landmark_sum(double v) {
-  v += dpp_f64<0x128>(v);                 // row_ror:8
-  if (LPP == 4) v += dpp_f64<0x124>(v);   // row_ror:4
-  return v;
+  if (LPP == 8) return v + dpp_f64<0x128>(v);                 // row_ror:8
+  return v + dpp_f64<0x105>(v) + dpp_f64<0x10A>(v);           // row_shl:5, row_shl:10
 }
 
 // K R, K t, Jr of camera i into LDS from the 21 doubles [R | t | Jr] of d_camera
@@ -158,9 +190,11 @@ __device__ __forceinline__ void ba2_linearize(const double* __restrict__ K, cons
 // grid (G0 * batch), 256 lanes; partial set = the part of the problem a workgroup serves (ba2_select_work)
 template <int RT, int SPL, int LPP>
 __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_dev prm, int it, double probe_lambda, int G0, int Gcap) {
-  constexpr int LPC = 64 / LPP;              // landmarks of a chunk
+  constexpr int LPC = ba2_map<LPP>::LPC;     // landmarks of a chunk
+  constexpr int LEAD = ba2_map<LPP>::LEAD;   // the lane of a landmark's group that holds its sums
   constexpr int ROWS = 3 * LPC;              // panel rows of a chunk
-  constexpr int RP = 16 * RT, PITCH = RP + 16;   // + 16: the four rows an MFMA operand fetch touches lie on disjoint banks
+  constexpr int RP = 16 * RT, PITCH = RP + (LPP == 8 ? 16 : 0);   // + 16: the four rows an MFMA operand fetch touches lie on disjoint banks (12 landmarks
+                                                                  // per wave: no room for it -- two workgroups of 4 x 36 x 64 doubles fill a CU's LDS)
   constexpr int NT = RT * (RT + 1) / 2;
   constexpr int REGION = ROWS * PITCH;       // doubles of LDS a wave owns
   const ba2_work wk = ba2_select_work<true>(Pall, it, G0, Gcap);
@@ -209,8 +243,9 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
   // the panels start as zeros: the padding columns behind 6 W + 1 are never written afterwards
   for (int i = tid; i < 4 * REGION / 2; i += 256) reinterpret_cast<double2*>(dyn)[i] = make_double2(0.0, 0.0);
   __syncthreads();
-  VO_STAMP(dbgb, 1);
-  const int pl = lane / LPP, q = lane - pl * LPP;
+  const ba2_map<LPP> mp(lane);
+  const int pl = mp.pl, q = mp.q;
+  const int lead4 = 4 * (lane - q + LEAD);        // (LPP = 5) ds_bpermute source: the leader of this lane's group
   const int nchunk = (N + LPC - 1) / LPC;
   const int n_live = P.n_live ? *P.n_live : N;
   const int nchunk_live = min(nchunk, (n_live + LPC - 1) / LPC);
@@ -226,21 +261,33 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
   const double lam = st.lambda, delta = prm.delta;
   const double K0 = P.K[0], K1 = P.K[1], K2 = P.K[2], K3 = P.K[3], K4 = P.K[4], K5 = P.K[5], K6 = P.K[6], K7 = P.K[7], K8 = P.K[8];
   const double Kk[9] = {K0, K1, K2, K3, K4, K5, K6, K7, K8};
-#pragma unroll 1
-  for (int chunk = part * 4 + wave; chunk < nchunk; chunk += 4 * G) {
-    const int j = chunk * LPC + pl;
-    const bool inr = j < N;
-    double X[3] = {0.0, 0.0, 0.0};
-    if (inr) { X[0] = pts[3 * j]; X[1] = pts[3 * j + 1]; X[2] = pts[3 * j + 2]; }
-    if (seed_x && q == 0 && inr) { double* dst = P.xa + 6 * W + 3 * j; dst[0] = X[0]; dst[1] = X[1]; dst[2] = X[2]; }
-    if (chunk >= nchunk_live) continue;           // (wave-uniform) an unused part of the table: only x[0] is seeded
-    double uo[SPL], vo[SPL];
+  // this lane's landmark and observations of a chunk; the NEXT chunk's are requested before the Gram phase of this one (a trip to HBM / L2
+  // at the head of every chunk otherwise, with one other wave on the SIMD to cover it)
+  double Xn[3], uon[SPL], von[SPL];
+  auto fetch = [&](const int ch) {
+    const int jn = ch * LPC + pl;
+    Xn[0] = Xn[1] = Xn[2] = 0.0;
+    if (ch < nchunk && jn < N && !mp.idle) { Xn[0] = pts[3 * jn]; Xn[1] = pts[3 * jn + 1]; Xn[2] = pts[3 * jn + 2]; }
 #pragma unroll
     for (int i = 0; i < SPL; i++) {
       const int s = q + LPP * i;
-      uo[i] = __builtin_nan(""); vo[i] = 0.0;
-      if (s < W && inr) { const double2 ob = *reinterpret_cast<const double2*>(P.obs + ((size_t)s * N + j) * 2); uo[i] = ob.x; vo[i] = ob.y; }
+      uon[i] = __builtin_nan(""); von[i] = 0.0;
+      if (ch < nchunk_live && s < W && jn < N && !mp.idle) { const double2 ob = *reinterpret_cast<const double2*>(P.obs + ((size_t)s * N + jn) * 2); uon[i] = ob.x; von[i] = ob.y; }
     }
+  };
+  fetch(part * 4 + wave);
+  int nwalk = 0;
+#pragma unroll 1
+  for (int chunk = part * 4 + wave; chunk < nchunk; chunk += 4 * G) {
+    const int j = chunk * LPC + pl;
+    const bool inr = j < N && !mp.idle;
+    if (nwalk == 2) VO_STAMP(dbgb, 1);   // (diagnostic stamps 1..4: the third chunk of the walk, steady state)
+    const double X[3] = {Xn[0], Xn[1], Xn[2]};
+    double uo[SPL], vo[SPL];
+#pragma unroll
+    for (int i = 0; i < SPL; i++) { uo[i] = uon[i]; vo[i] = von[i]; }
+    if (seed_x && q == LEAD && inr) { double* dst = P.xa + 6 * W + 3 * j; dst[0] = X[0]; dst[1] = X[1]; dst[2] = X[2]; }
+    if (chunk >= nchunk_live) { fetch(chunk + 4 * G); continue; }      // (wave-uniform) an unused part of the table: only x[0] is seeded
     // ---- pass 1: residual, weight and landmark block of this lane's observations; landmark sums over its slots.  What pass 2 needs again is
     //      kept per slot as 7 values (u, v, 1 / p_2, w, e, rho): the Jacobian blocks of ALL slots of a lane (36 values each) do not fit the
     //      256 registers beside the 80 accumulators, and d(u, v)/dX is 12 operations to form again ----
@@ -279,29 +326,33 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
       g1 += wl0[1] * e0 + wl1[1] * e1;
       g2 += wl0[2] * e0 + wl1[2] * e1;
     }
-    h00 = ba2_group_allreduce<LPP>(h00); h10 = ba2_group_allreduce<LPP>(h10); h11 = ba2_group_allreduce<LPP>(h11);
-    h20 = ba2_group_allreduce<LPP>(h20); h21 = ba2_group_allreduce<LPP>(h21); h22 = ba2_group_allreduce<LPP>(h22);
-    g0 = ba2_group_allreduce<LPP>(g0); g1 = ba2_group_allreduce<LPP>(g1); g2 = ba2_group_allreduce<LPP>(g2);
+    h00 = ba2_group_sum<LPP>(h00); h10 = ba2_group_sum<LPP>(h10); h11 = ba2_group_sum<LPP>(h11);
+    h20 = ba2_group_sum<LPP>(h20); h21 = ba2_group_sum<LPP>(h21); h22 = ba2_group_sum<LPP>(h22);
+    g0 = ba2_group_sum<LPP>(g0); g1 = ba2_group_sum<LPP>(g1); g2 = ba2_group_sum<LPP>(g2);
     // ---- damped 3x3 block: Cholesky C C^T, Cinv = C^-1 (lower), y = Cinv g, z = Cinv^T y = M g ----
     const double a00 = h00 + lam * fmax(h00, 1e-12), a11 = h11 + lam * fmax(h11, 1e-12), a22 = h22 + lam * fmax(h22, 1e-12);
-    const double i00 = rsqrt_nr(a00);
+    double i00 = rsqrt_nr(a00);
     const double c10 = h10 * i00, c20 = h20 * i00;
-    const double i11 = rsqrt_nr(a11 - c10 * c10);
+    double i11 = rsqrt_nr(a11 - c10 * c10);
     const double c21 = (h21 - c20 * c10) * i11;
-    const double i22 = rsqrt_nr(a22 - c20 * c20 - c21 * c21);
-    const double i10 = -c10 * i00 * i11;
-    const double i21 = -c21 * i11 * i22;
-    const double i20 = -(c20 * i00 + c21 * i10) * i22;
+    double i22 = rsqrt_nr(a22 - c20 * c20 - c21 * c21);
+    double i10 = -c10 * i00 * i11;
+    double i21 = -c21 * i11 * i22;
+    double i20 = -(c20 * i00 + c21 * i10) * i22;
     const double y0 = i00 * g0, y1 = i10 * g0 + i11 * g1, y2 = i20 * g0 + i21 * g1 + i22 * g2;
-    if (chunk == 0) VO_STAMP(dbgb, 2);   // first chunk: pass 1 + factor
-    if (q == 0 && inr) {
+    if (nwalk == 2) VO_STAMP(dbgb, 2);   // pass 1 + factor
+    if (q == LEAD && inr) {
       double2* ax = reinterpret_cast<double2*>(P.aux + (size_t)j * BA_AUX);
       ax[0] = make_double2(h00, h10); ax[1] = make_double2(h11, h20); ax[2] = make_double2(h21, h22);
       ax[3] = make_double2(g0, g1); ax[4] = make_double2(g2, i00); ax[5] = make_double2(i10, i11);
       ax[6] = make_double2(i20, i21); ax[7] = make_double2(i22, i00 * y0 + i10 * y1 + i20 * y2);
       ax[8] = make_double2(i11 * y1 + i21 * y2, i22 * y2);
     }
-    if (inr) gm = fmax(gm, fmax(fabs(g0), fmax(fabs(g1), fabs(g2))));
+    if (inr && (LPP == 8 || q == LEAD)) gm = fmax(gm, fmax(fabs(g0), fmax(fabs(g1), fabs(g2))));
+    if (LPP != 8) {      // the factor of the landmark to every lane of its group
+      i00 = ba2_from_leader<LPP>(i00, lead4); i10 = ba2_from_leader<LPP>(i10, lead4); i11 = ba2_from_leader<LPP>(i11, lead4);
+      i20 = ba2_from_leader<LPP>(i20, lead4); i21 = ba2_from_leader<LPP>(i21, lead4); i22 = ba2_from_leader<LPP>(i22, lead4);
+    }
     // ---- pass 2, slot by slot: the camera block Jp = [(X x Jl_k)^T Jr | A], the slot's camera sums, the landmark's panel rows
     //      Y[a][c] = sum_k Jp[k][a] (w Z[k][c]),  Z = Jl Cinv^T;  column 6 W = y ----
     double* const rw0 = pan + (3 * pl) * PITCH;
@@ -340,7 +391,7 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
 #pragma unroll
       for (int n = 0; n < 7; n++)
         camacc[7 * i + n] += rs16_sum(rs32_sum(term(4 * n), term(4 * n + 1)), rs32_sum(term(4 * n + 2), term(4 * n + 3)));
-      if (sr < W) {
+      if (sr < W && !mp.idle) {
         double Z[2][3];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -357,12 +408,13 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
         }
       }
     }
-    if (q == 0) { rw0[6 * W] = inr ? y0 : 0.0; rw1[6 * W] = inr ? y1 : 0.0; rw2[6 * W] = inr ? y2 : 0.0; }
+    if (q == LEAD && !mp.idle) { rw0[6 * W] = inr ? y0 : 0.0; rw1[6 * W] = inr ? y1 : 0.0; rw2[6 * W] = inr ? y2 : 0.0; }
     // ---- Gram matrix of the chunk's panel into the accumulators: one operand fetch per column block and k-step ----
     //   A[i][k] = panel[k0 + k][16 ta + i]  (lane: i = l & 15, k = l >> 4),  B[k][j] = panel[k0 + k][16 tb + j]
     //   D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
     __builtin_amdgcn_wave_barrier();
-    if (chunk == 0) VO_STAMP(dbgb, 3);   // first chunk: pass 2, panel written
+    if (nwalk == 2) VO_STAMP(dbgb, 3);   // first chunk: pass 2, panel written
+    fetch(chunk + 4 * G);
     {
       const double* base = pan + (lane >> 4) * PITCH + (lane & 15);
 #pragma unroll
@@ -378,7 +430,8 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (chunk == 0) VO_STAMP(dbgb, 4);   // first chunk: Gram
+    if (nwalk == 2) VO_STAMP(dbgb, 4);
+    nwalk++;   // first chunk: Gram
   }
   VO_STAMP(dbgb, 5);   // walk
   // ---- after the walk: the landmark bits the chunk stages left, then the four waves' sums through LDS in wave order ----
@@ -394,7 +447,7 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
   {
     // writer lanes: the remaining landmark bits clear (every lane of a (b5, b4, q) class holds the same total)
     const int b5 = lane >> 5, b4 = (lane >> 4) & 1;
-    const bool wr = (LPP == 8) ? ((lane & 8) == 0) : ((lane & 12) == 0);
+    const bool wr = (LPP == 8) ? ((lane & 8) == 0) : ((lane & 15) < 5);
     if (wr) {
 #pragma unroll
       for (int i = 0; i < SPL; i++) {
@@ -437,15 +490,15 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
 // grid (G0 * batch), 256 lanes, the same assignment as k_ba_build_w of the iteration; step statistics: one entry of evalpart per part
 template <int SPL, int LPP>
 __global__ void __launch_bounds__(256, 2) k_ba_update_w(ba_ptrs Pall, ba_params_dev prm, int it, double* __restrict__ probe_dl, int G0, int Gcap) {
-  constexpr int LPC = 64 / LPP;
+  constexpr int LPC = ba2_map<LPP>::LPC, LEAD = ba2_map<LPP>::LEAD;
   const ba2_work wk = ba2_select_work<false>(Pall, it, G0, Gcap);
   if (wk.prob < 0) return;
   const ba_ptrs P = ba_select(Pall, wk.prob);
   const int part = wk.part, G = wk.G;
   if (wk.prob != 0) probe_dl = nullptr;
-  __shared__ double s_cam[BA2_CAM * LPP * SPL];     // current poses: K R, K t, Jr
-  __shared__ double s_camt[12 * LPP * SPL];         // trial poses: K R, K t
-  __shared__ double s_dp[6 * LPP * SPL];
+  __shared__ double s_cam[BA2_CAM * 10];            // current poses: K R, K t, Jr (windows of <= 10 slots)
+  __shared__ double s_camt[12 * 10];                // trial poses: K R, K t
+  __shared__ double s_dp[6 * 10];
   __shared__ double s_red[4 * BA_EVAL_VALS];
   const ba_state st = P.state[it & 1];
   if (st.done) return;
@@ -473,7 +526,9 @@ __global__ void __launch_bounds__(256, 2) k_ba_update_w(ba_ptrs Pall, ba_params_
     if (part == 0) tposes[a] = poses[a] + d;
   }
   __syncthreads();
-  const int pl = lane / LPP, q = lane - pl * LPP;
+  const ba2_map<LPP> mp(lane);
+  const int pl = mp.pl, q = mp.q;
+  const int lead4 = 4 * (lane - q + LEAD);
   const int nchunk = (N + LPC - 1) / LPC;
   const int n_live = P.n_live ? *P.n_live : N;
   const int nchunk_live = min(nchunk, (n_live + LPC - 1) / LPC);
@@ -483,7 +538,7 @@ __global__ void __launch_bounds__(256, 2) k_ba_update_w(ba_ptrs Pall, ba_params_
 #pragma unroll 1
   for (int chunk = part * 4 + wave; chunk < nchunk_live; chunk += 4 * G) {
     const int j = chunk * LPC + pl;
-    const bool inr = j < N;
+    const bool inr = j < N && !mp.idle;
     double X[3] = {0.0, 0.0, 0.0};
     if (inr) { X[0] = pts[3 * j]; X[1] = pts[3 * j + 1]; X[2] = pts[3 * j + 2]; }
     double uo[SPL], vo[SPL];
@@ -521,7 +576,8 @@ __global__ void __launch_bounds__(256, 2) k_ba_update_w(ba_ptrs Pall, ba_params_
       v1 += o.w * (o.Jl[0][1] * q0 + o.Jl[1][1] * q1);
       v2 += o.w * (o.Jl[0][2] * q0 + o.Jl[1][2] * q1);
     }
-    v0 = ba2_group_allreduce<LPP>(v0); v1 = ba2_group_allreduce<LPP>(v1); v2 = ba2_group_allreduce<LPP>(v2);
+    v0 = ba2_from_leader<LPP>(ba2_group_sum<LPP>(v0), lead4); v1 = ba2_from_leader<LPP>(ba2_group_sum<LPP>(v1), lead4);
+    v2 = ba2_from_leader<LPP>(ba2_group_sum<LPP>(v2), lead4);
     const double w0 = ax[6] + v0, w1 = ax[7] + v1, w2 = ax[8] + v2;
     const double i00 = ax[9], i10 = ax[10], i11 = ax[11], i20 = ax[12], i21 = ax[13], i22 = ax[14];
     const double t0 = i00 * w0, t1 = i10 * w0 + i11 * w1, t2 = i20 * w0 + i21 * w1 + i22 * w2;   // Cinv u
@@ -542,7 +598,7 @@ __global__ void __launch_bounds__(256, 2) k_ba_update_w(ba_ptrs Pall, ba_params_
       const double irs = rsqrt_nr(inl ? 1.0 : sq);
       e0 += 0.5 * (inl ? sq : 2.0 * delta * (sq * irs) - d2);
     }
-    if (q == 0 && inr) {
+    if (q == LEAD && inr) {
       tpts[3 * j] = Xt[0]; tpts[3 * j + 1] = Xt[1]; tpts[3 * j + 2] = Xt[2];
       if (probe_dl) { probe_dl[3 * j] = dl0; probe_dl[3 * j + 1] = dl1; probe_dl[3 * j + 2] = dl2; }
       e1 += lam * (fmax(ax[0], 1e-12) * dl0 * dl0 + fmax(ax[2], 1e-12) * dl1 * dl1 + fmax(ax[5], 1e-12) * dl2 * dl2)
