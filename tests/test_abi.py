@@ -66,6 +66,17 @@ def test_product_does_not_import_the_oracle():
                 assert not bad, (f, bad)
 
 
+def test_oracle_does_not_import_the_product():
+    """the checker stands on its own: nothing under oracle/ imports the package it checks (round-4 review: pipe_oracle.py took its SO(3)
+    log map from vo_mi355x.so3)"""
+    for dp, _, files in os.walk(os.path.join(ROOT, "oracle")):
+        for f in files:
+            if f.endswith((".py", ".c", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                bad = re.findall(r"^\s*(?:import|from)\s+vo_mi355x\b|#include\s+\"[^\"]*vo_mi355x", txt, flags=re.M)
+                assert not bad, (f, bad)
+
+
 def test_synthetic_generators():
     from vo_mi355x import synthetic as syn
     fr, mo = syn.make_sequence(2, w=160, h=120, margin=48)

@@ -1324,10 +1324,11 @@ static void ba_geometry(vo_ba_ws* b, int W, int N) {
   if (const char* e = getenv("VO_BA_V2")) b->v2 = (W <= 10 && atoi(e) != 0) ? 1 : 0;
   b->v2_rt = b->RT; b->v2_spl = (W + 7) / 8;
   // windows of 9 and 10 slots: 5 lanes per landmark (12 landmarks per wave), else 8 (VO_BA_LPP5=0: 8 for every window, A/B knob)
-  b->v2_lpp = (b->v2_spl == 2) ? 5 : 8;
+  // and 4 for windows of <= 4 slots (16 landmarks per wave)
+  b->v2_lpp = (b->v2_spl == 2) ? 5 : (W <= 4) ? 4 : 8;
   if (const char* e = getenv("VO_BA_LPP5")) { if (atoi(e) == 0) b->v2_lpp = 8; }
   b->v2_lds = b->v2_lpp == 5 ? sizeof(double) * ((size_t)4 * 36 * (16 * b->v2_rt) + (size_t)BA2_CAM * W)
-                             : sizeof(double) * ((size_t)4 * 24 * (16 * b->v2_rt + 16) + (size_t)BA2_CAM * W);
+                             : sizeof(double) * ((size_t)4 * 3 * (64 / b->v2_lpp) * (16 * b->v2_rt + 16) + (size_t)BA2_CAM * W);
   const int n1 = 6 * W + 1, PT = n1 | 1;
   b->solve_lds = sizeof(double) * ((size_t)n1 * PT + (size_t)W * BA_POSE_VALS + n1 + n1 + 24 + (size_t)21 * W) + sizeof(unsigned short) * ((size_t)n1 * (n1 + 1) / 2 + 8);
 }
@@ -1393,6 +1394,7 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build_w<4, 2, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build_w<2, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   }
   ba_geometry(c->ba, W, N);
   VO_CHECK(c, c->ba->build_lds <= 130 * 1024 && c->ba->solve_lds <= 150 * 1024, VO_E_CAPACITY, "window too large for LDS");
@@ -1469,7 +1471,7 @@ static ba_ptrs ba_make_ptrs(const vo_ctx* c) {
   if (b->v2) {
     // G workgroups (4 waves each) per problem: enough for BA2_TARGET_WAVES waves in the launch, at most one chunk (8 landmarks) per wave.
     // VO_BA_G overrides (experiment knob).  The partial sums depend on G like the older kernels' on the chunks per workgroup.
-    const int nchunk = vo_div_up(b->N, b->v2_lpp == 5 ? 12 : 8), gmax = vo_div_up(nchunk, 4);
+    const int nchunk = vo_div_up(b->N, b->v2_lpp == 5 ? 12 : 64 / b->v2_lpp), gmax = vo_div_up(nchunk, 4);
     int G = vo_div_up(BA2_TARGET_WAVES, 4 * c->batch);
     if (const char* e = getenv("VO_BA_G")) { if (atoi(e) > 0) G = atoi(e); }
     if (G > gmax) G = gmax;
@@ -1555,7 +1557,9 @@ static int32_t ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& 
     else if (b->v2_spl == 2) hipLaunchKernelGGL((k_ba_build_w<4, 2, 8>), g, dim3(256), b->v2_lds, c->stream, P, prm, it, probe_lambda, g0, gc);
     else if (b->v2_rt == 4) hipLaunchKernelGGL((k_ba_build_w<4, 1, 8>), g, dim3(256), b->v2_lds, c->stream, P, prm, it, probe_lambda, g0, gc);
     else if (b->v2_rt == 3) hipLaunchKernelGGL((k_ba_build_w<3, 1, 8>), g, dim3(256), b->v2_lds, c->stream, P, prm, it, probe_lambda, g0, gc);
+    else if (b->v2_rt == 2 && b->v2_lpp == 4) hipLaunchKernelGGL((k_ba_build_w<2, 1, 4>), g, dim3(256), b->v2_lds, c->stream, P, prm, it, probe_lambda, g0, gc);
     else if (b->v2_rt == 2) hipLaunchKernelGGL((k_ba_build_w<2, 1, 8>), g, dim3(256), b->v2_lds, c->stream, P, prm, it, probe_lambda, g0, gc);
+    else if (b->v2_lpp == 4) hipLaunchKernelGGL((k_ba_build_w<1, 1, 4>), g, dim3(256), b->v2_lds, c->stream, P, prm, it, probe_lambda, g0, gc);
     else hipLaunchKernelGGL((k_ba_build_w<1, 1, 8>), g, dim3(256), b->v2_lds, c->stream, P, prm, it, probe_lambda, g0, gc);
   } else if (b->tpb == 256 && b->LPP == 8) hipLaunchKernelGGL((k_ba_build<256, 8>), dim3(P.nset, B), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
   else if (b->tpb == 256) hipLaunchKernelGGL(k_ba_build<256>, dim3(P.nset, B), dim3(256), b->build_lds, c->stream, P, prm, it, probe_lambda);
@@ -1572,6 +1576,7 @@ static int32_t ba_launch_iter(vo_ctx* c, const ba_ptrs& P, const ba_params_dev& 
   if (b->v2) {
     if (b->v2_spl == 2 && b->v2_lpp == 5) hipLaunchKernelGGL((k_ba_update_w<2, 5>), dim3(b->v2_g0 * B), dim3(256), 0, c->stream, P, prm, it, probe_dl, b->v2_g0, b->v2_gcap);
     else if (b->v2_spl == 2) hipLaunchKernelGGL((k_ba_update_w<2, 8>), dim3(b->v2_g0 * B), dim3(256), 0, c->stream, P, prm, it, probe_dl, b->v2_g0, b->v2_gcap);
+    else if (b->v2_lpp == 4) hipLaunchKernelGGL((k_ba_update_w<1, 4>), dim3(b->v2_g0 * B), dim3(256), 0, c->stream, P, prm, it, probe_dl, b->v2_g0, b->v2_gcap);
     else hipLaunchKernelGGL((k_ba_update_w<1, 8>), dim3(b->v2_g0 * B), dim3(256), 0, c->stream, P, prm, it, probe_dl, b->v2_g0, b->v2_gcap);
   } else if (b->tpb == 256 && b->LPP == 8) hipLaunchKernelGGL((k_ba_update<256, 8>), dim3(b->nblk, B), dim3(256), 0, c->stream, P, prm, it, probe_dl);
   else if (b->tpb == 256) hipLaunchKernelGGL(k_ba_update<256>, dim3(b->nblk, B), dim3(256), 0, c->stream, P, prm, it, probe_dl);

@@ -48,6 +48,11 @@ template <> struct ba2_map<8> {
   int pl, q; bool idle;
   __device__ __forceinline__ ba2_map(int lane) : pl(lane >> 3), q(lane & 7), idle(false) {}
 };
+template <> struct ba2_map<4> {      // windows of <= 4 slots (the reference's own window): 16 landmarks per wave
+  static constexpr int LPC = 16, LEAD = 0;
+  int pl, q; bool idle;
+  __device__ __forceinline__ ba2_map(int lane) : pl(lane >> 2), q(lane & 3), idle(false) {}
+};
 template <> struct ba2_map<5> {
   static constexpr int LPC = 12, LEAD = 4;
   int pl, q; bool idle;
@@ -63,6 +68,7 @@ template <> struct ba2_map<5> {
 template <int LPP>
 __device__ __forceinline__ double ba2_group_sum(double v) {
   if (LPP == 8) return group8_allreduce(v);
+  if (LPP == 4) { v += dpp_f64<0xB1>(v); return v + dpp_f64<0x4E>(v); }     // quad_perm [1, 0, 3, 2], [2, 3, 0, 1]
   double s = v + dpp_f64<0x111>(v);     // row_shr:1   v[l] + v[l-1]
   s += dpp_f64<0x112>(s);               // row_shr:2   ... + v[l-2] + v[l-3]
   return s + dpp_f64<0x114>(v);         // row_shr:4   ... + v[l-4]
@@ -70,7 +76,7 @@ __device__ __forceinline__ double ba2_group_sum(double v) {
 // the leader's value in every lane of its group (LPP = 5); src4 = 4 * (lane index of the group's leader)
 template <int LPP>
 __device__ __forceinline__ double ba2_from_leader(double v, int src4) {
-  if (LPP == 8) return v;
+  if (LPP != 5) return v;
   const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(v));
   const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(v));
   return __hiloint2double(hi, lo);
@@ -81,6 +87,7 @@ __device__ __forceinline__ double ba2_from_leader(double v, int src4) {
 template <int LPP>
 __device__ __forceinline__ double ba2_finish_landmark_sum(double v) {
   if (LPP == 8) return v + dpp_f64<0x128>(v);                 // row_ror:8
+  if (LPP == 4) { v += dpp_f64<0x128>(v); return v + dpp_f64<0x124>(v); }   // row_ror:8, row_ror:4
   return v + dpp_f64<0x105>(v) + dpp_f64<0x10A>(v);           // row_shl:5, row_shl:10
 }
 
@@ -193,7 +200,7 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
   constexpr int LPC = ba2_map<LPP>::LPC;     // landmarks of a chunk
   constexpr int LEAD = ba2_map<LPP>::LEAD;   // the lane of a landmark's group that holds its sums
   constexpr int ROWS = 3 * LPC;              // panel rows of a chunk
-  constexpr int RP = 16 * RT, PITCH = RP + (LPP == 8 ? 16 : 0);   // + 16: the four rows an MFMA operand fetch touches lie on disjoint banks (12 landmarks
+  constexpr int RP = 16 * RT, PITCH = RP + (LPP != 5 ? 16 : 0);   // + 16: the four rows an MFMA operand fetch touches lie on disjoint banks (12 landmarks
                                                                   // per wave: no room for it -- two workgroups of 4 x 36 x 64 doubles fill a CU's LDS)
   constexpr int NT = RT * (RT + 1) / 2;
   constexpr int REGION = ROWS * PITCH;       // doubles of LDS a wave owns
@@ -348,8 +355,8 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
       ax[6] = make_double2(i20, i21); ax[7] = make_double2(i22, i00 * y0 + i10 * y1 + i20 * y2);
       ax[8] = make_double2(i11 * y1 + i21 * y2, i22 * y2);
     }
-    if (inr && (LPP == 8 || q == LEAD)) gm = fmax(gm, fmax(fabs(g0), fmax(fabs(g1), fabs(g2))));
-    if (LPP != 8) {      // the factor of the landmark to every lane of its group
+    if (inr && (LPP != 5 || q == LEAD)) gm = fmax(gm, fmax(fabs(g0), fmax(fabs(g1), fabs(g2))));
+    if (LPP == 5) {      // the factor of the landmark to every lane of its group
       i00 = ba2_from_leader<LPP>(i00, lead4); i10 = ba2_from_leader<LPP>(i10, lead4); i11 = ba2_from_leader<LPP>(i11, lead4);
       i20 = ba2_from_leader<LPP>(i20, lead4); i21 = ba2_from_leader<LPP>(i21, lead4); i22 = ba2_from_leader<LPP>(i22, lead4);
     }
@@ -447,7 +454,7 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
   {
     // writer lanes: the remaining landmark bits clear (every lane of a (b5, b4, q) class holds the same total)
     const int b5 = lane >> 5, b4 = (lane >> 4) & 1;
-    const bool wr = (LPP == 8) ? ((lane & 8) == 0) : ((lane & 15) < 5);
+    const bool wr = (LPP == 8) ? ((lane & 8) == 0) : (LPP == 4) ? ((lane & 12) == 0) : ((lane & 15) < 5);
     if (wr) {
 #pragma unroll
       for (int i = 0; i < SPL; i++) {
