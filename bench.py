@@ -822,6 +822,22 @@ def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
                                                   "--seqs 96 --ctxs 3 --side-stream on --host-threads 3 --no-extras --no-cpu-baseline` run as a child process"}
     except Exception as e:      # noqa: BLE001
         out["layout_3_contexts_of_32"] = {"error": str(e)}
+    # BASELINE configs[4] at N = 1 (ONE 1920x1080 sequence, 5000 points, 20-frame BA through a 1-rank communicator): the anchor a multi-GPU
+    # run of `--workload config5` is compared with (child process: the workload rebinds the module's shape constants)
+    try:
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "config5", "--steps", "60", "--warmup", "10", "--regions", "3", "--no-extras",
+               "--no-cpu-baseline", "--ba-iters", str(a.ba_iters)]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                                "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+        pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env)
+        d5 = json.loads([l for l in pr.stdout.decode().splitlines() if l.startswith("{")][-1])
+        out["config5_n1"] = {"frames_per_s": d5["value"], "ms_per_step": d5["ms_per_step"], "n_gpus": 1, "workload": d5["config"]["workload"],
+                             "ba_lm_iterations_run": d5["config"].get("ba_lm_iterations_run"), "stage_ms": d5.get("stage_ms_per_batched_launch_group"),
+                             "what": "`python bench.py --workload config5 --no-extras --no-cpu-baseline` on one GPU: the landmark-sharded solve with ONE shard "
+                                     "(k_ba_xsum / k_ba_xstat + the 1-rank RCCL all-reduces in every LM iteration); N > 1 has never run on this pool"}
+    except Exception as e:      # noqa: BLE001
+        out["config5_n1"] = {"error": str(e)}
     kl = {}
     for batch in (1, 32):
         gk = g if batch == 1 else Group(device, frame_sets, seed0=7100, batch=32, ba_iters=a.ba_iters)
@@ -848,11 +864,16 @@ def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
         # the same with tables the scene does not fill (8 192 slots; the scene's steady state is ~4 400 keypoints): the loop measured is then the
         # reference's unbounded lists, not the capacity policy's (capacity_policy_frames.detection = 0 after the fill-up)
         a4big = _copy.copy(a4); a4big.pipe_max_pts = 8192
+        a4ad = _copy.copy(a4); a4ad.pipe_adaptive_budget = True
         out["pipeline_step"] = {"reference_configuration_window4": run_pipeline(device, a4, dist, 1, 96, 40, 10, 3, scenes),
                                 # (96 sequences: the batch rounds 2-3 reported; 256: the batch of the headline since the end of round 4)
                                 "reference_configuration_window4_256_sequences": run_pipeline(device, a4, dist, 1, 256, 40, 10, 3, scenes),
                                 "window10_dead_stay_dead": run_pipeline(device, a10, dist, 1, 96, 40, 10, 3, scenes),
+                                "closed_loop_window10_256_sequences": run_pipeline(device, a10, dist, 1, 256, 40, 10, 3, scenes),
                                 "one_sequence_window4": run_pipeline(device, a4, dist, 1, 1, 100, 10, 3, scenes),
+                                # the same with the LM launch groups bounded by what the newest fetched frame needed + 2 (3 .. --ba-iters)
+                                # instead of --ba-iters blind groups every frame: `ba_solves_cut_by_the_budget` counts what that changed
+                                "one_sequence_window4_adaptive_budget": run_pipeline(device, a4ad, dist, 1, 1, 100, 10, 3, scenes),
                                 "window4_tables_not_full_8192_slots": run_pipeline(device, a4big, dist, 1, 32, 40, 60, 3, scenes)}
         if cpu_pipe is not None:
             out["pipeline_step"]["reference_configuration_window4"]["cpu_baseline"] = cpu_pipe
@@ -896,6 +917,52 @@ def profile_constant(fname, key):
 VALU_ISSUE_PER_CLK_PER_SIMD = 0.5     # MI355X_MICROARCH.md: a wave64 VALU instruction passes a SIMD-32 in 2 cycles (full-rate ops)
 N_SIMDS, CLK_HZ = 1024, 2.4e9         # 256 CUs x 4 SIMDs, 2.4 GHz peak clock
 MIXED_CLK_PER_INST, MIXED_CLK_HZ = 4.1, 2.37e9    # tools/issue_probe.hip, "klt mix" rows (profiles/r02_issue_probe.txt)
+
+
+def kernel_rooflines():
+    """per-kernel figures of the default command from the committed rocprofv3 summaries (profiles/kernel_counters.json, written by
+    tools/profile_round.sh + tools/summarize_profiles.py; every number is recomputable from the <tag>_kernel_stats_default.csv and
+    <tag>_pmc_*_default.csv beside it): share of the kernel time, average launch, HBM bytes per launch against the 8 TB/s peak, vector
+    wave-instructions per launch against the SIMDs' nominal issue rate, float64 MFMA flops and MfmaUtil.  Stale (measured on other kernel
+    sources) -> reported as such, never as current."""
+    path = os.path.join(ROOT, "profiles", "kernel_counters.json")
+    if not os.path.exists(path):
+        return {"source": "profiles/kernel_counters.json missing", "kernels": []}
+    d = json.load(open(path))
+    import hashlib
+    h = hashlib.sha256()
+    cs = os.path.join(ROOT, "visual-odom-pipeline_amd", "csrc")
+    for n in sorted(os.listdir(cs)):
+        if n.endswith((".hip", ".h")):
+            with open(os.path.join(cs, n), "rb") as f:
+                h.update(f.read())
+    stale = d.get("csrc_sha256_16") != h.hexdigest()[:16]
+    peak_issue = VALU_ISSUE_PER_CLK_PER_SIMD * N_SIMDS * CLK_HZ
+    out = []
+    for e in d.get("kernels", []):
+        t = e["avg_launch_us"] * 1e-6
+        r = {"kernel": e["kernel"], "pct_of_kernel_time": e["pct_of_kernel_time"], "avg_launch_us": round(e["avg_launch_us"], 2), "calls": e["calls"]}
+        if "hbm_bytes_per_launch" in e:
+            r["hbm_bytes_per_launch"] = e["hbm_bytes_per_launch"]
+            r["hbm_gb_s"] = round(e["hbm_bytes_per_launch"] / t / 1e9, 1)
+            r["hbm_frac"] = round(e["hbm_bytes_per_launch"] / t / 1e9 / HBM_PEAK_GBS, 4)
+        if "valu_insts_per_launch" in e:
+            r["valu_wave_insts_per_launch"] = int(e["valu_insts_per_launch"])
+            r["valu_issue_frac"] = round(e["valu_insts_per_launch"] / t / peak_issue, 4)
+            r["valu_issue_frac_of_quarter_rate_roof"] = round(e["valu_insts_per_launch"] / t / (N_SIMDS * MIXED_CLK_HZ / MIXED_CLK_PER_INST), 4)
+        if "mfma_flops_f64_per_launch" in e and e["mfma_flops_f64_per_launch"] > 0:
+            r["mfma_util_pct_mean"], r["mfma_util_pct_max"] = e["mfma_util_pct_mean"], e["mfma_util_pct_max"]
+            r["mfma_f64_tflops"] = round(e["mfma_flops_f64_per_launch"] / t / 1e12, 2)
+            r["mfma_f64_frac_of_78.6_tflops"] = round(e["mfma_flops_f64_per_launch"] / t / 78.6e12, 4)
+        out.append(r)
+    return {"source": "profiles/kernel_counters.json (%s)%s" % (d.get("measured"), "; STALE: the kernel sources changed since" if stale else ""),
+            "files": d.get("files"), "stale": stale,
+            "how": "avg_launch_us, pct: rocprofv3 --kernel-trace --stats of the default command (launches averaged over full and tail LM groups); "
+                   "hbm = (2 x FETCH_SIZE + WRITE_SIZE) KB per launch / avg launch / 8 TB/s; valu_issue_frac = SQ_INSTS_VALU per launch / avg launch "
+                   "/ (0.5 wave-instruction per clk per SIMD x 1024 x 2.4 GHz); quarter-rate roof = 1 / 4.1 clk at 2.37 GHz (float64, dot, DPP, perm: "
+                   "profiles/r02_issue_probe.txt); a float64 MFMA occupies its SIMD like 14 such instructions and does not overlap with them "
+                   "(profiles/r05_mfma_overlap_probe.txt)",
+            "kernels": out}
 
 
 def valu_roofline(launch_s, n_waves):
@@ -1193,6 +1260,7 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "valu": valu,
                 "avg_launch_us": round(klt_avg_s * 1e6, 3), "algorithmic_bytes_per_launch": int(klt_bytes),
                 "klt_mean_iters_per_level": [round(x, 3) for x in it_mean],
+                "kernels": kernel_rooflines(),
                 # the same launch when context 0 runs its steps alone after the timed region (no other context's kernels beside it)
                 "alone_avg_launch_us": round(stage["klt"] * 1e3, 3),
                 "alone_frac": round(klt_bytes / max(stage["klt"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 5),

@@ -58,6 +58,14 @@ typedef struct {
   int32_t block_size;        /* 31   */
   double  quality_level;     /* 0.03 */
   double  min_distance;      /* min_kp_dist (7 in src/pipeline/pipeline.py:21,27) */
+  int32_t use_harris;        /* 0: cv2.goodFeaturesToTrack's default response, the minimum eigenvalue (what the reference runs: its parameter
+                                dict extractor.py:21-24 leaves useHarrisDetector at False); 1: useHarrisDetector=True -- the response becomes
+                                a c - b^2 - harris_k (a + c)^2 over the same box-filtered Sobel products without the 1/2 factors
+                                (imgproc/corner.cpp calcHarris), everything after the response map is unchanged.
+                                A frame whose largest masked response is not positive yields no corners here (OpenCV would rank negative
+                                responses). */
+  int32_t _pad;
+  double  harris_k;          /* 0.04 (OpenCV default) */
 } vo_st_params;
 
 /* BundleAdjuster configuration, src/bundle_adjuster/bundle_adjuster.py:8-16 and

@@ -44,7 +44,8 @@ class OracleContext:
                 o.circle_mask(m, (x, y), mask_radius, 0)
         elif mask is not None:
             m = np.asarray(mask, np.uint8)
-        return o.good_features(self._cur, m, prm.max_corners, prm.quality_level, prm.min_distance, prm.block_size)
+        return o.good_features(self._cur, m, prm.max_corners, prm.quality_level, prm.min_distance, prm.block_size,
+                               useHarrisDetector=bool(getattr(prm, "use_harris", 0)), k=getattr(prm, "harris_k", 0.04))
 
     def triangulate(self, P0, P1, uv0, uv1, K=None, H0=None, H1=None):
         X4 = o.triangulate(P0, P1, uv0, uv1)

@@ -139,10 +139,9 @@ def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts, winSize=(21, 21), m
 
 def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask=None,
                         blockSize=3, useHarrisDetector=False, k=0.04):
-    if useHarrisDetector:
-        raise NotImplementedError
-    pts = _need_backend("goodFeaturesToTrack").good_features(
-        image, mask, maxCorners, qualityLevel, minDistance, blockSize)
+    be = _need_backend("goodFeaturesToTrack")
+    pts = (be.good_features(image, mask, maxCorners, qualityLevel, minDistance, blockSize, useHarrisDetector=True, k=k) if useHarrisDetector
+           else be.good_features(image, mask, maxCorners, qualityLevel, minDistance, blockSize))
     if pts.shape[0] == 0:
         return None
     return pts.reshape(-1, 1, 2)

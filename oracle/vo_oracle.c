@@ -339,7 +339,20 @@ void vo_oracle_circle_rows(int radius, int* halfw /* radius+1 entries */) {
 /* ------------------------------------------------------------------------- */
 /* cornerMinEigenVal(img, blockSize, ksize=3) (imgproc/corner.cpp)             */
 /* ------------------------------------------------------------------------- */
+/* harris != 0: cornerHarris(img, blockSize, 3, k) -- the response goodFeaturesToTrack(useHarrisDetector=True, k) ranks (the reference
+ * leaves it off, extractor.py:21-24).  Same Sobel scale and box sums (cornerEigenValsVecs), then calcHarris
+ * (scalar form): a = cov_xx, b = cov_xy, c = cov_yy WITHOUT the halves, dst = (float)(a * c - b * b - k * (a + c) * (a + c)) with float
+ * a, b, c and double k -- the first difference is float arithmetic, the k term double.                                            */
+static inline float corner_value(float sxx, float sxy, float syy, int harris, double k) {
+  if (harris) { const float a = sxx, b = sxy, c = syy; return (float)((double)(a * c - b * b) - k * (double)(a + c) * (double)(a + c)); }
+  const float a = sxx * 0.5f, b = sxy, c = syy * 0.5f;
+  return (a + c) - sqrtf((a - c) * (a - c) + b * b);
+}
+void vo_oracle_corner_response(const uint8_t* img, int w, int h, int block, float* eig, int exact_int, int harris, double harris_k);
 void vo_oracle_min_eig(const uint8_t* img, int w, int h, int block, float* eig, int exact_int) {
+  vo_oracle_corner_response(img, w, h, block, eig, exact_int, 0, 0.04);
+}
+void vo_oracle_corner_response(const uint8_t* img, int w, int h, int block, float* eig, int exact_int, int harris, double harris_k) {
   const double scale_d = 1.0 / ((double)(1 << 2) * block * 255.0);
   const float sf = (float)scale_d;
   const int r = block / 2; /* anchor = centre; block odd */
@@ -379,8 +392,7 @@ void vo_oracle_min_eig(const uint8_t* img, int w, int h, int block, float* eig, 
           size_t q = (size_t)reflect101(y + j, h) * w + x;
           sa += hxx[q]; sb += hxy[q]; sc += hyy[q];
         }
-        float a = ((float)sa * s2) * 0.5f, b = (float)sb * s2, c = ((float)sc * s2) * 0.5f;
-        eig[(size_t)y * w + x] = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+        eig[(size_t)y * w + x] = corner_value((float)sa * s2, (float)sb * s2, (float)sc * s2, harris, harris_k);
       }
     free(pxx); free(pxy); free(pyy); free(hxx); free(hxy); free(hyy);
   } else {
@@ -428,8 +440,7 @@ void vo_oracle_min_eig(const uint8_t* img, int w, int h, int block, float* eig, 
           v[ch] = s0;
           sum[x * 3 + ch] = s0 - sm[x * 3 + ch];
         }
-        float a = v[0] * 0.5f, b = v[1], c = v[2] * 0.5f;
-        eig[(size_t)y * w + x] = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+        eig[(size_t)y * w + x] = corner_value(v[0], v[1], v[2], harris, harris_k);
       }
     }
     free(cov); free(rs); free(sum);
@@ -455,10 +466,10 @@ static int cand_cmp(const void* pa, const void* pb) {
  */
 int vo_oracle_good_features(const uint8_t* img, const uint8_t* mask, int w, int h, int max_corners,
                             double quality, double min_distance, int block, int exact_int,
-                            float* out_xy, float* eig_buf, int* n_cand_out) {
+                            float* out_xy, float* eig_buf, int* n_cand_out, int use_harris, double harris_k) {
   size_t np = (size_t)w * h;
   float* eig = eig_buf ? eig_buf : (float*)malloc(np * sizeof(float));
-  vo_oracle_min_eig(img, w, h, block, eig, exact_int);
+  vo_oracle_corner_response(img, w, h, block, eig, exact_int, use_harris, harris_k);
   double maxVal = 0; /* minMaxLoc over mask != 0 */
   int any = 0;
   for (size_t i = 0; i < np; i++)

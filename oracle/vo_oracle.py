@@ -48,8 +48,10 @@ def lib():
         L.vo_oracle_circle_rows.restype = None
         L.vo_oracle_min_eig.argtypes = [u8p, C.c_int, C.c_int, C.c_int, f32p, C.c_int]
         L.vo_oracle_min_eig.restype = None
+        L.vo_oracle_corner_response.argtypes = [u8p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_double]
+        L.vo_oracle_corner_response.restype = None
         L.vo_oracle_good_features.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
-                                              C.c_int, C.c_int, f32p, f32p, i32p]
+                                              C.c_int, C.c_int, f32p, f32p, i32p, C.c_int, C.c_double]
         L.vo_oracle_good_features.restype = C.c_int
         L.vo_oracle_triangulate.argtypes = [f32p, f32p, f32p, f32p, C.c_int, f32p]
         L.vo_oracle_bilateral.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, u8p]
@@ -142,8 +144,17 @@ def min_eig(img, block=31, exact_int=True):
     return out
 
 
+def harris(img, block=31, k=0.04, exact_int=True):
+    """cv2.cornerHarris(img, block, 3, k): the response goodFeaturesToTrack(useHarrisDetector=True) ranks"""
+    img = _img(img)
+    h, w = img.shape
+    out = np.empty((h, w), np.float32)
+    lib().vo_oracle_corner_response(_p(img, C.c_uint8), w, h, block, _p(out, C.c_float), int(exact_int), 1, float(k))
+    return out
+
+
 def good_features(img, mask, maxCorners=1000, qualityLevel=0.03, minDistance=7, blockSize=31,
-                  exact_int=True, return_aux=False):
+                  exact_int=True, return_aux=False, useHarrisDetector=False, k=0.04):
     img = _img(img)
     h, w = img.shape
     mp = None
@@ -157,7 +168,7 @@ def good_features(img, mask, maxCorners=1000, qualityLevel=0.03, minDistance=7, 
     nc = np.zeros(1, np.int32)
     n = lib().vo_oracle_good_features(_p(img, C.c_uint8), mp, w, h, int(maxCorners), float(qualityLevel),
                                       float(minDistance), int(blockSize), int(exact_int), _p(out, C.c_float),
-                                      _p(eig, C.c_float), _p(nc, C.c_int32))
+                                      _p(eig, C.c_float), _p(nc, C.c_int32), 1 if useHarrisDetector else 0, float(k))
     if return_aux:
         return out[:n].copy(), eig, int(nc[0])
     return out[:n].copy()

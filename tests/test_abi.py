@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from vo_mi355x import _lib
-    assert ctypes.sizeof(_lib.KltParams) == 32 and ctypes.sizeof(_lib.StParams) == 24
+    assert ctypes.sizeof(_lib.KltParams) == 32 and ctypes.sizeof(_lib.StParams) == 40
     assert ctypes.sizeof(_lib.BaParams) == 56 and ctypes.sizeof(_lib.BaStats) == 40
     assert ctypes.sizeof(_lib.PnpParams) == 24 and ctypes.sizeof(_lib.PnpStats) == 24
     assert ctypes.sizeof(_lib.EssParams) == 32 and ctypes.sizeof(_lib.EssStats) == 24 and ctypes.sizeof(_lib.SiftKp) == 24
@@ -40,6 +40,7 @@ def test_struct_layouts_match_header():
     assert (k.win, k.max_level, k.max_count) == (31, 3, 30) and abs(k.epsilon - 0.03) < 1e-15
     s = _lib.StParams(); L.vo_st_default_params(ctypes.byref(s))
     assert (s.max_corners, s.block_size) == (1000, 31) and s.quality_level == 0.03 and s.min_distance == 7.0
+    assert s.use_harris == 0 and s.harris_k == 0.04          # the reference never turns the Harris response on (extractor.py:21-24)
     b = _lib.BaParams(); L.vo_ba_default_params(ctypes.byref(b))
     assert b.ftol == 1e-3 and b.xtol == 1e-3 and b.huber_delta == 1.0
 

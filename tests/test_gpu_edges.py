@@ -104,3 +104,35 @@ def test_shi_tomasi_plateaus_every_pixel_a_local_maximum():
         for b in range(B):
             assert np.array_equal(eig[b] if B > 1 else eig, reig) and int(nc[b] if B > 1 else nc) == rnc
             assert np.array_equal(np.asarray(corners[b] if B > 1 else corners).reshape(-1, 2), ref.reshape(-1, 2))
+
+
+def test_unpaired_landmark_half_and_batched_row_reads_are_refused():
+    """VO_PIPE_TRACK_LANDMARKS alone is the second half of a VO_PIPE_TRACK | VO_PIPE_TRACK_CANDIDATES call (extractor.py:38-59 then :61-88): without
+    that call before it the point buffer holds stale positions -> VO_E_STATE; the row / inlier read-backs are single-sequence calls"""
+    from vo_mi355x import VoContext, VoError, State, Trajectory, synthetic as syn
+    from vo_mi355x.resident import ResidentPipeline, TRACK, TRACK_CANDIDATES, TRACK_LANDMARKS
+    frames, _ = syn.make_sequence(3, w=320, h=240, seed=2, margin=48)
+    K = np.array([[300.0, 0, 160], [0, 300.0, 120], [0, 0, 1]])
+    with VoContext(320, 240, max_pts=256) as c:
+        rp = ResidentPipeline(c, K)
+        rp.seed(State([], [], [], Trajectory({0: np.eye(4)})), [], [], t_step=0)
+        c.push_frame(frames[0]); c.push_frame(frames[1])
+        with pytest.raises(VoError) as e:
+            rp.step(-1, TRACK_LANDMARKS)                       # nothing tracked yet
+        assert e.value.code == -4
+        with pytest.raises(VoError) as e:
+            rp.step(-1, TRACK_CANDIDATES)                      # the candidates' half never comes without the tracking
+        assert e.value.code == -4
+        rp.step(-1, TRACK | TRACK_CANDIDATES); rp.fetch()
+        rp.step(-1, TRACK_LANDMARKS); rp.fetch()               # the pair, as the reference calls it
+        with pytest.raises(VoError) as e:
+            rp.step(-1, TRACK_LANDMARKS)                       # ... and only once per tracked set
+        assert e.value.code == -4
+        c.push_frame(frames[2])
+        rp.step(-1, TRACK); rp.fetch()                         # the context is still good
+    with VoContext(320, 240, max_pts=256, batch=2) as c2:
+        rp2 = ResidentPipeline(c2, np.stack([K, K]))
+        with pytest.raises(ValueError):
+            rp2.read_rows("K", [0, 1])
+        with pytest.raises(ValueError):
+            rp2.read_inliers(4)

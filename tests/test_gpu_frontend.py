@@ -147,6 +147,33 @@ def test_shi_tomasi_bit_exact(ctx_big, seq3):
     assert (rmask[c1[:, 1].astype(int), c1[:, 0].astype(int)] == 255).all()
 
 
+def test_harris_response_bit_exact(ctx_big, seq3):
+    """`vo_st_params.use_harris` = cv2.goodFeaturesToTrack(useHarrisDetector=True, k) (the option the reference's dict extractor.py:21-24
+    leaves off): response map, candidate count and the ordered corner list bit-equal to the oracle, with the
+    reference's exclusion discs and without, k = 0.04 and another one; the default parameters still give the minimum-eigenvalue corners"""
+    import vo_oracle as o
+    from vo_mi355x import synthetic as syn
+    frames, _ = seq3
+    h, w = frames.shape[1:]
+    cur = frames[1]
+    for k in (0.04, 0.15):
+        prm = ctx_big.st_params(use_harris=True, harris_k=k)
+        c0 = ctx_big.shi_tomasi(None, params=prm)
+        resp, mask, nc = ctx_big.shi_tomasi_read()
+        r0, rresp, rnc = o.good_features(cur, None, return_aux=True, useHarrisDetector=True, k=k)
+        assert np.array_equal(resp, rresp), "Harris response differs: %g" % np.abs(resp - rresp).max()
+        assert nc == rnc and np.array_equal(c0, r0) and len(c0) > 50
+    pts = syn.grid_points(2000, w, h, margin=0, seed=9) + np.float32(0.37)
+    prm = ctx_big.st_params(use_harris=True)
+    c1 = ctx_big.shi_tomasi(pts, mask_radius=7, params=prm)
+    rmask = np.full((h, w), 255, np.uint8)
+    for x, y in np.int32(pts):
+        o.circle_mask(rmask, (x, y), 7, 0)
+    assert np.array_equal(c1, o.good_features(cur, rmask, useHarrisDetector=True))
+    assert np.array_equal(ctx_big.shi_tomasi(None), o.good_features(cur, None))          # the default is untouched
+    assert not np.array_equal(c0, ctx_big.shi_tomasi(None))
+
+
 def test_shi_tomasi_vs_opencv_float_order(ctx_big, seq3):
     """the bridge to OpenCV's own arithmetic (ST-1 / ST-2): cv2's boxFilter keeps float running sums, the HIP path and the oracle's
     default keep exact int32 sums (oracle/vo_oracle.c header).  Against the oracle in OpenCV's float order (exact_int=False):

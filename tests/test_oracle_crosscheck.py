@@ -320,6 +320,34 @@ def test_bilateral_independent(shape):
     assert np.array_equal(o.bilateral(noisy), bilateral_np(noisy))
 
 
+# ---- cornerHarris (goodFeaturesToTrack(useHarrisDetector=True, k)): the same box sums, response a c - b^2 - k (a + c)^2 ---------------
+def harris_np(img, block=31, k=0.04):
+    a = img.astype(np.int64)
+    sm, df = np.array([1, 2, 1], np.int64), np.array([-1, 0, 1], np.int64)
+    dx = ndimage.correlate1d(ndimage.correlate1d(a, sm, axis=0, mode="mirror"), df, axis=1, mode="mirror")
+    dy = ndimage.correlate1d(ndimage.correlate1d(a, sm, axis=1, mode="mirror"), df, axis=0, mode="mirror")
+    box = np.ones(block, np.int64)
+
+    def boxsum(p):
+        return ndimage.correlate1d(ndimage.correlate1d(p, box, axis=1, mode="mirror"), box, axis=0, mode="mirror")
+    s = 1.0 / (4.0 * block * 255.0)
+    A, B, C = boxsum(dx * dx) * s * s, boxsum(dx * dy) * s * s, boxsum(dy * dy) * s * s
+    return A * C - B * B - k * (A + C) ** 2                 # float64
+
+
+@pytest.mark.parametrize("shape", SHAPES[:3])
+def test_harris_independent(shape):
+    img = _img(shape, 14)
+    ref = harris_np(img)
+    scale = np.abs(ref).max()
+    assert np.abs(o.harris(img, 31, 0.04, exact_int=True) - ref).max() <= 3e-6 * scale
+    assert np.abs(o.harris(img, 31, 0.04, exact_int=False) - ref).max() <= 5e-5 * scale
+    got, resp, nc = o.good_features(img, None, return_aux=True, useHarrisDetector=True, k=0.04)
+    want, nc_np = good_features_np(resp, None)              # the selection after the map is the same code path for both responses
+    assert nc == nc_np and np.array_equal(got, want) and len(got) > 10
+    assert not np.array_equal(got, o.good_features(img, None))      # ... and the two responses do rank differently
+
+
 # ---- cv2.circle(mask, c, r, 0, -1): closed form of the midpoint circle instead of its incremental loop --------------------------
 def circle_rows_np(r):
     """half-width of every row 0..r of the filled circle: the rasteriser walks the first octant with dx(dy) = floor(sqrt(r^2 - dy^2)) while

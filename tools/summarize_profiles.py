@@ -124,4 +124,40 @@ if path:
                            "`bench.py --steps 4 --warmup 2` (tools/profile_round.sh), mean over the k_klt_track launches (sq_waves_per_launch = "
                            "sequences x points of one launch); SQ_INSTS_VALU counts wave-instructions"},
                   open(os.path.join(out, "klt_valu.json"), "w"), indent=1)
+
+# ---- one file with everything bench.py's roofline.kernels reports, per kernel of the default command: time share and average launch
+# from the --stats summary, HBM bytes / vector instructions / MFMA figures per launch from the --pmc passes.  Every number in it can be
+# recomputed from <tag>_kernel_stats.csv and <tag>_pmc_{traffic,valu,mfma}.csv, which are committed beside it.
+def _rows(name):
+    path = os.path.join(out, name)
+    return list(csv.DictReader(open(path))) if os.path.exists(path) else []
+
+
+_h = hashlib.sha256()
+for _n in sorted(os.listdir(os.path.join("visual-odom-pipeline_amd", "csrc"))):
+    if _n.endswith((".hip", ".h")):
+        with open(os.path.join("visual-odom-pipeline_amd", "csrc", _n), "rb") as _f:
+            _h.update(_f.read())
+kc = {"measured": tag, "csrc_sha256_16": _h.hexdigest()[:16],
+      "command": "python3 bench.py --steps 20 --warmup 5 --regions 1 --no-extras --no-cpu-baseline (kernel stats); --steps 4 --warmup 2 (each --pmc pass)",
+      "files": [f"profiles/{tag}_kernel_stats_default.csv", f"profiles/{tag}_pmc_traffic_default.csv", f"profiles/{tag}_pmc_valu_default.csv",
+                f"profiles/{tag}_pmc_mfma_default.csv"],
+      "kernels": []}
+st = {short(r["Name"]): r for r in _rows(f"{tag}_kernel_stats.csv")}
+tr = {r["kernel"]: r for r in _rows(f"{tag}_pmc_traffic.csv")}
+va = {r["kernel"]: r for r in _rows(f"{tag}_pmc_valu.csv")}
+mf = {r["kernel"]: r for r in _rows(f"{tag}_pmc_mfma.csv")}
+for k, r in sorted(st.items(), key=lambda kv: -float(kv[1]["Percentage"])):
+    if float(r["Percentage"]) < 0.5:
+        continue
+    e = {"kernel": k, "pct_of_kernel_time": float(r["Percentage"]), "calls": int(r["Calls"]), "avg_launch_us": float(r["AverageNs"]) / 1e3}
+    if k in tr:
+        e["hbm_bytes_per_launch"] = int(tr[k]["hbm_bytes_per_launch"])
+    if k in va:
+        e["valu_insts_per_launch"] = float(va[k]["sq_insts_valu_mean"]); e["waves_per_launch"] = float(va[k]["sq_waves_mean"])
+    if k in mf:
+        e["mfma_util_pct_mean"] = float(mf[k]["mfma_util_pct_mean"]); e["mfma_util_pct_max"] = float(mf[k]["mfma_util_pct_max"])
+        e["mfma_flops_f64_per_launch"] = float(mf[k]["mfma_flops_f64_mean"])
+    kc["kernels"].append(e)
+json.dump(kc, open(os.path.join(out, "kernel_counters.json"), "w"), indent=1)
 print("summaries written for", tag)

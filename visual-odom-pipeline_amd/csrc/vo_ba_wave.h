@@ -247,8 +247,13 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
     }
   }
   if (it == 0 && part == 0 && tid < 6 * W) P.xa[tid] = poses[tid];
-  // the panels start as zeros: the padding columns behind 6 W + 1 are never written afterwards
-  for (int i = tid; i < 4 * REGION / 2; i += 256) reinterpret_cast<double2*>(dyn)[i] = make_double2(0.0, 0.0);
+  // the padding columns behind 6 W + 1 start as zeros and are never written afterwards (every chunk rewrites the columns before them in
+  // every row: a lane without a landmark writes zeros)
+  {
+    const int npad = RP - (6 * W + 1);
+    for (int i = tid; i < 4 * ROWS * npad; i += 256) { const int r = i / npad; dyn[r * PITCH + 6 * W + 1 + (i - r * npad)] = 0.0; }
+    if (PITCH > RP) for (int i = tid; i < 4 * ROWS * (PITCH - RP); i += 256) { const int r = i / (PITCH - RP); dyn[r * PITCH + RP + (i - r * (PITCH - RP))] = 0.0; }
+  }
   __syncthreads();
   const ba2_map<LPP> mp(lane);
   const int pl = mp.pl, q = mp.q;

@@ -69,6 +69,8 @@ struct vo_pipe_ws {
   hipEvent_t ev[VO_PIPE_INFLIGHT] = {};
   hipEvent_t ev_track = nullptr;                 // the side stream's pyramid + KLT of a step are done
   long enq = 0, fetched = 0;
+  bool lm_half_pending = false;                  // a TRACK | TRACK_CANDIDATES call has tracked every keypoint and applied the candidates' half only:
+                                                 // the landmarks' half (TRACK_LANDMARKS alone) may follow -- and only then
 };
 
 static pipe_ptrs pipe_make(const vo_pipe_ws* w) {
@@ -1428,6 +1430,13 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
   const bool side = c->side_stream != 0 && c->stream2 != nullptr;
   hipStream_t const main_stream = c->stream;
   const int halves = (stages & (VO_PIPE_TRACK_CANDIDATES | VO_PIPE_TRACK_LANDMARKS)) ? (((stages & VO_PIPE_TRACK_CANDIDATES) ? 1 : 0) | ((stages & VO_PIPE_TRACK_LANDMARKS) ? 2 : 0)) : 3;
+  // the landmarks' half on its own reads the positions a TRACK | TRACK_CANDIDATES call left in the point buffer: without that call before it
+  // k_pipe_extend would take stale positions for tracked ones
+  if (!(stages & VO_PIPE_TRACK) && (stages & VO_PIPE_TRACK_LANDMARKS))
+    VO_CHECK(c, halves == 2 && w->lm_half_pending, VO_E_STATE, "VO_PIPE_TRACK_LANDMARKS alone needs a VO_PIPE_TRACK | VO_PIPE_TRACK_CANDIDATES call before it");
+  if (!(stages & VO_PIPE_TRACK) && (stages & VO_PIPE_TRACK_CANDIDATES))
+    return vo_fail(c, VO_E_STATE, "pipe_step: VO_PIPE_TRACK_CANDIDATES without VO_PIPE_TRACK (the candidates' half follows the tracking in the same call)");
+  if (stages & (VO_PIPE_TRACK | VO_PIPE_TRACK_LANDMARKS)) w->lm_half_pending = (stages & VO_PIPE_TRACK) && halves == 1;
   if (stages & VO_PIPE_TRACK) {
     if (frame_idx >= 0) VO_CHECK(c, c->d_seq && frame_idx < c->seq_n, VO_E_STATE, "no resident sequence / bad frame index");
     VO_CHECK(c, c->n_pushed + (frame_idx >= 0 ? 1 : 0) >= 2, VO_E_STATE, "tracking needs two frames in the frame store");
@@ -1514,7 +1523,13 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
     r = (stages & VO_PIPE_DETECT) ? vo_shi_tomasi_resident_counts(c, w->N, prm.mask_radius, &prm.st, w->d_dn + DN_PTS * B, w->d_dn + DN_ROOM * B) : VO_OK;
     if (r == VO_OK) pipe_launch_spawn(c, (stages & VO_PIPE_DETECT) ? 1 : 0, (stages & VO_PIPE_KEEP_FREE_LISTS) ? 0 : 1);
     c->stream = main_stream;
-    if (r == VO_OK && (stages & VO_PIPE_ADJUST)) { vo_ba_set_live(c, (const int32_t*)w->tab[VO_PIPE_COUNTS] + C_NLM, PIPE_NCNT); r = vo_ba_enqueue_budget(c, &prm.ba, 0, prm.ba_budget); }
+    if (r == VO_OK && (stages & VO_PIPE_ADJUST)) {
+      // the live-slot counters are scoped to THIS enqueue: any other entry point that solves on the shared BA workspace afterwards
+      // (vo_ba_solve_resident on a problem written through vo_ba_obs_device) must see every slot again
+      vo_ba_set_live(c, (const int32_t*)w->tab[VO_PIPE_COUNTS] + C_NLM, PIPE_NCNT);
+      r = vo_ba_enqueue_budget(c, &prm.ba, 0, prm.ba_budget);
+      vo_ba_set_live(c, nullptr, 0);
+    }
     if (r == VO_OK) PIPE_DISPATCH(k_pipe_writeback, P, (stages & VO_PIPE_ADJUST) ? 1 : 0, bv.pub, bv.pub_bytes, bv.x0, bv.x_stride, bv.W, w->d_rec);
     const hipError_t e1 = hipEventRecord(c->ev_join, c->stream2);
     const hipError_t e2 = hipStreamWaitEvent(c->stream, c->ev_join, 0);     // joined on every path: nothing is left running on the side stream
@@ -1524,6 +1539,7 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
     if (stages & VO_PIPE_ADJUST) {
       vo_ba_set_live(c, (const int32_t*)w->tab[VO_PIPE_COUNTS] + C_NLM, PIPE_NCNT);
       r = vo_ba_enqueue_budget(c, &prm.ba, 0, prm.ba_budget);
+      vo_ba_set_live(c, nullptr, 0);
       if (r != VO_OK) return r;
     }
     if (stages & VO_PIPE_DETECT) {

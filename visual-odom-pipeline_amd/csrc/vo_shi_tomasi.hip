@@ -159,9 +159,12 @@ __global__ void __launch_bounds__(256) k_st_discs(const float* __restrict__ pts,
 #define ST_GROUPS 6   // groups per thread: a thread walks 48 rows with running sums, so the 31 start-up rows are read once
                       // per 48 outputs (7.8 loads per pixel instead of 16.9 at 8 rows; the pass is HBM / MALL bound)
 #define ST_ROWS (ST_RG * ST_GROUPS)
+// harris != 0: the response is OpenCV's calcHarris instead of calcMinEigenVal (imgproc/corner.cpp; goodFeaturesToTrack(useHarrisDetector=True,
+// k), the option the reference's parameter dict extractor.py:21-24 leaves off): a c - b^2 - k (a + c)^2 on the box sums WITHOUT the halves,
+// evaluated as the scalar C++ expression is -- a c - b^2 in float, the k term in double (k is a double), one rounding to float
 __global__ void __launch_bounds__(256) k_st_vsum_eig(const int32_t* __restrict__ hbase, const uint8_t* __restrict__ mask,
                                                      int W, int H, int r, float s2, float* __restrict__ eig,
-                                                     float* __restrict__ blockmax) {
+                                                     float* __restrict__ blockmax, int harris, double harris_k) {
   __shared__ float s_m[4];
   const int x = blockIdx.x * 256 + threadIdx.x;
   const int y0 = blockIdx.y * ST_ROWS;
@@ -205,8 +208,14 @@ __global__ void __launch_bounds__(256) k_st_vsum_eig(const int32_t* __restrict__
         const int y = yb + k;
         sa += da[k]; sb += db[k]; sc += dc[k];
         if (y < H) {
-          const float a = ((float)sa * s2) * 0.5f, b = (float)sb * s2, c = ((float)sc * s2) * 0.5f;
-          const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+          float e;
+          if (harris) {
+            const float a = (float)sa * s2, b = (float)sb * s2, c = (float)sc * s2;
+            e = (float)((double)(a * c - b * b) - harris_k * (double)(a + c) * (double)(a + c));
+          } else {
+            const float a = ((float)sa * s2) * 0.5f, b = (float)sb * s2, c = ((float)sc * s2) * 0.5f;
+            e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+          }
           eig[(size_t)y * W + x] = e;
           if (mk[k] && e > lmax) lmax = e;
         }
@@ -1114,6 +1123,7 @@ int32_t vo_st_prepare(vo_ctx* c, const vo_st_params* prm) {
 extern "C" int32_t vo_st_default_params(vo_st_params* p) {
   if (!p) return VO_E_INVALID;
   p->max_corners = 1000; p->block_size = 31; p->quality_level = 0.03; p->min_distance = 7.0;
+  p->use_harris = 0; p->_pad = 0; p->harris_k = 0.04;
   return VO_OK;
 }
 
@@ -1134,7 +1144,8 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
   const double scale_d = 1.0 / ((double)(1 << 2) * prm->block_size * 255.0);
   const float sf = (float)scale_d;
   const float s2 = sf * sf;
-  const bool fused = s->fused && r == 15 && H > 31 && W > 31;    // (single border reflection per row inside the kernel)
+  const bool fused = s->fused && r == 15 && H > 31 && W > 31 && !prm->use_harris;    // (single border reflection per row inside the kernel; the Harris
+                                                                                     //  response -- an option the reference never enables -- takes the two-kernel form)
   int n_blockmax;
   if (fused) {
     if (keep || d_user_mask || !s->mask_clean)
@@ -1179,7 +1190,7 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
   } else {
     n_blockmax = vo_div_up(W, 256) * vo_div_up(H, ST_ROWS);
     hipLaunchKernelGGL(k_st_vsum_eig, dim3(vo_div_up(W, 256), vo_div_up(H, ST_ROWS), B), dim3(256), 0, c->stream, s->d_h,
-                       s->d_mask, W, H, r, s2, s->d_eig, s->d_blockmax);
+                       s->d_mask, W, H, r, s2, s->d_eig, s->d_blockmax, prm->use_harris ? 1 : 0, prm->harris_k);
     hipLaunchKernelGGL(k_st_nms, dim3(vo_div_up(W - 2, 256), vo_div_up(H - 2, ST_NMS_ROWS), B), dim3(256), 0, c->stream, s->d_eig,
                        s->d_mask, W, H, prm->quality_level, s->d_blockmax, n_blockmax, s->d_cand, s->d_scalars, c->slab_seq, s->d_nraw);
     s->mask_clean = false; s->eig_valid = true;
@@ -1191,7 +1202,9 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
   while (((W + cell - 1) / cell) * ((H + cell - 1) / cell) > ST_MAX_CELLS) cell++;
   const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
   const double md2 = prm->min_distance * prm->min_distance;
-  if (limit_dev)
+  // the short-chunk instance keeps min(cap - accepted, ...) keys per pass: with a corner limit near its capacity the last corners would come
+  // one tiny chunk -- and one rescan of the raw list -- at a time, so limits above half of it take the large instance
+  if (limit_dev && (prm->max_corners > 0 && prm->max_corners <= ST_CAP_CLOSED_LOOP / 2))
     hipLaunchKernelGGL(k_st_select<ST_CAP_CLOSED_LOOP>, dim3(B), dim3(1024), st_sel_lds(ST_CAP_CLOSED_LOOP), c->stream, s->d_cand,
                        s->d_scalars, W, H, cell, gw, gh, md2, use_dist, prm->max_corners, s->d_out, c->slab_seq, c->d_dbg,
                        s->d_blockmax, n_blockmax, prm->quality_level, s->d_nraw, limit_dev);
@@ -1215,7 +1228,7 @@ static int32_t st_fetch(vo_ctx* c, float* out_pts, int32_t* n_out) {
                              sizeof(float) * 2 * (size_t)mc, B, hipMemcpyDeviceToHost, c->stream));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   for (int b = 0; b < B; b++) {
-    if (sc[4 * b + 2] == 0xFFFFFFFFu) { n_out[b] = 0; return vo_fail(c, VO_E_CAPACITY, "shi_tomasi: the 16384 strongest of the NMS candidates did not yield max_corners corners (or more than 262144 candidates)"); }
+    if (sc[4 * b + 2] == 0xFFFFFFFFu) { n_out[b] = 0; return vo_fail(c, VO_E_CAPACITY, "shi_tomasi: the strongest NMS candidates the selection holds (16384; 4096 with a device-side corner limit) did not yield max_corners corners, or more than 262144 candidates"); }
     n_out[b] = (int32_t)sc[4 * b + 2];
   }
   return VO_OK;

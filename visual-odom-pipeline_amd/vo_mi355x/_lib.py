@@ -32,7 +32,7 @@ class KltParams(C.Structure):
 
 class StParams(C.Structure):
     _fields_ = [("max_corners", C.c_int32), ("block_size", C.c_int32), ("quality_level", C.c_double),
-                ("min_distance", C.c_double)]
+                ("min_distance", C.c_double), ("use_harris", C.c_int32), ("_pad", C.c_int32), ("harris_k", C.c_double)]
 
 
 class BaParams(C.Structure):

@@ -173,10 +173,11 @@ class VoContext:
         self._ck(self._L.vo_klt_track_resident(self._h, n, C.byref(prm)))
 
     # -- Shi-Tomasi -----------------------------------------------------------------------------
-    def st_params(self, max_corners=1000, quality_level=0.03, min_distance=7, block_size=31):
+    def st_params(self, max_corners=1000, quality_level=0.03, min_distance=7, block_size=31, use_harris=False, harris_k=0.04):
         p = StParams()
         self._L.vo_st_default_params(C.byref(p))
         p.max_corners, p.quality_level, p.min_distance, p.block_size = max_corners, quality_level, min_distance, block_size
+        p.use_harris, p.harris_k = (1 if use_harris else 0), float(harris_k)
         return p
 
     def _corners(self, out, n_out):

@@ -206,8 +206,10 @@ class Extractor:
         self._ensure_cur(img)
         c = self._ctx
         sp = self._shitomasi_params
+        # the dict is what the reference splats into cv2.goodFeaturesToTrack (extractor.py:111); its optional keys are honoured too
         prm = c.st_params(max_corners=sp["maxCorners"], quality_level=sp["qualityLevel"],
-                          min_distance=sp["minDistance"], block_size=sp["blockSize"])
+                          min_distance=sp["minDistance"], block_size=sp["blockSize"],
+                          use_harris=bool(sp.get("useHarrisDetector", False)), harris_k=sp.get("k", 0.04))
         # np.int32(kp.uv) truncation happens on the device; float32 carries every pixel coordinate exactly
         cur = (np.array([k.uv for k in current_kp], dtype=np.float64).reshape(-1, 2).astype(np.float32) if len(current_kp)
                else np.zeros((0, 2), np.float32))

@@ -137,6 +137,8 @@ class ResidentPipeline:
 
     def read_rows(self, kind, rows):
         """object rows by index (batch 1): kind 'K' -> structured array K_ROW (history in ring-slot order), 'L' -> L_ROW"""
+        if self.B != 1:
+            raise ValueError("read_rows copies the rows of ONE sequence (vo_pipe_rows_read moves [batch][n] records): batch is %d" % self.B)
         rows = np.ascontiguousarray(rows, np.int32).reshape(-1)
         dt = self.K_ROW if kind == "K" else self.L_ROW
         out = np.empty(len(rows), dt)
@@ -148,6 +150,8 @@ class ResidentPipeline:
 
     def read_inliers(self, n):
         """consensus mask of the last POSE stage over the first n entries of the landmark list as it was before the pruning (batch 1)"""
+        if self.B != 1:
+            raise ValueError("read_inliers copies the mask of ONE sequence (vo_pipe_inliers_read moves [batch][n] bytes): batch is %d" % self.B)
         m = np.zeros(max(n, 1), np.uint8)
         self.ctx._ck(self._L.vo_pipe_inliers_read(self.ctx._h, m.ctypes.data_as(C.POINTER(C.c_uint8)), int(n)))
         return m[:n].astype(bool)
