@@ -31,9 +31,9 @@ class OracleContext:
         return o.klt(self._prev, self._cur, p0, (prm.win, prm.win), prm.max_level, (3, prm.max_count, prm.epsilon),
                      prm.min_eig_threshold)
 
-    def st_params(self, max_corners=1000, quality_level=0.03, min_distance=7, block_size=31):
+    def st_params(self, max_corners=1000, quality_level=0.03, min_distance=7, block_size=31, use_harris=False, harris_k=0.04):
         return SimpleNamespace(max_corners=max_corners, quality_level=quality_level, min_distance=min_distance,
-                               block_size=block_size)
+                               block_size=block_size, use_harris=1 if use_harris else 0, harris_k=harris_k)
 
     def shi_tomasi(self, cur_pts=None, mask_radius=7, mask=None, params=None):
         prm = params or self.st_params()

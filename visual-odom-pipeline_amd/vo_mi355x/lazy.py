@@ -220,7 +220,16 @@ class DeviceBackend:
 # ------------------------------------------------------------------------------------------------------------------------------------
 # the session
 # ------------------------------------------------------------------------------------------------------------------------------------
-_REFCOUNT_IDLE = 2        # sys.getrefcount of a proxy nobody holds any more (the local name + getrefcount's argument)
+def _idle_refcount():
+    """sys.getrefcount of an object that has just left the only container that held it and is bound to ONE local name -- measured on this
+    interpreter instead of assumed (CPython 3.10: the local name + getrefcount's argument = 2; an interpreter that borrows references on
+    its evaluation stack reports less, and `_retire` would then take a proxy somebody still holds for an idle one)"""
+    table = {0: object()}
+    p = table.pop(0)
+    return sys.getrefcount(p)
+
+
+_REFCOUNT_IDLE = _idle_refcount()
 
 
 class Session:
@@ -239,6 +248,7 @@ class Session:
         self.track_img = None                             # frame whose KLT has run and whose landmark half is still to come
         self._cache = {}                                  # kind -> (row -> index, structured array) of the last bulk gather
         self.stats = dict(fast=0, stages=0, gathers=0)
+        self._hinted = []         # proxies carrying a `_copy` hint of the last camera_pose (see _drop_hints)
 
     # ---- proxies / mirrors -----------------------------------------------------------------------------------------------------------
     def _proxies(self, kind, rows):
@@ -335,6 +345,7 @@ class Session:
                 d["_rec"] = rec.copy()
                 d["_row"] = -1
                 d.pop("_sess", None)
+                d.pop("_copy", None)               # a plain object copies itself
 
     def _field(self, proxy, name):
         """one field of an attached proxy: the first miss after a stage gathers every row of that kind that has a proxy"""
@@ -351,11 +362,20 @@ class Session:
             v = vals[key] = _field_of(kind, recs[index[key[0]]], name)
         return v
 
+    def _drop_hints(self):
+        """the deepcopy hints camera_pose attached (the copies the device made of the pruned entries) belong to the caller's deepcopy calls that
+        follow it directly (pipeline.py:130-134).  Once the next stage starts -- or the session ends -- a leftover hint would hand a stale dead-row
+        proxy to an unrelated copy.deepcopy of an object that is plain by then: dropped."""
+        for p in self._hinted:
+            p.__dict__.pop("_copy", None)
+        self._hinted = []
+
     # ---- leaving the fast path -------------------------------------------------------------------------------------------------------
     def desync(self, reason):
         """every proxy becomes a plain object holding its current values; the session is over"""
         if not self.alive:
             return
+        self._drop_hints()
         self.alive, self.reason = False, reason
         self._fill(list(self.Kp.values()) + list(self.Lp.values()), detach=True)
         self.Kp, self.Lp = {}, {}
@@ -405,6 +425,7 @@ class Session:
 
     # ---- the reference's calls -------------------------------------------------------------------------------------------------------
     def extend_tracks(self, im_prev, im_curr, kp, max_bidir_error):
+        self._drop_hints()
         if not (np.isinf(max_bidir_error) and kp == self.cand and self._same_image(im_prev, self.cur_img)
                 and im_curr.shape == (self.h, self.w) and self.track_img is None):
             return self._fail("extend_tracks: not the session's candidate list / frame pair")
@@ -419,6 +440,7 @@ class Session:
         return LazyList(self.cand)
 
     def extend_landmarks(self, im_prev, im_curr, landmarks, landmarks_kp, max_bidir_error):
+        self._drop_hints()
         from .resident import TRACK, TRACK_LANDMARKS
         if not (np.isinf(max_bidir_error) and landmarks == self.lm_L and landmarks_kp == self.lm_K and self._room(extra_dead=len(self.lm_L))):
             return self._fail("extend_landmarks: not the session's landmark lists (or the dead list could overflow)")
@@ -449,6 +471,7 @@ class Session:
         return LazyList(self.lm_L), LazyList(self.lm_K), ld, lkd
 
     def camera_pose(self, K, list_1, list_2, max_err_reproj):
+        self._drop_hints()
         from .resident import POSE
         if not (list_1 == self.lm_L and list_2 == self.lm_K and max_err_reproj == self.prm["max_reproj_err"] and np.array_equal(np.asarray(K, np.float64), self.K)
                 and self.track_img is None and self._room(extra_dead=len(self.lm_L))):
@@ -465,11 +488,13 @@ class Session:
         for j, i in enumerate(out):                        # deepcopy(state._landmarks[i]) / (..._kp[i]) of pipeline.py:133-134 = the device's copies
             old_L[i].__dict__.setdefault("_copy", []).append(self.dead_L[n_dead0 + j])
             old_K[i].__dict__.setdefault("_copy", []).append(self.dead_K[n_dead0 + j])
+            self._hinted += [old_L[i], old_K[i]]
         self.last_H = np.array(rec["H"], np.float64)
         self.stats["fast"] += 1
         return InlierList(np.nonzero(mask)[0].tolist()), self.last_H
 
     def triangulate_tracks(self, K, candidates_kp, trajectory, t_curr, min_track_length, min_bearing_angle, max_err_reproj):
+        self._drop_hints()
         from .resident import TRIANGULATE
         p = self.prm
         T = len(trajectory)
@@ -488,6 +513,7 @@ class Session:
         return LazyList(self.lm_L[n_l0:]), LazyList(self.lm_K[n_l0:]), LazyList(self.cand)
 
     def adjust(self, state, landmarks_dead, landmarks_kp_dead, K, t_now, window, ftol, xtol, max_iters):
+        self._drop_hints()
         from .resident import ADJUST
         p = self.prm
         # the caller's dead list = the device's dead list + the entries the device has dropped as inert (they can never return: flagged then)
@@ -548,6 +574,7 @@ class Session:
         return state, dead_l, dead_k, stats
 
     def extract(self, img, t, current_kp, mask_radius):
+        self._drop_hints()
         from .resident import DETECT
         if not (t == self.t and mask_radius == self.prm["mask_radius"] and self._same_image(img, self.cur_img) and current_kp == self.lm_K + self.cand
                 and self.track_img is None):
