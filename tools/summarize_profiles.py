@@ -62,12 +62,13 @@ for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
 
 if means:
     kernels = sorted(set().union(*[set(m) for m in means.values()]))
-    with open(os.path.join(out, f"{tag}_pmc_traffic.csv"), "w") as g:
-        g.write("kernel,launches,fetch_size_kb_raw,write_size_kb,hbm_bytes_per_launch\n")
+    with open(os.path.join(out, f"{tag}_pmc_traffic.csv"), "w", newline="") as g:
+        wcsv = csv.writer(g)                 # (kernel names carry template commas: quoted)
+        wcsv.writerow(["kernel", "launches", "fetch_size_kb_raw", "write_size_kb", "hbm_bytes_per_launch"])
         for k in kernels:
             fe, n = means.get("FETCH_SIZE", {}).get(k, (0.0, 0))
             wr, n2 = means.get("WRITE_SIZE", {}).get(k, (0.0, 0))
-            g.write(f"{k},{max(n, n2)},{fe:.1f},{wr:.1f},{int((2 * fe + wr) * 1024)}\n")
+            wcsv.writerow([k, max(n, n2), "%.1f" % fe, "%.1f" % wr, int((2 * fe + wr) * 1024)])
     klt = [k for k in kernels if "k_klt_track" in k]
     if klt:
         k = klt[0]
@@ -92,12 +93,13 @@ if path:
             a = acc[short(row["Kernel_Name"])][row["Counter_Name"]]
             v = float(row["Counter_Value"])
             a[0] += v; a[1] = max(a[1], v); a[2] += 1
-    with open(os.path.join(out, f"{tag}_pmc_mfma.csv"), "w") as g:
-        g.write("kernel,launches,mfma_util_pct_mean,mfma_util_pct_max,mfma_flops_f64_mean,mfma_flops_f64_max\n")
+    with open(os.path.join(out, f"{tag}_pmc_mfma.csv"), "w", newline="") as g:
+        wcsv = csv.writer(g)
+        wcsv.writerow(["kernel", "launches", "mfma_util_pct_mean", "mfma_util_pct_max", "mfma_flops_f64_mean", "mfma_flops_f64_max"])
         for k in sorted(acc):
             u, fl = acc[k].get("MfmaUtil", [0, 0, 0]), acc[k].get("MfmaFlopsF64", [0, 0, 0])
             n = max(u[2], fl[2], 1)
-            g.write(f"{k},{n},{u[0] / n:.3f},{u[1]:.3f},{fl[0] / n:.4g},{fl[1]:.4g}\n")
+            wcsv.writerow([k, n, "%.3f" % (u[0] / n), "%.3f" % u[1], "%.4g" % (fl[0] / n), "%.4g" % fl[1]])
 path = find(f"{tag}_pmc_valu/**/*counter_collection.csv")
 if path:
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
@@ -106,12 +108,13 @@ if path:
             a = acc[short(row["Kernel_Name"])][row["Counter_Name"]]
             a[0] += float(row["Counter_Value"]); a[1] += 1
     names = ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
-    with open(os.path.join(out, f"{tag}_pmc_valu.csv"), "w") as g:
-        g.write("kernel,launches," + ",".join(n.lower() + "_mean" for n in names) + ",valu_insts_per_wave\n")
+    with open(os.path.join(out, f"{tag}_pmc_valu.csv"), "w", newline="") as g:
+        wcsv = csv.writer(g)
+        wcsv.writerow(["kernel", "launches"] + [n.lower() + "_mean" for n in names] + ["valu_insts_per_wave"])
         for k in sorted(acc):
             n = max(v[1] for v in acc[k].values())
             m = {c: (acc[k][c][0] / acc[k][c][1] if acc[k][c][1] else 0.0) for c in names}
-            g.write(f"{k},{n}," + ",".join("%.6g" % m[c] for c in names) + ",%.1f\n" % (m["SQ_INSTS_VALU"] / max(m["SQ_WAVES"], 1)))
+            wcsv.writerow([k, n] + ["%.6g" % m[c] for c in names] + ["%.1f" % (m["SQ_INSTS_VALU"] / max(m["SQ_WAVES"], 1))])
     klt = [k for k in acc if "k_klt_track" in k]
     if klt:
         k = klt[0]
@@ -144,6 +147,15 @@ kc = {"measured": tag, "csrc_sha256_16": _h.hexdigest()[:16],
                 f"profiles/{tag}_pmc_mfma_default.csv"],
       "kernels": []}
 st = {short(r["Name"]): r for r in _rows(f"{tag}_kernel_stats.csv")}
+# the same command on ONE stream (tools/kstats256.sh <tag>): a launch's duration without the other streams' kernels on the chip.  In the
+# default three-stream layout a narrow kernel (k_ba_solve, k_ba_update_w) is "running" from the moment it is dispatched behind a
+# 3 ms tracker launch on another stream, so its --stats duration there is mostly waiting for compute units
+alone_path = find(f"{tag}_ks256/**/*kernel_stats.csv")
+alone = {short(r["Name"]): r for r in csv.DictReader(open(alone_path))} if alone_path else {}
+if alone_path:
+    with open(alone_path) as f, open(os.path.join(out, f"{tag}_kernel_stats_one_stream.csv"), "w") as g:
+        g.write(f.read())
+    kc["files"].append(f"profiles/{tag}_kernel_stats_one_stream.csv")
 tr = {r["kernel"]: r for r in _rows(f"{tag}_pmc_traffic.csv")}
 va = {r["kernel"]: r for r in _rows(f"{tag}_pmc_valu.csv")}
 mf = {r["kernel"]: r for r in _rows(f"{tag}_pmc_mfma.csv")}
@@ -151,6 +163,8 @@ for k, r in sorted(st.items(), key=lambda kv: -float(kv[1]["Percentage"])):
     if float(r["Percentage"]) < 0.5:
         continue
     e = {"kernel": k, "pct_of_kernel_time": float(r["Percentage"]), "calls": int(r["Calls"]), "avg_launch_us": float(r["AverageNs"]) / 1e3}
+    if k in alone:
+        e["one_stream_avg_launch_us"] = float(alone[k]["AverageNs"]) / 1e3; e["one_stream_pct_of_kernel_time"] = float(alone[k]["Percentage"])
     if k in tr:
         e["hbm_bytes_per_launch"] = int(tr[k]["hbm_bytes_per_launch"])
     if k in va:
