@@ -73,7 +73,7 @@ def test_shi_tomasi_fuzz(w, h, kind, seed, bs, md, q, radius, maxc):
     assert np.array_equal(mask, m) and np.array_equal(eig, reig) and nc == rnc
     if isinstance(corners, VoError):
         # flat plateaus (every pixel a 3x3 maximum): more candidates than the LDS sort holds and the strongest 16384 do not
-        # fill max_corners -> the library reports it instead of returning a possibly different list
+        # fill max_corners -> the library reports it instead of returning a possibly different list (EXPERIMENTS.md, design section 8)
         assert corners.code == -5 and rnc > 16384
     else:
         assert np.array_equal(corners, ref)

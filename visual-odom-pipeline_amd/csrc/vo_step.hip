@@ -199,7 +199,7 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
   // up to two steps may be in flight: step t + 1 is enqueued while the host still reads step t's (pinned) results.
   // A captured graph has its host destination baked in: one graph per (frame parity, mirror half), so graph mode keeps two steps
   // in flight as well (round 2 kept ONE graph per parity and one step in flight -- that, not the replay itself, is what made graph
-  // mode 0.2 ms per frame slower: tools/graph_probe.hip)
+  // mode 0.2 ms per frame slower: tools/graph_probe.hip, EXPERIMENTS.md, design section 8)
   VO_CHECK(c, c->steps_enq - c->steps_fetched < 2, VO_E_STATE, "vo_frame_fetch the previous step(s) first");
   c->main_dirty = true;
   const int half = (int)(c->steps_enq & 1);
