@@ -1475,6 +1475,9 @@ static ba_ptrs ba_make_ptrs(const vo_ctx* c) {
     int G = vo_div_up(BA2_TARGET_WAVES, 4 * c->batch);
     if (const char* e = getenv("VO_BA_G")) { if (atoi(e) > 0) G = atoi(e); }
     if (G > gmax) G = gmax;
+    // small windows, whose partial sets k_ba_solve sums itself (one value per thread): more than 16 sets make that loop the longest kernel
+    // of an iteration (ONE sequence, window 4: 32 sets 3 490, 16 sets 3 580, 8 sets 3 490 frames/s through the closed loop)
+    { const int n1 = 6 * b->W + 1; if ((n1 * (n1 + 1)) / 2 + b->W * BA_POSE_VALS <= BA_SOLVE_THREADS && G > 16 && !getenv("VO_BA_G")) G = 16; }
     if (G < 1) G = 1;
     P.nset = G; P.n_eval = G;
     // once problems of the batch have finished, a running one is given up to 16 workgroups (ba2_select_work)
