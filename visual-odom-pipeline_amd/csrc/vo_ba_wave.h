@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
 // ------------------------------------------------------------------------------------------------
 // grid (G0 * batch), 256 lanes, the same assignment as k_ba_build_w of the iteration; step statistics: one entry of evalpart per part
 template <int SPL, int LPP>
-__global__ void __launch_bounds__(256, 4) k_ba_update_w(ba_ptrs Pall, ba_params_dev prm, int it, double* __restrict__ probe_dl, int G0, int Gcap) {
+__global__ void __launch_bounds__(256, 2) k_ba_update_w(ba_ptrs Pall, ba_params_dev prm, int it, double* __restrict__ probe_dl, int G0, int Gcap) {
   constexpr int LPC = ba2_map<LPP>::LPC, LEAD = ba2_map<LPP>::LEAD;
   const ba2_work wk = ba2_select_work<false>(Pall, it, G0, Gcap);
   if (wk.prob < 0) return;
@@ -560,6 +560,15 @@ __global__ void __launch_bounds__(256, 4) k_ba_update_w(ba_ptrs Pall, ba_params_
       uo[i] = __builtin_nan(""); vo[i] = 0.0;
       if (s < W && inr) { const double2 ob = *reinterpret_cast<const double2*>(P.obs + ((size_t)s * N + j) * 2); uo[i] = ob.x; vo[i] = ob.y; }
     }
+    double ax[15];
+    if (inr) {
+      const double* axp = P.aux + (size_t)j * BA_AUX;
+#pragma unroll
+      for (int k = 0; k < 15; k++) ax[k] = axp[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 15; k++) ax[k] = 0.0;
+    }
     // B^T d_pose = sum over the slots of w Jl^T (Jp d_pose), Jp d without forming Jp:  -Jl (X x (Jr d_rot)) + A d_trans
     double v0 = 0, v1 = 0, v2 = 0;
 #pragma unroll
@@ -581,16 +590,6 @@ __global__ void __launch_bounds__(256, 4) k_ba_update_w(ba_ptrs Pall, ba_params_
     }
     v0 = ba2_from_leader<LPP>(ba2_group_sum<LPP>(v0), lead4); v1 = ba2_from_leader<LPP>(ba2_group_sum<LPP>(v1), lead4);
     v2 = ba2_from_leader<LPP>(ba2_group_sum<LPP>(v2), lead4);
-    asm volatile("" ::: "memory");      // (keeps the loads below behind the linearisation above: they would sit in 30 registers through it)
-    double ax[15];
-    if (inr) {
-      const double* axp = P.aux + (size_t)j * BA_AUX;
-#pragma unroll
-      for (int k = 0; k < 15; k++) ax[k] = axp[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 15; k++) ax[k] = 0.0;
-    }
     const double w0 = ax[6] + v0, w1 = ax[7] + v1, w2 = ax[8] + v2;
     const double i00 = ax[9], i10 = ax[10], i11 = ax[11], i20 = ax[12], i21 = ax[13], i22 = ax[14];
     const double t0 = i00 * w0, t1 = i10 * w0 + i11 * w1, t2 = i20 * w0 + i21 * w1 + i22 * w2;   // Cinv u
