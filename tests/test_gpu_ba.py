@@ -15,6 +15,15 @@ def _load(path):
     return g, K, poses, points, obs
 
 
+@pytest.fixture(autouse=True, params=["wave_private", "lane_per_observation"])
+def ba_kernels(request, monkeypatch):
+    """every test of this module runs through BOTH kernel families: the wave-private build / update (csrc/vo_ba_wave.h: what a batched context
+    runs for windows <= 10) and the lane-per-observation ones (windows of 11-20 slots; VO_BA_V2=0 selects them for every window).  VO_BA_V2 is
+    read at every upload."""
+    monkeypatch.setenv("VO_BA_V2", "1" if request.param == "wave_private" else "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def ctx():
     from vo_mi355x import VoContext

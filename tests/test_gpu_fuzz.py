@@ -93,10 +93,16 @@ def test_ba_fuzz(n_pts, n_slots, seed, vis, noise):
         obs[rng.integers(0, n_slots)] = np.nan                       # a frame that sees nothing
     if np.isfinite(obs[..., 0]).sum() < 1:
         return
-    with VoContext(64, 64, max_pts=64) as c:
-        c.ba_upload(s["K"], s["poses0"], s["points0"], obs)
-        pr = c.ba_probe(lam=1e-3)
-        po, pt, stt = c.ba_adjust(s["K"], s["poses0"], s["points0"], obs, c.ba_params(max_iters=8))
+    # both kernel families (VO_BA_V2 is read at every upload): the wave-private build / update of windows <= 10 -- every lane map (4, 8 and 5
+    # lanes per landmark), every panel width -- on even seeds, the lane-per-observation kernels (windows of 11-20 slots; here forced for every window) on odd ones
+    os.environ["VO_BA_V2"] = "1" if seed % 2 == 0 else "0"
+    try:
+        with VoContext(64, 64, max_pts=64) as c:
+            c.ba_upload(s["K"], s["poses0"], s["points0"], obs)
+            pr = c.ba_probe(lam=1e-3)
+            po, pt, stt = c.ba_adjust(s["K"], s["poses0"], s["points0"], obs, c.ba_params(max_iters=8))
+    finally:
+        del os.environ["VO_BA_V2"]
     ne = bo.normal_equations(s["K"], s["poses0"], s["points0"], obs)
     rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
     assert rel(pr["Hpp"], ne["Hpp"]) <= 1e-9 and rel(pr["Hll"], ne["Hll"]) <= 1e-9 and rel(pr["gp"], ne["gp"]) <= 1e-9

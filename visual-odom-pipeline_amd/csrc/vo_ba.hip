@@ -1322,6 +1322,9 @@ static void ba_geometry(vo_ba_ws* b, int W, int N) {
   // wave-private kernels: RT column blocks (6 W + 1 <= 16 RT <= 64), a lane serves SPL = ceil(W / 8) slots.  VO_BA_V2=0: the older kernels (A/B knob)
   b->v2 = (W <= 10) ? 1 : 0;
   if (const char* e = getenv("VO_BA_V2")) b->v2 = (W <= 10 && atoi(e) != 0) ? 1 : 0;
+  // (one problem alone is the one shape the older kernels still win: build 12 against 16 us per iteration -- a wave-private workgroup spends
+  //  ~7 us on its LM decision, camera staging and the four-wave fold of its tiles whatever it walks; 18 against 17 at four problems, 65 against
+  //  49 at 32.  Not switched by the batch: a batched context stays bit-identical to single contexts, tests/test_gpu_batch.py)
   b->v2_rt = b->RT; b->v2_spl = (W + 7) / 8;
   // windows of 9 and 10 slots: 5 lanes per landmark (12 landmarks per wave), else 8 (VO_BA_LPP5=0: 8 for every window, A/B knob)
   // and 4 for windows of <= 4 slots (16 landmarks per wave)

@@ -214,11 +214,19 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
   __shared__ ba_state s_st;
   __shared__ double s_esum[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if (it > 0) ba_reduce_evalpart<256>(P.sharded ? P.xstat : P.evalpart, P.sharded ? 1 : Pall.gdyn[((it - 1) & 1) * Pall.batch + wk.prob], s_esum);
+  // what the decision reads -- the previous state, k_ba_solve's record, the live-slot count -- is requested BEFORE the step statistics are
+  // summed: one trip to memory instead of three dependent ones at the head of every workgroup
+  const int n_live_ld = Pall.n_live ? *P.n_live : P.N;
+  ba_state prev;
+  ba_info inf;
+  if (it > 0) {
+    if (tid == 0) { prev = P.state[(it - 1) & 1]; inf = *P.info; }
+    ba_reduce_evalpart<256>(P.sharded ? P.xstat : P.evalpart, P.sharded ? 1 : Pall.gdyn[((it - 1) & 1) * Pall.batch + wk.prob], s_esum);
+  }
   if (tid == 0) {
     ba_state st;
     if (it == 0) st = ba_init_state(prm);
-    else ba_decide(P.state[(it - 1) & 1], *P.info, s_esum, prm, st);
+    else ba_decide(prev, inf, s_esum, prm, st);
     if (probe_lambda >= 0) st.lambda = probe_lambda;
     s_st = st;
     if (part == 0) { P.state[it & 1] = st; Pall.gdyn[(it & 1) * Pall.batch + wk.prob] = G; }
@@ -231,35 +239,12 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
   const int W = P.W, N = P.N;
   const double* poses = (it == 0) ? P.x0 : ba_x(P, st.cur);
   const double* pts = poses + 6 * W;
-  // cameras: [R | t | Jr] from the poses (iteration 0) or as k_ba_solve left them, then K R, K t per camera
-  if (tid < W) {
-    double c[BA_CAM];
-    if (it == 0) d_camera(poses + 6 * tid, c);
-    else {
-      const double* cg = P.cams + ((size_t)st.cur * W + tid) * BA_CAM;
-#pragma unroll
-      for (int k = 0; k < BA_CAM; k++) c[k] = cg[k];
-    }
-    ba2_stage_camera(P.K, c, s_cam + BA2_CAM * tid);
-    if (it == 0 && part == 0) {
-#pragma unroll
-      for (int k = 0; k < BA_CAM; k++) P.cams[(size_t)tid * BA_CAM + k] = c[k];   // cams[0] <-> x[0]
-    }
-  }
-  if (it == 0 && part == 0 && tid < 6 * W) P.xa[tid] = poses[tid];
-  // the padding columns behind 6 W + 1 start as zeros and are never written afterwards (every chunk rewrites the columns before them in
-  // every row: a lane without a landmark writes zeros)
-  {
-    const int npad = RP - (6 * W + 1);
-    for (int i = tid; i < 4 * ROWS * npad; i += 256) { const int r = i / npad; dyn[r * PITCH + 6 * W + 1 + (i - r * npad)] = 0.0; }
-    if (PITCH > RP) for (int i = tid; i < 4 * ROWS * (PITCH - RP); i += 256) { const int r = i / (PITCH - RP); dyn[r * PITCH + RP + (i - r * (PITCH - RP))] = 0.0; }
-  }
-  __syncthreads();
+  // (the first chunk's landmark and observations are requested before the cameras are staged: two trips to memory overlap)
   const ba2_map<LPP> mp(lane);
   const int pl = mp.pl, q = mp.q;
   const int lead4 = 4 * (lane - q + LEAD);        // (LPP = 5) ds_bpermute source: the leader of this lane's group
   const int nchunk = (N + LPC - 1) / LPC;
-  const int n_live = P.n_live ? *P.n_live : N;
+  const int n_live = n_live_ld;
   const int nchunk_live = min(nchunk, (n_live + LPC - 1) / LPC);
   const bool seed_x = it == 0;
   double* const pan = dyn + wave * REGION;
@@ -288,6 +273,30 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
     }
   };
   fetch(part * 4 + wave);
+  // cameras: [R | t | Jr] from the poses (iteration 0) or as k_ba_solve left them, then K R, K t per camera
+  if (tid < W) {
+    double c[BA_CAM];
+    if (it == 0) d_camera(poses + 6 * tid, c);
+    else {
+      const double* cg = P.cams + ((size_t)st.cur * W + tid) * BA_CAM;
+#pragma unroll
+      for (int k = 0; k < BA_CAM; k++) c[k] = cg[k];
+    }
+    ba2_stage_camera(P.K, c, s_cam + BA2_CAM * tid);
+    if (it == 0 && part == 0) {
+#pragma unroll
+      for (int k = 0; k < BA_CAM; k++) P.cams[(size_t)tid * BA_CAM + k] = c[k];   // cams[0] <-> x[0]
+    }
+  }
+  if (it == 0 && part == 0 && tid < 6 * W) P.xa[tid] = poses[tid];
+  // the padding columns behind 6 W + 1 start as zeros and are never written afterwards (every chunk rewrites the columns before them in
+  // every row: a lane without a landmark writes zeros)
+  {
+    const int npad = RP - (6 * W + 1);
+    for (int i = tid; i < 4 * ROWS * npad; i += 256) { const int r = i / npad; dyn[r * PITCH + 6 * W + 1 + (i - r * npad)] = 0.0; }
+    if (PITCH > RP) for (int i = tid; i < 4 * ROWS * (PITCH - RP); i += 256) { const int r = i / (PITCH - RP); dyn[r * PITCH + RP + (i - r * (PITCH - RP))] = 0.0; }
+  }
+  __syncthreads();
   int nwalk = 0;
 #pragma unroll 1
   for (int chunk = part * 4 + wave; chunk < nchunk; chunk += 4 * G) {
