@@ -1,4 +1,7 @@
-"""G5 on the device: `vo_mi355x.resident.ResidentPipeline` (csrc/vo_pipeline.hip, every stage a HIP kernel) against the reference's
+"""G5 on the device -- CONDITIONAL ON ONE SUBSTITUTION (see tests/test_pipe_golden.py): the goldens are the reference's `Pipeline.step` with scipy's
+`least_squares` replaced by the LM of oracle/ba_oracle.py.
+
+`vo_mi355x.resident.ResidentPipeline` (csrc/vo_pipeline.hip, every stage a HIP kernel) against the reference's
 OWN `Pipeline.step` (/root/reference/src/pipeline/pipeline.py:92-167, dumped frame by frame by tests/golden/gen_golden.py --pipe-only
 over the CPU oracle; tests/test_pipe_golden.py holds the CPU restatements to the same files bit for bit).
 

@@ -1,6 +1,10 @@
-"""G5: the closed loop against the reference's OWN `Pipeline.step` (/root/reference/src/pipeline/pipeline.py:92-167, imported unmodified
-by tests/golden/gen_golden.py --pipe-only: stand-in `visu`, cv2 = the stub over the CPU oracle, scipy's least_squares inside
-bundle_adjuster.py replaced by the LM of oracle/ba_oracle.py) -- frame by frame and entry by entry on the CPU oracle back end:
+"""G5 -- CONDITIONAL ON ONE SUBSTITUTION: the reference's `Pipeline.step` with `scipy.optimize.least_squares` inside its `bundle_adjuster` module
+replaced by the LM of oracle/ba_oracle.py (the solver `north_star` asks for).  With scipy's TRF left in, the landmark positions differ and the
+lists diverge after the first PnP; that run (`pipe_scipy_w4.npz`) is compared statistically at the bottom of this file, not entry by entry.
+
+The closed loop against the reference's OWN `Pipeline.step` (/root/reference/src/pipeline/pipeline.py:92-167, imported unmodified
+by tests/golden/gen_golden.py --pipe-only: stand-in `visu`, cv2 = the stub over the CPU oracle, the substitution above) -- frame by frame and
+entry by entry on the CPU oracle back end:
 
   * `pipe_helpers.ObjectLoop`  (the reference's loop restated over the drop-in Extractor / BundleAdjuster)  = G5
   * `pipe_oracle.PipeModel`    (the table algorithm csrc/vo_pipeline.hip implements)                         = G5
