@@ -72,6 +72,54 @@ def test_lazy_desync_and_reseed():
     assert started == [1, 4, 8] and ex._lazy.alive, started
 
 
+def test_lazy_history_beyond_the_device_ring_is_complete():
+    """`Keypoint.uv_history` is unbounded in the reference (state/keypoint.py:4-21); the device keeps the last 32 entries of a row.  Over 44 frames
+    (histories of up to 47 entries: the first 15 have left the ring) the lazy classes hand out the WHOLE history of every keypoint -- state lists and
+    dead lists (rows the device COPIED where the reference deep-copies), deep copies, and after the session has ended -- equal, entry for entry, to what the
+    plain object path accumulates (the session archives what leaves the ring: `lazy._HistArchive`)."""
+    from vo_mi355x import synthetic as syn
+    sc = syn.sway_scene(48, w=256, h=160, f=260.0, seed=2024, pose_fn=lambda t: syn.sway_pose(t, period=24.0))
+
+    def run(lazy, n):
+        ctx = _oracle_ctx(256, 160)
+        ctx.max_pts, ctx.batch = 2048, 1
+        state, t1 = ph.gt_bootstrap(ctx, sc, 0, 3)
+        loop = ph.ObjectLoop(ctx, sc["K"], state, sc["frames"][t1], t_step=1, ba_window=4, literal=True, lazy=lazy,
+                             lazy_backend=lambda c, K, prm, ww, hh: ModelBackend(c, K, prm, ww, hh, cap=2048))
+        for k in range(n):
+            loop.step(sc["frames"][t1 + 1 + k])
+        return loop
+
+    n = 44
+    a = run(True, n)
+    b = run(False, n)
+    sess = a.extractor._lazy
+    assert sess is not None and sess.alive and len(sess._arch.blocks) >= 2
+
+    def hist(k):
+        return np.array([np.asarray(h, np.float64).reshape(2) for h in k.uv_history])
+
+    def same(ka, kb, what):
+        ha, hb = hist(ka), hist(kb)
+        assert ha.shape == hb.shape and np.array_equal(ha, hb), (what, ha.shape, hb.shape)
+        return len(ha)
+    longest = 0
+    for la, lb, what in ((a.state._landmarks_kp, b.state._landmarks_kp, "landmark keypoints"), (a.state._candidates_kp, b.state._candidates_kp, "candidates"),
+                         (a.dead_kp, b.dead_kp, "dead keypoints")):
+        assert len(la) == len(lb), what
+        for ka, kb in zip(la, lb):
+            longest = max(longest, same(ka, kb, what))
+    assert longest > 40                                          # histories well beyond the 32-entry ring occurred
+    old = [k for k in a.state._landmarks_kp if len(k.uv_history) > 36][:5]
+    ref = [kb for ka, kb in zip(a.state._landmarks_kp, b.state._landmarks_kp) if len(ka.uv_history) > 36][:5]
+    cp = copy.deepcopy(old)                                      # a copy of an attached proxy carries the archived part with it
+    a.state._candidates_kp[0].t_total = int(a.state._candidates_kp[0].t_total)      # an outside write ends the session: every proxy becomes a plain object
+    assert not sess.alive
+    for ka, kc, kb in zip(old, cp, ref):
+        same(ka, kb, "after the session ended"); same(kc, kb, "deep copy")
+        assert not np.isnan(hist(ka)).any()
+
+
 def test_lazy_off_is_the_plain_path():
     g = pg.load("w4")
     loop, sc, fos, t0 = _loop(g, lazy=False)

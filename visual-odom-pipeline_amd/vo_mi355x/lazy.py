@@ -66,7 +66,7 @@ class _Proxy:
                 return d["_sess"]._field(self, name)
             rec = d.get("_rec")
             if rec is not None:
-                v = _field_of(self._KIND, rec, name)
+                v = _field_of(self._KIND, rec, name, d.get("_older"))
                 d[name] = v
                 return v
             if row == -2:
@@ -96,9 +96,13 @@ class _Proxy:
         nd["_row"] = -1
         if d.get("_row", -1) >= 0:                 # attached: the copy is an independent plain object with the values of now
             nd["_rec"] = d["_sess"]._gather(self._KIND, [d["_row"]])[0].copy()
+            if self._KIND == "K":
+                nd["_older"] = d["_sess"]._older(nd["_rec"], d["_row"])
         else:
             if "_rec" in d:
                 nd["_rec"] = d["_rec"].copy()
+                if d.get("_older") is not None:
+                    nd["_older"] = d["_older"]
             for f in self._FIELDS:
                 if f in d:
                     nd[f] = copy.deepcopy(d[f], memo)
@@ -108,8 +112,9 @@ class _Proxy:
         return "<%s row %d>" % (type(self).__name__, self.__dict__.get("_row", -1))
 
 
-def _field_of(kind, rec, name):
-    """one field of a packed table row (resident.ResidentPipeline.K_ROW / L_ROW) as the reference's objects hold it"""
+def _field_of(kind, rec, name, older=None):
+    """one field of a packed table row (resident.ResidentPipeline.K_ROW / L_ROW) as the reference's objects hold it; older: the history entries
+    that have left the row's ring ([hist_len - 32, 2] float32 from the session's archive, NaN where it has none)"""
     if kind == "L":
         if name == "t_latest":
             return int(rec["t_latest"])
@@ -128,8 +133,13 @@ def _field_of(kind, rec, name):
         n = int(rec["hist_len"])
         ring = np.array(rec["hist"], np.float32)
         lo = max(0, n - HIST)
-        # entries older than the ring (32) are gone: the window never reaches them (<= 20 frames); NaN stands in
-        return [np.full((2, 1), np.nan, np.float32)] * lo + [ring[i % HIST].reshape(2, 1).copy() for i in range(lo, n)]
+        # entries older than the device's ring (32; a window reaches 20) come from the host-side archive of the session (`_HistArchive`); without
+        # one (a row read outside a session) NaN stands in
+        if older is not None and len(older) == lo:
+            head = [older[i].reshape(2, 1).copy() for i in range(lo)]
+        else:
+            head = [np.full((2, 1), np.nan, np.float32) for _ in range(lo)]
+        return head + [ring[i % HIST].reshape(2, 1).copy() for i in range(lo, n)]
     return np.zeros((1, 1))
 
 
@@ -220,6 +230,86 @@ class DeviceBackend:
 # ------------------------------------------------------------------------------------------------------------------------------------
 # the session
 # ------------------------------------------------------------------------------------------------------------------------------------
+ARCH_EVERY = 16          # frames between two archive passes (<= half the ring: consecutive passes overlap)
+ARCH_BLOCKS = 4096       # passes kept (65 536 frames); older history entries come back as NaN
+
+
+class _HistArchive:
+    """`Keypoint.uv_history` is unbounded in the reference (state/keypoint.py:4-21: one entry per frame since detection, candidate phase included);
+    the device keeps the last 32 entries per row.  Every ARCH_EVERY frames the session copies the newest ARCH_EVERY entries of every keypoint row
+    that has a proxy to the host (one bulk gather), so that a caller who reads an old history gets all of it -- the window of the bundle
+    adjustment never reaches that far, nothing on the device needs it.
+    Rows are COPIED on the device where the reference deep-copies a keypoint (deaths, pruned non-inliers, survivors that shared a row): the copy
+    starts life in a new row with the history of its source.  What such a row has no record of itself is taken from the rows that share its
+    identity (birth frame and first position): of those, the one whose entries agree longest with the row's own oldest known entries is its
+    source (two lines of descent of one keypoint -- a resurrected dead copy tracked beside the original -- differ from where they parted)."""
+
+    def __init__(self):
+        self.blocks = []          # (rows [m] sorted, t_first [m], uv_first [m, 2], n [m], data [m, ARCH_EVERY, 2]): entries n - ARCH_EVERY .. n - 1 then
+        self.seeded = {}          # row -> (t_first, uv_first (2,), [n, 2]): the whole history of an object the session was seeded with
+
+    def add(self, rows, recs):
+        if not len(rows):
+            return
+        n = recs["hist_len"].astype(np.int64)
+        idx = n[:, None] - ARCH_EVERY + np.arange(ARCH_EVERY)[None, :]
+        data = np.array(recs["hist"], np.float32)[np.arange(len(rows))[:, None], idx % HIST]
+        data[idx < 0] = np.nan
+        self.blocks.append((np.asarray(rows, np.int64), recs["t_first"].astype(np.int64), np.array(recs["uv_first"], np.float32).reshape(-1, 2), n, data))
+        if len(self.blocks) > ARCH_BLOCKS:
+            del self.blocks[0]
+
+    def _own(self, row, t_first, uv_first, n_hi):
+        """what the archive holds of the keypoint (born at t_first at uv_first: rows are recycled, and a copy keeps its source's birth frame) while
+        it lived in `row`: entries 0 .. n_hi - 1, NaN where it has none"""
+        out = np.full((n_hi, 2), np.nan, np.float32)
+        sd = self.seeded.get(row)
+        if sd is not None and sd[0] == t_first and sd[1][0] == uv_first[0] and sd[1][1] == uv_first[1]:
+            m = min(len(sd[2]), n_hi)
+            out[:m] = sd[2][:m]
+        for rows, tf, uvf, n, data in self.blocks:
+            i = int(np.searchsorted(rows, row))
+            if i < len(rows) and rows[i] == row and tf[i] == t_first and uvf[i, 0] == uv_first[0] and uvf[i, 1] == uv_first[1]:
+                lo = int(n[i]) - ARCH_EVERY
+                a, b = max(lo, 0), min(int(n[i]), n_hi)
+                if b > a:
+                    out[a:b] = data[i, a - lo:b - lo]
+        return out
+
+    def _relatives(self, row, t_first, uv_first):
+        """other rows that hold (or held) a keypoint with this birth frame and first position"""
+        rel = set()
+        for r, sd in self.seeded.items():
+            if r != row and sd[0] == t_first and sd[1][0] == uv_first[0] and sd[1][1] == uv_first[1]:
+                rel.add(r)
+        for rows, tf, uvf, _, _ in self.blocks:
+            hit = np.nonzero((tf == t_first) & (uvf[:, 0] == uv_first[0]) & (uvf[:, 1] == uv_first[1]))[0]
+            rel.update(int(rows[i]) for i in hit if rows[i] != row)
+        return rel
+
+    def older(self, row, t_first, uv_first, n, ring):
+        """entries 0 .. n - 33 of the keypoint in `row` (history length n > 32, `ring` = its 32-entry ring)"""
+        n_old = n - HIST
+        own = self._own(row, t_first, uv_first, n)
+        for i in range(n_old, n):
+            own[i] = ring[i % HIST]
+        miss = np.isnan(own[:n_old, 0])
+        if miss.any():
+            first = int(np.argmax(~np.isnan(own[:, 0])))         # the oldest entry the row knows of itself
+            best, best_len = None, 0
+            for r in self._relatives(row, t_first, uv_first):
+                cand = self._own(r, t_first, uv_first, n)
+                k = first
+                while k < n and not np.isnan(cand[k, 0]) and cand[k, 0] == own[k, 0] and cand[k, 1] == own[k, 1]:
+                    k += 1
+                if k - first > best_len:
+                    best, best_len = cand, k - first
+            if best is not None:
+                fill = miss & ~np.isnan(best[:n_old, 0])
+                own[:n_old][fill] = best[:n_old][fill]
+        return own[:n_old].copy()
+
+
 def _idle_refcount():
     """sys.getrefcount of an object that has just left the only container that held it and is bound to ONE local name -- measured on this
     interpreter instead of assumed (CPython 3.10: the local name + getrefcount's argument = 2; an interpreter that borrows references on
@@ -249,6 +339,8 @@ class Session:
         self._cache = {}                                  # kind -> (row -> index, structured array) of the last bulk gather
         self.stats = dict(fast=0, stages=0, gathers=0)
         self._hinted = []         # proxies carrying a `_copy` hint of the last camera_pose (see _drop_hints)
+        self._arch = _HistArchive()
+        self._arch_frames = 0     # frames since the last archive pass
 
     # ---- proxies / mirrors -----------------------------------------------------------------------------------------------------------
     def _proxies(self, kind, rows):
@@ -333,6 +425,19 @@ class Session:
         self.stats["gathers"] += 1
         return self.be.rows(kind, np.asarray(rows, np.int32))
 
+    def _older(self, rec, row):
+        """the part of a keypoint row's history that has left its ring, from the archive (None: the ring holds everything)"""
+        n = int(rec["hist_len"])
+        if n <= HIST:
+            return None
+        return self._arch.older(int(row), int(rec["t_first"]), np.array(rec["uv_first"], np.float32).reshape(2), n, np.array(rec["hist"], np.float32))
+
+    def _archive_pass(self):
+        rows = np.nonzero(self._hasK)[0]
+        if len(rows):
+            self._arch.add(rows, self._gather("K", rows))
+        self._arch_frames = 0
+
     def _fill(self, proxies, detach=True):
         """the proxies take the table rows they stand for with them (`_rec`) and become plain objects; their fields are built on first use"""
         for kind in ("K", "L"):
@@ -343,6 +448,8 @@ class Session:
             for p, rec in zip(ps, recs):
                 d = p.__dict__
                 d["_rec"] = rec.copy()
+                if kind == "K":
+                    d["_older"] = self._older(rec, d["_row"])
                 d["_row"] = -1
                 d.pop("_sess", None)
                 d.pop("_copy", None)               # a plain object copies itself
@@ -359,7 +466,8 @@ class Session:
         key = (proxy.__dict__["_row"], name)
         v = vals.get(key)
         if v is None:
-            v = vals[key] = _field_of(kind, recs[index[key[0]]], name)
+            rec = recs[index[key[0]]]
+            v = vals[key] = _field_of(kind, rec, name, self._older(rec, key[0]) if (kind == "K" and name == "uv_history") else None)
         return v
 
     def _drop_hints(self):
@@ -416,6 +524,12 @@ class Session:
         L = self._refresh(("cand", "lm", "dead"), retire=True)
         if not (len(L["lm_l"]) == len(state._landmarks) and len(L["cand"]) == len(state._candidates_kp) and len(L["dead_l"]) == len(dead)):
             raise RuntimeError("seed: the tables do not hold the lists they were seeded with")
+        for objs, rows in ((state._landmarks_kp, L["lm_k"]), (state._candidates_kp, L["cand"]), (dead_kp, L["dead_k"])):
+            for k, r in zip(objs, rows.tolist()):
+                # (every history, however short: an archive pass keeps the newest ARCH_EVERY entries of a row, the passes are ARCH_EVERY frames
+                #  apart, so everything older than the first pass's reach has to be on the host already)
+                self._arch.seeded[r] = (int(k.t_first), np.asarray(k.uv_first, np.float32).reshape(2),
+                                        np.array([np.asarray(h, np.float32).reshape(2) for h in k.uv_history], np.float32).reshape(-1, 2))
         state._landmarks[:] = self.lm_L
         state._landmarks_kp[:] = self.lm_K
         state._candidates_kp[:] = self.cand
@@ -587,6 +701,9 @@ class Session:
         if len(new) != rec["n_detected"]:
             return self._fail("extract: list length")
         self._refresh(("cand",), retire=True)
+        self._arch_frames += 1
+        if self._arch_frames >= ARCH_EVERY:
+            self._archive_pass()
         self.stats["fast"] += 1
         return LazyList(self.cand[n_c0:])
 
