@@ -961,7 +961,18 @@ def kernel_rooflines():
             r["mfma_f64_tflops"] = round(e["mfma_flops_f64_per_launch"] / t / 1e12, 2)
             r["mfma_f64_frac_of_78.6_tflops"] = round(e["mfma_flops_f64_per_launch"] / t / 78.6e12, 4)
         out.append(r)
+    # the roof the WHOLE step runs against: every kernel of it is bound by vector-instruction issue (or, the BA build, by float64 MFMAs that
+    # block the same issue slots for 64 cycles = 14 quarter-rate instructions: profiles/r05_mfma_overlap_probe.txt), so what a step costs
+    # is the instructions it issues.  Per traced step of the default command: sum over the kernels of calls x (vector wave-instructions +
+    # 14 x MFMAs) -- filled in by the caller with the measured step time
+    steps = max(1, min([e["calls"] for e in d.get("kernels", []) if "k_klt_track" in e["kernel"]] or [1]))
+    issue, hbm_step = 0.0, 0.0
+    for e in d.get("kernels", []):
+        per_launch = e.get("valu_insts_per_launch", 0.0) + 14.0 * e.get("mfma_flops_f64_per_launch", 0.0) / 2048.0
+        issue += per_launch * e["calls"] / steps
+        hbm_step += e.get("hbm_bytes_per_launch", 0) * e["calls"] / steps
     return {"source": "profiles/kernel_counters.json (%s)%s" % (d.get("measured"), "; STALE: the kernel sources changed since" if stale else ""),
+            "issue_slots_per_step": int(issue), "hbm_bytes_per_step": int(hbm_step),
             "files": d.get("files"), "stale": stale,
             "how": "avg_launch_us, pct: rocprofv3 --kernel-trace --stats of the default command (launches averaged over full and tail LM groups); "
                    "hbm = (2 x FETCH_SIZE + WRITE_SIZE) KB per launch / avg launch / 8 TB/s; valu_issue_frac = SQ_INSTS_VALU per launch / avg launch "
@@ -1267,6 +1278,7 @@ def main():
                 "avg_launch_us": round(klt_avg_s * 1e6, 3), "algorithmic_bytes_per_launch": int(klt_bytes),
                 "klt_mean_iters_per_level": [round(x, 3) for x in it_mean],
                 "kernels": kernel_rooflines(),
+                "issue": None,      # filled below: the whole step against the chip's vector-issue capacity
                 # the same launch when context 0 runs its steps alone after the timed region (no other context's kernels beside it)
                 "alone_avg_launch_us": round(stage["klt"] * 1e3, 3),
                 "alone_frac": round(klt_bytes / max(stage["klt"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 5),
@@ -1274,6 +1286,18 @@ def main():
                         "(see `valu`: instructions issued per launch against the SIMDs' issue rate) and moves `traffic` bytes per launch through HBM. "
                         "`frac` is the launch as timed INSIDE the run: with several batched contexts it shares the vector ALUs with the "
                         "Shi-Tomasi / BA kernels of the other contexts and takes longer than on its own (`alone_*`)"}
+        if roof["kernels"].get("issue_slots_per_step") and not c5 and s0.B * len(seqs) == 256:
+            slots = roof["kernels"]["issue_slots_per_step"]
+            step_s = dt / a.steps
+            roof["issue"] = {"issue_slots_per_step": slots, "step_ms": round(step_s * 1e3, 4),
+                             "frac_of_quarter_rate_capacity": round(slots * MIXED_CLK_PER_INST / (N_SIMDS * MIXED_CLK_HZ * step_s), 4),
+                             "what": "vector wave-instructions + 14 per float64 MFMA of ALL kernels of a 256-sequence step (rocprofv3 counters of the default command, "
+                                     "profiles/kernel_counters.json) x 4.1 clk (the rate a stream of quarter-rate instructions issues at, profiles/r02_issue_probe.txt) "
+                                     "/ (1024 SIMDs x 2.37 GHz x the step time measured in this run): how much of the chip's issue capacity the step uses -- the "
+                                     "bound of the whole workload (at the ~2.07 GHz the chip sustains under it, profiles/r05_mfma_overlap_probe.txt, the same count "
+                                     "is 1.14 x this fraction); HBM: `hbm_gb_s` over the step",
+                             "frac_at_2.07_ghz": round(slots * MIXED_CLK_PER_INST / (N_SIMDS * 2.07e9 * step_s), 4),
+                             "hbm_gb_s": round(roof["kernels"].get("hbm_bytes_per_step", 0) / step_s / 1e9, 1)}
         out = {"metric": ("frames/sec @1920x1080, 5000 KLT pts, 20-frame sharded BA (config 5)" if c5 else
                           "frames/sec @1241x376, 2000 KLT pts, 10-frame BA window"), "value": round(fps, 2),
                "unit": "frames/s", "n_gpus": dist.world, "steps": a.steps, "warmup": a.warmup,
