@@ -244,68 +244,3 @@ def test_ba_eight_lanes_per_landmark_matches_oracle_and_the_sixteen_lane_form(mo
         assert abs(st["cost"] - ref["cost"]) <= 1e-7 * ref["cost"], (key, st["cost"], ref["cost"])
         assert abs(st["cost"] - out["l16"][2]["cost"]) <= 1e-10 * st["cost"]
         assert np.abs(po - out["l16"][0]).max() <= 1e-9 and np.abs(pt - out["l16"][1]).max() <= 1e-8
-
-
-@pytest.mark.parametrize("W,n_pts", [(2, 130), (4, 1001), (5, 700), (7, 333), (8, 1000), (9, 500), (10, 2000), (10, 611)])
-def test_ba_wave_private_lane_maps_and_workgroup_counts(monkeypatch, ba_kernels, W, n_pts):
-    """csrc/vo_ba_wave.h: every lane map (4 lanes per landmark up to W = 4, 8 up to W = 8, 5 at W = 9 and 10 -- and 8 lanes with two slot passes,
-    VO_BA_LPP5=0), every panel width (1-4 column blocks), landmark counts that leave the last chunk partly filled, and workgroup counts from ONE
-    (a wave walks every fourth chunk) to one chunk per wave (VO_BA_G): same LM iteration / acceptance sequence and cost as the oracle, solutions
-    equal to 1e-9 between the forms (their summation orders differ)."""
-    if ba_kernels != "wave_private":
-        pytest.skip("the lane-per-observation kernels have their own tests above")
-    import ba_oracle as bo
-    from vo_mi355x import VoContext, synthetic as syn
-    s = syn.make_ba_scene(n_pts=n_pts, n_slots=W, seed=20 + W, visibility=0.85)
-    ref = bo.solve(s["K"], s["poses0"], s["points0"], s["obs"], max_iters=12)
-    out = {}
-    forms = [("rule", {}), ("g1", {"VO_BA_G": "1"}), ("g3", {"VO_BA_G": "3"}), ("g999", {"VO_BA_G": "999"})]
-    if W >= 9:
-        forms.append(("lpp8", {"VO_BA_LPP5": "0"}))
-    for key, env in forms:
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        with VoContext(64, 64, max_pts=64) as c:
-            out[key] = c.ba_adjust(s["K"], s["poses0"], s["points0"], s["obs"], c.ba_params(max_iters=12))
-        for k in env:
-            monkeypatch.delenv(k)
-    for key, (po, pt, st) in out.items():
-        assert st["iters"] == ref["iters"] and st["accepted"] == ref["accepted"] and st["status"] == ref["status"], (key, st, ref["iters"])
-        assert abs(st["cost"] - ref["cost"]) <= 1e-7 * ref["cost"], (key, st["cost"], ref["cost"])
-        assert np.abs(po - ref["poses"]).max() <= 1e-6 and np.abs(pt - ref["points"]).max() <= 1e-5
-        assert np.abs(po - out["rule"][0]).max() <= 1e-9 and np.abs(pt - out["rule"][1]).max() <= 1e-8, key
-
-
-def test_ba_running_problem_compaction(monkeypatch, ba_kernels):
-    """64 problems of one batch that need between 2 and 12 LM iterations: once some have finished, the launch groups hand their workgroups to
-    the ones still running (`ba2_select_work`: 8 workgroups per problem in a full launch, up to 16 in the tail) -- a problem's partial sums are
-    then folded in another order, nothing else may change: every problem = the same problem solved alone (iterations, acceptance sequence,
-    status; cost 1e-10; poses 1e-9, points 1e-6 of their distance), and the easy ones really did finish early."""
-    if ba_kernels != "wave_private":
-        pytest.skip("compaction is the wave-private kernels'")
-    from vo_mi355x import VoContext, synthetic as syn
-    B, N, W = 64, 800, 10
-    sc = []
-    for b in range(B):
-        kind = b % 4
-        s = syn.make_ba_scene(n_pts=N, n_slots=W, seed=300 + b, visibility=(1.0, 0.9, 0.7, 0.5)[kind], obs_noise=(0.05, 0.3, 0.5, 1.0)[kind],
-                              pt_noise=(0.02, 0.3, 0.6, 1.0)[kind])
-        if b % 16 == 0:                                   # already at its minimum's doorstep: the poses and points it was rendered from
-            s["poses0"], s["points0"] = s["poses_gt"].copy(), s["points_gt"].copy()
-        sc.append(s)
-    stack = lambda k: np.stack([s[k] for s in sc])
-    with VoContext(64, 64, max_pts=64, batch=B) as c:
-        prm = c.ba_params(max_iters=12)
-        po, pt, st = c.ba_adjust(stack("K"), stack("poses0"), stack("points0"), stack("obs"), prm)
-    its = [x["iters"] for x in st]
-    assert min(its) + 2 <= max(its), its                 # the batch had a tail
-    with VoContext(64, 64, max_pts=64) as c1:
-        for b in range(0, B, 3):
-            s = sc[b]
-            po1, pt1, st1 = c1.ba_adjust(s["K"], s["poses0"], s["points0"], s["obs"], c1.ba_params(max_iters=12))
-            assert (st[b]["iters"], st[b]["accepted"], st[b]["status"]) == (st1["iters"], st1["accepted"], st1["status"]), (b, st[b], st1)
-            assert abs(st[b]["cost"] - st1["cost"]) <= 1e-10 * max(st1["cost"], 1e-30), (b, st[b]["cost"], st1["cost"])
-            # (points: relative to their distance -- a landmark two frames saw under a small angle moves 1e-6 m along its ray for a change in
-            #  the last bits of its 3 x 3 block; the median landmark agrees to 1e-11)
-            dp = np.linalg.norm(pt[b] - pt1, axis=1) / np.linalg.norm(pt1, axis=1)
-            assert np.abs(po[b] - po1).max() <= 1e-9 and dp.max() <= 1e-6 and np.median(dp) <= 1e-11, (b, dp.max(), np.median(dp))
