@@ -13,7 +13,13 @@
 //   obs   [W][N][2]   slot-major (slot 0 = newest frame), NaN = not observed
 //   x[2]  {poses [W][6], points [N][3]}  current / trial, selected by state.cur
 //
-// Work mapping: ONE LANE PER OBSERVATION.  A landmark owns a group of LPP = 8 (W <= 8), 16 (W <= 16) or 32 lanes, lane s of
+// Two kernel families build and update (chosen by the window, ba_geometry):
+//   * windows of <= 10 slots (BASELINE's 10, the reference's own 4): the WAVE-PRIVATE k_ba_build_w / k_ba_update_w of vo_ba_wave.h -- a wave walks
+//     landmark chunks with all Gram tiles in its accumulator registers, 5 / 8 / 4 lanes per landmark, running-problem compaction of the tail groups;
+//   * windows of 11 .. 20 slots (config 5), the sharded solve's default, and VO_BA_V2=0: the kernels below.
+// k_ba_reduce / k_ba_solve / k_ba_finalize serve both.
+//
+// Work mapping of the kernels in this file: ONE LANE PER OBSERVATION.  A landmark owns a group of LPP = 8 (W <= 8), 16 (W <= 16) or 32 lanes, lane s of
 // the group handles the observation in window slot s; landmark sums are DPP row-rotate all-reduces inside the
 // group, camera sums are cross-group shuffles + one LDS pass, so every observation is linearised exactly once
 // per kernel and nothing is re-read from HBM.
@@ -1400,6 +1406,7 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build_w<2, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   }
   ba_geometry(c->ba, W, N);
+  if (c->batch > 1024) c->ba->v2 = 0;             // (ba2_select_work keeps the running-problem flags of <= 1 024 problems in LDS)
   VO_CHECK(c, c->ba->build_lds <= 130 * 1024 && c->ba->solve_lds <= 150 * 1024, VO_E_CAPACITY, "window too large for LDS");
   VO_CHECK(c, c->ba->nblk <= 640, VO_E_CAPACITY, "too many landmarks for one adjust (raise the partial capacity)");
   return VO_OK;
