@@ -1,0 +1,7 @@
+for rb in 0 188 126 94 76 63 0; do
+  out=$(VO_ST_RB=$rb timeout 120 python bench.py --no-extras --no-cpu-baseline --steps 60 2>/dev/null | tail -1)
+  python - "$out" $rb <<'P'
+import json, sys
+d = json.loads(sys.argv[1]); print("VO_ST_RB=%s %9.1f frames/s  %.4f ms/step  st %.4f ba %.4f" % (sys.argv[2], d["value"], d["ms_per_step"], d["stage_ms_per_batched_launch_group"]["shi_tomasi"], d["stage_ms_per_batched_launch_group"]["ba"]))
+P
+done

@@ -1166,11 +1166,21 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
   if (fused) {
     // rows per band: few bands keep the 30-row start-up small; with few sequences in flight more, shorter bands fill the GPU
     const int gx = vo_div_up(W, 256 - 32);
-    // (4 workgroups fit a CU -- k_st_eig_fused is built for 4 waves per SIMD --: as many bands as keep the launch within those
-    //  1024 slots, at least 12 rows each; KITTI frames in a batch of 32: 5 bands of 76 rows x 6 column blocks = 960 workgroups)
-    int gyw = 1024 / (gx * B);
-    if (gyw > H / 12) gyw = H / 12;
-    if (gyw < 1) gyw = 1;
+    // (5 workgroups fit a CU: 95 registers, 28.7 KB of LDS.)  Bands of at least 12 rows; among the band counts the one with the least
+    // rounds x rows per workgroup (rb + the 30-row start-up), where rounds = workgroups / 1 280 slots, rounded up: a launch of 1.2 rounds
+    // takes two.  KITTI frames, 6 column blocks: a batch of 32 -> 6 bands of 63 rows (1 152 workgroups, one round); a batch of 256 ->
+    // 4 bands of 94 rows (6 144 workgroups, 5 rounds x 124 rows; ONE band of 376 rows -- what "as many bands as fit the slots" came to there --
+    // is 2 rounds x 406: `k_st_eig_fused` 748 -> 590 us per launch, tools/st_bands.sh)
+    int gyw = 1;
+    {
+      const int gy_max = H / 12 > 1 ? H / 12 : 1;
+      long long best = -1;
+      for (int g = 1; g <= gy_max; g++) {
+        const int rbg = vo_div_up(H, g), gyg = vo_div_up(H, rbg);
+        const long long rounds = ((long long)gx * gyg * B + 1279) / 1280, cost = rounds * (rbg + 30);
+        if (best < 0 || cost < best) { best = cost; gyw = g; }
+      }
+    }
     int rb = vo_div_up(H, gyw);
     if (s->force_rb > 0) rb = s->force_rb < H ? s->force_rb : H;
     const int gy = vo_div_up(H, rb);
