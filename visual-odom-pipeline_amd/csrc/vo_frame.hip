@@ -68,6 +68,26 @@ __global__ void __launch_bounds__(256) k_pad_level0_bilateral(const uint8_t* __r
   dst[(size_t)Y * pitch + X] = (uint8_t)(int)__builtin_rintf(sum / wsum);
 }
 
+// Flat thread index -> (row, group) of a padded image whose groups [g_lo, g_hi) of every row take the interior path and the others the
+// border path (reflect-101 index arithmetic per byte): the interior pairs of ALL rows come first, the border pairs behind them, so a wave
+// runs ONE of the two paths.  (With the plain row-major index nearly every wave held a few border groups and executed both: k_pad_level0
+// issued 229 vector instructions per wave for a 16-byte copy, the pyrDown role of k_scharr_pyrdown ~300 instead of ~60.)
+// Returns true for an interior pair; Y >= rows: no work.
+__device__ __forceinline__ bool vo_split_index(unsigned gid, int rows, int gpr, int g_lo, int g_hi, int& Y, int& G) {
+  const int gi = g_hi - g_lo, gb = gpr - gi;
+  const unsigned n_int = (unsigned)rows * (unsigned)gi;
+  if (gid < n_int) {
+    Y = (int)(gid / (unsigned)gi);
+    G = g_lo + (int)(gid - (unsigned)Y * (unsigned)gi);
+    return true;
+  }
+  gid -= n_int;
+  Y = gb > 0 ? (int)(gid / (unsigned)gb) : rows;
+  const int j = gb > 0 ? (int)(gid - (unsigned)Y * (unsigned)gb) : 0;
+  G = j < g_lo ? j : g_hi + (j - g_lo);
+  return false;
+}
+
 __global__ void __launch_bounds__(256) k_pad_level0(const uint8_t* __restrict__ raw, size_t raw_seq_stride,
                                                     const int32_t* __restrict__ frame_idx, int w, int h,
                                                     uint8_t* __restrict__ dst, size_t dst_seq_stride, int pitch, int ph, int remap) {
@@ -78,8 +98,11 @@ __global__ void __launch_bounds__(256) k_pad_level0(const uint8_t* __restrict__ 
   vo_xcd_assign(blockIdx.z * gridDim.x + blockIdx.x, gridDim.x, remap, blk, bseq);
   const int gpr = (w + 2 * VO_PAD + 15) / 16;                        // 16-byte groups per padded row
   const unsigned gid = (unsigned)blk * blockDim.x + threadIdx.x;
-  const int Y = (int)(gid / (unsigned)gpr);
-  const int X = (int)(gid - (unsigned)Y * (unsigned)gpr) * 16;
+  // interior groups: X >= VO_PAD and X + 15 - VO_PAD < w
+  const int g_lo = VO_PAD / 16, g_hi = max(g_lo, min(gpr, (w + VO_PAD - 16 >= 0 ? (w + VO_PAD - 16) / 16 + 1 : 0)));
+  int Y, G;
+  const bool interior = vo_split_index(gid, ph, gpr, g_lo, g_hi, Y, G);
+  const int X = G * 16;
   if (Y >= ph) return;
   raw += (size_t)bseq * raw_seq_stride;
   dst += (size_t)bseq * dst_seq_stride;
@@ -87,7 +110,7 @@ __global__ void __launch_bounds__(256) k_pad_level0(const uint8_t* __restrict__ 
   const int y = d_reflect101(Y - VO_PAD, h);
   const uint8_t* row = raw + (size_t)y * w;
   uint32_t v[4];
-  if (X >= VO_PAD && X + 15 - VO_PAD < w) {
+  if (interior) {
     __builtin_memcpy(v, row + (X - VO_PAD), 16);         // interior: four unaligned dword loads
   } else {
 #pragma unroll
@@ -176,16 +199,19 @@ __global__ void __launch_bounds__(256) k_scharr_pyrdown(const uint8_t* __restric
     // ---- pyrDown: 5x5 [1 4 6 4 1]^2, (sum + 128) >> 8, output padded domain, 4 outputs per thread ----
     const int b = bx - nb_scharr;
     const int pw = dw + 2 * VO_PAD;
-    const int gpr = (pw + 3) / 4;                                         // dwords per padded destination row; flat (row, dword) index
+    const int gpr = (pw + 3) / 4;                                         // dwords per padded destination row
     const unsigned gid = (unsigned)b * 256u + threadIdx.x;
-    const int Y = (int)(gid / (unsigned)gpr);
-    const int X0 = (int)(gid - (unsigned)Y * (unsigned)gpr) * 4;
+    // interior dwords: X0 >= VO_PAD and X0 + 3 - VO_PAD < dw
+    const int g_lo = VO_PAD / 4, g_hi = max(g_lo, min(gpr, (dw + VO_PAD - 4 >= 0 ? (dw + VO_PAD - 4) / 4 + 1 : 0)));
+    int Y, G;
+    const bool interior = vo_split_index(gid, dh + 2 * VO_PAD, gpr, g_lo, g_hi, Y, G);
+    const int X0 = G * 4;
     if (Y >= dh + 2 * VO_PAD) return;
     const int y = d_reflect101(Y - VO_PAD, dh);
     // source is padded by 32 with reflect-101, so 2x-2 .. 2x+2 never needs index reflection
     const uint8_t* prow = src + (size_t)(2 * y + VO_PAD) * pitch + VO_PAD;
     uint32_t res = 0;
-    if (X0 >= VO_PAD && X0 + 3 - VO_PAD < dw) {
+    if (interior) {
       // interior: outputs x0 .. x0 + 3 read source columns 2 x0 - 2 .. 2 x0 + 8: 4 aligned dwords per source row
       const int x0 = X0 - VO_PAD;
       // the 25 taps of an output are five dwords-pairs: v_dot4_u32_u8 with the vertical weight folded into the byte weights
