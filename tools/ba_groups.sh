@@ -22,5 +22,7 @@ for r in rows:
         grp[n][idx[n]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for n in grp:
     print("%-16s" % n, " ".join("%d:%.0f" % (g, sum(v) / len(v)) for g, v in sorted(grp[n].items())), " (us, mean over %d steps)" % len(grp[n][1]))
+    print("%-16s" % "  median", " ".join("%d:%.0f" % (g, sorted(v)[len(v) // 2]) for g, v in sorted(grp[n].items())))
+    print("%-16s" % "  max", " ".join("%d:%.0f" % (g, max(v)) for g, v in sorted(grp[n].items())))
 PY
 rm -rf $OUT/${TAG}_grp
