@@ -33,3 +33,17 @@ def test_front_end_bit_exact_on_odd_sizes(w, h):
             ref, aux_eig, ncr = o.good_features(frames[1], m, maxCorners=300, qualityLevel=0.02, minDistance=md, blockSize=bs, return_aux=True)
             assert np.array_equal(mask, m) and np.array_equal(eig, aux_eig) and nc == ncr, (w, h, bs)
             assert np.array_equal(corners, ref), (w, h, bs)
+
+
+@pytest.mark.parametrize("w,h,win", [(34, 34, 5), (47, 33, 7), (36, 90, 5), (33, 200, 9), (64, 35, 5), (17, 17, 3), (16, 40, 3), (15, 15, 3),
+                                     (23, 9, 3), (130, 12, 5), (12, 130, 5)])
+def test_pyramid_and_klt_on_tiny_images(w, h, win):
+    """the pyramid kernels deal interior and border (row, group) pairs to separate index ranges (vo_split_index, csrc/vo_frame.hip): sizes where a
+    padded row has few or NO interior groups, with windows small enough that such images keep several levels -- levels, 4x Scharr and the tracker
+    (points at the image corners included) bit-exact against the oracle"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import tiny_sizes_check as t
+    levels, pyramid_ok, klt_ok = t.check(w, h, win)
+    assert levels >= 2 and pyramid_ok and klt_ok, (w, h, win, levels, pyramid_ok, klt_ok)
