@@ -57,7 +57,11 @@ def parse():
                     "96 in three contexts: --seqs 96 --ctxs 3 --side-stream on, also measured by the default run as `layout_3_contexts_of_32`)")
     ap.add_argument("--ctxs", type=int, default=None, help="batched contexts the sequences are split over; default 1 (the stream layout of a "
                     "context overlaps its own stages: DESIGN.md section 6)")
-    ap.add_argument("--ba-iters", type=int, default=10, help="LM iteration budget per adjust")
+    ap.add_argument("--ba-iters", type=int, default=None, help="LM iteration cap per adjust.  Default 30 for workload A: every solve of the workload stops by the LM's own "
+                    "ftol / xtol tests (the slowest in its 21st iteration); rounds 1-4 ran 10, where 1 %% of the solves were cut (`lm_cap_10` of the default line).  "
+                    "Default 10 for config5, whose launch budget is fixed at the cap (its solves take 5 iterations)")
+    ap.add_argument("--pipe-ba-iters", type=int, default=10, help="--workload pipeline: LM iteration cap per adjust (= the blind launch groups per frame unless "
+                    "--pipe-adaptive-budget)")
     ap.add_argument("--frames", type=int, default=100, help="distinct synthetic frames per sequence: a closed loop of smooth motion, played round and round")
     ap.add_argument("--pipe-window", type=int, default=4, help="--workload pipeline: BA window (the reference's own setting is 4, pipeline.py:19; BASELINE's 10)")
     ap.add_argument("--pipe-no-resurrect", action="store_true", help="--workload pipeline: dead landmarks stay dead (the reference appends the recently dead "
@@ -86,7 +90,10 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames each CPU-baseline worker process runs")
     ap.add_argument("--cpu-procs", type=int, default=16, help="CPU-baseline worker processes (one core each), capped by the host's cores")
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)     # internal: run as CPU-baseline worker with this seed
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.ba_iters is None:
+        a.ba_iters = 10 if a.workload == "config5" else 30
+    return a
 
 
 class Dist:
@@ -386,7 +393,7 @@ def run_pipeline(device, a, dist, n_ctx, per_ctx, steps, warmup, regions, scenes
     if scenes is None:
         scenes = pipe_scenes(2, a.pipe_frames, 4321 + 16 * dist.rank)
     boot = VoContext(W_IMG, H_IMG, max_pts=4096, device=device)
-    groups = [PipeGroup(device, scenes, boot, i * per_ctx, per_ctx, a.ba_iters, max_pts, not a.pipe_adaptive_budget, a.pipe_window, not a.pipe_no_resurrect) for i in range(n_ctx)]
+    groups = [PipeGroup(device, scenes, boot, i * per_ctx, per_ctx, a.pipe_ba_iters, max_pts, not a.pipe_adaptive_budget, a.pipe_window, not a.pipe_no_resurrect) for i in range(n_ctx)]
     boot.close()
     t_setup = time.perf_counter() - t0
     pool = None
@@ -457,7 +464,7 @@ def run_pipeline(device, a, dist, n_ctx, per_ctx, steps, warmup, regions, scenes
            "ms_per_step": round(dt / steps * 1e3, 4), "sequences": n_seq, "contexts": n_ctx,
            "steps": steps, "regions_ms_per_step": [round(x / steps * 1e3, 4) for x in region_dt],
            "sequences_alive_at_end": alive, "frames_in_sequence": scenes[0]["frames"].shape[0], "max_tracked_keypoints": max_pts,
-           "ba_window": a.pipe_window, "resurrection_of_dead_landmarks": not a.pipe_no_resurrect, "ba_lm_iteration_cap": a.ba_iters, "ba_budget": "adaptive (newest fetched frame's maximum + 2)" if a.pipe_adaptive_budget else "the LM's full --ba-iters every frame (surplus groups exit early)",
+           "ba_window": a.pipe_window, "resurrection_of_dead_landmarks": not a.pipe_no_resurrect, "ba_lm_iteration_cap": a.pipe_ba_iters, "ba_budget": "adaptive (newest fetched frame's maximum + 2)" if a.pipe_adaptive_budget else "the LM's full --ba-iters every frame (surplus groups exit early)",
            "mean_tracked_keypoints": mean("n_tracked"), "mean_landmark_entries": mean("n_landmarks"), "mean_candidates": mean("n_candidates"),
            "mean_pnp_inliers": mean("pnp_inliers"), "mean_new_landmarks": mean("n_new"), "mean_resurrected": mean("n_resurrected"),
            "mean_detected": mean("n_detected"), "mean_ba_observations": mean("ba_observations"),
@@ -641,7 +648,7 @@ def cpu_pipeline_worker(a):
                 surface=lambda t, xy: sc["surface"]((t + off) % nf, xy))
     state, _ = syn.gt_bootstrap(ctx, roll, 0, PIPE_T1)
     m = po.PipeModel(ctx, sc["K"], W_IMG, H_IMG, cap=a.pipe_max_pts,
-                     params=po.Params(ba_window=a.pipe_window, ba_max_iters=a.ba_iters, resurrect=not a.pipe_no_resurrect))
+                     params=po.Params(ba_window=a.pipe_window, ba_max_iters=a.pipe_ba_iters, resurrect=not a.pipe_no_resurrect))
     m.seed(state, [], [], 1)
     ctx.push_frame(roll["frames"][PIPE_T1])
     f = PIPE_T1 + 1
@@ -662,7 +669,7 @@ def cpu_pipeline_baseline(a, n_procs):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     t0 = time.perf_counter()
-    argv = ["--cpu-pipe-frames", str(a.cpu_pipe_frames), "--ba-iters", str(a.ba_iters), "--pipe-frames", str(a.pipe_frames), "--pipe-window", str(a.pipe_window),
+    argv = ["--cpu-pipe-frames", str(a.cpu_pipe_frames), "--pipe-ba-iters", str(a.pipe_ba_iters), "--pipe-frames", str(a.pipe_frames), "--pipe-window", str(a.pipe_window),
             "--pipe-max-pts", str(a.pipe_max_pts)] + (["--pipe-no-resurrect"] if a.pipe_no_resurrect else [])
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-pipe-worker", str(i)] + argv, stdout=subprocess.PIPE, env=env, text=True)
              for i in range(n_procs)]
@@ -798,14 +805,17 @@ def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
     # the budget is baked into a capture), two steps in flight
     try:
         g.adaptive = False
+        cap0 = g.ba_iters_cap
+        g.ba_iters_cap = min(10, cap0)        # (a capture bakes the budget in: the LM cap of rounds 1-4, so that no solve counts as cut and is run again)
         g.ba_prm.max_iters = g.ba_iters_cap
         g.c.set_graph_mode(True)
         dt = run(g, 300, warm=40)
         g.c.set_graph_mode(False)
         dtp = run(g, 300)
         out["single_sequence"]["graph_replay"] = {"frames_per_s": round(300 / dt, 1), "plain_launches_same_settings_frames_per_s": round(300 / dtp, 1),
-                                                  "settings": "side-stream layout off under capture (one stream), fixed BA budget %d" % g.ba_iters_cap}
+                                                  "settings": "side-stream layout off under capture (one stream), fixed BA budget = LM cap %d" % g.ba_iters_cap}
         g.adaptive = True
+        g.ba_iters_cap = cap0
     except Exception as e:      # noqa: BLE001
         out["single_sequence"]["graph_replay"] = {"error": str(e)}
     # the default layout of rounds 1-3 on this build and box -- 96 sequences in three batched contexts of 32, side stream on, three host threads --
@@ -813,7 +823,7 @@ def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
     try:
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--seqs", "96", "--ctxs", "3", "--side-stream", "on", "--host-threads", "3", "--steps", "60",
-               "--warmup", "10", "--regions", "3", "--no-extras", "--no-cpu-baseline", "--ba-iters", str(a.ba_iters), "--frames", str(a.frames)]
+               "--warmup", "10", "--regions", "3", "--no-extras", "--no-cpu-baseline", "--ba-iters", "10", "--frames", str(a.frames)]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
                                                                 "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}      # (a 1-rank torchrun launch)
         pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env)
@@ -821,7 +831,7 @@ def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
         out["layout_3_contexts_of_32"] = {"frames_per_s": d3["value"], "ms_per_step": d3["ms_per_step"], "sequences": 96, "contexts": 3,
                                           "klt_roofline_frac": d3["roofline"]["frac"],
                                           "what": "the default configuration of rounds 1-3 (BENCH_r01 .. r03) on this build and box: `python bench.py "
-                                                  "--seqs 96 --ctxs 3 --side-stream on --host-threads 3 --no-extras --no-cpu-baseline` run as a child process"}
+                                                  "--seqs 96 --ctxs 3 --side-stream on --host-threads 3 --ba-iters 10 --no-extras --no-cpu-baseline` run as a child process"}
     except Exception as e:      # noqa: BLE001
         out["layout_3_contexts_of_32"] = {"error": str(e)}
     # BASELINE configs[4] at N = 1 (ONE 1920x1080 sequence, 5000 points, 20-frame BA through a 1-rank communicator): the anchor a multi-GPU
@@ -829,7 +839,7 @@ def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
     try:
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", "config5", "--steps", "60", "--warmup", "10", "--regions", "3", "--no-extras",
-               "--no-cpu-baseline", "--ba-iters", str(a.ba_iters)]
+               "--no-cpu-baseline"]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
                                                                 "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
         pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env)
@@ -840,24 +850,24 @@ def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
                                      "(k_ba_xsum / k_ba_xstat + the 1-rank RCCL all-reduces in every LM iteration); N > 1 has never run on this pool"}
     except Exception as e:      # noqa: BLE001
         out["config5_n1"] = {"error": str(e)}
-    # the headline's command with an LM cap no solve of the workload reaches (review: 1 % of the solves stop at the default --ba-iters 10, where the
-    # reference's least_squares would go on): same batch, same layout, child process
-    if a.ba_iters < 30:
+    # the headline's command at the LM cap rounds 1-4 ran (--ba-iters 10: 1 % of the solves stop there, where the reference's least_squares would go
+    # on), for comparison with their numbers: same batch, same layout, child process
+    if a.ba_iters != 10:
         try:
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(a.steps), "--warmup", "10", "--regions", "3", "--no-extras", "--no-cpu-baseline",
-                   "--ba-iters", "30", "--frames", str(a.frames), "--seqs", str(a.seqs)]
+                   "--ba-iters", "10", "--frames", str(a.frames), "--seqs", str(a.seqs)]
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
                                                                     "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
             pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env)
             dc = json.loads([l for l in pr.stdout.decode().splitlines() if l.startswith("{")][-1])
-            out["lm_cap_30"] = {"frames_per_s": dc["value"], "ms_per_step": dc["ms_per_step"], "sequences": a.seqs,
+            out["lm_cap_10"] = {"frames_per_s": dc["value"], "ms_per_step": dc["ms_per_step"], "sequences": a.seqs,
                                 "ba_lm_iterations_histogram": dc["config"].get("ba_lm_iterations_histogram"),
                                 "ba_solves_stopped_by_lm_max_iters": dc["config"].get("ba_solves_stopped_by_lm_max_iters"),
                                 "ba_iteration_groups_enqueued_per_step": dc["config"].get("ba_iteration_groups_enqueued_per_step"),
-                                "what": "the default command with `--ba-iters 30`: every solve of the workload stops by the LM's own ftol / xtol tests"}
+                                "what": "the default command with `--ba-iters 10`, the cap of rounds 1-4"}
         except Exception as e:      # noqa: BLE001
-            out["lm_cap_30"] = {"error": str(e)}
+            out["lm_cap_10"] = {"error": str(e)}
     kl = {}
     for batch in (1, 32):
         gk = g if batch == 1 else Group(device, frame_sets, seed0=7100, batch=32, ba_iters=a.ba_iters)
@@ -1300,10 +1310,14 @@ def main():
                 # the same launch when context 0 runs its steps alone after the timed region (no other context's kernels beside it)
                 "alone_avg_launch_us": round(stage["klt"] * 1e3, 3),
                 "alone_frac": round(klt_bytes / max(stage["klt"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 5),
+                "compute_units_of_the_launch": 256 - s0.c.step_layout()["reserved_cus"],
                 "note": "HBM figure = algorithmic bytes / launch time as the contract defines it; the kernel itself is vector-ALU bound "
                         "(see `valu`: instructions issued per launch against the SIMDs' issue rate) and moves `traffic` bytes per launch through HBM. "
                         "`frac` is the launch as timed INSIDE the run: with several batched contexts it shares the vector ALUs with the "
-                        "Shi-Tomasi / BA kernels of the other contexts and takes longer than on its own (`alone_*`)"}
+                        "Shi-Tomasi / BA kernels of the other contexts and takes longer than on its own (`alone_*`).  In the pipelined layout of a batch "
+                        "the launch is confined to `compute_units_of_the_launch` of the chip's 256 CUs (the others carry the previous frame's LM tail "
+                        "groups beside it, include/vo_mi355x.h: vo_set_side_stream): `frac` and `valu.frac` are taken against the WHOLE chip's peaks, "
+                        "so 224 CUs at the rate 256 reached before read 0.875 x as much"}
         if roof["kernels"].get("issue_slots_per_step") and not c5 and s0.B * len(seqs) == 256:
             slots = roof["kernels"]["issue_slots_per_step"]
             step_s = dt / a.steps
@@ -1334,7 +1348,7 @@ def main():
                           "ba_iteration_groups_enqueued_per_step": round(groups_enq, 3), "ba_iteration_groups_needed_per_step": round(groups_need, 3),
                           "ba_solves_cut_by_the_budget_and_rerun_in_the_timed_region": n_trunc, "ba_solves_stopped_by_lm_max_iters": n_at_cap,
                           ("adaptive_budget_frames_per_s" if a.fixed_ba_budget else "fixed_budget_frames_per_s"): None if other_fps is None else round(other_fps, 1),
-                          "one_stationary_ba_problem_frames_per_s": None if stationary_fps is None else round(stationary_fps, 1), "side_stream": a.side_stream, "host_threads": max(a.host_threads, 1),
+                          "one_stationary_ba_problem_frames_per_s": None if stationary_fps is None else round(stationary_fps, 1), "side_stream": a.side_stream, "stream_layout": seqs[0].c.step_layout(), "host_threads": max(a.host_threads, 1),
                           "host_wait": "blocking" if os.environ.get("VO_BLOCKING_SYNC", "0") not in ("", "0") else "spin",
                           "sequences_per_gpu": a.seqs, "batched_contexts_per_gpu": a.ctxs,
                           "frames_per_step": 1 if c5 else a.seqs * dist.world,

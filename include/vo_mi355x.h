@@ -507,8 +507,16 @@ int32_t vo_set_graph_mode(vo_ctx* ctx, int32_t on);
  * triangulation on a side stream beside the bundle adjustment (+10-20 % for one context, +1-2 % with three).  2: pipelined, three
  * streams -- pyramid + KLT | re-detection + triangulation | bundle adjustment -- so that the bundle adjustment of frame t also runs
  * beside the front end of frame t + 1 when two steps are in flight (ONE sequence: 3 600 -> 4 500 frames/s; three batched contexts lose
- * 2 %).  Results are identical in every layout.  Fetch the steps in flight first. */
+ * 2 %).  Results are identical in every layout.  Fetch the steps in flight first.
+ * Layout 2 with a batch of >= 8 sequences: the tracker's launch (one wave per keypoint, 512 000 workgroups at a batch of 256) takes every free
+ * wave slot for its whole duration and the previous frame's LM chain would stand still beside it, so (a) the tracker of frame t + 1 is
+ * enqueued behind the first `gate_groups` LM launch groups of frame t -- the groups in which (nearly) all problems still run get the whole
+ * chip -- and (b) the ctx stream is re-created as a queue that leaves `reserved_cus` compute units free (one per shader engine and XCD), on
+ * which the chain's narrow tail groups run beside the tracker.  +4 % at 256 sequences, +10-14 % at 8-192; a longer LM budget costs (almost)
+ * nothing more.  vo_step_layout reports what is in effect; environment VO_BA_WIDE_GROUPS / VO_FE_RESERVE_CUS override (0 = off).  Graph
+ * replay and vo_pipe_step run on the plain, unmasked stream. */
 int32_t vo_set_side_stream(vo_ctx* ctx, int32_t on);
+int32_t vo_step_layout(vo_ctx* ctx, int32_t* layout, int32_t* gate_groups, int32_t* reserved_cus);
 
 /* ---- in-stream timing (hipEvent pairs recorded on the ctx stream around a region's launches) -----
  * Used by bench.py for the roofline figure: region VO_PROF_KLT brackets exactly the k_klt_track launch.

@@ -1,4 +1,6 @@
 """GPU: a batched context (B sequences in lockstep, one launch for all) gives bit-identical results to B single contexts."""
+import os
+
 import numpy as np
 import pytest
 
@@ -80,7 +82,11 @@ def test_batched_context_equals_single_contexts(B):
                 assert got["ba_stats"][b]["cost"] == r["ba_stats"]["cost"]
                 assert np.array_equal(got["corners"][b], r["corners"])
         # the same steps again in the pipelined stream layout with two steps in flight (strided result copies of a batch)
-        c.set_side_stream("pipeline")
+        os.environ["VO_BA_WIDE_GROUPS"], os.environ["VO_FE_RESERVE_CUS"] = "3", "32"      # (the gate + CU mask a batch of >= 8 gets by default)
+        try:
+            c.set_side_stream("pipeline")
+        finally:
+            del os.environ["VO_BA_WIDE_GROUPS"], os.environ["VO_FE_RESERVE_CUS"]
         c.points_upload(np.stack(pts))
         c.push_frame_resident(0)
         order = (1, 2, 3, 2)

@@ -56,12 +56,17 @@ def test_frame_step_matches_individual_calls(graph, block_size):
             assert np.array_equal(got["corners"], corners), k
 
 
-@pytest.mark.parametrize("layout", [1, "pipeline"])
-def test_two_steps_in_flight_match_one_at_a_time(layout):
+@pytest.mark.parametrize("layout", [1, "pipeline", "pipeline_gated"])
+def test_two_steps_in_flight_match_one_at_a_time(layout, monkeypatch):
     """step t + 1 may be enqueued before step t is fetched (alternating pinned mirrors); results are those of the
     one-at-a-time loop on ONE stream, fetched oldest first; a third step without a fetch is refused.  layout 1: re-detection and
     triangulation on a side stream; "pipeline": three streams, the bundle adjustment of frame t runs beside the pyramid and the
-    KLT of frame t + 1 (vo_set_side_stream(ctx, 2))"""
+    KLT of frame t + 1 (vo_set_side_stream(ctx, 2)); "pipeline_gated": the form a batch of >= 8 sequences gets by default, forced here on one
+    sequence -- the tracker launch of frame t + 1 waits for the first 2 LM groups of frame t, stream A leaves 32 compute units free"""
+    gated = layout == "pipeline_gated"
+    if gated:
+        monkeypatch.setenv("VO_BA_WIDE_GROUPS", "2"); monkeypatch.setenv("VO_FE_RESERVE_CUS", "32")
+        layout = "pipeline"
     from vo_mi355x import VoContext, VoError, synthetic as syn
     w, h, n, n_new = 640, 240, 600, 200
     frames, _ = syn.make_sequence(5, w=w, h=h, seed=23, margin=64)
@@ -79,6 +84,8 @@ def test_two_steps_in_flight_match_one_at_a_time(layout):
             ref.append(c.frame_fetch())
     with VoContext(w, h, max_pts=1024) as c:
         c.set_side_stream(layout)
+        if gated:
+            assert c.step_layout() == {"layout": 2, "gate_groups": 2, "reserved_cus": 32}
         _setup(c, frames, pts, scene, n_new)
         bap = c.ba_params(max_iters=6)
         got = []
@@ -169,3 +176,22 @@ def test_graph_replay_two_steps_in_flight_with_a_ba_bank():
         for key in keys:
             assert np.array_equal(got[k][key], ref[k][key], equal_nan=True), (k, key)
         assert got[k]["ba_stats"] == ref[k]["ba_stats"]
+
+
+def test_step_layout_defaults():
+    """what vo_set_side_stream puts into effect (vo_step_layout): one sequence keeps the plain pipelined layout, a batch of >= 8 gets the gated
+    tracker launch and the compute-unit reserve; graph replay and layouts 0 / 1 run on the unmasked stream"""
+    from vo_mi355x import VoContext
+    with VoContext(160, 120, max_pts=64) as c:
+        c.set_side_stream("pipeline")
+        assert c.step_layout() == {"layout": 2, "gate_groups": 0, "reserved_cus": 0}
+    with VoContext(160, 120, max_pts=64, batch=8) as c:
+        assert c.step_layout() == {"layout": 1, "gate_groups": 0, "reserved_cus": 0}
+        c.set_side_stream("pipeline")
+        assert c.step_layout() == {"layout": 2, "gate_groups": 5, "reserved_cus": 32}
+        c.set_graph_mode(True)
+        assert c.step_layout() == {"layout": 2, "gate_groups": 0, "reserved_cus": 0}
+        c.set_graph_mode(False)
+        assert c.step_layout() == {"layout": 2, "gate_groups": 5, "reserved_cus": 32}
+        c.set_side_stream(True)
+        assert c.step_layout() == {"layout": 1, "gate_groups": 0, "reserved_cus": 0}

@@ -1611,7 +1611,10 @@ static int32_t ba_enqueue_iters(vo_ctx* c, const ba_params_dev& prm, int it0, in
   for (int it = it0; it < it0 + n_it; it++) {
     const int32_t r = ba_launch_iter(c, P, prm, it, -1.0, nullptr, nullptr, nullptr);
     if (r != VO_OK) return r;
+    // pipelined frame step: the groups in which (nearly) every problem of the batch still runs are over -- the next frame's tracker may start
+    if (c->ba_wide_event && it - it0 + 1 == c->ba_wide_groups) VO_HIP(c, hipEventRecord(c->ba_wide_event, c->stream));
   }
+  if (c->ba_wide_event && n_it < c->ba_wide_groups) VO_HIP(c, hipEventRecord(c->ba_wide_event, c->stream));
   VO_HIP(c, hipGetLastError());
   return VO_OK;
 }

@@ -365,10 +365,23 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
+  for (int k = 0; k < 2; k++) if (c->ev_ba_wide[k]) (void)hipEventDestroy(c->ev_ba_wide[k]);
   for (int k = 0; k < 2; k++) { if (c->ev_ba[k]) (void)hipEventDestroy(c->ev_ba[k]); if (c->ev_pub[k]) (void)hipEventDestroy(c->ev_pub[k]); if (c->ev_copy1[k]) (void)hipEventDestroy(c->ev_copy1[k]); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return VO_OK;
+}
+
+// a non-blocking stream; reserve_cus > 0: its queue is confined to the first 256 - reserve_cus bits of the compute-unit mask (the bits are dealt
+// round-robin to the 8 XCDs, so a multiple of 8 takes the same number of CUs from each)
+hipError_t vo_stream_create(hipStream_t* st, int reserve_cus) {
+  int dev = 0, n_cu = 0;
+  if (reserve_cus > 0 && (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)) n_cu = 0;
+  if (reserve_cus <= 0 || n_cu <= 2 * reserve_cus || n_cu > 1024) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  uint32_t mask[32];
+  for (int k = 0; k < 32; k++) mask[k] = 0;
+  for (int b = 0; b < n_cu - reserve_cus; b++) mask[b >> 5] |= 1u << (b & 31);
+  return hipExtStreamCreateWithCUMask(st, (uint32_t)((n_cu + 31) / 32), mask);
 }
 
 extern "C" int32_t vo_ctx_create(int32_t device, int32_t width, int32_t height, int32_t max_pts,

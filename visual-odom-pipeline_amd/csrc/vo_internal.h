@@ -54,6 +54,12 @@ struct vo_ctx {
   hipEvent_t ev_copy1[2] = {nullptr, nullptr};  // the KLT results of the step using half k have left the device (copy on stream A)
   hipEvent_t ev_pub[2] = {nullptr, nullptr};    // ... and the copy of it (on stream2) has left the device: the next k_ba_finalize may overwrite d_pub
   hipEvent_t ba_wait_before_publish = nullptr;  // set by the pipelined step around vo_ba_solve_resident
+  hipEvent_t ev_ba_wide[2] = {nullptr, nullptr}; // pipelined step: the first `ba_wide_groups` LM groups of the step using half k have run (recorded on stream C);
+                                                // the NEXT step's tracker launch waits for it -- the wide groups get the whole chip, the tail groups run beside the tracker
+  hipEvent_t ba_wide_event = nullptr;           // set by the pipelined step around vo_ba_solve_resident: record after `ba_wide_groups` groups
+  int ba_wide_groups = 0;                       // 0: no gating
+  bool ba_wide_recorded = false;
+  int stream_reserve = 0;                        // compute units `stream` leaves free (CU mask of its queue; vo_set_side_stream)
   bool pub_copy_pending = false;                // a pipelined step has recorded ev_pub at least once
   // loader pre-filter (vo_set_prefilter): cv2.bilateralFilter taps applied while a frame enters the frame store
   int bil_maxk = 0;                  // 0 = off
@@ -199,6 +205,8 @@ void vo_st_flags_restore(vo_ctx* c, int saved);
 // the pipelined stream layout (vo_set_side_stream 2) leaves work on streams B and C after a step: every entry point outside the
 // step / fetch pair that touches the result slab, the frame store, the BA / Shi-Tomasi / DLT / PnP workspaces waits for them first
 int32_t vo_quiesce_side(vo_ctx* c);
+int32_t vo_main_stream_reserve(vo_ctx* c, int reserve);               // the ctx stream re-created with / without a CU mask (vo_set_side_stream(c, 2) of a batch)
+hipError_t vo_stream_create(hipStream_t* st, int reserve_cus);      // reserve_cus > 0: the queue never uses the last `reserve_cus` bits of the CU mask
 int32_t vo_st_prepare(vo_ctx* c, const vo_st_params* prm);
 // the resident entry points with the per-sequence counters named by the caller (device arrays [batch], null = uniform): d_counts = live
 // points of each sequence (KLT input / exclusion discs), d_limit = cap on the corners each sequence's re-detection needs

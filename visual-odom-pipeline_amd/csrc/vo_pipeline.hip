@@ -1399,6 +1399,9 @@ extern "C" int32_t vo_pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages) {
   VO_CHECK(c, c->pipe, VO_E_STATE, "vo_pipe_create first");
   VO_CHECK(c, c->pipe->enq - c->pipe->fetched < VO_PIPE_INFLIGHT, VO_E_STATE, "vo_pipe_fetch the oldest step first");
   VO_HIP(c, hipSetDevice(c->device));
+  // the closed loop's chain (PnP, the adjustment) lives on the ctx stream: it gets every compute unit (the pipelined frame step of a batch
+  // confines that stream to 224 of them for its tracker launches, vo_set_side_stream)
+  if (c->stream_reserve > 0 && c->pipe->enq == c->pipe->fetched) { const int32_t rr = vo_main_stream_reserve(c, 0); if (rr != VO_OK) return rr; c->ba_wide_groups = 0; }
   const bool dirty = c->main_dirty;               // something other than a pipe step has used the ctx stream since the last one
   { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   c->main_dirty = false;

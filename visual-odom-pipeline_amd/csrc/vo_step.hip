@@ -69,6 +69,11 @@ static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame
   else r = vo_build_pyramid(c, c->d_seq + (size_t)frame_idx * fr, fr * c->seq_n, nullptr);
   if (r != VO_OK) return r;
   if (trace_a && c->side_stream == 2) trace_push(g_tb, c->stream, 6000);
+  // pipelined layout: the tracker's launch takes every free wave slot for its whole duration, the previous frame's LM chain would stand still
+  // beside it (EXPERIMENTS.md round 5 item 9).  Its wide groups -- all problems running -- go first and get the whole chip; the tracker follows and
+  // overlaps the chain's narrow tail groups, which run on the compute units stream A's CU mask leaves free (vo_set_side_stream)
+  if (c->side_stream == 2 && s.do_ba && !d_frame_idx && c->ba_wide_groups > 0 && c->ba_wide_recorded)
+    VO_HIP(c, hipStreamWaitEvent(c->stream, c->ev_ba_wide[half ^ 1], 0));
   r = vo_klt_track_resident(c, s.n_pts, &s.klt);
   if (r != VO_OK) return r;
   if (trace_a && c->side_stream == 2) trace_push(g_tb, c->stream, 6000);
@@ -98,8 +103,11 @@ static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame
     // C carries nothing but the LM iterations and k_ba_finalize: the copy of the solution goes to B (behind ev_ba), so that the next
     // frame's iterations follow this frame's directly; k_ba_finalize of the next step waits for that copy (ev_pub) -- long done by then
     c->ba_wait_before_publish = c->pub_copy_pending ? c->ev_pub[half ^ 1] : nullptr;
+    c->ba_wide_event = c->ba_wide_groups > 0 ? c->ev_ba_wide[half] : nullptr;
     r = vo_ba_solve_resident(c, &s.ba);
     c->ba_wait_before_publish = nullptr;
+    if (c->ba_wide_event && r == VO_OK) c->ba_wide_recorded = true;
+    c->ba_wide_event = nullptr;
     hipError_t e = hipEventRecord(c->ev_ba[half], c->stream3);
     if (trace) trace_push(g_tr, c->stream3, 4000);
     c->stream = c->stream2;
@@ -307,6 +315,39 @@ extern "C" int32_t vo_frame_fetch(vo_ctx* c, int32_t n_pts, float* p, uint8_t* s
   return rc;
 }
 
+// the ctx stream as a queue that leaves `reserve` compute units free (0: all of them): a fresh stream, after the old one has drained
+int32_t vo_main_stream_reserve(vo_ctx* c, int reserve) {
+  if (reserve == c->stream_reserve) return VO_OK;
+  VO_HIP(c, hipSetDevice(c->device));
+  VO_HIP(c, hipStreamSynchronize(c->stream));
+  hipStream_t fresh = nullptr;
+  hipError_t e = vo_stream_create(&fresh, reserve);
+  if (e != hipSuccess && reserve > 0) { (void)hipGetLastError(); reserve = 0; e = vo_stream_create(&fresh, 0); }   // (no CU masks on this runtime)
+  VO_HIP(c, e);
+  VO_HIP(c, hipStreamDestroy(c->stream));
+  c->stream = fresh;
+  c->stream_reserve = reserve;
+  return VO_OK;
+}
+
+// Pipelined layout of a batch: the tracker launch of frame t + 1 follows the first `ba_wide_groups` LM groups of frame t (step_enqueue), and
+// stream A leaves 32 compute units to the chain's tail groups that then run beside it -- one CU of each shader engine of each XCD: the mask
+// bits are dealt round-robin over XCDs and engines, a count that is no multiple of 32 unbalances the engines (240, 232 and 248 of 256 CUs
+// measured SLOWER than 224; tools/gate_ab.sh, EXPERIMENTS.md round 5 item 15).  One sequence (a 34 us tracker launch that starves nobody)
+// keeps the plain layout, and so does graph replay (a captured step stays on one stream, which must then have the whole chip).
+// VO_BA_WIDE_GROUPS / VO_FE_RESERVE_CUS override (0 = off).
+static int32_t step_layout_apply(vo_ctx* c) {
+  int groups = 0, reserve = 0;
+  if (c->side_stream == 2 && !c->use_graph) {
+    if (c->batch >= 8) { groups = c->batch >= 256 ? 4 : 5; reserve = 32; }
+    if (const char* e = getenv("VO_BA_WIDE_GROUPS")) groups = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("VO_FE_RESERVE_CUS")) reserve = atoi(e) > 0 ? atoi(e) : 0;
+  }
+  c->ba_wide_groups = groups;
+  c->ba_wide_recorded = false;
+  return vo_main_stream_reserve(c, reserve);
+}
+
 extern "C" int32_t vo_set_side_stream(vo_ctx* c, int32_t on) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->steps_enq == c->steps_fetched, VO_E_STATE, "fetch the steps in flight before switching the stream layout");
@@ -315,6 +356,8 @@ extern "C" int32_t vo_set_side_stream(vo_ctx* c, int32_t on) {
     // three batched contexts lost 10 % of their throughput to it
     VO_HIP(c, hipSetDevice(c->device));
     VO_HIP(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));     // (a highest-priority stream for the BA chain: no difference)
+    VO_HIP(c, hipEventCreateWithFlags(&c->ev_ba_wide[0], hipEventDisableTiming));
+    VO_HIP(c, hipEventCreateWithFlags(&c->ev_ba_wide[1], hipEventDisableTiming));
     VO_HIP(c, hipEventCreateWithFlags(&c->ev_ba[0], hipEventDisableTiming));
     VO_HIP(c, hipEventCreateWithFlags(&c->ev_ba[1], hipEventDisableTiming));
     VO_HIP(c, hipEventCreateWithFlags(&c->ev_pub[0], hipEventDisableTiming));
@@ -323,6 +366,14 @@ extern "C" int32_t vo_set_side_stream(vo_ctx* c, int32_t on) {
     VO_HIP(c, hipEventCreateWithFlags(&c->ev_copy1[1], hipEventDisableTiming));
   }
   c->side_stream = (on == 2) ? 2 : (on ? 1 : 0);      // 2: pipelined (BA of frame t beside the front end of frame t + 1)
+  return step_layout_apply(c);
+}
+
+extern "C" int32_t vo_step_layout(vo_ctx* c, int32_t* layout, int32_t* gate_groups, int32_t* reserved_cus) {
+  if (!c) return VO_E_INVALID;
+  if (layout) *layout = c->side_stream;
+  if (gate_groups) *gate_groups = c->ba_wide_groups;
+  if (reserved_cus) *reserved_cus = c->stream_reserve;
   return VO_OK;
 }
 
@@ -330,5 +381,6 @@ extern "C" int32_t vo_set_graph_mode(vo_ctx* c, int32_t on) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->steps_enq == c->steps_fetched, VO_E_STATE, "fetch the steps in flight before switching the launch mode");
   c->use_graph = on ? 1 : 0;
+  { const int32_t rr = step_layout_apply(c); if (rr != VO_OK) return rr; }
   return VO_OK;
 }

@@ -125,6 +125,7 @@ SIGNATURES = {
                                    C.POINTER(BaStats), _f32p, _i32p]),
     "vo_set_graph_mode": (C.c_int32, [_ctx, C.c_int32]),
     "vo_set_side_stream": (C.c_int32, [_ctx, C.c_int32]),
+    "vo_step_layout": (C.c_int32, [_ctx, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vo_profile_enable": (C.c_int32, [_ctx, C.c_int32]),
     "vo_profile_read": (C.c_int32, [_ctx, C.c_int32, _f64p, _i32p]),
     "vo_debug_cycles": (C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_int64)]),

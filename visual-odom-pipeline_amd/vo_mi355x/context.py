@@ -275,6 +275,13 @@ class VoContext:
         mode = 2 if on in (2, "pipeline") else (1 if on else 0)
         self._ck(self._L.vo_set_side_stream(self._h, mode))
 
+    def step_layout(self):
+        """-> {"layout": 0 | 1 | 2, "gate_groups": LM launch groups of frame t that precede the tracker launch of frame t + 1 (0: no gate),
+        "reserved_cus": compute units the front-end stream leaves free} -- what vo_set_side_stream put into effect"""
+        a, b, d = C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self._L.vo_step_layout(self._h, C.byref(a), C.byref(b), C.byref(d)))
+        return {"layout": a.value, "gate_groups": b.value, "reserved_cus": d.value}
+
     def frame_step_resident(self, frame_idx, n_pts, do_dlt=True, do_ba=True, do_st=True, mask_radius=7,
                             klt=None, st=None, ba=None):
         """enqueue one whole frame (pyramid, KLT, DLT, BA, re-detection, result copies); async"""
