@@ -195,3 +195,42 @@ def test_step_layout_defaults():
         assert c.step_layout() == {"layout": 2, "gate_groups": 5, "reserved_cus": 32}
         c.set_side_stream(True)
         assert c.step_layout() == {"layout": 1, "gate_groups": 0, "reserved_cus": 0}
+
+
+def test_gated_layout_with_steps_that_skip_the_adjustment(monkeypatch):
+    """the gated pipelined layout (the tracker launch of frame t + 1 waits for the wide LM groups of frame t) when some steps carry no bundle
+    adjustment, a zero-iteration budget or a budget shorter than the gate: the wait then refers to an older, finished record; results are those
+    of the one-stream loop"""
+    from vo_mi355x import VoContext, synthetic as syn
+    w, h, n, n_new = 640, 240, 600, 200
+    frames, _ = syn.make_sequence(5, w=w, h=h, seed=29, margin=64)
+    pts = syn.grid_points(n, w, h, seed=6)
+    scene = syn.make_ba_scene(n_pts=300, n_slots=6, seed=5, visibility=0.9)
+    plan = [(1, True, 6), (2, False, 6), (3, True, 0), (4, True, 2), (3, True, 6), (2, False, 6), (1, False, 6), (0, True, 1), (1, True, 6), (2, True, 6)]
+    keys = ("points2d", "status", "err", "X4", "poses", "landmarks", "corners")
+
+    def run(c, in_flight):
+        _setup(c, frames, pts, scene, n_new)
+        out = []
+        for k, (f, do_ba, iters) in enumerate(plan):
+            c.frame_step_resident(f, n, do_ba=do_ba, ba=c.ba_params(max_iters=iters))
+            if k >= in_flight - 1:
+                out.append(c.frame_fetch())
+        while len(out) < len(plan):
+            out.append(c.frame_fetch())
+        return out
+
+    with VoContext(w, h, max_pts=1024) as c:
+        c.set_side_stream(False)
+        ref = run(c, 1)
+    monkeypatch.setenv("VO_BA_WIDE_GROUPS", "3"); monkeypatch.setenv("VO_FE_RESERVE_CUS", "32")
+    with VoContext(w, h, max_pts=1024) as c:
+        c.set_side_stream("pipeline")
+        assert c.step_layout()["gate_groups"] == 3
+        got = run(c, 2)
+    for k in range(len(plan)):
+        assert set(got[k]) == set(ref[k]), (k, set(got[k]) ^ set(ref[k]))
+        for key in keys:
+            if key in got[k]:                      # (a step without an adjustment returns no poses / landmarks)
+                assert np.array_equal(got[k][key], ref[k][key], equal_nan=True), (k, key)
+        assert {"points2d", "status", "corners"} <= set(got[k])

@@ -290,12 +290,17 @@ class VoContext:
         ba = ba if ba is not None else self.ba_params()
         self._klt_levels = klt.max_level + 1
         self._st_max_corners = st.max_corners
-        self._step_cfg = (n_pts, do_dlt, do_ba, do_st)
         self._ck(self._L.vo_frame_step_resident(self._h, int(frame_idx), int(n_pts), int(do_dlt), int(do_ba), int(do_st),
                                                 int(mask_radius), C.byref(klt), C.byref(st), C.byref(ba)))
+        # what each step in flight will hand back (up to two are in flight, and they need not carry the same stages)
+        if not hasattr(self, "_step_cfgs"):
+            self._step_cfgs = []
+        self._step_cfgs.append((n_pts, do_dlt, do_ba, do_st))
 
     def frame_fetch(self):
         """wait for the enqueued frame and return its results as a dict of numpy arrays"""
+        if getattr(self, "_step_cfgs", None):
+            self._step_cfg = self._step_cfgs.pop(0)          # the OLDEST step not fetched yet (nothing in flight: the last one again)
         n_pts, do_dlt, do_ba, do_st = self._step_cfg
         B = self.batch
         p, stt, err = np.zeros((B, n_pts, 2), np.float32), np.zeros((B, n_pts), np.uint8), np.zeros((B, n_pts), np.float32)
