@@ -15,6 +15,7 @@ def test_ba_wave_private_lane_maps_and_workgroup_counts(monkeypatch, W, n_pts):
     equal to 1e-9 between the forms (their summation orders differ)."""
     import ba_oracle as bo
     from vo_mi355x import VoContext, synthetic as syn
+    monkeypatch.setenv("VO_BA_V2", "1")      # (a context of ONE sequence with a window of 9-10 slots takes the lane-per-observation kernels by default)
     s = syn.make_ba_scene(n_pts=n_pts, n_slots=W, seed=20 + W, visibility=0.85)
     ref = bo.solve(s["K"], s["poses0"], s["points0"], s["obs"], max_iters=12)
     out = {}
@@ -35,12 +36,13 @@ def test_ba_wave_private_lane_maps_and_workgroup_counts(monkeypatch, W, n_pts):
         assert np.abs(po - out["rule"][0]).max() <= 1e-9 and np.abs(pt - out["rule"][1]).max() <= 1e-8, key
 
 
-def test_ba_running_problem_compaction():
+def test_ba_running_problem_compaction(monkeypatch):
     """64 problems of one batch that need between 2 and 12 LM iterations: once some have finished, the launch groups hand their workgroups to
     the ones still running (`ba2_select_work`: 8 workgroups per problem in a full launch, up to 16 in the tail) -- a problem's partial sums are
     then folded in another order, nothing else may change: every problem = the same problem solved alone (iterations, acceptance sequence,
     status; cost 1e-10; poses 1e-9, points 1e-6 of their distance), and the easy ones really did finish early."""
     from vo_mi355x import VoContext, synthetic as syn
+    monkeypatch.setenv("VO_BA_V2", "1")      # (the single context below would take the lane-per-observation kernels otherwise)
     B, N, W = 64, 800, 10
     sc = []
     for b in range(B):

@@ -1330,7 +1330,7 @@ static void ba_geometry(vo_ba_ws* b, int W, int N) {
   if (const char* e = getenv("VO_BA_V2")) b->v2 = (W <= 10 && atoi(e) != 0) ? 1 : 0;
   // (one problem alone is the one shape the older kernels still win: build 12 against 16 us per iteration -- a wave-private workgroup spends
   //  ~7 us on its LM decision, camera staging and the four-wave fold of its tiles whatever it walks; 18 against 17 at four problems, 65 against
-  //  49 at 32.  Not switched by the batch: a batched context stays bit-identical to single contexts, tests/test_gpu_batch.py)
+  //  49 at 32: ba_alloc switches contexts of one or two sequences with windows of 9-10 slots back to them)
   b->v2_rt = b->RT; b->v2_spl = (W + 7) / 8;
   // windows of 9 and 10 slots: 5 lanes per landmark (12 landmarks per wave), else 8 (VO_BA_LPP5=0: 8 for every window, A/B knob)
   // and 4 for windows of <= 4 slots (16 landmarks per wave)
@@ -1407,6 +1407,11 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
   }
   ba_geometry(c->ba, W, N);
   if (c->batch > 1024) c->ba->v2 = 0;             // (ba2_select_work keeps the running-problem flags of <= 1 024 problems in LDS)
+  // one or two problems with BASELINE's window: the lane-per-observation kernels spread a problem over 125 workgroups of 1 024 lanes, the
+  // wave-private ones over 42 of 256 -- 3 430 against 3 260 frames/s for ONE sequence, 6 180 against 5 930 for two, even at three, behind from
+  // four on (tools/one_sequence_ba_knobs.sh, profiles/r05_small_batch_ba.txt).  Windows of <= 8 slots (the closed loop's 4) are faster
+  // wave-private at every batch.  The two families agree to ~1e-12, not bit for bit: like a batch of 32 against its problems one by one.
+  if (c->batch <= 2 && W >= 9 && !getenv("VO_BA_V2")) c->ba->v2 = 0;
   VO_CHECK(c, c->ba->build_lds <= 130 * 1024 && c->ba->solve_lds <= 150 * 1024, VO_E_CAPACITY, "window too large for LDS");
   VO_CHECK(c, c->ba->nblk <= 640, VO_E_CAPACITY, "too many landmarks for one adjust (raise the partial capacity)");
   return VO_OK;
