@@ -1,4 +1,6 @@
-for rb in 0 188 126 94 76 63 0; do
+#!/bin/bash
+# k_st_eig_fused band height (VO_ST_RB; 0 = the rule) in the default command: frames/s and the re-detection's launch group
+for rb in 0 376 188 126 94 76 63 0; do
   out=$(VO_ST_RB=$rb timeout 120 python bench.py --no-extras --no-cpu-baseline --steps 60 2>/dev/null | tail -1)
   python - "$out" $rb <<'P'
 import json, sys
