@@ -1340,7 +1340,8 @@ def main():
                "config": {"workload": WORKLOAD, "width": W_IMG, "height": H_IMG,
                           "klt_points": N_PTS, "klt_win": 31, "klt_levels": 4, "dlt_points": N_NEW,
                           "ba_landmarks": BA_N, "ba_window": BA_W, "ba_observations": BA_N * BA_W,
-                          "ba_lm_iteration_budget": a.ba_iters, "ba_lm_iterations_run": ba_stats["iters"],
+                          "ba_lm_iteration_budget": a.ba_iters, "ba_lm_iteration_budget_note": "LM cap per adjust; rounds 1-4 ran 10 (1 % of the solves cut there): `lm_cap_10` of this line is that configuration on this build",
+                          "ba_lm_iterations_run": ba_stats["iters"],
                           "ba_final_cost": round(ba_stats["cost"], 4), "ba_initial_cost": round(ba_stats["cost0"], 2),
                           "launch": "hipGraph replay" if a.graph else "plain",
                           "ba_problems_per_sequence": seqs[0].n_ba, "frames_per_sequence": a.frames,
