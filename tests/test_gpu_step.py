@@ -234,3 +234,60 @@ def test_gated_layout_with_steps_that_skip_the_adjustment(monkeypatch):
             if key in got[k]:                      # (a step without an adjustment returns no poses / landmarks)
                 assert np.array_equal(got[k][key], ref[k][key], equal_nan=True), (k, key)
         assert {"points2d", "status", "corners"} <= set(got[k])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_pipelined_batch_random_stage_patterns(seed):
+    """a batched context of 8 sequences in the pipelined layout AS vo_set_side_stream puts it into effect (gate of 5 LM groups, 32 compute units
+    set aside -- no environment override): random stage sets (with / without triangulation, adjustment, re-detection), random LM budgets (0 ... 9:
+    shorter and longer than the gate) and two steps in flight, against the same steps one at a time on ONE stream"""
+    from vo_mi355x import VoContext, synthetic as syn
+    rng = np.random.default_rng(1000 + seed)
+    B, w, h, n, n_new = 8, 320, 160, 250, 100
+    seqs = [syn.make_sequence(5, w=w, h=h, seed=40 + 3 * seed + b, margin=48)[0] for b in range(B)]
+    pts = np.stack([syn.grid_points(n, w, h, seed=9 + b) for b in range(B)])
+    scenes = [syn.make_ba_scene(n_pts=200, n_slots=6, seed=70 + 5 * seed + b, visibility=0.9, pt_noise=0.2 + 0.1 * b) for b in range(B)]
+    plan = [(int(rng.integers(0, 5)), bool(rng.integers(0, 2)), bool(rng.integers(0, 4) > 0), bool(rng.integers(0, 2)), int(rng.integers(0, 10))) for _ in range(14)]
+
+    def setup(c):
+        c.upload_sequence(np.stack(seqs)); c.points_upload(pts)
+        d = []
+        for s in scenes:
+            K = s["K"]
+            H0, H1 = np.eye(4), np.eye(4)
+            H0[:3, :3], H0[:3, 3] = syn.rodrigues(s["poses_gt"][3, :3]), s["poses_gt"][3, 3:]
+            H1[:3, :3], H1[:3, 3] = syn.rodrigues(s["poses_gt"][0, :3]), s["poses_gt"][0, 3:]
+            d.append(((K @ H0[:3]).astype(np.float32), (K @ H1[:3]).astype(np.float32), s["obs"][3, :n_new], s["obs"][0, :n_new], K, H0, H1))
+        c.dlt_upload(*[np.stack([x[k] for x in d]) for k in range(7)])
+        c.ba_upload(np.stack([s["K"] for s in scenes]), np.stack([s["poses0"] for s in scenes]), np.stack([s["points0"] for s in scenes]),
+                    np.stack([s["obs"] for s in scenes]))
+        c.push_frame_resident(0)
+
+    def run(c, in_flight):
+        out = []
+        for k, (f, do_dlt, do_ba, do_st, iters) in enumerate(plan):
+            c.frame_step_resident(f, n, do_dlt=do_dlt, do_ba=do_ba, do_st=do_st, ba=c.ba_params(max_iters=iters))
+            if k >= in_flight - 1:
+                out.append(c.frame_fetch())
+        while len(out) < len(plan):
+            out.append(c.frame_fetch())
+        return out
+
+    with VoContext(w, h, max_pts=512, batch=B) as c:
+        c.set_side_stream(False)
+        setup(c)
+        ref = run(c, 1)
+    with VoContext(w, h, max_pts=512, batch=B) as c:
+        c.set_side_stream("pipeline")
+        assert c.step_layout() == {"layout": 2, "gate_groups": 5, "reserved_cus": 32}
+        setup(c)
+        got = run(c, 2)
+    for k in range(len(plan)):
+        assert set(got[k]) == set(ref[k]), (k, plan[k])
+        for key in got[k]:
+            if key == "ba_stats":
+                assert got[k][key] == ref[k][key], (k, plan[k])
+            elif isinstance(got[k][key], list):            # (corners: one array per sequence, their lengths differ)
+                assert len(got[k][key]) == len(ref[k][key]) and all(np.array_equal(x, y) for x, y in zip(got[k][key], ref[k][key])), (k, key, plan[k])
+            else:
+                assert np.array_equal(got[k][key], ref[k][key], equal_nan=True), (k, key, plan[k])
