@@ -48,7 +48,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--regions", type=int, default=5, help="the K-step timed region is repeated this many times; the median is reported")
-    ap.add_argument("--no-extras", action="store_true", help="skip the informational single-sequence / KLT-only / pipeline measurements")
+    ap.add_argument("--extras", action="store_true", help="after the headline: the informational single-sequence / KLT-only / pipeline / drop-in measurements "
+                    "(minutes; they go to bench_extras.json, never into the printed line)")
+    ap.add_argument("--no-extras", action="store_true", help="the headline only: also skip the two second figures of the default line (`host_frames`, "
+                    "`closed_loop_w10_256`); what the profiling scripts under tools/ run")
+    ap.add_argument("--full-line", action="store_true", help="print the full result object (tens of KB) as the last line instead of the compact one "
+                    "(tools/ and the child runs of --extras parse it); the driver's contract is the compact line")
+    ap.add_argument("--extras-file", default=None, help="where the full result object goes (default: bench_extras.json beside bench.py, and gpurun_out/ when it exists)")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)     # launcher plumbing test: no GPU work
     ap.add_argument("--cpu-pipe-worker", type=int, default=-1, help=argparse.SUPPRESS)   # CPU-baseline worker of the closed loop (table model over the oracle)
     ap.add_argument("--cpu-pipe-frames", type=int, default=6, help="frames each CPU worker of the closed-loop baseline steps (after 2 untimed ones)")
@@ -775,6 +781,32 @@ def cpu_baseline(frames, n_frames, ba_iters):
     return n_frames / dt, dt
 
 
+CHILD_ENV_DROP = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")
+
+
+def closed_loop_child(a, extra_args, steps=40, timeout=150):
+    """`bench.py --workload pipeline ...` as a child process -> the short object the compact line carries (the child's full result object goes into
+    the side file under the same key + `_full`).  Never raises: an error or a timeout becomes {"error": ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "pipeline", "--ctxs", "1", "--steps", str(steps), "--warmup", "10", "--regions", "3",
+           "--no-cpu-baseline", "--full-line", "--extras-file", os.devnull, "--pipe-frames", str(a.pipe_frames), "--pipe-ba-iters", str(a.pipe_ba_iters)] + list(extra_args)
+    env = {k: v for k, v in os.environ.items() if k not in CHILD_ENV_DROP}
+    t0 = time.perf_counter()
+    try:
+        pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env)
+        d = json.loads([ln for ln in pr.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    except Exception as e:          # noqa: BLE001
+        return {"error": repr(e)[:200], "seconds": round(time.perf_counter() - t0, 1)}
+    pp, rf = d.get("pipeline") or {}, d.get("roofline") or {}
+    cap = pp.get("capacity_policy_frames") or {}
+    return {"value": d.get("value"), "unit": "frames/s", "ms_per_step": d.get("ms_per_step"), "sequences": pp.get("sequences"), "ba_window": pp.get("ba_window"),
+            "table_slots": pp.get("max_tracked_keypoints"), "mean_tracked_keypoints": pp.get("mean_tracked_keypoints"),
+            "capacity_policy_frames": int(sum(cap.values())) if cap else None, "frames_counted": int(pp.get("sequences", 0)) * int(pp.get("steps", 0)) * len(pp.get("regions_ms_per_step", [])),
+            "sequences_alive_at_end": pp.get("sequences_alive_at_end"), "rotation_deg_median": (pp.get("pose_error_vs_ground_truth") or {}).get("rotation_deg_median"),
+            "roofline": {"kernel": rf.get("kernel"), "frac": rf.get("frac"), "avg_launch_us": rf.get("avg_launch_us")},
+            "cmd": "bench.py --workload pipeline " + " ".join(extra_args), "seconds": round(time.perf_counter() - t0, 1)}
+
+
 def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
     """Informational, after the timed regions, rank 0 of a 1-GPU run: the other BASELINE configurations on the same device.
     single_sequence: configs[2] / [3] literally -- ONE sequence in one context (launch-latency bound).
@@ -823,7 +855,7 @@ def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
     try:
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--seqs", "96", "--ctxs", "3", "--side-stream", "on", "--host-threads", "3", "--steps", "60",
-               "--warmup", "10", "--regions", "3", "--no-extras", "--no-cpu-baseline", "--ba-iters", "10", "--frames", str(a.frames)]
+               "--warmup", "10", "--regions", "3", "--no-extras", "--no-cpu-baseline", "--ba-iters", "10", "--frames", str(a.frames), "--full-line", "--extras-file", os.devnull]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
                                                                 "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}      # (a 1-rank torchrun launch)
         pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env)
@@ -839,7 +871,7 @@ def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
     try:
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", "config5", "--steps", "60", "--warmup", "10", "--regions", "3", "--no-extras",
-               "--no-cpu-baseline"]
+               "--no-cpu-baseline", "--full-line", "--extras-file", os.devnull]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
                                                                 "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
         pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env)
@@ -903,7 +935,7 @@ def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
         try:
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(a.steps), "--warmup", "10", "--regions", "3", "--no-extras", "--no-cpu-baseline",
-                   "--ba-iters", "10", "--frames", str(a.frames), "--seqs", str(a.seqs)]
+                   "--ba-iters", "10", "--frames", str(a.frames), "--seqs", str(a.seqs), "--full-line", "--extras-file", os.devnull]
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
                                                                     "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
             pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env)
@@ -1037,6 +1069,123 @@ def valu_roofline(launch_s, n_waves):
             "source": src}
 
 
+LINE_MAX_BYTES = 4096       # the printed line stays below this (the round-5 line grew to 30 KB and the driver could not read it)
+
+
+def _strict(v):
+    """NaN / inf -> None, numpy scalars -> Python numbers, recursively: the line must load with a strict JSON parser"""
+    if isinstance(v, dict):
+        return {str(k): _strict(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_strict(x) for x in v]
+    if isinstance(v, (np.floating, float)):
+        v = float(v)
+        return v if np.isfinite(v) else None
+    if isinstance(v, (np.integer,)):
+        return int(v)
+    if isinstance(v, (np.bool_,)):
+        return bool(v)
+    return v
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _short_kernel(name):
+    """`void k_ba_build_w<4, 2, 5>(ba_args)` -> `k_ba_build_w<4,2,5>`"""
+    n = str(name).replace("void ", "").split("(")[0].replace(", ", ",").strip()
+    return n[:48]
+
+
+def compact_line(full, extras_file=None):
+    """The ONE line the driver reads: the contract's keys + `roofline` + `cpu_baseline` + the second figures, below LINE_MAX_BYTES,
+    strict JSON.  Everything else of `full` lives in the side file named by `extras_file`.  Pure function (tests/test_bench_line.py
+    builds the line from a committed full result)."""
+    full = _strict(full)
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    line["vs_baseline"] = full.get("vs_baseline")
+    line.update(_pick(full, ("dtype", "data")))
+    cfg = full.get("config") or {}
+    c = _pick(cfg, ("workload", "sequences_per_gpu", "batched_contexts_per_gpu", "frames_per_step", "frames_source", "ba_lm_iteration_budget",
+                    "ba_lm_iterations_run", "stream_layout", "launch"))
+    if "ba_solves_stopped_by_lm_max_iters" in cfg:
+        c["solves_stopped_by_cap"] = cfg["ba_solves_stopped_by_lm_max_iters"]
+    if "ba_solves_cut_by_the_budget_and_rerun_in_the_timed_region" in cfg:
+        c["solves_cut_and_rerun"] = cfg["ba_solves_cut_by_the_budget_and_rerun_in_the_timed_region"]
+    if "parallelism" in cfg:
+        c["parallelism"] = str(cfg["parallelism"])[:120]
+    line["config"] = c
+    reg = full.get("regions") or {}
+    if reg:
+        line["regions"] = _pick(reg, ("n", "frames_per_s_min", "frames_per_s_max"))
+    roof = full.get("roofline")
+    if isinstance(roof, dict):
+        r = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac"))
+        r["traffic"] = roof.get("traffic")
+        r.update(_pick(roof, ("avg_launch_us", "algorithmic_bytes_per_launch", "compute_units_of_the_launch")))
+        if roof.get("traffic_source"):
+            r["traffic_source"] = str(roof["traffic_source"])[:80]
+        valu = roof.get("valu") or {}
+        if valu.get("frac") is not None:
+            r["valu"] = _pick(valu, ("frac", "frac_of_mixed_stream_roof", "wave_insts_per_wave"))
+        issue = roof.get("issue") or {}
+        if issue.get("frac_of_quarter_rate_capacity") is not None:
+            r["issue"] = _pick(issue, ("frac_of_quarter_rate_capacity", "frac_at_2.07_ghz", "hbm_gb_s"))
+        ks = (roof.get("kernels") or {})
+        if isinstance(ks, dict) and ks.get("kernels"):
+            top = sorted(ks["kernels"], key=lambda e: -float(e.get("pct_of_kernel_time") or 0))[:3]
+            r["kernels"] = [dict(kernel=_short_kernel(e.get("kernel")), pct=e.get("pct_of_kernel_time"), us=e.get("one_stream_avg_launch_us", e.get("avg_launch_us")),
+                                 hbm_frac=e.get("hbm_frac"), valu_issue_frac=e.get("valu_issue_frac"), mfma_util_pct=e.get("mfma_util_pct_mean")) for e in top]
+            r["kernels_source"] = ("STALE " if ks.get("stale") else "") + str(ks.get("source", ""))[:60]
+        line["roofline"] = r
+    else:
+        line["roofline"] = None
+    cpu = full.get("cpu_baseline")
+    if isinstance(cpu, dict):
+        cb = _pick(cpu, ("value", "unit", "cores", "kind", "per_core"))
+        if cpu.get("sample"):
+            cb["sample"] = str(cpu["sample"])[:200]
+        rr = cpu.get("reference_recipe_ba")
+        if isinstance(rr, dict) and rr.get("seconds_per_adjust") is not None:
+            cb["reference_recipe_ba_seconds_per_adjust"] = rr["seconds_per_adjust"]
+        line["cpu_baseline"] = cb
+    else:
+        line["cpu_baseline"] = None
+    for k in ("resident_frames", "host_frames", "closed_loop_w10_256", "closed_loop_w10_uncapped_tables"):
+        if isinstance(full.get(k), dict):
+            line[k] = full[k]
+    if extras_file:
+        line["extras_file"] = extras_file
+    # never above the limit: shed the optional parts, least important first
+    for drop in (("closed_loop_w10_uncapped_tables",), ("roofline", "kernels"), ("cpu_baseline", "sample"), ("closed_loop_w10_256",), ("host_frames",),
+                 ("regions",), ("roofline", "traffic_source"), ("config", "parallelism")):
+        if len(json.dumps(line, separators=(",", ":"), allow_nan=False)) < LINE_MAX_BYTES:
+            break
+        if len(drop) == 1:
+            line.pop(drop[0], None)
+        elif isinstance(line.get(drop[0]), dict):
+            line[drop[0]].pop(drop[1], None)
+    return json.dumps(line, separators=(",", ":"), allow_nan=False)
+
+
+def emit(full, a):
+    """full result object -> side file(s); the compact line (or, --full-line, the object itself) -> the LAST line of stdout"""
+    full = _strict(full)
+    targets = [a.extras_file] if a.extras_file else [os.path.join(ROOT, "bench_extras.json")] + \
+        ([os.path.join(ROOT, "gpurun_out", "bench_extras.json")] if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else [])
+    written = None
+    for t in targets:
+        try:
+            with open(t, "w") as f:
+                json.dump(full, f, indent=1, allow_nan=False)
+            written = written or os.path.relpath(t, ROOT)
+        except Exception as e:          # noqa: BLE001  (a read-only tree must not cost the line)
+            sys.stderr.write("bench: could not write %s: %s\n" % (t, e))
+    sys.stdout.flush()
+    print(json.dumps(full, allow_nan=False) if a.full_line else compact_line(full, written), flush=True)
+
+
 def self_launch(a):
     """`bench.py --gpus N` outside a torch.distributed launch: start the N ranks as a CHILD process tree (one process per GPU,
     the command the driver itself uses) and relay rank 0's JSON line.  This process never initialises the GPU."""
@@ -1102,7 +1251,7 @@ def main():
                          "oracle (C: pyramid+KLT+Shi-Tomasi+DLT, numpy: BA), %.1f s wall; %.2f frames/s per core; host shows %d cores, "
                          "its cgroup grants %d" % (cores, a.cpu_frames, secs, v / max(cores, 1), os.cpu_count() or 0, usable_cores())}
     cpu_pipe = None
-    if dist.rank == 0 and dist.world == 1 and not a.no_cpu_baseline and (a.workload == "pipeline" or (a.workload == "A" and not a.no_extras)):
+    if dist.rank == 0 and dist.world == 1 and not a.no_cpu_baseline and (a.workload == "pipeline" or (a.workload == "A" and a.extras)):
         # (child processes: before anything initialises the GPU here.  In the default run it is the figure beside the informational
         #  `pipeline_step.reference_configuration_window4` entry: the reference's own window, 2 048-slot tables)
         ap = a
@@ -1129,13 +1278,13 @@ def main():
         tot = dist.sum(float(r["sequences"]))
         if dist.rank == 0:
             fps = tot * a.steps / (r["ms_per_step"] * 1e-3 * a.steps)
-            print(json.dumps({"metric": "frames/sec, Pipeline.step resident on the device @1241x376 (<= %d tracked keypoints, RANSAC-P3P pose, triangulation, "
-                                        "%d-frame BA, re-detection; closed loop)" % (a.pipe_max_pts, a.pipe_window), "value": round(fps, 2), "unit": "frames/s", "n_gpus": dist.world,
-                              "steps": a.steps, "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-                              "vs_baseline": None, "dtype": "u8/i32 (KLT, Shi-Tomasi) + f64 (P3P, DLT, BA)", "data": "synthetic (rendered two-plane scene, known trajectory)",
-                              "config": {"workload": "pipeline_step_closed_loop_1241x376_ba%d" % a.pipe_window, "sequences_per_gpu": r["sequences"],
-                                         "batched_contexts_per_gpu": r["contexts"], "parallelism": "independent sequences, no collective"},
-                              "pipeline": r, "roofline": r.pop("roofline", None), "cpu_baseline": cpu_pipe}))
+            emit({"metric": "frames/sec, Pipeline.step resident on the device @1241x376 (<= %d tracked keypoints, RANSAC-P3P pose, triangulation, "
+                            "%d-frame BA, re-detection; closed loop)" % (a.pipe_max_pts, a.pipe_window), "value": round(fps, 2), "unit": "frames/s", "n_gpus": dist.world,
+                  "steps": a.steps, "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                  "vs_baseline": None, "dtype": "u8/i32 (KLT, Shi-Tomasi) + f64 (P3P, DLT, BA)", "data": "synthetic (rendered two-plane scene, known trajectory)",
+                  "config": {"workload": "pipeline_step_closed_loop_1241x376_ba%d" % a.pipe_window, "sequences_per_gpu": r["sequences"],
+                             "batched_contexts_per_gpu": r["contexts"], "parallelism": "independent sequences, no collective"},
+                  "pipeline": r, "roofline": r.pop("roofline", None), "cpu_baseline": cpu_pipe}, a)
         dist.close()
         return
     if c5:
@@ -1367,14 +1516,19 @@ def main():
     dist.barrier()
     for s in seqs:
         s.c.close()
-    if out is not None and dist.world == 1 and a.workload == "A" and not a.no_extras:
-        try:
+    try:
+        if out is not None and dist.world == 1 and a.workload == "A" and not a.no_extras:
+            # second figure of the line: the coupled loop (Pipeline.step resident on the device) at BASELINE's window and the headline's batch, as a
+            # CHILD with a timeout -- whatever it does, the headline built above is printed
+            out["closed_loop_w10_256"] = closed_loop_child(a, ["--pipe-window", "10", "--pipe-no-resurrect", "--seqs", str(a.seqs)])
+        if out is not None and dist.world == 1 and a.workload == "A" and a.extras:
             out.update(measure_extras(dist.local_rank, frame_sets, a, dist, cpu_pipe))
-        except Exception as e:      # noqa: BLE001  (informational keys must never cost the bench line)
-            out["extras_error"] = str(e)
-    dist.close()
-    if out is not None:
-        print(json.dumps(out))
+    except Exception as e:          # noqa: BLE001  (informational keys must never cost the bench line)
+        out["extras_error"] = repr(e)
+    finally:
+        dist.close()
+        if out is not None:
+            emit(out, a)
 
 
 if __name__ == "__main__":
