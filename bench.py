@@ -229,6 +229,24 @@ class Group:
         self.t = 1
         self.inflight = 0
         self.max_inflight = 2          # plain launches and hipGraph replay alike (a graph per pinned mirror half)
+        self.host = None               # use_host_frames(): per frame index the step's images as host arrays
+        self.frame_sets = frame_sets
+
+    def use_host_frames(self, on=True):
+        """the frames of every following step are handed over by the host (vo_frame_step_host) instead of read from the sequence store in HBM:
+        the distinct synthetic sequences live in page-locked host memory (what a loader decodes into, VoContext.host_alloc), sequence b's image
+        of a step is a numpy view of it -- `batch` arrays and `batch` x width x height bytes over PCIe per step"""
+        if not on:
+            self.host = None
+            return 0
+        if getattr(self, "_host_store", None) is None:
+            self._host_store = self.c.host_alloc((len(self.frame_sets), self.nf, H_IMG, W_IMG))
+            for k, fs in enumerate(self.frame_sets):
+                self._host_store[k] = fs
+            ns = len(self.frame_sets)
+            self._host_sets = [self.c.host_frames([self._host_store[b % ns, f] for b in range(self.B)]) for f in range(self.nf)]
+        self.host = self._host_sets
+        return self.B * W_IMG * H_IMG
 
     def enqueue(self):
         # one C call: pyramid + KLT + DLT + BA + Shi-Tomasi + result copies for the whole batch; the frames are a closed loop
@@ -237,8 +255,13 @@ class Group:
         if self.n_ba > 1 and self.stages[1]:
             self.c.ba_select(k)
         self.pending.append((k, self.ba_prm.max_iters))
-        self.c.frame_step_resident(self.t % self.nf, N_PTS, self.stages[0], self.stages[1], self.stages[2], 7, self.klt_prm,
+        if self.host is not None:
+            # this step's images come from the HOST (one numpy array per sequence, as Pipeline.step(img) receives them: pipeline.py:98,171-172)
+            self.c.frame_step_host(self.host[self.t % self.nf], N_PTS, self.stages[0], self.stages[1], self.stages[2], 7, self.klt_prm,
                                    self.st_prm, self.ba_prm)
+        else:
+            self.c.frame_step_resident(self.t % self.nf, N_PTS, self.stages[0], self.stages[1], self.stages[2], 7, self.klt_prm,
+                                       self.st_prm, self.ba_prm)
         self.t += 1
         self.inflight += 1
 
@@ -1418,6 +1441,38 @@ def main():
         for s in seqs:
             s.stationary = False
             s.recent = []
+    # ---- the same step with every frame handed over by the host (numpy arrays in page-locked memory -> vo_frame_step_host: upload on a copy stream
+    # beside the previous frame's LM chain): 3 regions of exactly K steps, same barriers ----
+    host_fig = None
+    if not c5 and not a.no_extras and not a.graph:
+        try:
+            h2d_bytes = sum(s.use_host_frames(True) for s in seqs)
+            for _ in range(max(4, a.warmup)):
+                step()
+            drain()
+            host_dt = []
+            for _ in range(3):
+                for s in seqs:
+                    s.c.sync()
+                dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    step()
+                drain()
+                for s in seqs:
+                    s.c.sync()
+                dist.barrier()
+                host_dt.append(dist.max(time.perf_counter() - t0))
+            hdt = float(np.median(host_dt))
+            hfps = dist.sum(float(a.seqs)) * a.steps / hdt
+            host_fig = {"value": round(hfps, 2), "unit": "frames/s", "ms_per_step": round(hdt / a.steps * 1e3, 4),
+                        "h2d_mb_per_step": round(h2d_bytes / 1e6, 1), "h2d_gb_s": round(h2d_bytes * a.steps / hdt / 1e9, 2),
+                        "vs_resident": round(hfps / (dist.sum(float(a.seqs)) * a.steps / dt), 4),
+                        "what": "every step's images from page-locked host arrays through vo_frame_step_host (one array per sequence), copy stream"}
+        except Exception as e:      # noqa: BLE001
+            host_fig = {"error": repr(e)[:200]}
+        for s in seqs:
+            s.use_host_frames(False)
     frames_step = 1.0 if c5 else dist.sum(float(a.seqs))                             # config 5: ONE sequence on all ranks
     frames_total = frames_step * a.steps
     fps = frames_total / dt
@@ -1513,6 +1568,9 @@ def main():
                            "ms_per_step_each": [round(x / a.steps * 1e3, 4) for x in region_dt]},
                "stage_ms_per_batched_launch_group": stage, "roofline": roof, "cpu_baseline": cpu,
                "setup_s": round(t_setup, 2)}
+        out["config"]["frames_source"] = "resident in HBM (vo_seq_upload); `host_frames`: the same with every frame handed over by the host"
+        if host_fig is not None:
+            out["host_frames"] = host_fig
     dist.barrier()
     for s in seqs:
         s.c.close()

@@ -502,6 +502,19 @@ int32_t vo_frame_step_resident(vo_ctx* ctx, int32_t frame_idx, int32_t n_pts, in
 int32_t vo_frame_fetch(vo_ctx* ctx, int32_t n_pts, float* p, uint8_t* status, float* err, float* X4,
                        double* depth1, double* reproj, double* poses, double* points, vo_ba_stats* stats,
                        float* corners, int32_t* n_corners);
+/* The same step with the frames handed over BY THE HOST, as the reference's loop does (Loader.next -> Pipeline.step(img): src/loader/loader.py:86,
+ * src/pipeline/pipeline.py:98,171-172): frames[b] = this step's image of sequence b, `height` rows of `stride` bytes (>= width), uint8.  The
+ * upload runs on a copy stream of its own into a device buffer double-buffered by step parity, the pyramid of the step waits for it by an event:
+ * with two steps in flight the upload of frame t + 1 overlaps the bundle adjustment of frame t.  Images that follow each other in host memory (a
+ * [batch][height][width] array) travel as one copy.  Pinned memory (vo_host_alloc, or registered by the caller) is read by DMA asynchronously and
+ * must stay untouched until vo_frame_fetch has returned this step; pageable memory is consumed before the call returns (staged by the runtime:
+ * slower).  Results are bit-identical to vo_frame_step_resident on the same frames.  Plain launches (a captured graph bakes its source in). */
+int32_t vo_frame_step_host(vo_ctx* ctx, const uint8_t* const* frames, int32_t stride, int32_t n_pts, int32_t do_dlt, int32_t do_ba,
+                           int32_t do_st, int32_t mask_radius, const vo_klt_params* klt,
+                           const vo_st_params* st, const vo_ba_params* ba);                    /* async */
+/* page-locked host memory for frames a loader decodes into (numpy arrays over it: VoContext.host_alloc) */
+int32_t vo_host_alloc(uint64_t bytes, void** out);
+int32_t vo_host_free(void* p);
 int32_t vo_set_graph_mode(vo_ctx* ctx, int32_t on);
 /* Stream layout of vo_frame_step_resident.  0: one stream.  1 (default; environment VO_SIDE_STREAM sets the default): re-detection +
  * triangulation on a side stream beside the bundle adjustment (+10-20 % for one context, +1-2 % with three).  2: pipelined, three

@@ -291,3 +291,87 @@ def test_pipelined_batch_random_stage_patterns(seed):
                 assert len(got[k][key]) == len(ref[k][key]) and all(np.array_equal(x, y) for x, y in zip(got[k][key], ref[k][key])), (k, key, plan[k])
             else:
                 assert np.array_equal(got[k][key], ref[k][key], equal_nan=True), (k, key, plan[k])
+
+
+@pytest.mark.parametrize("batch,layout,source", [(1, 1, "pinned"), (8, "pipeline", "pinned"), (8, "pipeline", "pageable"), (3, 0, "strided")])
+def test_host_frame_step_equals_resident_step(batch, layout, source):
+    """vo_frame_step_host (this step's images handed over by the host, uploaded on the copy stream: the reference's Pipeline.step(img),
+    pipeline.py:98,171-172) = vo_frame_step_resident on the same frames, bit for bit, two steps in flight; pinned arrays (DMA), pageable arrays
+    (staged by the runtime), one [batch, h, w] array (one copy) and per-sequence arrays with a row stride > width"""
+    from vo_mi355x import VoContext, synthetic as syn
+    w, h, n, n_new = 480, 200, 400, 150
+    seqs = [syn.make_sequence(6, w=w, h=h, seed=31 + b, margin=64)[0] for b in range(batch)]
+    frames = np.stack(seqs)                                     # [batch, 6, h, w]
+    pts = np.stack([syn.grid_points(n, w, h, seed=9 + b) for b in range(batch)])
+    scenes = [syn.make_ba_scene(n_pts=200, n_slots=5, seed=4 + b, visibility=0.9) for b in range(batch)]
+    order = [1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1, 2]
+    keys = ("points2d", "status", "err", "X4", "depth1", "reproj", "poses", "landmarks", "corners")
+
+    def setup(c):
+        c.set_side_stream(layout)
+        K = np.stack([s["K"] for s in scenes])
+        P0, P1, u0, u1, H0s, H1s = [], [], [], [], [], []
+        for s in scenes:
+            H0, H1 = np.eye(4), np.eye(4)
+            H0[:3, :3], H0[:3, 3] = syn.rodrigues(s["poses_gt"][3, :3]), s["poses_gt"][3, 3:]
+            H1[:3, :3], H1[:3, 3] = syn.rodrigues(s["poses_gt"][0, :3]), s["poses_gt"][0, 3:]
+            P0.append((s["K"] @ H0[:3]).astype(np.float32)); P1.append((s["K"] @ H1[:3]).astype(np.float32))
+            u0.append(s["obs"][3, :n_new].astype(np.float32)); u1.append(s["obs"][0, :n_new].astype(np.float32)); H0s.append(H0); H1s.append(H1)
+        sq = (lambda x: np.stack(x)) if batch > 1 else (lambda x: x[0])
+        c.points_upload(pts if batch > 1 else pts[0])
+        c.dlt_upload(sq(P0), sq(P1), sq(u0), sq(u1), K if batch > 1 else K[0], sq(H0s), sq(H1s))
+        c.ba_upload(K if batch > 1 else K[0], sq([s["poses0"] for s in scenes]), sq([s["points0"] for s in scenes]), sq([s["obs"] for s in scenes]))
+
+    def run(c, enqueue):
+        out = []
+        bap = c.ba_params(max_iters=6)
+        for k, f in enumerate(order):
+            enqueue(c, f, bap)
+            if k >= 1:
+                out.append(c.frame_fetch())
+        out.append(c.frame_fetch())
+        return out
+
+    with VoContext(w, h, max_pts=512, batch=batch) as c:
+        setup(c)
+        c.upload_sequence(frames if batch > 1 else frames[0])
+        c.push_frame_resident(0)
+        ref = run(c, lambda c, f, bap: c.frame_step_resident(f, n, ba=bap))
+    with VoContext(w, h, max_pts=512, batch=batch) as c:
+        setup(c)
+        if source == "pinned":
+            host = VoContext.host_alloc((6, batch, h, w))       # a [batch, h, w] block per frame: ONE copy per step
+            host[:] = frames.transpose(1, 0, 2, 3)
+            give = lambda f: host[f]
+        elif source == "pageable":
+            give = lambda f: [seqs[b][f] for b in range(batch)]  # views into the sequences' own arrays: `batch` copies per step
+        else:
+            wide = np.zeros((batch, 6, h, w + 37), np.uint8)
+            wide[..., :w] = frames
+            give = lambda f: [wide[b, f, :, :w] for b in range(batch)]
+        c.push_frame(frames[:, 0] if batch > 1 else frames[0, 0])
+        got = run(c, lambda c, f, bap: c.frame_step_host(give(f), n, ba=bap))
+    assert len(got) == len(ref) == len(order)
+    for k, (g, r) in enumerate(zip(got, ref)):
+        for key in keys:
+            if key == "corners" and batch > 1:
+                assert all(np.array_equal(g[key][b], r[key][b]) for b in range(batch)), (k, key)
+            else:
+                assert np.array_equal(g[key], r[key], equal_nan=True), (k, key)
+        gs = g["ba_stats"] if isinstance(g["ba_stats"], list) else [g["ba_stats"]]
+        rs = r["ba_stats"] if isinstance(r["ba_stats"], list) else [r["ba_stats"]]
+        assert [(x["cost"], x["iters"], x["status"]) for x in gs] == [(x["cost"], x["iters"], x["status"]) for x in rs], k
+
+
+def test_host_alloc_is_a_plain_numpy_array_and_frees_itself():
+    import gc
+    from vo_mi355x import VoContext
+    a = VoContext.host_alloc((4, 16, 32))
+    assert a.shape == (4, 16, 32) and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"] and a.flags["WRITEABLE"]
+    a[:] = 7
+    v = a[1]
+    del a
+    gc.collect()
+    assert int(v.sum()) == 7 * 16 * 32           # a view keeps the allocation alive
+    del v
+    gc.collect()

@@ -337,6 +337,7 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);   // side branch of the frame step (an error path may have left it unjoined)
+  if (c->stream_h2d) (void)hipStreamSynchronize(c->stream_h2d);
   if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   (void)vo_comm_destroy(c);
   vo_pipe_destroy(c);
@@ -365,6 +366,13 @@ extern "C" int32_t vo_ctx_destroy(vo_ctx* c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
+  for (int k = 0; k < 2; k++) {
+    if (c->d_host_raw[k]) (void)hipFree(c->d_host_raw[k]);
+    if (c->ev_h2d[k]) (void)hipEventDestroy(c->ev_h2d[k]);
+    if (c->ev_raw_free[k]) (void)hipEventDestroy(c->ev_raw_free[k]);
+  }
+  if (c->stream_h2d) (void)hipStreamDestroy(c->stream_h2d);
+  if (c->h_ptr_tab) (void)hipHostFree(c->h_ptr_tab);
   for (int k = 0; k < 2; k++) if (c->ev_ba_wide[k]) (void)hipEventDestroy(c->ev_ba_wide[k]);
   for (int k = 0; k < 2; k++) { if (c->ev_ba[k]) (void)hipEventDestroy(c->ev_ba[k]); if (c->ev_pub[k]) (void)hipEventDestroy(c->ev_pub[k]); if (c->ev_copy1[k]) (void)hipEventDestroy(c->ev_copy1[k]); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -482,6 +490,7 @@ extern "C" int32_t vo_sync(vo_ctx* c) {
   VO_HIP(c, hipStreamSynchronize(c->stream));
   if (c->stream2) VO_HIP(c, hipStreamSynchronize(c->stream2));     // branches of a frame step that has not been fetched
   if (c->stream3) VO_HIP(c, hipStreamSynchronize(c->stream3));
+  if (c->stream_h2d) VO_HIP(c, hipStreamSynchronize(c->stream_h2d));
   return VO_OK;
 }
 

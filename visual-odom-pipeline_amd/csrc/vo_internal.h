@@ -81,6 +81,13 @@ struct vo_ctx {
   uint8_t* d_raw = nullptr;          // staging of one raw frame per sequence
   uint8_t* h_raw = nullptr;          // pinned host staging of vo_frame_push (allocated on first use)
   hipEvent_t ev_raw = nullptr;       // the upload out of h_raw is done
+  // vo_frame_step_host: the frames of a step arrive from the host on a copy stream of their own, double-buffered like the steps in flight
+  hipStream_t stream_h2d = nullptr;
+  uint8_t* d_host_raw[2] = {nullptr, nullptr};      // [batch][h][w], by step parity
+  hipEvent_t ev_h2d[2] = {nullptr, nullptr};        // the upload into d_host_raw[k] is complete (recorded on stream_h2d, awaited by the ctx stream)
+  hipEvent_t ev_raw_free[2] = {nullptr, nullptr};   // the pyramid has read d_host_raw[k] (recorded on the ctx stream, awaited by stream_h2d)
+  bool raw_free_recorded[2] = {false, false};
+  const uint8_t** h_ptr_tab = nullptr;              // page-locked [2][batch]: device-visible addresses of a step's images (read by k_gather_frames)
   uint8_t* d_seq = nullptr;          // preloaded sequences [batch][seq_n][h][w] (vo_seq_upload)
   int seq_n = 0;
   // tracked point sets live in the result slab (off_pa / off_pb, ping-pong selected by p_parity)

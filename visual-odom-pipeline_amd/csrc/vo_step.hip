@@ -59,13 +59,19 @@ struct step_cfg {
 };
 
 // enqueue everything of one frame on the ctx stream (also used under stream capture); *recorded: ev_step[half] has been recorded
+// frame_idx < 0: the frames of this step arrive from the host in c->d_host_raw[half] (vo_frame_step_host: the upload runs on the copy stream,
+// ev_h2d[half] says when it is there)
 static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame_idx, int frame_idx, int half, bool* recorded) {
   int32_t r;
   *recorded = false;
   static const bool trace_a = getenv("VO_STEP_TRACE") != nullptr;
   if (trace_a && c->side_stream == 2) trace_push(g_ta, c->stream, 4000);
   const size_t fr = (size_t)c->width * c->height;
-  if (d_frame_idx) r = vo_build_pyramid(c, c->d_seq, fr * c->seq_n, d_frame_idx);
+  if (frame_idx < 0) {
+    VO_HIP(c, hipStreamWaitEvent(c->stream, c->ev_h2d[half], 0));
+    r = vo_build_pyramid(c, c->d_host_raw[half], fr, nullptr);
+    if (r == VO_OK) { VO_HIP(c, hipEventRecord(c->ev_raw_free[half], c->stream)); c->raw_free_recorded[half] = true; }
+  } else if (d_frame_idx) r = vo_build_pyramid(c, c->d_seq, fr * c->seq_n, d_frame_idx);
   else r = vo_build_pyramid(c, c->d_seq + (size_t)frame_idx * fr, fr * c->seq_n, nullptr);
   if (r != VO_OK) return r;
   if (trace_a && c->side_stream == 2) trace_push(g_tb, c->stream, 6000);
@@ -187,11 +193,117 @@ static uint64_t step_signature(vo_ctx* c, const step_cfg& s) {
   return h;
 }
 
+// ---- frames from the host -------------------------------------------------------------------------------------------------------------
+// Page-locked host arrays are read by the GPU itself over PCIe: ONE launch per step gathers the `batch` images (wherever each of them lies,
+// whatever their row stride) into d_host_raw[half] -- a copy-engine transfer per image cost ~32 us each (256 images: 8 ms for 119 MB).  A
+// workgroup column per image, a thread moves 16 bytes per trip, U trips in flight per thread: a few hundred KB outstanding hide the bus latency.
+template <int U>
+__global__ __launch_bounds__(256) void k_gather_frames(const uint8_t* const* __restrict__ tab, int stride, int w, int h, uint8_t* __restrict__ dst, size_t fr) {
+  const uint8_t* __restrict__ src = tab[blockIdx.y];
+  uint8_t* __restrict__ d = dst + (size_t)blockIdx.y * fr;
+  const int cpr = (w + 15) >> 4, n = cpr * h, T = (int)gridDim.x * 256;
+  for (int i0 = (int)blockIdx.x * 256 + (int)threadIdx.x; i0 < n; i0 += U * T) {
+    uint4 v[U];
+    int so[U], dn[U], len[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * T;
+      len[u] = 0;
+      if (i < n) {
+        const int row = i / cpr, ch = i - row * cpr;
+        so[u] = row * stride + ch * 16; dn[u] = row * w + ch * 16;
+        len[u] = min(16, w - ch * 16);
+        if (len[u] == 16) __builtin_memcpy(&v[u], src + so[u], 16);          // (any alignment: the images of a batch lie w * h bytes apart)
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (len[u] == 16) __builtin_memcpy(d + dn[u], &v[u], 16);
+      else for (int k = 0; k < len[u]; k++) d[dn[u] + k] = src[so[u] + k];
+    }
+  }
+}
+
+// the upload of a host-frame step on the copy stream into d_host_raw[half].  Page-locked images: the gather kernel; pageable ones: a copy per
+// image (runs of images that follow each other in host memory -- a [batch][h][w] array -- go as ONE copy), which the runtime stages
+static int32_t host_frames_upload(vo_ctx* c, const uint8_t* const* frames, int32_t stride, int half) {
+  const size_t fr = (size_t)c->width * c->height;
+  if (!c->stream_h2d) {
+    VO_HIP(c, hipStreamCreateWithFlags(&c->stream_h2d, hipStreamNonBlocking));
+    VO_HIP(c, hipHostMalloc((void**)&c->h_ptr_tab, 2 * sizeof(void*) * (size_t)c->batch, hipHostMallocDefault));
+    for (int k = 0; k < 2; k++) {
+      VO_HIP(c, hipMalloc((void**)&c->d_host_raw[k], fr * c->batch));
+      VO_HIP(c, hipEventCreateWithFlags(&c->ev_h2d[k], hipEventDisableTiming));
+      VO_HIP(c, hipEventCreateWithFlags(&c->ev_raw_free[k], hipEventDisableTiming));
+    }
+  }
+  // the pyramid of the step that used this half two steps ago has read it (that step has been fetched, so this wait never blocks in practice)
+  if (c->raw_free_recorded[half]) VO_HIP(c, hipStreamWaitEvent(c->stream_h2d, c->ev_raw_free[half], 0));
+  uint8_t* const dst = c->d_host_raw[half];
+  // device-visible addresses of the images, if every one of them is page-locked
+  const uint8_t** tab = c->h_ptr_tab + (size_t)half * c->batch;
+  bool pinned = true;
+  for (int b = 0; b < c->batch && pinned; b++) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, frames[b]) != hipSuccess) { (void)hipGetLastError(); pinned = false; break; }
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) pinned = false;
+    else tab[b] = static_cast<const uint8_t*>(at.devicePointer);
+  }
+  if (pinned) {
+    const bool flat = stride == c->width;
+    const int w = flat ? (int)fr : c->width, h = flat ? 1 : c->height;
+    const int chunks = ((w + 15) >> 4) * h;
+    int gx = vo_div_up(256, c->batch) * 2;                                   // ~512 workgroups: 2 per compute unit, 2 MB in flight
+    gx = gx > vo_div_up(chunks, 1024) ? vo_div_up(chunks, 1024) : gx;
+    hipLaunchKernelGGL(k_gather_frames<4>, dim3(gx < 1 ? 1 : gx, c->batch), dim3(256), 0, c->stream_h2d, tab, flat ? (int)fr : stride, w, h, dst, fr);
+    VO_HIP(c, hipGetLastError());
+    VO_HIP(c, hipEventRecord(c->ev_h2d[half], c->stream_h2d));
+    return VO_OK;
+  }
+  for (int b = 0; b < c->batch;) {
+    int e = b + 1;
+    if (stride == c->width) while (e < c->batch && frames[e] == frames[e - 1] + fr) e++;
+    if (stride == c->width) VO_HIP(c, hipMemcpyAsync(dst + (size_t)b * fr, frames[b], fr * (size_t)(e - b), hipMemcpyHostToDevice, c->stream_h2d));
+    else VO_HIP(c, hipMemcpy2DAsync(dst + (size_t)b * fr, c->width, frames[b], stride, c->width, c->height, hipMemcpyHostToDevice, c->stream_h2d));
+    b = e;
+  }
+  VO_HIP(c, hipEventRecord(c->ev_h2d[half], c->stream_h2d));
+  return VO_OK;
+}
+
+static int32_t frame_step(vo_ctx* c, int32_t frame_idx, const uint8_t* const* host_frames, int32_t stride, int32_t n_pts, int32_t do_dlt, int32_t do_ba,
+                          int32_t do_st, int32_t mask_radius, const vo_klt_params* klt, const vo_st_params* st, const vo_ba_params* ba);
+
 extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t n_pts, int32_t do_dlt, int32_t do_ba,
                                           int32_t do_st, int32_t mask_radius, const vo_klt_params* klt,
                                           const vo_st_params* st, const vo_ba_params* ba) {
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->d_seq && frame_idx >= 0 && frame_idx < c->seq_n, VO_E_STATE, "no resident sequence / bad index");
+  return frame_step(c, frame_idx, nullptr, 0, n_pts, do_dlt, do_ba, do_st, mask_radius, klt, st, ba);
+}
+
+extern "C" int32_t vo_frame_step_host(vo_ctx* c, const uint8_t* const* frames, int32_t stride, int32_t n_pts, int32_t do_dlt, int32_t do_ba,
+                                      int32_t do_st, int32_t mask_radius, const vo_klt_params* klt,
+                                      const vo_st_params* st, const vo_ba_params* ba) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, frames != nullptr && stride >= c->width, VO_E_INVALID, "bad frame pointers / stride");
+  for (int b = 0; b < c->batch; b++) VO_CHECK(c, frames[b] != nullptr, VO_E_INVALID, "null frame pointer");
+  return frame_step(c, -1, frames, stride, n_pts, do_dlt, do_ba, do_st, mask_radius, klt, st, ba);
+}
+
+extern "C" int32_t vo_host_alloc(uint64_t bytes, void** out) {
+  if (!out || bytes == 0) return VO_E_INVALID;
+  *out = nullptr;
+  return hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault) == hipSuccess ? VO_OK : VO_E_NOMEM;
+}
+
+extern "C" int32_t vo_host_free(void* p) {
+  if (!p) return VO_OK;
+  return hipHostFree(p) == hipSuccess ? VO_OK : VO_E_HIP;
+}
+
+static int32_t frame_step(vo_ctx* c, int32_t frame_idx, const uint8_t* const* host_frames, int32_t stride, int32_t n_pts, int32_t do_dlt, int32_t do_ba,
+                          int32_t do_st, int32_t mask_radius, const vo_klt_params* klt, const vo_st_params* st, const vo_ba_params* ba) {
   VO_CHECK(c, c->n_pushed >= 1, VO_E_STATE, "push one frame before stepping");
   VO_HIP(c, hipSetDevice(c->device));
   step_cfg s;
@@ -211,7 +323,8 @@ extern "C" int32_t vo_frame_step_resident(vo_ctx* c, int32_t frame_idx, int32_t 
   VO_CHECK(c, c->steps_enq - c->steps_fetched < 2, VO_E_STATE, "vo_frame_fetch the previous step(s) first");
   c->main_dirty = true;
   const int half = (int)(c->steps_enq & 1);
-  const bool graph_ok = c->use_graph && c->prof.mask == 0 && c->n_pushed >= 2;
+  if (host_frames) { const int32_t ru = host_frames_upload(c, host_frames, stride, half); if (ru != VO_OK) return ru; }
+  const bool graph_ok = c->use_graph && c->prof.mask == 0 && c->n_pushed >= 2 && !host_frames;     // (host frames: plain launches)
   if (!graph_ok) {
     bool recorded = false;
     c->in_step = true;

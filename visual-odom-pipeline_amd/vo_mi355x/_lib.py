@@ -121,6 +121,10 @@ SIGNATURES = {
     "vo_dlt_fetch": (C.c_int32, [_ctx, _f32p, _f64p, _f64p]),
     "vo_frame_step_resident": (C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.POINTER(KltParams), C.POINTER(StParams), C.POINTER(BaParams)]),
+    "vo_frame_step_host": (C.c_int32, [_ctx, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.POINTER(KltParams), C.POINTER(StParams), C.POINTER(BaParams)]),
+    "vo_host_alloc": (C.c_int32, [C.c_uint64, C.POINTER(C.c_void_p)]),
+    "vo_host_free": (C.c_int32, [C.c_void_p]),
     "vo_frame_fetch": (C.c_int32, [_ctx, C.c_int32, _f32p, _u8p, _f32p, _f32p, _f64p, _f64p, _f64p, _f64p,
                                    C.POINTER(BaStats), _f32p, _i32p]),
     "vo_set_graph_mode": (C.c_int32, [_ctx, C.c_int32]),

@@ -297,6 +297,64 @@ class VoContext:
             self._step_cfgs = []
         self._step_cfgs.append((n_pts, do_dlt, do_ba, do_st))
 
+    def frame_step_host(self, frames, n_pts, do_dlt=True, do_ba=True, do_st=True, mask_radius=7, klt=None, st=None, ba=None):
+        """the same step with this frame's images handed over by the host, as the reference's loop does (pipeline.py:98,171-172):
+        frames = one uint8 [h, w] array per sequence (a list / tuple of `batch` arrays, rows contiguous, a common row stride) or one
+        [batch, h, w] array.  The upload runs on a copy stream beside the previous step's bundle adjustment.  Arrays over pinned memory
+        (`VoContext.host_alloc`) must stay untouched until `frame_fetch` has returned this step; the arrays are kept referenced until then."""
+        ptrs, stride, frames = frames if isinstance(frames, tuple) and len(frames) == 3 and isinstance(frames[1], int) else self.host_frames(frames)
+        klt = klt if klt is not None else self.klt_params()
+        st = st if st is not None else self.st_params()
+        ba = ba if ba is not None else self.ba_params()
+        self._klt_levels = klt.max_level + 1
+        self._st_max_corners = st.max_corners
+        self._ck(self._L.vo_frame_step_host(self._h, ptrs, int(stride), int(n_pts), int(do_dlt), int(do_ba), int(do_st),
+                                            int(mask_radius), C.byref(klt), C.byref(st), C.byref(ba)))
+        if not hasattr(self, "_step_cfgs"):
+            self._step_cfgs = []
+        self._step_cfgs.append((n_pts, do_dlt, do_ba, do_st))
+        if not hasattr(self, "_host_refs"):
+            self._host_refs = []
+        self._host_refs.append(frames)          # released by frame_fetch: DMA out of pinned arrays is asynchronous
+        while len(self._host_refs) > 2:
+            self._host_refs.pop(0)
+
+
+    def host_frames(self, frames):
+        """-> (pointer array, row stride, the arrays): the checked form of one step's images that `frame_step_host` also accepts directly (a loader
+        that cycles through a fixed set of buffers builds it once per buffer)"""
+        if isinstance(frames, np.ndarray):
+            frames = [frames] if frames.ndim == 2 else list(frames)
+        if len(frames) != self.batch:
+            raise ValueError("frame_step_host: %d frames for a batch of %d" % (len(frames), self.batch))
+        stride = None
+        ptrs = (C.c_void_p * self.batch)()
+        for b, f in enumerate(frames):
+            if f.dtype != np.uint8 or f.shape != (self.height, self.width) or f.strides[1] != 1 or f.strides[0] < self.width:
+                raise ValueError("frame_step_host: expected uint8 [%d, %d] images with contiguous rows" % (self.height, self.width))
+            if stride is None:
+                stride = f.strides[0]
+            elif f.strides[0] != stride:
+                raise ValueError("frame_step_host: the images of a step share one row stride")
+            ptrs[b] = f.ctypes.data
+        return ptrs, int(stride), frames
+
+    @classmethod
+    def host_alloc(cls, shape, dtype=np.uint8):
+        """numpy array over page-locked host memory (vo_host_alloc): what a loader decodes frames into so that `frame_step_host` uploads them
+        by DMA without a staging copy.  Freed when the array (and every view of it) is gone."""
+        import weakref
+        L = _lib.load()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        rc = L.vo_host_alloc(max(n, 1), C.byref(p))
+        if rc != 0:
+            raise VoError(rc, "vo_host_alloc(%d bytes) failed" % n)
+        buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        weakref.finalize(buf, L.vo_host_free, C.c_void_p(p.value))
+        return arr
+
     def frame_fetch(self):
         """wait for the enqueued frame and return its results as a dict of numpy arrays"""
         if getattr(self, "_step_cfgs", None):
