@@ -157,6 +157,26 @@ def pingpong(t, n):
     return k if k < n else period - k
 
 
+def ba_bank(seed0, b, **kw):
+    """the BA problems sequence b of a context (seeded seed0) cycles through, one per frame in turn: a sliding window never shows the same problem
+    twice, so the LM iteration count changes from frame to frame and the iteration budget has to cope with that"""
+    from vo_mi355x import synthetic as syn
+    return [syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=seed0 + b, **kw)] + \
+           [syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=seed0 + b + 7919 * k, obs_noise=v[0], pt_noise=v[1], pose_noise=v[2], visibility=v[3], **kw)
+            for k, v in enumerate(BA_VARIANTS) if k > 0]
+
+
+def dlt_inputs(scene):
+    """-> (P0, P1 float32 3x4, uv0, uv1 float32 [N_NEW, 2], K, H0, H1): 1000 new tracks between two window poses of a BA scene"""
+    from vo_mi355x import synthetic as syn
+    K = scene["K"]
+    H0, H1 = np.eye(4), np.eye(4)
+    H0[:3, :3], H0[:3, 3] = syn.rodrigues(scene["poses_gt"][3, :3]), scene["poses_gt"][3, 3:]
+    H1[:3, :3], H1[:3, 3] = syn.rodrigues(scene["poses_gt"][0, :3]), scene["poses_gt"][0, 3:]
+    return ((K @ H0[:3]).astype(np.float32), (K @ H1[:3]).astype(np.float32), scene["obs"][3, :N_NEW].astype(np.float32),
+            scene["obs"][0, :N_NEW].astype(np.float32), K, H0, H1)
+
+
 class Group:
     """`batch` independent VO sequences carried in lockstep by ONE batched context (one HIP stream): every launch of
     the hot path serves all of them.  Everything is resident in HBM."""
@@ -173,25 +193,18 @@ class Group:
         c.points_upload(pts0)
         # DLT: 1000 new tracks between two window poses of each BA scene; BA: N = 2000, W = 10 per sequence
         kw = {} if K_CAM is None else dict(K=K_CAM, width=W_IMG, height=H_IMG)
-        scenes = [syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=seed0 + b, **kw) for b in range(batch)]
-        P0s, P1s, u0, u1, Ks, H0s, H1s = [], [], [], [], [], [], []
-        for s in scenes:
-            K = s["K"]
-            H0, H1 = np.eye(4), np.eye(4)
-            H0[:3, :3], H0[:3, 3] = syn.rodrigues(s["poses_gt"][3, :3]), s["poses_gt"][3, 3:]
-            H1[:3, :3], H1[:3, 3] = syn.rodrigues(s["poses_gt"][0, :3]), s["poses_gt"][0, 3:]
-            P0s.append((K @ H0[:3]).astype(np.float32)); P1s.append((K @ H1[:3]).astype(np.float32))
-            u0.append(s["obs"][3, :N_NEW].astype(np.float32)); u1.append(s["obs"][0, :N_NEW].astype(np.float32))
-            Ks.append(K); H0s.append(H0); H1s.append(H1)
-        c.dlt_upload(np.stack(P0s), np.stack(P1s), np.stack(u0), np.stack(u1), np.stack(Ks), np.stack(H0s), np.stack(H1s))
         self.n_ba = 1
         if shard is None:
-            # a BANK of BA_BANK distinct problems per sequence, one per frame in turn: a sliding window never shows the same problem twice,
-            # so the LM iteration count changes from frame to frame (4 ... 7 here) and the iteration budget has to cope with that
+            # a BANK of distinct problems per sequence, one per frame in turn (4 ... 21 LM iterations here)
             self.n_ba = len(BA_VARIANTS)
-            bank = [[scenes[b]] + [syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=seed0 + b + 7919 * k, obs_noise=v[0], pt_noise=v[1],
-                                                     pose_noise=v[2], visibility=v[3], **kw) for k, v in enumerate(BA_VARIANTS) if k > 0]
-                    for b in range(batch)]
+            bank = [ba_bank(seed0, b, **kw) for b in range(batch)]
+            scenes = [bk[0] for bk in bank]
+        else:
+            scenes = [syn.make_ba_scene(n_pts=BA_N, n_slots=BA_W, seed=seed0 + b, **kw) for b in range(batch)]
+        d = [dlt_inputs(s) for s in scenes]
+        Ks = [s["K"] for s in scenes]
+        c.dlt_upload(*[np.stack([d[b][k] for b in range(batch)]) for k in range(7)])
+        if shard is None:
             c.ba_upload_bank(np.stack(Ks), np.stack([[bank[b][k]["poses0"] for b in range(batch)] for k in range(self.n_ba)]),
                              np.stack([[bank[b][k]["points0"] for b in range(batch)] for k in range(self.n_ba)]),
                              np.stack([[bank[b][k]["obs"] for b in range(batch)] for k in range(self.n_ba)]))
