@@ -92,6 +92,7 @@ def parse():
                          "iteration (front end replicated); strong scaling, not the headline metric.  pipeline: the whole Pipeline.step "
                          "resident on the device as a closed loop (tracks, landmarks, dead lists and the trajectory in device tables; one "
                          "enqueue per frame, every stage fed by the previous ones); informational")
+    ap.add_argument("--tune", default="", help="vo_tuning fields for every context of the run, e.g. ba_kernels=1,gate_groups=5 (include/vo_mi355x.h; A/B scripts under tools/)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames each CPU-baseline worker process runs")
     ap.add_argument("--cpu-procs", type=int, default=16, help="CPU-baseline worker processes (one core each), capped by the host's cores")
@@ -825,7 +826,8 @@ def closed_loop_child(a, extra_args, steps=40, timeout=150):
     the side file under the same key + `_full`).  Never raises: an error or a timeout becomes {"error": ...}."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "pipeline", "--ctxs", "1", "--steps", str(steps), "--warmup", "10", "--regions", "3",
-           "--no-cpu-baseline", "--full-line", "--extras-file", os.devnull, "--pipe-frames", str(a.pipe_frames), "--pipe-ba-iters", str(a.pipe_ba_iters)] + list(extra_args)
+           "--no-cpu-baseline", "--full-line", "--extras-file", os.devnull, "--pipe-frames", str(a.pipe_frames), "--pipe-ba-iters", str(a.pipe_ba_iters)] + \
+          (["--tune", a.tune] if a.tune else []) + list(extra_args)
     env = {k: v for k, v in os.environ.items() if k not in CHILD_ENV_DROP}
     t0 = time.perf_counter()
     try:
@@ -1296,6 +1298,8 @@ def main():
             ap = _c.copy(a); ap.pipe_window, ap.pipe_no_resurrect = 4, False
         cpu_pipe = cpu_pipeline_baseline(ap, max(1, min(a.cpu_procs, usable_cores())))
     from vo_mi355x import VoContext, synthetic as syn
+    if a.tune:
+        VoContext.default_tuning = {k.strip(): int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv.strip())}
     # more stepping host threads on this node than cores it grants (8 ranks x 3 threads on a 16-core cgroup): wait for a step's event
     # in the driver instead of spinning on it (1 GPU: 34 650 vs 34 640 frames/s, two ranks on one GPU 31 580 vs 31 190 -- no loss)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))

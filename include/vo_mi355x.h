@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VO_ABI_VERSION 3
+#define VO_ABI_VERSION 4
 
 enum {
   VO_OK = 0,
@@ -207,7 +207,7 @@ int32_t vo_shi_tomasi_resident(vo_ctx* ctx, int32_t n_cur, int32_t mask_radius,
 int32_t vo_shi_tomasi_fetch(vo_ctx* ctx, float* out_pts, int32_t* n_out);     /* sync + copy out */
 /* parity probes: min-eigenvalue map (h x w f32) and the mask actually used (h x w u8) of the last SYNCHRONOUS call
  * (vo_shi_tomasi).  The resident forms keep neither -- the map never leaves the kernel that forms it and the mask is handed
- * back clean for the next frame -- and eig_out / mask_out then return VO_E_STATE (environment VO_ST_KEEP_EIG=1 makes the
+ * back clean for the next frame -- and eig_out / mask_out then return VO_E_STATE (vo_tuning.st_keep_eig makes the
  * resident forms keep them); n_candidates (local maxima above the quality threshold) is always available.
  * More than 16384 candidates are consumed in rank-ordered chunks, like OpenCV's scan; VO_E_CAPACITY only beyond 262144. */
 int32_t vo_shi_tomasi_read(vo_ctx* ctx, float* eig_out, uint8_t* mask_out, int32_t* n_candidates);
@@ -486,6 +486,37 @@ int32_t vo_pipe_lists_read(vo_ctx* ctx, void* dst);
 int32_t vo_pipe_rows_read(vo_ctx* ctx, int32_t kind, const int32_t* rows, int32_t n, void* out);
 int32_t vo_pipe_inliers_read(vo_ctx* ctx, uint8_t* mask, int32_t n);
 
+/* ---- forced forms (parity tests, A/B measurements) ---------------------------------------------
+ * Every kernel choice the library makes by a rule (which bundle-adjustment family, how a problem is spread over workgroups, which form of the
+ * eigenvalue pass, the stream layout's gate ...) can be forced per context; 0 in a field = the rule.  This replaces the process-wide VO_* environment
+ * switches of rounds 1-5: the library reads no tuning from the environment any more.  Results do not depend on any of these fields except in the
+ * last bits of a bundle adjustment (its partial sums are folded in another order: ~1e-12).  Set it with nothing in flight; the bundle-adjustment
+ * fields marked (upload) shape the workspace and take effect at the next vo_ba_upload / vo_ba_upload_bank / vo_pipe_create. */
+typedef struct {
+  int32_t ba_kernels;          /* (upload) 1: lane-per-observation kernels (k_ba_build<>); 2: wave-private kernels (k_ba_build_w<>, windows <= 10) */
+  int32_t ba_lanes;            /* (upload) lanes per landmark: 8 = wave-private kernels at windows of 9-10 slots (rule: 5); 16 = lane-per-observation
+                                  kernels at windows <= 8 (rule: 8) */
+  int32_t ba_threads;          /* (upload) lane-per-observation kernels: workgroup size 256 / 512 / 1024 */
+  int32_t ba_pitch_pad;        /* (upload) lane-per-observation kernels: panel pitch = rows + (ba_pitch_pad - 1) doubles */
+  int32_t ba_chunks;           /* lane-per-observation kernels: landmark chunks per workgroup */
+  int32_t ba_workgroups;       /* wave-private kernels: workgroups per problem in a full launch */
+  int32_t ba_workgroup_cap;    /* wave-private kernels: most workgroups a running problem gets once others have finished (rule: 16) */
+  int32_t ba_fold;             /* 1: a reduce kernel folds the partial sets; 2: k_ba_solve folds them itself */
+  int32_t klt_waves;           /* occupancy bound the tracker is compiled for: 4 / 5 / 6 waves per SIMD (rule: 6) */
+  int32_t klt_pair;            /* builds with -DVO_EXPERIMENTS only: 3 / 4 / 5 = two keypoints per wave (k_klt_track2) */
+  int32_t st_two_kernels;      /* 1: Sobel + row sums and column sums + eigenvalue as two kernels at block size 31 too (rule: fused) */
+  int32_t st_band_rows;        /* rows per band of the fused eigenvalue kernel */
+  int32_t st_separate_nms;     /* 1: eigenvalue map through HBM to a separate non-maximum-suppression kernel */
+  int32_t st_keep_eig;         /* 1: resident launches keep the eigenvalue map and the mask (vo_shi_tomasi_read after them) */
+  int32_t st_host_limit;       /* 1: closed loop: the corner limit of a sequence is not read on the device */
+  int32_t xcd_remap_off;       /* 1: plain (block, sequence) order instead of one sequence per XCD */
+  int32_t gate_groups;         /* stream layout 2: LM launch groups of frame t ahead of the tracker launch of frame t + 1; -1: none */
+  int32_t reserve_cus;         /* stream layout 2: compute units the front-end stream leaves free; -1: none */
+  int32_t reserved[14];
+} vo_tuning;
+int32_t vo_get_tuning(vo_ctx* ctx, vo_tuning* out);
+int32_t vo_set_tuning(vo_ctx* ctx, const vo_tuning* t);
+
 /* ---- fused per-frame step on resident data ---------------------------------------------------
  * One call enqueues the hot path of one frame in the order of Pipeline.step (src/pipeline/pipeline.py:92-167):
  * frame `frame_idx` of the uploaded sequence -> pyramid/Scharr -> KLT of the resident points -> [DLT of the
@@ -516,7 +547,7 @@ int32_t vo_frame_step_host(vo_ctx* ctx, const uint8_t* const* frames, int32_t st
 int32_t vo_host_alloc(uint64_t bytes, void** out);
 int32_t vo_host_free(void* p);
 int32_t vo_set_graph_mode(vo_ctx* ctx, int32_t on);
-/* Stream layout of vo_frame_step_resident.  0: one stream.  1 (default; environment VO_SIDE_STREAM sets the default): re-detection +
+/* Stream layout of vo_frame_step_resident.  0: one stream.  1 (default): re-detection +
  * triangulation on a side stream beside the bundle adjustment (+10-20 % for one context, +1-2 % with three).  2: pipelined, three
  * streams -- pyramid + KLT | re-detection + triangulation | bundle adjustment -- so that the bundle adjustment of frame t also runs
  * beside the front end of frame t + 1 when two steps are in flight (ONE sequence: 3 600 -> 4 500 frames/s; three batched contexts lose
@@ -526,7 +557,7 @@ int32_t vo_set_graph_mode(vo_ctx* ctx, int32_t on);
  * enqueued behind the first `gate_groups` LM launch groups of frame t -- the groups in which (nearly) all problems still run get the whole
  * chip -- and (b) the ctx stream is re-created as a queue that leaves `reserved_cus` compute units free (one per shader engine and XCD), on
  * which the chain's narrow tail groups run beside the tracker.  +4 % at 256 sequences, +10-14 % at 8-192; a longer LM budget costs (almost)
- * nothing more.  vo_step_layout reports what is in effect; environment VO_BA_WIDE_GROUPS / VO_FE_RESERVE_CUS override (0 = off).  Graph
+ * nothing more.  vo_step_layout reports what is in effect; vo_tuning.gate_groups / reserve_cus force other values.  Graph
  * replay and vo_pipe_step run on the plain, unmasked stream. */
 int32_t vo_set_side_stream(vo_ctx* ctx, int32_t on);
 int32_t vo_step_layout(vo_ctx* ctx, int32_t* layout, int32_t* gate_groups, int32_t* reserved_cus);

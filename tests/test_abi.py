@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libvo_mi355x.so does not export %s" % n
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert _lib.load().vo_abi_version() == 3
+    assert _lib.load().vo_abi_version() == 4
 
 
 def test_struct_layouts_match_header():
@@ -43,6 +43,21 @@ def test_struct_layouts_match_header():
     assert s.use_harris == 0 and s.harris_k == 0.04          # the reference never turns the Harris response on (extractor.py:21-24)
     b = _lib.BaParams(); L.vo_ba_default_params(ctypes.byref(b))
     assert b.ftol == 1e-3 and b.xtol == 1e-3 and b.huber_delta == 1.0
+
+
+def test_the_library_reads_no_tuning_from_the_environment():
+    """rounds 1-5 shipped 23 getenv switches; forced forms now go through vo_set_tuning.  What is left: VO_BLOCKING_SYNC (how a host thread
+    waits) and the VO_STEP_TRACE debug trace."""
+    src = os.path.join(ROOT, "visual-odom-pipeline_amd", "csrc")
+    found = []
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".hip", ".h")):
+            found += re.findall(r'getenv\("([A-Z_0-9]+)"\)', open(os.path.join(src, f)).read())
+    assert sorted(set(found)) == ["VO_BLOCKING_SYNC", "VO_STEP_TRACE"], found
+    from vo_mi355x import _lib
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "vo_mi355x.h")).read(), flags=re.S)
+    body = re.search(r"typedef struct \{([^}]*)\} vo_tuning;", hdr).group(1)
+    assert tuple(re.findall(r"int32_t\s+(\w+);", body)) == _lib.TUNING_FIELDS
 
 
 def test_no_cpu_fallback_without_a_device():
@@ -100,7 +115,8 @@ def test_ctypes_mirrors_have_the_c_structs_sizes(tmp_path):
     if cc is None:
         pytest.skip("no host C compiler")
     pairs = [("vo_pipe_record", _lib.PipeRecord), ("vo_pipe_params", _lib.PipeParams), ("vo_klt_params", _lib.KltParams), ("vo_st_params", _lib.StParams),
-             ("vo_ba_params", _lib.BaParams), ("vo_ba_stats", _lib.BaStats), ("vo_pnp_params", _lib.PnpParams), ("vo_pnp_stats", _lib.PnpStats)]
+             ("vo_ba_params", _lib.BaParams), ("vo_ba_stats", _lib.BaStats), ("vo_pnp_params", _lib.PnpParams), ("vo_pnp_stats", _lib.PnpStats),
+             ("vo_tuning", _lib.Tuning)]
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "vo_mi355x.h"\nint main(void) { printf("%s\\n", %s); return 0; }\n' % (
         " ".join(["%zu"] * len(pairs)), ", ".join("sizeof(%s)" % n for n, _ in pairs)))

@@ -16,11 +16,14 @@ def _load(path):
 
 
 @pytest.fixture(autouse=True, params=["wave_private", "lane_per_observation"])
-def ba_kernels(request, monkeypatch):
+def ba_kernels(request, monkeypatch, ctx):
     """every test of this module runs through BOTH kernel families: the wave-private build / update (csrc/vo_ba_wave.h: what a batched context
-    runs for windows <= 10) and the lane-per-observation ones (windows of 11-20 slots; VO_BA_V2=0 selects them for every window).  VO_BA_V2 is
-    read at every upload."""
-    monkeypatch.setenv("VO_BA_V2", "1" if request.param == "wave_private" else "0")
+    runs for windows <= 10) and the lane-per-observation ones (windows of 11-20 slots; vo_tuning.ba_kernels = 1 selects them for every window).
+    The field takes effect at every upload: set on the module's shared context and as the default of every context a test makes."""
+    from vo_mi355x import VoContext
+    fam = 2 if request.param == "wave_private" else 1
+    monkeypatch.setattr(VoContext, "default_tuning", {"ba_kernels": fam})
+    ctx.set_tuning(ba_kernels=fam)
     return request.param
 
 
@@ -199,7 +202,7 @@ def test_ba_bank_select_equals_individual_uploads():
 
 def test_ba_chunked_partial_sets_match_one_chunk_per_workgroup(monkeypatch):
     """The headline batch (32 x 125 landmark chunks) makes a workgroup of k_ba_build walk up to 4 chunks and ADD their partial sums into
-    one set; a single problem keeps one chunk per workgroup.  VO_BA_CHUNKS forces either form: same LM iteration / acceptance sequence,
+    one set; a single problem keeps one chunk per workgroup.  vo_tuning.ba_chunks forces either form: same LM iteration / acceptance sequence,
     cost and solution to 1e-12 (the summation order differs, so not bit for bit), also for the last, partly filled workgroup
     (125 chunks = 31 x 4 + 1), and equal to the oracle."""
     import ba_oracle as bo
@@ -209,9 +212,9 @@ def test_ba_chunked_partial_sets_match_one_chunk_per_workgroup(monkeypatch):
     out = {}
     with VoContext(64, 64, max_pts=64) as c:
         for cpw in (1, 2, 4, 3):
-            monkeypatch.setenv("VO_BA_CHUNKS", str(cpw))
+            c.set_tuning(ba_chunks=cpw)
             out[cpw] = c.ba_adjust(s["K"], s["poses0"], s["points0"], s["obs"], c.ba_params(max_iters=12))
-        monkeypatch.delenv("VO_BA_CHUNKS")
+        c.set_tuning(ba_chunks=0)
         out[0] = c.ba_adjust(s["K"], s["poses0"], s["points0"], s["obs"], c.ba_params(max_iters=12))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])          # the rule: one chunk per workgroup for one problem
     for cpw in (2, 3, 4):
@@ -224,20 +227,17 @@ def test_ba_chunked_partial_sets_match_one_chunk_per_workgroup(monkeypatch):
 @pytest.mark.parametrize("W,n_pts", [(4, 2000), (8, 1000), (3, 333), (5, 700)])
 def test_ba_eight_lanes_per_landmark_matches_oracle_and_the_sixteen_lane_form(monkeypatch, W, n_pts):
     """Windows of <= 8 slots run k_ba_build<256, 8> / k_ba_update<256, 8> (a landmark owns 8 lanes, 32 landmarks per 256-lane workgroup);
-    VO_BA_LPP8=0 forces the 16-lane form.  Same LM iteration / acceptance sequence, cost and solution to 1e-10 between the two (the summation
-    order differs), equal to the oracle; also with a workgroup walking several landmark chunks (VO_BA_CHUNKS) and N not a multiple of 32."""
+    vo_tuning.ba_lanes = 16 forces the 16-lane form.  Same LM iteration / acceptance sequence, cost and solution to 1e-10 between the two (the summation
+    order differs), equal to the oracle; also with a workgroup walking several landmark chunks (vo_tuning.ba_chunks) and N not a multiple of 32."""
     import ba_oracle as bo
     from vo_mi355x import VoContext, synthetic as syn
     s = syn.make_ba_scene(n_pts=n_pts, n_slots=W, seed=10 + W, visibility=0.85)
     ref = bo.solve(s["K"], s["poses0"], s["points0"], s["obs"], max_iters=12)
     out = {}
-    for key, env in (("l8", {}), ("l16", {"VO_BA_LPP8": "0"}), ("l8c3", {"VO_BA_CHUNKS": "3"})):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for key, tune in (("l8", {}), ("l16", {"ba_lanes": 16}), ("l8c3", {"ba_chunks": 3})):
         with VoContext(64, 64, max_pts=64) as c:          # (the lane count is fixed when the workspace is built: a fresh context per form)
+            c.set_tuning(**tune)
             out[key] = c.ba_adjust(s["K"], s["poses0"], s["points0"], s["obs"], c.ba_params(max_iters=12))
-        for k in env:
-            monkeypatch.delenv(k)
     for key in ("l8", "l16", "l8c3"):
         po, pt, st = out[key]
         assert st["iters"] == ref["iters"] and st["accepted"] == ref["accepted"], (key, st, ref["iters"], ref["accepted"])

@@ -10,25 +10,22 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("W,n_pts", [(2, 130), (4, 1001), (5, 700), (7, 333), (8, 1000), (9, 500), (10, 2000), (10, 611)])
 def test_ba_wave_private_lane_maps_and_workgroup_counts(monkeypatch, W, n_pts):
     """csrc/vo_ba_wave.h: every lane map (4 lanes per landmark up to W = 4, 8 up to W = 8, 5 at W = 9 and 10 -- and 8 lanes with two slot passes,
-    VO_BA_LPP5=0), every panel width (1-4 column blocks), landmark counts that leave the last chunk partly filled, and workgroup counts from ONE
-    (a wave walks every fourth chunk) to one chunk per wave (VO_BA_G): same LM iteration / acceptance sequence and cost as the oracle, solutions
+    vo_tuning.ba_lanes = 8), every panel width (1-4 column blocks), landmark counts that leave the last chunk partly filled, and workgroup counts from ONE
+    (a wave walks every fourth chunk) to one chunk per wave (vo_tuning.ba_workgroups): same LM iteration / acceptance sequence and cost as the oracle, solutions
     equal to 1e-9 between the forms (their summation orders differ)."""
     import ba_oracle as bo
     from vo_mi355x import VoContext, synthetic as syn
-    monkeypatch.setenv("VO_BA_V2", "1")      # (a context of ONE sequence with a window of 9-10 slots takes the lane-per-observation kernels by default)
+    monkeypatch.setattr(VoContext, "default_tuning", {"ba_kernels": 2})   # (ONE sequence with a window of 9-10 slots takes the lane-per-observation kernels by default)
     s = syn.make_ba_scene(n_pts=n_pts, n_slots=W, seed=20 + W, visibility=0.85)
     ref = bo.solve(s["K"], s["poses0"], s["points0"], s["obs"], max_iters=12)
     out = {}
-    forms = [("rule", {}), ("g1", {"VO_BA_G": "1"}), ("g3", {"VO_BA_G": "3"}), ("g999", {"VO_BA_G": "999"})]
+    forms = [("rule", {}), ("g1", {"ba_workgroups": 1}), ("g3", {"ba_workgroups": 3}), ("g999", {"ba_workgroups": 999})]
     if W >= 9:
-        forms.append(("lpp8", {"VO_BA_LPP5": "0"}))
-    for key, env in forms:
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+        forms.append(("lpp8", {"ba_lanes": 8}))
+    for key, tune in forms:
         with VoContext(64, 64, max_pts=64) as c:
+            c.set_tuning(**tune)
             out[key] = c.ba_adjust(s["K"], s["poses0"], s["points0"], s["obs"], c.ba_params(max_iters=12))
-        for k in env:
-            monkeypatch.delenv(k)
     for key, (po, pt, st) in out.items():
         assert st["iters"] == ref["iters"] and st["accepted"] == ref["accepted"] and st["status"] == ref["status"], (key, st, ref["iters"])
         assert abs(st["cost"] - ref["cost"]) <= 1e-7 * ref["cost"], (key, st["cost"], ref["cost"])
@@ -42,7 +39,7 @@ def test_ba_running_problem_compaction(monkeypatch):
     then folded in another order, nothing else may change: every problem = the same problem solved alone (iterations, acceptance sequence,
     status; cost 1e-10; poses 1e-9, points 1e-6 of their distance), and the easy ones really did finish early."""
     from vo_mi355x import VoContext, synthetic as syn
-    monkeypatch.setenv("VO_BA_V2", "1")      # (the single context below would take the lane-per-observation kernels otherwise)
+    monkeypatch.setattr(VoContext, "default_tuning", {"ba_kernels": 2})   # (the single context below would take the lane-per-observation kernels otherwise)
     B, N, W = 64, 800, 10
     sc = []
     for b in range(B):

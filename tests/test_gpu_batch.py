@@ -82,11 +82,9 @@ def test_batched_context_equals_single_contexts(B):
                 assert got["ba_stats"][b]["cost"] == r["ba_stats"]["cost"]
                 assert np.array_equal(got["corners"][b], r["corners"])
         # the same steps again in the pipelined stream layout with two steps in flight (strided result copies of a batch)
-        os.environ["VO_BA_WIDE_GROUPS"], os.environ["VO_FE_RESERVE_CUS"] = "3", "32"      # (the gate + CU mask a batch of >= 8 gets by default)
-        try:
-            c.set_side_stream("pipeline")
-        finally:
-            del os.environ["VO_BA_WIDE_GROUPS"], os.environ["VO_FE_RESERVE_CUS"]
+        c.set_tuning(gate_groups=3, reserve_cus=32)       # (the gate + CU mask a batch of >= 8 gets by default)
+        c.set_side_stream("pipeline")
+        assert c.step_layout() == {"layout": 2, "gate_groups": 3, "reserved_cus": 32}
         c.points_upload(np.stack(pts))
         c.push_frame_resident(0)
         order = (1, 2, 3, 2)

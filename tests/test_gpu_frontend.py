@@ -279,21 +279,27 @@ def test_dlt_vs_oracle_and_ground_truth(golden_dir):
     assert all(border[i] or abs(g["depth1"][i]) < 1e-3 for i in sym)
 
 
-def test_klt_two_keypoints_per_wave_is_bit_identical(ctx_big, seq3, monkeypatch):
-    """k_klt_track2 (experiment, VO_KLT_PAIR): the two halves of a wave track one keypoint each and share the lane-uniform work.  Same
-    integer sums and float expressions -> the same bits as the shipped kernel, for an odd point count, points at and beyond the borders
-    and a truncated iteration budget (it is slower -- profiles/r03_klt_pair_counters.txt -- and stays opt-in)"""
-    from vo_mi355x import synthetic as syn
+def test_klt_two_keypoints_per_wave_is_bit_identical(ctx_big, seq3):
+    """k_klt_track2 (experiment: compiled with -DVO_EXPERIMENTS only, vo_tuning.klt_pair): the two halves of a wave track one keypoint each and share
+    the lane-uniform work.  Same integer sums and float expressions -> the same bits as the shipped kernel, for an odd point count, points at and
+    beyond the borders and a truncated iteration budget (it is slower -- profiles/r03_klt_pair_counters.txt -- and is not in the shipped library)"""
+    from vo_mi355x import VoError, synthetic as syn
+    try:
+        ctx_big.set_tuning(klt_pair=3)
+    except VoError:
+        pytest.skip("the library was built without -DVO_EXPERIMENTS (the default): k_klt_track2 is not in it")
     frames, _ = seq3
     p0 = syn.grid_points(1999, 1241, 376, seed=5)
     p0[::97] = [-40.0, 10.0]; p0[1::131] = [1300.0, 400.0]; p0[2::211] = [620.5, -31.5]
     p0[5] = [1239.7, 374.2]; p0[6] = [-31.0, -31.0]; p0[7] = [3.25, 370.9]
-    for prm in (None, ctx_big.klt_params(max_count=2), ctx_big.klt_params(win=21, max_level=2)):
-        monkeypatch.delenv("VO_KLT_PAIR", raising=False)
-        a = ctx_big.klt_track(p0, prm, return_iters=True)
-        for mode in ("3", "4"):
-            monkeypatch.setenv("VO_KLT_PAIR", mode)
-            b = ctx_big.klt_track(p0, prm, return_iters=True)
-            for x, y in zip(a, b):
-                assert np.array_equal(x, y, equal_nan=True)
-    monkeypatch.delenv("VO_KLT_PAIR", raising=False)
+    try:
+        for prm in (None, ctx_big.klt_params(max_count=2), ctx_big.klt_params(win=21, max_level=2)):
+            ctx_big.set_tuning(klt_pair=0)
+            a = ctx_big.klt_track(p0, prm, return_iters=True)
+            for mode in (3, 4):
+                ctx_big.set_tuning(klt_pair=mode)
+                b = ctx_big.klt_track(p0, prm, return_iters=True)
+                for x, y in zip(a, b):
+                    assert np.array_equal(x, y, equal_nan=True)
+    finally:
+        ctx_big.set_tuning(klt_pair=0)

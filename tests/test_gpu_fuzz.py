@@ -93,16 +93,13 @@ def test_ba_fuzz(n_pts, n_slots, seed, vis, noise):
         obs[rng.integers(0, n_slots)] = np.nan                       # a frame that sees nothing
     if np.isfinite(obs[..., 0]).sum() < 1:
         return
-    # both kernel families (VO_BA_V2 is read at every upload): the wave-private build / update of windows <= 10 -- every lane map (4, 8 and 5
+    # both kernel families (vo_tuning.ba_kernels): the wave-private build / update of windows <= 10 -- every lane map (4, 8 and 5
     # lanes per landmark), every panel width -- on even seeds, the lane-per-observation kernels (windows of 11-20 slots; here forced for every window) on odd ones
-    os.environ["VO_BA_V2"] = "1" if seed % 2 == 0 else "0"
-    try:
-        with VoContext(64, 64, max_pts=64) as c:
-            c.ba_upload(s["K"], s["poses0"], s["points0"], obs)
-            pr = c.ba_probe(lam=1e-3)
-            po, pt, stt = c.ba_adjust(s["K"], s["poses0"], s["points0"], obs, c.ba_params(max_iters=8))
-    finally:
-        del os.environ["VO_BA_V2"]
+    with VoContext(64, 64, max_pts=64) as c:
+        c.set_tuning(ba_kernels=2 if seed % 2 == 0 else 1)
+        c.ba_upload(s["K"], s["poses0"], s["points0"], obs)
+        pr = c.ba_probe(lam=1e-3)
+        po, pt, stt = c.ba_adjust(s["K"], s["poses0"], s["points0"], obs, c.ba_params(max_iters=8))
     ne = bo.normal_equations(s["K"], s["poses0"], s["points0"], obs)
     rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
     assert rel(pr["Hpp"], ne["Hpp"]) <= 1e-9 and rel(pr["Hll"], ne["Hll"]) <= 1e-9 and rel(pr["gp"], ne["gp"]) <= 1e-9
@@ -308,7 +305,7 @@ def test_sift_fuzz(w, h, kind, seed, nfeatures):
        st.sampled_from([1, 2, 5]))
 def test_shi_tomasi_fused_kernel_fuzz(w, h, kind, seed, rb, batch):
     """block size 31 goes through k_st_eig_fused: image widths across 1..4 column strips, every band height (the launch picks
-    it from the batch size; VO_ST_RB forces it here), batches -- eigenvalue map, mask, candidates and corners bit-exact"""
+    it from the batch size; vo_tuning.st_band_rows forces it here), batches -- eigenvalue map, mask, candidates and corners bit-exact"""
     import os
     import vo_oracle as o
     from vo_mi355x import VoContext
@@ -316,21 +313,17 @@ def test_shi_tomasi_fused_kernel_fuzz(w, h, kind, seed, rb, batch):
     imgs = [_image(rng, w, h, (kind + b) % 4) for b in range(batch)]
     n = int(rng.integers(0, 60))
     pts = np.stack([rng.uniform(-5, w + 5, (batch, n)), rng.uniform(-5, h + 5, (batch, n))], 2).astype(np.float32)
-    if rb:
-        os.environ["VO_ST_RB"] = str(rb)
-    try:
-        with VoContext(w, h, max_pts=128, batch=batch) as c:
-            prm = c.st_params(max_corners=300, quality_level=0.03, min_distance=7.0, block_size=31)
-            if batch == 1:
-                c.push_frame(imgs[0])
-                corners = [c.shi_tomasi(pts[0] if n else None, 7, params=prm)]
-                eig, mask, nc = (x[None] if isinstance(x, np.ndarray) else np.array([x]) for x in c.shi_tomasi_read())
-            else:
-                c.push_frame(np.stack(imgs))
-                corners = c.shi_tomasi(pts if n else None, 7, params=prm)
-                eig, mask, nc = c.shi_tomasi_read()
-    finally:
-        os.environ.pop("VO_ST_RB", None)
+    with VoContext(w, h, max_pts=128, batch=batch) as c:
+        c.set_tuning(st_band_rows=int(rb or 0))
+        prm = c.st_params(max_corners=300, quality_level=0.03, min_distance=7.0, block_size=31)
+        if batch == 1:
+            c.push_frame(imgs[0])
+            corners = [c.shi_tomasi(pts[0] if n else None, 7, params=prm)]
+            eig, mask, nc = (x[None] if isinstance(x, np.ndarray) else np.array([x]) for x in c.shi_tomasi_read())
+        else:
+            c.push_frame(np.stack(imgs))
+            corners = c.shi_tomasi(pts if n else None, 7, params=prm)
+            eig, mask, nc = c.shi_tomasi_read()
     for b in range(batch):
         m = np.full((h, w), 255, np.uint8)
         for x, y in np.int32(pts[b]):

@@ -416,7 +416,7 @@ def test_side_stream_layout_equals_one_stream_with_steps_in_flight():
 def test_device_side_corner_limit_gives_the_same_corners(monkeypatch):
     """In the closed loop the re-detection can use at most (free slots of the table + 1) corners of a sequence; k_st_select then consumes the
     candidate list in short rank-ordered chunks (radix select of the strongest 512 ...) instead of sorting all ~1 600 candidates of a full-size
-    frame.  Same corners, same records, same tables as with the limit switched off (VO_ST_DEV_LIMIT=0), from an empty-ish table that takes
+    frame.  Same corners, same records, same tables as with the limit switched off (vo_tuning.st_host_limit), from an empty-ish table that takes
     hundreds of corners per frame to the full table that takes a handful."""
     from vo_mi355x.resident import ResidentPipeline
     w, h, t1, n = 1241, 376, 4, 10
@@ -424,9 +424,9 @@ def test_device_side_corner_limit_gives_the_same_corners(monkeypatch):
     boot = _ctx(w, h, max_pts=4096)
     states = [ph.gt_bootstrap(boot, sc, 0, t1)[0] for sc in scs]
     runs = []
-    for lim in ("1", "0"):
-        monkeypatch.setenv("VO_ST_DEV_LIMIT", lim)
+    for host_limit in (0, 1):
         c = _ctx(w, h, max_pts=1500, batch=2)              # 1 500 slots: the bootstrap fills ~1 000, the table is full after a few frames
+        c.set_tuning(st_host_limit=host_limit)
         c.upload_sequence(np.stack([sc["frames"] for sc in scs]))
         rp = ResidentPipeline(c, np.stack([sc["K"] for sc in scs]), ba_window=4, ba_max_iters=10)
         rp.seed([copy.deepcopy(s) for s in states], None, None, 1)
@@ -435,7 +435,6 @@ def test_device_side_corner_limit_gives_the_same_corners(monkeypatch):
         for s in range(n):
             rp.step(t1 + 1 + s); recs.append(rp.fetch())
         runs.append((recs, rp.read_tables()))
-    monkeypatch.delenv("VO_ST_DEV_LIMIT")
     (ra, Ta), (rb, Tb) = runs
     dets = [ra[s][b]["n_detected"] for s in range(n) for b in range(2)]
     assert max(dets) >= 100 and min(dets) <= 40, dets      # both regimes were visited

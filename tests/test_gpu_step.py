@@ -64,10 +64,10 @@ def test_two_steps_in_flight_match_one_at_a_time(layout, monkeypatch):
     KLT of frame t + 1 (vo_set_side_stream(ctx, 2)); "pipeline_gated": the form a batch of >= 8 sequences gets by default, forced here on one
     sequence -- the tracker launch of frame t + 1 waits for the first 2 LM groups of frame t, stream A leaves 32 compute units free"""
     gated = layout == "pipeline_gated"
-    if gated:
-        monkeypatch.setenv("VO_BA_WIDE_GROUPS", "2"); monkeypatch.setenv("VO_FE_RESERVE_CUS", "32")
-        layout = "pipeline"
     from vo_mi355x import VoContext, VoError, synthetic as syn
+    if gated:
+        monkeypatch.setattr(VoContext, "default_tuning", {"gate_groups": 2, "reserve_cus": 32})
+        layout = "pipeline"
     w, h, n, n_new = 640, 240, 600, 200
     frames, _ = syn.make_sequence(5, w=w, h=h, seed=23, margin=64)
     pts = syn.grid_points(n, w, h, seed=5)
@@ -223,8 +223,8 @@ def test_gated_layout_with_steps_that_skip_the_adjustment(monkeypatch):
     with VoContext(w, h, max_pts=1024) as c:
         c.set_side_stream(False)
         ref = run(c, 1)
-    monkeypatch.setenv("VO_BA_WIDE_GROUPS", "3"); monkeypatch.setenv("VO_FE_RESERVE_CUS", "32")
     with VoContext(w, h, max_pts=1024) as c:
+        c.set_tuning(gate_groups=3, reserve_cus=32)
         c.set_side_stream("pipeline")
         assert c.step_layout()["gate_groups"] == 3
         got = run(c, 2)

@@ -3,7 +3,7 @@
 #   tools/ba_groups.sh [tag] [seqs]
 TAG=${1:-g}; SEQS=${2:-256}
 OUT=$PWD/gpurun_out
-export TMPDIR=/tmp VO_SIDE_STREAM=0
+export TMPDIR=/tmp
 BENCH="$PWD/bench.py"
 cd /tmp; rm -rf $OUT/${TAG}_grp
 rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_grp -o ks -- python3 $BENCH --steps 20 --warmup 5 --regions 1 --no-extras --seqs $SEQS --ctxs 1 --host-threads 1 --side-stream off --no-cpu-baseline > $OUT/${TAG}_grp.log 2>&1

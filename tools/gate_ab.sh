@@ -1,8 +1,8 @@
 #!/bin/bash
-# A/B: the next frame's tracker launch gated behind the first K LM groups of the previous frame's chain (VO_BA_WIDE_GROUPS), stream A leaving R
-# compute units free (VO_FE_RESERVE_CUS).  usage: tools/gate_ab.sh
+# A/B: the next frame's tracker launch gated behind the first K LM groups of the previous frame's chain (vo_tuning.gate_groups), stream A leaving R
+# compute units free (vo_tuning.reserve_cus).  usage: tools/gate_ab.sh
 run() {
-  out=$(env "$@" timeout 150 python bench.py --no-extras --no-cpu-baseline --steps 60 $EXTRA 2>/dev/null | tail -1)
+  out=$(timeout 150 python bench.py --no-extras --no-cpu-baseline --full-line --steps 60 $EXTRA ${1:+--tune $1} 2>/dev/null | tail -1)
   python - "$out" "$* $EXTRA" <<'P'
 import json, sys
 try:
@@ -13,7 +13,7 @@ P
 }
 for seqs in 1 8 16 32; do
   EXTRA="--ba-iters 30 --seqs $seqs --steps 200"
-  run X=0
-  run VO_BA_WIDE_GROUPS=5 VO_FE_RESERVE_CUS=32
-  run VO_BA_WIDE_GROUPS=5
+  run ""
+  run gate_groups=5,reserve_cus=32
+  run gate_groups=5,reserve_cus=-1
 done

@@ -3,7 +3,7 @@
 #   tools/kstats256.sh [tag]      -> gpurun_out/<tag>_kstats256.txt
 TAG=${1:-k}
 OUT=$PWD/gpurun_out
-export TMPDIR=/tmp VO_SIDE_STREAM=0
+export TMPDIR=/tmp
 BENCH="$PWD/bench.py"
 cd /tmp
 rm -rf $OUT/${TAG}_ks256

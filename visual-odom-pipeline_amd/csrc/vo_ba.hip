@@ -1303,39 +1303,38 @@ extern "C" int32_t vo_ba_default_params(vo_ba_params* p) {
   return VO_OK;
 }
 
-static void ba_geometry(vo_ba_ws* b, int W, int N) {
+static void ba_geometry(vo_ba_ws* b, int W, int N, const vo_tuning& tn) {
   b->W = W; b->N = N;
   b->LPP = (W <= 8) ? 8 : (W <= 16) ? 16 : 32;
-  if (const char* e = getenv("VO_BA_LPP8")) { if (atoi(e) == 0 && b->LPP == 8) b->LPP = 16; }      // A/B knob
+  if (tn.ba_lanes == 16 && b->LPP == 8) b->LPP = 16;                                              // (vo_tuning: A/B)
   // workgroup size: 256 lanes (more workgroups -> more CUs, less contention on the f64 pipes) unless that would
   // produce more than 160 partial sets, then 1024
   // (8-lane groups -- windows of <= 8 slots -- keep 256 lanes whatever N: with 1 024-lane workgroups they fell back to 16 lanes per landmark,
   //  three quarters of them idle at the reference's window of 4; the chunk walk of k_ba_build bounds the partial sets instead.  Measured on the
   //  closed loop's 8 192-slot tables: k_ba_build 78 us -> see DESIGN section 4)
   b->tpb = (b->LPP == 8 || vo_div_up(N, 256 / b->LPP) <= 160) ? 256 : 1024;
-  if (const char* e = getenv("VO_BA_TPB")) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) b->tpb = t; }   // experiment knob
+  if (tn.ba_threads == 256 || tn.ba_threads == 512 || tn.ba_threads == 1024) b->tpb = tn.ba_threads;                    // (vo_tuning)
   if (b->LPP == 8 && b->tpb != 256) { b->LPP = 16; b->tpb = (vo_div_up(N, 256 / b->LPP) <= 160) ? 256 : 1024; }          // (8-lane groups exist for 256-lane workgroups only)
   b->PPB = b->tpb / b->LPP;
   b->nblk = vo_div_up(N, b->PPB);
   b->RP = ((6 * W + 1 + 15) / 16) * 16; b->RT = b->RP / 16; b->n_tiles = b->RT * (b->RT + 1) / 2;
   b->pitch = b->RP + BA_PITCH_PAD;
-  if (const char* e = getenv("VO_BA_PAD")) b->pitch = b->RP + atoi(e);      // experiment knob
+  if (tn.ba_pitch_pad > 0) b->pitch = b->RP + tn.ba_pitch_pad - 1;           // (vo_tuning)
   const size_t panel = sizeof(double) * (size_t)3 * b->PPB * b->pitch;
   const size_t scratch = sizeof(double) * (size_t)(b->tpb / 64) * b->LPP * BA_POSE_VALS;
   b->build_lds = panel > scratch ? panel : scratch;
   b->cam_off = (int)(b->build_lds / sizeof(double));
   b->build_lds += sizeof(double) * (size_t)BA_CAM * W;
-  // wave-private kernels: RT column blocks (6 W + 1 <= 16 RT <= 64), a lane serves SPL = ceil(W / 8) slots.  VO_BA_V2=0: the older kernels (A/B knob)
-  b->v2 = (W <= 10) ? 1 : 0;
-  if (const char* e = getenv("VO_BA_V2")) b->v2 = (W <= 10 && atoi(e) != 0) ? 1 : 0;
+  // wave-private kernels: RT column blocks (6 W + 1 <= 16 RT <= 64), a lane serves SPL = ceil(W / 8) slots.  vo_tuning.ba_kernels = 1: the older kernels
+  b->v2 = (W <= 10 && tn.ba_kernels != 1) ? 1 : 0;
   // (one problem alone is the one shape the older kernels still win: build 12 against 16 us per iteration -- a wave-private workgroup spends
   //  ~7 us on its LM decision, camera staging and the four-wave fold of its tiles whatever it walks; 18 against 17 at four problems, 65 against
   //  49 at 32: ba_alloc switches contexts of one or two sequences with windows of 9-10 slots back to them)
   b->v2_rt = b->RT; b->v2_spl = (W + 7) / 8;
-  // windows of 9 and 10 slots: 5 lanes per landmark (12 landmarks per wave), else 8 (VO_BA_LPP5=0: 8 for every window, A/B knob)
+  // windows of 9 and 10 slots: 5 lanes per landmark (12 landmarks per wave), else 8 (vo_tuning.ba_lanes = 8: 8 for every window, A/B)
   // and 4 for windows of <= 4 slots (16 landmarks per wave)
   b->v2_lpp = (b->v2_spl == 2) ? 5 : (W <= 4) ? 4 : 8;
-  if (const char* e = getenv("VO_BA_LPP5")) { if (atoi(e) == 0) b->v2_lpp = 8; }
+  if (tn.ba_lanes == 8 && b->v2_lpp == 5) b->v2_lpp = 8;
   b->v2_lds = b->v2_lpp == 5 ? sizeof(double) * ((size_t)4 * 36 * (16 * b->v2_rt) + (size_t)BA2_CAM * W)
                              : sizeof(double) * ((size_t)4 * 3 * (64 / b->v2_lpp) * (16 * b->v2_rt + 16) + (size_t)BA2_CAM * W);
   const int n1 = 6 * W + 1, PT = n1 | 1;
@@ -1351,7 +1350,7 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     // the workgroup size switches with N (ba_geometry), so a SMALLER N can need MORE partial sets than the N the
     // workspace was sized for (W = 4: N = 2600 -> 41 sets of 64 landmarks, N = 2500 -> 157 sets of 16): rebuild then
     vo_ba_ws probe;
-    ba_geometry(&probe, W, N);
+    ba_geometry(&probe, W, N, c->tune);
     if (probe.nblk > c->ba->cap_nblk) vo_ba_destroy(c);
   }
   const size_t B = (size_t)c->batch;
@@ -1359,7 +1358,7 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     vo_ba_ws* b = new vo_ba_ws();
     c->ba = b;
     b->cap_W = W; b->cap_N = N;
-    ba_geometry(b, W, N);
+    ba_geometry(b, W, N, c->tune);
     // any N' <= N runs with 256-lane workgroups when that gives <= 160 sets, else with the 1024-lane ones of N at most
     {
       const int small = vo_div_up(N, 256 / b->LPP);
@@ -1405,13 +1404,13 @@ static int32_t ba_alloc(vo_ctx* c, int W, int N) {
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build_w<4, 2, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build_w<2, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   }
-  ba_geometry(c->ba, W, N);
+  ba_geometry(c->ba, W, N, c->tune);
   if (c->batch > 1024) c->ba->v2 = 0;             // (ba2_select_work keeps the running-problem flags of <= 1 024 problems in LDS)
   // one or two problems with BASELINE's window: the lane-per-observation kernels spread a problem over 125 workgroups of 1 024 lanes, the
   // wave-private ones over 42 of 256 -- 3 430 against 3 260 frames/s for ONE sequence, 6 180 against 5 930 for two, even at three, behind from
   // four on (tools/one_sequence_ba_knobs.sh, profiles/r05_small_batch_ba.txt).  Windows of <= 8 slots (the closed loop's 4) are faster
   // wave-private at every batch.  The two families agree to ~1e-12, not bit for bit: like a batch of 32 against its problems one by one.
-  if (c->batch <= 2 && W >= 9 && !getenv("VO_BA_V2")) c->ba->v2 = 0;
+  if (c->batch <= 2 && W >= 9 && c->tune.ba_kernels == 0) c->ba->v2 = 0;
   VO_CHECK(c, c->ba->build_lds <= 130 * 1024 && c->ba->solve_lds <= 150 * 1024, VO_E_CAPACITY, "window too large for LDS");
   VO_CHECK(c, c->ba->nblk <= 640, VO_E_CAPACITY, "too many landmarks for one adjust (raise the partial capacity)");
   return VO_OK;
@@ -1472,11 +1471,10 @@ static ba_ptrs ba_make_ptrs(const vo_ctx* c) {
   {
     // landmark chunks per workgroup: as many as keep >= 1024 workgroups (4 per CU, what the kernel's registers allow) in the launch,
     // at most 4 -- a batch of 32 problems x 125 chunks -> 32 workgroups per problem; ONE sequence keeps a workgroup per chunk
-    // VO_BA_CHUNKS (read at every solve, so a test can switch it): chunks per workgroup, 0 / unset = the rule.  NB the partial sums of a
+    // vo_tuning.ba_chunks (read at every solve, so a test can switch it): chunks per workgroup, 0 = the rule.  NB the partial sums of a
     // workgroup's chunks are added in chunk order, so the last bits of a solution depend on this number -- and through the rule on the
     // batch size: a batch of 32 problems is not bit-identical to the same problems solved one by one (tests/test_gpu_ba.py pins 1e-12)
-    const char* cpw_s = getenv("VO_BA_CHUNKS");
-    const int cpw_env = cpw_s ? atoi(cpw_s) : 0;
+    const int cpw_env = c->tune.ba_chunks;
     int cpw = cpw_env > 0 ? cpw_env : (int)(((long long)c->batch * b->nblk + 512) / 1024);
     if (cpw < 1) cpw = 1;
     if (cpw > 4 && cpw_env <= 0) cpw = 4;
@@ -1485,19 +1483,19 @@ static ba_ptrs ba_make_ptrs(const vo_ctx* c) {
   P.n_eval = b->nblk;
   if (b->v2) {
     // G workgroups (4 waves each) per problem: enough for BA2_TARGET_WAVES waves in the launch, at most one chunk (8 landmarks) per wave.
-    // VO_BA_G overrides (experiment knob).  The partial sums depend on G like the older kernels' on the chunks per workgroup.
+    // vo_tuning.ba_workgroups overrides.  The partial sums depend on G like the older kernels' on the chunks per workgroup.
     const int nchunk = vo_div_up(b->N, b->v2_lpp == 5 ? 12 : 64 / b->v2_lpp), gmax = vo_div_up(nchunk, 4);
     int G = vo_div_up(BA2_TARGET_WAVES, 4 * c->batch);
-    if (const char* e = getenv("VO_BA_G")) { if (atoi(e) > 0) G = atoi(e); }
+    if (c->tune.ba_workgroups > 0) G = c->tune.ba_workgroups;
     if (G > gmax) G = gmax;
     // small windows, whose partial sets k_ba_solve sums itself (one value per thread): more than 16 sets make that loop the longest kernel
     // of an iteration (ONE sequence, window 4: 32 sets 3 490, 16 sets 3 580, 8 sets 3 490 frames/s through the closed loop)
-    { const int n1 = 6 * b->W + 1; if ((n1 * (n1 + 1)) / 2 + b->W * BA_POSE_VALS <= BA_SOLVE_THREADS && G > 16 && !getenv("VO_BA_G")) G = 16; }
+    { const int n1 = 6 * b->W + 1; if ((n1 * (n1 + 1)) / 2 + b->W * BA_POSE_VALS <= BA_SOLVE_THREADS && G > 16 && c->tune.ba_workgroups <= 0) G = 16; }
     if (G < 1) G = 1;
     P.nset = G; P.n_eval = G;
     // once problems of the batch have finished, a running one is given up to 16 workgroups (ba2_select_work)
     int cap = 16;
-    if (const char* e = getenv("VO_BA_GCAP")) { if (atoi(e) > 0) cap = atoi(e); }
+    if (c->tune.ba_workgroup_cap > 0) cap = c->tune.ba_workgroup_cap;
     if (cap > gmax) cap = gmax;
     if (cap < G) cap = G;
     b->v2_g0 = G; b->v2_gcap = cap;
@@ -1513,15 +1511,14 @@ static ba_ptrs ba_make_ptrs(const vo_ctx* c) {
   P.n_live = b->d_nlive; P.s_nlive = b->nlive_stride;
   {
     // the solve sums the partial sets itself when that is ONE trip per thread (lower triangle of [S rhs] + camera sums <= 1 024 values: windows
-    // of <= 6 slots; <= 32 sets) and no exchange between shards needs the reduced packet; VO_BA_FOLD = 0 / 1 overrides (A/B knob).  Measured
+    // of <= 6 slots; <= 32 sets) and no exchange between shards needs the reduced packet; vo_tuning.ba_fold = 1 / 2 overrides (A/B).  Measured
     // interleaved on one box (closed loop, window 4): 32 sequences (32 sets) 33 800 -> 35 000 frames/s, 96 sequences (16 sets) 42 200 ->
     // 42 500; ONE sequence (64 sets) 3 134 -> 3 077: worse, and at window 10 (2 171 values from 32 sets, three trips) the headline loses 4 %
     // and one sequence with 125 sets halves -- hence the rule
     const int n1 = 6 * b->W + 1;
-    const char* e = getenv("VO_BA_FOLD");
     const bool small = ((n1 * (n1 + 1)) / 2 + b->W * BA_POSE_VALS <= BA_SOLVE_THREADS && P.nset <= 32) || (b->v2 && P.nset <= 4);
     // (wave-private kernels: the rule looks at the sets of a full launch; a tail launch hands a running problem up to v2_gcap of them)
-    P.fold = (!c->ba_sharded && (e ? atoi(e) != 0 : small)) ? 1 : 0;
+    P.fold = (!c->ba_sharded && (c->tune.ba_fold ? c->tune.ba_fold == 2 : small)) ? 1 : 0;
   }
   return P;
 }

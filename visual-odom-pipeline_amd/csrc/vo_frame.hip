@@ -318,6 +318,13 @@ extern "C" int32_t vo_profile_read(vo_ctx* c, int32_t region, double* total_ms, 
 // ------------------------------------------------------------------------------------------------
 extern "C" int32_t vo_abi_version(void) { return VO_ABI_VERSION; }
 
+// the ONE environment switch of the library that is not a debug trace: how a host thread waits (a property of the process's thread / core budget,
+// not of a context's kernels)
+bool vo_blocking_sync() {
+  static const bool on = getenv("VO_BLOCKING_SYNC") && atoi(getenv("VO_BLOCKING_SYNC")) != 0;
+  return on;
+}
+
 extern "C" int32_t vo_device_count(int32_t* n) {
   if (!n) return VO_E_INVALID;
   int c = 0;
@@ -424,12 +431,11 @@ extern "C" int32_t vo_ctx_create_batched(int32_t device, int32_t width, int32_t 
   CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   CR(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
 
-  if (const char* e = getenv("VO_SIDE_STREAM")) c->side_stream = atoi(e) != 0;
   CR(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   CR(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   {
     // VO_BLOCKING_SYNC=1: vo_frame_fetch sleeps in the driver instead of spinning on the step's event (for more host threads than cores)
-    const unsigned fl = hipEventDisableTiming | ((getenv("VO_BLOCKING_SYNC") && atoi(getenv("VO_BLOCKING_SYNC"))) ? hipEventBlockingSync : 0u);
+    const unsigned fl = hipEventDisableTiming | (vo_blocking_sync() ? hipEventBlockingSync : 0u);
     CR(hipEventCreateWithFlags(&c->ev_step[0], fl));
     CR(hipEventCreateWithFlags(&c->ev_step[1], fl));
   }
@@ -502,8 +508,7 @@ int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, size_t raw_seq_str
   c->cur ^= 1;
   vo_frame& F = c->fr[c->cur];
   const int B = c->batch;
-  static const int remap_env = getenv("VO_XCD_REMAP") ? atoi(getenv("VO_XCD_REMAP")) : 1;
-  const int remap = (remap_env && B % 8 == 0) ? 1 : 0;       // every sequence's frame chain on one XCD (vo_xcd_assign)
+  const int remap = (!c->tune.xcd_remap_off && B % 8 == 0) ? 1 : 0;       // every sequence's frame chain on one XCD (vo_xcd_assign)
   {
     const vo_level& L = c->lv[0];
     dim3 grid(vo_div_up(((L.w + 2 * VO_PAD + 15) / 16) * L.ph, 256), 1, B);   // 16 columns per thread, flat (row, group) index

@@ -66,7 +66,8 @@ struct vo_ctx {
   signed char bil_dx[49], bil_dy[49];
   float bil_sw[49];
   float* d_bil_cw = nullptr;         // [256] colour weights
-  int side_stream = 1;               // env VO_SIDE_STREAM=0 keeps the frame step on one stream
+  int side_stream = 1;               // vo_set_side_stream
+  vo_tuning tune = {};               // forced forms (vo_set_tuning); all zero = the library's rules
   bool in_step = false;              // inside vo_frame_step_resident: its stage calls must not wait for the side streams (vo_quiesce_side)
   bool main_dirty = true;            // an entry point other than vo_pipe_step may have enqueued work on `stream` since the last pipe step (set by
                                      // vo_quiesce_side, which every such entry point calls): the next pipe step orders its side streams behind it
@@ -212,6 +213,7 @@ void vo_st_flags_restore(vo_ctx* c, int saved);
 // the pipelined stream layout (vo_set_side_stream 2) leaves work on streams B and C after a step: every entry point outside the
 // step / fetch pair that touches the result slab, the frame store, the BA / Shi-Tomasi / DLT / PnP workspaces waits for them first
 int32_t vo_quiesce_side(vo_ctx* c);
+bool vo_blocking_sync();             // environment VO_BLOCKING_SYNC=1: events a host thread waits on sleep in the driver instead of spinning
 int32_t vo_main_stream_reserve(vo_ctx* c, int reserve);               // the ctx stream re-created with / without a CU mask (vo_set_side_stream(c, 2) of a batch)
 hipError_t vo_stream_create(hipStream_t* st, int reserve_cus);      // reserve_cus > 0: the queue never uses the last `reserve_cus` bits of the CU mask
 int32_t vo_st_prepare(vo_ctx* c, const vo_st_params* prm);

@@ -437,8 +437,9 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track(klt_args A, const float
   }
 }
 
+#ifdef VO_EXPERIMENTS
 // ================================================================================================
-// k_klt_track2: TWO keypoints per wave (experiment, VO_KLT_PAIR=1).  Of the ~150 vector instructions of an LK iteration ~62 are the same
+// k_klt_track2: TWO keypoints per wave (experiment: compiled with -DVO_EXPERIMENTS only, selected by vo_tuning.klt_pair; slower than k_klt_track).  Of the ~150 vector instructions of an LK iteration ~62 are the same
 // for every lane (weights, solve, tests, the cross-lane sums' tails): one wave per keypoint pays them per keypoint.  Here the two halves of
 // a wave own one keypoint each -- lane = h * 32 + r * 16 + cp, a lane covers window rows 16 r + s (s = 0..15), columns 2 cp and 2 cp + 1 --
 // so the per-pixel work per keypoint is unchanged (twice the steps on half the lanes) and the lane-uniform work is issued once per PAIR.
@@ -677,6 +678,7 @@ __global__ void __launch_bounds__(64, WAVES) k_klt_track2(klt_args A, const floa
     err[pt] = st ? errv : 0.f;
   }
 }
+#endif  // VO_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -728,7 +730,7 @@ static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, size_t off
     A.lv[l].w = c->lv[l].w; A.lv[l].h = c->lv[l].h; A.lv[l].pitch = c->lv[l].pitch;
   }
   A.top = top; A.win = prm->win;
-  { static const int remap = getenv("VO_KLT_XCD_REMAP") ? atoi(getenv("VO_KLT_XCD_REMAP")) : 1; A.xcd_remap = (remap && c->batch % 8 == 0) ? 1 : 0; }
+  A.xcd_remap = (!c->tune.xcd_remap_off && c->batch % 8 == 0) ? 1 : 0;
   int mc = prm->max_count; if (mc < 0) mc = 0; if (mc > 100) mc = 100;
   double eps = prm->epsilon; if (eps < 0) eps = 0; if (eps > 10) eps = 10;
   A.max_count = mc; A.eps2 = eps * eps; A.n = n;
@@ -739,13 +741,13 @@ static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, size_t off
   c->iters_stride = A.iters_stride;
   {
     vo_prof_scope prof(c, VO_PROF_KLT);   // brackets exactly this launch (bench.py roofline figure)
-    static const int waves = getenv("VO_KLT_WAVES") ? atoi(getenv("VO_KLT_WAVES")) : 6;
+    const int waves = c->tune.klt_waves > 0 ? c->tune.klt_waves : 6;
 #define VO_KLT_LAUNCH(WV) hipLaunchKernelGGL(k_klt_track<WV>, dim3(n, c->batch), dim3(64), 0, c->stream, A,                \
                        vo_slab<const float>(c, off_in), vo_slab<float>(c, off_out), vo_slab<uint8_t>(c, c->off_status),     \
                        vo_slab<float>(c, c->off_err), c->d_iters, c->d_dbg, counts)
-    // VO_KLT_PAIR=1 (experiment): two keypoints per wave (k_klt_track2); read per launch so that a test can compare both kernels
-    const char* pair_s = getenv("VO_KLT_PAIR");
-    const int pair = pair_s ? atoi(pair_s) : 0;
+#ifdef VO_EXPERIMENTS
+    // vo_tuning.klt_pair (builds with -DVO_EXPERIMENTS): two keypoints per wave (k_klt_track2, slower); read per launch so that a test can compare both
+    const int pair = c->tune.klt_pair;
     if (pair) {
       const int npair = (n + 1) / 2;
 #define VO_KLT_LAUNCH2(WV) hipLaunchKernelGGL(k_klt_track2<WV>, dim3(npair, c->batch), dim3(64), 0, c->stream, A,            \
@@ -753,7 +755,9 @@ static int32_t klt_launch(vo_ctx* c, int n, const vo_klt_params* prm, size_t off
                        vo_slab<float>(c, c->off_err), c->d_iters, counts)
       if (pair == 3) VO_KLT_LAUNCH2(3); else if (pair == 5) VO_KLT_LAUNCH2(5); else VO_KLT_LAUNCH2(4);
 #undef VO_KLT_LAUNCH2
-    } else if (waves <= 4) VO_KLT_LAUNCH(4); else if (waves == 5) VO_KLT_LAUNCH(5); else VO_KLT_LAUNCH(6);
+    } else
+#endif
+    if (waves <= 4) VO_KLT_LAUNCH(4); else if (waves == 5) VO_KLT_LAUNCH(5); else VO_KLT_LAUNCH(6);
 #undef VO_KLT_LAUNCH
   }
   VO_HIP(c, hipGetLastError());

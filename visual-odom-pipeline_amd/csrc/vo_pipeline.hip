@@ -1212,7 +1212,7 @@ static int32_t pipe_create(vo_ctx* c, const double* K, const vo_pipe_params* prm
   VO_HIP(c, hipMalloc((void**)&w->d_rec, sizeof(vo_pipe_record) * B));
   VO_HIP(c, hipMemsetAsync(w->d_rec, 0, sizeof(vo_pipe_record) * B, c->stream));
   VO_HIP(c, hipHostMalloc((void**)&w->h_rec, sizeof(vo_pipe_record) * B * VO_PIPE_INFLIGHT, hipHostMallocDefault));
-  const unsigned fl = hipEventDisableTiming | ((getenv("VO_BLOCKING_SYNC") && atoi(getenv("VO_BLOCKING_SYNC"))) ? hipEventBlockingSync : 0u);
+  const unsigned fl = hipEventDisableTiming | (vo_blocking_sync() ? hipEventBlockingSync : 0u);
   for (int i = 0; i < VO_PIPE_INFLIGHT; i++) VO_HIP(c, hipEventCreateWithFlags(&w->ev[i], fl));
   VO_HIP(c, hipEventCreateWithFlags(&w->ev_track, hipEventDisableTiming));
   // k_pipe_extend keeps 28 bytes of LDS per table slot (112 KB at 4 096 slots: above the default limit of a launch)

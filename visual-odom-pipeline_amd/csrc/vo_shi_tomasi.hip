@@ -12,7 +12,7 @@
 //   k_st_mask_init  : mask = 255 (or the caller's mask), scalars zeroed
 //   k_st_discs      : filled midpoint circles of the tracked keypoints into the mask
 //   k_st_eig_fused  : Sobel products, 31 x 31 box sums, min-eigenvalue map + masked maxima in one pass (block size 31;
-//                     other block sizes, tiny images or VO_ST_FUSED=0: k_st_sobel_hsum -> 3 int32 planes -> k_st_vsum_eig)
+//                     other block sizes, the Harris response, tiny images or vo_tuning.st_two_kernels: k_st_sobel_hsum -> 3 int32 planes -> k_st_vsum_eig)
 //   k_st_nms        : threshold + 3x3 non-max suppression + mask -> compacted (value, index) keys
 //   k_st_select     : ONE workgroup: bitonic sort of the keys in LDS (value desc, index desc) and the
 //                     greedy min-distance selection done as parallel fixed-point rounds (a candidate is
@@ -37,7 +37,6 @@ struct vo_st_ws {
   uint32_t* d_scalars = nullptr;   // [0] max eig bits, [1] n candidates, [2] n out (int), [3] rounds
   unsigned long long* d_cand = nullptr;
   uint32_t* d_nraw = nullptr;      // [batch] raw candidate counters (appended to by the NMS stage, re-armed by k_st_select)
-  bool keep_default = false;       // VO_ST_KEEP_EIG=1: resident launches store the eigenvalue map and keep the mask too (diagnostics)
   bool mask_clean = false;         // the mask is all 255 (k_st_eig_fused restored it): the next resident launch needs no k_st_mask_init
   bool eig_valid = false;          // the last launch stored the eigenvalue map (vo_shi_tomasi_read)
   float* d_blockmax = nullptr;     // per-workgroup masked maxima of the eigenvalue pass
@@ -45,8 +44,6 @@ struct vo_st_ws {
   float* d_pts = nullptr;          // uploaded cur_pts (non-resident call)
   int n_blockmax = 0;
   int last_max_corners = 0;
-  int force_rb = 0;
-  bool fused = true;               // block_size 31: k_st_eig_fused instead of k_st_sobel_hsum + k_st_vsum_eig (VO_ST_FUSED=0: off)
 };
 
 struct disc_rows { int hw[ST_MAX_RADIUS + 1]; };
@@ -1067,14 +1064,11 @@ static int32_t st_init(vo_ctx* c) {
   const size_t np = (size_t)c->width * c->height, B = (size_t)c->batch;
   VO_HIP(c, hipMalloc((void**)&s->d_mask, np * B));
   VO_HIP(c, hipMalloc((void**)&s->d_user_mask, np * B));
-  s->fused = !(getenv("VO_ST_FUSED") && atoi(getenv("VO_ST_FUSED")) == 0);
-  s->force_rb = getenv("VO_ST_RB") ? atoi(getenv("VO_ST_RB")) : 0;       // test knob: rows per band of the fused kernel
   VO_HIP(c, hipMalloc((void**)&s->d_eig, np * sizeof(float) * B));
   s->d_scalars = vo_slab<uint32_t>(c, c->off_st_scalars);
   VO_HIP(c, hipMalloc((void**)&s->d_cand, sizeof(unsigned long long) * ST_CAND_STRIDE * B));
   VO_HIP(c, hipMalloc((void**)&s->d_nraw, sizeof(uint32_t) * B));
   VO_HIP(c, hipMemsetAsync(s->d_nraw, 0, sizeof(uint32_t) * B, c->stream));
-  s->keep_default = getenv("VO_ST_KEEP_EIG") && atoi(getenv("VO_ST_KEEP_EIG")) != 0;
   s->n_blockmax = vo_div_up(c->width, 256 - 32) * c->height;                     // upper bound over both eigenvalue paths (1-row bands)
   VO_HIP(c, hipMalloc((void**)&s->d_blockmax, sizeof(float) * (size_t)s->n_blockmax * B));
   s->d_out = vo_slab<float>(c, c->off_st_out);
@@ -1109,13 +1103,13 @@ int vo_st_last_max_corners(const vo_ctx* c) { return c->st ? c->st->last_max_cor
 // resident launch skips k_st_mask_init on a mask that still holds the previous frame's discs
 int vo_st_flags_save(const vo_ctx* c) { return c->st ? (c->st->mask_clean ? 1 : 0) | (c->st->eig_valid ? 2 : 0) : -1; }
 void vo_st_flags_restore(vo_ctx* c, int saved) { if (c->st && saved >= 0) { c->st->mask_clean = (saved & 1) != 0; c->st->eig_valid = (saved & 2) != 0; } }
-int vo_st_launch_state(const vo_ctx* c) { return c->st ? (c->st->mask_clean ? 1 : 0) | (c->st->keep_default ? 2 : 0) : 0; }   // decides which kernels a resident launch enqueues
+int vo_st_launch_state(const vo_ctx* c) { return c->st ? (c->st->mask_clean ? 1 : 0) | (c->tune.st_keep_eig ? 2 : 0) : 0; }   // decides which kernels a resident launch enqueues
 // all allocations a launch with these parameters needs (called outside any graph capture)
 int32_t vo_st_prepare(vo_ctx* c, const vo_st_params* prm) {
   int32_t r = st_init(c);
   if (r != VO_OK) return r;
   vo_st_ws* s = c->st;
-  const bool fused = s->fused && prm && prm->block_size == 31 && c->height > 31 && c->width > 31;
+  const bool fused = !c->tune.st_two_kernels && prm && prm->block_size == 31 && c->height > 31 && c->width > 31;
   if (!fused && !s->d_h) VO_HIP(c, hipMalloc((void**)&s->d_h, (size_t)c->width * c->height * 3 * sizeof(int32_t) * c->batch));
   return VO_OK;
 }
@@ -1144,7 +1138,7 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
   const double scale_d = 1.0 / ((double)(1 << 2) * prm->block_size * 255.0);
   const float sf = (float)scale_d;
   const float s2 = sf * sf;
-  const bool fused = s->fused && r == 15 && H > 31 && W > 31 && !prm->use_harris;    // (single border reflection per row inside the kernel; the Harris
+  const bool fused = !c->tune.st_two_kernels && r == 15 && H > 31 && W > 31 && !prm->use_harris;    // (single border reflection per row inside the kernel; the Harris
                                                                                      //  response -- an option the reference never enables -- takes the two-kernel form)
   int n_blockmax;
   if (fused) {
@@ -1182,13 +1176,12 @@ static int32_t st_launch(vo_ctx* c, const float* d_pts, size_t pts_seq, int n_cu
       }
     }
     int rb = vo_div_up(H, gyw);
-    if (s->force_rb > 0) rb = s->force_rb < H ? s->force_rb : H;
+    if (c->tune.st_band_rows > 0) rb = c->tune.st_band_rows < H ? c->tune.st_band_rows : H;
     const int gy = vo_div_up(H, rb);
     n_blockmax = gx * gy;
-    // VO_ST_NMS_FUSED=0 (experiment knob): the eigenvalue map goes through HBM to the separate k_st_nms, as in round 1
-    static const bool nms_fused = !(getenv("VO_ST_NMS_FUSED") && atoi(getenv("VO_ST_NMS_FUSED")) == 0);
-    static const int remap_env = getenv("VO_XCD_REMAP") ? atoi(getenv("VO_XCD_REMAP")) : 1;
-    const int xcd_remap = (remap_env && B % 8 == 0) ? 1 : 0;
+    // vo_tuning.st_separate_nms: the eigenvalue map goes through HBM to the separate k_st_nms, as in round 1
+    const bool nms_fused = !c->tune.st_separate_nms;
+    const int xcd_remap = (!c->tune.xcd_remap_off && B % 8 == 0) ? 1 : 0;
     const bool restore = !keep && !d_user_mask && nms_fused;
     hipLaunchKernelGGL(k_st_eig_fused<15>, dim3(gx, gy, B), dim3(256), 0, c->stream, F.img[0], c->lvl_px[0], c->lv[0].pitch, W, H, rb, s2,
                        s->d_mask, (keep || !nms_fused) ? s->d_eig : nullptr, s->d_blockmax, prm->quality_level, s->d_cand, s->d_nraw,
@@ -1281,10 +1274,9 @@ int32_t vo_shi_tomasi_resident_counts(vo_ctx* c, int32_t n_cur, int32_t mask_rad
   { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   int32_t r = st_init(c);
   if (r != VO_OK) return r;
-  const char* dl = getenv("VO_ST_DEV_LIMIT");                                                              // A/B knob, read per call (tests compare both)
-  const bool dev_limit = !(dl && atoi(dl) == 0);
+  const bool dev_limit = !c->tune.st_host_limit;                                                           // (vo_tuning: A/B, read per call -- tests compare both)
   return st_launch(c, vo_slab<const float>(c, vo_off_p(c)), c->slab_seq, n_cur, mask_radius, nullptr, prm, d_counts,
-                   c->st->keep_default, dev_limit ? d_limit : nullptr);
+                   c->tune.st_keep_eig != 0, dev_limit ? d_limit : nullptr);
 }
 
 extern "C" int32_t vo_shi_tomasi_fetch(vo_ctx* c, float* out_pts, int32_t* n_out) {
@@ -1299,7 +1291,7 @@ extern "C" int32_t vo_shi_tomasi_read(vo_ctx* c, float* eig_out, uint8_t* mask_o
   if (!c) return VO_E_INVALID;
   VO_CHECK(c, c->st, VO_E_STATE, "no shi_tomasi call yet");
   VO_CHECK(c, c->st->eig_valid || (!eig_out && !mask_out), VO_E_STATE,
-           "the last launch was a resident one: it keeps neither the eigenvalue map nor the mask (VO_ST_KEEP_EIG=1 makes it)");
+           "the last launch was a resident one: it keeps neither the eigenvalue map nor the mask (vo_tuning.st_keep_eig makes it)");
   VO_HIP(c, hipSetDevice(c->device));
   VO_HIP(c, hipStreamSynchronize(c->stream));
   if (c->stream2) VO_HIP(c, hipStreamSynchronize(c->stream2));

@@ -61,10 +61,12 @@ struct step_cfg {
 // enqueue everything of one frame on the ctx stream (also used under stream capture); *recorded: ev_step[half] has been recorded
 // frame_idx < 0: the frames of this step arrive from the host in c->d_host_raw[half] (vo_frame_step_host: the upload runs on the copy stream,
 // ev_h2d[half] says when it is there)
+static bool step_trace_on() { static const bool on = getenv("VO_STEP_TRACE") != nullptr; return on; }
+
 static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame_idx, int frame_idx, int half, bool* recorded) {
   int32_t r;
   *recorded = false;
-  static const bool trace_a = getenv("VO_STEP_TRACE") != nullptr;
+  const bool trace_a = step_trace_on();
   if (trace_a && c->side_stream == 2) trace_push(g_ta, c->stream, 4000);
   const size_t fr = (size_t)c->width * c->height;
   if (frame_idx < 0) {
@@ -104,7 +106,7 @@ static int32_t step_enqueue(vo_ctx* c, const step_cfg& s, const int32_t* d_frame
     if (trace_a) trace_push(g_ta, c->stream, 4000);
     hipStream_t main_stream = c->stream;
     c->stream = c->stream3;
-    static const bool trace = getenv("VO_STEP_TRACE") != nullptr;      // debug: GPU-side timeline of stream C, printed by vo_debug_step_trace_dump
+    const bool trace = trace_a;                                        // debug: GPU-side timeline of stream C, printed by vo_debug_step_trace_dump
     if (trace) trace_push(g_tr, c->stream3, 4000);
     // C carries nothing but the LM iterations and k_ba_finalize: the copy of the solution goes to B (behind ev_ba), so that the next
     // frame's iterations follow this frame's directly; k_ba_finalize of the next step waits for that copy (ev_pub) -- long done by then
@@ -448,13 +450,13 @@ int32_t vo_main_stream_reserve(vo_ctx* c, int reserve) {
 // bits are dealt round-robin over XCDs and engines, a count that is no multiple of 32 unbalances the engines (240, 232 and 248 of 256 CUs
 // measured SLOWER than 224; tools/gate_ab.sh, EXPERIMENTS.md round 5 item 15).  One sequence (a 34 us tracker launch that starves nobody)
 // keeps the plain layout, and so does graph replay (a captured step stays on one stream, which must then have the whole chip).
-// VO_BA_WIDE_GROUPS / VO_FE_RESERVE_CUS override (0 = off).
+// vo_tuning.gate_groups / reserve_cus override (-1 = off).
 static int32_t step_layout_apply(vo_ctx* c) {
   int groups = 0, reserve = 0;
   if (c->side_stream == 2 && !c->use_graph) {
     if (c->batch >= 8) { groups = c->batch >= 256 ? 4 : 5; reserve = 32; }
-    if (const char* e = getenv("VO_BA_WIDE_GROUPS")) groups = atoi(e) > 0 ? atoi(e) : 0;
-    if (const char* e = getenv("VO_FE_RESERVE_CUS")) reserve = atoi(e) > 0 ? atoi(e) : 0;
+    if (c->tune.gate_groups) groups = c->tune.gate_groups > 0 ? c->tune.gate_groups : 0;
+    if (c->tune.reserve_cus) reserve = c->tune.reserve_cus > 0 ? c->tune.reserve_cus : 0;
   }
   c->ba_wide_groups = groups;
   c->ba_wide_recorded = false;
@@ -479,6 +481,34 @@ extern "C" int32_t vo_set_side_stream(vo_ctx* c, int32_t on) {
     VO_HIP(c, hipEventCreateWithFlags(&c->ev_copy1[1], hipEventDisableTiming));
   }
   c->side_stream = (on == 2) ? 2 : (on ? 1 : 0);      // 2: pipelined (BA of frame t beside the front end of frame t + 1)
+  return step_layout_apply(c);
+}
+
+extern "C" int32_t vo_get_tuning(vo_ctx* c, vo_tuning* out) {
+  if (!c || !out) return VO_E_INVALID;
+  *out = c->tune;
+  return VO_OK;
+}
+
+extern "C" int32_t vo_set_tuning(vo_ctx* c, const vo_tuning* t) {
+  if (!c || !t) return VO_E_INVALID;
+  VO_CHECK(c, c->steps_enq == c->steps_fetched, VO_E_STATE, "fetch the steps in flight before changing the tuning");
+  VO_CHECK(c, (t->ba_kernels >= 0 && t->ba_kernels <= 2) && (t->ba_lanes == 0 || t->ba_lanes == 8 || t->ba_lanes == 16) &&
+              (t->ba_threads == 0 || t->ba_threads == 256 || t->ba_threads == 512 || t->ba_threads == 1024) && t->ba_pitch_pad >= 0 && t->ba_pitch_pad <= 64 &&
+              t->ba_chunks >= 0 && t->ba_workgroups >= 0 && t->ba_workgroup_cap >= 0 && t->ba_fold >= 0 && t->ba_fold <= 2 &&
+              (t->klt_waves == 0 || (t->klt_waves >= 4 && t->klt_waves <= 6)) && t->st_band_rows >= 0 && t->gate_groups >= -1 && t->reserve_cus >= -1 &&
+              t->reserve_cus < 256, VO_E_INVALID, "field out of range");
+#ifndef VO_EXPERIMENTS
+  VO_CHECK(c, t->klt_pair == 0, VO_E_INVALID, "klt_pair needs a build with -DVO_EXPERIMENTS");
+#else
+  VO_CHECK(c, t->klt_pair == 0 || (t->klt_pair >= 3 && t->klt_pair <= 5), VO_E_INVALID, "klt_pair: 3, 4 or 5");
+#endif
+  for (int k = 0; k < 14; k++) VO_CHECK(c, t->reserved[k] == 0, VO_E_INVALID, "reserved fields must be 0");
+  VO_HIP(c, hipSetDevice(c->device));
+  { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
+  c->tune = *t;
+  for (auto& g : c->step_graphs) if (g.second) (void)hipGraphExecDestroy(g.second);      // a captured step bakes the kernel choices in
+  c->step_graphs.clear();
   return step_layout_apply(c);
 }
 

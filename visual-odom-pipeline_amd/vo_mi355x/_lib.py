@@ -40,6 +40,15 @@ class BaParams(C.Structure):
                 ("gtol", C.c_double), ("lambda0", C.c_double), ("huber_delta", C.c_double), ("lambda_min", C.c_double)]
 
 
+TUNING_FIELDS = ("ba_kernels", "ba_lanes", "ba_threads", "ba_pitch_pad", "ba_chunks", "ba_workgroups", "ba_workgroup_cap", "ba_fold", "klt_waves", "klt_pair",
+                 "st_two_kernels", "st_band_rows", "st_separate_nms", "st_keep_eig", "st_host_limit", "xcd_remap_off", "gate_groups", "reserve_cus")
+
+
+class Tuning(C.Structure):
+    """vo_tuning: forced forms for parity tests and A/B measurements; 0 = the library's rule"""
+    _fields_ = [(k, C.c_int32) for k in TUNING_FIELDS] + [("reserved", C.c_int32 * 14)]
+
+
 class PnpParams(C.Structure):
     _fields_ = [("reproj_err", C.c_double), ("confidence", C.c_double), ("max_iters", C.c_int32), ("seed", C.c_int32)]
 
@@ -127,6 +136,8 @@ SIGNATURES = {
     "vo_host_free": (C.c_int32, [C.c_void_p]),
     "vo_frame_fetch": (C.c_int32, [_ctx, C.c_int32, _f32p, _u8p, _f32p, _f32p, _f64p, _f64p, _f64p, _f64p,
                                    C.POINTER(BaStats), _f32p, _i32p]),
+    "vo_get_tuning": (C.c_int32, [_ctx, C.POINTER(Tuning)]),
+    "vo_set_tuning": (C.c_int32, [_ctx, C.POINTER(Tuning)]),
     "vo_set_graph_mode": (C.c_int32, [_ctx, C.c_int32]),
     "vo_set_side_stream": (C.c_int32, [_ctx, C.c_int32]),
     "vo_step_layout": (C.c_int32, [_ctx, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

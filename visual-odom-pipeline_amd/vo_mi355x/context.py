@@ -12,10 +12,14 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import BaParams, BaStats, EssParams, EssStats, KltParams, SiftKp, PnpParams, PnpStats, StParams, VoError, as_c, ptr
+from ._lib import BaParams, BaStats, EssParams, EssStats, KltParams, SiftKp, PnpParams, PnpStats, StParams, Tuning, VoError, as_c, ptr
 
 
 class VoContext:
+    # vo_tuning fields applied to every NEW context (a test module forces one kernel family for all the contexts its tests make this way; the
+    # library itself reads no tuning from the environment)
+    default_tuning = {}
+
     def __init__(self, width, height, max_pts=4096, device=0, max_level=3, win=31, batch=1):
         self._L = _lib.load()
         self._h = C.c_void_p()
@@ -28,6 +32,8 @@ class VoContext:
         self._st_max_corners = 1000
         self._klt_levels = max_level + 1
         self.comm_ranks, self.comm_rank = 1, 0
+        if self.default_tuning:
+            self.set_tuning(**self.default_tuning)
 
     # -- lifetime -------------------------------------------------------------------------------
     def close(self):
@@ -54,6 +60,23 @@ class VoContext:
 
     def sync(self):
         self._ck(self._L.vo_sync(self._h))
+
+    def tuning(self):
+        """-> dict of the vo_tuning fields in effect (0 = the library's rule)"""
+        t = Tuning()
+        self._ck(self._L.vo_get_tuning(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k in _lib.TUNING_FIELDS}
+
+    def set_tuning(self, **fields):
+        """force forms the library otherwise chooses by rule (include/vo_mi355x.h: vo_tuning; parity tests and A/B measurements).  Fields not
+        named keep their value; `set_tuning(**dict.fromkeys(ctx.tuning(), 0))` restores the rules."""
+        t = Tuning()
+        self._ck(self._L.vo_get_tuning(self._h, C.byref(t)))
+        for k, v in fields.items():
+            if k not in _lib.TUNING_FIELDS:
+                raise ValueError("set_tuning: unknown field %r" % k)
+            setattr(t, k, int(v))
+        self._ck(self._L.vo_set_tuning(self._h, C.byref(t)))
 
     # -- batch helpers --------------------------------------------------------------------------
     def _in(self, a, dtype, per_seq_shape):
