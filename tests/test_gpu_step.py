@@ -375,3 +375,57 @@ def test_host_alloc_is_a_plain_numpy_array_and_frees_itself():
     assert int(v.sum()) == 7 * 16 * 32           # a view keeps the allocation alive
     del v
     gc.collect()
+
+
+def test_gated_layout_is_suspended_by_closed_loop_steps_and_comes_back():
+    """The gate + CU mask of a batch's pipelined layout are a property only vo_set_side_stream / vo_set_graph_mode / vo_set_tuning change: a
+    closed-loop step (vo_pipe_step: its chain needs the whole chip) SUSPENDS them -- vo_step_layout says so -- and the next frame step puts them
+    back; the layout cannot be switched while closed-loop steps are in flight; tracker results around it are those of a context that never ran the loop"""
+    import copy
+    from vo_mi355x import VoContext, VoError, synthetic as syn
+    from vo_mi355x.resident import ResidentPipeline
+    w, h, B, n, t1 = 256, 160, 8, 200, 3
+    sc = syn.sway_scene(10, w=w, h=h, f=260.0, seed=2024, pose_fn=lambda t: syn.sway_pose(t, period=24.0))
+    frames = np.stack([sc["frames"]] * B)
+    pts = np.stack([syn.grid_points(n, w, h, seed=b, margin=12) for b in range(B)])
+
+    def klt_steps(c, order):
+        out = []
+        for f in order:
+            c.frame_step_resident(f, n, do_dlt=False, do_ba=False, do_st=False)
+            r = c.frame_fetch()
+            out.append((r["points2d"].copy(), r["status"].copy(), r["err"].copy()))
+        return out
+
+    with VoContext(w, h, max_pts=1024, batch=B) as c:
+        c.upload_sequence(frames); c.points_upload(pts); c.push_frame_resident(0)
+        ref = klt_steps(c, [1, 2]) + klt_steps(c, [5, 6])
+    with VoContext(w, h, max_pts=1024) as boot:
+        state, _ = syn.gt_bootstrap(boot, sc, 0, t1)
+    with VoContext(w, h, max_pts=1024, batch=B) as c:
+        c.upload_sequence(frames); c.points_upload(pts); c.push_frame_resident(0)
+        c.set_side_stream("pipeline")
+        gated = {"layout": 2, "gate_groups": 5, "reserved_cus": 32}
+        assert c.step_layout() == gated
+        got = klt_steps(c, [1, 2])
+        assert c.step_layout() == gated
+        rp = ResidentPipeline(c, np.stack([sc["K"]] * B), ba_max_iters=6, pnp_blind_batches=4)
+        rp.seed([copy.deepcopy(state) for _ in range(B)], None, None, 1)
+        c.push_frame_resident(t1)
+        rp.step(t1 + 1)
+        assert c.step_layout() == {"layout": 2, "gate_groups": 0, "reserved_cus": 0}          # suspended, not silently gone: layout is still 2
+        with pytest.raises(VoError):
+            c.set_side_stream("pipeline")                                                     # a closed-loop step is in flight
+        rec = rp.fetch()
+        assert all(r["status"] == 0 for r in rec)
+        rp.step(t1 + 2); rp.fetch()
+        # back to the frame steps: the points of the first run, the frame store re-primed
+        c.points_upload(got[-1][0]); c.push_frame_resident(2); c.push_frame_resident(4)
+        got += klt_steps(c, [5, 6])
+        assert c.step_layout() == gated
+    with VoContext(w, h, max_pts=1024, batch=B) as c:     # the reference for the second half: frames 4 -> 5 -> 6 from the same points
+        c.upload_sequence(frames); c.points_upload(ref[1][0]); c.push_frame_resident(4)
+        ref = ref[:2] + klt_steps(c, [5, 6])
+    for k, (a, b) in enumerate(zip(got, ref)):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), k

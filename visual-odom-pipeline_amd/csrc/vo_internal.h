@@ -60,6 +60,7 @@ struct vo_ctx {
   int ba_wide_groups = 0;                       // 0: no gating
   bool ba_wide_recorded = false;
   int stream_reserve = 0;                        // compute units `stream` leaves free (CU mask of its queue; vo_set_side_stream)
+  bool layout_suspended = false;                 // vo_pipe_step took the gate and the CU mask off (its chain needs the whole chip): the next frame step re-applies them
   bool pub_copy_pending = false;                // a pipelined step has recorded ev_pub at least once
   // loader pre-filter (vo_set_prefilter): cv2.bilateralFilter taps applied while a frame enters the frame store
   int bil_maxk = 0;                  // 0 = off
@@ -229,6 +230,7 @@ int32_t vo_comm_allgather_f64(vo_ctx* c, const double* send, double* recv, size_
 
 void vo_trk_destroy(vo_ctx* c);
 void vo_pipe_destroy(vo_ctx* c);
+bool vo_pipe_busy(const vo_ctx* c);            // closed-loop steps enqueued and not fetched yet
 
 // ---- hooks of the closed-loop pipeline (vo_pipeline.hip) into the stage units: device-resident inputs, per-sequence counts ----
 // bundle adjustment: workspace for W slots x N landmark slots with K uploaded, problem written on the device into x0 / obs

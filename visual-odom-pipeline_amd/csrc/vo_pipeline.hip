@@ -1134,6 +1134,8 @@ __global__ void __launch_bounds__(PIPE_TPB) k_pipe_dense(pipe_ptrs Pall, float* 
 // ================================================================================================
 // host
 // ================================================================================================
+bool vo_pipe_busy(const vo_ctx* c) { return c->pipe && c->pipe->enq != c->pipe->fetched; }
+
 void vo_pipe_destroy(vo_ctx* c) {
   if (!c->pipe) return;
   vo_pipe_ws* w = c->pipe;
@@ -1401,7 +1403,15 @@ extern "C" int32_t vo_pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages) {
   VO_HIP(c, hipSetDevice(c->device));
   // the closed loop's chain (PnP, the adjustment) lives on the ctx stream: it gets every compute unit (the pipelined frame step of a batch
   // confines that stream to 224 of them for its tracker launches, vo_set_side_stream)
-  if (c->stream_reserve > 0 && c->pipe->enq == c->pipe->fetched) { const int32_t rr = vo_main_stream_reserve(c, 0); if (rr != VO_OK) return rr; c->ba_wide_groups = 0; }
+  // -- the layout stays what vo_set_side_stream made it: it is SUSPENDED here and the next vo_frame_step_* puts it back (vo_step_layout reports
+  // what is in effect at the moment).  vo_set_side_stream / vo_set_tuning refuse while pipe steps are in flight, so a masked stream is never met
+  // with steps of this loop still on it
+  if (c->stream_reserve > 0 || c->ba_wide_groups > 0) {
+    VO_CHECK(c, c->pipe->enq == c->pipe->fetched && c->steps_enq == c->steps_fetched, VO_E_STATE, "steps in flight on the gated stream layout");
+    const int32_t rr = vo_main_stream_reserve(c, 0);
+    if (rr != VO_OK) return rr;
+    c->ba_wide_groups = 0; c->ba_wide_recorded = false; c->layout_suspended = true;
+  }
   const bool dirty = c->main_dirty;               // something other than a pipe step has used the ctx stream since the last one
   { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   c->main_dirty = false;

@@ -51,6 +51,8 @@ int32_t vo_quiesce_side(vo_ctx* c) {
   return VO_OK;
 }
 
+static int32_t step_layout_apply(vo_ctx* c);
+
 struct step_cfg {
   int n_pts, do_dlt, do_ba, do_st, mask_radius;
   vo_klt_params klt;
@@ -308,6 +310,11 @@ static int32_t frame_step(vo_ctx* c, int32_t frame_idx, const uint8_t* const* ho
                           int32_t do_st, int32_t mask_radius, const vo_klt_params* klt, const vo_st_params* st, const vo_ba_params* ba) {
   VO_CHECK(c, c->n_pushed >= 1, VO_E_STATE, "push one frame before stepping");
   VO_HIP(c, hipSetDevice(c->device));
+  if (c->layout_suspended) {
+    // a closed-loop step (vo_pipe_step) took the gate and the CU mask off; this is the first frame step since: put the layout back
+    VO_CHECK(c, !vo_pipe_busy(c), VO_E_STATE, "vo_pipe_fetch the closed-loop steps in flight first");
+    if (c->steps_enq == c->steps_fetched) { const int32_t rl = step_layout_apply(c); if (rl != VO_OK) return rl; }
+  }
   step_cfg s;
   memset(&s, 0, sizeof(s));
   s.n_pts = n_pts; s.do_dlt = do_dlt ? 1 : 0; s.do_ba = do_ba ? 1 : 0; s.do_st = do_st ? 1 : 0; s.mask_radius = mask_radius;
@@ -437,7 +444,10 @@ int32_t vo_main_stream_reserve(vo_ctx* c, int reserve) {
   VO_HIP(c, hipStreamSynchronize(c->stream));
   hipStream_t fresh = nullptr;
   hipError_t e = vo_stream_create(&fresh, reserve);
-  if (e != hipSuccess && reserve > 0) { (void)hipGetLastError(); reserve = 0; e = vo_stream_create(&fresh, 0); }   // (no CU masks on this runtime)
+  if (e != hipSuccess && reserve > 0) {          // no CU masks on this runtime: then no gate either -- the tail groups would have no compute units of their own
+    (void)hipGetLastError(); reserve = 0; c->ba_wide_groups = 0;
+    e = vo_stream_create(&fresh, 0);
+  }
   VO_HIP(c, e);
   VO_HIP(c, hipStreamDestroy(c->stream));
   c->stream = fresh;
@@ -460,12 +470,13 @@ static int32_t step_layout_apply(vo_ctx* c) {
   }
   c->ba_wide_groups = groups;
   c->ba_wide_recorded = false;
+  c->layout_suspended = false;
   return vo_main_stream_reserve(c, reserve);
 }
 
 extern "C" int32_t vo_set_side_stream(vo_ctx* c, int32_t on) {
   if (!c) return VO_E_INVALID;
-  VO_CHECK(c, c->steps_enq == c->steps_fetched, VO_E_STATE, "fetch the steps in flight before switching the stream layout");
+  VO_CHECK(c, c->steps_enq == c->steps_fetched && !vo_pipe_busy(c), VO_E_STATE, "fetch the steps in flight before switching the stream layout");
   if (on == 2 && !c->stream3) {
     // created on demand: streams share the hardware queues, and a third (idle) stream per context re-deals which of them share one --
     // three batched contexts lost 10 % of their throughput to it
@@ -492,7 +503,7 @@ extern "C" int32_t vo_get_tuning(vo_ctx* c, vo_tuning* out) {
 
 extern "C" int32_t vo_set_tuning(vo_ctx* c, const vo_tuning* t) {
   if (!c || !t) return VO_E_INVALID;
-  VO_CHECK(c, c->steps_enq == c->steps_fetched, VO_E_STATE, "fetch the steps in flight before changing the tuning");
+  VO_CHECK(c, c->steps_enq == c->steps_fetched && !vo_pipe_busy(c), VO_E_STATE, "fetch the steps in flight before changing the tuning");
   VO_CHECK(c, (t->ba_kernels >= 0 && t->ba_kernels <= 2) && (t->ba_lanes == 0 || t->ba_lanes == 8 || t->ba_lanes == 16) &&
               (t->ba_threads == 0 || t->ba_threads == 256 || t->ba_threads == 512 || t->ba_threads == 1024) && t->ba_pitch_pad >= 0 && t->ba_pitch_pad <= 64 &&
               t->ba_chunks >= 0 && t->ba_workgroups >= 0 && t->ba_workgroup_cap >= 0 && t->ba_fold >= 0 && t->ba_fold <= 2 &&
@@ -522,7 +533,7 @@ extern "C" int32_t vo_step_layout(vo_ctx* c, int32_t* layout, int32_t* gate_grou
 
 extern "C" int32_t vo_set_graph_mode(vo_ctx* c, int32_t on) {
   if (!c) return VO_E_INVALID;
-  VO_CHECK(c, c->steps_enq == c->steps_fetched, VO_E_STATE, "fetch the steps in flight before switching the launch mode");
+  VO_CHECK(c, c->steps_enq == c->steps_fetched && !vo_pipe_busy(c), VO_E_STATE, "fetch the steps in flight before switching the launch mode");
   c->use_graph = on ? 1 : 0;
   { const int32_t rr = step_layout_apply(c); if (rr != VO_OK) return rr; }
   return VO_OK;
