@@ -61,7 +61,10 @@ typedef struct {
   int32_t use_harris;        /* 0: cv2.goodFeaturesToTrack's default response, the minimum eigenvalue (what the reference runs: its parameter
                                 dict extractor.py:21-24 leaves useHarrisDetector at False); 1: useHarrisDetector=True -- the response becomes
                                 a c - b^2 - harris_k (a + c)^2 over the same box-filtered Sobel products without the 1/2 factors
-                                (imgproc/corner.cpp calcHarris), everything after the response map is unchanged.
+                                (imgproc/corner.cpp calcHarris, its SCALAR form: float a c - b^2, the k term in double; a SIMD build of
+                                cv2 evaluates all but the last pixels of a row in float throughout and differs by ~1 ulp -- parity is with
+                                oracle/vo_oracle.c's restatement, not with cv2 bit for bit), everything after
+                                the response map is unchanged.
                                 A frame whose largest masked response is not positive yields no corners here (OpenCV would rank negative
                                 responses). */
   int32_t _pad;

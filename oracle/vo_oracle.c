@@ -342,7 +342,11 @@ void vo_oracle_circle_rows(int radius, int* halfw /* radius+1 entries */) {
 /* harris != 0: cornerHarris(img, blockSize, 3, k) -- the response goodFeaturesToTrack(useHarrisDetector=True, k) ranks (the reference
  * leaves it off, extractor.py:21-24).  Same Sobel scale and box sums (cornerEigenValsVecs), then calcHarris
  * (scalar form): a = cov_xx, b = cov_xy, c = cov_yy WITHOUT the halves, dst = (float)(a * c - b * b - k * (a + c) * (a + c)) with float
- * a, b, c and double k -- the first difference is float arithmetic, the k term double.                                            */
+ * a, b, c and double k -- the first difference is float arithmetic, the k term double.
+ * NB this is the SCALAR tail of calcHarris.  A cv2 built with SIMD (every stock wheel) runs all but the last width % lanes pixels of a row
+ * through the vector form -- float k, (a * c - b * b) - (kf * (a + c)) * (a + c) entirely in float -- which differs from this form by ~1 ulp and
+ * depends on the build's vector width (4 / 8 / 16 lanes).  Harris parity is therefore pinned to THIS restatement, not to cv2 bit for bit; the
+ * reference never turns the option on.                                                                                            */
 static inline float corner_value(float sxx, float sxy, float syy, int harris, double k) {
   if (harris) { const float a = sxx, b = sxy, c = syy; return (float)((double)(a * c - b * b) - k * (double)(a + c) * (double)(a + c)); }
   const float a = sxx * 0.5f, b = sxy, c = syy * 0.5f;

@@ -150,7 +150,9 @@ def test_shi_tomasi_bit_exact(ctx_big, seq3):
 def test_harris_response_bit_exact(ctx_big, seq3):
     """`vo_st_params.use_harris` = cv2.goodFeaturesToTrack(useHarrisDetector=True, k) (the option the reference's dict extractor.py:21-24
     leaves off): response map, candidate count and the ordered corner list bit-equal to the oracle, with the
-    reference's exclusion discs and without, k = 0.04 and another one; the default parameters still give the minimum-eigenvalue corners"""
+    reference's exclusion discs and without, k = 0.04 and another one; the default parameters still give the minimum-eigenvalue corners.
+    Bit-equal to the ORACLE'S restatement (the scalar form of OpenCV's calcHarris); a SIMD build of cv2 evaluates the k term in float for all but
+    the last few pixels of a row and differs from it by ~1 ulp, depending on its vector width -- not a cv2-bit-for-bit claim"""
     import vo_oracle as o
     from vo_mi355x import synthetic as syn
     frames, _ = seq3

@@ -151,3 +151,45 @@ def test_the_references_unmodified_pipeline_step_over_the_lazy_classes(name, n_s
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "ref_caller_check.py"), name, str(n_steps)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+
+
+def test_history_archive_is_indexed_and_bounded_in_bytes():
+    """`lazy._HistArchive`: a lookup touches only the passes that hold the row, host memory is bounded by a byte budget (oldest passes first:
+    their entries come back as NaN), a recycled row's old tenant is told apart by its identity, a copy finds its source's record by identity"""
+    from vo_mi355x import lazy
+    HIST, EV = lazy.HIST, lazy.ARCH_EVERY
+    dt = np.dtype([("t_first", np.int32), ("uv_first", np.float32, (2,)), ("hist_len", np.int32), ("hist", np.float32, (HIST, 2))])
+    truth = lambda row, i: np.array([row * 1000.0 + i, -float(i)], np.float32)         # entry i of the keypoint living in `row`
+
+    def recs(rows, n, t_first=0):
+        r = np.zeros(len(rows), dt)
+        for k, row in enumerate(rows):
+            r["t_first"][k], r["uv_first"][k], r["hist_len"][k] = t_first, truth(row, 0), n
+            for i in range(max(0, n - HIST), n):
+                r["hist"][k][i % HIST] = truth(row, i)
+        return r
+    rows = np.arange(50)
+    a = lazy._HistArchive()
+    for n in range(EV, 10 * EV + 1, EV):                     # ten passes, every 16 frames
+        a.add(rows, recs(rows, n))
+    n = 10 * EV
+    got = a.older(7, 0, truth(7, 0), n, recs([7], n)["hist"][0])
+    assert got.shape == (n - HIST, 2) and np.array_equal(got, np.stack([truth(7, i) for i in range(n - HIST)]))
+    assert len(a.by_row[7]) == 10 and a._relatives(7, 0, truth(7, 0)) == []
+    # the row is recycled: a new keypoint (other birth frame) lives there; its lookups do not see the old tenant's entries
+    a.add(np.array([7]), recs([7], EV, t_first=200))
+    r2 = recs([7], HIST + 4, t_first=200)
+    assert np.isnan(a.older(7, 200, truth(7, 0), HIST + 4, r2["hist"][0])).all()       # (entries 0 .. 3 left the ring before the first pass of this tenant)
+    # a copy (row 60) of row 3's keypoint: no record of its own before the copy -> row 3's entries by identity
+    cp = recs([3], n)
+    a.add(np.array([60]), cp)
+    got = a.older(60, 0, truth(3, 0), n, cp["hist"][0])
+    assert np.array_equal(got, np.stack([truth(3, i) for i in range(n - HIST)]))
+    # byte budget: only the newest passes stay
+    b = lazy._HistArchive(budget_bytes=3 * (50 * EV * 2 * 4 + 50 * (8 + 8 + 8 + 8)))
+    for n in range(EV, 10 * EV + 1, EV):
+        b.add(rows, recs(rows, n))
+    assert b.bytes <= b.budget and len(b.blocks) == 3 and b.first_id == 7
+    got = b.older(7, 0, truth(7, 0), 10 * EV, recs([7], 10 * EV)["hist"][0])
+    assert np.isnan(got[:7 * EV]).all() and np.array_equal(got[7 * EV:], np.stack([truth(7, i) for i in range(7 * EV, 10 * EV - HIST)]))
+    assert len(b.by_row[7]) == 3                              # index entries of the passes that are gone were pruned on sight

@@ -96,8 +96,8 @@ class _Proxy:
         nd["_row"] = -1
         if d.get("_row", -1) >= 0:                 # attached: the copy is an independent plain object with the values of now
             nd["_rec"] = d["_sess"]._gather(self._KIND, [d["_row"]])[0].copy()
-            if self._KIND == "K":
-                nd["_older"] = d["_sess"]._older(nd["_rec"], d["_row"])
+            if self._KIND == "K" and int(nd["_rec"]["hist_len"]) > HIST:
+                nd["_older"] = _LazyOlder(d["_sess"]._arch, d["_row"])
         else:
             if "_rec" in d:
                 nd["_rec"] = d["_rec"].copy()
@@ -135,6 +135,8 @@ def _field_of(kind, rec, name, older=None):
         lo = max(0, n - HIST)
         # entries older than the device's ring (32; a window reaches 20) come from the host-side archive of the session (`_HistArchive`); without
         # one (a row read outside a session) NaN stands in
+        if isinstance(older, _LazyOlder):
+            older = older.resolve(rec)
         if older is not None and len(older) == lo:
             head = [older[i].reshape(2, 1).copy() for i in range(lo)]
         else:
@@ -231,7 +233,7 @@ class DeviceBackend:
 # the session
 # ------------------------------------------------------------------------------------------------------------------------------------
 ARCH_EVERY = 16          # frames between two archive passes (<= half the ring: consecutive passes overlap)
-ARCH_BLOCKS = 4096       # passes kept (65 536 frames); older history entries come back as NaN
+ARCH_BYTES = 256 << 20   # host bytes the archive may hold (4 000 tracked rows: ~0.5 MB per pass -> ~8 000 frames); older entries come back as NaN
 
 
 class _HistArchive:
@@ -242,11 +244,25 @@ class _HistArchive:
     Rows are COPIED on the device where the reference deep-copies a keypoint (deaths, pruned non-inliers, survivors that shared a row): the copy
     starts life in a new row with the history of its source.  What such a row has no record of itself is taken from the rows that share its
     identity (birth frame and first position): of those, the one whose entries agree longest with the row's own oldest known entries is its
-    source (two lines of descent of one keypoint -- a resurrected dead copy tracked beside the original -- differ from where they parted)."""
+    source (two lines of descent of one keypoint -- a resurrected dead copy tracked beside the original -- differ from where they parted).
+    Host memory is bounded by a BYTE budget (`ARCH_BYTES`: the oldest passes go first, their entries come back as NaN); a lookup touches only the
+    passes that hold the row (`by_row`) or its identity (`by_id`), and nothing is looked up before somebody reads a `uv_history` (`_LazyOlder`)."""
 
-    def __init__(self):
-        self.blocks = []          # (rows [m] sorted, t_first [m], uv_first [m, 2], n [m], data [m, ARCH_EVERY, 2]): entries n - ARCH_EVERY .. n - 1 then
+    def __init__(self, budget_bytes=None):
+        self.blocks = {}          # pass id -> (rows [m] sorted, t_first [m], uv_first [m, 2], n [m], data [m, ARCH_EVERY, 2]): entries n - ARCH_EVERY .. n - 1 then
+        self.by_row = {}          # row -> [(pass id, index in the pass)], oldest first
+        self.by_id = {}           # (t_first, u_first, v_first) -> set of rows that held a keypoint of that identity
         self.seeded = {}          # row -> (t_first, uv_first (2,), [n, 2]): the whole history of an object the session was seeded with
+        self.next_id, self.first_id, self.bytes = 0, 0, 0
+        self.budget = ARCH_BYTES if budget_bytes is None else budget_bytes
+
+    @staticmethod
+    def _key(t_first, uv_first):
+        return (int(t_first), float(uv_first[0]), float(uv_first[1]))
+
+    def seed(self, row, t_first, uv_first, hist):
+        self.seeded[row] = (t_first, uv_first, hist)
+        self.by_id.setdefault(self._key(t_first, uv_first), set()).add(row)
 
     def add(self, rows, recs):
         if not len(rows):
@@ -255,9 +271,19 @@ class _HistArchive:
         idx = n[:, None] - ARCH_EVERY + np.arange(ARCH_EVERY)[None, :]
         data = np.array(recs["hist"], np.float32)[np.arange(len(rows))[:, None], idx % HIST]
         data[idx < 0] = np.nan
-        self.blocks.append((np.asarray(rows, np.int64), recs["t_first"].astype(np.int64), np.array(recs["uv_first"], np.float32).reshape(-1, 2), n, data))
-        if len(self.blocks) > ARCH_BLOCKS:
-            del self.blocks[0]
+        rows = np.asarray(rows, np.int64)
+        tf, uvf = recs["t_first"].astype(np.int64), np.array(recs["uv_first"], np.float32).reshape(-1, 2)
+        bid = self.next_id
+        self.next_id += 1
+        self.blocks[bid] = (rows, tf, uvf, n, data)
+        self.bytes += data.nbytes + rows.nbytes + tf.nbytes + uvf.nbytes + n.nbytes
+        for i, r in enumerate(rows.tolist()):
+            self.by_row.setdefault(r, []).append((bid, i))
+            self.by_id.setdefault((int(tf[i]), float(uvf[i, 0]), float(uvf[i, 1])), set()).add(r)
+        while self.bytes > self.budget and len(self.blocks) > 1:          # the oldest passes go first (index entries of a gone pass are skipped and pruned on sight)
+            old = self.blocks.pop(self.first_id)
+            self.bytes -= old[4].nbytes + old[0].nbytes + old[1].nbytes + old[2].nbytes + old[3].nbytes
+            self.first_id += 1
 
     def _own(self, row, t_first, uv_first, n_hi):
         """what the archive holds of the keypoint (born at t_first at uv_first: rows are recycled, and a copy keeps its source's birth frame) while
@@ -267,25 +293,22 @@ class _HistArchive:
         if sd is not None and sd[0] == t_first and sd[1][0] == uv_first[0] and sd[1][1] == uv_first[1]:
             m = min(len(sd[2]), n_hi)
             out[:m] = sd[2][:m]
-        for rows, tf, uvf, n, data in self.blocks:
-            i = int(np.searchsorted(rows, row))
-            if i < len(rows) and rows[i] == row and tf[i] == t_first and uvf[i, 0] == uv_first[0] and uvf[i, 1] == uv_first[1]:
-                lo = int(n[i]) - ARCH_EVERY
-                a, b = max(lo, 0), min(int(n[i]), n_hi)
-                if b > a:
-                    out[a:b] = data[i, a - lo:b - lo]
+        ent = self.by_row.get(row)
+        if ent:
+            if ent[0][0] < self.first_id:
+                ent[:] = [e for e in ent if e[0] >= self.first_id]
+            for bid, i in ent:
+                rows, tf, uvf, n, data = self.blocks[bid]
+                if tf[i] == t_first and uvf[i, 0] == uv_first[0] and uvf[i, 1] == uv_first[1]:
+                    lo = int(n[i]) - ARCH_EVERY
+                    a, b = max(lo, 0), min(int(n[i]), n_hi)
+                    if b > a:
+                        out[a:b] = data[i, a - lo:b - lo]
         return out
 
     def _relatives(self, row, t_first, uv_first):
         """other rows that hold (or held) a keypoint with this birth frame and first position"""
-        rel = set()
-        for r, sd in self.seeded.items():
-            if r != row and sd[0] == t_first and sd[1][0] == uv_first[0] and sd[1][1] == uv_first[1]:
-                rel.add(r)
-        for rows, tf, uvf, _, _ in self.blocks:
-            hit = np.nonzero((tf == t_first) & (uvf[:, 0] == uv_first[0]) & (uvf[:, 1] == uv_first[1]))[0]
-            rel.update(int(rows[i]) for i in hit if rows[i] != row)
-        return rel
+        return [r for r in self.by_id.get(self._key(t_first, uv_first), ()) if r != row]
 
     def older(self, row, t_first, uv_first, n, ring):
         """entries 0 .. n - 33 of the keypoint in `row` (history length n > 32, `ring` = its 32-entry ring)"""
@@ -308,6 +331,21 @@ class _HistArchive:
                 fill = miss & ~np.isnan(best[:n_old, 0])
                 own[:n_old][fill] = best[:n_old][fill]
         return own[:n_old].copy()
+
+
+class _LazyOlder:
+    """the part of a detached keypoint's history that had left the device's ring when it was detached: looked up in the session's archive the
+    first time its `uv_history` is read (most detached keypoints are never asked), from the table row the proxy took with it"""
+    __slots__ = ("arch", "row")
+
+    def __init__(self, arch, row):
+        self.arch, self.row = arch, int(row)
+
+    def resolve(self, rec):
+        n = int(rec["hist_len"])
+        if n <= HIST:
+            return None
+        return self.arch.older(self.row, int(rec["t_first"]), np.array(rec["uv_first"], np.float32).reshape(2), n, np.array(rec["hist"], np.float32))
 
 
 def _idle_refcount():
@@ -448,8 +486,8 @@ class Session:
             for p, rec in zip(ps, recs):
                 d = p.__dict__
                 d["_rec"] = rec.copy()
-                if kind == "K":
-                    d["_older"] = self._older(rec, d["_row"])
+                if kind == "K" and int(rec["hist_len"]) > HIST:
+                    d["_older"] = _LazyOlder(self._arch, d["_row"])
                 d["_row"] = -1
                 d.pop("_sess", None)
                 d.pop("_copy", None)               # a plain object copies itself
@@ -528,8 +566,8 @@ class Session:
             for k, r in zip(objs, rows.tolist()):
                 # (every history, however short: an archive pass keeps the newest ARCH_EVERY entries of a row, the passes are ARCH_EVERY frames
                 #  apart, so everything older than the first pass's reach has to be on the host already)
-                self._arch.seeded[r] = (int(k.t_first), np.asarray(k.uv_first, np.float32).reshape(2),
-                                        np.array([np.asarray(h, np.float32).reshape(2) for h in k.uv_history], np.float32).reshape(-1, 2))
+                self._arch.seed(r, int(k.t_first), np.asarray(k.uv_first, np.float32).reshape(2),
+                                np.array([np.asarray(h, np.float32).reshape(2) for h in k.uv_history], np.float32).reshape(-1, 2))
         state._landmarks[:] = self.lm_L
         state._landmarks_kp[:] = self.lm_K
         state._candidates_kp[:] = self.cand
