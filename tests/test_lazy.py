@@ -176,10 +176,14 @@ def test_history_archive_is_indexed_and_bounded_in_bytes():
     got = a.older(7, 0, truth(7, 0), n, recs([7], n)["hist"][0])
     assert got.shape == (n - HIST, 2) and np.array_equal(got, np.stack([truth(7, i) for i in range(n - HIST)]))
     assert len(a.by_row[7]) == 10 and a._relatives(7, 0, truth(7, 0)) == []
-    # the row is recycled: a new keypoint (other birth frame) lives there; its lookups do not see the old tenant's entries
-    a.add(np.array([7]), recs([7], EV, t_first=200))
+    # the row is recycled: a new keypoint (other birth frame) lives there; its lookups see its own entries, not the old tenant's
+    new_tenant = recs([7], EV, t_first=200)
+    new_tenant["hist"] += 0.5
+    a.add(np.array([7]), new_tenant)
     r2 = recs([7], HIST + 4, t_first=200)
-    assert np.isnan(a.older(7, 200, truth(7, 0), HIST + 4, r2["hist"][0])).all()       # (entries 0 .. 3 left the ring before the first pass of this tenant)
+    r2["hist"] += 0.5
+    got = a.older(7, 200, truth(7, 0), HIST + 4, r2["hist"][0])
+    assert np.array_equal(got, np.stack([truth(7, i) + 0.5 for i in range(4)]))
     # a copy (row 60) of row 3's keypoint: no record of its own before the copy -> row 3's entries by identity
     cp = recs([3], n)
     a.add(np.array([60]), cp)
