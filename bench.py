@@ -625,6 +625,25 @@ def dropin_step_ms(device, scene, ba_window=4, n_warm=4, n_time=8):
 
 
 
+def _render_one(args):
+    from vo_mi355x import synthetic as syn
+    seed, n = args
+    return syn.make_sequence(n, W_IMG, H_IMG, seed=seed, periodic=True)[0]
+
+
+def render_sequences(seeds, n_frames, parallel=True):
+    """the distinct synthetic image sequences of a rank, rendered side by side in forked workers (4 x 100 frames of 1241 x 376 take ~10 s on one
+    core: a third of the driver's run).  Called before this process touches the GPU -- a fork after that is not allowed on this pool"""
+    if parallel and len(seeds) > 1 and usable_cores() > 1:       # (a multi-rank launch has its rendezvous threads running: no fork there)
+        try:
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(min(len(seeds), usable_cores())) as pool:
+                return pool.map(_render_one, [(sd, n_frames) for sd in seeds])
+        except Exception as e:          # noqa: BLE001
+            sys.stderr.write("bench: parallel rendering failed (%s), rendering in line\n" % e)
+    return [_render_one((sd, n_frames)) for sd in seeds]
+
+
 def usable_cores():
     """host cores this process may actually use: os.cpu_count() capped by the cgroup CPU quota (the GPU box shows 256 cores and
     grants 16: 64 workers there were slower in total than 16)"""
@@ -821,11 +840,11 @@ def cpu_baseline(frames, n_frames, ba_iters):
 CHILD_ENV_DROP = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")
 
 
-def closed_loop_child(a, extra_args, steps=40, timeout=150):
+def closed_loop_child(a, extra_args, steps=40, timeout=150, warmup=10):
     """`bench.py --workload pipeline ...` as a child process -> the short object the compact line carries (the child's full result object goes into
     the side file under the same key + `_full`).  Never raises: an error or a timeout becomes {"error": ...}."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "pipeline", "--ctxs", "1", "--steps", str(steps), "--warmup", "10", "--regions", "3",
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "pipeline", "--ctxs", "1", "--steps", str(steps), "--warmup", str(warmup), "--regions", "3",
            "--no-cpu-baseline", "--full-line", "--extras-file", os.devnull, "--pipe-frames", str(a.pipe_frames), "--pipe-ba-iters", str(a.pipe_ba_iters)] + \
           (["--tune", a.tune] if a.tune else []) + list(extra_args)
     env = {k: v for k, v in os.environ.items() if k not in CHILD_ENV_DROP}
@@ -1340,7 +1359,7 @@ def main():
     else:
         a.ctxs = max(1, min(a.ctxs, a.seqs))
         per = [a.seqs // a.ctxs + (1 if i < a.seqs % a.ctxs else 0) for i in range(a.ctxs)]
-        frame_sets = [syn.make_sequence(a.frames, W_IMG, H_IMG, seed=1234 + 16 * dist.rank + k, periodic=True)[0] for k in range(min(4, a.seqs))]
+        frame_sets = render_sequences([1234 + 16 * dist.rank + k for k in range(min(4, a.seqs))], a.frames, parallel=dist.world == 1)
         seqs = [Group(dist.local_rank, frame_sets, seed0=1000 * dist.rank + 100 * i, batch=per[i], ba_iters=a.ba_iters)
                 for i in range(a.ctxs)]
     t_setup = time.perf_counter() - t_gen
@@ -1596,6 +1615,10 @@ def main():
             # second figure of the line: the coupled loop (Pipeline.step resident on the device) at BASELINE's window and the headline's batch, as a
             # CHILD with a timeout -- whatever it does, the headline built above is printed
             out["closed_loop_w10_256"] = closed_loop_child(a, ["--pipe-window", "10", "--pipe-no-resurrect", "--seqs", str(a.seqs)])
+            # ... and with tables the scene does not fill (8 192 slots per sequence; ~4 200 keypoints tracked): no frame of it is shaped by the
+            # capacity policy (`capacity_policy_frames` 0) -- the reference's unbounded lists at the headline's batch
+            out["closed_loop_w10_uncapped_tables"] = closed_loop_child(a, ["--pipe-window", "10", "--pipe-no-resurrect", "--seqs", str(a.seqs), "--pipe-max-pts", "8192"],
+                                                                       warmup=60)
         if out is not None and dist.world == 1 and a.workload == "A" and a.extras:
             out.update(measure_extras(dist.local_rank, frame_sets, a, dist, cpu_pipe))
     except Exception as e:          # noqa: BLE001  (informational keys must never cost the bench line)

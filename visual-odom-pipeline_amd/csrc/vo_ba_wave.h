@@ -24,6 +24,15 @@
 
 #define BA2_CAM 21           // per window slot in LDS: K R (9), K t (3), Jr (9)
 #define BA2_TARGET_WAVES 2048   // waves a batched launch aims for: 2 per SIMD (the register budget of the build kernel)
+#ifndef BA2_PIN_CAMACC
+#define BA2_PIN_CAMACC 1
+#endif
+#ifndef BA2_SCHED_FENCE
+#define BA2_SCHED_FENCE 0
+#endif
+#ifndef BA2_TERMS_EARLY
+#define BA2_TERMS_EARLY 0       // 1: k_ba_build_w forms a slot's camera sums in pass 1 (experiment, EXPERIMENTS.md round 6)
+#endif
 
 // reciprocal to double precision without the division's scaling / fix-up sequence (the operand is a depth times the focal scale: far
 // from the denormals and from overflow)
@@ -158,6 +167,13 @@ __device__ __forceinline__ ba2_work ba2_select_work(const ba_ptrs& Pall, int it,
   return w;
 }
 
+// a value every lane of the workgroup holds alike, as the compiler cannot know (it came out of LDS): moved to scalar registers, so that the pointers
+// and constants derived from it (the problem's base addresses, K, lambda) stop occupying vector registers -- 30 of the build kernel's 256
+__device__ __forceinline__ int ba2_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double ba2_uniform(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 struct ba2_lin {
   double e0, e1, w, rho;
   double Jl[2][3];
@@ -204,7 +220,8 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
                                                                   // per wave: no room for it -- two workgroups of 4 x 36 x 64 doubles fill a CU's LDS)
   constexpr int NT = RT * (RT + 1) / 2;
   constexpr int REGION = ROWS * PITCH;       // doubles of LDS a wave owns
-  const ba2_work wk = ba2_select_work<true>(Pall, it, G0, Gcap);
+  ba2_work wk = ba2_select_work<true>(Pall, it, G0, Gcap);
+  wk.prob = ba2_uniform(wk.prob); wk.part = ba2_uniform(wk.part); wk.G = ba2_uniform(wk.G);
   if (wk.prob < 0) return;                   // (uniform) more workgroups than the running problems can use
   const ba_ptrs P = ba_select(Pall, wk.prob);
   const int part = wk.part, G = wk.G;
@@ -216,7 +233,7 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // what the decision reads -- the previous state, k_ba_solve's record, the live-slot count -- is requested BEFORE the step statistics are
   // summed: one trip to memory instead of three dependent ones at the head of every workgroup
-  const int n_live_ld = Pall.n_live ? *P.n_live : P.N;
+  const int n_live_ld = ba2_uniform(Pall.n_live ? *P.n_live : P.N);
   ba_state prev;
   ba_info inf;
   if (it > 0) {
@@ -232,7 +249,8 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
     if (part == 0) { P.state[it & 1] = st; Pall.gdyn[(it & 1) * Pall.batch + wk.prob] = G; }
   }
   __syncthreads();
-  const ba_state st = s_st;
+  ba_state st = s_st;
+  st.done = ba2_uniform(st.done); st.cur = ba2_uniform(st.cur); st.lambda = ba2_uniform(st.lambda);
   if (st.done) return;
   unsigned long long* dbgb = (blockIdx.x == 0 && P.dbg) ? P.dbg + 16 : nullptr;
   VO_STAMP(dbgb, 0);
@@ -256,8 +274,9 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
   for (int t = 0; t < 7 * SPL; t++) camacc[t] = 0.0;
   double gm = 0.0;
   const double lam = st.lambda, delta = prm.delta;
-  const double K0 = P.K[0], K1 = P.K[1], K2 = P.K[2], K3 = P.K[3], K4 = P.K[4], K5 = P.K[5], K6 = P.K[6], K7 = P.K[7], K8 = P.K[8];
-  const double Kk[9] = {K0, K1, K2, K3, K4, K5, K6, K7, K8};
+  // (K in SCALAR registers: as vector registers its nine values were 18 of the 256, eight of them spilled and reloaded twice per chunk)
+  const double Kk[9] = {ba2_uniform(P.K[0]), ba2_uniform(P.K[1]), ba2_uniform(P.K[2]), ba2_uniform(P.K[3]), ba2_uniform(P.K[4]), ba2_uniform(P.K[5]),
+                        ba2_uniform(P.K[6]), ba2_uniform(P.K[7]), ba2_uniform(P.K[8])};
   // this lane's landmark and observations of a chunk; the NEXT chunk's are requested before the Gram phase of this one (a trip to HBM / L2
   // at the head of every chunk otherwise, with one other wave on the SIMD to cover it)
   double Xn[3], uon[SPL], von[SPL];
@@ -312,7 +331,11 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
     // ---- pass 1: residual, weight and landmark block of this lane's observations; landmark sums over its slots.  What pass 2 needs again is
     //      kept per slot as 7 values (u, v, 1 / p_2, w, e, rho): the Jacobian blocks of ALL slots of a lane (36 values each) do not fit the
     //      256 registers beside the 80 accumulators, and d(u, v)/dX is 12 operations to form again ----
+#if BA2_TERMS_EARLY
+    double ku[SPL], kv[SPL], kip[SPL], kw[SPL];
+#else
     double ku[SPL], kv[SPL], kip[SPL], kw[SPL], ke0[SPL], ke1[SPL], krho[SPL];
+#endif
     double h00 = 0, h10 = 0, h11 = 0, h20 = 0, h21 = 0, h22 = 0, g0 = 0, g1 = 0, g2 = 0;
 #pragma unroll
     for (int i = 0; i < SPL; i++) {
@@ -330,11 +353,44 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
       const bool inl = sq <= d2;
       const double irs = rsqrt_nr(inl ? 1.0 : sq);            // 1 / |e| (outliers only)
       const double w = inl ? 1.0 : delta * irs;
-      ku[i] = u; kv[i] = v; kip[i] = ip2; kw[i] = w; ke0[i] = e0; ke1[i] = e1;
+      ku[i] = u; kv[i] = v; kip[i] = ip2; kw[i] = w;
+#if !BA2_TERMS_EARLY
+      ke0[i] = e0; ke1[i] = e1;
       krho[i] = inl ? sq : 2.0 * delta * (sq * irs) - d2;
+#endif
       double l0[3], l1[3];
 #pragma unroll
       for (int c = 0; c < 3; c++) { l0[c] = (cam[c] - u * cam[6 + c]) * ip2; l1[c] = (cam[3 + c] - v * cam[6 + c]) * ip2; }
+#if BA2_TERMS_EARLY
+      {
+        // the slot's camera sums HERE, where the landmark's factor and the panel rows are not live yet: the camera block is formed twice (42
+        // operations per slot more), the residual, the cost term and the 28 temporaries never meet pass 2's registers
+        double Jp[2][6];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { Jp[0][3 + c] = (Kk[c] - u * Kk[6 + c]) * ip2; Jp[1][3 + c] = (Kk[3 + c] - v * Kk[6 + c]) * ip2; }
+        {
+          const double c0 = X[1] * l0[2] - X[2] * l0[1], c1 = X[2] * l0[0] - X[0] * l0[2], c2 = X[0] * l0[1] - X[1] * l0[0];
+#pragma unroll
+          for (int c = 0; c < 3; c++) Jp[0][c] = c0 * cam[12 + c] + c1 * cam[15 + c] + c2 * cam[18 + c];
+        }
+        {
+          const double c0 = X[1] * l1[2] - X[2] * l1[1], c1 = X[2] * l1[0] - X[0] * l1[2], c2 = X[0] * l1[1] - X[1] * l1[0];
+#pragma unroll
+          for (int c = 0; c < 3; c++) Jp[1][c] = c0 * cam[12 + c] + c1 * cam[15 + c] + c2 * cam[18 + c];
+        }
+        constexpr int QA[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+        constexpr int QC[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+        const double we0 = w * e0, we1 = w * e1, hrho = 0.5 * (inl ? sq : 2.0 * delta * (sq * irs) - d2);
+        auto term = [&](int t) -> double {
+          if (t < 21) return w * (Jp[0][QA[t]] * Jp[0][QC[t]] + Jp[1][QA[t]] * Jp[1][QC[t]]);
+          if (t < 27) return Jp[0][t - 21] * we0 + Jp[1][t - 21] * we1;
+          return hrho;
+        };
+#pragma unroll
+        for (int n = 0; n < 7; n++)
+          camacc[7 * i + n] += rs16_sum(rs32_sum(term(4 * n), term(4 * n + 1)), rs32_sum(term(4 * n + 2), term(4 * n + 3)));
+      }
+#endif
       const double wl0[3] = {w * l0[0], w * l0[1], w * l0[2]};
       const double wl1[3] = {w * l1[0], w * l1[1], w * l1[2]};
       h00 += wl0[0] * l0[0] + wl1[0] * l1[0];
@@ -346,6 +402,9 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
       g0 += wl0[0] * e0 + wl1[0] * e1;
       g1 += wl0[1] * e0 + wl1[1] * e1;
       g2 += wl0[2] * e0 + wl1[2] * e1;
+#if BA2_SCHED_FENCE
+      __builtin_amdgcn_sched_barrier(0);      // a slot's work is not interleaved with the next slot's (register pressure)
+#endif
     }
     h00 = ba2_group_sum<LPP>(h00); h10 = ba2_group_sum<LPP>(h10); h11 = ba2_group_sum<LPP>(h11);
     h20 = ba2_group_sum<LPP>(h20); h21 = ba2_group_sum<LPP>(h21); h22 = ba2_group_sum<LPP>(h22);
@@ -401,6 +460,7 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
       // camera sums of the slot: 28 values (21 of the upper H_pp, 6 of g_p, the cost) four at a time through two reduce-scatter stages over
       // the landmark bits 5 and 4 of the lane index: the lane with bits (b5, b4) then holds value 4 n + 2 b4 + b5 summed over four of the
       // chunk's landmarks, and keeps adding to it chunk after chunk; the remaining landmark bits are summed once, after the walk
+#if !BA2_TERMS_EARLY
       constexpr int QA[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
       constexpr int QC[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
       const double we0 = w * ke0[i], we1 = w * ke1[i], hrho = 0.5 * krho[i];
@@ -410,8 +470,15 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
         return hrho;
       };
 #pragma unroll
-      for (int n = 0; n < 7; n++)
+      for (int n = 0; n < 7; n++) {
         camacc[7 * i + n] += rs16_sum(rs32_sum(term(4 * n), term(4 * n + 1)), rs32_sum(term(4 * n + 2), term(4 * n + 3)));
+#if BA2_PIN_CAMACC
+        // the sum is taken HERE: left to itself the compiler carries the 14 reduce-scatter results through the Gram phase to the loop's latch and
+        // spills half of the accumulators to make room for them (7 x 8 bytes of scratch stored and reloaded per chunk)
+        asm volatile("" : "+v"(camacc[7 * i + n]));
+#endif
+      }
+#endif
       if (sr < W && !mp.idle) {
         double Z[2][3];
 #pragma unroll
@@ -428,6 +495,9 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
           *reinterpret_cast<double2*>(rw2 + 6 * sr + a) = make_double2(Jp[0][a] * Z[0][2] + Jp[1][a] * Z[1][2], Jp[0][a + 1] * Z[0][2] + Jp[1][a + 1] * Z[1][2]);
         }
       }
+#if BA2_SCHED_FENCE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     if (q == LEAD && !mp.idle) { rw0[6 * W] = inr ? y0 : 0.0; rw1[6 * W] = inr ? y1 : 0.0; rw2[6 * W] = inr ? y2 : 0.0; }
     // ---- Gram matrix of the chunk's panel into the accumulators: one operand fetch per column block and k-step ----
@@ -512,7 +582,8 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
 template <int SPL, int LPP>
 __global__ void __launch_bounds__(256, 2) k_ba_update_w(ba_ptrs Pall, ba_params_dev prm, int it, double* __restrict__ probe_dl, int G0, int Gcap) {
   constexpr int LPC = ba2_map<LPP>::LPC, LEAD = ba2_map<LPP>::LEAD;
-  const ba2_work wk = ba2_select_work<false>(Pall, it, G0, Gcap);
+  ba2_work wk = ba2_select_work<false>(Pall, it, G0, Gcap);
+  wk.prob = ba2_uniform(wk.prob); wk.part = ba2_uniform(wk.part); wk.G = ba2_uniform(wk.G);
   if (wk.prob < 0) return;
   const ba_ptrs P = ba_select(Pall, wk.prob);
   const int part = wk.part, G = wk.G;
@@ -521,7 +592,7 @@ __global__ void __launch_bounds__(256, 2) k_ba_update_w(ba_ptrs Pall, ba_params_
   __shared__ double s_camt[12 * 10];                // trial poses: K R, K t
   __shared__ double s_dp[6 * 10];
   __shared__ double s_red[4 * BA_EVAL_VALS];
-  const ba_state st = P.state[it & 1];
+  const ba_state st = P.state[it & 1];       // (a scalar load: P is uniform now)
   if (st.done) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, W = P.W, N = P.N;
   const double* poses = ba_x(P, st.cur);
@@ -551,10 +622,11 @@ __global__ void __launch_bounds__(256, 2) k_ba_update_w(ba_ptrs Pall, ba_params_
   const int pl = mp.pl, q = mp.q;
   const int lead4 = 4 * (lane - q + LEAD);
   const int nchunk = (N + LPC - 1) / LPC;
-  const int n_live = P.n_live ? *P.n_live : N;
+  const int n_live = ba2_uniform(P.n_live ? *P.n_live : N);
   const int nchunk_live = min(nchunk, (n_live + LPC - 1) / LPC);
   const double lam = st.lambda, delta = prm.delta, d2 = delta * delta;
-  const double Kk[9] = {P.K[0], P.K[1], P.K[2], P.K[3], P.K[4], P.K[5], P.K[6], P.K[7], P.K[8]};
+  const double Kk[9] = {ba2_uniform(P.K[0]), ba2_uniform(P.K[1]), ba2_uniform(P.K[2]), ba2_uniform(P.K[3]), ba2_uniform(P.K[4]), ba2_uniform(P.K[5]),
+                        ba2_uniform(P.K[6]), ba2_uniform(P.K[7]), ba2_uniform(P.K[8])};
   double e0 = 0, e1 = 0, e2 = 0, e3 = 0;
 #pragma unroll 1
   for (int chunk = part * 4 + wave; chunk < nchunk_live; chunk += 4 * G) {

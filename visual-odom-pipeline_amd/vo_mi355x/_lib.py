@@ -11,7 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libvo_mi355x.so")
+# (VO_MI355X_LIB: another build of the same sources -- an experiment compiled beside the shipped library, csrc/Makefile -- for A/B runs in one call)
+LIB_PATH = os.environ.get("VO_MI355X_LIB") or os.path.join(PKG_ROOT, "lib", "libvo_mi355x.so")
 CSRC_DIR = os.path.join(PKG_ROOT, "csrc")
 
 VO_OK = 0
