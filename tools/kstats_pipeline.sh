@@ -22,7 +22,7 @@ for r in rows:
     t = float(r["TotalDurationNs"]) / 1e3
     tot += t
     print("%-26s calls %5s avg %8.1f us  per-step %7.1f us" % (n, r["Calls"], float(r["AverageNs"]) / 1e3, t / steps))
-print("sum per 32-frame step: %.1f us  (incl. the one-off bootstrap launches)" % (tot / steps))
+print("sum per step of the batch: %.1f us  (incl. the one-off bootstrap launches)" % (tot / steps))
 try:
     d = json.loads([l for l in open("$OUT/${TAG}_ks.log") if l.startswith("{")][-1])["pipeline"]
     print("bench line of this run:", {k: d[k] for k in ("frames_per_s", "ms_per_step", "ba_window", "resurrection_of_dead_landmarks", "mean_tracked_keypoints", "mean_landmark_entries", "mean_ba_observations", "ba_iterations_histogram")})
