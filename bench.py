@@ -837,6 +837,49 @@ def cpu_baseline(frames, n_frames, ba_iters):
     return n_frames / dt, dt
 
 
+def seeded_points_figure(device, seqs, frame_sets, a, step, drain):
+    """the headline's step with the tracked points of every sequence = the strongest N_PTS Shi-Tomasi corners of its frame 0 (the build's own
+    detector, the reference's quality level 0.03 and minimum distance 7; a sequence whose frame yields fewer is topped up from the grid)"""
+    from vo_mi355x import VoContext, synthetic as syn
+    corners = []
+    with VoContext(W_IMG, H_IMG, max_pts=max(N_PTS, 4096), device=device) as c:
+        for fs in frame_sets:
+            c.push_frame(fs[0])
+            corners.append(c.shi_tomasi(None, 7, params=c.st_params(max_corners=N_PTS)))
+    n_found = [len(x) for x in corners]
+    for g in seqs:
+        pts = []
+        for b in range(g.B):
+            p = corners[b % len(corners)]
+            if len(p) < N_PTS:
+                p = np.concatenate([p, syn.grid_points(N_PTS, W_IMG, H_IMG, seed=b)[:N_PTS - len(p)]])
+            pts.append(p[:N_PTS])
+        g.c.points_upload(np.stack(pts) if g.B > 1 else pts[0])
+        g.c.push_frame_resident(0)
+        g.t = 1
+    for _ in range(max(6, a.warmup)):
+        step()
+    drain()
+    dts = []
+    for _ in range(3):
+        for g in seqs:
+            g.c.sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        drain()
+        for g in seqs:
+            g.c.sync()
+        dts.append(time.perf_counter() - t0)
+    dt = float(np.median(dts))
+    _, st, _, it = seqs[0].c.points_download(N_PTS, return_iters=True)
+    it = np.maximum(it.reshape(-1, it.shape[-1]), 0)
+    return {"value": round(sum(g.B for g in seqs) * a.steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / a.steps * 1e3, 4),
+            "corners_found_per_distinct_sequence": n_found, "klt_mean_iters_per_level": [round(float(x), 3) for x in it.mean(0)],
+            "tracked_with_status_1": round(float(st.mean()), 4),
+            "what": "tracked points = the build's own Shi-Tomasi corners of frame 0 (max_corners %d, quality 0.03, min distance 7) instead of the jittered grid" % N_PTS}
+
+
 CHILD_ENV_DROP = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")
 
 
@@ -1164,7 +1207,7 @@ def compact_line(full, extras_file=None):
     line["vs_baseline"] = full.get("vs_baseline")
     line.update(_pick(full, ("dtype", "data")))
     cfg = full.get("config") or {}
-    c = _pick(cfg, ("workload", "sequences_per_gpu", "batched_contexts_per_gpu", "frames_per_step", "frames_source", "ba_lm_iteration_budget",
+    c = _pick(cfg, ("workload", "sequences_per_gpu", "batched_contexts_per_gpu", "frames_per_step", "frames_source", "tracked_points", "ba_lm_iteration_budget",
                     "ba_lm_iterations_run", "stream_layout", "launch"))
     if "ba_solves_stopped_by_lm_max_iters" in cfg:
         c["solves_stopped_by_cap"] = cfg["ba_solves_stopped_by_lm_max_iters"]
@@ -1209,13 +1252,13 @@ def compact_line(full, extras_file=None):
         line["cpu_baseline"] = cb
     else:
         line["cpu_baseline"] = None
-    for k in ("resident_frames", "host_frames", "closed_loop_w10_256", "closed_loop_w10_uncapped_tables"):
+    for k in ("resident_frames", "host_frames", "shi_tomasi_seeded_points", "closed_loop_w10_256", "closed_loop_w10_uncapped_tables"):
         if isinstance(full.get(k), dict):
-            line[k] = full[k]
+            line[k] = {kk: v for kk, v in full[k].items() if kk not in ("what", "cmd", "seconds", "frames_counted")}      # (prose stays in the side file)
     if extras_file:
         line["extras_file"] = extras_file
     # never above the limit: shed the optional parts, least important first
-    for drop in (("closed_loop_w10_uncapped_tables",), ("roofline", "kernels"), ("cpu_baseline", "sample"), ("closed_loop_w10_256",), ("host_frames",),
+    for drop in (("shi_tomasi_seeded_points",), ("closed_loop_w10_uncapped_tables",), ("roofline", "kernels"), ("cpu_baseline", "sample"), ("closed_loop_w10_256",), ("host_frames",),
                  ("regions",), ("roofline", "traffic_source"), ("config", "parallelism")):
         if len(json.dumps(line, separators=(",", ":"), allow_nan=False)) < LINE_MAX_BYTES:
             break
@@ -1605,8 +1648,16 @@ def main():
                "stage_ms_per_batched_launch_group": stage, "roofline": roof, "cpu_baseline": cpu,
                "setup_s": round(t_setup, 2)}
         out["config"]["frames_source"] = "resident in HBM (vo_seq_upload); `host_frames`: the same with every frame handed over by the host"
+        out["config"]["tracked_points"] = "jittered grid (SURVEY 8d's fallback); `shi_tomasi_seeded_points`: the build's own corners of frame 0"
         if host_fig is not None:
             out["host_frames"] = host_fig
+    # ---- the tracked points seeded by the build's OWN Shi-Tomasi on frame 0 (SURVEY 8d's first choice; the headline tracks its fallback, a jittered
+    # grid): 2 000 corners per distinct sequence at the reference's quality level and minimum distance, 3 regions of K steps ----
+    if out is not None and dist.world == 1 and a.workload == "A" and not a.no_extras and not c5:
+        try:
+            out["shi_tomasi_seeded_points"] = seeded_points_figure(dist.local_rank, seqs, frame_sets, a, step, drain)
+        except Exception as e:      # noqa: BLE001
+            out["shi_tomasi_seeded_points"] = {"error": repr(e)[:200]}
     dist.barrier()
     for s in seqs:
         s.c.close()
