@@ -77,6 +77,8 @@ def parse():
                          "(+5 %%; a solve the budget cuts cannot be continued in a closed loop -- the next frame already depends on it -- so the default "
                          "enqueues the LM's full --ba-iters, whose surplus groups exit early)")
     ap.add_argument("--pipe-max-pts", type=int, default=2048, help="--workload pipeline: capacity of the tracked keypoint set per sequence (<= 8192)")
+    ap.add_argument("--pipe-host-frames", action="store_true", help="--workload pipeline: every step's images are handed over by the host (page-locked numpy arrays, "
+                    "one per sequence -> vo_pipe_step_host) instead of read from the sequence store in HBM")
     ap.add_argument("--pipe-frames", type=int, default=40, help="--workload pipeline: rendered frames per scene (= the period of the camera's sway; played in a loop)")
     ap.add_argument("--graph", action="store_true", help="replay each frame from a captured hipGraph instead of plain launches")
     ap.add_argument("--host-threads", type=int, default=3, help="enqueue/fetch the contexts from this many host threads")
@@ -359,15 +361,16 @@ class PipeGroup:
     resurrection of recently dead landmarks, 10-frame bundle adjustment + write-back, Shi-Tomasi re-detection + spawn); every stage
     reads what the previous stages and frames left in the device tables.  Up to 3 steps in flight; only the small records come back."""
 
-    def __init__(self, device, scenes, boot_ctx, first, batch, ba_iters, max_pts, fixed_budget, ba_window, resurrect):
+    def __init__(self, device, scenes, boot_ctx, first, batch, ba_iters, max_pts, fixed_budget, ba_window, resurrect, host_frames=False):
         from vo_mi355x import VoContext, synthetic as syn
         from vo_mi355x.resident import ResidentPipeline
         self.B, self.nf = batch, len(scenes[0]["frames"])
         self.c = VoContext(W_IMG, H_IMG, max_pts=max_pts, device=device, batch=batch)
-        frames, states, Ks, self.gt = [], [], [], []
+        frames, states, Ks, self.gt, where = [], [], [], [], []
         for b in range(batch):
             sc = scenes[(first + b) % len(scenes)]
             off = pipe_phase_offsets(sc, first + b + 1)[-1]
+            where.append(((first + b) % len(scenes), off))
             roll = dict(frames=np.roll(sc["frames"], -off, axis=0), poses=np.roll(sc["poses"], -off, axis=0), K=sc["K"], f=sc["f"],
                         surface=lambda t, xy, sc=sc, off=off: sc["surface"]((t + off) % self.nf, xy))
             st, _ = syn.gt_bootstrap(boot_ctx, roll, 0, PIPE_T1)
@@ -375,11 +378,23 @@ class PipeGroup:
             G0 = roll["poses"][0]
             unit = np.linalg.norm((roll["poses"][PIPE_T1] @ np.linalg.inv(G0))[:3, 3])
             self.gt.append((roll["poses"], G0, unit))
-        self.c.upload_sequence(np.stack(frames))
+        self.host = None
+        if host_frames:
+            # the scenes' frames in page-locked host memory (what a loader decodes into); sequence b's image of a step is a numpy view of it
+            store = self.c.host_alloc((len(scenes), self.nf, H_IMG, W_IMG))
+            for k, sc in enumerate(scenes):
+                store[k] = sc["frames"]
+            self._store = store
+            self.host = [self.c.host_frames([store[k, (f + off) % self.nf] for k, off in where]) for f in range(self.nf)]
+        else:
+            self.c.upload_sequence(np.stack(frames))
         self.ba_cap, self.fixed = ba_iters, fixed_budget
         self.rp = ResidentPipeline(self.c, np.stack(Ks), ba_window=ba_window, ba_max_iters=ba_iters, ba_budget=ba_iters, pnp_blind_batches=2, resurrect=resurrect)
         self.rp.seed(states, None, None, t_step=1)
-        self.c.push_frame_resident(PIPE_T1)
+        if host_frames:
+            self.c.push_frame(np.stack([fr[PIPE_T1] for fr in frames]) if batch > 1 else frames[0][PIPE_T1])
+        else:
+            self.c.push_frame_resident(PIPE_T1)
         self.frame, self.inflight, self.max_inflight = PIPE_T1 + 1, 0, 3
         self.recs = []                      # records of the timed region (kept for the statistics)
         self.keep = False
@@ -387,7 +402,10 @@ class PipeGroup:
         self.last = None
 
     def enqueue(self):
-        self.rp.step(self.frame % self.nf)
+        if self.host is not None:
+            self.rp.step_host(self.host[self.frame % self.nf])
+        else:
+            self.rp.step(self.frame % self.nf)
         self.frame += 1
         self.inflight += 1
 
@@ -436,7 +454,7 @@ def run_pipeline(device, a, dist, n_ctx, per_ctx, steps, warmup, regions, scenes
     if scenes is None:
         scenes = pipe_scenes(2, a.pipe_frames, 4321 + 16 * dist.rank)
     boot = VoContext(W_IMG, H_IMG, max_pts=4096, device=device)
-    groups = [PipeGroup(device, scenes, boot, i * per_ctx, per_ctx, a.pipe_ba_iters, max_pts, not a.pipe_adaptive_budget, a.pipe_window, not a.pipe_no_resurrect) for i in range(n_ctx)]
+    groups = [PipeGroup(device, scenes, boot, i * per_ctx, per_ctx, a.pipe_ba_iters, max_pts, not a.pipe_adaptive_budget, a.pipe_window, not a.pipe_no_resurrect, a.pipe_host_frames) for i in range(n_ctx)]
     boot.close()
     t_setup = time.perf_counter() - t0
     pool = None
@@ -507,6 +525,7 @@ def run_pipeline(device, a, dist, n_ctx, per_ctx, steps, warmup, regions, scenes
            "ms_per_step": round(dt / steps * 1e3, 4), "sequences": n_seq, "contexts": n_ctx,
            "steps": steps, "regions_ms_per_step": [round(x / steps * 1e3, 4) for x in region_dt],
            "sequences_alive_at_end": alive, "frames_in_sequence": scenes[0]["frames"].shape[0], "max_tracked_keypoints": max_pts,
+           "frames_source": "host (page-locked arrays -> vo_pipe_step_host)" if a.pipe_host_frames else "resident in HBM (vo_seq_upload)",
            "ba_window": a.pipe_window, "resurrection_of_dead_landmarks": not a.pipe_no_resurrect, "ba_lm_iteration_cap": a.pipe_ba_iters, "ba_budget": "adaptive (newest fetched frame's maximum + 2)" if a.pipe_adaptive_budget else "the LM's full --ba-iters every frame (surplus groups exit early)",
            "mean_tracked_keypoints": mean("n_tracked"), "mean_landmark_entries": mean("n_landmarks"), "mean_candidates": mean("n_candidates"),
            "mean_pnp_inliers": mean("pnp_inliers"), "mean_new_landmarks": mean("n_new"), "mean_resurrected": mean("n_resurrected"),

@@ -476,6 +476,11 @@ int32_t vo_pipe_commit(vo_ctx* ctx);
  * default) the re-detection and spawn of frame t and the pyramid + KLT of frame t + 1 (frame_idx >= 0) run beside the bundle
  * adjustment of frame t; results are bit-identical to the one-stream order.  Many sequences: ONE context with a large batch. */
 int32_t vo_pipe_step(vo_ctx* ctx, int32_t frame_idx, int32_t stages);
+/* the same step with the frame handed over by the host, as the reference's loop does (Pipeline.step(img): src/pipeline/pipeline.py:98,171-172):
+ * frames[b] = the new image of sequence b (rows of `stride` bytes).  Upload on the copy stream (see vo_frame_step_host: one gather launch for
+ * page-locked images), pyramid + tracking on the side stream behind it -- the overlap of a resident frame.  `stages` must contain VO_PIPE_TRACK.
+ * Page-locked images must stay untouched until the step has been fetched. */
+int32_t vo_pipe_step_host(vo_ctx* ctx, const uint8_t* const* frames, int32_t stride, int32_t stages);
 int32_t vo_pipe_fetch(vo_ctx* ctx, vo_pipe_record* rec /* [batch] */);        /* waits for the OLDEST step not fetched yet */
 int32_t vo_pipe_set_ba_budget(vo_ctx* ctx, int32_t budget);
 /* Read-backs for the object boundary (vo_mi355x/lazy.py: the reference's Extractor / BundleAdjuster interface, src/extractor/extractor.py:38-277 and
@@ -515,7 +520,8 @@ typedef struct {
   int32_t xcd_remap_off;       /* 1: plain (block, sequence) order instead of one sequence per XCD */
   int32_t gate_groups;         /* stream layout 2: LM launch groups of frame t ahead of the tracker launch of frame t + 1; -1: none */
   int32_t reserve_cus;         /* stream layout 2: compute units the front-end stream leaves free; -1: none */
-  int32_t reserved[14];
+  int32_t gather_workgroups;   /* frames from the host: workgroups of k_gather_frames (rule: 2 per image in the gated layout of a batch, else 32) */
+  int32_t reserved[13];
 } vo_tuning;
 int32_t vo_get_tuning(vo_ctx* ctx, vo_tuning* out);
 int32_t vo_set_tuning(vo_ctx* ctx, const vo_tuning* t);

@@ -489,3 +489,58 @@ def test_tables_beyond_4096_slots_at_1080p_window20():
         for t in range(model.t + 1):
             assert np.abs(e["poses"][t] - model.poses[t]).max() <= 1e-7, (what, t)
     assert biggest > 4096, biggest          # reached with nothing cut
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("source", ["pinned", "pageable"])
+def test_closed_loop_with_host_frames_equals_resident_frames(source):
+    """`vo_pipe_step_host` (the new frame handed over by the host, as Pipeline.step(img) receives it: pipeline.py:98,171-172; upload on the copy
+    stream, pyramid + tracking on the side stream) = `vo_pipe_step` on the uploaded sequence: records and tables bit for bit, three steps in flight,
+    a batch of 3 sequences; page-locked images (one gather launch) and pageable ones (staged copies)"""
+    from vo_mi355x import VoContext
+    from vo_mi355x.resident import ResidentPipeline
+    w, h, t1, n = 256, 160, 3, 9
+    scs = [ph.scene(t1 + n + 1, w=w, h=h, f=260.0, seed=sd, pose_fn=lambda t: ph.sway_pose(t, period=24.0)) for sd in (2024, 77)]
+    order = [0, 1, 0]
+    boot = _ctx(w, h)
+    states = [ph.gt_bootstrap(boot, sc, 0, t1)[0] for sc in scs]
+    frames = np.stack([scs[i]["frames"] for i in order])            # [3, frames, h, w]
+
+    def run(host):
+        c = _ctx(w, h, batch=3)
+        rp = ResidentPipeline(c, np.stack([scs[i]["K"] for i in order]), ba_max_iters=12)
+        rp.seed([copy.deepcopy(states[i]) for i in order], None, None, 1)
+        if host is None:
+            c.upload_sequence(frames)
+            c.push_frame_resident(t1)
+        else:
+            c.push_frame(frames[:, t1])
+        recs = []
+        for s0 in range(0, n, 3):
+            for s in range(s0, s0 + 3):
+                if host is None:
+                    rp.step(t1 + 1 + s)
+                else:
+                    rp.step_host(host(t1 + 1 + s))
+            for s in range(s0, s0 + 3):
+                recs.append(rp.fetch())
+        return recs, rp.read_tables()
+
+    ref_recs, ref_T = run(None)
+    if source == "pinned":
+        store = VoContext.host_alloc(scs[0]["frames"].shape[:1] + (2,) + (h, w))      # [frame][scene][h][w]: sequences 0 and 2 share an image
+        for k in range(2):
+            store[:, k] = scs[k]["frames"]
+        give = lambda f: [store[f, i] for i in order]
+    else:
+        give = lambda f: [scs[i]["frames"][f] for i in order]
+    got_recs, got_T = run(give)
+    for s in range(n):
+        for b in range(3):
+            for k, v in ref_recs[s][b].items():
+                if isinstance(v, np.ndarray):
+                    assert np.array_equal(got_recs[s][b][k], v), (s, b, k)
+                else:
+                    assert got_recs[s][b][k] == v, (s, b, k, got_recs[s][b][k], v)
+    for name in ref_T:
+        assert np.array_equal(got_T[name], ref_T[name]), name

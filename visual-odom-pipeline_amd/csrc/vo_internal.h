@@ -89,6 +89,7 @@ struct vo_ctx {
   hipEvent_t ev_h2d[2] = {nullptr, nullptr};        // the upload into d_host_raw[k] is complete (recorded on stream_h2d, awaited by the ctx stream)
   hipEvent_t ev_raw_free[2] = {nullptr, nullptr};   // the pyramid has read d_host_raw[k] (recorded on the ctx stream, awaited by stream_h2d)
   bool raw_free_recorded[2] = {false, false};
+  int pipe_host_slot = 0;                           // vo_pipe_step_host alternates the two buffers on its own count
   const uint8_t** h_ptr_tab = nullptr;              // page-locked [2][batch]: device-visible addresses of a step's images (read by k_gather_frames)
   uint8_t* d_seq = nullptr;          // preloaded sequences [batch][seq_n][h][w] (vo_seq_upload)
   int seq_n = 0;
@@ -202,6 +203,8 @@ static inline int vo_div_up(int a, int b) { return (a + b - 1) / b; }
 
 // cross-unit internals used by the fused frame step (vo_step.hip)
 int32_t vo_build_pyramid(vo_ctx* c, const uint8_t* d_raw_img, size_t raw_seq_stride, const int32_t* d_frame_idx);
+// a step's `batch` images from the host into d_host_raw[slot] on the copy stream (vo_step.hip); ev_h2d[slot] is recorded behind it
+int32_t vo_host_frames_upload(vo_ctx* c, const uint8_t* const* frames, int32_t stride, int slot);
 int32_t vo_ba_enqueue_pub_copy(vo_ctx* c, int half);     // half: which pinned mirror (0 / 1)
 void vo_ba_unpack_pub(vo_ctx* c, int half, double* poses_out, double* points_out, vo_ba_stats* stats);   // arrays over the batch
 bool vo_ba_ready(const vo_ctx* c);

@@ -1396,8 +1396,31 @@ extern "C" int32_t vo_pipe_set_ba_budget(vo_ctx* c, int32_t budget) {
 
 static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main_dirty);
 
+#define PIPE_FRAME_FROM_HOST (-2)      // internal frame index: the step's images are in c->d_host_raw[c->pipe_host_slot] behind ev_h2d
+
+static int32_t pipe_step_entry(vo_ctx* c, int32_t frame_idx, int32_t stages);
+
 extern "C" int32_t vo_pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages) {
   if (!c) return VO_E_INVALID;
+  return pipe_step_entry(c, frame_idx < 0 ? -1 : frame_idx, stages);
+}
+
+// the same step with this frame's images handed over by the host (Pipeline.step(img), pipeline.py:98,171-172): the upload runs on the copy stream
+// (k_gather_frames for page-locked images), the pyramid + tracking of the step on the side stream behind it, exactly like a resident frame
+extern "C" int32_t vo_pipe_step_host(vo_ctx* c, const uint8_t* const* frames, int32_t stride, int32_t stages) {
+  if (!c) return VO_E_INVALID;
+  VO_CHECK(c, c->pipe, VO_E_STATE, "vo_pipe_create first");
+  VO_CHECK(c, frames != nullptr && stride >= c->width, VO_E_INVALID, "bad frame pointers / stride");
+  VO_CHECK(c, (stages & VO_PIPE_TRACK) != 0, VO_E_INVALID, "a step that takes a frame tracks it (VO_PIPE_TRACK)");
+  for (int b = 0; b < c->batch; b++) VO_CHECK(c, frames[b] != nullptr, VO_E_INVALID, "null frame pointer");
+  VO_CHECK(c, c->pipe->enq - c->pipe->fetched < VO_PIPE_INFLIGHT, VO_E_STATE, "vo_pipe_fetch the oldest step first");
+  VO_HIP(c, hipSetDevice(c->device));
+  c->pipe_host_slot ^= 1;
+  { const int32_t ru = vo_host_frames_upload(c, frames, stride, c->pipe_host_slot); if (ru != VO_OK) return ru; }
+  return pipe_step_entry(c, PIPE_FRAME_FROM_HOST, stages);
+}
+
+static int32_t pipe_step_entry(vo_ctx* c, int32_t frame_idx, int32_t stages) {
   VO_CHECK(c, c->pipe, VO_E_STATE, "vo_pipe_create first");
   VO_CHECK(c, c->pipe->enq - c->pipe->fetched < VO_PIPE_INFLIGHT, VO_E_STATE, "vo_pipe_fetch the oldest step first");
   VO_HIP(c, hipSetDevice(c->device));
@@ -1451,9 +1474,10 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
     return vo_fail(c, VO_E_STATE, "pipe_step: VO_PIPE_TRACK_CANDIDATES without VO_PIPE_TRACK (the candidates' half follows the tracking in the same call)");
   if (stages & (VO_PIPE_TRACK | VO_PIPE_TRACK_LANDMARKS)) w->lm_half_pending = (stages & VO_PIPE_TRACK) && halves == 1;
   if (stages & VO_PIPE_TRACK) {
+    const bool from_host = frame_idx == PIPE_FRAME_FROM_HOST, has_frame = frame_idx >= 0 || from_host;
     if (frame_idx >= 0) VO_CHECK(c, c->d_seq && frame_idx < c->seq_n, VO_E_STATE, "no resident sequence / bad frame index");
-    VO_CHECK(c, c->n_pushed + (frame_idx >= 0 ? 1 : 0) >= 2, VO_E_STATE, "tracking needs two frames in the frame store");
-    const bool track_side = side && frame_idx >= 0;
+    VO_CHECK(c, c->n_pushed + (has_frame ? 1 : 0) >= 2, VO_E_STATE, "tracking needs two frames in the frame store");
+    const bool track_side = side && has_frame;
     r = VO_OK;
     if (track_side && main_dirty) {
       // between two pipe steps the side stream needs no order against the main stream beyond the events below (that is the overlap); after
@@ -1464,7 +1488,13 @@ static int32_t pipe_step(vo_ctx* c, int32_t frame_idx, int32_t stages, bool main
     // (the pyramid on a stream of its own, ahead of the side stream's re-detection: measured, slower -- every cross-stream event costs more
     //  than the five launches it would overlap; one context of 96 sequences 37.5 k against 39.0 k frames/s, one sequence 2 320 against 2 715)
     if (track_side) c->stream = c->stream2;
-    if (frame_idx >= 0) {
+    if (from_host) {
+      const int slot = c->pipe_host_slot;
+      const hipError_t ew = hipStreamWaitEvent(c->stream, c->ev_h2d[slot], 0);
+      if (ew != hipSuccess) { c->stream = main_stream; VO_HIP(c, ew); }
+      r = vo_build_pyramid(c, c->d_host_raw[slot], (size_t)c->width * c->height, nullptr);
+      if (r == VO_OK && hipEventRecord(c->ev_raw_free[slot], c->stream) == hipSuccess) c->raw_free_recorded[slot] = true;
+    } else if (frame_idx >= 0) {
       const size_t fr = (size_t)c->width * c->height;
       r = vo_build_pyramid(c, c->d_seq + (size_t)frame_idx * fr, fr * c->seq_n, nullptr);
     }

@@ -199,38 +199,45 @@ static uint64_t step_signature(vo_ctx* c, const step_cfg& s) {
 
 // ---- frames from the host -------------------------------------------------------------------------------------------------------------
 // Page-locked host arrays are read by the GPU itself over PCIe: ONE launch per step gathers the `batch` images (wherever each of them lies,
-// whatever their row stride) into d_host_raw[half] -- a copy-engine transfer per image cost ~32 us each (256 images: 8 ms for 119 MB).  A
-// workgroup column per image, a thread moves 16 bytes per trip, U trips in flight per thread: a few hundred KB outstanding hide the bus latency.
+// whatever their row stride) into d_host_raw[half] -- a copy-engine transfer per image cost ~32 us each (256 images: 8 ms for 119 MB).
+// FEW workgroups take the images in turn, U chunks in flight per lane (tools/pcie_gather_probe.hip: 32 workgroups x 256 lanes x 4 chunks reach
+// the bus's 56 GB/s; more buy nothing): the kernel's waves sit on a few compute units for the 2.1 ms the bus needs instead of two on every
+// SIMD of the chip beside the tracker.
 template <int U>
-__global__ __launch_bounds__(256) void k_gather_frames(const uint8_t* const* __restrict__ tab, int stride, int w, int h, uint8_t* __restrict__ dst, size_t fr) {
-  const uint8_t* __restrict__ src = tab[blockIdx.y];
-  uint8_t* __restrict__ d = dst + (size_t)blockIdx.y * fr;
-  const int cpr = (w + 15) >> 4, n = cpr * h, T = (int)gridDim.x * 256;
-  for (int i0 = (int)blockIdx.x * 256 + (int)threadIdx.x; i0 < n; i0 += U * T) {
-    uint4 v[U];
-    int so[U], dn[U], len[U];
+__global__ __launch_bounds__(256) void k_gather_frames(const uint8_t* const* __restrict__ tab, int stride, int w, int h, uint8_t* __restrict__ dst, size_t fr, int n_img,
+                                                        int parts) {
+  // a workgroup takes (image, part) units in turn -- a part = a contiguous 1 / parts of an image's 16-byte chunks (rows) --, its lanes walk the
+  // unit with a fixed stride: no division per chunk (beside the tracker a wave of this kernel gets one issue slot in seven; index arithmetic
+  // is what it cannot afford)
+  for (int unit = (int)blockIdx.x; unit < n_img * parts; unit += (int)gridDim.x) {
+    const int img = unit / parts, part = unit - img * parts;
+    const uint8_t* __restrict__ src = tab[img];
+    uint8_t* __restrict__ d = dst + (size_t)img * fr;
+    if (h == 1) {                                                          // rows contiguous: one run of w bytes
+      const int n16 = w >> 4, per = (n16 + parts - 1) / parts, lo = part * per, hi = min(n16, lo + per);
+      for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += U * 256) {
+        uint4 v[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int i = i0 + u * T;
-      len[u] = 0;
-      if (i < n) {
-        const int row = i / cpr, ch = i - row * cpr;
-        so[u] = row * stride + ch * 16; dn[u] = row * w + ch * 16;
-        len[u] = min(16, w - ch * 16);
-        if (len[u] == 16) __builtin_memcpy(&v[u], src + so[u], 16);          // (any alignment: the images of a batch lie w * h bytes apart)
+        for (int u = 0; u < U; u++) if (i0 + u * 256 < hi) __builtin_memcpy(&v[u], src + (size_t)(i0 + u * 256) * 16, 16);   // (any alignment)
+#pragma unroll
+        for (int u = 0; u < U; u++) if (i0 + u * 256 < hi) __builtin_memcpy(d + (size_t)(i0 + u * 256) * 16, &v[u], 16);
       }
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (len[u] == 16) __builtin_memcpy(d + dn[u], &v[u], 16);
-      else for (int k = 0; k < len[u]; k++) d[dn[u] + k] = src[so[u] + k];
+      if (part == parts - 1) for (int k = (n16 << 4) + (int)threadIdx.x; k < w; k += 256) d[k] = src[k];
+    } else {
+      const int n16 = w >> 4, per = (h + parts - 1) / parts, lo = part * per, hi = min(h, lo + per);
+      for (int row = lo + ((int)threadIdx.x >> 6); row < hi; row += 4) {   // a wave per row
+        const uint8_t* s = src + (size_t)row * stride;
+        uint8_t* o = d + (size_t)row * w;
+        for (int c = (int)threadIdx.x & 63; c < n16; c += 64) { uint4 v; __builtin_memcpy(&v, s + c * 16, 16); __builtin_memcpy(o + c * 16, &v, 16); }
+        for (int k = (n16 << 4) + ((int)threadIdx.x & 63); k < w; k += 64) o[k] = s[k];
+      }
     }
   }
 }
 
 // the upload of a host-frame step on the copy stream into d_host_raw[half].  Page-locked images: the gather kernel; pageable ones: a copy per
 // image (runs of images that follow each other in host memory -- a [batch][h][w] array -- go as ONE copy), which the runtime stages
-static int32_t host_frames_upload(vo_ctx* c, const uint8_t* const* frames, int32_t stride, int half) {
+int32_t vo_host_frames_upload(vo_ctx* c, const uint8_t* const* frames, int32_t stride, int half) {
   const size_t fr = (size_t)c->width * c->height;
   if (!c->stream_h2d) {
     VO_HIP(c, hipStreamCreateWithFlags(&c->stream_h2d, hipStreamNonBlocking));
@@ -256,10 +263,16 @@ static int32_t host_frames_upload(vo_ctx* c, const uint8_t* const* frames, int32
   if (pinned) {
     const bool flat = stride == c->width;
     const int w = flat ? (int)fr : c->width, h = flat ? 1 : c->height;
-    const int chunks = ((w + 15) >> 4) * h;
-    int gx = vo_div_up(256, c->batch) * 2;                                   // ~512 workgroups: 2 per compute unit, 2 MB in flight
-    gx = gx > vo_div_up(chunks, 1024) ? vo_div_up(chunks, 1024) : gx;
-    hipLaunchKernelGGL(k_gather_frames<4>, dim3(gx < 1 ? 1 : gx, c->batch), dim3(256), 0, c->stream_h2d, tab, flat ? (int)fr : stride, w, h, dst, fr);
+    // how many workgroups: the bus is saturated from 32 x 256 lanes on (tools/pcie_gather_probe.hip), so the count is about who else is on the chip.
+    // Gated layout of a batch (compute units set aside beside the tracker): many short units, they find the free compute units (512 workgroups:
+    // host frames = resident frames; 32: 0.90 x).  Otherwise (closed loop, one stream layouts): few -- every resident workgroup of this kernel
+    // holds wave slots for the 2.1 ms the bus needs, and the one-workgroup-per-problem kernels of the LM chain wait for compute units with
+    // sixteen free ones (closed loop, 256 sequences: 47 300 frames/s with 16-32 workgroups, 41 700 with 128, 35 600 with 512)
+    int parts = 1, gx = 32;
+    if (c->side_stream == 2 && c->stream_reserve > 0) { parts = 2; gx = 2 * c->batch; }
+    if (c->tune.gather_workgroups > 0) { gx = c->tune.gather_workgroups; parts = gx > c->batch ? (gx + c->batch - 1) / c->batch : 1; }
+    if (gx > parts * c->batch) gx = parts * c->batch;
+    hipLaunchKernelGGL(k_gather_frames<4>, dim3(gx), dim3(256), 0, c->stream_h2d, tab, flat ? (int)fr : stride, w, h, dst, fr, c->batch, parts);
     VO_HIP(c, hipGetLastError());
     VO_HIP(c, hipEventRecord(c->ev_h2d[half], c->stream_h2d));
     return VO_OK;
@@ -332,7 +345,7 @@ static int32_t frame_step(vo_ctx* c, int32_t frame_idx, const uint8_t* const* ho
   VO_CHECK(c, c->steps_enq - c->steps_fetched < 2, VO_E_STATE, "vo_frame_fetch the previous step(s) first");
   c->main_dirty = true;
   const int half = (int)(c->steps_enq & 1);
-  if (host_frames) { const int32_t ru = host_frames_upload(c, host_frames, stride, half); if (ru != VO_OK) return ru; }
+  if (host_frames) { const int32_t ru = vo_host_frames_upload(c, host_frames, stride, half); if (ru != VO_OK) return ru; }
   const bool graph_ok = c->use_graph && c->prof.mask == 0 && c->n_pushed >= 2 && !host_frames;     // (host frames: plain launches)
   if (!graph_ok) {
     bool recorded = false;
@@ -514,7 +527,8 @@ extern "C" int32_t vo_set_tuning(vo_ctx* c, const vo_tuning* t) {
 #else
   VO_CHECK(c, t->klt_pair == 0 || (t->klt_pair >= 3 && t->klt_pair <= 5), VO_E_INVALID, "klt_pair: 3, 4 or 5");
 #endif
-  for (int k = 0; k < 14; k++) VO_CHECK(c, t->reserved[k] == 0, VO_E_INVALID, "reserved fields must be 0");
+  VO_CHECK(c, t->gather_workgroups >= 0 && t->gather_workgroups <= 65536, VO_E_INVALID, "gather_workgroups out of range");
+  for (int k = 0; k < 13; k++) VO_CHECK(c, t->reserved[k] == 0, VO_E_INVALID, "reserved fields must be 0");
   VO_HIP(c, hipSetDevice(c->device));
   { const int32_t rq = vo_quiesce_side(c); if (rq != VO_OK) return rq; }
   c->tune = *t;

@@ -42,12 +42,13 @@ class BaParams(C.Structure):
 
 
 TUNING_FIELDS = ("ba_kernels", "ba_lanes", "ba_threads", "ba_pitch_pad", "ba_chunks", "ba_workgroups", "ba_workgroup_cap", "ba_fold", "klt_waves", "klt_pair",
-                 "st_two_kernels", "st_band_rows", "st_separate_nms", "st_keep_eig", "st_host_limit", "xcd_remap_off", "gate_groups", "reserve_cus")
+                 "st_two_kernels", "st_band_rows", "st_separate_nms", "st_keep_eig", "st_host_limit", "xcd_remap_off", "gate_groups", "reserve_cus",
+                 "gather_workgroups")
 
 
 class Tuning(C.Structure):
     """vo_tuning: forced forms for parity tests and A/B measurements; 0 = the library's rule"""
-    _fields_ = [(k, C.c_int32) for k in TUNING_FIELDS] + [("reserved", C.c_int32 * 14)]
+    _fields_ = [(k, C.c_int32) for k in TUNING_FIELDS] + [("reserved", C.c_int32 * 13)]
 
 
 class PnpParams(C.Structure):
@@ -181,6 +182,7 @@ SIGNATURES = {
     "vo_pipe_table_write": (C.c_int32, [_ctx, C.c_int32, C.c_void_p]),
     "vo_pipe_table_read": (C.c_int32, [_ctx, C.c_int32, C.c_void_p]),
     "vo_pipe_commit": (C.c_int32, [_ctx]),
+    "vo_pipe_step_host": (C.c_int32, [_ctx, C.POINTER(C.c_void_p), C.c_int32, C.c_int32]),
     "vo_pipe_step": (C.c_int32, [_ctx, C.c_int32, C.c_int32]),
     "vo_pipe_fetch": (C.c_int32, [_ctx, C.POINTER(PipeRecord)]),
     "vo_pipe_set_ba_budget": (C.c_int32, [_ctx, C.c_int32]),

@@ -91,6 +91,15 @@ class ResidentPipeline:
         self.ctx._ck(self._L.vo_pipe_step(self.ctx._h, int(frame_idx), int(stages)))
         self._inflight += 1
 
+    def step_host(self, frames, stages=ALL):
+        """enqueue one frame whose images the HOST hands over (one uint8 [h, w] array per sequence, or the tuple `VoContext.host_frames` returns):
+        Pipeline.step(img) of the reference (pipeline.py:98,171-172).  The upload runs on the copy stream, pyramid + tracking on the side stream.
+        Arrays over page-locked memory (`VoContext.host_alloc`) must stay untouched until the step has been fetched (they are kept referenced)."""
+        ptrs, stride, frames = frames if isinstance(frames, tuple) and len(frames) == 3 and isinstance(frames[1], int) else self.ctx.host_frames(frames)
+        self.ctx._ck(self._L.vo_pipe_step_host(self.ctx._h, ptrs, int(stride), int(stages)))
+        self._inflight += 1
+        self._host_refs = (getattr(self, "_host_refs", []) + [frames])[-4:]
+
     def fetch(self):
         """records of the OLDEST step in flight: list of dicts, one per sequence (a dict when batch == 1)"""
         rec = (PipeRecord * self.B)()
