@@ -1544,7 +1544,7 @@ def main():
     host_fig = None
     if not c5 and not a.no_extras and not a.graph:
         try:
-            h2d_bytes = sum(s.use_host_frames(True) for s in seqs)
+            h2d_bytes = dist.sum(float(sum(s.use_host_frames(True) for s in seqs)))      # all ranks: every GPU has its own link to the host
             for _ in range(max(4, a.warmup)):
                 step()
             drain()
