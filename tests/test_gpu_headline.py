@@ -98,3 +98,46 @@ def test_headline_shape_256_sequences_against_the_oracle():
         assert its_all.min() >= 3 and its_all.max() <= 30 and len(np.unique(its_all)) >= 3
     finally:
         g.c.close()
+
+
+def test_closed_loop_figure_256_sequences_equals_its_sequences_alone():
+    """`closed_loop_w10_256` of the bench line (bench.PipeGroup: Pipeline.step resident on the device, BASELINE's window 10, dead landmarks stay dead,
+    2 048-slot tables, 256 sequences in ONE context, three steps in flight): sequences 0, 1 and 255 of the batch against the same sequences stepped
+    ALONE in a context of their own -- every integer of the record (list lengths, inliers, new / detected / resurrected counts, LM iterations, status,
+    capacity flags) equal, poses and costs to 1e-9 (a batch folds a problem's partial sums in another order than a single problem: ~1e-12)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from vo_mi355x import VoContext
+    n_steps = 5
+    scenes = bench.pipe_scenes(2, 12, 4321)
+    boot = VoContext(bench.W_IMG, bench.H_IMG, max_pts=4096, device=0)
+    try:
+        big = bench.PipeGroup(0, scenes, boot, 0, 256, 10, 2048, True, 10, False)
+        try:
+            recs = []
+            for _ in range(n_steps):
+                big.enqueue()
+                if big.inflight == 3:
+                    big.fetch(); recs.append(big.last)
+            while big.inflight:
+                big.fetch(); recs.append(big.last)
+        finally:
+            big.c.close()
+        assert len(recs) == n_steps and all(r["status"] == 0 for step in recs for r in step)
+        for b in (0, 1, 255):
+            one = bench.PipeGroup(0, scenes, boot, b, 1, 10, 2048, True, 10, False)
+            try:
+                for s in range(n_steps):
+                    one.enqueue(); one.fetch()
+                    ref, got = one.last[0], recs[s][b]
+                    for k, v in ref.items():
+                        if isinstance(v, np.ndarray):
+                            assert np.abs(got[k] - v).max() <= 1e-9, (b, s, k)
+                        elif isinstance(v, float):
+                            assert abs(got[k] - v) <= 1e-9 * max(1.0, abs(v)), (b, s, k, got[k], v)
+                        else:
+                            assert got[k] == v, (b, s, k, got[k], v)
+            finally:
+                one.c.close()
+    finally:
+        boot.close()
