@@ -125,3 +125,28 @@ def test_ctypes_mirrors_have_the_c_structs_sizes(tmp_path):
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     for (name, mirror), size in zip(pairs, got):
         assert ctypes.sizeof(mirror) == size, (name, ctypes.sizeof(mirror), size)
+
+
+def test_headline_ba_kernels_keep_their_register_budget():
+    """`k_ba_build_w<4, 2, 5>` / `k_ba_update_w<2, 5>` (the headline's window-10 instances) must fit 256 vector registers at two waves per SIMD WITHOUT
+    scratch: round 5 shipped the build kernel with 136 bytes per lane of spills (stored and reloaded per landmark chunk: 10 % of the fully active launch).
+    hipcc's resource remarks of a device-only compile (cross-compiles here, no GPU)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "visual-odom-pipeline_amd", "csrc")
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+                        "-fgpu-default-stream=per-thread", "-I", os.path.join(ROOT, "include"), "-I", src, "-S", "--cuda-device-only",
+                        "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, os.path.join(src, "vo_ba.hip")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rem = r.stderr
+    seen = 0
+    for mangled in ("_Z12k_ba_build_wILi4ELi2ELi5EE", "_Z13k_ba_update_wILi2ELi5EE"):
+        m = re.search(r"Function Name: %s\S*.*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)" % mangled, rem, flags=re.S)
+        assert m, mangled
+        vgprs, scratch, occ = (int(x) for x in m.groups())
+        assert scratch == 0 and vgprs <= 256 and occ >= 2, (mangled, vgprs, scratch, occ)
+        seen += 1
+    assert seen == 2

@@ -24,15 +24,6 @@
 
 #define BA2_CAM 21           // per window slot in LDS: K R (9), K t (3), Jr (9)
 #define BA2_TARGET_WAVES 2048   // waves a batched launch aims for: 2 per SIMD (the register budget of the build kernel)
-#ifndef BA2_PIN_CAMACC
-#define BA2_PIN_CAMACC 1
-#endif
-#ifndef BA2_SCHED_FENCE
-#define BA2_SCHED_FENCE 0
-#endif
-#ifndef BA2_TERMS_EARLY
-#define BA2_TERMS_EARLY 0       // 1: k_ba_build_w forms a slot's camera sums in pass 1 (experiment, EXPERIMENTS.md round 6)
-#endif
 
 // reciprocal to double precision without the division's scaling / fix-up sequence (the operand is a depth times the focal scale: far
 // from the denormals and from overflow)
@@ -331,11 +322,7 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
     // ---- pass 1: residual, weight and landmark block of this lane's observations; landmark sums over its slots.  What pass 2 needs again is
     //      kept per slot as 7 values (u, v, 1 / p_2, w, e, rho): the Jacobian blocks of ALL slots of a lane (36 values each) do not fit the
     //      256 registers beside the 80 accumulators, and d(u, v)/dX is 12 operations to form again ----
-#if BA2_TERMS_EARLY
-    double ku[SPL], kv[SPL], kip[SPL], kw[SPL];
-#else
     double ku[SPL], kv[SPL], kip[SPL], kw[SPL], ke0[SPL], ke1[SPL], krho[SPL];
-#endif
     double h00 = 0, h10 = 0, h11 = 0, h20 = 0, h21 = 0, h22 = 0, g0 = 0, g1 = 0, g2 = 0;
 #pragma unroll
     for (int i = 0; i < SPL; i++) {
@@ -354,43 +341,11 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
       const double irs = rsqrt_nr(inl ? 1.0 : sq);            // 1 / |e| (outliers only)
       const double w = inl ? 1.0 : delta * irs;
       ku[i] = u; kv[i] = v; kip[i] = ip2; kw[i] = w;
-#if !BA2_TERMS_EARLY
       ke0[i] = e0; ke1[i] = e1;
       krho[i] = inl ? sq : 2.0 * delta * (sq * irs) - d2;
-#endif
       double l0[3], l1[3];
 #pragma unroll
       for (int c = 0; c < 3; c++) { l0[c] = (cam[c] - u * cam[6 + c]) * ip2; l1[c] = (cam[3 + c] - v * cam[6 + c]) * ip2; }
-#if BA2_TERMS_EARLY
-      {
-        // the slot's camera sums HERE, where the landmark's factor and the panel rows are not live yet: the camera block is formed twice (42
-        // operations per slot more), the residual, the cost term and the 28 temporaries never meet pass 2's registers
-        double Jp[2][6];
-#pragma unroll
-        for (int c = 0; c < 3; c++) { Jp[0][3 + c] = (Kk[c] - u * Kk[6 + c]) * ip2; Jp[1][3 + c] = (Kk[3 + c] - v * Kk[6 + c]) * ip2; }
-        {
-          const double c0 = X[1] * l0[2] - X[2] * l0[1], c1 = X[2] * l0[0] - X[0] * l0[2], c2 = X[0] * l0[1] - X[1] * l0[0];
-#pragma unroll
-          for (int c = 0; c < 3; c++) Jp[0][c] = c0 * cam[12 + c] + c1 * cam[15 + c] + c2 * cam[18 + c];
-        }
-        {
-          const double c0 = X[1] * l1[2] - X[2] * l1[1], c1 = X[2] * l1[0] - X[0] * l1[2], c2 = X[0] * l1[1] - X[1] * l1[0];
-#pragma unroll
-          for (int c = 0; c < 3; c++) Jp[1][c] = c0 * cam[12 + c] + c1 * cam[15 + c] + c2 * cam[18 + c];
-        }
-        constexpr int QA[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
-        constexpr int QC[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
-        const double we0 = w * e0, we1 = w * e1, hrho = 0.5 * (inl ? sq : 2.0 * delta * (sq * irs) - d2);
-        auto term = [&](int t) -> double {
-          if (t < 21) return w * (Jp[0][QA[t]] * Jp[0][QC[t]] + Jp[1][QA[t]] * Jp[1][QC[t]]);
-          if (t < 27) return Jp[0][t - 21] * we0 + Jp[1][t - 21] * we1;
-          return hrho;
-        };
-#pragma unroll
-        for (int n = 0; n < 7; n++)
-          camacc[7 * i + n] += rs16_sum(rs32_sum(term(4 * n), term(4 * n + 1)), rs32_sum(term(4 * n + 2), term(4 * n + 3)));
-      }
-#endif
       const double wl0[3] = {w * l0[0], w * l0[1], w * l0[2]};
       const double wl1[3] = {w * l1[0], w * l1[1], w * l1[2]};
       h00 += wl0[0] * l0[0] + wl1[0] * l1[0];
@@ -402,9 +357,6 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
       g0 += wl0[0] * e0 + wl1[0] * e1;
       g1 += wl0[1] * e0 + wl1[1] * e1;
       g2 += wl0[2] * e0 + wl1[2] * e1;
-#if BA2_SCHED_FENCE
-      __builtin_amdgcn_sched_barrier(0);      // a slot's work is not interleaved with the next slot's (register pressure)
-#endif
     }
     h00 = ba2_group_sum<LPP>(h00); h10 = ba2_group_sum<LPP>(h10); h11 = ba2_group_sum<LPP>(h11);
     h20 = ba2_group_sum<LPP>(h20); h21 = ba2_group_sum<LPP>(h21); h22 = ba2_group_sum<LPP>(h22);
@@ -460,7 +412,6 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
       // camera sums of the slot: 28 values (21 of the upper H_pp, 6 of g_p, the cost) four at a time through two reduce-scatter stages over
       // the landmark bits 5 and 4 of the lane index: the lane with bits (b5, b4) then holds value 4 n + 2 b4 + b5 summed over four of the
       // chunk's landmarks, and keeps adding to it chunk after chunk; the remaining landmark bits are summed once, after the walk
-#if !BA2_TERMS_EARLY
       constexpr int QA[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
       constexpr int QC[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
       const double we0 = w * ke0[i], we1 = w * ke1[i], hrho = 0.5 * krho[i];
@@ -472,13 +423,10 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
 #pragma unroll
       for (int n = 0; n < 7; n++) {
         camacc[7 * i + n] += rs16_sum(rs32_sum(term(4 * n), term(4 * n + 1)), rs32_sum(term(4 * n + 2), term(4 * n + 3)));
-#if BA2_PIN_CAMACC
         // the sum is taken HERE: left to itself the compiler carries the 14 reduce-scatter results through the Gram phase to the loop's latch and
         // spills half of the accumulators to make room for them (7 x 8 bytes of scratch stored and reloaded per chunk)
         asm volatile("" : "+v"(camacc[7 * i + n]));
-#endif
       }
-#endif
       if (sr < W && !mp.idle) {
         double Z[2][3];
 #pragma unroll
@@ -495,9 +443,6 @@ __global__ void __launch_bounds__(256, 2) k_ba_build_w(ba_ptrs Pall, ba_params_d
           *reinterpret_cast<double2*>(rw2 + 6 * sr + a) = make_double2(Jp[0][a] * Z[0][2] + Jp[1][a] * Z[1][2], Jp[0][a + 1] * Z[0][2] + Jp[1][a + 1] * Z[1][2]);
         }
       }
-#if BA2_SCHED_FENCE
-      __builtin_amdgcn_sched_barrier(0);
-#endif
     }
     if (q == LEAD && !mp.idle) { rw0[6 * W] = inr ? y0 : 0.0; rw1[6 * W] = inr ? y1 : 0.0; rw2[6 * W] = inr ? y2 : 0.0; }
     // ---- Gram matrix of the chunk's panel into the accumulators: one operand fetch per column block and k-step ----
