@@ -200,9 +200,8 @@ static uint64_t step_signature(vo_ctx* c, const step_cfg& s) {
 // ---- frames from the host -------------------------------------------------------------------------------------------------------------
 // Page-locked host arrays are read by the GPU itself over PCIe: ONE launch per step gathers the `batch` images (wherever each of them lies,
 // whatever their row stride) into d_host_raw[half] -- a copy-engine transfer per image cost ~32 us each (256 images: 8 ms for 119 MB).
-// FEW workgroups take the images in turn, U chunks in flight per lane (tools/pcie_gather_probe.hip: 32 workgroups x 256 lanes x 4 chunks reach
-// the bus's 56 GB/s; more buy nothing): the kernel's waves sit on a few compute units for the 2.1 ms the bus needs instead of two on every
-// SIMD of the chip beside the tracker.
+// Workgroups take (image, part) units in turn, U chunks in flight per lane (tools/pcie_gather_probe.hip: 32 workgroups x 256 lanes x 4 chunks
+// reach the bus's 56 GB/s; more buy nothing for the bus).  How many are launched is decided by who else is on the chip: vo_host_frames_upload.
 template <int U>
 __global__ __launch_bounds__(256) void k_gather_frames(const uint8_t* const* __restrict__ tab, int stride, int w, int h, uint8_t* __restrict__ dst, size_t fr, int n_img,
                                                         int parts) {
