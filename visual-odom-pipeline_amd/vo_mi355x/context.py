@@ -375,7 +375,7 @@ class VoContext:
             raise VoError(rc, "vo_host_alloc(%d bytes) failed" % n)
         buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
         arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-        weakref.finalize(buf, L.vo_host_free, C.c_void_p(p.value))
+        weakref.finalize(buf, L.vo_host_free, C.c_void_p(p.value)).atexit = False      # (at interpreter exit the process's memory goes anyway; the HIP runtime may be gone first)
         return arr
 
     def frame_fetch(self):
