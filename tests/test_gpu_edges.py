@@ -136,3 +136,66 @@ def test_unpaired_landmark_half_and_batched_row_reads_are_refused():
             rp2.read_rows("K", [0, 1])
         with pytest.raises(ValueError):
             rp2.read_inliers(4)
+
+
+def test_host_frame_and_tuning_error_paths():
+    """round-6 entry points: bad arguments are refused with a code and a message, nothing is enqueued, the context stays usable"""
+    import ctypes as C
+    from vo_mi355x import VoContext, VoError, synthetic as syn
+    from vo_mi355x.resident import ResidentPipeline
+    w, h = 320, 240
+    frames, _ = syn.make_sequence(3, w=w, h=h, seed=2, margin=48)
+    pts = syn.grid_points(100, w, h, seed=1)
+    with VoContext(w, h, max_pts=128, batch=2) as c:
+        c.points_upload(np.stack([pts, pts]))
+        with pytest.raises(VoError) as e:
+            c.frame_step_host([frames[1], frames[1]], 100, do_dlt=False, do_ba=False, do_st=False)       # no frame pushed yet
+        assert e.value.code == -4
+        c.push_frame(np.stack([frames[0], frames[0]]))
+        with pytest.raises(ValueError):
+            c.frame_step_host([frames[1]], 100)                                  # one image for a batch of two
+        with pytest.raises(ValueError):
+            c.frame_step_host([frames[1], frames[1][:, ::2]], 100)               # wrong shape
+        with pytest.raises(ValueError):
+            c.frame_step_host([frames[1], np.asfortranarray(frames[1])], 100)    # rows not contiguous
+        ptrs = (C.c_void_p * 2)(frames[1].ctypes.data, None)
+        with pytest.raises(VoError) as e:
+            c.frame_step_host((ptrs, w, [frames[1]]), 100, do_dlt=False, do_ba=False, do_st=False)      # a null image pointer
+        assert e.value.code == -1 and "null frame pointer" in str(e.value)
+        ptrs = (C.c_void_p * 2)(frames[1].ctypes.data, frames[1].ctypes.data)
+        with pytest.raises(VoError) as e:
+            c.frame_step_host((ptrs, w - 1, [frames[1]]), 100, do_dlt=False, do_ba=False, do_st=False)  # stride < width
+        assert e.value.code == -1
+        with pytest.raises(VoError) as e:
+            c.frame_step_host([frames[1], frames[1]], 100, do_dlt=True, do_ba=False, do_st=False)       # DLT without an upload
+        assert e.value.code == -4
+        # tuning: unknown field, out of range, experiment-only field
+        with pytest.raises(ValueError):
+            c.set_tuning(no_such_field=1)
+        for bad in (dict(ba_kernels=3), dict(ba_lanes=5), dict(ba_threads=128), dict(klt_waves=7), dict(reserve_cus=256), dict(gate_groups=-2), dict(gather_workgroups=-1)):
+            with pytest.raises(VoError) as e:
+                c.set_tuning(**bad)
+            assert e.value.code == -1, bad
+        assert all(v == 0 for v in c.tuning().values())                         # a refused call changes nothing
+        # still good: two host steps, results of the second = the resident call on the same frame
+        c.frame_step_host([frames[1], frames[1]], 100, do_dlt=False, do_ba=False, do_st=False)
+        c.frame_step_host([frames[2], frames[2]], 100, do_dlt=False, do_ba=False, do_st=False)
+        with pytest.raises(VoError) as e:
+            c.frame_step_host([frames[1], frames[1]], 100, do_dlt=False, do_ba=False, do_st=False)      # a third step without a fetch
+        assert e.value.code == -4
+        with pytest.raises(VoError) as e:
+            c.set_tuning(klt_waves=5)                                            # steps in flight
+        assert e.value.code == -4
+        c.frame_fetch(); got = c.frame_fetch()
+    with VoContext(w, h, max_pts=128, batch=2) as c:
+        c.push_frame(np.stack([frames[0], frames[0]])); c.push_frame(np.stack([frames[1], frames[1]]))
+        p1, _, _ = c.klt_track(np.stack([pts, pts]))
+        c.push_frame(np.stack([frames[2], frames[2]]))
+        p2, st2, err2 = c.klt_track(p1)
+    assert np.array_equal(got["points2d"], p2) and np.array_equal(got["status"], st2) and np.array_equal(got["err"], err2)
+    # the closed loop's host step needs TRACK among its stages
+    with VoContext(w, h, max_pts=256) as c:
+        rp = ResidentPipeline(c, syn.KITTI_K, ba_max_iters=4)
+        with pytest.raises(VoError) as e:
+            rp.step_host([frames[1]], stages=0)
+        assert e.value.code == -1
