@@ -331,3 +331,60 @@ def test_shi_tomasi_fused_kernel_fuzz(w, h, kind, seed, rb, batch):
         ref, reig, rnc = o.good_features(imgs[b], m, maxCorners=300, qualityLevel=0.03, minDistance=7.0, blockSize=31, return_aux=True)
         assert np.array_equal(mask[b], m) and np.array_equal(eig[b], reig) and int(nc[b]) == rnc
         assert np.array_equal(np.asarray(corners[b]).reshape(-1, 2), ref.reshape(-1, 2))
+
+
+@settings(**dict(FUZZ, max_examples=int(os.environ.get("VO_FUZZ_EXAMPLES", "60"))))
+@given(st.integers(33, 300), st.integers(33, 200), st.integers(1, 6), st.integers(0, 2 ** 31 - 1), st.sampled_from(["pinned", "pinned_block", "pageable", "strided", "mixed"]),
+       st.sampled_from([0, 1, 3, 7, 64]), st.sampled_from([0, 1, 2]))
+def test_host_frames_fuzz(w, h, batch, seed, source, workgroups, layout):
+    """`vo_frame_step_host` delivers exactly the caller's images: odd widths (the gather's byte tails), page-locked views at any alignment, one
+    page-locked block, pageable arrays, rows with a stride, a mix of page-locked and pageable images, any workgroup count of the gather, every
+    stream layout -- level 0 of the frame store after the step = the images handed over, and the tracker's results = the resident step's"""
+    from vo_mi355x import VoContext
+    rng = np.random.default_rng(seed)
+    imgs = [[_image(rng, w, h, int(rng.integers(0, 4))) for _ in range(3)] for _ in range(batch)]       # [batch][frame]
+    n = int(rng.integers(1, 40))
+    pts = np.stack([rng.uniform(0, w, (batch, n)), rng.uniform(0, h, (batch, n))], 2).astype(np.float32)
+    frames = np.array(imgs)                                                       # [batch, 3, h, w]
+
+    def give(f):
+        if source == "pinned_block":
+            blk = VoContext.host_alloc((batch, h, w)); blk[:] = frames[:, f]
+            return blk
+        out = []
+        extra = int(rng.integers(1, 40))                                          # (the images of a step share one row stride)
+        for b in range(batch):
+            if source == "pinned" or (source == "mixed" and b % 2 == 0):
+                off = int(rng.integers(0, 17))                                    # any alignment
+                raw = VoContext.host_alloc((h * w + 16,))
+                a = raw[off:off + h * w].reshape(h, w); a[:] = frames[b, f]
+            elif source == "strided":
+                wide = np.zeros((h, w + extra), np.uint8); wide[:, :w] = frames[b, f]
+                a = wide[:, :w]
+            else:
+                a = frames[b, f].copy()
+            out.append(a)
+        return out
+
+    with VoContext(w, h, max_pts=64, batch=batch) as c:
+        c.upload_sequence(frames if batch > 1 else frames[0])
+        c.points_upload(pts if batch > 1 else pts[0])
+        c.push_frame_resident(0)
+        ref = []
+        for f in (1, 2):
+            c.frame_step_resident(f, n, do_dlt=False, do_ba=False, do_st=False)
+            r = c.frame_fetch(); ref.append((r["points2d"].copy(), r["status"].copy(), r["err"].copy()))
+    with VoContext(w, h, max_pts=64, batch=batch) as c:
+        c.set_side_stream(layout)
+        c.set_tuning(gather_workgroups=workgroups)
+        c.points_upload(pts if batch > 1 else pts[0])
+        c.push_frame(frames[:, 0] if batch > 1 else frames[0, 0])
+        keep = []
+        for k, f in enumerate((1, 2)):
+            g = give(f); keep.append(g)
+            c.frame_step_host(g, n, do_dlt=False, do_ba=False, do_st=False)
+            r = c.frame_fetch()
+            for x, y in zip((r["points2d"], r["status"], r["err"]), ref[k]):
+                assert np.array_equal(x, y), (k, source)
+            for b in range(batch):
+                assert np.array_equal(c.pyramid_read(1, 0, seq=b)[0], frames[b, f]), (k, b, source)
