@@ -323,7 +323,9 @@ class Group:
             if self.adaptive:
                 # next budget: one more than the most any of the last 16 fetched frames needed (maximum over the batch), never more than
                 # --ba-iters.  Every blind group beyond the need costs ~2 % of a step; a budget below the need costs a whole second solve.
-                self.ba_prm.max_iters = max(3, min(self.ba_iters_cap, max(self.recent) + 1))
+                # Until one cycle of the bank has been seen the budget stays at the cap (a short warm-up must not start the timed region
+                # on a budget learnt from two frames: the driver's `--warmup 5` cut and re-ran two solves in its first region).
+                self.ba_prm.max_iters = self.ba_iters_cap if len(self.recent) < self.n_ba else max(3, min(self.ba_iters_cap, max(self.recent) + 1))
             else:
                 self.ba_prm.max_iters = self.ba_iters_cap
         return self.last
