@@ -1,6 +1,6 @@
 #!/bin/bash
 # VALU instruction counters of the two KLT kernels on the same launch (32 sequences x 2000 keypoints): one wave per keypoint
-# (k_klt_track<6>, shipped) against two keypoints per wave (k_klt_track2<3>, VO_KLT_PAIR=3, experiment)  -> gpurun_out/klt_pair_counters.txt
+# (k_klt_track<6>, shipped) against two keypoints per wave (k_klt_track2<3>, vo_tuning.klt_pair = 3: a library built with -DVO_EXPERIMENTS)  -> gpurun_out/klt_pair_counters.txt
 OUT=$PWD/gpurun_out
 export TMPDIR=/tmp
 BENCH="$PWD/bench.py"
@@ -26,7 +26,7 @@ for mode in (0, 3):
     m = {k: v[0] / max(v[1], 1) for k, v in acc.items()}
     t = sorted(glob.glob("$OUT/kpair_t%d/**/*kernel_stats.csv" % mode, recursive=True))[-1]
     us = [float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(t)) if "k_klt_track" in r["Name"]]
-    print("VO_KLT_PAIR=%d: SQ_INSTS_VALU %.4g per launch = %.0f per keypoint, SQ_WAVES %.0f, SQ_BUSY_CYCLES %.4g, GRBM_GUI_ACTIVE %.4g, %.1f us per launch (rocprofv3 --stats, single stream)"
+    print("klt_pair=%d: SQ_INSTS_VALU %.4g per launch = %.0f per keypoint, SQ_WAVES %.0f, SQ_BUSY_CYCLES %.4g, GRBM_GUI_ACTIVE %.4g, %.1f us per launch (rocprofv3 --stats, single stream)"
           % (mode, m.get("SQ_INSTS_VALU", 0), m.get("SQ_INSTS_VALU", 0) / 64000.0, m.get("SQ_WAVES", 0), m.get("SQ_BUSY_CYCLES", 0), m.get("GRBM_GUI_ACTIVE", 0), us[0] if us else -1))
 PY
 cat $OUT/klt_pair_counters.txt

@@ -16,7 +16,7 @@
 // Two kernel families build and update (chosen by the window, ba_geometry):
 //   * windows of <= 10 slots (BASELINE's 10, the reference's own 4): the WAVE-PRIVATE k_ba_build_w / k_ba_update_w of vo_ba_wave.h -- a wave walks
 //     landmark chunks with all Gram tiles in its accumulator registers, 5 / 8 / 4 lanes per landmark, running-problem compaction of the tail groups;
-//   * windows of 11 .. 20 slots (config 5), the sharded solve's default, and VO_BA_V2=0: the kernels below.
+//   * windows of 11 .. 20 slots (config 5), the sharded solve's default, one or two problems at windows of 9-10 slots, and vo_tuning.ba_kernels = 1: the kernels below.
 // k_ba_reduce / k_ba_solve / k_ba_finalize serve both.
 //
 // Work mapping of the kernels in this file: ONE LANE PER OBSERVATION.  A landmark owns a group of LPP = 8 (W <= 8), 16 (W <= 16) or 32 lanes, lane s of
@@ -56,7 +56,7 @@
 #define BA_MAX_SLOTS 20
 #define BA_EVAL_VALS 4
 #define BA_PITCH_PAD 8       // panel row pitch = RP + 8 doubles.  A pitch of RP + 16 keeps the 16-lane row groups of the MFMA operand reads on
-                             // disjoint LDS banks, but its 30.7 KB panel lets only 4 workgroups share a CU; measured (VO_BA_PAD): pads 0..12
+                             // disjoint LDS banks, but its 30.7 KB panel lets only 4 workgroups share a CU; measured (vo_tuning.ba_pitch_pad): pads 0..12
                              // 54 us per launch, pad 16 57 us -- the bank conflicts cost nothing here, the fifth workgroup is worth 5 %
 #define BA_CAM 21            // per-slot camera data staged in LDS: R(9) t(3) Jr(9)
 
