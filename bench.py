@@ -1071,14 +1071,16 @@ def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
     return out
 
 
+def _source_digest(names=None):
+    """digest of kernel sources, comments and white space not counted (tools/source_digest.py)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import source_digest
+    return source_digest.digest(names)
+
+
 def _klt_source_digest(with_frame_store=False):
     """digest of the tracker's source; with_frame_store: also of vo_frame.hip, whose 4x derivative format the tracker consumes"""
-    import hashlib
-    h = hashlib.sha256()
-    for name in ("vo_klt.hip",) + (("vo_frame.hip",) if with_frame_store else ()):
-        with open(os.path.join(ROOT, "visual-odom-pipeline_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()[:16]
+    return _source_digest(["vo_klt.hip"] + (["vo_frame.hip"] if with_frame_store else []))
 
 
 def profile_constant(fname, key):
@@ -1114,14 +1116,7 @@ def kernel_rooflines():
     if not os.path.exists(path):
         return {"source": "profiles/kernel_counters.json missing", "kernels": []}
     d = json.load(open(path))
-    import hashlib
-    h = hashlib.sha256()
-    cs = os.path.join(ROOT, "visual-odom-pipeline_amd", "csrc")
-    for n in sorted(os.listdir(cs)):
-        if n.endswith((".hip", ".h")):
-            with open(os.path.join(cs, n), "rb") as f:
-                h.update(f.read())
-    stale = d.get("csrc_sha256_16") != h.hexdigest()[:16]
+    stale = d.get("csrc_sha256_16") != _source_digest()
     peak_issue = VALU_ISSUE_PER_CLK_PER_SIMD * N_SIMDS * CLK_HZ
     out = []
     for e in d.get("kernels", []):

@@ -18,13 +18,11 @@ import hashlib
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = "gpurun_out"
-with open(os.path.join("visual-odom-pipeline_amd", "csrc", "vo_klt.hip"), "rb") as _f:
-    KLT_DIGEST = hashlib.sha256(_f.read()).hexdigest()[:16]       # bench.py refuses these constants for any other kernel source
-_h = hashlib.sha256()
-for _n in ("vo_klt.hip", "vo_frame.hip"):                          # ... and for another frame store (the 4x derivative format the tracker consumes)
-    with open(os.path.join("visual-odom-pipeline_amd", "csrc", _n), "rb") as _f:
-        _h.update(_f.read())
-KLT_FRAME_DIGEST = _h.hexdigest()[:16]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import source_digest  # noqa: E402  (comments and white space do not count)
+
+KLT_DIGEST = source_digest.digest(["vo_klt.hip"])                       # bench.py refuses these constants for any other kernel source
+KLT_FRAME_DIGEST = source_digest.digest(["vo_klt.hip", "vo_frame.hip"])  # ... and for another frame store (the 4x derivative format the tracker consumes)
 
 
 def find(pattern):
@@ -136,12 +134,7 @@ def _rows(name):
     return list(csv.DictReader(open(path))) if os.path.exists(path) else []
 
 
-_h = hashlib.sha256()
-for _n in sorted(os.listdir(os.path.join("visual-odom-pipeline_amd", "csrc"))):
-    if _n.endswith((".hip", ".h")):
-        with open(os.path.join("visual-odom-pipeline_amd", "csrc", _n), "rb") as _f:
-            _h.update(_f.read())
-kc = {"measured": tag, "csrc_sha256_16": _h.hexdigest()[:16],
+kc = {"measured": tag, "csrc_sha256_16": source_digest.digest(),
       "command": "python3 bench.py --steps 20 --warmup 5 --regions 1 --no-extras --no-cpu-baseline (kernel stats); --steps 4 --warmup 2 (each --pmc pass)",
       "files": [f"profiles/{tag}_kernel_stats_default.csv", f"profiles/{tag}_pmc_traffic_default.csv", f"profiles/{tag}_pmc_valu_default.csv",
                 f"profiles/{tag}_pmc_mfma_default.csv"],
