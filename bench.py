@@ -68,6 +68,8 @@ def parse():
                     "Default 10 for config5, whose launch budget is fixed at the cap (its solves take 5 iterations)")
     ap.add_argument("--pipe-ba-iters", type=int, default=10, help="--workload pipeline: LM iteration cap per adjust (= the blind launch groups per frame unless "
                     "--pipe-adaptive-budget)")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic image sequences behind a GPU's batch (default: 8 if 8 cores can render them "
+                    "side by side, else 4)")
     ap.add_argument("--frames", type=int, default=100, help="distinct synthetic frames per sequence: a closed loop of smooth motion, played round and round")
     ap.add_argument("--pipe-window", type=int, default=4, help="--workload pipeline: BA window (the reference's own setting is 4, pipeline.py:19; BASELINE's 10)")
     ap.add_argument("--pipe-no-resurrect", action="store_true", help="--workload pipeline: dead landmarks stay dead (the reference appends the recently dead "
@@ -1223,7 +1225,7 @@ def compact_line(full, extras_file=None):
     line["vs_baseline"] = full.get("vs_baseline")
     line.update(_pick(full, ("dtype", "data")))
     cfg = full.get("config") or {}
-    c = _pick(cfg, ("workload", "sequences_per_gpu", "batched_contexts_per_gpu", "frames_per_step", "frames_source", "tracked_points", "ba_lm_iteration_budget",
+    c = _pick(cfg, ("workload", "sequences_per_gpu", "batched_contexts_per_gpu", "frames_per_step", "distinct_image_sequences", "frames_source", "tracked_points", "ba_lm_iteration_budget",
                     "ba_lm_iterations_run", "stream_layout", "launch"))
     if "ba_solves_stopped_by_lm_max_iters" in cfg:
         c["solves_stopped_by_cap"] = cfg["ba_solves_stopped_by_lm_max_iters"]
@@ -1418,7 +1420,10 @@ def main():
     else:
         a.ctxs = max(1, min(a.ctxs, a.seqs))
         per = [a.seqs // a.ctxs + (1 if i < a.seqs % a.ctxs else 0) for i in range(a.ctxs)]
-        frame_sets = render_sequences([1234 + 16 * dist.rank + k for k in range(min(4, a.seqs))], a.frames, parallel=dist.world == 1)
+        # distinct image sequences behind the batch: 8 when they can be rendered side by side (one core each), 4 otherwise (rounds 1-5); sequence b
+        # of a context tracks its own point set on image sequence b % n
+        n_distinct = min(a.distinct, a.seqs) if a.distinct > 0 else min(8 if (dist.world == 1 and usable_cores() >= 8) else 4, a.seqs)
+        frame_sets = render_sequences([1234 + 16 * dist.rank + k for k in range(n_distinct)], a.frames, parallel=dist.world == 1)
         seqs = [Group(dist.local_rank, frame_sets, seed0=1000 * dist.rank + 100 * i, batch=per[i], ba_iters=a.ba_iters)
                 for i in range(a.ctxs)]
     t_setup = time.perf_counter() - t_gen
@@ -1664,6 +1669,7 @@ def main():
                "stage_ms_per_batched_launch_group": stage, "roofline": roof, "cpu_baseline": cpu,
                "setup_s": round(t_setup, 2)}
         out["config"]["frames_source"] = "resident in HBM (vo_seq_upload); `host_frames`: the same with every frame handed over by the host"
+        out["config"]["distinct_image_sequences"] = len(frame_sets)
         out["config"]["tracked_points"] = "jittered grid (SURVEY 8d's fallback); `shi_tomasi_seeded_points`: the build's own corners of frame 0"
         if host_fig is not None:
             out["host_frames"] = host_fig

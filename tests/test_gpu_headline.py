@@ -27,8 +27,8 @@ def test_headline_shape_256_sequences_against_the_oracle():
     W, H, N, B = bench.W_IMG, bench.H_IMG, bench.N_PTS, 256
     assert (W, H, N, bench.N_NEW, bench.BA_N, bench.BA_W) == (1241, 376, 2000, 1000, 2000, 10)
     n_steps = 3
-    # the bench's frames: the first frames of its 100-frame periodic sequences, 4 distinct sequences serving the batch (bench.py main())
-    frame_sets = [syn.make_sequence(100, W, H, seed=1234 + k, periodic=True, n_render=n_steps + 2)[0] for k in range(4)]
+    # the bench's frames: the first frames of its 100-frame periodic sequences, 8 distinct sequences serving the batch (bench.py main())
+    frame_sets = [syn.make_sequence(100, W, H, seed=1234 + k, periodic=True, n_render=n_steps + 2)[0] for k in range(8)]
     g = bench.Group(0, frame_sets, seed0=0, batch=B, ba_iters=30)
     try:
         g.c.set_side_stream("pipeline")
@@ -45,7 +45,7 @@ def test_headline_shape_256_sequences_against_the_oracle():
         _, _, _, it_dev = g.c.points_download(N, return_iters=True)          # iteration counts of the LAST tracker launch
         it_dev = it_dev.reshape(B, N, -1)
         for b in CHECKED:
-            fs = frame_sets[b % 4]
+            fs = frame_sets[b % 8]
             p = syn.grid_points(N, W, H, seed=b)
             bank = bench.ba_bank(0, b)
             P0, P1, u0, u1 = bench.dlt_inputs(bank[0])[:4]
@@ -88,7 +88,7 @@ def test_headline_shape_256_sequences_against_the_oracle():
         g.enqueue()
         r = g.fetch()
         for b in CHECKED:
-            fs = frame_sets[b % 4]
+            fs = frame_sets[b % 8]
             p1, st, err = o.klt(fs[n_steps], fs[n_steps + 1], results[-1]["points2d"][b])
             assert np.array_equal(r["points2d"][b], p1) and np.array_equal(r["status"][b], st) and np.array_equal(r["err"][b], err), b
             img, der = g.c.pyramid_read(1, 0, seq=b)
