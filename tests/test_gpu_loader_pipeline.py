@@ -55,6 +55,12 @@ def test_loader_reads_the_dataset_layout(tmp_path):
         ld.getPose(3)
     with pytest.raises(Exception):
         Loader("unknown", {"unknown": {"path": str(tmp_path)}})
+    # the frame as decoded (no pre-filter), optionally into the caller's buffer (a page-locked one on the GPU path)
+    assert np.array_equal(ld.getRawImage(1), frames[1])
+    buf = np.zeros((480, 640), np.uint8)
+    assert ld.getRawImage(2, out=buf) is buf and np.array_equal(buf, frames[2])
+    with pytest.raises(ValueError):
+        ld.getRawImage(2, out=np.zeros((480, 641), np.uint8))
 
 
 @pytest.mark.gpu
@@ -67,6 +73,17 @@ def test_loader_prefilter_and_pipeline_run(tmp_path):
     im, pose = ld.getFrame(5)
     assert np.array_equal(im, o.bilateral(frames[5], 5, 1.5, 1.5))            # getImage = imread + bilateralFilter(5, 1.5, 1.5)
     _check_run(_loop_over_loader(ld, _gpu_ctx, 7), 7)                         # frames 5 .. 11
+    # the same frame decoded into page-locked memory and pre-filtered while it enters the frame store of a fused host-frame step: level 0 of the
+    # frame store = getImage's result (loader.py:86 applied on the device, no read-back, no staging copy)
+    from vo_mi355x import VoContext
+    with VoContext(640, 480, max_pts=64) as c:
+        c.set_prefilter(5, 1.5, 1.5)
+        pin = VoContext.host_alloc((480, 640))
+        c.push_frame(ld.getRawImage(4, out=pin))
+        c.points_upload(np.array([[100.0, 100.0]], np.float32))
+        c.frame_step_host(ld.getRawImage(5, out=pin), 1, do_dlt=False, do_ba=False, do_st=False)
+        c.frame_fetch()
+        assert np.array_equal(c.pyramid_read(1, 0)[0], im)
 
 
 def test_pipeline_run_cpu_twin(tmp_path):

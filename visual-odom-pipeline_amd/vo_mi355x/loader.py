@@ -112,6 +112,18 @@ class Loader:
         raw = imread_gray(self._at(self.image_paths, id))
         return self._prefilter_context(raw.shape).bilateral(raw, PREFILTER["d"], PREFILTER["sigmaColor"], PREFILTER["sigmaSpace"])
 
+    def getRawImage(self, id, out=None):
+        """the frame as decoded, WITHOUT the pre-filter -- for a context that applies it while the frame enters the frame store
+        (`VoContext.set_prefilter(**...)`: fused into the level-0 pass, bit-identical to `getImage`).  `out`: a uint8 [h, w] array to decode into, e.g. a
+        page-locked one (`VoContext.host_alloc`) that `frame_step_host` / `ResidentPipeline.step_host` then read over PCIe without a staging copy."""
+        raw = imread_gray(self._at(self.image_paths, id))
+        if out is None:
+            return raw
+        if out.shape != raw.shape or out.dtype != np.uint8:
+            raise ValueError("getRawImage: out must be uint8 %r" % (raw.shape,))
+        out[...] = raw
+        return out
+
     def getPose(self, id):
         return self._at(self._poses, id)
 
