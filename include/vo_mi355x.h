@@ -157,7 +157,11 @@ int32_t vo_ctx_create(int32_t device, int32_t width, int32_t height, int32_t max
  * array argument of every entry point below gains a leading dimension of length `batch` (images [batch][h][w],
  * points [batch][n][2], status [batch][n], X4 [batch][4][n], P0 [batch][12], K [batch][9], obs [batch][W][N][2],
  * out_pts [batch][max_corners][2], n_out [batch], stats [batch], ...); scalars (n, parameters) are shared.
- * vo_ctx_create(...) == vo_ctx_create_batched(..., 1, ...). */
+ * vo_ctx_create(...) == vo_ctx_create_batched(..., 1, ...).
+ * STREAMS: a context owns its streams (up to five: front end, side, bundle adjustment, copy-in, and a CU-masked form of the first in the gated
+ * layout); the library is compiled with -fgpu-default-stream=per-thread, so its SYNCHRONOUS copies (uploads, read-backs, probes) run on the calling
+ * thread's own default stream and never join the process's legacy null stream -- a caller that relies on null-stream ordering with its own HIP work
+ * must synchronise explicitly (vo_sync). */
 int32_t vo_ctx_create_batched(int32_t device, int32_t width, int32_t height, int32_t max_pts,
                               int32_t max_level, int32_t win, int32_t batch, vo_ctx** out);
 int32_t vo_ctx_destroy(vo_ctx* ctx);
