@@ -22,4 +22,8 @@ rocprofv3 --pmc MfmaUtil MfmaFlopsF64 --output-format csv -d $OUT/${TAG}_pmc_mfm
 # vector-instruction issue: the roof that binds k_klt_track (bench.py roofline.valu)
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_valu -o valu -- python3 $BENCH $PMCARGS > $OUT/${TAG}_pmc_valu.log 2>&1
 cd - > /dev/null
+# the same command on ONE stream (per-kernel durations without the other streams' kernels on the chip), then the summaries, then the copies
+# under profiles/ that bench.py and profiles/README_<tag>.md refer to
+bash tools/kstats256.sh $TAG > /dev/null 2>&1
 python3 tools/summarize_profiles.py $TAG
+bash tools/collect_profiles.sh $TAG > /dev/null
