@@ -648,23 +648,26 @@ def dropin_step_ms(device, scene, ba_window=4, n_warm=4, n_time=8):
 
 
 
-def _render_one(args):
-    from vo_mi355x import synthetic as syn
-    seed, n = args
-    return syn.make_sequence(n, W_IMG, H_IMG, seed=seed, periodic=True)[0]
-
-
 def render_sequences(seeds, n_frames, parallel=True):
-    """the distinct synthetic image sequences of a rank, rendered side by side in forked workers (4 x 100 frames of 1241 x 376 take ~10 s on one
-    core: a third of the driver's run).  Called before this process touches the GPU -- a fork after that is not allowed on this pool"""
-    if parallel and len(seeds) > 1 and usable_cores() > 1:       # (a multi-rank launch has its rendezvous threads running: no fork there)
-        try:
-            import multiprocessing as mp
-            with mp.get_context("fork").Pool(min(len(seeds), usable_cores())) as pool:
-                return pool.map(_render_one, [(sd, n_frames) for sd in seeds])
-        except Exception as e:          # noqa: BLE001
-            sys.stderr.write("bench: parallel rendering failed (%s), rendering in line\n" % e)
-    return [_render_one((sd, n_frames)) for sd in seeds]
+    """the distinct synthetic image sequences of a rank (`synthetic.make_sequence(n_frames, periodic=True)` of each seed, frame by frame), rendered by
+    a pool of THREADS -- numpy drops the interpreter lock inside its array operations: ~4-6 x on 8-16 cores (8 x 100 frames of 1241 x 376 take
+    ~40 s on one).  Not processes: forked workers hung the run under `rocprofv3 --pmc` once in ten (the profiler has initialised the GPU and
+    installed its signal handlers before the fork; `Pool` terminates its workers with SIGTERM and waited for them for ever -- 40 GPU-minutes)."""
+    from vo_mi355x import synthetic as syn
+    margin = 96
+    n_thr = max(1, min(usable_cores(), 16)) if parallel else 1
+    if n_thr == 1:
+        return [syn.make_sequence(n_frames, W_IMG, H_IMG, seed=sd, periodic=True)[0] for sd in seeds]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(n_thr) as ex:
+        texs = list(ex.map(lambda sd: syn.make_texture(H_IMG + 2 * margin, W_IMG + 2 * margin, sd), seeds))
+        out = [np.empty((n_frames, H_IMG, W_IMG), np.uint8) for _ in seeds]
+
+        def one(job):
+            k, t = job
+            out[k][t] = syn.render_frame(texs[k], syn.frame_motion_periodic(t, W_IMG, H_IMG, n_frames), W_IMG, H_IMG, margin)
+        list(ex.map(one, [(k, t) for k in range(len(seeds)) for t in range(n_frames)]))
+    return out
 
 
 def usable_cores():

@@ -5,7 +5,7 @@ B=${1:-256}; TAG=${2:-act}
 OUT=$PWD/gpurun_out; SCRIPT=$PWD/tools/phase_probe_batch.py
 export TMPDIR=/tmp
 cd /tmp; rm -rf $OUT/${TAG}_act
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_act -o ks -- python3 $SCRIPT $B > $OUT/${TAG}_act.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_act -o ks -- python3 $SCRIPT $B > $OUT/${TAG}_act.log 2>&1
 cd - >/dev/null
 python3 - <<PY
 import csv, glob

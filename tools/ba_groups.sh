@@ -6,7 +6,7 @@ OUT=$PWD/gpurun_out
 export TMPDIR=/tmp
 BENCH="$PWD/bench.py"
 cd /tmp; rm -rf $OUT/${TAG}_grp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_grp -o ks -- python3 $BENCH --steps 20 --warmup 5 --regions 1 --no-extras --seqs $SEQS --ctxs 1 --host-threads 1 --side-stream off --no-cpu-baseline > $OUT/${TAG}_grp.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_grp -o ks -- python3 $BENCH --steps 20 --warmup 5 --regions 1 --no-extras --seqs $SEQS --ctxs 1 --host-threads 1 --side-stream off --no-cpu-baseline > $OUT/${TAG}_grp.log 2>&1
 cd - > /dev/null
 python3 - <<PY | tee $OUT/${TAG}_groups.txt
 import csv, glob, collections

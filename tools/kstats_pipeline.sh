@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 BENCH="$PWD/bench.py"
 cd /tmp
 rm -rf $OUT/${TAG}_ks
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_ks -o ks -- python3 $BENCH --steps 40 --warmup 10 --regions 1 --seqs 32 --ctxs 1 --host-threads 1 --workload pipeline --no-cpu-baseline --full-line --extras-file /dev/null "$@" > $OUT/${TAG}_ks.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_ks -o ks -- python3 $BENCH --steps 40 --warmup 10 --regions 1 --seqs 32 --ctxs 1 --host-threads 1 --workload pipeline --no-cpu-baseline --full-line --extras-file /dev/null "$@" > $OUT/${TAG}_ks.log 2>&1
 cd - > /dev/null
 python3 - <<PY > $OUT/${TAG}_kstats.txt
 import csv, glob, json

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 BENCH="$PWD/bench.py"
 cd /tmp
 rm -rf $OUT/${TAG}_ks
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_ks -o ks -- python3 $BENCH --steps 100 --warmup 10 --regions 1 --seqs 1 --ctxs 1 --host-threads 1 --workload pipeline --no-cpu-baseline --full-line --extras-file /dev/null "$@" > $OUT/${TAG}_ks.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_ks -o ks -- python3 $BENCH --steps 100 --warmup 10 --regions 1 --seqs 1 --ctxs 1 --host-threads 1 --workload pipeline --no-cpu-baseline --full-line --extras-file /dev/null "$@" > $OUT/${TAG}_ks.log 2>&1
 cd - > /dev/null
 python3 - <<PY
 import csv, glob, json

@@ -6,7 +6,7 @@ OUT=$PWD/gpurun_out
 export TMPDIR=/tmp
 BENCH="$PWD/bench.py"
 cd /tmp; rm -rf $OUT/ptl
-rocprofv3 --kernel-trace --output-format csv -d $OUT/ptl -o ks -- python3 $BENCH --workload pipeline --seqs $SEQS --pipe-window $WIN --steps 12 --warmup 6 --regions 1 --no-cpu-baseline > $OUT/ptl.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/ptl -o ks -- python3 $BENCH --workload pipeline --seqs $SEQS --pipe-window $WIN --steps 12 --warmup 6 --regions 1 --no-cpu-baseline > $OUT/ptl.log 2>&1
 cd - > /dev/null
 python3 - <<PY | tee $OUT/pipe_timeline_${SEQS}_w${WIN}.txt
 import csv, glob, collections

@@ -8,9 +8,9 @@ cd /tmp
 for MODE in 0 3; do
   TUNE=""; [ "$MODE" != 0 ] && TUNE="--tune klt_pair=$MODE"      # (needs a library built with -DVO_EXPERIMENTS)
   rm -rf $OUT/kpair_$MODE
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/kpair_$MODE -o c -- python3 $BENCH --steps 4 --warmup 2 --regions 1 --no-extras --no-cpu-baseline --seqs 32 --ctxs 1 $TUNE > $OUT/kpair_$MODE.log 2>&1
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/kpair_$MODE -o c -- python3 $BENCH --steps 4 --warmup 2 --regions 1 --no-extras --no-cpu-baseline --seqs 32 --ctxs 1 $TUNE > $OUT/kpair_$MODE.log 2>&1
   rm -rf $OUT/kpair_t$MODE
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kpair_t$MODE -o t -- python3 $BENCH --steps 20 --warmup 5 --regions 1 --no-extras --no-cpu-baseline --seqs 32 --ctxs 1 --side-stream off $TUNE > $OUT/kpair_t$MODE.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kpair_t$MODE -o t -- python3 $BENCH --steps 20 --warmup 5 --regions 1 --no-extras --no-cpu-baseline --seqs 32 --ctxs 1 --side-stream off $TUNE > $OUT/kpair_t$MODE.log 2>&1
 done
 cd - > /dev/null
 python3 - <<PY > $OUT/klt_pair_counters.txt

@@ -15,12 +15,12 @@ ARGS="--steps 20 --warmup 5 --regions 1 --no-extras --no-cpu-baseline $EXTRA"
 PMCARGS="--steps 4 --warmup 2 --regions 1 --no-extras --no-cpu-baseline $EXTRA"
 cd /tmp
 rm -rf $OUT/${TAG}_stats $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma $OUT/${TAG}_pmc_valu
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o stats -- python3 $BENCH $ARGS > $OUT/${TAG}_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o fetch -- python3 $BENCH $PMCARGS > $OUT/${TAG}_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o write -- python3 $BENCH $PMCARGS > $OUT/${TAG}_pmc_write.log 2>&1
-rocprofv3 --pmc MfmaUtil MfmaFlopsF64 --output-format csv -d $OUT/${TAG}_pmc_mfma -o mfma -- python3 $BENCH $PMCARGS > $OUT/${TAG}_pmc_mfma.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o stats -- python3 $BENCH $ARGS > $OUT/${TAG}_stats.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o fetch -- python3 $BENCH $PMCARGS > $OUT/${TAG}_pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o write -- python3 $BENCH $PMCARGS > $OUT/${TAG}_pmc_write.log 2>&1
+timeout 600 rocprofv3 --pmc MfmaUtil MfmaFlopsF64 --output-format csv -d $OUT/${TAG}_pmc_mfma -o mfma -- python3 $BENCH $PMCARGS > $OUT/${TAG}_pmc_mfma.log 2>&1
 # vector-instruction issue: the roof that binds k_klt_track (bench.py roofline.valu)
-rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_valu -o valu -- python3 $BENCH $PMCARGS > $OUT/${TAG}_pmc_valu.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_valu -o valu -- python3 $BENCH $PMCARGS > $OUT/${TAG}_pmc_valu.log 2>&1
 cd - > /dev/null
 # the same command on ONE stream (per-kernel durations without the other streams' kernels on the chip), then the summaries, then the copies
 # under profiles/ that bench.py and profiles/README_<tag>.md refer to

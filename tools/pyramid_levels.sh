@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 BENCH="$PWD/bench.py"
 cd /tmp
 rm -rf $OUT/${TAG}_pyr
-rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_pyr -o ks -- python3 $BENCH --steps 10 --warmup 3 --regions 1 --no-extras --seqs 256 --ctxs 1 --host-threads 1 --side-stream off --no-cpu-baseline > $OUT/${TAG}_pyr.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_pyr -o ks -- python3 $BENCH --steps 10 --warmup 3 --regions 1 --no-extras --seqs 256 --ctxs 1 --host-threads 1 --side-stream off --no-cpu-baseline > $OUT/${TAG}_pyr.log 2>&1
 cd - > /dev/null
 python3 - <<PY > $OUT/${TAG}_pyramid_levels.txt
 import csv, glob, collections
