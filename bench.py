@@ -81,6 +81,9 @@ def parse():
     ap.add_argument("--pipe-max-pts", type=int, default=2048, help="--workload pipeline: capacity of the tracked keypoint set per sequence (<= 8192)")
     ap.add_argument("--pipe-host-frames", action="store_true", help="--workload pipeline: every step's images are handed over by the host (page-locked numpy arrays, "
                     "one per sequence -> vo_pipe_step_host) instead of read from the sequence store in HBM")
+    ap.add_argument("--pipe-second-max-pts", type=int, default=0, help="--workload pipeline: after the run, the same run once more with this table capacity (same scenes, "
+                    "one process: what the default line's two closed-loop figures share); its result object goes under `second`")
+    ap.add_argument("--pipe-second-warmup", type=int, default=60)
     ap.add_argument("--pipe-frames", type=int, default=40, help="--workload pipeline: rendered frames per scene (= the period of the camera's sway; played in a loop)")
     ap.add_argument("--graph", action="store_true", help="replay each frame from a captured hipGraph instead of plain launches")
     ap.add_argument("--host-threads", type=int, default=3, help="enqueue/fetch the contexts from this many host threads")
@@ -909,20 +912,8 @@ def seeded_points_figure(device, seqs, frame_sets, a, step, drain):
 CHILD_ENV_DROP = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")
 
 
-def closed_loop_child(a, extra_args, steps=40, timeout=150, warmup=10):
-    """`bench.py --workload pipeline ...` as a child process -> the short object the compact line carries (the child's full result object goes into
-    the side file under the same key + `_full`).  Never raises: an error or a timeout becomes {"error": ...}."""
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "pipeline", "--ctxs", "1", "--steps", str(steps), "--warmup", str(warmup), "--regions", "3",
-           "--no-cpu-baseline", "--full-line", "--extras-file", os.devnull, "--pipe-frames", str(a.pipe_frames), "--pipe-ba-iters", str(a.pipe_ba_iters)] + \
-          (["--tune", a.tune] if a.tune else []) + list(extra_args)
-    env = {k: v for k, v in os.environ.items() if k not in CHILD_ENV_DROP}
-    t0 = time.perf_counter()
-    try:
-        pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env)
-        d = json.loads([ln for ln in pr.stdout.decode().splitlines() if ln.startswith("{")][-1])
-    except Exception as e:          # noqa: BLE001
-        return {"error": repr(e)[:200], "seconds": round(time.perf_counter() - t0, 1)}
+def _closed_loop_short(d, cmd, seconds):
+    """the short object of a closed-loop result the compact line carries"""
     pp, rf = d.get("pipeline") or {}, d.get("roofline") or {}
     cap = pp.get("capacity_policy_frames") or {}
     return {"value": d.get("value"), "unit": "frames/s", "ms_per_step": d.get("ms_per_step"), "sequences": pp.get("sequences"), "ba_window": pp.get("ba_window"),
@@ -930,7 +921,32 @@ def closed_loop_child(a, extra_args, steps=40, timeout=150, warmup=10):
             "capacity_policy_frames": int(sum(cap.values())) if cap else None, "frames_counted": int(pp.get("sequences", 0)) * int(pp.get("steps", 0)) * len(pp.get("regions_ms_per_step", [])),
             "sequences_alive_at_end": pp.get("sequences_alive_at_end"), "rotation_deg_median": (pp.get("pose_error_vs_ground_truth") or {}).get("rotation_deg_median"),
             "roofline": {"kernel": rf.get("kernel"), "frac": rf.get("frac"), "avg_launch_us": rf.get("avg_launch_us")},
-            "cmd": "bench.py --workload pipeline " + " ".join(extra_args), "seconds": round(time.perf_counter() - t0, 1)}
+            "cmd": cmd, "seconds": seconds}
+
+
+def closed_loop_child(a, extra_args, steps=40, timeout=150, warmup=10):
+    """`bench.py --workload pipeline ...` as a child process -> the short object the compact line carries; with `--pipe-second-max-pts` among the
+    arguments a pair (first run, second run: same scenes, one process).  Never raises: an error or a timeout becomes {"error": ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "pipeline", "--ctxs", "1", "--steps", str(steps), "--warmup", str(warmup), "--regions", "3",
+           "--no-cpu-baseline", "--full-line", "--extras-file", os.devnull, "--pipe-frames", str(a.pipe_frames), "--pipe-ba-iters", str(a.pipe_ba_iters)] + \
+          (["--tune", a.tune] if a.tune else []) + list(extra_args)
+    env = {k: v for k, v in os.environ.items() if k not in CHILD_ENV_DROP}
+    pair = "--pipe-second-max-pts" in extra_args
+    t0 = time.perf_counter()
+    try:
+        pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env)
+        d = json.loads([ln for ln in pr.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    except Exception as e:          # noqa: BLE001
+        err = {"error": repr(e)[:200], "seconds": round(time.perf_counter() - t0, 1)}
+        return (err, err) if pair else err
+    secs = round(time.perf_counter() - t0, 1)
+    text = "bench.py --workload pipeline " + " ".join(extra_args)
+    first = _closed_loop_short(d, text, secs)
+    if not pair:
+        return first
+    d2 = d.get("second") or {}
+    return first, (_closed_loop_short(d2, text + " (second run)", secs) if d2 else {"error": "no second run in the child's result"})
 
 
 def measure_extras(device, frame_sets, a, dist, cpu_pipe=None):
@@ -1397,8 +1413,16 @@ def main():
     if a.workload == "pipeline":
         # the closed loop is its own harness (no resident BA problem, no uploaded point set: everything comes out of the device tables)
         a.ctxs = max(1, min(a.ctxs, a.seqs))
-        r = run_pipeline(dist.local_rank, a, dist, a.ctxs, max(1, a.seqs // a.ctxs), a.steps, a.warmup, a.regions)
+        scenes = pipe_scenes(2, a.pipe_frames, 4321 + 16 * dist.rank)
+        r = run_pipeline(dist.local_rank, a, dist, a.ctxs, max(1, a.seqs // a.ctxs), a.steps, a.warmup, a.regions, scenes)
         tot = dist.sum(float(r["sequences"]))
+        second = None
+        if a.pipe_second_max_pts > 0:
+            import copy as _c
+            a2 = _c.copy(a); a2.pipe_max_pts = a.pipe_second_max_pts
+            r2 = run_pipeline(dist.local_rank, a2, dist, a.ctxs, max(1, a.seqs // a.ctxs), a.steps, a.pipe_second_warmup, a.regions, scenes)
+            tot2 = dist.sum(float(r2["sequences"]))
+            second = {"value": round(tot2 * a.steps / (r2["ms_per_step"] * 1e-3 * a.steps), 2), "ms_per_step": r2["ms_per_step"], "roofline": r2.pop("roofline", None), "pipeline": r2}
         if dist.rank == 0:
             fps = tot * a.steps / (r["ms_per_step"] * 1e-3 * a.steps)
             emit({"metric": "frames/sec, Pipeline.step resident on the device @1241x376 (<= %d tracked keypoints, RANSAC-P3P pose, triangulation, "
@@ -1407,7 +1431,7 @@ def main():
                   "vs_baseline": None, "dtype": "u8/i32 (KLT, Shi-Tomasi) + f64 (P3P, DLT, BA)", "data": "synthetic (rendered two-plane scene, known trajectory)",
                   "config": {"workload": "pipeline_step_closed_loop_1241x376_ba%d" % a.pipe_window, "sequences_per_gpu": r["sequences"],
                              "batched_contexts_per_gpu": r["contexts"], "parallelism": "independent sequences, no collective"},
-                  "pipeline": r, "roofline": r.pop("roofline", None), "cpu_baseline": cpu_pipe}, a)
+                  "pipeline": r, "roofline": r.pop("roofline", None), "cpu_baseline": cpu_pipe, "second": second}, a)
         dist.close()
         return
     if c5:
@@ -1690,11 +1714,10 @@ def main():
         if out is not None and dist.world == 1 and a.workload == "A" and not a.no_extras:
             # second figure of the line: the coupled loop (Pipeline.step resident on the device) at BASELINE's window and the headline's batch, as a
             # CHILD with a timeout -- whatever it does, the headline built above is printed
-            out["closed_loop_w10_256"] = closed_loop_child(a, ["--pipe-window", "10", "--pipe-no-resurrect", "--seqs", str(a.seqs)])
-            # ... and with tables the scene does not fill (8 192 slots per sequence; ~4 200 keypoints tracked): no frame of it is shaped by the
-            # capacity policy (`capacity_policy_frames` 0) -- the reference's unbounded lists at the headline's batch
-            out["closed_loop_w10_uncapped_tables"] = closed_loop_child(a, ["--pipe-window", "10", "--pipe-no-resurrect", "--seqs", str(a.seqs), "--pipe-max-pts", "8192"],
-                                                                       warmup=60)
+            # ... and, in the same child (same scenes), with tables the scene does not fill (8 192 slots per sequence; ~4 200 keypoints tracked): no
+            # frame of it is shaped by the capacity policy (`capacity_policy_frames` 0) -- the reference's unbounded lists at the headline's batch
+            out["closed_loop_w10_256"], out["closed_loop_w10_uncapped_tables"] = closed_loop_child(
+                a, ["--pipe-window", "10", "--pipe-no-resurrect", "--seqs", str(a.seqs), "--pipe-second-max-pts", "8192"], timeout=240)
         if out is not None and dist.world == 1 and a.workload == "A" and a.extras:
             out.update(measure_extras(dist.local_rank, frame_sets, a, dist, cpu_pipe))
     except Exception as e:          # noqa: BLE001  (informational keys must never cost the bench line)
