@@ -18,11 +18,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHECKED = (0, 1, 127, 255)
 
 
-def test_headline_shape_256_sequences_against_the_oracle():
+@pytest.fixture(scope="module")
+def headline_run():
+    """bench.Group in the bench's default configuration, three steps with two in flight, then one step with the frames handed over by the host;
+    everything the tests below look at is read back here, the context is closed before they run"""
     sys.path.insert(0, ROOT)
-    import ba_oracle as bo
     import bench
-    import vo_oracle as o
     from vo_mi355x import synthetic as syn
     W, H, N, B = bench.W_IMG, bench.H_IMG, bench.N_PTS, 256
     assert (W, H, N, bench.N_NEW, bench.BA_N, bench.BA_W) == (1241, 376, 2000, 1000, 2000, 10)
@@ -43,61 +44,106 @@ def test_headline_shape_256_sequences_against_the_oracle():
             results.append(g.fetch())
         assert len(results) == n_steps and g.at_cap == 0
         _, _, _, it_dev = g.c.points_download(N, return_iters=True)          # iteration counts of the LAST tracker launch
-        it_dev = it_dev.reshape(B, N, -1)
-        for b in CHECKED:
-            fs = frame_sets[b % 8]
-            p = syn.grid_points(N, W, H, seed=b)
-            bank = bench.ba_bank(0, b)
-            P0, P1, u0, u1 = bench.dlt_inputs(bank[0])[:4]
-            Xr = o.triangulate(P0, P1, u0, u1)
-            Xr = (Xr[:3] / Xr[3]).T
-            for t in range(1, n_steps + 1):
-                r = results[t - 1]
-                # ---- KLT (extractor.py:44-45,65-66): positions, status, err bit-exact; iteration counts of the last launch ----
-                p1, st, err, its = o.klt(fs[t - 1], fs[t], p, return_iters=True)
-                assert np.array_equal(r["points2d"][b], p1), (b, t)
-                assert np.array_equal(r["status"][b], st) and np.array_equal(r["err"][b], err), (b, t)
-                if t == n_steps:
-                    assert np.array_equal(it_dev[b][:, :its.shape[1]], its), b
-                # ---- re-detection (extractor.py:104-112): discs at the tracked points, ordered corner list bit-exact ----
-                mask = np.full((H, W), 255, np.uint8)
-                for x, y in np.int32(p1):
-                    o.circle_mask(mask, (x, y), 7, 0)
-                assert np.array_equal(r["corners"][b], o.good_features(fs[t], mask)), (b, t)
-                # ---- DLT (extractor.py:255-277): 1e-4 relative ----
-                X = (r["X4"][b][:3] / r["X4"][b][3]).T
-                assert (np.linalg.norm(X - Xr, axis=1) / np.linalg.norm(Xr, axis=1)).max() <= 1e-4, (b, t)
-                # ---- bundle adjustment (bundle_adjuster.py:127-215 through the LM of oracle/ba_oracle.py): problem t % 8 of the bank ----
-                q = bank[t % 8]
-                ref = bo.solve(q["K"], q["poses0"], q["points0"], q["obs"], max_iters=30, ftol=1e-3, xtol=1e-3)
-                s = r["ba_stats"][b]
-                assert (s["iters"], s["accepted"], s["status"]) == (ref["iters"], ref["accepted"], ref["status"]), (b, t, s, ref["iters"])
-                assert abs(s["cost"] - ref["cost"]) <= 1e-7 * ref["cost"] and abs(s["cost0"] - ref["cost0"]) <= 1e-9 * ref["cost0"], (b, t)
-                assert np.abs(r["poses"][b] - ref["poses"]).max() <= 1e-6 and np.abs(r["landmarks"][b] - ref["points"]).max() <= 1e-5, (b, t)
-                p = p1
-            # ---- frame store after the last step: pyramid levels and Scharr derivatives of cur (frame 3) and prev (frame 2), bit-exact ----
-            for which, f in ((1, n_steps), (0, n_steps - 1)):
-                pyr = o.build_pyramid(fs[f])
-                for lvl, im in enumerate(pyr):
-                    img, der = g.c.pyramid_read(which, lvl, seq=b)
-                    assert np.array_equal(img, im), (b, which, lvl)
-                    assert np.array_equal(der, o.scharr(im)), (b, which, lvl)
-        # ---- one more step with the frames handed over by the host (page-locked arrays, one per sequence: vo_frame_step_host, what the bench's
-        # `host_frames` figure times): the same tracker results as the oracle on the next frame ----
+        pyr = {(b, which, lvl): g.c.pyramid_read(which, lvl, seq=b) for b in CHECKED for which in (0, 1) for lvl in range(4)}
+        # one more step with the frames handed over by the host (page-locked arrays, one per sequence: vo_frame_step_host, what the bench's
+        # `host_frames` figure times)
         assert g.use_host_frames(True) == B * W * H
         g.enqueue()
-        r = g.fetch()
-        for b in CHECKED:
-            fs = frame_sets[b % 8]
-            p1, st, err = o.klt(fs[n_steps], fs[n_steps + 1], results[-1]["points2d"][b])
-            assert np.array_equal(r["points2d"][b], p1) and np.array_equal(r["status"][b], st) and np.array_equal(r["err"][b], err), b
-            img, der = g.c.pyramid_read(1, 0, seq=b)
-            assert np.array_equal(img, fs[n_steps + 1]), b
-        # the iteration counts of the batch are what the bench reports its budget on: not all problems take the same number
-        its_all = np.array([[x["iters"] for x in r["ba_stats"]] for r in results])
-        assert its_all.min() >= 3 and its_all.max() <= 30 and len(np.unique(its_all)) >= 3
+        r_host = g.fetch()
+        lvl0_host = {b: g.c.pyramid_read(1, 0, seq=b)[0] for b in CHECKED}
     finally:
         g.c.close()
+    return dict(bench=bench, frame_sets=frame_sets, results=results, it_dev=it_dev.reshape(B, N, -1), pyr=pyr, r_host=r_host, lvl0_host=lvl0_host,
+                n_steps=n_steps, W=W, H=H, N=N, B=B)
+
+
+def test_headline_shape_256_sequences_against_the_oracle(headline_run):
+    import ba_oracle as bo
+    import vo_oracle as o
+    from vo_mi355x import synthetic as syn
+    R = headline_run
+    bench, frame_sets, results, n_steps, W, H, N = R["bench"], R["frame_sets"], R["results"], R["n_steps"], R["W"], R["H"], R["N"]
+    for b in CHECKED:
+        fs = frame_sets[b % 8]
+        p = syn.grid_points(N, W, H, seed=b)
+        bank = bench.ba_bank(0, b)
+        P0, P1, u0, u1 = bench.dlt_inputs(bank[0])[:4]
+        Xr = o.triangulate(P0, P1, u0, u1)
+        Xr = (Xr[:3] / Xr[3]).T
+        for t in range(1, n_steps + 1):
+            r = results[t - 1]
+            # ---- KLT (extractor.py:44-45,65-66): positions, status, err bit-exact; iteration counts of the last launch ----
+            p1, st, err, its = o.klt(fs[t - 1], fs[t], p, return_iters=True)
+            assert np.array_equal(r["points2d"][b], p1), (b, t)
+            assert np.array_equal(r["status"][b], st) and np.array_equal(r["err"][b], err), (b, t)
+            if t == n_steps:
+                assert np.array_equal(R["it_dev"][b][:, :its.shape[1]], its), b
+            # ---- re-detection (extractor.py:104-112): discs at the tracked points, ordered corner list bit-exact ----
+            mask = np.full((H, W), 255, np.uint8)
+            for x, y in np.int32(p1):
+                o.circle_mask(mask, (x, y), 7, 0)
+            assert np.array_equal(r["corners"][b], o.good_features(fs[t], mask)), (b, t)
+            # ---- DLT (extractor.py:255-277): 1e-4 relative ----
+            X = (r["X4"][b][:3] / r["X4"][b][3]).T
+            assert (np.linalg.norm(X - Xr, axis=1) / np.linalg.norm(Xr, axis=1)).max() <= 1e-4, (b, t)
+            # ---- bundle adjustment (bundle_adjuster.py:127-215 through the LM of oracle/ba_oracle.py): problem t % 8 of the bank ----
+            q = bank[t % 8]
+            ref = bo.solve(q["K"], q["poses0"], q["points0"], q["obs"], max_iters=30, ftol=1e-3, xtol=1e-3)
+            s = r["ba_stats"][b]
+            assert (s["iters"], s["accepted"], s["status"]) == (ref["iters"], ref["accepted"], ref["status"]), (b, t, s, ref["iters"])
+            assert abs(s["cost"] - ref["cost"]) <= 1e-7 * ref["cost"] and abs(s["cost0"] - ref["cost0"]) <= 1e-9 * ref["cost0"], (b, t)
+            assert np.abs(r["poses"][b] - ref["poses"]).max() <= 1e-6 and np.abs(r["landmarks"][b] - ref["points"]).max() <= 1e-5, (b, t)
+            p = p1
+        # ---- frame store after the last step: pyramid levels and Scharr derivatives of cur (frame 3) and prev (frame 2), bit-exact ----
+        for which, f in ((1, n_steps), (0, n_steps - 1)):
+            for lvl, im in enumerate(o.build_pyramid(fs[f])):
+                img, der = R["pyr"][(b, which, lvl)]
+                assert np.array_equal(img, im), (b, which, lvl)
+                assert np.array_equal(der, o.scharr(im)), (b, which, lvl)
+        # ---- the step with the frames from the host: the same tracker results as the oracle on the next frame ----
+        p1, st, err = o.klt(fs[n_steps], fs[n_steps + 1], results[-1]["points2d"][b])
+        rh = R["r_host"]
+        assert np.array_equal(rh["points2d"][b], p1) and np.array_equal(rh["status"][b], st) and np.array_equal(rh["err"][b], err), b
+        assert np.array_equal(R["lvl0_host"][b], fs[n_steps + 1]), b
+    # the iteration counts of the batch are what the bench reports its budget on: not all problems take the same number
+    its_all = np.array([[x["iters"] for x in r["ba_stats"]] for r in results])
+    assert its_all.min() >= 3 and its_all.max() <= 30 and len(np.unique(its_all)) >= 3
+
+
+def test_headline_properties_over_all_256_sequences(headline_run):
+    """what the oracle comparison shows for four sequences, as size-independent properties of ALL 256 (and of the host-frame step): the re-detection
+    honours its own rules (<= 1 000 corners, pairwise >= 7 px apart, none on an exclusion disc of a tracked point, integer pixels inside the image);
+    tracked points stay finite, lost ones are flagged; every adjustment ends by the LM's own tests with a cost not above its start and finite poses /
+    landmarks; sequences that share an image sequence AND a bank problem index but not the point set differ (no sequence is served another's data),
+    while the triangulation -- the same scene for every sequence b -- is per-sequence deterministic across steps"""
+    from scipy.spatial import cKDTree
+    R = headline_run
+    results, W, H, B = R["results"] + [R["r_host"]], R["W"], R["H"], R["B"]
+    for t, r in enumerate(results):
+        p, st = r["points2d"], r["status"]
+        assert p.shape == (B, 2000, 2) and np.isfinite(p).all() and set(np.unique(st)) <= {0, 1}
+        assert st.mean() > 0.98                                                     # the synthetic motion loses (almost) nothing
+        inside = (p[..., 0] >= -31) & (p[..., 0] <= W + 31) & (p[..., 1] >= -31) & (p[..., 1] <= H + 31)
+        assert inside[st == 1].all()
+        for b in range(B):
+            c = r["corners"][b]
+            assert len(c) <= 1000 and (c == np.rint(c)).all()
+            assert (c[:, 0] >= 0).all() and (c[:, 0] < W).all() and (c[:, 1] >= 0).all() and (c[:, 1] < H).all()
+            if len(c) > 1:
+                assert len(cKDTree(c).query_pairs(6.999)) == 0, (t, b)              # minDistance 7 (featureselect.cpp keeps dx^2 + dy^2 >= 49)
+            # no corner on a disc of radius 7 drawn at int32(tracked point) (extractor.py:104-107): the disc covers dx^2 + dy^2 <= 49 at least up to r - 1
+            d, _ = cKDTree(np.int32(p[b]).astype(np.float64)).query(c)
+            assert (d > 6.0).all(), (t, b, d.min())
+        for b, s in enumerate(r["ba_stats"]):
+            assert s["status"] in (1, 2, 3) and 3 <= s["iters"] <= 30 and s["cost"] <= s["cost0"] and np.isfinite(s["cost"]), (t, b, s)
+        assert np.isfinite(r["poses"]).all() and np.isfinite(r["landmarks"]).all()
+        assert np.isfinite(r["X4"][:, :, :]).all()
+    # own data per sequence: sequences 0 and 8 share image sequence 0 but not the points, the scene or the bank
+    a, b = results[0], results[0]
+    assert not np.array_equal(a["points2d"][0], b["points2d"][8]) and not np.array_equal(a["poses"][0], b["poses"][8])
+    # the triangulation inputs of a sequence do not change from step to step (an uploaded pair set): identical output every step
+    for r in results[1:]:
+        assert np.array_equal(r["X4"], results[0]["X4"])
 
 
 def test_closed_loop_figure_256_sequences_equals_its_sequences_alone():
