@@ -51,9 +51,15 @@ def headline_run():
         g.enqueue()
         r_host = g.fetch()
         lvl0_host = {b: g.c.pyramid_read(1, 0, seq=b)[0] for b in CHECKED}
+        # ... and a step whose frame IS the previous one (the host's frame 4 again, this time from the resident store): the tracker must not move a point
+        g.use_host_frames(False)
+        g.c.frame_step_resident(n_steps + 1, N, False, False, False, 7, g.klt_prm, g.st_prm, g.ba_prm)
+        r_same = g.c.frame_fetch()
+        _, _, _, it_same = g.c.points_download(N, return_iters=True)
     finally:
         g.c.close()
     return dict(bench=bench, frame_sets=frame_sets, results=results, it_dev=it_dev.reshape(B, N, -1), pyr=pyr, r_host=r_host, lvl0_host=lvl0_host,
+                r_same=r_same, it_same=it_same.reshape(B, N, -1),
                 n_steps=n_steps, W=W, H=H, N=N, B=B)
 
 
@@ -138,6 +144,12 @@ def test_headline_properties_over_all_256_sequences(headline_run):
             assert s["status"] in (1, 2, 3) and 3 <= s["iters"] <= 30 and s["cost"] <= s["cost0"] and np.isfinite(s["cost"]), (t, b, s)
         assert np.isfinite(r["poses"]).all() and np.isfinite(r["landmarks"]).all()
         assert np.isfinite(r["X4"][:, :, :]).all()
+    # idempotence: tracking a frame against itself leaves every point where it was (up to the float rounding of (p - 15) + 15 at each of the four
+    # levels: OpenCV's own arithmetic -- the oracle gives the same bits), with a residual of (almost) nothing (the patch is re-sampled at a position an ulp away:
+    # err <= 0.01 grey levels), in ONE iteration per level
+    rs, ok = R["r_same"], R["r_host"]["status"] == 1
+    assert np.abs(rs["points2d"][ok] - R["r_host"]["points2d"][ok]).max() <= 1e-3 and (rs["status"][ok] == 1).all() and (rs["err"][ok] <= 0.01).all()
+    assert (R["it_same"][ok] == 1).all()
     # own data per sequence: sequences 0 and 8 share image sequence 0 but not the points, the scene or the bank
     a, b = results[0], results[0]
     assert not np.array_equal(a["points2d"][0], b["points2d"][8]) and not np.array_equal(a["poses"][0], b["poses"][8])
