@@ -199,3 +199,28 @@ def test_closed_loop_figure_256_sequences_equals_its_sequences_alone():
                 one.c.close()
     finally:
         boot.close()
+
+
+def test_headline_step_is_bitwise_reproducible(headline_run):
+    """every reduction of the path has a fixed order (integer sums in the tracker and the eigenvalue pass, partial sets folded in workgroup order, the LM's
+    decision derived by every workgroup from the same statistics): a second run of the same three steps in a fresh context -- other launch timing, other
+    placement of the 512 000 tracker waves, the tail groups compacted as the running problems of THAT run allow -- gives the same bits for all 256 sequences"""
+    R = headline_run
+    bench = R["bench"]
+    g = bench.Group(0, R["frame_sets"], seed0=0, batch=R["B"], ba_iters=30)
+    try:
+        g.c.set_side_stream("pipeline")
+        again = []
+        for _ in range(R["n_steps"]):
+            g.enqueue()
+            if g.inflight == 2:
+                again.append(g.fetch())
+        while g.inflight:
+            again.append(g.fetch())
+    finally:
+        g.c.close()
+    for t, (a, b) in enumerate(zip(R["results"], again)):
+        for k in ("points2d", "status", "err", "X4", "depth1", "reproj", "poses", "landmarks"):
+            assert np.array_equal(a[k], b[k], equal_nan=True), (t, k)
+        assert all(np.array_equal(x, y) for x, y in zip(a["corners"], b["corners"])), t
+        assert [(s["iters"], s["accepted"], s["status"], s["cost"]) for s in a["ba_stats"]] == [(s["iters"], s["accepted"], s["status"], s["cost"]) for s in b["ba_stats"]], t
